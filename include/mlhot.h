@@ -1,0 +1,167 @@
+/* mlhot.h - C ABI of libmlhot.so, the MI355X-native CNP/ANP meta-batch hot path.
+ *
+ * The reference (boschresearch/what-matters-for-meta-learning) is pure Python on torch and
+ * has no FFI of its own; its plugin boundary is `networks/<Method>.py::<Method>(config)`
+ * (train.py:41-45).  This header is the C boundary UNDER that plugin (SURVEY.md §8b, row
+ * "C-ABI under the plugin"): one forward and one backward entry per hot-path row of
+ * SURVEY.md §8(a), each citing the reference code it replaces.  The Python host mirror
+ * (what-matters-for-meta-learning_amd/networks/*) binds these with ctypes.
+ *
+ * Contract for every entry:
+ *   - returns 0 on success, a non-zero MLHOT_ERR_* code otherwise (mlhot_last_error() has text);
+ *   - all pointers are DEVICE pointers to fp32 unless noted, caller-owned, 16-byte aligned;
+ *   - no allocation, no host synchronisation, no default-stream use inside: work is enqueued
+ *     on `stream` in order, so calls are hipGraph-capturable and re-entrant across streams;
+ *   - workspaces are caller-provided; the *_bytes() helpers size them.
+ *   - `stream` is a hipStream_t passed as void*.
+ */
+#ifndef MLHOT_H
+#define MLHOT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLHOT_ABI_VERSION 1
+
+enum { MLHOT_ACT_NONE = 0, MLHOT_ACT_RELU = 1, MLHOT_ACT_TANH = 2 };
+enum { MLHOT_AGG_MEAN = 0, MLHOT_AGG_MAX = 1, MLHOT_AGG_BACO = 2, MLHOT_AGG_ATTENTION = 3 };
+/* trainer/losses.py:32-80 */
+enum { MLHOT_LOSS_AZIMUTH = 0, MLHOT_LOSS_MSE = 1, MLHOT_LOSS_QUATERNION = 2, MLHOT_LOSS_DEGREE = 3, MLHOT_LOSS_DISTRACTOR = 4 };
+
+int mlhot_version(void);
+const char* mlhot_last_error(void);
+
+/* ---- E1: vanilla image encoder `encoder_w0` -------------------------------------------
+ * replaces nn.Sequential(conv3x3s2+ReLU, conv3x3s2+ReLU, MaxPool2d(2), conv3x3s2+ReLU,
+ * Flatten, Linear(4096,dim_w))   (networks/ANPShapeNet1D.py:46-56, CNPShapeNet1D.py:46-56,
+ * CNPVanillaPascal1D.py:48-58, ANPVanillaPascal1D.py:50-60) for [n,1,128,128] images.
+ * The image batch may come as two segments (context images, target images) that share the
+ * weights; rows [0,n0) of the logical batch read img0 / write feat0, rows [n0,n0+n1) use
+ * img1 / feat1 (n1 may be 0).  feat rows have leading dimension ld0 / ld1 (floats).        */
+typedef struct mlhot_enc_params {
+  const float *w1, *b1;   /* encoder_w0.0  [32,1,3,3],  [32] */
+  const float *w2, *b2;   /* encoder_w0.2  [48,32,3,3], [48] */
+  const float *w3, *b3;   /* encoder_w0.5  [64,48,3,3], [64] */
+  const float *wl, *bl;   /* encoder_w0.8  [dim_w,4096], [dim_w] */
+} mlhot_enc_params;
+typedef struct mlhot_enc_grads {
+  float *w1, *b1, *w2, *b2, *w3, *b3, *wl, *bl;
+} mlhot_enc_grads;
+
+size_t mlhot_enc_vanilla_saved_bytes(int n_img);
+size_t mlhot_enc_vanilla_scratch_bytes(int n_img, int dim_w);
+int mlhot_enc_vanilla_fwd(const float* img0, int n0, const float* img1, int n1, const mlhot_enc_params* p, int dim_w,
+                          float* feat0, int ld0, float* feat1, int ld1,
+                          void* saved, void* scratch, size_t scratch_bytes, void* stream);
+int mlhot_enc_vanilla_bwd(const float* img0, int n0, const float* img1, int n1, const mlhot_enc_params* p, int dim_w,
+                          const float* dfeat0, int ldd0, const float* dfeat1, int ldd1,
+                          const void* saved, const mlhot_enc_grads* g, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- M1 / D1 / A1 / A4: nn.Linear (+ReLU / tanh) ----------------------------------------
+ * y[M,N] = act(x[M,K] w[N,K]^T + b)   (networks/models.py:27-60 EncoderFC, 195-203 AttnLinear;
+ * ANPShapeNet1D.py:58-72 transform_y / r_to_z / decoder0).  b may be NULL.                  */
+size_t mlhot_linear_bwd_scratch_bytes(int M, int K, int N);
+int mlhot_linear_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
+                     int M, int K, int N, int act, void* stream);
+/* dx (+)= (dy*act'(y)) w ; dw = (dy*act'(y))^T x ; db = column sums.  dx/dw/db may be NULL. */
+int mlhot_linear_bwd(const float* x, int ldx, const float* w, const float* y, int ldy, const float* dy, int lddy,
+                     int M, int K, int N, int act, float* dx, int lddx, int accumulate, float* dw, float* db,
+                     void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- G1: per-task aggregation over the shot axis ------------------------------------------
+ * mean / max / Bayesian ("baco") over dim 1 of rs[T,Nc,R]   (CNPShapeNet1D.py:78-126,
+ * CondNeuralProcess.py:59-108).  baco: `rs` holds mu, `lv` the pre-softplus variance logits;
+ * var = 1e-5 + softplus(lv), sigma_z = 1/(1+sum 1/var), r = sigma_z * sum(mu/var).
+ * amax[T,R] (int32) receives the arg-max shot for mode MAX.                                  */
+int mlhot_agg_fwd(int mode, const float* rs, const float* lv, int T, int Nc, int R,
+                  float* r, float* sigma_z, int32_t* amax, void* stream);
+int mlhot_agg_bwd(int mode, const float* rs, const float* lv, const float* r, const float* sigma_z, const int32_t* amax,
+                  const float* dr, int T, int Nc, int R, float* drs, float* dlv, void* stream);
+
+/* ---- A2 / A3: FAVOR+ softmax-kernel features + non-causal linear attention ----------------
+ * replaces FastAttention.forward = linear_attention(softmax_kernel(q,True),
+ * softmax_kernel(k,False), v)   (networks/fast_attention.py:74-99,151-156,187-205), including
+ * the batch-global key stabiliser torch.max(data_dash) (fast_attention.py:97).
+ * Layouts: q[T,Nq,H,d], k[T,Nc,H,d], v[T,Nc,H,d] (token-major, head-minor rows - what the head
+ * projections write), proj[m,d].  out[T,Nq,d*H] is already in the reference's merged order
+ * out[t,n,e*H+h] (ANPShapeNet1D.py:113-114 permute(0,2,3,1).view).                           */
+size_t mlhot_favor_ws_bytes(int T, int H, int Nq, int Nc, int d, int m);
+int mlhot_favor_fwd(const float* q, const float* k, const float* v, const float* proj,
+                    int T, int H, int Nq, int Nc, int d, int m, float* out,
+                    void* ws, size_t ws_bytes, void* stream);
+/* ws must be the workspace the matching forward filled. */
+int mlhot_favor_bwd(const float* q, const float* k, const float* v, const float* proj,
+                    int T, int H, int Nq, int Nc, int d, int m, const float* out, const float* dout,
+                    float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- L1: losses --------------------------------------------------------------------------
+ * LossFunc.calc_loss (trainer/losses.py:32-80).  mu[rows,y_dim], gt[rows,gt_dim];
+ * loss / dloss are device scalars.                                                            */
+int mlhot_loss_fwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim, float* loss, void* stream);
+int mlhot_loss_bwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim,
+                   const float* dloss, float* dmu, void* stream);
+
+/* ---- whole vanilla CNP/ANP model: forward + backward in one call each --------------------
+ * replaces <Model>.forward for CNPVanillaPascal1D / CNPShapeNet1D / ANPVanillaPascal1D /
+ * ANPShapeNet1D (CNPShapeNet1D.py:96-140, ANPShapeNet1D.py:93-157) and its autograd backward. */
+#define MLHOT_MAX_HIDDEN 4
+#define MLHOT_HEADS 8
+typedef struct mlhot_np_dims {
+  int T, Nc, Nq;              /* tasks, context shots, target shots (Nc may be 0)             */
+  int label_dim, y_dim;       /* config.input_dim, config.output_dim                           */
+  int dim_w, dim_r, dim_z;    /* 64, 64|100|256, 64                                            */
+  int n_hidden;               /* len(n_hidden_units_r)                                         */
+  int hidden[MLHOT_MAX_HIDDEN];
+  int dec_hidden;             /* 100                                                           */
+  int agg_mode;               /* MLHOT_AGG_*                                                   */
+  int out_tanh;               /* 1 for the ShapeNet1D classes                                  */
+  int m_feat;                 /* FAVOR+ features (attention only)                              */
+} mlhot_np_dims;
+
+typedef struct mlhot_np_params {
+  mlhot_enc_params enc;
+  const float *ty_w, *ty_b;                                   /* transform_y                  */
+  const float *er_w[MLHOT_MAX_HIDDEN + 1], *er_b[MLHOT_MAX_HIDDEN + 1]; /* encoder_r.layers.{0,2,..} */
+  const float *r2z_w, *r2z_b;                                 /* r_to_z                       */
+  const float *dec_w[3], *dec_b[3];                           /* decoder0.{0,2,4}             */
+  const float *mu_w, *mu_b, *var_w, *var_b;                   /* rs_to_mu / rs_to_var (baco)  */
+  const float *wk_w[MLHOT_HEADS], *wk_b[MLHOT_HEADS];         /* _W_k.i.linear                */
+  const float *wv_w[MLHOT_HEADS], *wv_b[MLHOT_HEADS];         /* _W_v.i.linear                */
+  const float *wq_w[MLHOT_HEADS], *wq_b[MLHOT_HEADS];         /* _W_q.i.linear                */
+  const float *wo_w, *wo_b;                                   /* _W.linear                    */
+  const float *proj;                                          /* attn.projection_matrix       */
+} mlhot_np_params;
+
+typedef struct mlhot_np_grads {
+  mlhot_enc_grads enc;
+  float *ty_w, *ty_b;
+  float *er_w[MLHOT_MAX_HIDDEN + 1], *er_b[MLHOT_MAX_HIDDEN + 1];
+  float *r2z_w, *r2z_b;
+  float *dec_w[3], *dec_b[3];
+  float *mu_w, *mu_b, *var_w, *var_b;
+  float *wk_w[MLHOT_HEADS], *wk_b[MLHOT_HEADS];
+  float *wv_w[MLHOT_HEADS], *wv_b[MLHOT_HEADS];
+  float *wq_w[MLHOT_HEADS], *wq_b[MLHOT_HEADS];
+  float *wo_w, *wo_b;
+} mlhot_np_grads;
+
+size_t mlhot_np_struct_bytes(int which); /* 0 dims, 1 params, 2 grads: binding self-check */
+size_t mlhot_np_saved_bytes(const mlhot_np_dims* d);
+size_t mlhot_np_scratch_bytes(const mlhot_np_dims* d);
+/* ctx_x[T,Nc,1,128,128], ctx_y[T,Nc,label_dim], qry_x[T,Nq,1,128,128] -> mu[T,Nq,y_dim] */
+int mlhot_np_vanilla_fwd(const mlhot_np_dims* d, const mlhot_np_params* p,
+                         const float* ctx_x, const float* ctx_y, const float* qry_x, float* mu,
+                         void* saved, void* scratch, size_t scratch_bytes, void* stream);
+/* Every gradient buffer in g is OVERWRITTEN (parameters the forward did not use get zeros). */
+int mlhot_np_vanilla_bwd(const mlhot_np_dims* d, const mlhot_np_params* p,
+                         const float* ctx_x, const float* ctx_y, const float* qry_x,
+                         const float* mu, const float* dmu, const mlhot_np_grads* g,
+                         const void* saved, void* scratch, size_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLHOT_H */

@@ -1,0 +1,269 @@
+"""CPU oracle for the task-batched CNP/ANP hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is the checker, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+The shipped path (``what-matters-for-meta-learning_amd/``) never falls back to it.
+
+It is a straight-line fp32 restatement of the reference's arithmetic on torch-CPU
+tensors, written from SURVEY.md Appendix A (A.1-A.7), one function per row of
+SURVEY.md §8(a).  Every function cites the reference file:line it restates.  The
+element arithmetic (convolution, GEMM, exp) is torch/ATen CPU, which is also what
+the reference itself runs on (the reference has no kernels of its own).
+
+Parity pin: the reference holds NO tests or golden vectors for this path
+(SURVEY.md §4), so the oracle is pinned against outputs of the reference itself,
+imported in the build container by ``tests/golden/make_fixtures.py`` and committed
+as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every function
+here against those vectors (forward taps, loss and gradients).
+
+Parameters are passed as plain dicts keyed exactly like the reference's
+``state_dict`` so a fixture's weights drop straight in.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# E1  vanilla encoder                      (ANPShapeNet1D.py:46-56, CNPShapeNet1D.py:46-56)
+# --------------------------------------------------------------------------------------
+
+
+def vanilla_encoder(img, p, prefix="encoder_w0.", taps=None):
+    """conv(1->32,k3,s2,p1)+ReLU, conv(32->48)+ReLU, maxpool2, conv(48->64)+ReLU,
+    flatten (C-major), Linear(4096->dim_w).  img: [N,C,128,128] -> [N,dim_w]."""
+    a1 = F.relu(F.conv2d(img, p[prefix + "0.weight"], p[prefix + "0.bias"], stride=2, padding=1))
+    a2 = F.relu(F.conv2d(a1, p[prefix + "2.weight"], p[prefix + "2.bias"], stride=2, padding=1))
+    p2 = F.max_pool2d(a2, 2)
+    a3 = F.relu(F.conv2d(p2, p[prefix + "5.weight"], p[prefix + "5.bias"], stride=2, padding=1))
+    flat = a3.reshape(a3.shape[0], -1)
+    out = F.linear(flat, p[prefix + "8.weight"], p[prefix + "8.bias"])
+    if taps is not None:
+        taps.update(a1=a1, a2=a2, p2=p2, a3=a3)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# M1  task-side MLPs                                               (models.py:27-60)
+# --------------------------------------------------------------------------------------
+
+
+def encoder_fc(x, p, prefix="encoder_r.layers.", n_hidden=2):
+    """EncoderFC: (Linear+ReLU) x n_hidden, then Linear without activation."""
+    idx = 0
+    for _ in range(n_hidden):
+        x = F.relu(F.linear(x, p[f"{prefix}{idx}.weight"], p[f"{prefix}{idx}.bias"]))
+        idx += 2
+    return F.linear(x, p[f"{prefix}{idx}.weight"], p[f"{prefix}{idx}.bias"])
+
+
+def decoder_mlp(x, p, prefix="decoder0.", tanh=True):
+    """decoder0: L(128->100) ReLU L(100->100) ReLU L(100->y) [tanh]
+    (ANPShapeNet1D.py:65-72; no tanh in CNPVanillaPascal1D.py:67-73)."""
+    x = F.relu(F.linear(x, p[prefix + "0.weight"], p[prefix + "0.bias"]))
+    x = F.relu(F.linear(x, p[prefix + "2.weight"], p[prefix + "2.bias"]))
+    x = F.linear(x, p[prefix + "4.weight"], p[prefix + "4.bias"])
+    return torch.tanh(x) if tanh else x
+
+
+# --------------------------------------------------------------------------------------
+# G1  aggregators over the shot axis              (CNPShapeNet1D.py:78-126, A.2)
+# --------------------------------------------------------------------------------------
+
+
+def agg_mean(rs):
+    return rs.mean(dim=1)
+
+
+def agg_max(rs):
+    return rs.max(dim=1)[0]
+
+
+def agg_baco(mu, var):
+    """Bayesian context aggregation with prior N(0,1): sigma_z = 1/(1+sum 1/var),
+    mu_z = sigma_z * sum(mu/var)          (CNPShapeNet1D.py:78-94)."""
+    inv = 1.0 / var
+    sigma_z = 1.0 / (1.0 + inv.sum(dim=1))
+    mu_z = sigma_z * (inv * mu).sum(dim=1)
+    return mu_z, sigma_z
+
+
+# --------------------------------------------------------------------------------------
+# A2/A3  FAVOR+                                              (fast_attention.py:74-156)
+# --------------------------------------------------------------------------------------
+
+
+def favor_features(x, proj, is_query, eps=1e-4):
+    """softmax_kernel (fast_attention.py:74-99).  x: [T,H,N,d], proj: [m,d]."""
+    d = x.shape[-1]
+    m = proj.shape[0]
+    c = d ** -0.25
+    ratio = m ** -0.5
+    dd = torch.einsum("thnd,md->thnm", c * x, proj)
+    diag = (x * x).sum(dim=-1, keepdim=True) * 0.5 * (c * c)
+    if is_query:
+        stab = dd.max(dim=-1, keepdim=True).values
+    else:
+        stab = dd.max()  # ONE scalar over the whole [T,H,N,m] tensor (fast_attention.py:97)
+    return ratio * (torch.exp(dd - diag - stab) + eps)
+
+
+def linear_attention(qp, kp, v):
+    """Non-causal linear attention (fast_attention.py:151-156)."""
+    ksum = kp.sum(dim=-2)
+    dinv = 1.0 / torch.einsum("thnm,thm->thn", qp, ksum)
+    ctx = torch.einsum("thnm,thne->thme", kp, v)
+    return torch.einsum("thme,thnm,thn->thne", ctx, qp, dinv)
+
+
+def favor_attention(q, k, v, proj):
+    """FastAttention.forward, default branch (fast_attention.py:187-205)."""
+    return linear_attention(favor_features(q, proj, True), favor_features(k, proj, False), v)
+
+
+def gaussian_orthogonal_random_matrix(nb_rows, nb_cols):
+    """Projection-matrix draw, scaling=0 (fast_attention.py:117-146).  Consumes the
+    global torch CPU generator exactly like the reference: per block randn(d,d) -> QR
+    -> Q^T; then one randn(m,d) whose row norms scale the rows."""
+    blocks = []
+    full = nb_rows // nb_cols
+    for _ in range(full):
+        qm, _ = torch.linalg.qr(torch.randn(nb_cols, nb_cols))
+        blocks.append(qm.t())
+    rem = nb_rows - full * nb_cols
+    if rem > 0:
+        qm, _ = torch.linalg.qr(torch.randn(nb_cols, nb_cols))
+        blocks.append(qm.t()[:rem])
+    mat = torch.cat(blocks)
+    mult = torch.randn(nb_rows, nb_cols).norm(dim=1)
+    return torch.diag(mult) @ mat
+
+
+# --------------------------------------------------------------------------------------
+# A1/A4  multi-head wrapper                                 (ANPShapeNet1D.py:93-116)
+# --------------------------------------------------------------------------------------
+
+
+def multihead_attention(k, v, q, p, n_heads=8, taps=None):
+    """8 per-head Linear(h,h) for K(x_ctx), V(rs), Q(x_qry); FAVOR+; merge with
+    merged[t,n,d*8+i] = out[t,i,n,d]; _W Linear(8h->h)."""
+    def heads(x, name):
+        return torch.stack([F.linear(x, p[f"{name}.{i}.linear.weight"], p[f"{name}.{i}.linear.bias"])
+                            for i in range(n_heads)], dim=1)
+    kh, vh, qh = heads(k, "_W_k"), heads(v, "_W_v"), heads(q, "_W_q")
+    out = favor_attention(qh, kh, vh, p["attn.projection_matrix"])
+    merged = out.permute(0, 2, 3, 1).reshape(out.shape[0], out.shape[2], -1)
+    if taps is not None:
+        taps.update(kh=kh, vh=vh, qh=qh, attn_out=out)
+    return F.linear(merged, p["_W.linear.weight"], p["_W.linear.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# whole-model forwards (c1-c4)
+# --------------------------------------------------------------------------------------
+
+
+def vanilla_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, tanh, taps=None):
+    """CNP/ANP vanilla model forward for Pascal1D / ShapeNet1D
+    (CNPShapeNet1D.py:96-140, ANPShapeNet1D.py:118-157, CNPVanillaPascal1D.py:98-142,
+    ANPVanillaPascal1D.py:136-176).  Returns mu [T,Nq,y]."""
+    T, Nq = qry_x.shape[:2]
+    Nc = ctx_x.shape[1]
+    dim_w = p["encoder_w0.8.weight"].shape[0]
+    dim_z = p["r_to_z.weight"].shape[0]
+    x_qry = vanilla_encoder(qry_x.reshape(T * Nq, *qry_x.shape[2:]), p).reshape(T, Nq, dim_w)
+    t = {}
+    if Nc:
+        x_ctx = vanilla_encoder(ctx_x.reshape(T * Nc, *ctx_x.shape[2:]), p).reshape(T, Nc, dim_w)
+        ly = F.linear(ctx_y, p["transform_y.weight"], p["transform_y.bias"])
+        n_hidden = sum(1 for k_ in p if k_.startswith("encoder_r.layers.") and k_.endswith(".weight")) - 1
+        rs = encoder_fc(torch.cat([x_ctx, ly], dim=2), p, n_hidden=n_hidden)
+        if agg_mode == "attention":
+            r = multihead_attention(x_ctx, rs, x_qry, p, taps=t)
+            z = F.linear(r, p["r_to_z.weight"], p["r_to_z.bias"])
+        else:
+            if agg_mode == "mean":
+                r = agg_mean(rs)
+            elif agg_mode == "max":
+                r = agg_max(rs)
+            elif agg_mode == "baco":
+                mu = F.linear(rs, p["rs_to_mu.weight"], p["rs_to_mu.bias"])
+                var = 1e-5 + F.softplus(F.linear(rs, p["rs_to_var.weight"], p["rs_to_var.bias"]))
+                r, _ = agg_baco(mu, var)
+            else:
+                raise TypeError(f"agg_mode {agg_mode!r} is not applicable")
+            z = F.linear(r, p["r_to_z.weight"], p["r_to_z.bias"])[:, None, :].expand(T, Nq, dim_z)
+        t.update(x_ctx=x_ctx, rs=rs, r=r)
+    else:
+        z = torch.zeros(T, Nq, dim_z)
+    mu = decoder_mlp(torch.cat([x_qry, z], dim=-1), p, tanh=tanh)
+    if taps is not None:
+        taps.update(t, x_qry=x_qry, z=z)
+    return mu
+
+
+# --------------------------------------------------------------------------------------
+# L1  losses                                                   (trainer/losses.py:32-80)
+# --------------------------------------------------------------------------------------
+
+
+def azimuth_loss(gt, pr):
+    return ((gt[..., :2] - pr) ** 2).sum(dim=-1).mean()
+
+
+def mean_square_loss(gt, pr):
+    return ((gt - pr) ** 2).mean()
+
+
+def quaternion_loss(gt, pr):
+    pr = pr / pr.pow(2).sum(dim=-1, keepdim=True).sqrt()
+    pos = (gt - pr).abs().sum(dim=-1)
+    neg = (-gt - pr).abs().sum(dim=-1)
+    return torch.minimum(pos, neg).mean()
+
+
+def degree_loss(gt, pr):
+    g = torch.rad2deg(gt[..., -1])
+    ang = torch.acos(pr[..., 0])
+    ang = torch.where(pr[..., 1] < 0, 2 * math.pi - ang, ang)
+    d = torch.rad2deg(ang)
+    err = torch.stack([(g - d).abs(), (g + 360.0 - d).abs(), (g - (d + 360.0)).abs()], dim=-1)
+    return err.min(dim=-1)[0].mean()
+
+
+def distractor_loss(gt, pr):
+    return ((gt - pr) ** 2).sum(dim=-1).sqrt().mean()
+
+
+def calc_loss(task, mu, gt, test=False):
+    if task == "shapenet_1d":
+        return degree_loss(gt, mu) if test else azimuth_loss(gt, mu)
+    if task == "pascal_1d":
+        return mean_square_loss(gt, mu)
+    if task == "shapenet_3d":
+        return quaternion_loss(gt, mu)
+    if task == "distractor":
+        return distractor_loss(gt, mu)
+    raise TypeError(task)
+
+
+# --------------------------------------------------------------------------------------
+# X1  ConvEmbeddingModel (MMAML task embedding)      (conv_embedding_model.py:99-184)
+# --------------------------------------------------------------------------------------
+
+
+def conv_embedding_forward(x, p, num_conv=4, pooling="avg", bn_eps=1e-5):
+    """4x{conv3x3 s2 p1, train-mode batch norm over the shots of ONE task, ReLU},
+    spatial mean, Linear+ReLU, avg/max pool over the shot axis, one Linear per head."""
+    for i in range(1, num_conv + 1):
+        x = F.conv2d(x, p[f"conv.conv{i}.weight"], p[f"conv.conv{i}.bias"], stride=2, padding=1)
+        mean = x.mean(dim=(0, 2, 3), keepdim=True)
+        var = x.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+        x = (x - mean) / torch.sqrt(var + bn_eps)
+        x = x * p[f"conv.bn{i}.weight"].view(1, -1, 1, 1) + p[f"conv.bn{i}.bias"].view(1, -1, 1, 1)
+        x = F.relu(x)
+    x = x.reshape(x.shape[0], x.shape[1], -1).mean(dim=2)
+    hid = F.relu(F.linear(x, p["linear.weight"], p["linear.bias"]))
+    emb = hid.mean(dim=0, keepdim=True) if pooling == "avg" else hid.max(dim=0, keepdim=True)[0]
+    n_heads = sum(1 for k_ in p if k_.startswith("_embeddings.") and k_.endswith(".weight"))
+    return [F.linear(emb, p[f"_embeddings.{i}.weight"], p[f"_embeddings.{i}.bias"]) for i in range(n_heads)]

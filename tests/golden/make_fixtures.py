@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, which never travels to the
+GPU box).  It imports the reference's own ``networks/*`` and ``trainer/losses.py``
+on torch-CPU with import stubs for the third-party packages the image lacks
+(SURVEY.md Appendix C - none of the stubs touches hot-path arithmetic), feeds them
+seeded inputs and stores inputs' hashes, forward taps, outputs, loss and gradients.
+
+    python tests/golden/make_fixtures.py            # rewrites tests/golden/*.npz
+
+The fixtures are data only: no reference source text is stored.  Weights are NOT
+stored; each fixture keeps the sha256 of every state_dict tensor so the tests can
+prove that the identically-seeded modules of this repo regenerate the same weights.
+"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+FULL_GRAD_BYTES = 64 * 1024
+
+warnings.filterwarnings("ignore")
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            raise RuntimeError("stub called")
+
+    tv = mod("torchvision")
+    tv.models = mod("torchvision.models")
+    tv.models.utils = mod("torchvision.models.utils", load_state_dict_from_url=_Any())
+    tv.transforms = mod("torchvision.transforms")
+
+    class MetaModule(torch.nn.Module):
+        pass
+
+    tm = mod("torchmeta")
+    tm.modules = mod(
+        "torchmeta.modules", MetaModule=MetaModule,
+        MetaSequential=type("MetaSequential", (torch.nn.Sequential, MetaModule), {}),
+        MetaConv2d=type("MetaConv2d", (torch.nn.Conv2d, MetaModule), {}),
+        MetaLinear=type("MetaLinear", (torch.nn.Linear, MetaModule), {}),
+        MetaBatchNorm2d=type("MetaBatchNorm2d", (torch.nn.BatchNorm2d, MetaModule), {}))
+    tm.utils = mod("torchmeta.utils", gradient_update_parameters=None)
+    ia = mod("imgaug", seed=lambda *a, **k: None, ALL="ALL")
+    ia.augmenters = mod("imgaug.augmenters")
+    for n in ["Sometimes", "Sequential", "CropAndPad", "GammaContrast", "AddToBrightness",
+              "AverageBlur", "Affine", "OneOf", "Dropout", "CoarseDropout"]:
+        setattr(ia.augmenters, n, _Any)
+    pml = mod("pytorch_metric_learning")
+    pml.losses = mod("pytorch_metric_learning.losses", NTXentLoss=_Any)
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()
+
+
+def np32(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+
+
+BASE = dict(seed=2578, temperature=0.07, img_size=[128, 128, 1], img_agg="", dim_w=64,
+            n_hidden_units_r=[100, 100], dim_z=64)
+
+# name -> (method, cfg overrides, Nc, Nq)
+MODEL_CASES = {
+    # BASELINE.json configs[0..2]
+    "c1_cnp_pascal1d": ("CNPVanillaPascal1D", dict(task="pascal_1d", tasks_per_batch=4, input_dim=1, output_dim=1,
+                                                    agg_mode="mean", dim_r=100), 5, 5),
+    "c2_cnp_shapenet1d_mean": ("CNPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=16, input_dim=3, output_dim=2,
+                                                      agg_mode="mean", dim_r=100), 15, 15),
+    "c3_anp_shapenet1d": ("ANPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=16, input_dim=3, output_dim=2,
+                                                 agg_mode="attention", dim_r=64), 15, 15),
+    # ragged / edge cases (Nc != Nq, Nc = 0, T = 1, other aggregators, Pascal ANP)
+    "s_anp_shapenet1d_ragged": ("ANPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=2, input_dim=3, output_dim=2,
+                                                       agg_mode="attention", dim_r=64), 3, 5),
+    "s_anp_shapenet1d_t1": ("ANPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=1, input_dim=3, output_dim=2,
+                                                   agg_mode="attention", dim_r=64), 25, 30),
+    "s_anp_shapenet1d_nc0": ("ANPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=2, input_dim=3, output_dim=2,
+                                                    agg_mode="attention", dim_r=64), 0, 4),
+    "s_anp_pascal1d": ("ANPVanillaPascal1D", dict(task="pascal_1d", tasks_per_batch=3, input_dim=1, output_dim=1,
+                                                   agg_mode="attention", dim_r=64), 4, 6),
+    "s_cnp_shapenet1d_max": ("CNPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=3, input_dim=3, output_dim=2,
+                                                    agg_mode="max", dim_r=100), 7, 2),
+    "s_cnp_shapenet1d_baco": ("CNPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=2, input_dim=3, output_dim=2,
+                                                     agg_mode="baco", dim_r=256), 5, 3),
+    "s_cnp_shapenet1d_nc0": ("CNPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=2, input_dim=3, output_dim=2,
+                                                    agg_mode="mean", dim_r=100), 0, 3),
+    "s_cnp_pascal1d_max": ("CNPVanillaPascal1D", dict(task="pascal_1d", tasks_per_batch=2, input_dim=1, output_dim=1,
+                                                       agg_mode="max", dim_r=100), 1, 2),
+}
+
+
+def make_inputs(T, Nc, Nq, C, H, W, L):
+    g = torch.Generator().manual_seed(1234)
+    cx = torch.rand(T, Nc, C, H, W, generator=g)
+    qx = torch.rand(T, Nq, C, H, W, generator=g)
+    cy = torch.rand(T, Nc, L, generator=g)
+    qy = torch.rand(T, Nq, L, generator=g)
+    return cx, qx, cy, qy
+
+
+def run_model_case(name, method, over, Nc, Nq, LossFunc):
+    cfgd = dict(BASE, **over)
+    cfg = types.SimpleNamespace(device=torch.device("cpu"), **cfgd)
+    model = getattr(importlib.import_module(f"networks.{method}"), method)(cfg)
+    T = cfg.tasks_per_batch
+    H, W, C = cfg.img_size
+    cx, qx, cy, qy = make_inputs(T, Nc, Nq, C, H, W, cfg.input_dim)
+
+    calls = {}
+
+    def hook(tag):
+        def fn(_m, _inp, out):
+            calls.setdefault(tag, []).append(out.detach().clone())
+        return fn
+
+    for tag in ["encoder_w0", "encoder_r", "attn", "_W", "r_to_z", "transform_y"]:
+        if hasattr(model, tag):
+            getattr(model, tag).register_forward_hook(hook(tag))
+
+    model.train()
+    mu, var, kl = model(cx, cy, qx)
+    assert var is None
+    loss = LossFunc("mse", cfg.task).calc_loss(mu, var, qy)
+    (loss + 1e-7 * kl if torch.is_tensor(kl) else loss).backward()
+    with torch.no_grad():
+        model.eval()
+        mu_test, _, _ = model(cx, cy, qx, test=True)
+        loss_test = LossFunc("mse", cfg.task).calc_loss(mu_test, None, qy, test=True)
+
+    out = {"meta": None, "mu": np32(mu), "loss": np.float64(loss.item()),
+           "loss_test": np.float64(loss_test.item()), "kl": np.float64(float(kl))}
+    enc = calls.get("encoder_w0", [])
+    is_anp = method.startswith("ANP")
+    if Nc:
+        # ANP encodes qry first (ANPShapeNet1D.py:129-134), CNP ctx first (CNPShapeNet1D.py:108-134)
+        out["x_qry"], out["x_ctx"] = (np32(enc[0]), np32(enc[1])) if is_anp else (np32(enc[1]), np32(enc[0]))
+        out["rs"] = np32(calls["encoder_r"][0])
+        out["z_lin"] = np32(calls["r_to_z"][0])
+        if is_anp:
+            out["attn_out"] = np32(calls["attn"][0])
+            out["r"] = np32(calls["_W"][0])
+    else:
+        out["x_qry"] = np32(enc[0])
+
+    state_sha, grad_norm = {}, {}
+    for k, v in model.state_dict().items():
+        state_sha[k] = sha(v)
+    for k, prm in model.named_parameters():
+        if prm.grad is None:
+            grad_norm[k] = None
+            continue
+        gnp = np32(prm.grad)
+        grad_norm[k] = float(np.linalg.norm(gnp.astype(np.float64)))
+        if gnp.nbytes <= FULL_GRAD_BYTES:
+            out["grad/" + k] = gnp
+        else:
+            flat = gnp.reshape(-1)
+            out["gradhead/" + k] = flat[:4096].copy()
+            out["gradstride/" + k] = flat[1::61].copy()
+    meta = dict(name=name, method=method, cfg=cfgd, Nc=Nc, Nq=Nq, input_seed=1234,
+                input_sha=dict(cx=sha(cx), qx=sha(qx), cy=sha(cy), qy=sha(qy)),
+                state_sha=state_sha, grad_norm=grad_norm,
+                n_params=sum(p.numel() for p in model.parameters()),
+                torch=torch.__version__, threads=torch.get_num_threads())
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.8f} sum(mu)={mu.sum().item():.8f} "
+          f"gradnorm={np.sqrt(sum(v * v for v in grad_norm.values() if v is not None)):.8f}")
+
+
+def run_favor_cases():
+    """FastAttention / softmax_kernel / linear_attention in isolation (fast_attention.py)."""
+    fa = importlib.import_module("networks.fast_attention")
+    out = {}
+    meta = {}
+    for tag, (T, H, Nc, Nq, d, scale) in {"d64": (3, 8, 5, 7, 64, 1.0), "d64_big": (2, 8, 15, 15, 64, 4.0),
+                                          "d256": (1, 2, 3, 4, 256, 0.5)}.items():
+        torch.manual_seed(77)
+        attn = fa.FastAttention(dim_heads=d, causal=False)
+        g = torch.Generator().manual_seed(4321)
+        q = (torch.randn(T, H, Nq, d, generator=g) * scale).requires_grad_()
+        k = (torch.randn(T, H, Nc, d, generator=g) * scale).requires_grad_()
+        v = torch.randn(T, H, Nc, d, generator=g).requires_grad_()
+        wout = torch.randn(T, H, Nq, d, generator=g)
+        proj = attn.projection_matrix
+        qp = fa.softmax_kernel(q, projection_matrix=proj, is_query=True)
+        kp = fa.softmax_kernel(k, projection_matrix=proj, is_query=False)
+        o = attn(q, k, v)
+        (o * wout).sum().backward()
+        if proj.numel() * 4 <= FULL_GRAD_BYTES * 2:   # big ones regenerate from proj_seed (sha-checked)
+            out[f"{tag}/proj"] = np32(proj)
+        out.update({f"{tag}/q": np32(q), f"{tag}/k": np32(k), f"{tag}/v": np32(v),
+                    f"{tag}/wout": np32(wout), f"{tag}/qp": np32(qp), f"{tag}/kp": np32(kp), f"{tag}/out": np32(o),
+                    f"{tag}/dq": np32(q.grad), f"{tag}/dk": np32(k.grad), f"{tag}/dv": np32(v.grad)})
+        meta[tag] = dict(T=T, H=H, Nc=Nc, Nq=Nq, d=d, m=int(proj.shape[0]), proj_seed=77, proj_sha=sha(proj))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "favor.npz"), **out)
+    print("favor:", {k: v["m"] for k, v in meta.items()})
+
+
+def run_loss_cases(LossFunc):
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    pr2 = torch.tanh(torch.randn(4, 6, 2, generator=g))
+    ang = torch.rand(4, 6, 1, generator=g) * 2 * np.pi
+    gt3 = torch.cat([torch.cos(ang), torch.sin(ang), ang], dim=-1)
+    out["az/pr"], out["az/gt"] = np32(pr2), np32(gt3)
+    out["az/train"] = np.float64(LossFunc("mse", "shapenet_1d").calc_loss(pr2, None, gt3).item())
+    out["az/test"] = np.float64(LossFunc("mse", "shapenet_1d").calc_loss(pr2.clone(), None, gt3, test=True).item())
+    pr1, gt1 = torch.randn(3, 5, 1, generator=g), torch.rand(3, 5, 1, generator=g)
+    out["pas/pr"], out["pas/gt"] = np32(pr1), np32(gt1)
+    out["pas/train"] = np.float64(LossFunc("mse", "pascal_1d").calc_loss(pr1, None, gt1).item())
+    pr4 = torch.randn(2, 7, 4, generator=g)
+    gt4 = torch.nn.functional.normalize(torch.randn(2, 7, 4, generator=g), dim=-1)
+    out["quat/pr"], out["quat/gt"] = np32(pr4), np32(gt4)
+    out["quat/train"] = np.float64(LossFunc("mse", "shapenet_3d").calc_loss(pr4, None, gt4).item())
+    prd, gtd = torch.randn(2, 3, 2, generator=g), torch.rand(2, 3, 2, generator=g)
+    out["dis/pr"], out["dis/gt"] = np32(prd), np32(gtd)
+    out["dis/train"] = np.float64(LossFunc("mse", "distractor").calc_loss(prd, None, gtd).item())
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
+    print("losses: ok")
+
+
+def run_conv_embedding_case():
+    """ConvEmbeddingModel with the MMAMLShapeNet1D settings (MMAMLShapeNet1D.py:63-81)."""
+    cem = importlib.import_module("networks.conv_embedding_model")
+    torch.manual_seed(2578)
+    model = cem.ConvEmbeddingModel(
+        input_size=np.prod((1, 128, 128)), output_size=2, embedding_dims=[64, 128, 256, 512], hidden_size=128,
+        num_layers=2, convolutional=True, num_conv=4, num_channels=32, rnn_aggregation=False,
+        linear_before_rnn=False, embedding_pooling="avg", batch_norm=True, avgpool_after_conv=True,
+        img_size=(1, 128, 128))
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(6, 1, 128, 128, generator=g)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    embs = model(x)
+    sum(((e * (i + 1)).sum() for i, e in enumerate(embs))).backward()
+    out = {}
+    for i, e in enumerate(embs):
+        out[f"emb{i}"] = np32(e)
+    meta = dict(state_sha={k: sha(v) for k, v in sd0.items()}, seed=2578, input_seed=1234, x_sha=sha(x),
+                grad_norm={k: float(p.grad.norm()) for k, p in model.named_parameters() if p.grad is not None})
+    for k, p in model.named_parameters():
+        if p.grad is not None and p.grad.numel() * 4 <= FULL_GRAD_BYTES:
+            out["grad/" + k] = np32(p.grad)
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            out["after/" + k] = np32(v)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "conv_embedding.npz"), **out)
+    print("conv_embedding: ok", [tuple(e.shape) for e in embs])
+
+
+def main():
+    assert os.path.isdir(REF), "the reference is only available in the build container"
+    install_stubs()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    torch.set_num_threads(8)
+    LossFunc = importlib.import_module("trainer.losses").LossFunc
+    only = set(sys.argv[1:])
+    for name, (method, over, Nc, Nq) in MODEL_CASES.items():
+        if only and name not in only:
+            continue
+        run_model_case(name, method, over, Nc, Nq, LossFunc)
+    if not only or "favor" in only:
+        run_favor_cases()
+    if not only or "losses" in only:
+        run_loss_cases(LossFunc)
+    if not only or "conv_embedding" in only:
+        run_conv_embedding_case()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,185 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors of the reference.  Run on the MI355X box:  pytest tests -m gpu"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(*ts):
+    return [t.to(DEV) if t is not None else None for t in ts]
+
+
+# ---- igemm engine on plain GEMM shapes (MFMA lane maps, LDS images, split-K slab) --------------
+@pytest.mark.parametrize("M,K,N", [(1, 3, 16), (37, 80, 100), (240, 100, 64), (480, 512, 64), (65, 17, 130), (16, 4096, 64)])
+@pytest.mark.parametrize("act", ["none", "relu", "tanh"])
+def test_linear_fwd_bwd(gpulib, M, K, N, act):
+    g = torch.Generator().manual_seed(M * 1000 + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = {"none": lambda t: t, "relu": torch.relu, "tanh": torch.tanh}[act](F.linear(xr, wr, br))
+    yr.backward(dy)
+    xd, wd, bd, dyd = dev(x, w, b, dy)
+    y = gpulib.linear_fwd(xd, wd, bd, act)
+    dx, dw, db = gpulib.linear_bwd(xd, wd, y, dyd, act)
+    assert U.rel_err(y, yr) <= U.RTOL
+    assert U.rel_err(dx, xr.grad) <= U.RTOL
+    assert U.rel_err(dw, wr.grad) <= U.RTOL
+    assert U.rel_err(db, br.grad) <= U.RTOL
+
+
+def test_linear_asymmetric_identity(gpulib):
+    """A = I with an asymmetric B catches a transposed C/D lane map (cdna guide §3)."""
+    n = 48
+    x = torch.eye(n)
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97) / 7.0
+    y = gpulib.linear_fwd(x.to(DEV), w.to(DEV), None, "none")
+    assert torch.equal(y.cpu(), w.t())
+
+
+@pytest.mark.parametrize("mode", ["mean", "max", "baco"])
+@pytest.mark.parametrize("T,Nc,R", [(3, 7, 100), (16, 15, 64), (1, 1, 256), (2, 25, 100)])
+def test_agg_fwd_bwd(gpulib, mode, T, Nc, R):
+    g = torch.Generator().manual_seed(T + Nc + R)
+    rs, lv, dr = torch.randn(T, Nc, R, generator=g), torch.randn(T, Nc, R, generator=g) * 2, torch.randn(T, R, generator=g)
+    rr, ll = rs.clone().requires_grad_(), lv.clone().requires_grad_()
+    ro = O.agg_mean(rr) if mode == "mean" else O.agg_max(rr) if mode == "max" else O.agg_baco(rr, 1e-5 + F.softplus(ll))[0]
+    ro.backward(dr)
+    rsd, lvd, drd = dev(rs, lv if mode == "baco" else None, dr)
+    r, sigma, amax = gpulib.agg_fwd(mode, rsd, lvd)
+    drs, dlv = gpulib.agg_bwd(mode, rsd, lvd, r, sigma, amax, drd)
+    assert U.rel_err(r, ro) <= U.RTOL
+    assert U.rel_err(drs, rr.grad) <= U.RTOL
+    if mode == "baco":
+        assert U.rel_err(dlv, ll.grad) <= U.RTOL
+
+
+def test_favor_against_reference_vectors(gpulib):
+    fx = np.load(os.path.join(U.GOLDEN, "favor.npz"))
+    meta = json.loads(str(fx["meta"]))
+    for tag, mt in meta.items():
+        if f"{tag}/proj" in fx.files:
+            proj = torch.from_numpy(fx[f"{tag}/proj"])
+        else:
+            torch.manual_seed(mt["proj_seed"])
+            proj = O.gaussian_orthogonal_random_matrix(mt["m"], mt["d"])
+        q, k, v, wout = (torch.from_numpy(fx[f"{tag}/{n}"]) for n in ("q", "k", "v", "wout"))
+        T, H, Nq, d = q.shape
+        qn, kn, vn = (t.permute(0, 2, 1, 3).contiguous().to(DEV) for t in (q, k, v))
+        out, ws = gpulib.favor_fwd(qn, kn, vn, proj.to(DEV))
+        assert U.rel_err(out.view(T, Nq, d, H).permute(0, 3, 1, 2), fx[f"{tag}/out"]) <= U.RTOL, tag
+        dout = wout.permute(0, 2, 3, 1).reshape(T, Nq, d * H).contiguous().to(DEV)
+        dq, dk, dv = gpulib.favor_bwd(qn, kn, vn, proj.to(DEV), out, dout, ws)
+        for n, gt in (("dq", dq), ("dk", dk), ("dv", dv)):
+            assert U.rel_err(gt.permute(0, 2, 1, 3), fx[f"{tag}/{n}"], floor=1e-12) <= U.RTOL, (tag, n)
+
+
+def test_losses_against_reference_vectors(gpulib):
+    fx = np.load(os.path.join(U.GOLDEN, "losses.npz"))
+    for kind, tag, key, task in (("azimuth", "az", "train", "shapenet_1d"), ("degree", "az", "test", "shapenet_1d"),
+                                 ("mse", "pas", "train", "pascal_1d"), ("quaternion", "quat", "train", "shapenet_3d"),
+                                 ("distractor", "dis", "train", "distractor")):
+        pr, gt = torch.from_numpy(fx[f"{tag}/pr"]), torch.from_numpy(fx[f"{tag}/gt"])
+        loss = gpulib.loss_fwd(kind, pr.to(DEV), gt.to(DEV)).item()
+        want = float(fx[f"{tag}/{key}"])
+        assert abs(loss - want) <= 1e-5 * max(1.0, abs(want)), kind
+        if kind != "degree":
+            pro = pr.clone().requires_grad_()
+            O.calc_loss(task, pro, gt).backward()
+            dmu = gpulib.loss_bwd(kind, pr.to(DEV), gt.to(DEV), torch.tensor(1.0, device=DEV))
+            assert U.rel_err(dmu, pro.grad) <= U.RTOL, kind
+
+
+# ---- E1 encoder vs oracle -----------------------------------------------------------------------
+def _enc_params(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [("0.weight", (32, 1, 3, 3), 0.3), ("0.bias", (32,), 0.1), ("2.weight", (48, 32, 3, 3), 0.06), ("2.bias", (48,), 0.1),
+              ("5.weight", (64, 48, 3, 3), 0.05), ("5.bias", (64,), 0.1), ("8.weight", (64, 4096), 0.02), ("8.bias", (64,), 0.1)]
+    return {"encoder_w0." + k: torch.randn(*s, generator=g) * a for k, s, a in shapes}
+
+
+@pytest.mark.parametrize("n0,n1", [(1, 0), (3, 2), (8, 9)])
+def test_encoder_fwd_bwd_vs_oracle(gpulib, n0, n1):
+    p = _enc_params()
+    g = torch.Generator().manual_seed(n0 * 10 + n1)
+    x0, x1 = torch.rand(n0, 1, 128, 128, generator=g), torch.rand(n1, 1, 128, 128, generator=g)
+    df = torch.randn(n0 + n1, 64, generator=g)
+    pr = {k: v.clone().requires_grad_() for k, v in p.items()}
+    taps = {}
+    fr = O.vanilla_encoder(torch.cat([x0, x1]), pr, taps=taps)
+    fr.backward(df)
+    plist = [t.to(DEV) for t in p.values()]
+    f0, f1, saved = gpulib.enc_vanilla_fwd(x0.to(DEV), x1.to(DEV) if n1 else None, plist, 64)
+    assert U.rel_err(torch.cat([f0, f1]), fr) <= U.RTOL
+    grads = gpulib.enc_vanilla_bwd(x0.to(DEV), x1.to(DEV) if n1 else None, plist, 64, df[:n0].contiguous().to(DEV),
+                                   df[n0:].contiguous().to(DEV), saved)
+    for (k, ref), got in zip(pr.items(), grads):
+        assert U.rel_err(got, ref.grad) <= U.RTOL, k
+
+
+# ---- whole model through the plugin boundary vs the reference's golden vectors -------------------
+def _run_case(name):
+    fx, meta = U.load_case(name)
+    model = U.build_model(meta, DEV).to(DEV)
+    for k, v in model.state_dict().items():
+        assert U.sha(v) == meta["state_sha"][k]
+    cx, qx, cy, qy = (t.to(DEV) for t in U.case_inputs(meta))
+    from trainer.losses import LossFunc
+    model.train()
+    mu, var, kl = model(cx, cy, qx)
+    assert var is None and kl == 0
+    loss = LossFunc("mse", meta["cfg"]["task"]).calc_loss(mu, var, qy)
+    loss.backward()
+    assert U.rel_err(mu, fx["mu"]) <= U.RTOL
+    assert abs(loss.item() - float(fx["loss"])) <= U.RTOL * max(1.0, abs(float(fx["loss"])))
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    U.check_grads_against_fixture(grads, fx, meta)
+    with torch.no_grad():
+        model.eval()
+        mu_t, _, _ = model(cx, cy, qx, test=True)
+        lt = LossFunc("mse", meta["cfg"]["task"]).calc_loss(mu_t, None, qy, test=True)
+    assert abs(lt.item() - float(fx["loss_test"])) <= 1e-3 * max(1.0, abs(float(fx["loss_test"])))
+
+
+@pytest.mark.parametrize("name", U.model_case_names("s_"))
+def test_model_edge_cases_vs_reference(gpulib, name):
+    _run_case(name)
+
+
+@pytest.mark.parametrize("name", U.model_case_names("c"))
+def test_model_baseline_configs_vs_reference(gpulib, name):
+    """BASELINE.json configs[0..2] at their full sizes (T=4 5+5; T=16 15+15 CNP / ANP)."""
+    _run_case(name)
+
+
+def test_forward_is_deterministic_and_task_independent(gpulib):
+    """Size-independent properties at the full c3 size: bitwise run-to-run determinism, and
+    (tasks are independent apart from the FAVOR+ global key stabiliser) a task's output does not
+    depend on the other tasks of the batch beyond 1e-6."""
+    fx, meta = U.load_case("c3_anp_shapenet1d")
+    model = U.build_model(meta, DEV).to(DEV)
+    cx, qx, cy, _ = (t.to(DEV) for t in U.case_inputs(meta))
+    with torch.no_grad():
+        a = model(cx, cy, qx)[0]
+        b = model(cx, cy, qx)[0]
+        assert torch.equal(a, b)
+        perm = torch.arange(15, -1, -1, device=DEV)
+        c = model(cx[perm].contiguous(), cy[perm].contiguous(), qx[perm].contiguous())[0]
+        assert U.rel_err(c[perm], a) <= 1e-6
+
+
+def test_cpu_tensors_are_refused(gpulib):
+    from mlhot.binding import MlhotError
+    from mlhot.ops import LinearFunction
+    with pytest.raises(MlhotError):
+        LinearFunction.apply(torch.randn(2, 3), torch.randn(4, 3), None, "none")

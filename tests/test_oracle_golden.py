@@ -1,0 +1,104 @@
+"""Pins the CPU oracle (oracle/ref_cpu.py) against golden vectors produced by the reference
+itself (tests/golden/make_fixtures.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from tests import util as U
+
+TIGHT = 2e-6   # oracle and reference run the same ATen CPU kernels; only op grouping differs
+
+
+@pytest.mark.parametrize("name", U.model_case_names())
+def test_oracle_model_matches_reference(name):
+    fx, meta = U.load_case(name)
+    model = U.build_model(meta)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(meta["state_sha"].keys())
+    for k, v in sd.items():
+        assert U.sha(v) == meta["state_sha"][k], f"{k}: seeded init differs from the reference"
+    cx, qx, cy, qy = U.case_inputs(meta)
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in sd.items()}
+    taps = {}
+    mu = O.vanilla_np_forward(p, cx, cy, qx, meta["cfg"]["agg_mode"], tanh=model.OUT_TANH, taps=taps)
+    assert U.rel_err(mu, fx["mu"]) <= TIGHT
+    for tap in ("x_qry", "x_ctx", "rs"):
+        if tap in fx.files:
+            assert U.rel_err(taps[tap], fx[tap]) <= TIGHT, tap
+    if "attn_out" in fx.files:
+        assert U.rel_err(taps["attn_out"], fx["attn_out"]) <= TIGHT
+        assert U.rel_err(taps["r"], fx["r"]) <= TIGHT
+    loss = O.calc_loss(meta["cfg"]["task"], mu, qy)
+    assert abs(loss.item() - float(fx["loss"])) <= TIGHT * max(1.0, abs(float(fx["loss"])))
+    loss_test = O.calc_loss(meta["cfg"]["task"], mu.detach(), qy, test=True)
+    assert abs(loss_test.item() - float(fx["loss_test"])) <= 1e-5 * max(1.0, abs(float(fx["loss_test"])))
+    loss.backward()
+    grads = {k: p[k].grad for k, _ in model.named_parameters()}
+    U.check_grads_against_fixture(grads, fx, meta, tol=1e-5)
+
+
+def test_oracle_known_answers_of_the_survey():
+    """SURVEY.md §8c known answers (loss values of configs c1-c3)."""
+    for name, want in (("c1_cnp_pascal1d", 0.37023053), ("c2_cnp_shapenet1d_mean", 0.66624528), ("c3_anp_shapenet1d", 0.51365805)):
+        fx, _ = U.load_case(name)
+        assert abs(float(fx["loss"]) - want) < 2e-7
+
+
+def test_oracle_favor_matches_reference():
+    fx = np.load(os.path.join(U.GOLDEN, "favor.npz"))
+    meta = json.loads(str(fx["meta"]))
+    for tag, mt in meta.items():
+        if f"{tag}/proj" in fx.files:
+            proj = torch.from_numpy(fx[f"{tag}/proj"])
+        else:
+            torch.manual_seed(mt["proj_seed"])
+            proj = O.gaussian_orthogonal_random_matrix(mt["m"], mt["d"])
+        assert U.sha(proj) == mt["proj_sha"]
+        q, k, v, wout = (torch.from_numpy(fx[f"{tag}/{n}"]).requires_grad_(n != "wout") for n in ("q", "k", "v", "wout"))
+        assert U.rel_err(O.favor_features(q, proj, True), fx[f"{tag}/qp"]) <= TIGHT
+        assert U.rel_err(O.favor_features(k, proj, False), fx[f"{tag}/kp"]) <= TIGHT
+        out = O.favor_attention(q, k, v, proj)
+        assert U.rel_err(out, fx[f"{tag}/out"]) <= TIGHT
+        (out * wout).sum().backward()
+        for n, t in (("dq", q), ("dk", k), ("dv", v)):
+            assert U.rel_err(t.grad, fx[f"{tag}/{n}"], floor=1e-12) <= 1e-5, (tag, n)
+
+
+def test_oracle_losses_match_reference():
+    fx = np.load(os.path.join(U.GOLDEN, "losses.npz"))
+    for tag, task, key, test in (("az", "shapenet_1d", "train", False), ("az", "shapenet_1d", "test", True),
+                                 ("pas", "pascal_1d", "train", False), ("quat", "shapenet_3d", "train", False),
+                                 ("dis", "distractor", "train", False)):
+        got = O.calc_loss(task, torch.from_numpy(fx[f"{tag}/pr"]), torch.from_numpy(fx[f"{tag}/gt"]), test=test).item()
+        assert abs(got - float(fx[f"{tag}/{key}"])) <= 2e-6 * max(1.0, abs(got)), (tag, key)
+
+
+def test_oracle_conv_embedding_matches_reference():
+    fx = np.load(os.path.join(U.GOLDEN, "conv_embedding.npz"))
+    meta = json.loads(str(fx["meta"]))
+    from networks.conv_embedding_model import ConvEmbeddingModel
+    torch.manual_seed(meta["seed"])
+    model = ConvEmbeddingModel(input_size=128 * 128, output_size=2, embedding_dims=[64, 128, 256, 512], hidden_size=128,
+                               num_layers=2, convolutional=True, num_conv=4, num_channels=32, rnn_aggregation=False,
+                               linear_before_rnn=False, embedding_pooling="avg", batch_norm=True, avgpool_after_conv=True,
+                               img_size=(1, 128, 128))
+    sd = model.state_dict()
+    for k, v in sd.items():
+        assert U.sha(v) == meta["state_sha"][k], k
+    x = torch.rand(6, 1, 128, 128, generator=torch.Generator().manual_seed(meta["input_seed"]))
+    assert U.sha(x) == meta["x_sha"]
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    embs = O.conv_embedding_forward(x, p)
+    for i, e in enumerate(embs):
+        assert U.rel_err(e, fx[f"emb{i}"]) <= 1e-5
+    sum((e * (i + 1)).sum() for i, e in enumerate(embs)).backward()
+    # conv biases feed a train-mode batch norm, so their gradient is exactly zero in real
+    # arithmetic and ~1e-6 noise in fp32: compare at the floor the model tests use
+    floor = U.GRAD_FLOOR * max(float(np.abs(fx[k]).max()) for k in fx.files if k.startswith("grad/"))
+    for k in fx.files:
+        if k.startswith("grad/"):
+            assert U.rel_err(p[k[5:]].grad, fx[k], floor=floor) <= 1e-4, k

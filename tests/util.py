@@ -1,0 +1,99 @@
+"""Shared helpers for the parity tests."""
+import glob
+import hashlib
+import importlib
+import json
+import os
+import types
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# north_star: "outputs match the reference PyTorch CPU path within 1e-4 rel fp32".
+# Metric (SURVEY.md §7 hard parts): tensor-scale relative error  max|a-b| / max|b|.
+RTOL = 1e-4
+# Gradients far below the model's largest gradient entry are fp32 cancellation residue (at
+# init the FAVOR+ normaliser cancels the Q/K scale, leaving ~1e-9 gradients next to ~1e-1
+# ones); they are compared at a floor of GRAD_FLOOR x (largest |grad| entry of the model).
+GRAD_FLOOR = 1e-4
+
+
+def rel_err(a, b, floor=0.0):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    assert a.numel() == b.numel(), (a.shape, b.shape)
+    a = a.reshape(b.shape)
+    scale = max(b.abs().max().item(), floor, 1e-30)
+    return (a - b).abs().max().item() / scale
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()
+
+
+def model_case_names(prefix=""):
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, prefix + "*.npz"))
+                  if os.path.basename(f)[0] in "cs" and os.path.basename(f)[1] in "123_" and "conv_emb" not in f)
+
+
+def load_case(name):
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return fx, json.loads(str(fx["meta"]))
+
+
+def case_config(meta, device="cpu"):
+    return types.SimpleNamespace(device=torch.device(device), **meta["cfg"])
+
+
+def build_model(meta, device="cpu"):
+    cfg = case_config(meta, device)
+    mod = importlib.import_module("networks." + meta["method"])
+    return getattr(mod, meta["method"])(cfg)
+
+
+def case_inputs(meta):
+    c = meta["cfg"]
+    T, Nc, Nq = c["tasks_per_batch"], meta["Nc"], meta["Nq"]
+    H, W, C = c["img_size"]
+    g = torch.Generator().manual_seed(meta["input_seed"])
+    cx = torch.rand(T, Nc, C, H, W, generator=g)
+    qx = torch.rand(T, Nq, C, H, W, generator=g)
+    cy = torch.rand(T, Nc, c["input_dim"], generator=g)
+    qy = torch.rand(T, Nq, c["input_dim"], generator=g)
+    for k, t in (("cx", cx), ("qx", qx), ("cy", cy), ("qy", qy)):
+        assert sha(t) == meta["input_sha"][k], f"input {k} does not regenerate from the seed"
+    return cx, qx, cy, qy
+
+
+def loss_kind(task):
+    return {"shapenet_1d": "azimuth", "pascal_1d": "mse", "shapenet_3d": "quaternion", "distractor": "distractor"}[task]
+
+
+def check_grads_against_fixture(grads, fx, meta, tol=RTOL):
+    """grads: dict key -> tensor (or None).  Compares with the fixture's full / sampled grads."""
+    gmax = 0.0
+    for k in grads:
+        if "grad/" + k in fx:
+            gmax = max(gmax, float(np.abs(fx["grad/" + k]).max()))
+        elif "gradhead/" + k in fx:
+            gmax = max(gmax, float(np.abs(fx["gradhead/" + k]).max()))
+    floor = GRAD_FLOOR * gmax
+    worst = (0.0, None)
+    for k, g in grads.items():
+        want_norm = meta["grad_norm"][k]
+        if want_norm is None:
+            assert g is None, f"{k}: reference has grad=None"
+            continue
+        assert g is not None, f"{k}: missing gradient"
+        g = g.detach().cpu()
+        if "grad/" + k in fx:
+            e = rel_err(g, fx["grad/" + k], floor)
+        else:
+            flat = g.reshape(-1)
+            e = max(rel_err(flat[:4096], fx["gradhead/" + k], floor), rel_err(flat[1::61], fx["gradstride/" + k], floor))
+            assert abs(float(flat.double().norm()) - want_norm) <= tol * max(want_norm, floor), f"{k}: grad norm"
+        if e > worst[0]:
+            worst = (e, k)
+        assert e <= tol, f"{k}: gradient rel err {e:.3e} > {tol}"
+    return worst

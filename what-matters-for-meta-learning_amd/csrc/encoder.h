@@ -1,0 +1,154 @@
+// E1: the vanilla image encoder (conv-conv-pool-conv-linear), forward and backward.
+// Activations stay NCHW fp32 in HBM; what the backward needs is kept in `saved`:
+//   a1  [n][32][64][64]  conv1 output (post-ReLU)          512 KiB / image
+//   p2  [n][48][16][16]  pooled conv2 output (post-ReLU)    48 KiB / image
+//   am2 [n][48][16][16]  pool arg-max (uint8)               12 KiB / image
+//   a3  [n][4096]        conv3 output (post-ReLU, C-major flatten = nn.Flatten order)
+// conv2's 192 KiB/image pre-pool map is scratch: ReLU and pool commute, so the pooled value
+// and the arg-max are all the backward needs (DyPooled in problems.h).
+#pragma once
+#include "common.h"
+#include "foreach.h"
+#include "igemm.h"
+#include "ops_direct.h"
+#include "problems.h"
+#include "favor.h"   // MLHOT_TRY
+#include "../../include/mlhot.h"
+
+namespace mlhot {
+
+struct EncSaved {
+  float* a1; float* p2; uint8_t* am2; float* a3; bool ok; size_t bytes;
+};
+inline EncSaved enc_saved_carve(int n, void* base, size_t cap) {
+  Arena a(base, cap);
+  EncSaved s;
+  s.a1 = a.take<float>((size_t)n * 32 * 64 * 64);
+  s.p2 = a.take<float>((size_t)n * 48 * 16 * 16);
+  s.am2 = a.take<uint8_t>((size_t)n * 48 * 16 * 16);
+  s.a3 = a.take<float>((size_t)n * 4096);
+  s.ok = a.ok; s.bytes = a.off + 256;
+  return s;
+}
+inline size_t enc_saved_bytes(int n) { return enc_saved_carve(n, nullptr, 0).bytes; }
+
+// split-K factors (bounded so the slabs stay a few MB and every launch has >= ~256 workgroups)
+inline int enc_lin_split(int n) { (void)n; return 32; }
+inline int enc_linw_split(int n) { return n >= 64 ? 4 : 1; }
+inline int conv3w_split(int n) { int s = n / 4; return s < 1 ? 1 : (s > 128 ? 128 : s); }
+inline int conv2w_split(int n) { int s = n / 2; return s < 1 ? 1 : (s > 240 ? 240 : s); }
+inline int conv1w_split(int n) { int s = n * 2; return s > 1024 ? 1024 : s; }
+
+struct EncScratch {
+  float* a2;      // fwd: [n][48][32][32]
+  float* slab;    // split-K partials (fwd linear, bwd wgrads)
+  float* dy3;     // bwd: [n][4096]
+  float* dp2;     // bwd: [n][48][16][16]
+  float* dy1;     // bwd: [n][32][64][64]
+  bool ok; size_t bytes;
+};
+inline size_t enc_slab_floats(int n, int dim_w) {
+  size_t m = (size_t)enc_lin_split(n) * n * dim_w;
+  size_t v;
+  v = (size_t)enc_linw_split(n) * dim_w * 4097; if (v > m) m = v;
+  v = (size_t)conv3w_split(n) * 64 * 433;       if (v > m) m = v;
+  v = (size_t)conv2w_split(n) * 48 * 289;       if (v > m) m = v;
+  v = (size_t)conv1w_split(n) * 32 * 10;        if (v > m) m = v;
+  return m;
+}
+inline EncScratch enc_scratch_carve(int n, int dim_w, void* base, size_t cap) {
+  Arena a(base, cap);
+  EncScratch s;
+  s.slab = a.take<float>(enc_slab_floats(n, dim_w));
+  // forward and backward never run concurrently on one scratch: a2 aliases the backward buffers
+  const size_t mark = a.off;
+  s.a2 = a.take<float>((size_t)n * 48 * 32 * 32);
+  const size_t fwd_end = a.off;
+  a.off = mark;
+  s.dy3 = a.take<float>((size_t)n * 4096);
+  s.dp2 = a.take<float>((size_t)n * 48 * 16 * 16);
+  s.dy1 = a.take<float>((size_t)n * 32 * 64 * 64);
+  if (fwd_end > a.off) a.off = fwd_end;
+  s.ok = a.ok; s.bytes = a.off + 256;
+  return s;
+}
+inline size_t enc_scratch_bytes(int n, int dim_w) { return enc_scratch_carve(n, dim_w, nullptr, 0).bytes; }
+
+inline int enc_forward(const float* img0, int n0, const float* img1, int n1, const mlhot_enc_params& p, int dim_w,
+                       Rows2 feat, void* saved, void* scratch, size_t scratch_bytes, hipStream_t s) {
+  const int n = n0 + n1;
+  if (n <= 0) return MLHOT_OK;
+  EncSaved sv = enc_saved_carve(n, saved, (size_t)-1 / 2);
+  EncScratch sc = enc_scratch_carve(n, dim_w, scratch, scratch_bytes);
+  if (!sc.ok) { set_error("enc_vanilla_fwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
+  const Src2 x{img0, n0, img1, (size_t)128 * 128};
+  MLHOT_TRY(run_foreach(Conv1Fwd<Src2>{x, p.w1, p.b1, sv.a1}, (size_t)n * 4096, s, "enc.conv1"));
+  typedef ConvFwd<32, 64, 64, 48, Src1> C2;
+  C2 c2{n * 1024, 48, 288, Src1{sv.a1, (size_t)32 * 4096}, p.w2, p.b2, sc.a2};
+  MLHOT_TRY((run_igemm<C2, 128, 48, 16, 4, 1>(c2, 1, nullptr, s, "enc.conv2")));
+  MLHOT_TRY(run_foreach(Pool2Fwd{sc.a2, sv.p2, sv.am2, 32, 32}, (size_t)n * 48 * 256, s, "enc.pool"));
+  typedef ConvFwd<48, 16, 16, 64, Src1> C3;
+  C3 c3{n * 64, 64, 432, Src1{sv.p2, (size_t)48 * 256}, p.w3, p.b3, sv.a3};
+  MLHOT_TRY((run_igemm<C3, 64, 64, 16, 2, 2>(c3, 1, nullptr, s, "enc.conv3")));
+  EncLinFwd lf{n, dim_w, 4096, sv.a3, p.wl, p.bl, feat};
+  MLHOT_TRY((run_igemm<EncLinFwd, 64, 64, 16, 2, 2>(lf, enc_lin_split(n), sc.slab, s, "enc.linear")));
+  return MLHOT_OK;
+}
+
+template <int PY, int PX>
+inline int enc_conv3_dgrad(int n, const float* dy3, const float* w3, float* dp2, hipStream_t s) {
+  typedef DyPlain<64, 8, 8> DY;
+  typedef ConvDgrad<48, 16, 16, 64, PY, PX, DY> P;
+  P p{n * 64, 48, P::NTY * P::NTX * 64, DY{dy3}, w3, nullptr, dp2};
+  return run_igemm<P, 64, 48, 16, 4, 1>(p, 1, nullptr, s, "enc.bwd.conv3.dgrad");
+}
+template <int PY, int PX>
+inline int enc_conv2_dgrad(int n, const DyPooled<48, 32, 32>& dy, const float* w2, const float* a1, float* dy1, hipStream_t s) {
+  typedef ConvDgrad<32, 64, 64, 48, PY, PX, DyPooled<48, 32, 32>> P;
+  P p{n * 1024, 32, P::NTY * P::NTX * 48, dy, w2, a1, dy1};
+  return run_igemm<P, 128, 32, 16, 4, 1>(p, 1, nullptr, s, "enc.bwd.conv2.dgrad");
+}
+
+inline int enc_backward(const float* img0, int n0, const float* img1, int n1, const mlhot_enc_params& p, int dim_w,
+                        Rows2 dfeat, const void* saved, const mlhot_enc_grads& g,
+                        void* scratch, size_t scratch_bytes, hipStream_t s) {
+  const int n = n0 + n1;
+  if (n <= 0) return MLHOT_OK;
+  EncSaved sv = enc_saved_carve(n, (void*)saved, (size_t)-1 / 2);
+  EncScratch sc = enc_scratch_carve(n, dim_w, scratch, scratch_bytes);
+  if (!sc.ok) { set_error("enc_vanilla_bwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
+  const Src2 x{img0, n0, img1, (size_t)128 * 128};
+
+  // Linear(4096 -> dim_w): input gradient (masked by conv3's ReLU), weight + bias gradient
+  EncLinDgrad ld{n, 4096, dim_w, dfeat, p.wl, sv.a3, sc.dy3};
+  MLHOT_TRY((run_igemm<EncLinDgrad, 64, 64, 16, 2, 2>(ld, 1, nullptr, s, "enc.bwd.linear.dgrad")));
+  EncLinWgrad lw{dim_w, 4097, n, dfeat, sv.a3, g.wl, g.bl};
+  MLHOT_TRY((run_igemm<EncLinWgrad, 64, 64, 16, 2, 2>(lw, enc_linw_split(n), sc.slab, s, "enc.bwd.linear.wgrad")));
+
+  // conv3
+  typedef ConvWgrad<48, 16, 16, 64, DyPlain<64, 8, 8>, Src1> W3;
+  W3 w3{64, 433, n * 64, DyPlain<64, 8, 8>{sc.dy3}, Src1{sv.p2, (size_t)48 * 256}, g.w3, g.b3};
+  MLHOT_TRY((run_igemm<W3, 64, 64, 16, 2, 2>(w3, conv3w_split(n), sc.slab, s, "enc.bwd.conv3.wgrad")));
+  MLHOT_TRY((enc_conv3_dgrad<0, 0>(n, sc.dy3, p.w3, sc.dp2, s)));
+  MLHOT_TRY((enc_conv3_dgrad<0, 1>(n, sc.dy3, p.w3, sc.dp2, s)));
+  MLHOT_TRY((enc_conv3_dgrad<1, 0>(n, sc.dy3, p.w3, sc.dp2, s)));
+  MLHOT_TRY((enc_conv3_dgrad<1, 1>(n, sc.dy3, p.w3, sc.dp2, s)));
+
+  // conv2 (pool + ReLU backward are folded into the dY gather)
+  const DyPooled<48, 32, 32> dy2{sc.dp2, sv.p2, sv.am2};
+  typedef ConvWgrad<32, 64, 64, 48, DyPooled<48, 32, 32>, Src1> W2;
+  W2 w2{48, 289, n * 1024, dy2, Src1{sv.a1, (size_t)32 * 4096}, g.w2, g.b2};
+  MLHOT_TRY((run_igemm<W2, 48, 64, 16, 1, 4>(w2, conv2w_split(n), sc.slab, s, "enc.bwd.conv2.wgrad")));
+  MLHOT_TRY((enc_conv2_dgrad<0, 0>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
+  MLHOT_TRY((enc_conv2_dgrad<0, 1>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
+  MLHOT_TRY((enc_conv2_dgrad<1, 0>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
+  MLHOT_TRY((enc_conv2_dgrad<1, 1>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
+
+  // conv1 (no input gradient: images are leaves)
+  typedef ConvWgrad<1, 128, 128, 32, DyPlain<32, 64, 64>, Src2> W1;
+  W1 w1{32, 10, n * 4096, DyPlain<32, 64, 64>{sc.dy1}, x, g.w1, g.b1};
+  MLHOT_TRY((run_igemm<W1, 32, 16, 16, 2, 1>(w1, conv1w_split(n), sc.slab, s, "enc.bwd.conv1.wgrad")));
+  return MLHOT_OK;
+}
+
+}  // namespace mlhot

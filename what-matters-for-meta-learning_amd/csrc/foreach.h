@@ -1,0 +1,62 @@
+// Element-parallel and single-block-reduction launch helpers.
+//
+// Memory-bound glue (pool, aggregators, FAVOR+ feature maps, loss) is written as index
+// functors `f(i)`; on the GPU they run under a grid-stride kernel sized for 256 CUs, in the
+// hostsim flavour under a plain loop.  Reductions to a scalar run in ONE 256-thread workgroup
+// with a fixed-order LDS tree, so results are bitwise reproducible run to run.
+#pragma once
+#include "common.h"
+
+namespace mlhot {
+
+#ifndef MLHOT_HOSTSIM
+template <class F>
+__global__ __launch_bounds__(256) void foreach_kernel(const F f, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) f(i);
+}
+
+template <class R>
+__global__ __launch_bounds__(256) void reduce1_kernel(const R r, int n) {
+  __shared__ typename R::T sm[256];
+  typename R::T acc = r.identity();
+  for (int i = threadIdx.x; i < n; i += 256) acc = r.combine(acc, r.load(i));
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = r.combine(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) r.finish(sm[0]);
+}
+#endif
+
+template <class F>
+int run_foreach(const F& f, size_t n, hipStream_t stream, const char* what) {
+  if (n == 0) return MLHOT_OK;
+#ifdef MLHOT_HOSTSIM
+  (void)stream; (void)what;
+  for (size_t i = 0; i < n; ++i) f(i);
+  return MLHOT_OK;
+#else
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL((foreach_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, stream, f, n);
+  return check_launch(what);
+#endif
+}
+
+template <class R>
+int run_reduce1(const R& r, int n, hipStream_t stream, const char* what) {
+#ifdef MLHOT_HOSTSIM
+  (void)stream; (void)what;
+  typename R::T acc = r.identity();
+  for (int i = 0; i < n; ++i) acc = r.combine(acc, r.load(i));
+  r.finish(acc);
+  return MLHOT_OK;
+#else
+  hipLaunchKernelGGL((reduce1_kernel<R>), dim3(1), dim3(256), 0, stream, r, n);
+  return check_launch(what);
+#endif
+}
+
+}  // namespace mlhot

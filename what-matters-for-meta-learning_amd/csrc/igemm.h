@@ -1,0 +1,197 @@
+// Generic implicit-GEMM engine on the gfx950 fp32 matrix cores.
+//
+//   out(m, n) = sum_k  A(m, k) * B(k, n)            m < M, n < N, k < K
+//
+// A "problem" P is a small POD functor that maps logical GEMM indices to tensor
+// elements (im2col gather, stride-2 parity classes, pooled-gradient routing, blocked
+// head weights, fused bias / activation / ReLU-mask epilogues).  The kernel stages
+// BM x BK / BK x BN tiles of A(.,.) / B(.,.) through LDS and contracts them with
+// v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain).  Operand lane maps
+// (cdna_hip_programming.md §3): A lane l holds A[row l&15][k l>>4], B lane l holds
+// B[k l>>4][col l&15], C/D lane l reg r holds C[row 4*(l>>4)+r][col l&15].
+//
+// LDS images are laid out so both halves of a 32-lane ds_read_b32 group hit disjoint
+// banks: [k][m] rows with a leading dimension == 16 (mod 32), or (for operands whose
+// global image is k-contiguous) [m][k] rows of BK+1 floats.
+//
+// Split-K: grid.z slices the reduction; partial tiles go to a [split][M][N] slab and a
+// second kernel sums the slab in a fixed order (bitwise reproducible, no atomics).
+#pragma once
+#include "common.h"
+
+namespace mlhot {
+
+template <class P>
+struct SlabReduceArgs {
+  P p;
+  const float* slab;
+  int nsplit;
+};
+
+#ifndef MLHOT_HOSTSIM
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int lds_ld16(int b) { return (b % 32 == 16) ? b : b + 16; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <class P, int BM, int BN, int BK, int WM, int WN, bool SPLIT>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __restrict__ slab, int k_chunk) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && BK % 4 == 0, "tile shape");
+  constexpr bool AK = P::A_ALONG_K, BKc = P::B_ALONG_K;
+  constexpr int LDA = lds_ld16(BM), LDB = lds_ld16(BN), LDK = BK + 1;
+  constexpr int A_SZ = AK ? BM * LDK : BK * LDA;
+  constexpr int B_SZ = BKc ? BN * LDK : BK * LDB;
+  __shared__ float As[A_SZ];
+  __shared__ float Bs[B_SZ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kb = blockIdx.z * k_chunk;
+  const int ke = (kb + k_chunk < p.K) ? kb + k_chunk : p.K;
+
+  constexpr int EA = (BM * BK + NT - 1) / NT, EB = (BN * BK + NT - 1) / NT;
+  float ra[EA], rb[EB];
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < EA; ++i) {
+      const int e = tid + i * NT;
+      const int mm = AK ? e / BK : e % BM, kk = AK ? e % BK : e / BM;
+      const int m = m0 + mm, k = k0 + kk;
+      ra[i] = (e < BM * BK && m < p.M && k < ke) ? p.A(m, k) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < EB; ++i) {
+      const int e = tid + i * NT;
+      const int nn = BKc ? e / BK : e % BN, kk = BKc ? e % BK : e / BN;
+      const int n = n0 + nn, k = k0 + kk;
+      rb[i] = (e < BN * BK && n < p.N && k < ke) ? p.B(k, n) : 0.f;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < EA; ++i) {
+      const int e = tid + i * NT;
+      const int mm = AK ? e / BK : e % BM, kk = AK ? e % BK : e / BM;
+      if (e < BM * BK) As[AK ? mm * LDK + kk : kk * LDA + mm] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < EB; ++i) {
+      const int e = tid + i * NT;
+      const int nn = BKc ? e / BK : e % BN, kk = BKc ? e % BK : e / BN;
+      if (e < BN * BK) Bs[BKc ? nn * LDK + kk : kk * LDB + nn] = rb[i];
+    }
+  };
+
+  const int lr = lane & 15, lk = lane >> 4;
+  if (kb < ke) fetch(kb);
+  for (int k0 = kb; k0 < ke; k0 += BK) {
+    stash();
+    __syncthreads();
+    if (k0 + BK < ke) fetch(k0 + BK);  // next tile's gathers fly under this tile's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      const int kk = ks * 4 + lk;
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mm = (wm * TM + i) * 16 + lr;
+        a[i] = As[AK ? mm * LDK + kk : kk * LDA + mm];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nn = (wn * TN + j) * 16 + lr;
+        b[j] = Bs[BKc ? nn * LDK + kk : kk * LDB + nn];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (wm * TM + i) * 16 + lk * 4 + r;
+        const int n = n0 + (wn * TN + j) * 16 + lr;
+        if (m < p.M && n < p.N) {
+          if (SPLIT)
+            slab[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+          else
+            p.store(m, n, acc[i][j][r]);
+        }
+      }
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs<P> a) {
+  const size_t total = (size_t)a.p.M * a.p.N;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < a.nsplit; ++z) s += a.slab[(size_t)z * total + e];
+    a.p.store((int)(e / a.p.N), (int)(e % a.p.N), s);
+  }
+}
+
+#endif  // !MLHOT_HOSTSIM
+
+// Bytes of slab a split-K launch of problem (M, N) needs.
+inline size_t igemm_slab_bytes(int M, int N, int nsplit) { return nsplit > 1 ? (size_t)nsplit * M * N * sizeof(float) : 0; }
+
+// Launch (or, in the hostsim flavour, evaluate on the host) one implicit GEMM.
+template <class P, int BM, int BN, int BK, int WM, int WN>
+int run_igemm(const P& p, int nsplit, float* slab, hipStream_t stream, const char* what) {
+  if (p.M <= 0 || p.N <= 0) return MLHOT_OK;
+#ifdef MLHOT_HOSTSIM
+  (void)nsplit; (void)slab; (void)stream; (void)what;
+  for (int m = 0; m < p.M; ++m)
+    for (int n = 0; n < p.N; ++n) {
+      float s = 0.f;
+      for (int k = 0; k < p.K; ++k) s = fmaf(p.A(m, k), p.B(k, n), s);
+      p.store(m, n, s);
+    }
+  return MLHOT_OK;
+#else
+  if (nsplit < 1) nsplit = 1;
+  int k_chunk = (p.K + nsplit - 1) / nsplit;
+  k_chunk = (k_chunk + BK - 1) / BK * BK;
+  if (k_chunk < BK) k_chunk = BK;
+  nsplit = (p.K + k_chunk - 1) / k_chunk;
+  if (nsplit < 1) nsplit = 1;
+  dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, nsplit);
+  dim3 block(WM * WN * 64);
+  if (nsplit == 1) {
+    hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, WM, WN, false>), grid, block, 0, stream, p, (float*)nullptr, k_chunk);
+    return check_launch(what);
+  }
+  if (slab == nullptr) {
+    set_error("%s: split-K launch without a slab", what);
+    return MLHOT_ERR_WORKSPACE;
+  }
+  hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, WM, WN, true>), grid, block, 0, stream, p, slab, k_chunk);
+  int rc = check_launch(what);
+  if (rc) return rc;
+  SlabReduceArgs<P> a{p, slab, nsplit};
+  size_t total = (size_t)p.M * p.N;
+  int rb = (int)((total + 255) / 256);
+  if (rb > 2048) rb = 2048;
+  hipLaunchKernelGGL((slab_reduce_kernel<P>), dim3(rb), dim3(256), 0, stream, a);
+  return check_launch(what);
+#endif
+}
+
+}  // namespace mlhot

@@ -1,0 +1,133 @@
+// libmlhot.so - C ABI (include/mlhot.h) over the gfx950 kernels.  Single translation unit:
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC mlhot.hip -o libmlhot.so
+#include <stdarg.h>
+
+#include "common.h"
+#include "foreach.h"
+#include "igemm.h"
+#include "problems.h"
+#include "ops_direct.h"
+#include "favor.h"
+#include "encoder.h"
+#include "np_vanilla.h"
+#include "../../include/mlhot.h"
+
+namespace mlhot {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace mlhot
+
+using namespace mlhot;
+
+extern "C" {
+
+int mlhot_version(void) { return MLHOT_ABI_VERSION; }
+const char* mlhot_last_error(void) { return g_err; }
+
+// ---- E1 ---------------------------------------------------------------------------------------
+size_t mlhot_enc_vanilla_saved_bytes(int n_img) { return enc_saved_bytes(n_img); }
+size_t mlhot_enc_vanilla_scratch_bytes(int n_img, int dim_w) { return enc_scratch_bytes(n_img, dim_w); }
+
+int mlhot_enc_vanilla_fwd(const float* img0, int n0, const float* img1, int n1, const mlhot_enc_params* p, int dim_w,
+                          float* feat0, int ld0, float* feat1, int ld1, void* saved, void* scratch, size_t scratch_bytes,
+                          void* stream) {
+  if (!p || n0 < 0 || n1 < 0 || dim_w <= 0) { set_error("enc_vanilla_fwd: bad argument"); return MLHOT_ERR_ARG; }
+  return enc_forward(img0, n0, img1, n1, *p, dim_w, Rows2{feat0, ld0, n0, feat1, ld1}, saved, scratch, scratch_bytes,
+                     (hipStream_t)stream);
+}
+
+int mlhot_enc_vanilla_bwd(const float* img0, int n0, const float* img1, int n1, const mlhot_enc_params* p, int dim_w,
+                          const float* dfeat0, int ldd0, const float* dfeat1, int ldd1, const void* saved,
+                          const mlhot_enc_grads* g, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!p || !g || n0 < 0 || n1 < 0 || dim_w <= 0) { set_error("enc_vanilla_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  return enc_backward(img0, n0, img1, n1, *p, dim_w, Rows2{(float*)dfeat0, ldd0, n0, (float*)dfeat1, ldd1}, saved, *g,
+                      scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+// ---- linear -----------------------------------------------------------------------------------
+size_t mlhot_linear_bwd_scratch_bytes(int M, int K, int N) { (void)M; (void)K; (void)N; return 256; }
+
+int mlhot_linear_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
+                     int act, void* stream) {
+  if (M < 0 || K <= 0 || N <= 0 || act < 0 || act > 2) { set_error("linear_fwd: bad argument"); return MLHOT_ERR_ARG; }
+  return lin_fwd(x, ldx, wb1(w, b, N), y, ldy, M, K, N, act, (hipStream_t)stream, "linear_fwd");
+}
+
+int mlhot_linear_bwd(const float* x, int ldx, const float* w, const float* y, int ldy, const float* dy, int lddy, int M,
+                     int K, int N, int act, float* dx, int lddx, int accumulate, float* dw, float* db, void* scratch,
+                     size_t scratch_bytes, void* stream) {
+  (void)scratch; (void)scratch_bytes;
+  if (M < 0 || K <= 0 || N <= 0 || act < 0 || act > 2) { set_error("linear_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  if (dw) MLHOT_TRY(lin_wgrad(dy, lddy, y, ldy, act, x, ldx, gb1(dw, db, N), M, K, N, s, "linear_bwd.w"));
+  if (dx) MLHOT_TRY(lin_dgrad(dy, lddy, y, ldy, act, wb1(w, nullptr, N), dx, lddx, accumulate, M, K, N, s, "linear_bwd.x"));
+  return MLHOT_OK;
+}
+
+// ---- aggregators ------------------------------------------------------------------------------
+int mlhot_agg_fwd(int mode, const float* rs, const float* lv, int T, int Nc, int R, float* r, float* sigma_z,
+                  int32_t* amax, void* stream) {
+  if (mode < 0 || mode > 2 || T <= 0 || Nc <= 0 || R <= 0) { set_error("agg_fwd: bad argument"); return MLHOT_ERR_ARG; }
+  return run_foreach(AggFwd{mode, Nc, R, rs, lv, r, sigma_z, amax}, (size_t)T * R, (hipStream_t)stream, "agg_fwd");
+}
+int mlhot_agg_bwd(int mode, const float* rs, const float* lv, const float* r, const float* sigma_z, const int32_t* amax,
+                  const float* dr, int T, int Nc, int R, float* drs, float* dlv, void* stream) {
+  if (mode < 0 || mode > 2 || T <= 0 || Nc <= 0 || R <= 0) { set_error("agg_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  return run_foreach(AggBwd{mode, Nc, R, rs, lv, r, sigma_z, amax, dr, drs, dlv}, (size_t)T * R, (hipStream_t)stream, "agg_bwd");
+}
+
+// ---- FAVOR+ -----------------------------------------------------------------------------------
+size_t mlhot_favor_ws_bytes(int T, int H, int Nq, int Nc, int d, int m) {
+  size_t need = 0;
+  favor_carve(FavorDims{T, H, Nq, Nc, d, m}, nullptr, 0, &need);
+  return need;
+}
+int mlhot_favor_fwd(const float* q, const float* k, const float* v, const float* proj, int T, int H, int Nq, int Nc,
+                    int d, int m, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (T <= 0 || H <= 0 || Nq <= 0 || Nc <= 0 || d <= 0 || m <= 0) { set_error("favor_fwd: bad argument"); return MLHOT_ERR_ARG; }
+  return favor_forward(FavorDims{T, H, Nq, Nc, d, m}, q, k, v, proj, out, ws, ws_bytes, (hipStream_t)stream);
+}
+int mlhot_favor_bwd(const float* q, const float* k, const float* v, const float* proj, int T, int H, int Nq, int Nc,
+                    int d, int m, const float* out, const float* dout, float* dq, float* dk, float* dv, void* ws,
+                    size_t ws_bytes, void* stream) {
+  (void)proj;
+  if (T <= 0 || H <= 0 || Nq <= 0 || Nc <= 0 || d <= 0 || m <= 0) { set_error("favor_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  return favor_backward(FavorDims{T, H, Nq, Nc, d, m}, q, k, v, out, dout, dq, dk, dv, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- losses -----------------------------------------------------------------------------------
+int mlhot_loss_fwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim, float* loss, void* stream) {
+  if (kind < 0 || kind > 4 || rows <= 0 || y_dim <= 0 || y_dim > 8 || gt_dim < 1) { set_error("loss_fwd: bad argument"); return MLHOT_ERR_ARG; }
+  return run_reduce1(LossRed{kind, y_dim, gt_dim, rows, mu, gt, loss}, rows, (hipStream_t)stream, "loss_fwd");
+}
+int mlhot_loss_bwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim, const float* dloss,
+                   float* dmu, void* stream) {
+  if (kind < 0 || kind > 4 || rows <= 0 || y_dim <= 0 || y_dim > 8 || gt_dim < 1) { set_error("loss_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  return run_foreach(LossBwd{kind, y_dim, gt_dim, rows, mu, gt, dloss, dmu}, (size_t)rows, (hipStream_t)stream, "loss_bwd");
+}
+
+// ---- whole model ------------------------------------------------------------------------------
+size_t mlhot_np_struct_bytes(int which) {
+  return which == 0 ? sizeof(mlhot_np_dims) : which == 1 ? sizeof(mlhot_np_params) : sizeof(mlhot_np_grads);
+}
+size_t mlhot_np_saved_bytes(const mlhot_np_dims* d) { return d ? np_saved_carve(*d, nullptr, 0).bytes : 0; }
+size_t mlhot_np_scratch_bytes(const mlhot_np_dims* d) { return d ? np_scratch_carve(*d, nullptr, 0).bytes : 0; }
+
+int mlhot_np_vanilla_fwd(const mlhot_np_dims* d, const mlhot_np_params* p, const float* ctx_x, const float* ctx_y,
+                         const float* qry_x, float* mu, void* saved, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!d || !p) { set_error("np_vanilla_fwd: null dims/params"); return MLHOT_ERR_ARG; }
+  return np_forward(*d, *p, ctx_x, ctx_y, qry_x, mu, saved, scratch, scratch_bytes, (hipStream_t)stream);
+}
+int mlhot_np_vanilla_bwd(const mlhot_np_dims* d, const mlhot_np_params* p, const float* ctx_x, const float* ctx_y,
+                         const float* qry_x, const float* mu, const float* dmu, const mlhot_np_grads* g, const void* saved,
+                         void* scratch, size_t scratch_bytes, void* stream) {
+  if (!d || !p || !g) { set_error("np_vanilla_bwd: null dims/params/grads"); return MLHOT_ERR_ARG; }
+  return np_backward(*d, *p, ctx_x, ctx_y, qry_x, mu, dmu, *g, saved, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

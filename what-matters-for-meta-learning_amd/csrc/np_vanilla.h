@@ -1,0 +1,242 @@
+// Whole-model forward / backward of the vanilla CNP / ANP family (c1-c4):
+// CNPVanillaPascal1D, CNPShapeNet1D, ANPVanillaPascal1D, ANPShapeNet1D.
+// One C call enqueues the full kernel sequence; nothing returns to Python in between.
+//
+// Data flow (reference: CNPShapeNet1D.py:96-140, ANPShapeNet1D.py:93-157):
+//   images --E1--> x_ctx (cols 0..dw of cat_in) | x_qry (cols 0..dw of dec_in)
+//   cat_in = [x_ctx | transform_y(ctx_y)] --EncoderFC--> rs
+//   CNP: r = agg(rs) -> z = r_to_z(r), broadcast over targets into dec_in[:, dw:]
+//   ANP: K = W_k(x_ctx), V = W_v(rs), Q = W_q(x_qry) (8 heads in one GEMM each) -> FAVOR+
+//        -> merged -> _W -> r_to_z -> dec_in[:, dw:]
+//   mu = decoder0(dec_in)
+#pragma once
+#include "encoder.h"
+
+namespace mlhot {
+
+struct NpBuf {   // forward activations kept for the backward ("saved")
+  void* enc;
+  float *cat_in, *h[MLHOT_MAX_HIDDEN], *rs, *dec_in, *d1, *d2;
+  float *r, *sigma, *zt, *mu_l, *lv; int32_t* amax;
+  float *kh, *vh, *qh, *merged, *rr; void* favor; size_t favor_bytes;
+  bool ok; size_t bytes;
+};
+
+inline NpBuf np_saved_carve(const mlhot_np_dims& d, void* base, size_t cap) {
+  Arena a(base, cap);
+  NpBuf b{};
+  const size_t Rc = (size_t)d.T * d.Nc, Rq = (size_t)d.T * d.Nq;
+  const int n = (int)(Rc + Rq), dw = d.dim_w, H = MLHOT_HEADS;
+  b.enc = a.take<char>(enc_saved_bytes(n));
+  b.dec_in = a.take<float>(Rq * (dw + d.dim_z));
+  b.d1 = a.take<float>(Rq * d.dec_hidden);
+  b.d2 = a.take<float>(Rq * d.dec_hidden);
+  if (d.Nc > 0) {
+    b.cat_in = a.take<float>(Rc * (dw + dw / 4));
+    for (int i = 0; i < d.n_hidden; ++i) b.h[i] = a.take<float>(Rc * d.hidden[i]);
+    b.rs = a.take<float>(Rc * d.dim_r);
+    if (d.agg_mode == MLHOT_AGG_ATTENTION) {
+      b.kh = a.take<float>(Rc * H * dw); b.vh = a.take<float>(Rc * H * dw); b.qh = a.take<float>(Rq * H * dw);
+      b.merged = a.take<float>(Rq * H * dw); b.rr = a.take<float>(Rq * dw);
+      FavorDims f{d.T, H, d.Nq, d.Nc, dw, d.m_feat};
+      favor_carve(f, nullptr, 0, &b.favor_bytes);
+      b.favor = a.take<char>(b.favor_bytes);
+    } else {
+      b.r = a.take<float>((size_t)d.T * d.dim_r); b.zt = a.take<float>((size_t)d.T * d.dim_z);
+      b.amax = a.take<int32_t>((size_t)d.T * d.dim_r); b.sigma = a.take<float>((size_t)d.T * d.dim_r);
+      if (d.agg_mode == MLHOT_AGG_BACO) { b.mu_l = a.take<float>(Rc * d.dim_r); b.lv = a.take<float>(Rc * d.dim_r); }
+    }
+  }
+  b.ok = a.ok; b.bytes = a.off + 256;
+  return b;
+}
+
+struct NpScratch {
+  void* enc; size_t enc_bytes;
+  float *d_dec_in, *dd1, *dd2, *d_cat_in, *dh[MLHOT_MAX_HIDDEN], *d_rs;
+  float *d_rr, *d_merged, *dqh, *dkh, *dvh, *dzt, *dr, *d_mu_l, *d_lv;
+  bool ok; size_t bytes;
+};
+
+inline NpScratch np_scratch_carve(const mlhot_np_dims& d, void* base, size_t cap) {
+  Arena a(base, cap);
+  NpScratch s{};
+  const size_t Rc = (size_t)d.T * d.Nc, Rq = (size_t)d.T * d.Nq;
+  const int n = (int)(Rc + Rq), dw = d.dim_w, H = MLHOT_HEADS;
+  s.enc_bytes = enc_scratch_bytes(n, dw);
+  s.enc = a.take<char>(s.enc_bytes);
+  s.d_dec_in = a.take<float>(Rq * (dw + d.dim_z));
+  s.dd1 = a.take<float>(Rq * d.dec_hidden); s.dd2 = a.take<float>(Rq * d.dec_hidden);
+  if (d.Nc > 0) {
+    s.d_cat_in = a.take<float>(Rc * (dw + dw / 4));
+    for (int i = 0; i < d.n_hidden; ++i) s.dh[i] = a.take<float>(Rc * d.hidden[i]);
+    s.d_rs = a.take<float>(Rc * d.dim_r);
+    if (d.agg_mode == MLHOT_AGG_ATTENTION) {
+      s.d_rr = a.take<float>(Rq * dw); s.d_merged = a.take<float>(Rq * H * dw);
+      s.dqh = a.take<float>(Rq * H * dw); s.dkh = a.take<float>(Rc * H * dw); s.dvh = a.take<float>(Rc * H * dw);
+    } else {
+      s.dzt = a.take<float>((size_t)d.T * d.dim_z); s.dr = a.take<float>((size_t)d.T * d.dim_r);
+      if (d.agg_mode == MLHOT_AGG_BACO) { s.d_mu_l = a.take<float>(Rc * d.dim_r); s.d_lv = a.take<float>(Rc * d.dim_r); }
+    }
+  }
+  s.ok = a.ok; s.bytes = a.off + 256;
+  return s;
+}
+
+inline int np_check_dims(const mlhot_np_dims& d) {
+  if (d.T <= 0 || d.Nq <= 0 || d.Nc < 0 || d.n_hidden < 1 || d.n_hidden > MLHOT_MAX_HIDDEN || d.dim_w % 4 ||
+      d.agg_mode < 0 || d.agg_mode > 3 || d.y_dim < 1 || d.y_dim > 8) {
+    set_error("np_vanilla: bad dims"); return MLHOT_ERR_ARG;
+  }
+  if (d.agg_mode == MLHOT_AGG_ATTENTION && (d.dim_r != d.dim_w || d.m_feat <= 0)) {
+    set_error("np_vanilla: attention needs dim_r == dim_w and m_feat > 0"); return MLHOT_ERR_ARG;
+  }
+  return MLHOT_OK;
+}
+
+// ---- thin wrappers over the igemm problems -------------------------------------------------
+inline WBlocks wb1(const float* w, const float* b, int rows) { WBlocks x{}; x.w[0] = w; x.b[0] = b; x.rows = rows; return x; }
+inline WBlocks wb8(const float* const* w, const float* const* b, int rows) {
+  WBlocks x{}; for (int i = 0; i < MLHOT_HEADS; ++i) { x.w[i] = w[i]; x.b[i] = b ? b[i] : nullptr; } x.rows = rows; return x;
+}
+inline WBlocksMut gb1(float* w, float* b, int rows) { WBlocksMut x{}; x.w[0] = w; x.b[0] = b; x.rows = rows; return x; }
+inline WBlocksMut gb8(float* const* w, float* const* b, int rows) {
+  WBlocksMut x{}; for (int i = 0; i < MLHOT_HEADS; ++i) { x.w[i] = w[i]; x.b[i] = b[i]; } x.rows = rows; return x;
+}
+
+inline int lin_fwd(const float* x, int ldx, const WBlocks& wb, float* y, int ldy, int M, int K, int N, int act,
+                   hipStream_t s, const char* what) {
+  LinearFwd p{M, N, K, x, ldx, wb, y, ldy, act};
+  return run_igemm<LinearFwd, 64, 64, 16, 2, 2>(p, 1, nullptr, s, what);
+}
+// dx[M][Kin] (+)= (dy * act'(y)) W
+inline int lin_dgrad(const float* dy, int lddy, const float* y, int ldy, int act, const WBlocks& wb,
+                     float* dx, int lddx, int accumulate, int M, int Kin, int Nout, hipStream_t s, const char* what) {
+  LinearDgrad p{M, Kin, Nout, dy, lddy, y, ldy, act, wb, dx, lddx, accumulate};
+  return run_igemm<LinearDgrad, 64, 64, 16, 2, 2>(p, 1, nullptr, s, what);
+}
+inline int lin_wgrad(const float* dy, int lddy, const float* y, int ldy, int act, const float* x, int ldx,
+                     const WBlocksMut& gb, int M, int Kin, int Nout, hipStream_t s, const char* what) {
+  LinearWgrad p{Nout, Kin + 1, M, dy, lddy, y, ldy, act, x, ldx, gb};
+  return run_igemm<LinearWgrad, 64, 64, 16, 2, 2>(p, 1, nullptr, s, what);
+}
+
+inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_x, const float* ctx_y,
+                      const float* qry_x, float* mu, void* saved, void* scratch, size_t scratch_bytes, hipStream_t s) {
+  MLHOT_TRY(np_check_dims(d));
+  NpBuf b = np_saved_carve(d, saved, (size_t)-1 / 2);
+  NpScratch sc = np_scratch_carve(d, scratch, scratch_bytes);
+  if (!sc.ok) { set_error("np_vanilla_fwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
+  const int Rc = d.T * d.Nc, Rq = d.T * d.Nq, dw = d.dim_w, H = MLHOT_HEADS;
+  const int ldc = dw + dw / 4, ldd = dw + d.dim_z;
+
+  // E1 on [context | target] images in one pass; rows land in cat_in / dec_in
+  MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s));
+
+  if (d.Nc > 0) {
+    MLHOT_TRY(lin_fwd(ctx_y, d.label_dim, wb1(p.ty_w, p.ty_b, dw / 4), b.cat_in + dw, ldc, Rc, d.label_dim, dw / 4, ACT_NONE, s, "np.transform_y"));
+    const float* x = b.cat_in; int ldx = ldc, kin = ldc;
+    for (int i = 0; i < d.n_hidden; ++i) {
+      MLHOT_TRY(lin_fwd(x, ldx, wb1(p.er_w[i], p.er_b[i], d.hidden[i]), b.h[i], d.hidden[i], Rc, kin, d.hidden[i], ACT_RELU, s, "np.encoder_r"));
+      x = b.h[i]; ldx = kin = d.hidden[i];
+    }
+    MLHOT_TRY(lin_fwd(x, ldx, wb1(p.er_w[d.n_hidden], p.er_b[d.n_hidden], d.dim_r), b.rs, d.dim_r, Rc, kin, d.dim_r, ACT_NONE, s, "np.encoder_r.out"));
+
+    if (d.agg_mode == MLHOT_AGG_ATTENTION) {
+      MLHOT_TRY(lin_fwd(b.cat_in, ldc, wb8(p.wk_w, p.wk_b, dw), b.kh, H * dw, Rc, dw, H * dw, ACT_NONE, s, "np.W_k"));
+      MLHOT_TRY(lin_fwd(b.rs, d.dim_r, wb8(p.wv_w, p.wv_b, dw), b.vh, H * dw, Rc, dw, H * dw, ACT_NONE, s, "np.W_v"));
+      MLHOT_TRY(lin_fwd(b.dec_in, ldd, wb8(p.wq_w, p.wq_b, dw), b.qh, H * dw, Rq, dw, H * dw, ACT_NONE, s, "np.W_q"));
+      FavorDims f{d.T, H, d.Nq, d.Nc, dw, d.m_feat};
+      MLHOT_TRY(favor_forward(f, b.qh, b.kh, b.vh, p.proj, b.merged, b.favor, b.favor_bytes, s));
+      MLHOT_TRY(lin_fwd(b.merged, H * dw, wb1(p.wo_w, p.wo_b, dw), b.rr, dw, Rq, H * dw, dw, ACT_NONE, s, "np.W"));
+      MLHOT_TRY(lin_fwd(b.rr, dw, wb1(p.r2z_w, p.r2z_b, d.dim_z), b.dec_in + dw, ldd, Rq, d.dim_r, d.dim_z, ACT_NONE, s, "np.r_to_z"));
+    } else {
+      const float* src = b.rs;
+      if (d.agg_mode == MLHOT_AGG_BACO) {
+        MLHOT_TRY(lin_fwd(b.rs, d.dim_r, wb1(p.mu_w, p.mu_b, d.dim_r), b.mu_l, d.dim_r, Rc, d.dim_r, d.dim_r, ACT_NONE, s, "np.rs_to_mu"));
+        MLHOT_TRY(lin_fwd(b.rs, d.dim_r, wb1(p.var_w, p.var_b, d.dim_r), b.lv, d.dim_r, Rc, d.dim_r, d.dim_r, ACT_NONE, s, "np.rs_to_var"));
+        src = b.mu_l;
+      }
+      MLHOT_TRY(run_foreach(AggFwd{d.agg_mode, d.Nc, d.dim_r, src, b.lv, b.r, b.sigma, b.amax}, (size_t)d.T * d.dim_r, s, "np.agg"));
+      MLHOT_TRY(lin_fwd(b.r, d.dim_r, wb1(p.r2z_w, p.r2z_b, d.dim_z), b.zt, d.dim_z, d.T, d.dim_r, d.dim_z, ACT_NONE, s, "np.r_to_z"));
+      MLHOT_TRY(run_foreach(BcastRows{b.zt, d.dim_z, d.Nq, b.dec_in + dw, ldd}, (size_t)Rq * d.dim_z, s, "np.bcast_z"));
+    }
+  } else {
+    MLHOT_TRY(run_foreach(Fill2D{b.dec_in + dw, ldd, d.dim_z, 0.f}, (size_t)Rq * d.dim_z, s, "np.zero_z"));
+  }
+  MLHOT_TRY(lin_fwd(b.dec_in, ldd, wb1(p.dec_w[0], p.dec_b[0], d.dec_hidden), b.d1, d.dec_hidden, Rq, ldd, d.dec_hidden, ACT_RELU, s, "np.decoder0.0"));
+  MLHOT_TRY(lin_fwd(b.d1, d.dec_hidden, wb1(p.dec_w[1], p.dec_b[1], d.dec_hidden), b.d2, d.dec_hidden, Rq, d.dec_hidden, d.dec_hidden, ACT_RELU, s, "np.decoder0.2"));
+  MLHOT_TRY(lin_fwd(b.d2, d.dec_hidden, wb1(p.dec_w[2], p.dec_b[2], d.y_dim), mu, d.y_dim, Rq, d.dec_hidden, d.y_dim,
+                    d.out_tanh ? ACT_TANH : ACT_NONE, s, "np.decoder0.4"));
+  return MLHOT_OK;
+}
+
+inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_x, const float* ctx_y,
+                       const float* qry_x, const float* mu, const float* dmu, const mlhot_np_grads& g,
+                       const void* saved, void* scratch, size_t scratch_bytes, hipStream_t s) {
+  MLHOT_TRY(np_check_dims(d));
+  NpBuf b = np_saved_carve(d, (void*)saved, (size_t)-1 / 2);
+  NpScratch sc = np_scratch_carve(d, scratch, scratch_bytes);
+  if (!sc.ok) { set_error("np_vanilla_bwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
+  const int Rc = d.T * d.Nc, Rq = d.T * d.Nq, dw = d.dim_w, H = MLHOT_HEADS, dh = d.dec_hidden;
+  const int ldc = dw + dw / 4, ldd = dw + d.dim_z;
+  const int out_act = d.out_tanh ? ACT_TANH : ACT_NONE;
+
+  // decoder0
+  MLHOT_TRY(lin_wgrad(dmu, d.y_dim, mu, d.y_dim, out_act, b.d2, dh, gb1(g.dec_w[2], g.dec_b[2], d.y_dim), Rq, dh, d.y_dim, s, "np.bwd.dec4.w"));
+  MLHOT_TRY(lin_dgrad(dmu, d.y_dim, mu, d.y_dim, out_act, wb1(p.dec_w[2], nullptr, d.y_dim), sc.dd2, dh, 0, Rq, dh, d.y_dim, s, "np.bwd.dec4.x"));
+  MLHOT_TRY(lin_wgrad(sc.dd2, dh, b.d2, dh, ACT_RELU, b.d1, dh, gb1(g.dec_w[1], g.dec_b[1], dh), Rq, dh, dh, s, "np.bwd.dec2.w"));
+  MLHOT_TRY(lin_dgrad(sc.dd2, dh, b.d2, dh, ACT_RELU, wb1(p.dec_w[1], nullptr, dh), sc.dd1, dh, 0, Rq, dh, dh, s, "np.bwd.dec2.x"));
+  MLHOT_TRY(lin_wgrad(sc.dd1, dh, b.d1, dh, ACT_RELU, b.dec_in, ldd, gb1(g.dec_w[0], g.dec_b[0], dh), Rq, ldd, dh, s, "np.bwd.dec0.w"));
+  MLHOT_TRY(lin_dgrad(sc.dd1, dh, b.d1, dh, ACT_RELU, wb1(p.dec_w[0], nullptr, dh), sc.d_dec_in, ldd, 0, Rq, ldd, dh, s, "np.bwd.dec0.x"));
+
+  if (d.Nc > 0) {
+    const float* dz = sc.d_dec_in + dw;   // [Rq][dim_z], ld = ldd
+    if (d.agg_mode == MLHOT_AGG_ATTENTION) {
+      MLHOT_TRY(lin_wgrad(dz, ldd, nullptr, 0, ACT_NONE, b.rr, dw, gb1(g.r2z_w, g.r2z_b, d.dim_z), Rq, d.dim_r, d.dim_z, s, "np.bwd.r2z.w"));
+      MLHOT_TRY(lin_dgrad(dz, ldd, nullptr, 0, ACT_NONE, wb1(p.r2z_w, nullptr, d.dim_z), sc.d_rr, dw, 0, Rq, d.dim_r, d.dim_z, s, "np.bwd.r2z.x"));
+      MLHOT_TRY(lin_wgrad(sc.d_rr, dw, nullptr, 0, ACT_NONE, b.merged, H * dw, gb1(g.wo_w, g.wo_b, dw), Rq, H * dw, dw, s, "np.bwd.W.w"));
+      MLHOT_TRY(lin_dgrad(sc.d_rr, dw, nullptr, 0, ACT_NONE, wb1(p.wo_w, nullptr, dw), sc.d_merged, H * dw, 0, Rq, H * dw, dw, s, "np.bwd.W.x"));
+      FavorDims f{d.T, H, d.Nq, d.Nc, dw, d.m_feat};
+      MLHOT_TRY(favor_backward(f, b.qh, b.kh, b.vh, b.merged, sc.d_merged, sc.dqh, sc.dkh, sc.dvh, b.favor, b.favor_bytes, s));
+      // Q projection: x_qry gradient accumulates onto the decoder's
+      MLHOT_TRY(lin_wgrad(sc.dqh, H * dw, nullptr, 0, ACT_NONE, b.dec_in, ldd, gb8(g.wq_w, g.wq_b, dw), Rq, dw, H * dw, s, "np.bwd.W_q.w"));
+      MLHOT_TRY(lin_dgrad(sc.dqh, H * dw, nullptr, 0, ACT_NONE, wb8(p.wq_w, nullptr, dw), sc.d_dec_in, ldd, 1, Rq, dw, H * dw, s, "np.bwd.W_q.x"));
+      MLHOT_TRY(lin_wgrad(sc.dvh, H * dw, nullptr, 0, ACT_NONE, b.rs, d.dim_r, gb8(g.wv_w, g.wv_b, dw), Rc, dw, H * dw, s, "np.bwd.W_v.w"));
+      MLHOT_TRY(lin_dgrad(sc.dvh, H * dw, nullptr, 0, ACT_NONE, wb8(p.wv_w, nullptr, dw), sc.d_rs, d.dim_r, 0, Rc, dw, H * dw, s, "np.bwd.W_v.x"));
+      MLHOT_TRY(lin_wgrad(sc.dkh, H * dw, nullptr, 0, ACT_NONE, b.cat_in, ldc, gb8(g.wk_w, g.wk_b, dw), Rc, dw, H * dw, s, "np.bwd.W_k.w"));
+    } else {
+      MLHOT_TRY(run_foreach(BcastRowsBwd{dz, ldd, d.dim_z, d.Nq, sc.dzt}, (size_t)d.T * d.dim_z, s, "np.bwd.bcast_z"));
+      MLHOT_TRY(lin_wgrad(sc.dzt, d.dim_z, nullptr, 0, ACT_NONE, b.r, d.dim_r, gb1(g.r2z_w, g.r2z_b, d.dim_z), d.T, d.dim_r, d.dim_z, s, "np.bwd.r2z.w"));
+      MLHOT_TRY(lin_dgrad(sc.dzt, d.dim_z, nullptr, 0, ACT_NONE, wb1(p.r2z_w, nullptr, d.dim_z), sc.dr, d.dim_r, 0, d.T, d.dim_r, d.dim_z, s, "np.bwd.r2z.x"));
+      if (d.agg_mode == MLHOT_AGG_BACO) {
+        MLHOT_TRY(run_foreach(AggBwd{d.agg_mode, d.Nc, d.dim_r, b.mu_l, b.lv, b.r, b.sigma, b.amax, sc.dr, sc.d_mu_l, sc.d_lv},
+                              (size_t)d.T * d.dim_r, s, "np.bwd.agg"));
+        MLHOT_TRY(lin_wgrad(sc.d_mu_l, d.dim_r, nullptr, 0, ACT_NONE, b.rs, d.dim_r, gb1(g.mu_w, g.mu_b, d.dim_r), Rc, d.dim_r, d.dim_r, s, "np.bwd.rs_to_mu.w"));
+        MLHOT_TRY(lin_dgrad(sc.d_mu_l, d.dim_r, nullptr, 0, ACT_NONE, wb1(p.mu_w, nullptr, d.dim_r), sc.d_rs, d.dim_r, 0, Rc, d.dim_r, d.dim_r, s, "np.bwd.rs_to_mu.x"));
+        MLHOT_TRY(lin_wgrad(sc.d_lv, d.dim_r, nullptr, 0, ACT_NONE, b.rs, d.dim_r, gb1(g.var_w, g.var_b, d.dim_r), Rc, d.dim_r, d.dim_r, s, "np.bwd.rs_to_var.w"));
+        MLHOT_TRY(lin_dgrad(sc.d_lv, d.dim_r, nullptr, 0, ACT_NONE, wb1(p.var_w, nullptr, d.dim_r), sc.d_rs, d.dim_r, 1, Rc, d.dim_r, d.dim_r, s, "np.bwd.rs_to_var.x"));
+      } else {
+        MLHOT_TRY(run_foreach(AggBwd{d.agg_mode, d.Nc, d.dim_r, b.rs, nullptr, b.r, b.sigma, b.amax, sc.dr, sc.d_rs, nullptr},
+                              (size_t)d.T * d.dim_r, s, "np.bwd.agg"));
+      }
+    }
+    // EncoderFC, last layer first
+    const float* dy = sc.d_rs; int lddy = d.dim_r, nout = d.dim_r, act = ACT_NONE; const float* yv = nullptr; int ldy = 0;
+    for (int i = d.n_hidden; i >= 0; --i) {
+      const float* x = i > 0 ? b.h[i - 1] : b.cat_in;
+      const int kin = i > 0 ? d.hidden[i - 1] : ldc, ldx = kin;
+      float* dx = i > 0 ? sc.dh[i - 1] : sc.d_cat_in;
+      MLHOT_TRY(lin_wgrad(dy, lddy, yv, ldy, act, x, ldx, gb1(g.er_w[i], g.er_b[i], nout), Rc, kin, nout, s, "np.bwd.encoder_r.w"));
+      MLHOT_TRY(lin_dgrad(dy, lddy, yv, ldy, act, wb1(p.er_w[i], nullptr, nout), dx, kin, 0, Rc, kin, nout, s, "np.bwd.encoder_r.x"));
+      if (i > 0) { dy = dx; lddy = kin; nout = kin; act = ACT_RELU; yv = b.h[i - 1]; ldy = kin; }
+    }
+    if (d.agg_mode == MLHOT_AGG_ATTENTION)   // K projection: second consumer of x_ctx
+      MLHOT_TRY(lin_dgrad(sc.dkh, H * dw, nullptr, 0, ACT_NONE, wb8(p.wk_w, nullptr, dw), sc.d_cat_in, ldc, 1, Rc, dw, H * dw, s, "np.bwd.W_k.x"));
+    MLHOT_TRY(lin_wgrad(sc.d_cat_in + dw, ldc, nullptr, 0, ACT_NONE, ctx_y, d.label_dim, gb1(g.ty_w, g.ty_b, dw / 4), Rc, d.label_dim, dw / 4, s, "np.bwd.transform_y.w"));
+  }
+  MLHOT_TRY(enc_backward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{sc.d_cat_in, ldc, Rc, sc.d_dec_in, ldd}, b.enc, g.enc, sc.enc, sc.enc_bytes, s));
+  return MLHOT_OK;
+}
+
+}  // namespace mlhot

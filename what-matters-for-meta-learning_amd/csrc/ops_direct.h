@@ -1,0 +1,237 @@
+// Element-parallel functors of the hot path (run by run_foreach / run_reduce1).
+#pragma once
+#include "common.h"
+#include "problems.h"
+
+namespace mlhot {
+
+// ------------------------------------------------------------------------------------------
+// conv1 of the vanilla encoder: 1 -> 32 channels, 3x3 s2 p1 + ReLU on 128x128 images
+// (ANPShapeNet1D.py:47-48).  K = 9 is far too short for the matrix cores and the layer is
+// bound by its 512 KiB/image output write, so one lane owns one output pixel: the 9 taps
+// stay in registers, weights come through the scalar cache (uniform index), and the 32
+// channel-plane stores are each a full 256-B line per wave.
+// ------------------------------------------------------------------------------------------
+template <class XS>
+struct Conv1Fwd {
+  XS x;             // [n][1][128][128]
+  const float* w;   // [32][9]
+  const float* b;   // [32]
+  float* y;         // [n][32][64][64]
+  MLHOT_HD void operator()(size_t i) const {
+    const int ox = (int)(i & 63), oy = (int)((i >> 6) & 63), img = (int)(i >> 12);
+    const float* xi = x.img(img);
+    float t[9];
+#ifndef MLHOT_HOSTSIM
+#pragma unroll
+#endif
+    for (int ky = 0; ky < 3; ++ky)
+#ifndef MLHOT_HOSTSIM
+#pragma unroll
+#endif
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+        t[ky * 3 + kx] = (iy >= 0 && ix >= 0) ? xi[iy * 128 + ix] : 0.f;   // iy, ix <= 127 always
+      }
+    float* yo = y + (size_t)img * 32 * 4096 + oy * 64 + ox;
+    for (int co = 0; co < 32; ++co) {
+      float s = 0.f;
+#ifndef MLHOT_HOSTSIM
+#pragma unroll
+#endif
+      for (int q = 0; q < 9; ++q) s = fmaf(t[q], w[co * 9 + q], s);
+      s += b[co];
+      yo[(size_t)co * 4096] = s > 0.f ? s : 0.f;
+    }
+  }
+};
+
+// MaxPool2d((2,2)) on a post-ReLU map [n][C][H][W] -> [n][C][H/2][W/2] + window arg-max
+// (first maximum in scan order (0,0),(0,1),(1,0),(1,1), as ATen's max_pool2d).
+struct Pool2Fwd {
+  const float* a; float* p; uint8_t* amax; int H, W;   // H, W: input size
+  MLHOT_HD void operator()(size_t i) const {
+    const int wo = W / 2, ho = H / 2;
+    const int px = (int)(i % wo), py = (int)((i / wo) % ho);
+    const size_t plane = i / ((size_t)wo * ho);
+    const float* s = a + plane * H * W + (size_t)(2 * py) * W + 2 * px;
+    float best = s[0]; int which = 0;
+    if (s[1] > best) { best = s[1]; which = 1; }
+    if (s[W] > best) { best = s[W]; which = 2; }
+    if (s[W + 1] > best) { best = s[W + 1]; which = 3; }
+    p[i] = best; amax[i] = (uint8_t)which;
+  }
+};
+
+struct FillF { float* p; float v; MLHOT_HD void operator()(size_t i) const { p[i] = v; } };
+
+// strided 2-D fill: rows x cols window of a [rows][ld] matrix
+struct Fill2D {
+  float* p; int ld, cols; float v;
+  MLHOT_HD void operator()(size_t i) const { p[(i / cols) * ld + (i % cols)] = v; }
+};
+
+// ------------------------------------------------------------------------------------------
+// G1 aggregators over the shot axis.  One lane per (task, feature): lanes of a wave walk the
+// contiguous feature axis, so every shot row is read as full lines and the reduction over the
+// (<= 30) shots is a register loop.
+// ------------------------------------------------------------------------------------------
+MLHOT_HD float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }     // F.softplus, beta=1, threshold=20
+MLHOT_HD float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
+
+struct AggFwd {
+  int mode, Nc, R;
+  const float* rs; const float* lv; float* r; float* sigma; int32_t* amax;
+  MLHOT_HD void operator()(size_t i) const {
+    const int j = (int)(i % R); const size_t t = i / R;
+    const float* src = rs + t * Nc * R + j;
+    if (mode == 0) {
+      float s = 0.f;
+      for (int n = 0; n < Nc; ++n) s += src[(size_t)n * R];
+      r[i] = s / (float)Nc;
+    } else if (mode == 1) {
+      float best = src[0]; int arg = 0;
+      for (int n = 1; n < Nc; ++n) { const float v = src[(size_t)n * R]; if (v > best) { best = v; arg = n; } }
+      r[i] = best; amax[i] = arg;
+    } else {
+      const float* lsrc = lv + t * Nc * R + j;
+      float s1 = 1.f, s2 = 0.f;   // prior: mu_z = 0, sigma_z = 1  (CNPShapeNet1D.py:87-88)
+      for (int n = 0; n < Nc; ++n) {
+        const float iv = 1.f / (1e-5f + softplus_f(lsrc[(size_t)n * R]));
+        s1 += iv; s2 += iv * src[(size_t)n * R];
+      }
+      const float sz = 1.f / s1;
+      sigma[i] = sz; r[i] = sz * s2;
+    }
+  }
+};
+
+struct AggBwd {
+  int mode, Nc, R;
+  const float* rs; const float* lv; const float* r; const float* sigma; const int32_t* amax;
+  const float* dr; float* drs; float* dlv;
+  MLHOT_HD void operator()(size_t i) const {
+    const int j = (int)(i % R); const size_t t = i / R;
+    float* dst = drs + t * Nc * R + j;
+    const float g = dr[i];
+    if (mode == 0) {
+      const float v = g / (float)Nc;
+      for (int n = 0; n < Nc; ++n) dst[(size_t)n * R] = v;
+    } else if (mode == 1) {
+      const int arg = amax[i];
+      for (int n = 0; n < Nc; ++n) dst[(size_t)n * R] = (n == arg) ? g : 0.f;
+    } else {
+      const float* src = rs + t * Nc * R + j;
+      const float* lsrc = lv + t * Nc * R + j;
+      float* ldst = dlv + t * Nc * R + j;
+      const float sz = sigma[i], mz = r[i];
+      for (int n = 0; n < Nc; ++n) {
+        const float l = lsrc[(size_t)n * R];
+        const float var = 1e-5f + softplus_f(l);
+        const float mu = src[(size_t)n * R];
+        dst[(size_t)n * R] = g * sz / var;
+        // d mu_z / d var_n = -(mu_n - mu_z) * sigma_z / var_n^2 ; d var / d lv = sigmoid(lv)
+        ldst[(size_t)n * R] = -g * (mu - mz) * sz / (var * var) * (l > 20.f ? 1.f : sigmoid_f(l));
+      }
+    }
+  }
+};
+
+// z[t][dim_z] broadcast over the Nq target rows of the decoder input (…[:, None, :].repeat)
+struct BcastRows {
+  const float* z; int dz, Nq; float* dst; int ld;
+  MLHOT_HD void operator()(size_t i) const {
+    const int j = (int)(i % dz); const size_t row = i / dz;   // row = t*Nq + n
+    dst[row * ld + j] = z[(row / Nq) * dz + j];
+  }
+};
+// its backward: dz[t][j] = sum_n d dst[(t,n)][j]
+struct BcastRowsBwd {
+  const float* dsrc; int ld, dz, Nq; float* dzt;
+  MLHOT_HD void operator()(size_t i) const {
+    const int j = (int)(i % dz); const size_t t = i / dz;
+    float s = 0.f;
+    for (int n = 0; n < Nq; ++n) s += dsrc[(t * Nq + n) * ld + j];
+    dzt[i] = s;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// L1 losses (trainer/losses.py:32-80)
+// ------------------------------------------------------------------------------------------
+struct LossRed {
+  typedef float T;
+  int kind, y_dim, gt_dim, rows;
+  const float* mu; const float* gt; float* out;
+  MLHOT_HD float identity() const { return 0.f; }
+  MLHOT_HD float combine(float a, float b) const { return a + b; }
+  MLHOT_HD float load(int r) const {
+    const float* m = mu + (size_t)r * y_dim; const float* g = gt + (size_t)r * gt_dim;
+    if (kind == 0 || kind == 1) {                       // azimuth (first 2 labels) / plain MSE
+      float s = 0.f;
+      for (int j = 0; j < y_dim; ++j) { const float d = g[j] - m[j]; s += d * d; }
+      return s;
+    }
+    if (kind == 2) {                                    // quaternion: min(L1(q - q^), L1(-q - q^)), q^ normalised
+      float nn = 0.f;
+      for (int j = 0; j < y_dim; ++j) nn += m[j] * m[j];
+      nn = sqrtf(nn);
+      float p = 0.f, q = 0.f;
+      for (int j = 0; j < y_dim; ++j) { const float u = m[j] / nn; p += fabsf(g[j] - u); q += fabsf(-g[j] - u); }
+      return p < q ? p : q;
+    }
+    if (kind == 3) {                                    // degree error (test-time, shapenet_1d)
+      const float kRad2Deg = 57.29577951308232f;
+      const float gd = g[gt_dim - 1] * kRad2Deg;
+      float ang = acosf(m[0]);
+      if (m[1] < 0.f) ang = 6.283185307179586f - ang;
+      const float pd = ang * kRad2Deg;
+      float e = fabsf(gd - pd);
+      const float e2 = fabsf(gd + 360.f - pd), e3 = fabsf(gd - (pd + 360.f));
+      if (e2 < e) e = e2;
+      if (e3 < e) e = e3;
+      return e;
+    }
+    float s = 0.f;                                      // distractor: L2 distance
+    for (int j = 0; j < y_dim; ++j) { const float d = g[j] - m[j]; s += d * d; }
+    return sqrtf(s);
+  }
+  MLHOT_HD void finish(float s) const { out[0] = s / (float)(kind == 1 ? rows * y_dim : rows); }
+};
+
+struct LossBwd {
+  int kind, y_dim, gt_dim, rows;
+  const float* mu; const float* gt; const float* dloss; float* dmu;
+  MLHOT_HD void operator()(size_t r) const {
+    const float* m = mu + r * y_dim; const float* g = gt + r * gt_dim; float* d = dmu + r * y_dim;
+    const float up = dloss[0];
+    if (kind == 0 || kind == 1) {
+      const float s = up * 2.f / (float)(kind == 1 ? rows * y_dim : rows);
+      for (int j = 0; j < y_dim; ++j) d[j] = s * (m[j] - g[j]);
+    } else if (kind == 2) {
+      float nn = 0.f;
+      for (int j = 0; j < y_dim; ++j) nn += m[j] * m[j];
+      nn = sqrtf(nn);
+      float p = 0.f, q = 0.f;
+      for (int j = 0; j < y_dim; ++j) { const float u = m[j] / nn; p += fabsf(g[j] - u); q += fabsf(-g[j] - u); }
+      const float sgn = (p <= q) ? 1.f : -1.f;          // torch.minimum routes ties to ... measure zero
+      // dL/du_j = -sign(sgn*g_j - u_j) / rows ;  u = m/|m|  =>  dm = (du - u (u.du)) / |m|
+      float du[8]; float dot = 0.f;
+      for (int j = 0; j < y_dim; ++j) {
+        const float u = m[j] / nn, e = sgn * g[j] - u;
+        du[j] = -(e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * up / (float)rows;
+        dot += du[j] * u;
+      }
+      for (int j = 0; j < y_dim; ++j) d[j] = (du[j] - (m[j] / nn) * dot) / nn;
+    } else if (kind == 4) {
+      float s = 0.f;
+      for (int j = 0; j < y_dim; ++j) { const float e = g[j] - m[j]; s += e * e; }
+      s = sqrtf(s);
+      for (int j = 0; j < y_dim; ++j) d[j] = up * (m[j] - g[j]) / (s * (float)rows);
+    } else {
+      for (int j = 0; j < y_dim; ++j) d[j] = 0.f;       // degree error is evaluation-only
+    }
+  }
+};
+
+}  // namespace mlhot

@@ -1,0 +1,21 @@
+"""mlhot - MI355X-native CNP/ANP meta-batch hot path (host side).
+
+`lib()` returns the ctypes binding of csrc/libmlhot.so.  There is no fallback: if the
+HIP library is missing, or a tensor is not on a HIP device, the call raises.
+"""
+import threading
+
+from .binding import MlhotError, MlhotLib  # noqa: F401
+from .build import PRODUCT_SO, build_product  # noqa: F401
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                _lib = MlhotLib(PRODUCT_SO)
+    return _lib

@@ -1,0 +1,304 @@
+"""ctypes binding of the C ABI in include/mlhot.h.
+
+`MlhotLib(path)` wraps ONE shared object.  The product loads
+`csrc/libmlhot.so` through `mlhot.lib()`; the test-suite additionally wraps the
+host-simulation flavour (tests/hostsim) with the same class to check the index
+arithmetic without a GPU.  Every wrapper takes torch tensors, passes raw
+`data_ptr()`s and the current HIP stream, and raises `MlhotError` on a non-zero
+return code - nothing here computes anything.
+"""
+import ctypes as C
+import os
+
+import torch
+
+HEADS = 8
+MAX_HIDDEN = 4
+
+ACT = {"none": 0, "relu": 1, "tanh": 2}
+AGG = {"mean": 0, "max": 1, "baco": 2, "attention": 3}
+LOSS = {"azimuth": 0, "mse": 1, "quaternion": 2, "degree": 3, "distractor": 4}
+
+_f = C.c_void_p  # every device pointer travels as void*
+
+
+class MlhotError(RuntimeError):
+    pass
+
+
+class EncParams(C.Structure):
+    _fields_ = [(n, _f) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "wl", "bl")]
+
+
+class NpDims(C.Structure):
+    _fields_ = [("T", C.c_int), ("Nc", C.c_int), ("Nq", C.c_int), ("label_dim", C.c_int), ("y_dim", C.c_int),
+                ("dim_w", C.c_int), ("dim_r", C.c_int), ("dim_z", C.c_int), ("n_hidden", C.c_int),
+                ("hidden", C.c_int * MAX_HIDDEN), ("dec_hidden", C.c_int), ("agg_mode", C.c_int),
+                ("out_tanh", C.c_int), ("m_feat", C.c_int)]
+
+
+class NpParams(C.Structure):
+    """Mirrors mlhot_np_params AND mlhot_np_grads (same field order, grads lack `proj`)."""
+    _fields_ = [("enc", EncParams), ("ty_w", _f), ("ty_b", _f),
+                ("er_w", _f * (MAX_HIDDEN + 1)), ("er_b", _f * (MAX_HIDDEN + 1)),
+                ("r2z_w", _f), ("r2z_b", _f), ("dec_w", _f * 3), ("dec_b", _f * 3),
+                ("mu_w", _f), ("mu_b", _f), ("var_w", _f), ("var_b", _f),
+                ("wk_w", _f * HEADS), ("wk_b", _f * HEADS), ("wv_w", _f * HEADS), ("wv_b", _f * HEADS),
+                ("wq_w", _f * HEADS), ("wq_b", _f * HEADS), ("wo_w", _f), ("wo_b", _f), ("proj", _f)]
+
+
+class NpGrads(C.Structure):
+    _fields_ = NpParams._fields_[:-1]
+
+
+# (struct path, state_dict key) for the vanilla CNP/ANP family
+def vanilla_param_map(n_hidden, baco, attention):
+    m = [(("enc", "w1"), "encoder_w0.0.weight"), (("enc", "b1"), "encoder_w0.0.bias"),
+         (("enc", "w2"), "encoder_w0.2.weight"), (("enc", "b2"), "encoder_w0.2.bias"),
+         (("enc", "w3"), "encoder_w0.5.weight"), (("enc", "b3"), "encoder_w0.5.bias"),
+         (("enc", "wl"), "encoder_w0.8.weight"), (("enc", "bl"), "encoder_w0.8.bias"),
+         (("ty_w",), "transform_y.weight"), (("ty_b",), "transform_y.bias"),
+         (("r2z_w",), "r_to_z.weight"), (("r2z_b",), "r_to_z.bias")]
+    for i in range(n_hidden + 1):
+        m += [(("er_w", i), f"encoder_r.layers.{2 * i}.weight"), (("er_b", i), f"encoder_r.layers.{2 * i}.bias")]
+    for i in range(3):
+        m += [(("dec_w", i), f"decoder0.{2 * i}.weight"), (("dec_b", i), f"decoder0.{2 * i}.bias")]
+    if baco:
+        m += [(("mu_w",), "rs_to_mu.weight"), (("mu_b",), "rs_to_mu.bias"),
+              (("var_w",), "rs_to_var.weight"), (("var_b",), "rs_to_var.bias")]
+    if attention:
+        for tag, name in (("wk", "_W_k"), ("wv", "_W_v"), ("wq", "_W_q")):
+            for i in range(HEADS):
+                m += [((tag + "_w", i), f"{name}.{i}.linear.weight"), ((tag + "_b", i), f"{name}.{i}.linear.bias")]
+        m += [(("wo_w",), "_W.linear.weight"), (("wo_b",), "_W.linear.bias")]
+    return m
+
+
+def _set(struct, path, ptr):
+    if len(path) == 1:
+        setattr(struct, path[0], ptr)
+    elif isinstance(path[1], int):
+        getattr(struct, path[0])[path[1]] = ptr
+    else:
+        setattr(getattr(struct, path[0]), path[1], ptr)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else None
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None and (t.dtype not in (torch.float32, torch.int32, torch.uint8) or not t.is_contiguous()):
+            raise MlhotError(f"mlhot expects contiguous fp32 tensors, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+class MlhotLib:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise MlhotError(f"mlhot: shared library not found: {path} (run __graft_entry__.build())")
+        self.path = path
+        self.c = C.CDLL(path)
+        c = self.c
+        c.mlhot_version.restype = C.c_int
+        c.mlhot_last_error.restype = C.c_char_p
+        for fn in ("mlhot_enc_vanilla_saved_bytes", "mlhot_enc_vanilla_scratch_bytes", "mlhot_linear_bwd_scratch_bytes",
+                   "mlhot_favor_ws_bytes", "mlhot_np_struct_bytes", "mlhot_np_saved_bytes", "mlhot_np_scratch_bytes"):
+            getattr(c, fn).restype = C.c_size_t
+        c.mlhot_enc_vanilla_saved_bytes.argtypes = [C.c_int]
+        c.mlhot_enc_vanilla_scratch_bytes.argtypes = [C.c_int, C.c_int]
+        c.mlhot_favor_ws_bytes.argtypes = [C.c_int] * 6
+        c.mlhot_np_struct_bytes.argtypes = [C.c_int]
+        c.mlhot_np_saved_bytes.argtypes = [C.POINTER(NpDims)]
+        c.mlhot_np_scratch_bytes.argtypes = [C.POINTER(NpDims)]
+        i, z, P = C.c_int, C.c_size_t, C.c_void_p
+        c.mlhot_enc_vanilla_fwd.argtypes = [P, i, P, i, C.POINTER(EncParams), i, P, i, P, i, P, P, z, P]
+        c.mlhot_enc_vanilla_bwd.argtypes = [P, i, P, i, C.POINTER(EncParams), i, P, i, P, i, P, C.POINTER(EncParams), P, z, P]
+        c.mlhot_linear_fwd.argtypes = [P, i, P, P, P, i, i, i, i, i, P]
+        c.mlhot_linear_bwd.argtypes = [P, i, P, P, i, P, i, i, i, i, i, P, i, i, P, P, P, z, P]
+        c.mlhot_agg_fwd.argtypes = [i, P, P, i, i, i, P, P, P, P]
+        c.mlhot_agg_bwd.argtypes = [i, P, P, P, P, P, P, i, i, i, P, P, P]
+        c.mlhot_favor_fwd.argtypes = [P, P, P, P, i, i, i, i, i, i, P, P, z, P]
+        c.mlhot_favor_bwd.argtypes = [P, P, P, P, i, i, i, i, i, i, P, P, P, P, P, P, z, P]
+        c.mlhot_loss_fwd.argtypes = [i, P, P, i, i, i, P, P]
+        c.mlhot_loss_bwd.argtypes = [i, P, P, i, i, i, P, P, P]
+        c.mlhot_np_vanilla_fwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, P, z, P]
+        c.mlhot_np_vanilla_bwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, C.POINTER(NpGrads), P, P, z, P]
+        for which, st in ((0, NpDims), (1, NpParams), (2, NpGrads)):
+            if c.mlhot_np_struct_bytes(which) != C.sizeof(st):
+                raise MlhotError(f"mlhot: ABI struct size mismatch for {st.__name__}")
+        if c.mlhot_version() != 1:
+            raise MlhotError("mlhot: ABI version mismatch")
+
+    # ------------------------------------------------------------------------------------------
+    def _rc(self, rc, what):
+        if rc != 0:
+            raise MlhotError(f"{what} failed (code {rc}): {self.c.mlhot_last_error().decode()}")
+
+    @staticmethod
+    def _bytes(n, like):
+        return torch.empty(max(int(n), 256), dtype=torch.uint8, device=like.device)
+
+    # ---- E1 ------------------------------------------------------------------------------------
+    @staticmethod
+    def enc_struct(tensors):
+        """tensors: (w1,b1,w2,b2,w3,b3,wl,bl)"""
+        s = EncParams()
+        for name, t in zip(("w1", "b1", "w2", "b2", "w3", "b3", "wl", "bl"), tensors):
+            setattr(s, name, t.data_ptr())
+        return s
+
+    def enc_vanilla_fwd(self, img0, img1, params, dim_w):
+        """img0 [n0,1,128,128], img1 [n1,1,128,128] or None -> feat0 [n0,dim_w], feat1, saved"""
+        n0 = img0.shape[0]
+        n1 = 0 if img1 is None else img1.shape[0]
+        _chk(img0, img1, *params)
+        n = n0 + n1
+        feat0 = torch.empty(n0, dim_w, device=img0.device)
+        feat1 = torch.empty(n1, dim_w, device=img0.device)
+        saved = self._bytes(self.c.mlhot_enc_vanilla_saved_bytes(n), img0)
+        sb = self.c.mlhot_enc_vanilla_scratch_bytes(n, dim_w)
+        scratch = self._bytes(sb, img0)
+        ps = self.enc_struct(params)
+        self._rc(self.c.mlhot_enc_vanilla_fwd(_ptr(img0), n0, _ptr(img1), n1, C.byref(ps), dim_w, _ptr(feat0), dim_w,
+                                              _ptr(feat1), dim_w, _ptr(saved), _ptr(scratch), sb, _stream(img0)),
+                 "mlhot_enc_vanilla_fwd")
+        return feat0, feat1, saved
+
+    def enc_vanilla_bwd(self, img0, img1, params, dim_w, dfeat0, dfeat1, saved):
+        n0 = img0.shape[0]
+        n1 = 0 if img1 is None else img1.shape[0]
+        _chk(dfeat0, dfeat1)
+        grads = [torch.empty_like(p) for p in params]
+        sb = self.c.mlhot_enc_vanilla_scratch_bytes(n0 + n1, dim_w)
+        scratch = self._bytes(sb, img0)
+        ps, gs = self.enc_struct(params), self.enc_struct(grads)
+        self._rc(self.c.mlhot_enc_vanilla_bwd(_ptr(img0), n0, _ptr(img1), n1, C.byref(ps), dim_w, _ptr(dfeat0), dim_w,
+                                              _ptr(dfeat1), dim_w, _ptr(saved), C.byref(gs), _ptr(scratch), sb, _stream(img0)),
+                 "mlhot_enc_vanilla_bwd")
+        return grads
+
+    # ---- linear --------------------------------------------------------------------------------
+    def linear_fwd(self, x, w, b, act="none"):
+        _chk(x, w, b)
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, device=x.device)
+        self._rc(self.c.mlhot_linear_fwd(_ptr(x), K, _ptr(w), _ptr(b), _ptr(y), N, M, K, N, ACT[act], _stream(x)), "mlhot_linear_fwd")
+        return y
+
+    def linear_bwd(self, x, w, y, dy, act="none", need_dx=True):
+        _chk(x, w, y, dy)
+        M, K = x.shape
+        N = w.shape[0]
+        dx = torch.empty_like(x) if need_dx else None
+        dw, db = torch.empty_like(w), torch.empty(N, device=x.device)
+        self._rc(self.c.mlhot_linear_bwd(_ptr(x), K, _ptr(w), _ptr(y), N, _ptr(dy), N, M, K, N, ACT[act], _ptr(dx), K, 0,
+                                         _ptr(dw), _ptr(db), None, 0, _stream(x)), "mlhot_linear_bwd")
+        return dx, dw, db
+
+    # ---- aggregators ---------------------------------------------------------------------------
+    def agg_fwd(self, mode, rs, lv=None):
+        _chk(rs, lv)
+        T, Nc, R = rs.shape
+        r = torch.empty(T, R, device=rs.device)
+        sigma = torch.empty(T, R, device=rs.device)
+        amax = torch.empty(T, R, dtype=torch.int32, device=rs.device)
+        self._rc(self.c.mlhot_agg_fwd(AGG[mode], _ptr(rs), _ptr(lv), T, Nc, R, _ptr(r), _ptr(sigma), _ptr(amax), _stream(rs)), "mlhot_agg_fwd")
+        return r, sigma, amax
+
+    def agg_bwd(self, mode, rs, lv, r, sigma, amax, dr):
+        _chk(dr)
+        T, Nc, R = rs.shape
+        drs = torch.empty_like(rs)
+        dlv = torch.empty_like(rs) if mode == "baco" else None
+        self._rc(self.c.mlhot_agg_bwd(AGG[mode], _ptr(rs), _ptr(lv), _ptr(r), _ptr(sigma), _ptr(amax), _ptr(dr), T, Nc, R,
+                                      _ptr(drs), _ptr(dlv), _stream(rs)), "mlhot_agg_bwd")
+        return drs, dlv
+
+    # ---- FAVOR+ --------------------------------------------------------------------------------
+    def favor_fwd(self, q, k, v, proj):
+        """q [T,Nq,H,d], k/v [T,Nc,H,d], proj [m,d] -> out [T,Nq,d*H] (merged order), ws"""
+        _chk(q, k, v, proj)
+        T, Nq, H, d = q.shape
+        Nc, m = k.shape[1], proj.shape[0]
+        out = torch.empty(T, Nq, d * H, device=q.device)
+        wb = self.c.mlhot_favor_ws_bytes(T, H, Nq, Nc, d, m)
+        ws = self._bytes(wb, q)
+        self._rc(self.c.mlhot_favor_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(proj), T, H, Nq, Nc, d, m, _ptr(out), _ptr(ws), wb, _stream(q)),
+                 "mlhot_favor_fwd")
+        return out, ws
+
+    def favor_bwd(self, q, k, v, proj, out, dout, ws):
+        _chk(dout)
+        T, Nq, H, d = q.shape
+        Nc, m = k.shape[1], proj.shape[0]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        self._rc(self.c.mlhot_favor_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(proj), T, H, Nq, Nc, d, m, _ptr(out), _ptr(dout),
+                                        _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), ws.numel(), _stream(q)), "mlhot_favor_bwd")
+        return dq, dk, dv
+
+    # ---- losses --------------------------------------------------------------------------------
+    def loss_fwd(self, kind, mu, gt):
+        _chk(mu, gt)
+        rows = mu.numel() // mu.shape[-1]
+        loss = torch.empty((), device=mu.device)
+        self._rc(self.c.mlhot_loss_fwd(LOSS[kind], _ptr(mu), _ptr(gt), rows, mu.shape[-1], gt.shape[-1], _ptr(loss), _stream(mu)), "mlhot_loss_fwd")
+        return loss
+
+    def loss_bwd(self, kind, mu, gt, dloss):
+        _chk(dloss)
+        rows = mu.numel() // mu.shape[-1]
+        dmu = torch.empty_like(mu)
+        self._rc(self.c.mlhot_loss_bwd(LOSS[kind], _ptr(mu), _ptr(gt), rows, mu.shape[-1], gt.shape[-1], _ptr(dloss), _ptr(dmu), _stream(mu)),
+                 "mlhot_loss_bwd")
+        return dmu
+
+    # ---- whole vanilla model -------------------------------------------------------------------
+    @staticmethod
+    def np_dims(T, Nc, Nq, label_dim, y_dim, dim_w, dim_r, dim_z, hidden, dec_hidden, agg_mode, out_tanh, m_feat):
+        d = NpDims()
+        d.T, d.Nc, d.Nq, d.label_dim, d.y_dim = T, Nc, Nq, label_dim, y_dim
+        d.dim_w, d.dim_r, d.dim_z, d.n_hidden, d.dec_hidden = dim_w, dim_r, dim_z, len(hidden), dec_hidden
+        for i, h in enumerate(hidden):
+            d.hidden[i] = h
+        d.agg_mode, d.out_tanh, d.m_feat = AGG[agg_mode], int(out_tanh), m_feat
+        return d
+
+    @staticmethod
+    def np_struct(cls, dims, tensors, proj=None):
+        """tensors: dict state_dict-key -> tensor (params or grads)"""
+        s = cls()
+        pm = vanilla_param_map(dims.n_hidden, dims.agg_mode == AGG["baco"], dims.agg_mode == AGG["attention"])
+        for path, key in pm:
+            _set(s, path, tensors[key].data_ptr())
+        if proj is not None:
+            s.proj = proj.data_ptr()
+        return s
+
+    def np_vanilla_fwd(self, dims, params, ctx_x, ctx_y, qry_x, proj=None):
+        _chk(ctx_x, ctx_y, qry_x, proj, *params.values())
+        mu = torch.empty(dims.T, dims.Nq, dims.y_dim, device=qry_x.device)
+        saved = self._bytes(self.c.mlhot_np_saved_bytes(C.byref(dims)), qry_x)
+        sb = self.c.mlhot_np_scratch_bytes(C.byref(dims))
+        scratch = self._bytes(sb, qry_x)
+        ps = self.np_struct(NpParams, dims, params, proj)
+        self._rc(self.c.mlhot_np_vanilla_fwd(C.byref(dims), C.byref(ps), _ptr(ctx_x), _ptr(ctx_y), _ptr(qry_x), _ptr(mu),
+                                             _ptr(saved), _ptr(scratch), sb, _stream(qry_x)), "mlhot_np_vanilla_fwd")
+        return mu, saved, scratch
+
+    def np_vanilla_bwd(self, dims, params, ctx_x, ctx_y, qry_x, mu, dmu, saved, scratch=None, proj=None):
+        _chk(dmu, mu)
+        grads = {k: torch.empty_like(v) for k, v in params.items()}
+        sb = self.c.mlhot_np_scratch_bytes(C.byref(dims))
+        if scratch is None or scratch.numel() < sb:
+            scratch = self._bytes(sb, qry_x)
+        ps = self.np_struct(NpParams, dims, params, proj)
+        gs = self.np_struct(NpGrads, dims, grads)
+        self._rc(self.c.mlhot_np_vanilla_bwd(C.byref(dims), C.byref(ps), _ptr(ctx_x), _ptr(ctx_y), _ptr(qry_x), _ptr(mu), _ptr(dmu),
+                                             C.byref(gs), _ptr(saved), _ptr(scratch), sb, _stream(qry_x)), "mlhot_np_vanilla_bwd")
+        return grads

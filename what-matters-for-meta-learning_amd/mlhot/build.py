@@ -1,0 +1,52 @@
+"""Build recipes for the native library (no cmake: one hipcc / g++ command each)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+PRODUCT_SO = os.path.join(CSRC, "libmlhot.so")
+SOURCES = ["mlhot.hip"]
+HEADERS = ["common.h", "foreach.h", "igemm.h", "problems.h", "ops_direct.h", "favor.h", "encoder.h", "np_vanilla.h",
+           "conv_tc.h", os.path.join("..", "..", "include", "mlhot.h")]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+
+
+def build_product(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> csrc/libmlhot.so (cross-compiles without a GPU)."""
+    if not force and not _stale(PRODUCT_SO, _deps()):
+        return PRODUCT_SO
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        if os.path.exists(PRODUCT_SO):
+            return PRODUCT_SO      # GPU box without a toolchain: use the prebuilt file that travelled
+        raise RuntimeError("mlhot: hipcc not found and no prebuilt libmlhot.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-comment",
+           os.path.join(CSRC, "mlhot.hip"), "-o", PRODUCT_SO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return PRODUCT_SO
+
+
+def build_hostsim(out_dir, force=False):
+    """TEST-ONLY: the same sources compiled for the host (kernel launches -> plain loops)."""
+    out_dir = os.path.abspath(out_dir)
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libmlhot_hostsim.so")
+    if not force and not _stale(out, _deps()):
+        return out
+    cmd = ["g++", "-x", "c++", "-std=c++17", "-O2", "-DMLHOT_HOSTSIM", "-shared", "-fPIC", "-Wno-comment",
+           os.path.join(CSRC, "mlhot.hip"), "-o", out]
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out

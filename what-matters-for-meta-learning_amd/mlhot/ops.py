@@ -1,0 +1,152 @@
+"""torch.autograd bridges onto the C ABI (one Function per hot-path row of SURVEY.md §8a).
+
+The Functions are glue only: they hand raw device pointers to libmlhot.so and keep the
+opaque `saved` workspace alive between forward and backward.  There is NO eager/CPU
+fallback - a tensor that is not on a HIP device raises.
+"""
+import torch
+
+from . import lib
+from .binding import MlhotError
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MlhotError("mlhot: the hand-written HIP path needs tensors on a ROCm device "
+                             "(got a CPU tensor); there is no CPU fallback")
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+class VanillaNPFunction(torch.autograd.Function):
+    """Whole CNP/ANP vanilla forward+backward: mlhot_np_vanilla_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, dims, keys, proj, ctx_x, ctx_y, qry_x, *params):
+        _need_gpu(ctx_x, ctx_y, qry_x, *params)
+        L = lib()
+        ctx_x, ctx_y, qry_x = _c(ctx_x.float()), _c(ctx_y.float()), _c(qry_x.float())
+        pd = {k: _c(p.detach()) for k, p in zip(keys, params)}
+        mu, saved, scratch = L.np_vanilla_fwd(dims, pd, ctx_x, ctx_y, qry_x, proj)
+        ctx.dims, ctx.keys, ctx.proj = dims, keys, proj
+        ctx.scratch = scratch
+        ctx.save_for_backward(ctx_x, ctx_y, qry_x, mu, saved, *[pd[k] for k in keys])
+        return mu
+
+    @staticmethod
+    def backward(ctx, dmu):
+        ctx_x, ctx_y, qry_x, mu, saved, *params = ctx.saved_tensors
+        pd = dict(zip(ctx.keys, params))
+        grads = lib().np_vanilla_bwd(ctx.dims, pd, ctx_x, ctx_y, qry_x, mu, _c(dmu), saved, ctx.scratch, ctx.proj)
+        ctx.scratch = None
+        used = used_param_keys(ctx.keys, ctx.dims.Nc)
+        return (None, None, None, None, None, None) + tuple(grads[k] if k in used else None for k in ctx.keys)
+
+
+def used_param_keys(keys, Nc):
+    """Parameters the forward touches: with an empty context only the image encoder and the
+    decoder run (the zero-latent branch, ANPShapeNet1D.py:148-149), the rest get grad=None."""
+    if Nc > 0:
+        return set(keys)
+    return {k for k in keys if k.startswith("encoder_w0.") or k.startswith("decoder0.")}
+
+
+class EncVanillaFunction(torch.autograd.Function):
+    """E1 alone: mlhot_enc_vanilla_fwd / _bwd on one image batch."""
+
+    @staticmethod
+    def forward(ctx, img, *params):
+        _need_gpu(img, *params)
+        img = _c(img.float())
+        ps = [_c(p.detach()) for p in params]
+        dim_w = ps[6].shape[0]
+        feat, _, saved = lib().enc_vanilla_fwd(img, None, ps, dim_w)
+        ctx.dim_w = dim_w
+        ctx.save_for_backward(img, saved, *ps)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        img, saved, *ps = ctx.saved_tensors
+        empty = torch.empty(0, ctx.dim_w, device=img.device)
+        grads = lib().enc_vanilla_bwd(img, None, ps, ctx.dim_w, _c(dfeat), empty, saved)
+        return (None,) + tuple(grads)
+
+
+class LinearFunction(torch.autograd.Function):
+    """y = act(x W^T + b): mlhot_linear_fwd / _bwd (rows = all leading dims)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        _need_gpu(x, w, b)
+        shp = x.shape
+        x2 = _c(x.reshape(-1, shp[-1]).float())
+        y = lib().linear_fwd(x2, _c(w.detach()), _c(b.detach()) if b is not None else None, act)
+        ctx.act, ctx.shp, ctx.has_b = act, shp, b is not None
+        ctx.save_for_backward(x2, _c(w.detach()), y)
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        dx, dw, db = lib().linear_bwd(x2, w, y, _c(dy.reshape(-1, w.shape[0])), ctx.act, need_dx=ctx.needs_input_grad[0])
+        return (dx.view(ctx.shp) if dx is not None else None), dw, (db if ctx.has_b else None), None
+
+
+class AggFunction(torch.autograd.Function):
+    """mean / max / baco over dim 1 of rs[T,Nc,R]: mlhot_agg_fwd / _bwd.
+    For baco, `rs` is mu and `lv` the pre-softplus variance logits; returns (r, sigma_z)."""
+
+    @staticmethod
+    def forward(ctx, mode, rs, lv):
+        _need_gpu(rs, lv)
+        rs, lv = _c(rs), _c(lv)
+        r, sigma, amax = lib().agg_fwd(mode, rs, lv)
+        ctx.mode = mode
+        ctx.save_for_backward(rs, lv, r, sigma, amax)
+        ctx.mark_non_differentiable(sigma)
+        return r, sigma
+
+    @staticmethod
+    def backward(ctx, dr, _dsigma):
+        rs, lv, r, sigma, amax = ctx.saved_tensors
+        drs, dlv = lib().agg_bwd(ctx.mode, rs, lv, r, sigma, amax, _c(dr))
+        return None, drs, dlv
+
+
+class FavorFunction(torch.autograd.Function):
+    """FAVOR+ attention on token-major rows q[T,Nq,H,d], k/v[T,Nc,H,d] -> merged [T,Nq,d*H]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, proj):
+        _need_gpu(q, k, v, proj)
+        q, k, v, proj = _c(q), _c(k), _c(v), _c(proj)
+        out, ws = lib().favor_fwd(q, k, v, proj)
+        ctx.save_for_backward(q, k, v, proj, out, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, proj, out, ws = ctx.saved_tensors
+        dq, dk, dv = lib().favor_bwd(q, k, v, proj, out, _c(dout), ws)
+        return dq, dk, dv, None
+
+
+class LossFunction(torch.autograd.Function):
+    """LossFunc.calc_loss kinds: mlhot_loss_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, kind, mu, gt):
+        _need_gpu(mu, gt)
+        mu, gt = _c(mu.float()), _c(gt.float())
+        ctx.kind = kind
+        ctx.save_for_backward(mu, gt)
+        return lib().loss_fwd(kind, mu, gt)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        mu, gt = ctx.saved_tensors
+        return None, lib().loss_bwd(ctx.kind, mu, gt, _c(dloss.float())), None
