@@ -34,6 +34,13 @@ enum { MLHOT_LOSS_AZIMUTH = 0, MLHOT_LOSS_MSE = 1, MLHOT_LOSS_QUATERNION = 2, ML
 int mlhot_version(void);
 const char* mlhot_last_error(void);
 
+/* ---- bench-only: per-launch HIP-event timing ------------------------------------------------
+ * Between begin and end every kernel launch of the library is bracketed by two events recorded
+ * on its launch stream.  end() synchronises them and returns (label, milliseconds) records.
+ * Not re-entrant, not capturable; used only by bench.py's roofline leg.                        */
+int mlhot_prof_begin(int max_records);
+int mlhot_prof_end(const char** labels, float* ms, int cap);
+
 /* ---- E1: vanilla image encoder `encoder_w0` -------------------------------------------
  * replaces nn.Sequential(conv3x3s2+ReLU, conv3x3s2+ReLU, MaxPool2d(2), conv3x3s2+ReLU,
  * Flatten, Linear(4096,dim_w))   (networks/ANPShapeNet1D.py:46-56, CNPShapeNet1D.py:46-56,

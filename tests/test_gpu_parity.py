@@ -68,11 +68,7 @@ def test_favor_against_reference_vectors(gpulib):
     fx = np.load(os.path.join(U.GOLDEN, "favor.npz"))
     meta = json.loads(str(fx["meta"]))
     for tag, mt in meta.items():
-        if f"{tag}/proj" in fx.files:
-            proj = torch.from_numpy(fx[f"{tag}/proj"])
-        else:
-            torch.manual_seed(mt["proj_seed"])
-            proj = O.gaussian_orthogonal_random_matrix(mt["m"], mt["d"])
+        proj = torch.from_numpy(fx[f"{tag}/proj"])
         q, k, v, wout = (torch.from_numpy(fx[f"{tag}/{n}"]) for n in ("q", "k", "v", "wout"))
         T, H, Nq, d = q.shape
         qn, kn, vn = (t.permute(0, 2, 1, 3).contiguous().to(DEV) for t in (q, k, v))
@@ -130,9 +126,7 @@ def test_encoder_fwd_bwd_vs_oracle(gpulib, n0, n1):
 # ---- whole model through the plugin boundary vs the reference's golden vectors -------------------
 def _run_case(name):
     fx, meta = U.load_case(name)
-    model = U.build_model(meta, DEV).to(DEV)
-    for k, v in model.state_dict().items():
-        assert U.sha(v) == meta["state_sha"][k]
+    model = U.build_model(meta, DEV, fx=fx).to(DEV)
     cx, qx, cy, qy = (t.to(DEV) for t in U.case_inputs(meta))
     from trainer.losses import LossFunc
     model.train()
@@ -167,7 +161,7 @@ def test_forward_is_deterministic_and_task_independent(gpulib):
     (tasks are independent apart from the FAVOR+ global key stabiliser) a task's output does not
     depend on the other tasks of the batch beyond 1e-6."""
     fx, meta = U.load_case("c3_anp_shapenet1d")
-    model = U.build_model(meta, DEV).to(DEV)
+    model = U.build_model(meta, DEV, fx=fx).to(DEV)
     cx, qx, cy, _ = (t.to(DEV) for t in U.case_inputs(meta))
     with torch.no_grad():
         a = model(cx, cy, qx)[0]

@@ -46,10 +46,24 @@ def case_config(meta, device="cpu"):
     return types.SimpleNamespace(device=torch.device(device), **meta["cfg"])
 
 
-def build_model(meta, device="cpu"):
+def build_model(meta, device="cpu", fx=None):
+    """Identically-seeded module of this repo.  Parameters must regenerate bit-exactly (sha-checked
+    against the reference); the FAVOR+ projection buffer comes out of a LAPACK QR whose low bits
+    depend on the host CPU, so it is checked to 1e-5 and then loaded from the fixture."""
     cfg = case_config(meta, device)
     mod = importlib.import_module("networks." + meta["method"])
-    return getattr(mod, meta["method"])(cfg)
+    model = getattr(mod, meta["method"])(cfg)
+    for k, v in model.state_dict().items():
+        if k == "attn.projection_matrix":
+            continue
+        assert sha(v) == meta["state_sha"][k], f"{k}: seeded init differs from the reference"
+    if fx is not None and "projection_matrix" in fx.files:
+        ref = torch.from_numpy(fx["projection_matrix"])
+        assert sha(ref) == meta["state_sha"]["attn.projection_matrix"]
+        assert rel_err(model.attn.projection_matrix, ref) <= 1e-5
+        with torch.no_grad():
+            model.attn.projection_matrix.copy_(ref)
+    return model
 
 
 def case_inputs(meta):

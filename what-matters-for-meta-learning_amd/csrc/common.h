@@ -65,6 +65,20 @@ struct Arena {
   }
 };
 
+// Optional per-launch HIP-event timing (bench.py's roofline leg).  Off by default; when on,
+// every kernel launch is bracketed by two events recorded on the launch stream.
+#ifndef MLHOT_HOSTSIM
+void prof_record(const char* what, hipStream_t s, bool begin);
+extern bool g_prof_on;
+struct ProfScope {
+  const char* what; hipStream_t s;
+  ProfScope(const char* w, hipStream_t st) : what(w), s(st) { if (g_prof_on) prof_record(what, s, true); }
+  ~ProfScope() { if (g_prof_on) prof_record(what, s, false); }
+};
+#else
+struct ProfScope { ProfScope(const char*, hipStream_t) {} };
+#endif
+
 #ifndef MLHOT_HOSTSIM
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

@@ -40,6 +40,7 @@ int run_foreach(const F& f, size_t n, hipStream_t stream, const char* what) {
 #else
   size_t blocks = (n + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
+  ProfScope ps(what, stream);
   hipLaunchKernelGGL((foreach_kernel<F>), dim3((unsigned)blocks), dim3(256), 0, stream, f, n);
   return check_launch(what);
 #endif
@@ -54,6 +55,7 @@ int run_reduce1(const R& r, int n, hipStream_t stream, const char* what) {
   r.finish(acc);
   return MLHOT_OK;
 #else
+  ProfScope ps(what, stream);
   hipLaunchKernelGGL((reduce1_kernel<R>), dim3(1), dim3(256), 0, stream, r, n);
   return check_launch(what);
 #endif

@@ -175,6 +175,7 @@ int run_igemm(const P& p, int nsplit, float* slab, hipStream_t stream, const cha
   dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, nsplit);
   dim3 block(WM * WN * 64);
   if (nsplit == 1) {
+    ProfScope ps(what, stream);
     hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, WM, WN, false>), grid, block, 0, stream, p, (float*)nullptr, k_chunk);
     return check_launch(what);
   }
@@ -182,9 +183,13 @@ int run_igemm(const P& p, int nsplit, float* slab, hipStream_t stream, const cha
     set_error("%s: split-K launch without a slab", what);
     return MLHOT_ERR_WORKSPACE;
   }
-  hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, WM, WN, true>), grid, block, 0, stream, p, slab, k_chunk);
+  {
+    ProfScope ps(what, stream);
+    hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, WM, WN, true>), grid, block, 0, stream, p, slab, k_chunk);
+  }
   int rc = check_launch(what);
   if (rc) return rc;
+  ProfScope ps2("slab_reduce", stream);
   SlabReduceArgs<P> a{p, slab, nsplit};
   size_t total = (size_t)p.M * p.N;
   int rb = (int)((total + 255) / 256);

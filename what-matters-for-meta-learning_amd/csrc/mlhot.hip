@@ -20,6 +20,25 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+#ifndef MLHOT_HOSTSIM
+// ---- per-launch event profiler -------------------------------------------------------------------
+bool g_prof_on = false;
+struct ProfRec { const char* what; hipEvent_t a, b; };
+static ProfRec* g_prof = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0;
+void prof_record(const char* what, hipStream_t s, bool begin) {
+  if (begin) {
+    if (g_prof_n >= g_prof_cap) return;
+    g_prof[g_prof_n].what = what;
+    hipEventRecord(g_prof[g_prof_n].a, s);
+  } else {
+    if (g_prof_n >= g_prof_cap) return;
+    hipEventRecord(g_prof[g_prof_n].b, s);
+    ++g_prof_n;
+  }
+}
+#endif
 }  // namespace mlhot
 
 using namespace mlhot;
@@ -28,6 +47,38 @@ extern "C" {
 
 int mlhot_version(void) { return MLHOT_ABI_VERSION; }
 const char* mlhot_last_error(void) { return g_err; }
+
+// ---- profiler (bench only) ----------------------------------------------------------------------
+int mlhot_prof_begin(int max_records) {
+#ifndef MLHOT_HOSTSIM
+  if (g_prof) return MLHOT_ERR_ARG;
+  g_prof = new ProfRec[max_records];
+  for (int i = 0; i < max_records; ++i) { hipEventCreate(&g_prof[i].a); hipEventCreate(&g_prof[i].b); }
+  g_prof_cap = max_records; g_prof_n = 0; g_prof_on = true;
+#else
+  (void)max_records;
+#endif
+  return MLHOT_OK;
+}
+// Stops recording, synchronises the events and returns the number of records; record i is
+// (label, milliseconds).  Labels are static strings owned by the library.
+int mlhot_prof_end(const char** labels, float* ms, int cap) {
+  int n = 0;
+#ifndef MLHOT_HOSTSIM
+  g_prof_on = false;
+  for (int i = 0; i < g_prof_n; ++i) {
+    hipEventSynchronize(g_prof[i].b);
+    float t = 0.f;
+    hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
+    if (n < cap) { labels[n] = g_prof[i].what; ms[n] = t; ++n; }
+  }
+  for (int i = 0; i < g_prof_cap; ++i) { hipEventDestroy(g_prof[i].a); hipEventDestroy(g_prof[i].b); }
+  delete[] g_prof; g_prof = nullptr; g_prof_cap = g_prof_n = 0;
+#else
+  (void)labels; (void)ms; (void)cap;
+#endif
+  return n;
+}
 
 // ---- E1 ---------------------------------------------------------------------------------------
 size_t mlhot_enc_vanilla_saved_bytes(int n_img) { return enc_saved_bytes(n_img); }

@@ -143,6 +143,20 @@ class MlhotLib:
     def _bytes(n, like):
         return torch.empty(max(int(n), 256), dtype=torch.uint8, device=like.device)
 
+    # ---- bench-only launch profiler -----------------------------------------------------------
+    def prof_begin(self, max_records=4096):
+        self._prof_cap = max_records
+        self.c.mlhot_prof_begin.argtypes = [C.c_int]
+        self._rc(self.c.mlhot_prof_begin(max_records), "mlhot_prof_begin")
+
+    def prof_end(self):
+        """-> list of (label, ms) per kernel launch since prof_begin()"""
+        cap = self._prof_cap
+        labels, ms = (C.c_char_p * cap)(), (C.c_float * cap)()
+        self.c.mlhot_prof_end.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+        n = self.c.mlhot_prof_end(labels, ms, cap)
+        return [(labels[i].decode(), float(ms[i])) for i in range(n)]
+
     # ---- E1 ------------------------------------------------------------------------------------
     @staticmethod
     def enc_struct(tensors):
