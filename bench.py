@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: meta-tasks/s, forward+backward, ANPShapeNet1D 15+15-shot, 16 tasks per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = zero_grad + forward + loss + backward (+ one flat gradient all-reduce when N>1) of the
+hand-written HIP path on a synthetic meta-batch that is already resident in HBM.  Rank 0 prints ONE
+JSON line; it also carries `roofline` (the dominant kernel, timed live with HIP events on its launch
+stream) and `cpu_baseline` (the CPU oracle - a port of the reference arithmetic - on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "what-matters-for-meta-learning_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+WORKLOADS = {   # BASELINE.json configs[1] / configs[2]
+    "c3": dict(method="ANPShapeNet1D", agg_mode="attention", dim_r=64,
+               name="ANPShapeNet1D 128x128x1 15-shot context + 15 target, 16 tasks/GPU (BASELINE configs[2])"),
+    "c2": dict(method="CNPShapeNet1D", agg_mode="mean", dim_r=100,
+               name="CNPShapeNet1D mean-agg 128x128x1 15+15-shot, 16 tasks/GPU (BASELINE configs[1])"),
+}
+T_LOCAL, NC, NQ = 16, 15, 15
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = fp32 vector rate
+
+
+def alg_flops(label, n_img):
+    """Algorithmic FLOPs of ONE launch carrying `label` (2 x MACs of the layer)."""
+    pos2 = n_img * 1024
+    table = {
+        "enc.conv2": 2.0 * pos2 * 48 * 288,
+        "enc.bwd.conv2.wgrad": 2.0 * pos2 * 48 * 288,
+        "enc.bwd.conv2.dgrad": 2.0 * pos2 * 32 * 48 * 9 / 4,      # 9 taps spread over 4 parity launches
+        "enc.conv3": 2.0 * n_img * 64 * 64 * 432,
+        "enc.bwd.conv3.wgrad": 2.0 * n_img * 64 * 64 * 432,
+        "enc.bwd.conv3.dgrad": 2.0 * n_img * 64 * 48 * 64 * 9 / 4,
+        "enc.conv1": 2.0 * n_img * 4096 * 32 * 9,
+        "enc.bwd.conv1.wgrad": 2.0 * n_img * 4096 * 32 * 9,
+        "enc.linear": 2.0 * n_img * 4096 * 64,
+        "enc.bwd.linear.dgrad": 2.0 * n_img * 4096 * 64,
+        "enc.bwd.linear.wgrad": 2.0 * n_img * 4096 * 64,
+    }
+    return table.get(label)
+
+
+def make_cfg(w, device):
+    return types.SimpleNamespace(device=device, seed=2578, img_size=[128, 128, 1], tasks_per_batch=T_LOCAL, input_dim=3,
+                                 output_dim=2, agg_mode=w["agg_mode"], img_agg="", dim_w=64, n_hidden_units_r=[100, 100],
+                                 dim_r=w["dim_r"], dim_z=64, task="shapenet_1d", method=w["method"])
+
+
+def cpu_baseline(w, steps=3):
+    """The CPU oracle (torch-CPU restatement of the reference forward, autograd backward) on the
+    same 16-task batch, all host cores; a bounded sample: 1 warm-up + `steps` timed steps."""
+    import importlib
+    from oracle import ref_cpu as O
+    from mlhot import synth
+    cfg = make_cfg(w, torch.device("cpu"))
+    model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(cfg)
+    p = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "projection" not in k)
+         for k, v in model.state_dict().items()}
+    cx, qx, cy, qy = synth.get_batch("shapenet_1d", T_LOCAL, NC, NQ, seed=1234)
+    times = []
+    for i in range(steps + 1):
+        for t in p.values():
+            t.grad = None
+        t0 = time.perf_counter()
+        mu = O.vanilla_np_forward(p, cx, cy, qx, w["agg_mode"], tanh=True)
+        O.calc_loss("shapenet_1d", mu, qy).backward()
+        dt = time.perf_counter() - t0
+        if i:
+            times.append(dt)
+    med = sorted(times)[len(times) // 2]
+    return {"value": T_LOCAL / med, "unit": "meta-tasks/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} fwd+bwd steps of the same 16-task 15+15 batch after 1 warm-up, median {med * 1e3:.1f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-steps", type=int, default=5)
+    args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+
+    import importlib
+    import torch.distributed as dist
+    import mlhot
+    from mlhot import dist as mdist, synth
+    from trainer.losses import LossFunc
+    rank, local, world = mdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    mlhot.build_product()
+
+    model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(make_cfg(w, device)).to(device)
+    loss_fn = LossFunc("mse", "shapenet_1d")
+    cx, qx, cy, qy = synth.get_batch("shapenet_1d", T_LOCAL, NC, NQ, seed=1234 + rank, device=device)
+    bucket = mdist.GradBucket(model.parameters())
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        mu, var, kl = model(cx, cy, qx)
+        loss = loss_fn.calc_loss(mu, var, qy)
+        loss.backward()
+        bucket.sync()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+
+    # ---- roofline leg: per-launch HIP-event timing of every kernel over a few more steps ----------
+    roof, kernels = None, None
+    if args.prof_steps > 0:
+        L = mlhot.lib()
+        L.prof_begin(8192)
+        for _ in range(args.prof_steps):
+            step()
+        torch.cuda.synchronize()
+        recs = L.prof_end()
+        agg = {}
+        for label, ms in recs:
+            a = agg.setdefault(label, [0, 0.0])
+            a[0] += 1
+            a[1] += ms
+        n_img = T_LOCAL * (NC + NQ)
+        kernels = {k: {"launches_per_step": v[0] / args.prof_steps, "avg_us": 1e3 * v[1] / v[0],
+                       "us_per_step": 1e3 * v[1] / args.prof_steps} for k, v in agg.items()}
+        dom = max((k for k in agg if alg_flops(k, n_img)), key=lambda k: agg[k][1])
+        avg_s = agg[dom][1] / agg[dom][0] * 1e-3
+        ach = alg_flops(dom, n_img) / avg_s / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                "alg_flops_per_launch": alg_flops(dom, n_img)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        out = {"metric": "meta-tasks/sec (fwd+bwd), ANP ShapeNet1D 15+15-shot 16-task batch",
+               "value": world * T_LOCAL * args.steps / elapsed, "unit": "meta-tasks/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": w["name"], "tasks_per_gpu": T_LOCAL, "global_tasks": world * T_LOCAL,
+                          "context_shots": NC, "target_shots": NQ, "image": "128x128x1",
+                          "parallelism": f"task-sharded x{world}, one flat grad all-reduce" if world > 1 else "single GPU"},
+               "final_loss": final_loss, "roofline": roof}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w)
+        else:
+            out["cpu_baseline"] = None
+        if kernels:
+            top = sorted(kernels.items(), key=lambda kv: -kv[1]["us_per_step"])[:12]
+            out["kernel_us_per_step"] = {k: round(v["us_per_step"], 1) for k, v in top}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

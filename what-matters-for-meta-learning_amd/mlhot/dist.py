@@ -1,0 +1,59 @@
+"""Task-parallel training across the GPUs of one node.
+
+Tasks of a meta-batch are independent, so each rank (one process per GPU) owns a contiguous
+slice of the tasks and builds its model with the LOCAL tasks_per_batch.  The only exchange is
+one sum all-reduce of a single flat fp32 gradient bucket per step (RCCL over xGMI on the GPU
+box, gloo in the CPU tests); with equal shards mean_r(grad_r) equals the full-batch gradient
+because every loss is a mean over (task, target).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+    return rank, local, world
+
+
+def task_slice(n_tasks, rank, world):
+    """Contiguous, equal task shard of rank `rank`."""
+    if n_tasks % world:
+        raise ValueError(f"{n_tasks} tasks do not split evenly over {world} ranks")
+    per = n_tasks // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+class GradBucket:
+    """One flat fp32 bucket for every parameter that receives a gradient.
+
+    sync(): pack -> all_reduce(SUM) -> scale by 1/world -> unpack, i.e. exactly one collective
+    per step (1.96 MB for ANPShapeNet1D).  Parameters whose grad is None on this step (e.g. the
+    latent path with an empty context) must be None on every rank; they are skipped."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.flat = None
+
+    def sync(self):
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        live = [p for p in self.params if p.grad is not None]
+        if world == 1 or not live:
+            return
+        n = sum(p.grad.numel() for p in live)
+        if self.flat is None or self.flat.numel() != n or self.flat.device != live[0].grad.device:
+            self.flat = torch.empty(n, dtype=torch.float32, device=live[0].grad.device)
+        views = list(self.flat.split([p.grad.numel() for p in live]))
+        torch._foreach_copy_(views, [p.grad.reshape(-1) for p in live])
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.mul_(1.0 / world)
+        torch._foreach_copy_([p.grad.view(-1) for p in live], views)

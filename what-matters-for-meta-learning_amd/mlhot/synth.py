@@ -1,0 +1,25 @@
+"""Shape-faithful synthetic meta-batches (the datasets are git-LFS pointers in the reference).
+
+Layouts follow dataset/shapenet_1d.py:189-196 / pascal_1d.py get_batch: float32 tensors
+ctx_x [T,Nc,C,H,W], qry_x [T,Nq,C,H,W] in [0,1) (the reference divides uint8 by 255),
+labels [T,N,L]: shapenet_1d L=3 = [cos a, sin a, a] with a ~ U[0,2pi); pascal_1d L=1 ~ U[0,1)."""
+import math
+
+import torch
+
+
+def get_batch(task, tasks_per_batch, n_ctx, n_qry, seed=1234, device="cpu"):
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.rand(tasks_per_batch, n_ctx, 1, 128, 128, generator=g)
+    xq = torch.rand(tasks_per_batch, n_qry, 1, 128, 128, generator=g)
+    if task == "shapenet_1d":
+        a_s = torch.rand(tasks_per_batch, n_ctx, 1, generator=g) * 2 * math.pi
+        a_q = torch.rand(tasks_per_batch, n_qry, 1, generator=g) * 2 * math.pi
+        ys = torch.cat([torch.cos(a_s), torch.sin(a_s), a_s], dim=-1)
+        yq = torch.cat([torch.cos(a_q), torch.sin(a_q), a_q], dim=-1)
+    elif task == "pascal_1d":
+        ys = torch.rand(tasks_per_batch, n_ctx, 1, generator=g)
+        yq = torch.rand(tasks_per_batch, n_qry, 1, generator=g)
+    else:
+        raise ValueError(task)
+    return tuple(t.to(device) for t in (xs, xq, ys, yq))
