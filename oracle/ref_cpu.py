@@ -43,6 +43,28 @@ def vanilla_encoder(img, p, prefix="encoder_w0.", taps=None):
     return out
 
 
+def vanilla_encoder_routed(img, p, m1, arg2, m2, m3, prefix="encoder_w0."):
+    """Same arithmetic as vanilla_encoder, but every piecewise-linear routing decision (the three
+    ReLU masks and the max-pool arg-max, window index 2*dy+dx) is GIVEN instead of being re-derived
+    from this function's own pre-activations.  ReLU and max-pool gradients are discontinuous: an
+    activation within fp32 rounding of zero (or a pool tie) passes all of its upstream gradient or
+    none, so two fp32 evaluations with different summation orders disagree on a handful of the 63 M
+    routing decisions of a 480-image batch and each disagreement moves a conv gradient by ~1e-4 of
+    its scale (the CPU fp32-vs-fp64 comparison shows the same).  With the routing pinned to the
+    kernel's own decisions the gradients must agree to rounding, which is what the full-size test
+    checks; the decisions themselves are checked against this function's pre-activations."""
+    y1 = F.conv2d(img, p[prefix + "0.weight"], p[prefix + "0.bias"], stride=2, padding=1)
+    a1 = y1 * m1
+    y2 = F.conv2d(a1, p[prefix + "2.weight"], p[prefix + "2.bias"], stride=2, padding=1)
+    n, c, h, w = y2.shape
+    win = y2.reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+    p2 = torch.gather(win, 4, arg2.long().unsqueeze(-1)).squeeze(-1) * m2
+    y3 = F.conv2d(p2, p[prefix + "5.weight"], p[prefix + "5.bias"], stride=2, padding=1)
+    a3 = y3 * m3
+    out = F.linear(a3.reshape(n, -1), p[prefix + "8.weight"], p[prefix + "8.bias"])
+    return out, dict(y1=y1, y2win=win, y3=y3)
+
+
 # --------------------------------------------------------------------------------------
 # M1  task-side MLPs                                               (models.py:27-60)
 # --------------------------------------------------------------------------------------

@@ -123,8 +123,47 @@ def test_encoder_fwd_bwd_vs_oracle(gpulib, n0, n1):
         assert U.rel_err(got, ref.grad) <= U.RTOL, k
 
 
+def test_encoder_full_size_gradients_with_pinned_routing(gpulib):
+    """480 images (the c2/c3 batch).  ReLU / max-pool routing is discontinuous, so gradients are
+    compared with the oracle evaluated under the KERNEL's routing decisions (see
+    oracle.ref_cpu.vanilla_encoder_routed); the decisions themselves must match the oracle's except
+    where the oracle's own pre-activation is a rounding-level tie."""
+    n = 480
+    p = _enc_params(3)
+    g = torch.Generator().manual_seed(480)
+    x = torch.rand(n, 1, 128, 128, generator=g)
+    df = torch.randn(n, 64, generator=g)
+    plist = [t.to(DEV) for t in p.values()]
+    xd = x.to(DEV)
+    f0, _, saved = gpulib.enc_vanilla_fwd(xd, None, plist, 64)
+    grads = gpulib.enc_vanilla_bwd(xd, None, plist, 64, df.to(DEV), torch.empty(0, 64, device=DEV), saved)
+    a1, p2, am2, a3 = (t.cpu() for t in gpulib.enc_saved_views(saved, n))
+    pr = {k: v.clone().requires_grad_() for k, v in p.items()}
+    fr, pre = O.vanilla_encoder_routed(x, pr, (a1 > 0).float(), am2, (p2 > 0).float(), (a3 > 0).float())
+    assert U.rel_err(f0, fr) <= 1e-5
+    # routing decisions: any disagreement must sit on a rounding-level tie of the oracle's values
+    tie = 1e-5
+    bad1 = ((a1 > 0) != (pre["y1"] > 0)) & (pre["y1"].abs() > tie * pre["y1"].abs().max())
+    bad3 = ((a3 > 0) != (pre["y3"] > 0)) & (pre["y3"].abs() > tie * pre["y3"].abs().max())
+    win = pre["y2win"].detach()
+    chosen = torch.gather(win, 4, am2.long().unsqueeze(-1)).squeeze(-1)
+    bad2 = (win.max(dim=4).values - chosen) > tie * win.abs().max()
+    assert int(bad1.sum()) == 0 and int(bad2.sum()) == 0 and int(bad3.sum()) == 0
+    fr.backward(df)
+    for (k, ref), got in zip(pr.items(), grads):
+        assert U.rel_err(got, ref.grad) <= 2e-5, k
+
+
 # ---- whole model through the plugin boundary vs the reference's golden vectors -------------------
-def _run_case(name):
+# Full-size batches (16 tasks x 30 images = 63 M ReLU / pool routing decisions): a handful of
+# rounding-level ties route differently than in the reference's CPU run, each moving a conv
+# gradient by ~1e-4 of its scale (measured: CPU fp32 vs CPU fp64 differ by 4e-4 from ONE flip at
+# n=256).  Outputs and loss are held to 1e-4; at these two sizes the gradient check is 1e-3 and the
+# rounding-exact statement is test_encoder_full_size_gradients_with_pinned_routing above.
+FULL_SIZE_GRAD_TOL = 1e-3
+
+
+def _run_case(name, grad_tol=U.RTOL):
     fx, meta = U.load_case(name)
     model = U.build_model(meta, DEV, fx=fx).to(DEV)
     cx, qx, cy, qy = (t.to(DEV) for t in U.case_inputs(meta))
@@ -137,7 +176,7 @@ def _run_case(name):
     assert U.rel_err(mu, fx["mu"]) <= U.RTOL
     assert abs(loss.item() - float(fx["loss"])) <= U.RTOL * max(1.0, abs(float(fx["loss"])))
     grads = {k: p.grad for k, p in model.named_parameters()}
-    U.check_grads_against_fixture(grads, fx, meta)
+    U.check_grads_against_fixture(grads, fx, meta, tol=grad_tol)
     with torch.no_grad():
         model.eval()
         mu_t, _, _ = model(cx, cy, qx, test=True)
@@ -153,7 +192,7 @@ def test_model_edge_cases_vs_reference(gpulib, name):
 @pytest.mark.parametrize("name", U.model_case_names("c"))
 def test_model_baseline_configs_vs_reference(gpulib, name):
     """BASELINE.json configs[0..2] at their full sizes (T=4 5+5; T=16 15+15 CNP / ANP)."""
-    _run_case(name)
+    _run_case(name, grad_tol=U.RTOL if name.startswith("c1") else FULL_SIZE_GRAD_TOL)
 
 
 def test_forward_is_deterministic_and_task_independent(gpulib):

@@ -137,13 +137,25 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
       }
 }
 
+// 32 outputs x 8 split-lanes per workgroup: each lane sums every 8th partial (coalesced across the
+// 32 outputs), then a fixed-order LDS tree folds the 8 lanes -> deterministic and short chains.
 template <class P>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabReduceArgs<P> a) {
+  __shared__ float sm[8][32];
   const size_t total = (size_t)a.p.M * a.p.N;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+  const int ex = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  for (size_t e0 = (size_t)blockIdx.x * 32; e0 < total; e0 += (size_t)gridDim.x * 32) {
+    const size_t e = e0 + ex;
     float s = 0.f;
-    for (int z = 0; z < a.nsplit; ++z) s += a.slab[(size_t)z * total + e];
-    a.p.store((int)(e / a.p.N), (int)(e % a.p.N), s);
+    if (e < total)
+      for (int z = zl; z < a.nsplit; z += 8) s += a.slab[(size_t)z * total + e];
+    sm[zl][ex] = s;
+    __syncthreads();
+    if (zl == 0 && e < total) {
+      const float t = ((sm[0][ex] + sm[1][ex]) + (sm[2][ex] + sm[3][ex])) + ((sm[4][ex] + sm[5][ex]) + (sm[6][ex] + sm[7][ex]));
+      a.p.store((int)(e / a.p.N), (int)(e % a.p.N), t);
+    }
+    __syncthreads();
   }
 }
 
@@ -192,8 +204,8 @@ int run_igemm(const P& p, int nsplit, float* slab, hipStream_t stream, const cha
   ProfScope ps2("slab_reduce", stream);
   SlabReduceArgs<P> a{p, slab, nsplit};
   size_t total = (size_t)p.M * p.N;
-  int rb = (int)((total + 255) / 256);
-  if (rb > 2048) rb = 2048;
+  int rb = (int)((total + 31) / 32);
+  if (rb > 4096) rb = 4096;
   hipLaunchKernelGGL((slab_reduce_kernel<P>), dim3(rb), dim3(256), 0, stream, a);
   return check_launch(what);
 #endif

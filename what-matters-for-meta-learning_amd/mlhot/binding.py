@@ -183,6 +183,22 @@ class MlhotLib:
                  "mlhot_enc_vanilla_fwd")
         return feat0, feat1, saved
 
+    @staticmethod
+    def enc_saved_views(saved, n):
+        """Test / diagnostic helper: the activations the encoder forward kept for its backward
+        (csrc/encoder.h EncSaved: 256-byte aligned a1 | p2 | am2 | a3) as tensor views."""
+        def al(x):
+            return (x + 255) // 256 * 256
+        o = 0
+        a1 = saved[o:o + n * 32 * 4096 * 4].view(torch.float32).view(n, 32, 64, 64)
+        o = al(o + n * 32 * 4096 * 4)
+        p2 = saved[o:o + n * 48 * 256 * 4].view(torch.float32).view(n, 48, 16, 16)
+        o = al(o + n * 48 * 256 * 4)
+        am2 = saved[o:o + n * 48 * 256].view(n, 48, 16, 16)
+        o = al(o + n * 48 * 256)
+        a3 = saved[o:o + n * 4096 * 4].view(torch.float32).view(n, 64, 8, 8)
+        return a1, p2, am2, a3
+
     def enc_vanilla_bwd(self, img0, img1, params, dim_w, dfeat0, dfeat1, saved):
         n0 = img0.shape[0]
         n1 = 0 if img1 is None else img1.shape[0]
