@@ -34,6 +34,10 @@ enum { MLHOT_LOSS_AZIMUTH = 0, MLHOT_LOSS_MSE = 1, MLHOT_LOSS_QUATERNION = 2, ML
 int mlhot_version(void);
 const char* mlhot_last_error(void);
 
+/* Implementation switches for A/B tests: "conv2_tc" = 1 (default) runs the weight-stationary
+ * conv2 kernels (csrc/conv_tc.h), 0 the generic implicit-GEMM problems.                        */
+int mlhot_set_option(const char* name, int value);
+
 /* ---- bench-only: per-launch HIP-event timing ------------------------------------------------
  * Between begin and end every kernel launch of the library is bracketed by two events recorded
  * on its launch stream.  end() synchronises them and returns (label, milliseconds) records.

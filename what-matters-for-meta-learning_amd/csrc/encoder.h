@@ -13,9 +13,16 @@
 #include "ops_direct.h"
 #include "problems.h"
 #include "favor.h"   // MLHOT_TRY
+#include "conv_tc.h"
 #include "../../include/mlhot.h"
 
 namespace mlhot {
+
+// Run-time switches (mlhot_set_option): which implementation of a hot-path row runs.  The
+// generic igemm problems are always available as the A/B reference of the specialised kernels.
+struct Options { int conv2_tc; };
+extern Options g_opt;
+constexpr int C2_GRID = 256;   // one persistent workgroup per CU
 
 struct EncSaved {
   float* a1; float* p2; uint8_t* am2; float* a3; bool ok; size_t bytes;
@@ -54,6 +61,7 @@ inline size_t enc_slab_floats(int n, int dim_w) {
   v = (size_t)conv3w_split(n) * 64 * 433;       if (v > m) m = v;
   v = (size_t)conv2w_split(n) * 48 * 289;       if (v > m) m = v;
   v = (size_t)conv1w_split(n) * 32 * 10;        if (v > m) m = v;
+  v = (size_t)2 * C2_GRID * 48 * 288 + (size_t)C2_GRID * 48; if (v > m) m = v;   // conv_tc wgrad partials
   return m;
 }
 inline EncScratch enc_scratch_carve(int n, int dim_w, void* base, size_t cap) {
@@ -83,10 +91,22 @@ inline int enc_forward(const float* img0, int n0, const float* img1, int n1, con
   if (!sc.ok) { set_error("enc_vanilla_fwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
   const Src2 x{img0, n0, img1, (size_t)128 * 128};
   MLHOT_TRY(run_foreach(Conv1Fwd<Src2>{x, p.w1, p.b1, sv.a1}, (size_t)n * 4096, s, "enc.conv1"));
-  typedef ConvFwd<32, 64, 64, 48, Src1> C2;
-  C2 c2{n * 1024, 48, 288, Src1{sv.a1, (size_t)32 * 4096}, p.w2, p.b2, sc.a2};
-  MLHOT_TRY((run_igemm<C2, 128, 48, 16, 4, 1>(c2, 1, nullptr, s, "enc.conv2")));
-  MLHOT_TRY(run_foreach(Pool2Fwd{sc.a2, sv.p2, sv.am2, 32, 32}, (size_t)n * 48 * 256, s, "enc.pool"));
+#ifndef MLHOT_HOSTSIM
+  if (g_opt.conv2_tc) {
+    const int grid = n * 8 < C2_GRID ? n * 8 : C2_GRID;
+    {
+      ProfScope ps("enc.conv2", s);
+      hipLaunchKernelGGL(c2::conv2_fwd_pool_kernel, dim3(grid), dim3(c2::NT), 0, s, sv.a1, p.w2, p.b2, sv.p2, sv.am2, n);
+    }
+    MLHOT_TRY(check_launch("enc.conv2"));
+  } else
+#endif
+  {
+    typedef ConvFwd<32, 64, 64, 48, Src1> C2;
+    C2 c2{n * 1024, 48, 288, Src1{sv.a1, (size_t)32 * 4096}, p.w2, p.b2, sc.a2};
+    MLHOT_TRY((run_igemm<C2, 128, 48, 16, 4, 1>(c2, 1, nullptr, s, "enc.conv2")));
+    MLHOT_TRY(run_foreach(Pool2Fwd{sc.a2, sv.p2, sv.am2, 32, 32}, (size_t)n * 48 * 256, s, "enc.pool"));
+  }
   typedef ConvFwd<48, 16, 16, 64, Src1> C3;
   C3 c3{n * 64, 64, 432, Src1{sv.p2, (size_t)48 * 256}, p.w3, p.b3, sv.a3};
   MLHOT_TRY((run_igemm<C3, 64, 64, 16, 2, 2>(c3, 1, nullptr, s, "enc.conv3")));
@@ -136,13 +156,38 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
 
   // conv2 (pool + ReLU backward are folded into the dY gather)
   const DyPooled<48, 32, 32> dy2{sc.dp2, sv.p2, sv.am2};
-  typedef ConvWgrad<32, 64, 64, 48, DyPooled<48, 32, 32>, Src1> W2;
-  W2 w2{48, 289, n * 1024, dy2, Src1{sv.a1, (size_t)32 * 4096}, g.w2, g.b2};
-  MLHOT_TRY((run_igemm<W2, 48, 64, 16, 1, 4>(w2, conv2w_split(n), sc.slab, s, "enc.bwd.conv2.wgrad")));
-  MLHOT_TRY((enc_conv2_dgrad<0, 0>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
-  MLHOT_TRY((enc_conv2_dgrad<0, 1>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
-  MLHOT_TRY((enc_conv2_dgrad<1, 0>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
-  MLHOT_TRY((enc_conv2_dgrad<1, 1>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
+#ifndef MLHOT_HOSTSIM
+  if (g_opt.conv2_tc) {
+    const int grid = n * 8 < C2_GRID ? n * 8 : C2_GRID;
+    float* slab_w = sc.slab;
+    float* slab_b = sc.slab + (size_t)2 * C2_GRID * 48 * 288;
+    {
+      ProfScope ps("enc.bwd.conv2.wgrad", s);
+      hipLaunchKernelGGL(c2::conv2_wgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, sv.a1, sc.dp2, sv.p2, sv.am2, slab_w, slab_b, n);
+    }
+    MLHOT_TRY(check_launch("enc.bwd.conv2.wgrad"));
+    {
+      ProfScope ps("slab_reduce", s);
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(432), dim3(256), 0, s, slab_w, 2 * grid, 48 * 288, g.w2);
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(2), dim3(256), 0, s, slab_b, grid, 48, g.b2);
+    }
+    MLHOT_TRY(check_launch("enc.bwd.conv2.wgrad.reduce"));
+    {
+      ProfScope ps("enc.bwd.conv2.dgrad", s);
+      hipLaunchKernelGGL(c2::conv2_dgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, sc.dp2, sv.p2, sv.am2, p.w2, sv.a1, sc.dy1, n);
+    }
+    MLHOT_TRY(check_launch("enc.bwd.conv2.dgrad"));
+  } else
+#endif
+  {
+    typedef ConvWgrad<32, 64, 64, 48, DyPooled<48, 32, 32>, Src1> W2;
+    W2 w2{48, 289, n * 1024, dy2, Src1{sv.a1, (size_t)32 * 4096}, g.w2, g.b2};
+    MLHOT_TRY((run_igemm<W2, 48, 64, 16, 1, 4>(w2, conv2w_split(n), sc.slab, s, "enc.bwd.conv2.wgrad")));
+    MLHOT_TRY((enc_conv2_dgrad<0, 0>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
+    MLHOT_TRY((enc_conv2_dgrad<0, 1>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
+    MLHOT_TRY((enc_conv2_dgrad<1, 0>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
+    MLHOT_TRY((enc_conv2_dgrad<1, 1>(n, dy2, p.w2, sv.a1, sc.dy1, s)));
+  }
 
   // conv1 (no input gradient: images are leaves)
   typedef ConvWgrad<1, 128, 128, 32, DyPlain<32, 64, 64>, Src2> W1;

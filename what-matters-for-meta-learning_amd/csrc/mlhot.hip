@@ -21,6 +21,8 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+Options g_opt = {1};
+
 #ifndef MLHOT_HOSTSIM
 // ---- per-launch event profiler -------------------------------------------------------------------
 bool g_prof_on = false;
@@ -47,6 +49,13 @@ extern "C" {
 
 int mlhot_version(void) { return MLHOT_ABI_VERSION; }
 const char* mlhot_last_error(void) { return g_err; }
+
+// ---- run-time options -------------------------------------------------------------------------
+int mlhot_set_option(const char* name, int value) {
+  if (!strcmp(name, "conv2_tc")) { g_opt.conv2_tc = value; return MLHOT_OK; }
+  set_error("mlhot_set_option: unknown option %s", name);
+  return MLHOT_ERR_ARG;
+}
 
 // ---- profiler (bench only) ----------------------------------------------------------------------
 int mlhot_prof_begin(int max_records) {

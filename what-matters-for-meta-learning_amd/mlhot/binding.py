@@ -143,6 +143,10 @@ class MlhotLib:
     def _bytes(n, like):
         return torch.empty(max(int(n), 256), dtype=torch.uint8, device=like.device)
 
+    def set_option(self, name, value):
+        self.c.mlhot_set_option.argtypes = [C.c_char_p, C.c_int]
+        self._rc(self.c.mlhot_set_option(name.encode(), int(value)), "mlhot_set_option")
+
     # ---- bench-only launch profiler -----------------------------------------------------------
     def prof_begin(self, max_records=4096):
         self._prof_cap = max_records
