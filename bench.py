@@ -159,8 +159,14 @@ def main():
         dom = max((k for k in agg if alg_flops(k, n_img)), key=lambda k: agg[k][1])
         avg_s = agg[dom][1] / agg[dom][0] * 1e-3
         ach = alg_flops(dom, n_img) / avg_s / 1e12
+        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get(dom, {}).get("hbm_bytes")
+        except OSError:
+            pass
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_us": avg_s * 1e6,
                 "alg_flops_per_launch": alg_flops(dom, n_img)}
     if world > 1:
         dist.barrier()
