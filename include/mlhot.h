@@ -35,7 +35,8 @@ int mlhot_version(void);
 const char* mlhot_last_error(void);
 
 /* Implementation switches for A/B tests: "conv2_tc" = 1 (default) runs the weight-stationary
- * conv2 kernels (csrc/conv_tc.h), 0 the generic implicit-GEMM problems.                        */
+ * conv2 kernels (csrc/conv_tc.h), 0 the generic implicit-GEMM problems; "tail_fused" = 1
+ * (default) runs the fused per-task tail kernels (csrc/tail_fused.h) where they apply.          */
 int mlhot_set_option(const char* name, int value);
 
 /* ---- bench-only: per-launch HIP-event timing ------------------------------------------------

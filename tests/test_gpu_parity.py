@@ -193,13 +193,21 @@ def _run_case(name, grad_tol=U.RTOL):
     assert abs(lt.item() - float(fx["loss_test"])) <= 1e-3 * max(1.0, abs(float(fx["loss_test"])))
 
 
+@pytest.fixture(params=[1, 0], ids=["tail_fused", "tail_generic"])
+def tail_impl(gpulib, request):
+    """Fused per-task tail kernels (csrc/tail_fused.h; ANP with <= 16 shots) vs the generic chain."""
+    gpulib.set_option("tail_fused", request.param)
+    yield request.param
+    gpulib.set_option("tail_fused", 1)
+
+
 @pytest.mark.parametrize("name", U.model_case_names("s_"))
-def test_model_edge_cases_vs_reference(gpulib, name):
+def test_model_edge_cases_vs_reference(gpulib, tail_impl, name):
     _run_case(name)
 
 
 @pytest.mark.parametrize("name", U.model_case_names("c"))
-def test_model_baseline_configs_vs_reference(gpulib, name):
+def test_model_baseline_configs_vs_reference(gpulib, tail_impl, name):
     """BASELINE.json configs[0..2] at their full sizes (T=4 5+5; T=16 15+15 CNP / ANP)."""
     _run_case(name, grad_tol=U.RTOL if name.startswith("c1") else FULL_SIZE_GRAD_TOL)
 

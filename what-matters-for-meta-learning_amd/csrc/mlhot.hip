@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-Options g_opt = {1};
+Options g_opt = {1, 1};
 
 #ifndef MLHOT_HOSTSIM
 // ---- per-launch event profiler -------------------------------------------------------------------
@@ -53,6 +53,7 @@ const char* mlhot_last_error(void) { return g_err; }
 // ---- run-time options -------------------------------------------------------------------------
 int mlhot_set_option(const char* name, int value) {
   if (!strcmp(name, "conv2_tc")) { g_opt.conv2_tc = value; return MLHOT_OK; }
+  if (!strcmp(name, "tail_fused")) { g_opt.tail_fused = value; return MLHOT_OK; }
   set_error("mlhot_set_option: unknown option %s", name);
   return MLHOT_ERR_ARG;
 }

@@ -11,6 +11,7 @@
 //   mu = decoder0(dec_in)
 #pragma once
 #include "encoder.h"
+#include "tail_fused.h"
 
 namespace mlhot {
 
@@ -121,6 +122,55 @@ inline int lin_wgrad(const float* dy, int lddy, const float* y, int ldy, int act
   return run_igemm<LinearWgrad, 64, 64, 16, 2, 2>(p, 1, nullptr, s, what);
 }
 
+#ifndef MLHOT_HOSTSIM
+// ---- fused tail (csrc/tail_fused.h) ---------------------------------------------------------------
+inline bool tail_fused_applies(const mlhot_np_dims& d) {
+  return g_opt.tail_fused && d.agg_mode == MLHOT_AGG_ATTENTION && d.Nc >= 1 && d.Nc <= 16 && d.Nq <= 16 &&
+         d.n_hidden == 2 && d.dim_w % 16 == 0 && d.dim_r == d.dim_w;
+}
+inline tf::TailDims tail_dims(const mlhot_np_dims& d) {
+  return tf::TailDims{d.T, d.Nc, d.Nq, d.label_dim, d.y_dim, d.dim_w, d.dim_z, d.hidden[0], d.hidden[1], d.dec_hidden,
+                      d.out_tanh ? ACT_TANH : ACT_NONE, d.m_feat};
+}
+inline tf::TailParams tail_params(const mlhot_np_params& p) {
+  tf::TailParams q;
+  q.ty_w = p.ty_w; q.ty_b = p.ty_b;
+  for (int i = 0; i < 3; ++i) { q.er_w[i] = p.er_w[i]; q.er_b[i] = p.er_b[i]; q.dec_w[i] = p.dec_w[i]; q.dec_b[i] = p.dec_b[i]; }
+  q.r2z_w = p.r2z_w; q.r2z_b = p.r2z_b;
+  for (int i = 0; i < MLHOT_HEADS; ++i) {
+    q.wk_w[i] = p.wk_w[i]; q.wk_b[i] = p.wk_b[i]; q.wv_w[i] = p.wv_w[i]; q.wv_b[i] = p.wv_b[i];
+    q.wq_w[i] = p.wq_w[i]; q.wq_b[i] = p.wq_b[i];
+  }
+  q.wo_w = p.wo_w; q.wo_b = p.wo_b; q.proj = p.proj;
+  return q;
+}
+template <class K, class A>
+inline int tail_launch(K kernel, int grid, int block, size_t lds, const A& args, hipStream_t s, const char* what) {
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    ProfScope ps(what, s);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, args);
+  }
+  return check_launch(what);
+}
+
+inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, float* mu,
+                              const NpBuf& b, hipStream_t s) {
+  const tf::TailDims td = tail_dims(d);
+  const tf::TailParams tp = tail_params(p);
+  FavorDims f{d.T, MLHOT_HEADS, d.Nq, d.Nc, d.dim_w, d.m_feat};
+  FavorWs w = favor_carve(f, b.favor, b.favor_bytes);
+  if (!w.ok) { set_error("tail_fused: favor workspace"); return MLHOT_ERR_WORKSPACE; }
+  tf::PhaseAArgs a{td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, b.vh, b.qh, w.pc, w.max_k, w.arg_k};
+  MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
+  tf::PhaseBArgs bb{td, b.qh, b.kh, b.vh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged};
+  MLHOT_TRY(tail_launch(tf::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 256, tf::phaseB_lds_bytes(td), bb, s, "tail.B"));
+  tf::PhaseCArgs c{td, tp, b.merged, b.rr, b.dec_in, b.d1, b.d2, mu};
+  MLHOT_TRY(tail_launch(tf::phaseC_fwd_kernel, d.T, 512, tf::phaseC_lds_bytes(td), c, s, "tail.C"));
+  return MLHOT_OK;
+}
+#endif
+
 inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_x, const float* ctx_y,
                       const float* qry_x, float* mu, void* saved, void* scratch, size_t scratch_bytes, hipStream_t s) {
   MLHOT_TRY(np_check_dims(d));
@@ -132,6 +182,9 @@ inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const fl
 
   // E1 on [context | target] images in one pass; rows land in cat_in / dec_in
   MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s));
+#ifndef MLHOT_HOSTSIM
+  if (tail_fused_applies(d)) return tail_forward_fused(d, p, ctx_y, mu, b, s);
+#endif
 
   if (d.Nc > 0) {
     MLHOT_TRY(lin_fwd(ctx_y, d.label_dim, wb1(p.ty_w, p.ty_b, dw / 4), b.cat_in + dw, ldc, Rc, d.label_dim, dw / 4, ACT_NONE, s, "np.transform_y"));
