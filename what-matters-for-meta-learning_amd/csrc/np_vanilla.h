@@ -56,6 +56,7 @@ struct NpScratch {
   void* enc; size_t enc_bytes;
   float *d_dec_in, *dd1, *dd2, *d_cat_in, *dh[MLHOT_MAX_HIDDEN], *d_rs;
   float *d_rr, *d_merged, *dqh, *dkh, *dvh, *dzt, *dr, *d_mu_l, *d_lv;
+  float* tail_slab;   // fused tail: per-task weight-gradient partials
   bool ok; size_t bytes;
 };
 
@@ -75,6 +76,12 @@ inline NpScratch np_scratch_carve(const mlhot_np_dims& d, void* base, size_t cap
     if (d.agg_mode == MLHOT_AGG_ATTENTION) {
       s.d_rr = a.take<float>(Rq * dw); s.d_merged = a.take<float>(Rq * H * dw);
       s.dqh = a.take<float>(Rq * H * dw); s.dkh = a.take<float>(Rc * H * dw); s.dvh = a.take<float>(Rc * H * dw);
+#ifndef MLHOT_HOSTSIM
+      if (d.n_hidden == 2) {
+        const tf::TailDims td{d.T, d.Nc, d.Nq, d.label_dim, d.y_dim, dw, d.dim_z, d.hidden[0], d.hidden[1], d.dec_hidden, 0, d.m_feat};
+        s.tail_slab = a.take<float>((size_t)d.T * tf::tail_slab_layout(td).total);
+      }
+#endif
     } else {
       s.dzt = a.take<float>((size_t)d.T * d.dim_z); s.dr = a.take<float>((size_t)d.T * d.dim_r);
       if (d.agg_mode == MLHOT_AGG_BACO) { s.d_mu_l = a.take<float>(Rc * d.dim_r); s.d_lv = a.take<float>(Rc * d.dim_r); }
@@ -169,6 +176,49 @@ inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   MLHOT_TRY(tail_launch(tf::phaseC_fwd_kernel, d.T, 512, tf::phaseC_lds_bytes(td), c, s, "tail.C"));
   return MLHOT_OK;
 }
+
+inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu,
+                               const float* dmu, const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s) {
+  const tf::TailDims td = tail_dims(d);
+  const tf::TailParams tp = tail_params(p);
+  const tf::TailSlab sl = tf::tail_slab_layout(td);
+  FavorDims f{d.T, MLHOT_HEADS, d.Nq, d.Nc, d.dim_w, d.m_feat};
+  FavorWs w = favor_carve(f, b.favor, b.favor_bytes);
+  if (!w.ok || !sc.tail_slab) { set_error("tail_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
+  float* part_k = w.rsum_k;   // [T*H]
+  tf::PhaseCBwdArgs c{td, tp, sl, dmu, mu, b.d2, b.d1, b.dec_in, b.rr, b.merged, sc.d_dec_in, sc.d_merged, sc.tail_slab};
+  MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
+  tf::PhaseBBwdArgs bb{td, b.qh, b.kh, b.vh, w.pc, w.qf, w.kf, w.S, w.D, b.merged, sc.d_merged, w.arg_q, sc.dqh, sc.dkh, sc.dvh, part_k};
+  MLHOT_TRY(tail_launch(tf::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 256, tf::phaseB_bwd_lds_bytes(td), bb, s, "tail.bwd.B"));
+  tf::PhaseABwdArgs a{td, tp, sl, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, sc.dqh, sc.dkh, sc.dvh, w.pc, part_k, w.gpos,
+                      sc.d_dec_in, sc.d_cat_in, sc.tail_slab};
+  MLHOT_TRY(tail_launch(tf::phaseA_bwd_kernel, d.T, 512, tf::phaseA_bwd_lds_bytes(td), a, s, "tail.bwd.A"));
+  // per-task slabs -> parameter gradients
+  tf::SlabReduce r{};
+  int ns = 0, maxlen = 0;
+  auto seg = [&](float* dst, int off, int len) { r.dst[ns] = dst; r.off[ns] = off; r.len[ns] = len; if (len > maxlen) maxlen = len; ++ns; };
+  const int dw = d.dim_w, ldc = dw + dw / 4, ldd = dw + d.dim_z;
+  seg(g.ty_w, sl.ty_w, dw / 4 * d.label_dim); seg(g.ty_b, sl.ty_b, dw / 4);
+  seg(g.er_w[0], sl.er_w[0], td.h0 * ldc); seg(g.er_b[0], sl.er_b[0], td.h0);
+  seg(g.er_w[1], sl.er_w[1], td.h1 * td.h0); seg(g.er_b[1], sl.er_b[1], td.h1);
+  seg(g.er_w[2], sl.er_w[2], dw * td.h1); seg(g.er_b[2], sl.er_b[2], dw);
+  seg(g.r2z_w, sl.r2z_w, d.dim_z * dw); seg(g.r2z_b, sl.r2z_b, d.dim_z);
+  seg(g.dec_w[0], sl.dec_w[0], td.dec_h * ldd); seg(g.dec_b[0], sl.dec_b[0], td.dec_h);
+  seg(g.dec_w[1], sl.dec_w[1], td.dec_h * td.dec_h); seg(g.dec_b[1], sl.dec_b[1], td.dec_h);
+  seg(g.dec_w[2], sl.dec_w[2], d.y_dim * td.dec_h); seg(g.dec_b[2], sl.dec_b[2], d.y_dim);
+  for (int i = 0; i < MLHOT_HEADS; ++i) {
+    seg(g.wk_w[i], sl.wk_w + i * dw * dw, dw * dw); seg(g.wk_b[i], sl.wk_b + i * dw, dw);
+    seg(g.wv_w[i], sl.wv_w + i * dw * dw, dw * dw); seg(g.wv_b[i], sl.wv_b + i * dw, dw);
+    seg(g.wq_w[i], sl.wq_w + i * dw * dw, dw * dw); seg(g.wq_b[i], sl.wq_b + i * dw, dw);
+  }
+  seg(g.wo_w, sl.wo_w, dw * MLHOT_HEADS * dw); seg(g.wo_b, sl.wo_b, dw);
+  r.nseg = ns; r.T = d.T; r.total = sl.total; r.slab = sc.tail_slab;
+  {
+    ProfScope ps("tail.bwd.reduce", s);
+    hipLaunchKernelGGL(tf::slab_to_grads_kernel, dim3((maxlen + 255) / 256, ns), dim3(256), 0, s, r);
+  }
+  return check_launch("tail.bwd.reduce");
+}
 #endif
 
 inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_x, const float* ctx_y,
@@ -235,6 +285,12 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
   const int ldc = dw + dw / 4, ldd = dw + d.dim_z;
   const int out_act = d.out_tanh ? ACT_TANH : ACT_NONE;
 
+#ifndef MLHOT_HOSTSIM
+  if (tail_fused_applies(d)) {
+    MLHOT_TRY(tail_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s));
+    return enc_backward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{sc.d_cat_in, ldc, Rc, sc.d_dec_in, ldd}, b.enc, g.enc, sc.enc, sc.enc_bytes, s);
+  }
+#endif
   // decoder0
   MLHOT_TRY(lin_wgrad(dmu, d.y_dim, mu, d.y_dim, out_act, b.d2, dh, gb1(g.dec_w[2], g.dec_b[2], d.y_dim), Rq, dh, d.y_dim, s, "np.bwd.dec4.w"));
   MLHOT_TRY(lin_dgrad(dmu, d.y_dim, mu, d.y_dim, out_act, wb1(p.dec_w[2], nullptr, d.y_dim), sc.dd2, dh, 0, Rq, dh, d.y_dim, s, "np.bwd.dec4.x"));

@@ -441,6 +441,469 @@ __host__ inline size_t phaseC_lds_bytes(const TailDims& d) {
   return sizeof(float) * 16 * (ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.dw + d.dz) + 2 * ldpad(d.dec_h));
 }
 
+// ==================================================================================================
+// backward building blocks (16-row tiles in LDS, zero-padded to a multiple of 16 columns)
+// ==================================================================================================
+
+// dW[Nout][Kin] = dY^T X (sum over the 16 rows; padded rows of dY are zero), db = column sums of dY.
+// Output tiles (16 j x 16 i) round-robin over the waves, 4 MFMAs each; results go to the task's slab.
+template <int NW>
+__device__ __forceinline__ void wg_wgrad(const float* dys, int ldy, int Nout, const float* xs, int ldx, int Kin,
+                                         float* dw, float* db, int wave, int lane, int tid) {
+  const int lr = lane & 15, lq = lane >> 4;
+  const int nj = (Nout + 15) / 16, ni = (Kin + 15) / 16;
+  for (int it = wave; it < nj * ni; it += NW) {
+    const int j0 = (it / ni) * 16, i0 = (it % ni) * 16;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int row = 4 * s4 + lq;
+      acc = mfma4(dys[row * ldy + j0 + lr], xs[row * ldx + i0 + lr], acc);
+    }
+    const int i = i0 + lr;
+    if (i < Kin) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + 4 * lq + r;
+        if (j < Nout) dw[(size_t)j * Kin + i] = acc[r];
+      }
+    }
+  }
+  if (db) {
+    for (int j = tid; j < Nout; j += NW * 64) {
+      float sum = 0.f;
+#pragma unroll
+      for (int row = 0; row < 16; ++row) sum += dys[row * ldy + j];
+      db[j] = sum;
+    }
+  }
+}
+
+// dX[16][Kin] = dY[16][Nout] W[Nout][Kin]  (W as row blocks of `rows` rows).  N-tiles over i round-robin
+// over the waves; per 16-wide j block: A = one float4 of dY from LDS, B = 4 coalesced dwords of W.
+// Result to LDS (dxs) and/or global (dxg: rows < nrows; accumulate adds to what is there).
+template <int NW>
+__device__ __forceinline__ void wg_dgrad(const float* dys, int ldy, int Nout, const WB& wb, int Kin,
+                                         float* dxs, int ldxs, float* dxg, int ldg, int nrows, bool accumulate,
+                                         int wave, int lane) {
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int it = wave; it * 16 < Kin; it += NW) {
+    const int i = it * 16 + lr;
+    const bool vi = i < Kin;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int j0 = 0; j0 < Nout; j0 += 16) {
+      const int blk = j0 / wb.rows;
+      const float* wsel = wb.w[0];
+#pragma unroll
+      for (int q = 1; q < H; ++q)
+        if (blk == q) wsel = wb.w[q];
+      const int jb = j0 + 4 * lq - blk * wb.rows;          // row inside the block
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      if (vi) {
+        const int j = j0 + 4 * lq;
+        if (j < Nout) b0 = wsel[(size_t)jb * Kin + i];
+        if (j + 1 < Nout) b1 = wsel[(size_t)(jb + 1) * Kin + i];
+        if (j + 2 < Nout) b2 = wsel[(size_t)(jb + 2) * Kin + i];
+        if (j + 3 < Nout) b3 = wsel[(size_t)(jb + 3) * Kin + i];
+      }
+      const float* ap = dys + lr * ldy + j0 + 4 * lq;
+      acc = mfma4(ap[0], b0, acc);
+      acc = mfma4(ap[1], b1, acc);
+      acc = mfma4(ap[2], b2, acc);
+      acc = mfma4(ap[3], b3, acc);
+    }
+    if (vi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * lq + r;
+        if (dxs) dxs[row * ldxs + i] = acc[r];
+        if (dxg && row < nrows) {
+          float* o = dxg + (size_t)row * ldg + i;
+          *o = accumulate ? *o + acc[r] : acc[r];
+        }
+      }
+    }
+  }
+}
+
+// g[row][c] *= act'(y[row][c]) on the valid columns
+__device__ __forceinline__ void lds_actgrad(float* g, int ldg_, const float* y, int ldy, int width, int act, int tid, int nthreads) {
+  for (int i = tid; i < 16 * width; i += nthreads) {
+    const int r = i / width, c = i % width;
+    g[r * ldg_ + c] *= act_grad_from_out(act, y[r * ldy + c]);
+  }
+}
+
+// per-task gradient slab: offsets (floats) of every tail parameter, in reduce order
+struct TailSlab {
+  int ty_w, ty_b, er_w[3], er_b[3], r2z_w, r2z_b, dec_w[3], dec_b[3], wk_w, wk_b, wv_w, wv_b, wq_w, wq_b, wo_w, wo_b, total;
+};
+__host__ inline TailSlab tail_slab_layout(const TailDims& d) {
+  TailSlab s; int o = 0;
+  auto take = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
+  const int ldc = d.dw + d.dw / 4, ldd = d.dw + d.dz;
+  s.ty_w = take(d.dw / 4 * d.label_dim); s.ty_b = take(d.dw / 4);
+  s.er_w[0] = take(d.h0 * ldc); s.er_b[0] = take(d.h0);
+  s.er_w[1] = take(d.h1 * d.h0); s.er_b[1] = take(d.h1);
+  s.er_w[2] = take(d.dw * d.h1); s.er_b[2] = take(d.dw);
+  s.r2z_w = take(d.dz * d.dw); s.r2z_b = take(d.dz);
+  s.dec_w[0] = take(d.dec_h * ldd); s.dec_b[0] = take(d.dec_h);
+  s.dec_w[1] = take(d.dec_h * d.dec_h); s.dec_b[1] = take(d.dec_h);
+  s.dec_w[2] = take(d.y_dim * d.dec_h); s.dec_b[2] = take(d.y_dim);
+  s.wk_w = take(H * d.dw * d.dw); s.wk_b = take(H * d.dw);
+  s.wv_w = take(H * d.dw * d.dw); s.wv_b = take(H * d.dw);
+  s.wq_w = take(H * d.dw * d.dw); s.wq_b = take(H * d.dw);
+  s.wo_w = take(d.dw * H * d.dw); s.wo_b = take(d.dw);
+  s.total = o;
+  return s;
+}
+
+// ==================================================================================================
+// phase C backward, one workgroup per task: decoder0, r_to_z and _W backward.
+//   in : dmu, saved mu / d2 / d1 / dec_in / rr / merged
+//   out: d_dec_in[:, :dw] (decoder's share of d x_qry), d_merged, weight-gradient slab entries
+// ==================================================================================================
+struct PhaseCBwdArgs {
+  TailDims d; TailParams p; TailSlab sl;
+  const float *dmu, *mu, *d2, *d1, *dec_in, *rr, *merged;
+  float *d_dec_in, *d_merged, *slab;
+};
+
+__global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) {
+  extern __shared__ float lds[];
+  const TailDims& d = a.d;
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ldd = d.dw + d.dz, HD = H * d.dw;
+  const int Ly = ldpad(d.y_dim), Lh = ldpad(d.dec_h), Ld = ldpad(ldd), Lr = ldpad(d.dw), Lm = ldpad(HD);
+  float* s_g = lds;                  // [16][Ly]   dmu * act'(mu)
+  float* s_d2 = s_g + 16 * Ly;       // saved activations
+  float* s_d1 = s_d2 + 16 * Lh;
+  float* s_dec = s_d1 + 16 * Lh;
+  float* s_rr = s_dec + 16 * Ld;
+  float* s_m = s_rr + 16 * Lr;
+  float* s_dd2 = s_m + 16 * Lm;      // gradients
+  float* s_dd1 = s_dd2 + 16 * Lh;
+  float* s_ddec = s_dd1 + 16 * Lh;
+  float* s_drr = s_ddec + 16 * Ld;
+  lds_zero(lds, 16 * (Ly + 4 * Lh + 2 * Ld + 2 * Lr + Lm), tid, 512);
+  __syncthreads();
+  const size_t rq = (size_t)t * d.Nq;
+  for (int i = tid; i < d.Nq * d.y_dim; i += 512) {
+    const int r = i / d.y_dim, c = i % d.y_dim;
+    s_g[r * Ly + c] = a.dmu[(rq + r) * d.y_dim + c] * act_grad_from_out(d.out_act, a.mu[(rq + r) * d.y_dim + c]);
+  }
+  lds_load(s_d2, Lh, a.d2 + rq * d.dec_h, d.dec_h, d.Nq, d.dec_h, tid, 512);
+  lds_load(s_d1, Lh, a.d1 + rq * d.dec_h, d.dec_h, d.Nq, d.dec_h, tid, 512);
+  lds_load(s_dec, Ld, a.dec_in + rq * ldd, ldd, d.Nq, ldd, tid, 512);
+  lds_load(s_rr, Lr, a.rr + rq * d.dw, d.dw, d.Nq, d.dw, tid, 512);
+  lds_load(s_m, Lm, a.merged + rq * HD, HD, d.Nq, HD, tid, 512);
+  __syncthreads();
+  float* sl = a.slab + (size_t)t * a.sl.total;
+  // decoder0.4
+  wg_wgrad<8>(s_g, Ly, d.y_dim, s_d2, Lh, d.dec_h, sl + a.sl.dec_w[2], sl + a.sl.dec_b[2], wave, lane, tid);
+  wg_dgrad<8>(s_g, Ly, d.y_dim, wb1(a.p.dec_w[2], nullptr, d.y_dim), d.dec_h, s_dd2, Lh, nullptr, 0, 0, false, wave, lane);
+  __syncthreads();
+  lds_actgrad(s_dd2, Lh, s_d2, Lh, d.dec_h, ACT_RELU, tid, 512);
+  __syncthreads();
+  // decoder0.2
+  wg_wgrad<8>(s_dd2, Lh, d.dec_h, s_d1, Lh, d.dec_h, sl + a.sl.dec_w[1], sl + a.sl.dec_b[1], wave, lane, tid);
+  wg_dgrad<8>(s_dd2, Lh, d.dec_h, wb1(a.p.dec_w[1], nullptr, d.dec_h), d.dec_h, s_dd1, Lh, nullptr, 0, 0, false, wave, lane);
+  __syncthreads();
+  lds_actgrad(s_dd1, Lh, s_d1, Lh, d.dec_h, ACT_RELU, tid, 512);
+  __syncthreads();
+  // decoder0.0: input gradient = [d x_qry | dz]
+  wg_wgrad<8>(s_dd1, Lh, d.dec_h, s_dec, Ld, ldd, sl + a.sl.dec_w[0], sl + a.sl.dec_b[0], wave, lane, tid);
+  wg_dgrad<8>(s_dd1, Lh, d.dec_h, wb1(a.p.dec_w[0], nullptr, d.dec_h), ldd, s_ddec, Ld, a.d_dec_in + rq * ldd, ldd, d.Nq, false, wave, lane);
+  __syncthreads();
+  // r_to_z (dz = s_ddec[:, dw:])
+  wg_wgrad<8>(s_ddec + d.dw, Ld, d.dz, s_rr, Lr, d.dw, sl + a.sl.r2z_w, sl + a.sl.r2z_b, wave, lane, tid);
+  wg_dgrad<8>(s_ddec + d.dw, Ld, d.dz, wb1(a.p.r2z_w, nullptr, d.dz), d.dw, s_drr, Lr, nullptr, 0, 0, false, wave, lane);
+  __syncthreads();
+  // _W
+  wg_wgrad<8>(s_drr, Lr, d.dw, s_m, Lm, HD, sl + a.sl.wo_w, sl + a.sl.wo_b, wave, lane, tid);
+  wg_dgrad<8>(s_drr, Lr, d.dw, wb1(a.p.wo_w, nullptr, d.dw), HD, nullptr, 0, a.d_merged + rq * HD, HD, d.Nq, false, wave, lane);
+}
+__host__ inline size_t phaseC_bwd_lds_bytes(const TailDims& d) {
+  return sizeof(float) * 16 * (ldpad(d.y_dim) + 4 * ldpad(d.dec_h) + 2 * ldpad(d.dw + d.dz) + 2 * ldpad(d.dw) + ldpad(H * d.dw));
+}
+
+// ==================================================================================================
+// phase B backward, one workgroup per (task, head): FAVOR+ backward (S-form, see favor.h).
+//   out: dqh / dkh (without the global arg-max correction) / dvh, part_k[t*H+h] = sum of rsum_k
+// ==================================================================================================
+struct PhaseBBwdArgs {
+  TailDims d;
+  const float *qh, *kh, *vh, *pc, *qf, *kf, *S, *D, *merged, *d_merged; const int* arg_q;
+  float *dqh, *dkh, *dvh, *part_k;
+};
+
+__global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) {
+  extern __shared__ float lds[];
+  const TailDims& d = a.d;
+  const int t = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int Lx = ldpad(d.dw), Lf = ldpad(d.m), HD = H * d.dw;
+  float* s_q = lds;                    // [16][Lx]
+  float* s_k = s_q + 16 * Lx;
+  float* s_v = s_k + 16 * Lx;
+  float* s_do = s_v + 16 * Lx;         // dO
+  float* s_qf = s_do + 16 * Lx;        // [16][Lf] E features, later d(dd)
+  float* s_kf = s_qf + 16 * Lf;
+  float* s_gq = s_kf + 16 * Lf;        // G
+  float* s_gk = s_gq + 16 * Lf;
+  float* s_S = s_gk + 16 * Lf;         // [16][17]  S / D
+  float* s_dS = s_S + 16 * 17;         // [16][17]
+  float* s_st = s_dS + 16 * 17;        // wv[16], D[16], rsum_q[16], rsum_k[16]
+  const int total = 16 * (4 * Lx + 4 * Lf) + 2 * 16 * 17 + 64;
+  lds_zero(lds, total, tid, 256);
+  __syncthreads();
+  lds_load(s_q, Lx, a.qh + (size_t)t * d.Nq * HD + h * d.dw, HD, d.Nq, d.dw, tid, 256);
+  lds_load(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
+  lds_load(s_v, Lx, a.vh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
+  for (int i = tid; i < d.Nq * d.m; i += 256) {
+    const int row = i / d.m, j = i % d.m;
+    s_qf[row * Lf + j] = a.qf[((size_t)(t * d.Nq + row) * H + h) * d.m + j];
+  }
+  for (int i = tid; i < d.Nc * d.m; i += 256) {
+    const int row = i / d.m, j = i % d.m;
+    s_kf[row * Lf + j] = a.kf[((size_t)(t * d.Nc + row) * H + h) * d.m + j];
+  }
+  // dO[n][e] = d_merged[(t,n)][e*H + h];  wv[n] = sum_e dO * O
+  for (int i = tid; i < d.Nq * d.dw; i += 256) {
+    const int n = i / d.dw, e = i % d.dw;
+    s_do[n * Lx + e] = a.d_merged[(size_t)(t * d.Nq + n) * HD + e * H + h];
+  }
+  if (tid < d.Nq) s_st[16 + tid] = a.D[((size_t)t * H + h) * d.Nq + tid];
+  __syncthreads();
+  {
+    const int n = tid >> 4, part = tid & 15;
+    float s = 0.f;
+    if (n < d.Nq)
+      for (int e = part; e < d.dw; e += 16) s += s_do[n * Lx + e] * a.merged[(size_t)(t * d.Nq + n) * HD + e * H + h];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
+    if (part == 0) s_st[n] = s;
+    // S / D
+    float sd = 0.f;
+    if (n < d.Nq && part < d.Nc) sd = a.S[(((size_t)t * H + h) * d.Nq + n) * d.Nc + part] / s_st[16 + n];
+    s_S[n * 17 + part] = sd;
+  }
+  __syncthreads();
+  // dS[n][n'] = (dO[n] . v[n'] - wv[n]) / D[n]   (wave 0), valid entries only
+  if (wave == 0) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int e0 = 0; e0 < d.dw; e0 += 4) acc = mfma4(s_do[lr * Lx + e0 + lq], s_v[lr * Lx + e0 + lq], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 4 * lq + r, np = lr;
+      s_dS[n * 17 + np] = (n < d.Nq && np < d.Nc) ? (acc[r] - s_st[n]) / s_st[16 + n] : 0.f;
+    }
+  }
+  __syncthreads();
+  // dV[n'][e] = sum_n (S/D)[n][n'] dO[n][e]  -> dvh
+  for (int et = wave; et * 16 < d.dw; et += 4) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int n = 4 * s4 + lq;
+      acc = mfma4(s_S[n * 17 + lr], s_do[n * Lx + et * 16 + lr], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int np = 4 * lq + r;
+      if (np < d.Nc) a.dvh[(size_t)(t * d.Nc + np) * HD + h * d.dw + et * 16 + lr] = acc[r];
+    }
+  }
+  // G = dF (.) E with dQ' = dS (Ek + re), dK' = dS^T (Eq + re): feature tiles over the waves
+  const float ratio = 1.0f / sqrtf((float)d.m), re = ratio * 1e-4f;
+  const int ntile = (d.m + 15) / 16;
+  for (int it = wave; it < 2 * ntile; it += 4) {
+    const int isk = it >= ntile, jt = isk ? it - ntile : it;
+    const int j = jt * 16 + lr;
+    const bool vj = j < d.m;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int o = 4 * s4 + lq;                    // summed row index (n' for queries, n for keys)
+      const float av = isk ? s_dS[o * 17 + lr] : s_dS[lr * 17 + o];
+      const float bv = vj ? (isk ? s_qf[o * Lf + j] : s_kf[o * Lf + j]) + re : 0.f;
+      acc = mfma4(av, bv, acc);
+    }
+    if (vj) {
+      float* g = isk ? s_gk : s_gq;
+      const float* f = isk ? s_kf : s_qf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 4 * lq + r; g[row * Lf + j] = acc[r] * f[row * Lf + j]; }
+    }
+  }
+  __syncthreads();
+  // row sums of G (32 rows x 8 threads), then d(dd): queries subtract the row sum at the arg-max
+  {
+    const int row = tid >> 3, part = tid & 7;
+    const float* g = row < 16 ? s_gq + row * Lf : s_gk + (row - 16) * Lf;
+    float s = 0.f;
+    for (int j = part; j < d.m; j += 8) s += g[j];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (part == 0) s_st[32 + row] = s;
+  }
+  __syncthreads();
+  if (tid < d.Nq) s_gq[tid * Lf + a.arg_q[(t * d.Nq + tid) * H + h]] -= s_st[32 + tid];
+  if (tid == 0) {
+    float s = 0.f;
+    for (int np = 0; np < d.Nc; ++np) s += s_st[48 + np];
+    a.part_k[t * H + h] = s;
+  }
+  __syncthreads();
+  // dx[row][e] = sum_j d(dd)[row][j] pc[j][e] - rsum[row] c^2 x[row][e]: waves 0,1 -> q (e tiles 0..), 2,3 -> k
+  {
+    const float c2 = 1.0f / sqrtf((float)d.dw);
+    const int net = d.dw / 16;
+    for (int it = wave; it < 2 * net; it += 4) {
+      const int isk = it >= net, et = isk ? it - net : it;
+      const float* g = isk ? s_gk : s_gq;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int j0 = 0; j0 < d.m; j0 += 4) {
+        const int j = j0 + lq;
+        const float bv = j < d.m ? a.pc[(size_t)j * d.dw + et * 16 + lr] : 0.f;
+        acc = mfma4(g[lr * Lf + j], bv, acc);
+      }
+      const float* xs = isk ? s_k : s_q;
+      float* dst = isk ? a.dkh : a.dqh;
+      const int nrows = isk ? d.Nc : d.Nq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * lq + r, e = et * 16 + lr;
+        if (row < nrows)
+          dst[(size_t)(t * nrows + row) * HD + h * d.dw + e] = acc[r] - s_st[32 + (isk ? 16 : 0) + row] * c2 * xs[row * Lx + e];
+      }
+    }
+  }
+}
+__host__ inline size_t phaseB_bwd_lds_bytes(const TailDims& d) {
+  return sizeof(float) * (16 * (4 * ldpad(d.dw) + 4 * ldpad(d.m)) + 2 * 16 * 17 + 64);
+}
+
+// ==================================================================================================
+// phase A backward, one workgroup per task: global key arg-max correction, W_q / W_v / W_k backward,
+// EncoderFC backward, transform_y weight gradient.
+//   out: d_dec_in[:, :dw] += d x_qry (attention share), d_cat_in, slab entries
+// ==================================================================================================
+struct PhaseABwdArgs {
+  TailDims d; TailParams p; TailSlab sl;
+  const float *ctx_y, *cat_in, *h0, *h1, *rs, *dec_in, *dqh, *dkh, *dvh, *pc, *part_k; const int* gpos;
+  float *d_dec_in, *d_cat_in, *slab;
+};
+
+__global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) {
+  extern __shared__ float lds[];
+  const TailDims& d = a.d;
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ldc = d.dw + d.dw / 4, ldd = d.dw + d.dz, HD = H * d.dw;
+  const int Lcat = ldpad(ldc), Lh0 = ldpad(d.h0), Lh1 = ldpad(d.h1), Lw = ldpad(d.dw), Lhd = ldpad(HD), Ly = ldpad(d.label_dim);
+  float* s_cat = lds;                  // saved activations
+  float* s_h0 = s_cat + 16 * Lcat;
+  float* s_h1 = s_h0 + 16 * Lh0;
+  float* s_rs = s_h1 + 16 * Lh1;
+  float* s_xq = s_rs + 16 * Lw;
+  float* s_y = s_xq + 16 * Lw;
+  float* s_dq = s_y + 16 * Ly;         // [16][Lhd] head-space gradients (one buffer, reused q -> v -> k)
+  float* s_drs = s_dq + 16 * Lhd;      // gradients
+  float* s_dxc = s_drs + 16 * Lw;
+  float* s_dh1 = s_dxc + 16 * Lw;
+  float* s_dh0 = s_dh1 + 16 * Lh1;
+  float* s_dcat = s_dh0 + 16 * Lh0;
+  lds_zero(lds, 16 * (2 * Lcat + 2 * Lh0 + 2 * Lh1 + 4 * Lw + Ly + Lhd), tid, 512);
+  __syncthreads();
+  const size_t rc = (size_t)t * d.Nc, rq = (size_t)t * d.Nq;
+  lds_load(s_cat, Lcat, a.cat_in + rc * ldc, ldc, d.Nc, ldc, tid, 512);
+  lds_load(s_h0, Lh0, a.h0 + rc * d.h0, d.h0, d.Nc, d.h0, tid, 512);
+  lds_load(s_h1, Lh1, a.h1 + rc * d.h1, d.h1, d.Nc, d.h1, tid, 512);
+  lds_load(s_rs, Lw, a.rs + rc * d.dw, d.dw, d.Nc, d.dw, tid, 512);
+  lds_load(s_xq, Lw, a.dec_in + rq * ldd, ldd, d.Nq, d.dw, tid, 512);
+  lds_load(s_y, Ly, a.ctx_y + rc * d.label_dim, d.label_dim, d.Nc, d.label_dim, tid, 512);
+  lds_load(s_dq, Lhd, a.dqh + rq * HD, HD, d.Nq, HD, tid, 512);
+  float* sl = a.slab + (size_t)t * a.sl.total;
+  __syncthreads();
+  // W_q: weight gradient and the attention share of d x_qry (accumulated onto the decoder's)
+  wg_wgrad<8>(s_dq, Lhd, HD, s_xq, Lw, d.dw, sl + a.sl.wq_w, sl + a.sl.wq_b, wave, lane, tid);
+  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wq_w, nullptr, d.dw), d.dw, nullptr, 0, a.d_dec_in + rq * ldd, ldd, d.Nq, true, wave, lane);
+  __syncthreads();
+  // W_v
+  lds_zero(s_dq, 16 * Lhd, tid, 512);
+  __syncthreads();
+  lds_load(s_dq, Lhd, a.dvh + rc * HD, HD, d.Nc, HD, tid, 512);
+  __syncthreads();
+  wg_wgrad<8>(s_dq, Lhd, HD, s_rs, Lw, d.dw, sl + a.sl.wv_w, sl + a.sl.wv_b, wave, lane, tid);
+  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wv_w, nullptr, d.dw), d.dw, s_drs, Lw, nullptr, 0, 0, false, wave, lane);
+  __syncthreads();
+  // W_k, with the batch-global key arg-max correction: that ONE element's d(dd) carries minus the
+  // sum of G over every key row of the batch (fast_attention.py:97), i.e. dk[row] -= total * pc[col]
+  lds_zero(s_dq, 16 * Lhd, tid, 512);
+  __syncthreads();
+  lds_load(s_dq, Lhd, a.dkh + rc * HD, HD, d.Nc, HD, tid, 512);
+  __syncthreads();
+  {
+    const int grow = a.gpos[0], gcol = a.gpos[1];
+    const int gt = grow / (d.Nc * H);
+    if (gt == t && tid < d.dw) {
+      float total = 0.f;
+      for (int i = 0; i < d.T * H; ++i) total += a.part_k[i];
+      const int n = (grow / H) % d.Nc, hh = grow % H;
+      s_dq[n * Lhd + hh * d.dw + tid] -= total * a.pc[(size_t)gcol * d.dw + tid];
+    }
+  }
+  __syncthreads();
+  wg_wgrad<8>(s_dq, Lhd, HD, s_cat, Lcat, d.dw, sl + a.sl.wk_w, sl + a.sl.wk_b, wave, lane, tid);
+  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wk_w, nullptr, d.dw), d.dw, s_dxc, Lw, nullptr, 0, 0, false, wave, lane);
+  // EncoderFC, last layer first
+  wg_wgrad<8>(s_drs, Lw, d.dw, s_h1, Lh1, d.h1, sl + a.sl.er_w[2], sl + a.sl.er_b[2], wave, lane, tid);
+  wg_dgrad<8>(s_drs, Lw, d.dw, wb1(a.p.er_w[2], nullptr, d.dw), d.h1, s_dh1, Lh1, nullptr, 0, 0, false, wave, lane);
+  __syncthreads();
+  lds_actgrad(s_dh1, Lh1, s_h1, Lh1, d.h1, ACT_RELU, tid, 512);
+  __syncthreads();
+  wg_wgrad<8>(s_dh1, Lh1, d.h1, s_h0, Lh0, d.h0, sl + a.sl.er_w[1], sl + a.sl.er_b[1], wave, lane, tid);
+  wg_dgrad<8>(s_dh1, Lh1, d.h1, wb1(a.p.er_w[1], nullptr, d.h1), d.h0, s_dh0, Lh0, nullptr, 0, 0, false, wave, lane);
+  __syncthreads();
+  lds_actgrad(s_dh0, Lh0, s_h0, Lh0, d.h0, ACT_RELU, tid, 512);
+  __syncthreads();
+  wg_wgrad<8>(s_dh0, Lh0, d.h0, s_cat, Lcat, ldc, sl + a.sl.er_w[0], sl + a.sl.er_b[0], wave, lane, tid);
+  wg_dgrad<8>(s_dh0, Lh0, d.h0, wb1(a.p.er_w[0], nullptr, d.h0), ldc, s_dcat, Lcat, nullptr, 0, 0, false, wave, lane);
+  __syncthreads();
+  // d_cat_in = EncoderFC input gradient (+ K-projection share on the x_ctx columns)
+  for (int i = tid; i < d.Nc * ldc; i += 512) {
+    const int r = i / ldc, c = i % ldc;
+    a.d_cat_in[(rc + r) * ldc + c] = s_dcat[r * Lcat + c] + (c < d.dw ? s_dxc[r * Lw + c] : 0.f);
+  }
+  // transform_y: dW = d_cat[:, dw:]^T ctx_y, db
+  wg_wgrad<8>(s_dcat + d.dw, Lcat, d.dw / 4, s_y, Ly, d.label_dim, sl + a.sl.ty_w, sl + a.sl.ty_b, wave, lane, tid);
+}
+__host__ inline size_t phaseA_bwd_lds_bytes(const TailDims& d) {
+  const int ldc = d.dw + d.dw / 4;
+  return sizeof(float) * 16 * (2 * ldpad(ldc) + 2 * ldpad(d.h0) + 2 * ldpad(d.h1) + 4 * ldpad(d.dw) + ldpad(d.label_dim) + ldpad(H * d.dw));
+}
+
+// ---- sum the per-task slabs into the parameter gradients (fixed task order) -------------------------
+constexpr int MAX_SEG = 72;
+struct SlabReduce {
+  float* dst[MAX_SEG]; int off[MAX_SEG]; int len[MAX_SEG];
+  int nseg, T, total; const float* slab;
+};
+__global__ __launch_bounds__(256) void slab_to_grads_kernel(const SlabReduce a) {
+  const int seg = blockIdx.y;
+  // compare chain instead of a[seg]: a runtime-indexed by-value kernel argument would be copied to scratch
+  float* dst = a.dst[0]; int off = a.off[0], len = a.len[0];
+#pragma unroll
+  for (int i = 1; i < MAX_SEG; ++i)
+    if (i == seg) { dst = a.dst[i]; off = a.off[i]; len = a.len[i]; }
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < len; e += gridDim.x * 256) {
+    float s = 0.f;
+    for (int t = 0; t < a.T; ++t) s += a.slab[(size_t)t * a.total + off + e];
+    dst[e] = s;
+  }
+}
+
 }  // namespace tf
 }  // namespace mlhot
 #endif  // !MLHOT_HOSTSIM
