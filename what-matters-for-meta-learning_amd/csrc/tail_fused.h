@@ -196,6 +196,7 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
     const int j = jt * 16 + lr;
     const bool vj = j < d.m;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int k0 = 0; k0 < d.dw; k0 += 16) {
       const int kk = k0 + 4 * lq;
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -479,33 +480,45 @@ __device__ __forceinline__ void wg_wgrad(const float* dys, int ldy, int Nout, co
   }
 }
 
-// dX[16][Kin] = dY[16][Nout] W[Nout][Kin]  (W as row blocks of `rows` rows).  N-tiles over i round-robin
-// over the waves; per 16-wide j block: A = one float4 of dY from LDS, B = 4 coalesced dwords of W.
-// Result to LDS (dxs) and/or global (dxg: rows < nrows; accumulate adds to what is there).
+// dX[16][Kin] = dY[16][Nout] W[Nout][Kin]  (W as row blocks of `rows` rows).  Work items are
+// (16-column tile of i) x (chunk of the reduction index j): when Kin has fewer tiles than there are
+// waves (the head projections: Kin = 64, Nout = 512) the j range is split over the idle waves and
+// the partial tiles are folded through `red` (LDS, NW*256 floats).  Per 16-wide j block: A = one
+// float4 of dY from LDS, B = 4 coalesced dwords of W.  Result to LDS (dxs) and/or global (dxg: rows
+// < nrows; accumulate adds to what is there).  Contains barriers: call from all waves.
 template <int NW>
 __device__ __forceinline__ void wg_dgrad(const float* dys, int ldy, int Nout, const WB& wb, int Kin,
                                          float* dxs, int ldxs, float* dxg, int ldg, int nrows, bool accumulate,
-                                         int wave, int lane) {
+                                         float* red, int wave, int lane) {
   const int lr = lane & 15, lq = lane >> 4;
-  for (int it = wave; it * 16 < Kin; it += NW) {
-    const int i = it * 16 + lr;
-    const bool vi = i < Kin;
+  const int ntile = (Kin + 15) / 16;
+  int nchunk = 1;
+  if (ntile * 2 <= NW) nchunk = NW / ntile;
+  const int jblocks = (Nout + 15) / 16, per = (jblocks + nchunk - 1) / nchunk;
+  for (int it0 = 0; it0 < ntile * nchunk; it0 += NW) {
+    const int it = it0 + wave;
+    const bool active = it < ntile * nchunk;
+    const int tile = active ? it % ntile : 0, chunk = active ? it / ntile : 0;
+    const int i = tile * 16 + lr;
+    const bool vi = active && i < Kin;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int j0 = 0; j0 < Nout; j0 += 16) {
+    const int jb0 = chunk * per, jb1 = active ? (jb0 + per < jblocks ? jb0 + per : jblocks) : jb0;
+#pragma unroll 4
+    for (int jb = jb0; jb < jb1; ++jb) {
+      const int j0 = jb * 16;
       const int blk = j0 / wb.rows;
       const float* wsel = wb.w[0];
 #pragma unroll
       for (int q = 1; q < H; ++q)
         if (blk == q) wsel = wb.w[q];
-      const int jb = j0 + 4 * lq - blk * wb.rows;          // row inside the block
+      const int jr = j0 + 4 * lq - blk * wb.rows;          // row inside the block
       float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
       if (vi) {
         const int j = j0 + 4 * lq;
-        if (j < Nout) b0 = wsel[(size_t)jb * Kin + i];
-        if (j + 1 < Nout) b1 = wsel[(size_t)(jb + 1) * Kin + i];
-        if (j + 2 < Nout) b2 = wsel[(size_t)(jb + 2) * Kin + i];
-        if (j + 3 < Nout) b3 = wsel[(size_t)(jb + 3) * Kin + i];
+        if (j < Nout) b0 = wsel[(size_t)jr * Kin + i];
+        if (j + 1 < Nout) b1 = wsel[(size_t)(jr + 1) * Kin + i];
+        if (j + 2 < Nout) b2 = wsel[(size_t)(jr + 2) * Kin + i];
+        if (j + 3 < Nout) b3 = wsel[(size_t)(jr + 3) * Kin + i];
       }
       const float* ap = dys + lr * ldy + j0 + 4 * lq;
       acc = mfma4(ap[0], b0, acc);
@@ -513,7 +526,22 @@ __device__ __forceinline__ void wg_dgrad(const float* dys, int ldy, int Nout, co
       acc = mfma4(ap[2], b2, acc);
       acc = mfma4(ap[3], b3, acc);
     }
-    if (vi) {
+    if (nchunk > 1) {                                       // fold the j chunks (fixed order)
+      if (active && chunk > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+      }
+      __syncthreads();
+      if (active && chunk == 0) {
+        for (int c = 1; c < nchunk; ++c) {
+          const int ow = wave + c * ntile - it0;           // wave that holds chunk c of this tile
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] += red[(ow * 4 + r) * 64 + lane];
+        }
+      }
+      __syncthreads();
+    }
+    if (vi && chunk == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * lq + r;
@@ -586,6 +614,7 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   float* s_dd1 = s_dd2 + 16 * Lh;
   float* s_ddec = s_dd1 + 16 * Lh;
   float* s_drr = s_ddec + 16 * Ld;
+  float* s_red = s_drr + 16 * Lr;    // [8 waves][256] partial tiles of wg_dgrad
   lds_zero(lds, 16 * (Ly + 4 * Lh + 2 * Ld + 2 * Lr + Lm), tid, 512);
   __syncthreads();
   const size_t rq = (size_t)t * d.Nq;
@@ -602,30 +631,30 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   float* sl = a.slab + (size_t)t * a.sl.total;
   // decoder0.4
   wg_wgrad<8>(s_g, Ly, d.y_dim, s_d2, Lh, d.dec_h, sl + a.sl.dec_w[2], sl + a.sl.dec_b[2], wave, lane, tid);
-  wg_dgrad<8>(s_g, Ly, d.y_dim, wb1(a.p.dec_w[2], nullptr, d.y_dim), d.dec_h, s_dd2, Lh, nullptr, 0, 0, false, wave, lane);
+  wg_dgrad<8>(s_g, Ly, d.y_dim, wb1(a.p.dec_w[2], nullptr, d.y_dim), d.dec_h, s_dd2, Lh, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   lds_actgrad(s_dd2, Lh, s_d2, Lh, d.dec_h, ACT_RELU, tid, 512);
   __syncthreads();
   // decoder0.2
   wg_wgrad<8>(s_dd2, Lh, d.dec_h, s_d1, Lh, d.dec_h, sl + a.sl.dec_w[1], sl + a.sl.dec_b[1], wave, lane, tid);
-  wg_dgrad<8>(s_dd2, Lh, d.dec_h, wb1(a.p.dec_w[1], nullptr, d.dec_h), d.dec_h, s_dd1, Lh, nullptr, 0, 0, false, wave, lane);
+  wg_dgrad<8>(s_dd2, Lh, d.dec_h, wb1(a.p.dec_w[1], nullptr, d.dec_h), d.dec_h, s_dd1, Lh, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   lds_actgrad(s_dd1, Lh, s_d1, Lh, d.dec_h, ACT_RELU, tid, 512);
   __syncthreads();
   // decoder0.0: input gradient = [d x_qry | dz]
   wg_wgrad<8>(s_dd1, Lh, d.dec_h, s_dec, Ld, ldd, sl + a.sl.dec_w[0], sl + a.sl.dec_b[0], wave, lane, tid);
-  wg_dgrad<8>(s_dd1, Lh, d.dec_h, wb1(a.p.dec_w[0], nullptr, d.dec_h), ldd, s_ddec, Ld, a.d_dec_in + rq * ldd, ldd, d.Nq, false, wave, lane);
+  wg_dgrad<8>(s_dd1, Lh, d.dec_h, wb1(a.p.dec_w[0], nullptr, d.dec_h), ldd, s_ddec, Ld, a.d_dec_in + rq * ldd, ldd, d.Nq, false, s_red, wave, lane);
   __syncthreads();
   // r_to_z (dz = s_ddec[:, dw:])
   wg_wgrad<8>(s_ddec + d.dw, Ld, d.dz, s_rr, Lr, d.dw, sl + a.sl.r2z_w, sl + a.sl.r2z_b, wave, lane, tid);
-  wg_dgrad<8>(s_ddec + d.dw, Ld, d.dz, wb1(a.p.r2z_w, nullptr, d.dz), d.dw, s_drr, Lr, nullptr, 0, 0, false, wave, lane);
+  wg_dgrad<8>(s_ddec + d.dw, Ld, d.dz, wb1(a.p.r2z_w, nullptr, d.dz), d.dw, s_drr, Lr, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   // _W
   wg_wgrad<8>(s_drr, Lr, d.dw, s_m, Lm, HD, sl + a.sl.wo_w, sl + a.sl.wo_b, wave, lane, tid);
-  wg_dgrad<8>(s_drr, Lr, d.dw, wb1(a.p.wo_w, nullptr, d.dw), HD, nullptr, 0, a.d_merged + rq * HD, HD, d.Nq, false, wave, lane);
+  wg_dgrad<8>(s_drr, Lr, d.dw, wb1(a.p.wo_w, nullptr, d.dw), HD, nullptr, 0, a.d_merged + rq * HD, HD, d.Nq, false, s_red, wave, lane);
 }
 __host__ inline size_t phaseC_bwd_lds_bytes(const TailDims& d) {
-  return sizeof(float) * 16 * (ldpad(d.y_dim) + 4 * ldpad(d.dec_h) + 2 * ldpad(d.dw + d.dz) + 2 * ldpad(d.dw) + ldpad(H * d.dw));
+  return sizeof(float) * (16 * (ldpad(d.y_dim) + 4 * ldpad(d.dec_h) + 2 * ldpad(d.dw + d.dz) + 2 * ldpad(d.dw) + ldpad(H * d.dw)) + 8 * 256);
 }
 
 // ==================================================================================================
@@ -814,6 +843,7 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   float* s_dh1 = s_dxc + 16 * Lw;
   float* s_dh0 = s_dh1 + 16 * Lh1;
   float* s_dcat = s_dh0 + 16 * Lh0;
+  float* s_red = s_dcat + 16 * Lcat;   // [8 waves][256] partial tiles of wg_dgrad
   lds_zero(lds, 16 * (2 * Lcat + 2 * Lh0 + 2 * Lh1 + 4 * Lw + Ly + Lhd), tid, 512);
   __syncthreads();
   const size_t rc = (size_t)t * d.Nc, rq = (size_t)t * d.Nq;
@@ -828,7 +858,7 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   __syncthreads();
   // W_q: weight gradient and the attention share of d x_qry (accumulated onto the decoder's)
   wg_wgrad<8>(s_dq, Lhd, HD, s_xq, Lw, d.dw, sl + a.sl.wq_w, sl + a.sl.wq_b, wave, lane, tid);
-  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wq_w, nullptr, d.dw), d.dw, nullptr, 0, a.d_dec_in + rq * ldd, ldd, d.Nq, true, wave, lane);
+  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wq_w, nullptr, d.dw), d.dw, nullptr, 0, a.d_dec_in + rq * ldd, ldd, d.Nq, true, s_red, wave, lane);
   __syncthreads();
   // W_v
   lds_zero(s_dq, 16 * Lhd, tid, 512);
@@ -836,7 +866,7 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   lds_load(s_dq, Lhd, a.dvh + rc * HD, HD, d.Nc, HD, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dq, Lhd, HD, s_rs, Lw, d.dw, sl + a.sl.wv_w, sl + a.sl.wv_b, wave, lane, tid);
-  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wv_w, nullptr, d.dw), d.dw, s_drs, Lw, nullptr, 0, 0, false, wave, lane);
+  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wv_w, nullptr, d.dw), d.dw, s_drs, Lw, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   // W_k, with the batch-global key arg-max correction: that ONE element's d(dd) carries minus the
   // sum of G over every key row of the batch (fast_attention.py:97), i.e. dk[row] -= total * pc[col]
@@ -856,20 +886,20 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   }
   __syncthreads();
   wg_wgrad<8>(s_dq, Lhd, HD, s_cat, Lcat, d.dw, sl + a.sl.wk_w, sl + a.sl.wk_b, wave, lane, tid);
-  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wk_w, nullptr, d.dw), d.dw, s_dxc, Lw, nullptr, 0, 0, false, wave, lane);
+  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wk_w, nullptr, d.dw), d.dw, s_dxc, Lw, nullptr, 0, 0, false, s_red, wave, lane);
   // EncoderFC, last layer first
   wg_wgrad<8>(s_drs, Lw, d.dw, s_h1, Lh1, d.h1, sl + a.sl.er_w[2], sl + a.sl.er_b[2], wave, lane, tid);
-  wg_dgrad<8>(s_drs, Lw, d.dw, wb1(a.p.er_w[2], nullptr, d.dw), d.h1, s_dh1, Lh1, nullptr, 0, 0, false, wave, lane);
+  wg_dgrad<8>(s_drs, Lw, d.dw, wb1(a.p.er_w[2], nullptr, d.dw), d.h1, s_dh1, Lh1, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   lds_actgrad(s_dh1, Lh1, s_h1, Lh1, d.h1, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dh1, Lh1, d.h1, s_h0, Lh0, d.h0, sl + a.sl.er_w[1], sl + a.sl.er_b[1], wave, lane, tid);
-  wg_dgrad<8>(s_dh1, Lh1, d.h1, wb1(a.p.er_w[1], nullptr, d.h1), d.h0, s_dh0, Lh0, nullptr, 0, 0, false, wave, lane);
+  wg_dgrad<8>(s_dh1, Lh1, d.h1, wb1(a.p.er_w[1], nullptr, d.h1), d.h0, s_dh0, Lh0, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   lds_actgrad(s_dh0, Lh0, s_h0, Lh0, d.h0, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dh0, Lh0, d.h0, s_cat, Lcat, ldc, sl + a.sl.er_w[0], sl + a.sl.er_b[0], wave, lane, tid);
-  wg_dgrad<8>(s_dh0, Lh0, d.h0, wb1(a.p.er_w[0], nullptr, d.h0), ldc, s_dcat, Lcat, nullptr, 0, 0, false, wave, lane);
+  wg_dgrad<8>(s_dh0, Lh0, d.h0, wb1(a.p.er_w[0], nullptr, d.h0), ldc, s_dcat, Lcat, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   // d_cat_in = EncoderFC input gradient (+ K-projection share on the x_ctx columns)
   for (int i = tid; i < d.Nc * ldc; i += 512) {
@@ -881,7 +911,7 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
 }
 __host__ inline size_t phaseA_bwd_lds_bytes(const TailDims& d) {
   const int ldc = d.dw + d.dw / 4;
-  return sizeof(float) * 16 * (2 * ldpad(ldc) + 2 * ldpad(d.h0) + 2 * ldpad(d.h1) + 4 * ldpad(d.dw) + ldpad(d.label_dim) + ldpad(H * d.dw));
+  return sizeof(float) * (16 * (2 * ldpad(ldc) + 2 * ldpad(d.h0) + 2 * ldpad(d.h1) + 4 * ldpad(d.dw) + ldpad(d.label_dim) + ldpad(H * d.dw)) + 8 * 256);
 }
 
 // ---- sum the per-task slabs into the parameter gradients (fixed task order) -------------------------
