@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
 
@@ -125,12 +126,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The step has static shapes and no host sync, so it is captured once into a hipGraph and replayed
+    # (the RCCL all-reduce stays outside the graph).  --no-graph runs it eagerly.
+    run = step
+    graphed = False
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    model.zero_grad(set_to_none=True)
+                    loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            model.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                static_loss = loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy)
+                static_loss.backward()
+
+            def run():
+                graph.replay()
+                bucket.sync()
+                return static_loss
+            graphed = True
+        except Exception as e:  # noqa: BLE001 - fall back to eager, say so
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            run = step
+
     for _ in range(args.warmup):
-        step()
+        run()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
+    t_enqueue = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -179,7 +210,8 @@ def main():
                "config": {"workload": w["name"], "tasks_per_gpu": T_LOCAL, "global_tasks": world * T_LOCAL,
                           "context_shots": NC, "target_shots": NQ, "image": "128x128x1",
                           "parallelism": f"task-sharded x{world}, one flat grad all-reduce" if world > 1 else "single GPU"},
-               "final_loss": final_loss, "roofline": roof}
+               "final_loss": final_loss, "hipgraph": graphed, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
+               "roofline": roof}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         else:
