@@ -36,7 +36,9 @@ const char* mlhot_last_error(void);
 
 /* Implementation switches for A/B tests: "conv2_tc" = 1 (default) runs the weight-stationary
  * conv2 kernels (csrc/conv_tc.h), 0 the generic implicit-GEMM problems; "tail_fused" = 1
- * (default) runs the fused per-task tail kernels (csrc/tail_fused.h) where they apply.          */
+ * (default) runs the fused per-task tail kernels (csrc/tail_fused.h) where they apply;
+ * "materialize_a1" = 1 additionally stores the conv1 output (debug / tests; the fused conv1+conv2
+ * kernels never need it).                                                                       */
 int mlhot_set_option(const char* name, int value);
 
 /* ---- bench-only: per-launch HIP-event timing ------------------------------------------------

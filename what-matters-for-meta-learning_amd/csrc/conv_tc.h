@@ -384,6 +384,422 @@ __global__ __launch_bounds__(NT) void conv2_dgrad_kernel(const float* __restrict
   }
 }
 
+
+// ==================================================================================================
+// conv1-fused variants ("c12"): the conv1 output `a1` (512 KiB / image, the largest tensor of the
+// model) is never written to HBM.  Each band's 32 x 9 x 64 slice of a1 is recomputed from the
+// 19-row image strip (9.7 KB, L1/L2 resident) straight into the LDS patch, on the VALU, in the
+// issue gaps of the MFMA loop; in the backward the same recompute supplies conv1's ReLU mask and
+// the conv1 weight gradient is accumulated in registers right where d a1 is produced, so `d a1`
+// (another 512 KiB / image) is never written either.  conv1 adds 6.8 % FLOPs and removes
+// ~1.5 GB of HBM traffic per step at 480 images.
+// ==================================================================================================
+
+struct ImgSrc {           // two-segment image batch (context | target), [n][1][128][128]
+  const float* p0; int n0; const float* p1;
+  __device__ __forceinline__ const float* img(int i) const { return i < n0 ? p0 + (size_t)i * 16384 : p1 + (size_t)(i - n0) * 16384; }
+};
+
+// one thread = one a1 position (patch row cr, column cc) of the band; 576 of the 768 threads
+struct Conv1Taps { float t[9]; };
+__device__ __forceinline__ void taps_fetch(Conv1Taps& tp, const ImgSrc& x, int tile, int cr, int cc) {
+  const int img = tile >> 3, band = tile & 7;
+  const float* xi = x.img(img);
+  const int iy1 = 8 * band - 1 + cr;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = 2 * iy1 + ky - 1, ix = 2 * cc + kx - 1;
+      tp.t[ky * 3 + kx] = (iy1 >= 0 && iy >= 0 && ix >= 0) ? xi[iy * 128 + ix] : 0.f;
+    }
+}
+// a1[ci][row][col] = relu(b1 + w1 . taps) for ci in [c0, c1) -> patch; rows above the image are conv2's zero padding
+template <int C0, int C1>
+__device__ __forceinline__ void conv1_to_patch(const Conv1Taps& tp, const float* __restrict__ w1, const float* __restrict__ b1,
+                                               float* patch, int tile, int cr, int cc) {
+  const bool valid = 8 * (tile & 7) - 1 + cr >= 0;
+  float* d = patch + cr * RS + 1 + cc;
+#pragma unroll
+  for (int ci = C0; ci < C1; ++ci) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) sacc = fmaf(tp.t[q], w1[ci * 9 + q], sacc);
+    sacc += b1[ci];
+    d[ci * PS] = valid ? fmaxf(sacc, 0.f) : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ p2, uint8_t* __restrict__ amax, int n_img) {
+  __shared__ float patch2[2 * PATCH_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int n = nt * 16 + lr;
+  const bool cact = tid < 576;
+  const int cr = tid >> 6, cc = tid & 63;
+
+  float wr[72];
+#pragma unroll
+  for (int ks = 0; ks < 72; ++ks) wr[ks] = w[((size_t)n * CIN + (ks & 7) * 4 + lq) * 9 + (ks >> 3)];
+  const float bn = bias[n];
+
+  patch_zero_pad(patch2, tid);
+  patch_zero_pad(patch2 + PATCH_FLOATS, tid);
+  const int ntiles = n_img * 8;
+  int tile = blockIdx.x;
+  Conv1Taps tp;
+  if (tile < ntiles && cact) {
+    taps_fetch(tp, x, tile, cr, cc);
+    conv1_to_patch<0, 32>(tp, w1, b1, patch2, tile, cr, cc);
+    if (tile + (int)gridDim.x < ntiles) taps_fetch(tp, x, tile + gridDim.x, cr, cc);
+  }
+  __syncthreads();
+  const int aoff = lq * PS + (4 * rp) * RS + 2 * (16 * ch + lr);
+  int cur = 0;
+  for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+    const float* ab = patch2 + cur * PATCH_FLOATS + aoff;
+    float* nb = patch2 + (cur ^ 1) * PATCH_FLOATS;
+    const int next = tile + (int)gridDim.x;
+    const bool stage = next < ntiles && cact;
+
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int seg = 0; seg < 6; ++seg) {
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        const int ks = seg * 12 + q;
+        const int tap = ks >> 3, ky = tap / 3, kx = tap % 3, cg = ks & 7;
+        const float x0 = ab[cg * 4 * PS + ky * RS + kx];
+        const float x1 = ab[cg * 4 * PS + (2 + ky) * RS + kx];
+        acc0 = mfma4(x0, wr[ks], acc0);
+        acc1 = mfma4(x1, wr[ks], acc1);
+      }
+      // the next band's a1 slice, 8 channels per segment, on the VALU between the MFMAs
+      if (stage) {
+        if (seg == 0) conv1_to_patch<0, 8>(tp, w1, b1, nb, next, cr, cc);
+        if (seg == 1) conv1_to_patch<8, 16>(tp, w1, b1, nb, next, cr, cc);
+        if (seg == 2) conv1_to_patch<16, 24>(tp, w1, b1, nb, next, cr, cc);
+        if (seg == 3) conv1_to_patch<24, 32>(tp, w1, b1, nb, next, cr, cc);
+      }
+      if (seg == 4 && cact && next + (int)gridDim.x < ntiles) taps_fetch(tp, x, next + gridDim.x, cr, cc);
+    }
+    const int img = tile >> 3, band = tile & 7;
+    float pv[2]; unsigned pa[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float c0 = fmaxf(acc0[2 * j] + bn, 0.f), c1 = fmaxf(acc0[2 * j + 1] + bn, 0.f);
+      const float c2v = fmaxf(acc1[2 * j] + bn, 0.f), c3 = fmaxf(acc1[2 * j + 1] + bn, 0.f);
+      float best = c0; unsigned which = 0;
+      if (c1 > best) { best = c1; which = 1; }
+      if (c2v > best) { best = c2v; which = 2; }
+      if (c3 > best) { best = c3; which = 3; }
+      pv[j] = best; pa[j] = which;
+    }
+    const size_t o = (((size_t)img * COUT + n) * 16 + 2 * band + rp) * 16 + 8 * ch + 2 * lq;
+    *reinterpret_cast<float2*>(p2 + o) = make_float2(pv[0], pv[1]);
+    *reinterpret_cast<unsigned short*>(amax + o) = (unsigned short)(pa[0] | (pa[1] << 8));
+    __syncthreads();
+  }
+}
+
+// ---- weight + bias gradient of conv2 with the a1 patch recomputed from the image ------------------
+__global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ dp2, const float* __restrict__ p2,
+                                                          const uint8_t* __restrict__ amax, float* __restrict__ slab_w,
+                                                          float* __restrict__ slab_b, int n_img) {
+  __shared__ float lds[PATCH_FLOATS + DYT_FLOATS];
+  float* patch = lds;
+  float* dyt = lds + PATCH_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mg = wave % 6, ph = wave / 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const bool cact = tid < 576;
+  const int cr = tid >> 6, cc = tid & 63;
+
+  f32x4_t acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+
+  patch_zero_pad(patch, tid);
+  const int ntiles = n_img * 8;
+  Conv1Taps tp;
+  float cdp[2], cp[2]; unsigned cam[2];
+  auto cells_fetch = [&](int t) {
+    const int img = t >> 3, band = t & 7;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * NT, px = e & 15, pyl = (e >> 4) & 1, co = e >> 5;
+      const size_t o = (((size_t)img * COUT + co) * 16 + 2 * band + pyl) * 16 + px;
+      cdp[j] = dp2[o]; cp[j] = p2[o]; cam[j] = amax[o];
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) { if (cact) taps_fetch(tp, x, tile, cr, cc); cells_fetch(tile); }
+  int aoff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int mt = 3 * mg + i, tap = mt >> 1, ky = tap / 3, kx = tap % 3;
+    aoff[i] = (16 * (mt & 1) + lr) * PS + ky * RS + kx + 2 * (8 * lq);
+  }
+  const int boff = (8 * lq) * DS + lr;
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    if (cact) conv1_to_patch<0, 32>(tp, w1, b1, patch, tile, cr, cc);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * NT, px = e & 15, pyl = (e >> 4) & 1, co = e >> 5;
+      const float g = cp[j] > 0.f ? cdp[j] : 0.f;
+      bsum[j] += g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        dyt[((2 * pyl + (q >> 1)) * 32 + 2 * px + (q & 1)) * DS + co] = (cam[j] == (unsigned)q) ? g : 0.f;
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) { if (cact) taps_fetch(tp, x, tile + gridDim.x, cr, cc); cells_fetch(tile + gridDim.x); }
+
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int orow_l = s >> 3, oxb = s & 7;
+      float a[3], b[3];
+      const int arow = (2 * (2 * ph + orow_l)) * RS + 2 * oxb;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[i] = patch[aoff[i] + arow];
+      const int brow = ((2 * ph + orow_l) * 32 + oxb) * DS;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) b[j] = dyt[boff + brow + 16 * j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
+    }
+  }
+
+  float* sw = slab_w + (size_t)(2 * blockIdx.x + ph) * (COUT * CIN * 9);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int mt = 3 * mg + i, tap = mt >> 1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = 16 * (mt & 1) + 4 * lq + r, co = 16 * j + lr;
+        sw[((size_t)co * CIN + ci) * 9 + tap] = acc[i][j][r];
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float v = bsum[j];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((lane & 31) == 0) slab_b[(size_t)blockIdx.x * COUT + ((tid + j * NT) >> 5)] = v;
+  }
+}
+
+// ---- data gradient of conv2 + conv1 ReLU mask + conv1 weight/bias gradient ------------------------
+// 512 threads (8 waves, 2 per SIMD): wave w owns input channels 16*(w&1)..+15 and the band's a1 rows
+// {2pg, 2pg+1} (pg = w>>1): 72 + 144 = 216 MFMAs per band for every wave.  After each row's two
+// parity tiles the lane holds d a1 for 8 consecutive x of one channel; it recomputes a1 there from the
+// image strip staged in LDS (mask), and accumulates dW1[ci][3][3] / db1[ci] in registers.
+constexpr int NT2 = 512;
+constexpr int SRS = 132, STRIP_FLOATS = 17 * SRS;     // image strip rows 16b-1 .. 16b+15, col c <-> ix = c - 1
+
+template <int PY>
+__device__ __forceinline__ void dgrad12_row(const float* dyp, const float* strip, const float (&wr)[9][12],
+                                            const float (&w1r)[9], float b1r, float (&dw1)[9], float& db1,
+                                            int yl, int lr, int lq) {
+  const int yp = yl >> 1;
+  // xh stays a real loop and every 12-MFMA group is fenced for the scheduler: fully unrolled and
+  // unfenced, hipcc hoists all ~150 LDS operand reads of a row to the top (408 registers).
+#pragma unroll 1
+  for (int xh = 0; xh < 2; ++xh) {
+    f32x4_t e = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+    const float* base = dyp + lq * DPS + yp * DRS + 16 * xh + lr;
+    constexpr int NTY = PY ? 2 : 1;
+#pragma unroll
+    for (int ty = 0; ty < NTY; ++ty) {
+      const int ky = PY ? (ty == 0 ? 0 : 2) : 1, doy = (PY && ty == 0) ? 1 : 0;
+#pragma unroll
+      for (int ks = 0; ks < 12; ++ks) e = mfma4(base[ks * 4 * DPS + doy * DRS], wr[ky * 3 + 1][ks], e);          // px = 0: kx = 1
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx) {
+        const int kx = tx == 0 ? 0 : 2, dox = tx == 0 ? 1 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) d = mfma4(base[ks * 4 * DPS + doy * DRS + dox], wr[ky * 3 + kx][ks], d);   // px = 1
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // this lane: channel ci, a1 row yl of the band, columns x0 .. x0+7 (x0 = 32xh + 8lq)
+    // image strip rows 2yl + ky, columns 2*x0 + 2i + kx  (17 values per row)
+    // Two passes over the 3 strip rows (re-read from LDS) keep only one row of 17 values live.
+    const float* sp = strip + (2 * yl) * SRS + 2 * (32 * xh + 8 * lq);
+    float pre[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pre[i] = b1r;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      float t[17];
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {
+        const float4 q = *reinterpret_cast<const float4*>(sp + ky * SRS + 4 * v4);
+        t[4 * v4] = q.x; t[4 * v4 + 1] = q.y; t[4 * v4 + 2] = q.z; t[4 * v4 + 3] = q.w;
+      }
+      t[16] = sp[ky * SRS + 16];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) pre[i] = fmaf(t[2 * i + kx], w1r[ky * 3 + kx], pre[i]);
+    }
+    float g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float gv = (i & 1) ? d[i >> 1] : e[i >> 1];
+      g[i] = pre[i] > 0.f ? gv : 0.f;
+      db1 += g[i];
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      float t[17];
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {
+        const float4 q = *reinterpret_cast<const float4*>(sp + ky * SRS + 4 * v4);
+        t[4 * v4] = q.x; t[4 * v4 + 1] = q.y; t[4 * v4 + 2] = q.z; t[4 * v4 + 3] = q.w;
+      }
+      t[16] = sp[ky * SRS + 16];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float sacc = dw1[ky * 3 + kx];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sacc = fmaf(g[i], t[2 * i + kx], sacc);
+        dw1[ky * 3 + kx] = sacc;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ dp2, const float* __restrict__ p2,
+                                                           const uint8_t* __restrict__ amax, const float* __restrict__ w,
+                                                           float* __restrict__ slab1, int n_img) {
+  __shared__ float lds[DYP_FLOATS + STRIP_FLOATS + 8 * 16 * 10];
+  float* dyp = lds;
+  float* strip = lds + DYP_FLOATS;
+  float* red = strip + STRIP_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = wave & 1, pg = wave >> 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ci = 16 * nt + lr;
+
+  float wr[9][12];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) wr[tap][ks] = w[((size_t)(4 * ks + lq) * CIN + ci) * 9 + tap];
+  float w1r[9], dw1[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { w1r[q] = w1[ci * 9 + q]; dw1[q] = 0.f; }
+  const float b1r = b1[ci];
+  float db1 = 0.f;
+
+  for (int i = tid; i < COUT * 5; i += NT2) dyp[(i / 5) * DPS + (i % 5) * DRS + 32] = 0.f;   // halo column
+  for (int i = tid; i < 17; i += NT2) strip[i * SRS] = 0.f;                                   // ix = -1 column
+  const int ntiles = n_img * 8;
+  float cdp[5], cp[5]; unsigned cam[5];
+  float4 sv[2];
+  auto cells_fetch = [&](int t) {       // 48 co x 3 pooled rows x 16 px = 2304 cells, <= 5 per thread
+    const int img = t >> 3, band = t & 7;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int e = tid + j * NT2, px = e & 15, pyl = (e >> 4) % 3, co = e / 48;
+      const int py = 2 * band + pyl;
+      cdp[j] = 0.f; cp[j] = 0.f; cam[j] = 0;
+      if (e < 2304 && py < 16) {
+        const size_t o = (((size_t)img * COUT + co) * 16 + py) * 16 + px;
+        cdp[j] = dp2[o]; cp[j] = p2[o]; cam[j] = amax[o];
+      }
+    }
+    // image strip: 17 rows x 32 float4
+    const float* xi = x.img(img);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * NT2, row = e >> 5, x4 = e & 31;
+      const int iy = 16 * band - 1 + row;
+      sv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < 17 * 32 && iy >= 0) sv[j] = *reinterpret_cast<const float4*>(xi + iy * 128 + 4 * x4);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) cells_fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int e = tid + j * NT2, px = e & 15, pyl = (e >> 4) % 3, co = e / 48;
+      if (e < 2304) {
+        const float g = cp[j] > 0.f ? cdp[j] : 0.f;
+        float* d = dyp + co * DPS + (2 * pyl) * DRS + 2 * px;
+        d[0] = cam[j] == 0u ? g : 0.f;
+        d[1] = cam[j] == 1u ? g : 0.f;
+        if (pyl < 2) {
+          d[DRS] = cam[j] == 2u ? g : 0.f;
+          d[DRS + 1] = cam[j] == 3u ? g : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * NT2, row = e >> 5, x4 = e & 31;
+      if (e < 17 * 32) {
+        float* d = strip + row * SRS + 1 + 4 * x4;
+        d[0] = sv[j].x; d[1] = sv[j].y; d[2] = sv[j].z; d[3] = sv[j].w;
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) cells_fetch(tile + gridDim.x);
+    dgrad12_row<0>(dyp, strip, wr, w1r, b1r, dw1, db1, 2 * pg, lr, lq);
+    dgrad12_row<1>(dyp, strip, wr, w1r, b1r, dw1, db1, 2 * pg + 1, lr, lq);
+  }
+  // conv1 gradient partials: fold the 4 lq lanes of a channel, then the 4 row-group waves
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { dw1[q] += __shfl_xor(dw1[q], 16, 64); dw1[q] += __shfl_xor(dw1[q], 32, 64); }
+  db1 += __shfl_xor(db1, 16, 64); db1 += __shfl_xor(db1, 32, 64);
+  __syncthreads();
+  if (lq == 0) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) red[(wave * 16 + lr) * 10 + q] = dw1[q];
+    red[(wave * 16 + lr) * 10 + 9] = db1;
+  }
+  __syncthreads();
+  if (tid < 320) {
+    const int c = tid / 10, q = tid % 10, ntc = c >> 4, lrc = c & 15;
+    float sacc = 0.f;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) sacc += red[((2 * g4 + ntc) * 16 + lrc) * 10 + q];
+    slab1[(size_t)blockIdx.x * 320 + tid] = sacc;      // [block][ci][9 weights | bias]
+  }
+}
+
+// slab1 [nblocks][32][10] -> dw1 [32][9], db1 [32]
+__global__ __launch_bounds__(320) void conv1_grads_kernel(const float* __restrict__ slab1, int nblocks, float* __restrict__ dw1, float* __restrict__ db1) {
+  const int tid = threadIdx.x, c = tid / 10, q = tid % 10;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    s0 += slab1[(size_t)b * 320 + tid]; s1 += slab1[(size_t)(b + 1) * 320 + tid];
+    s2 += slab1[(size_t)(b + 2) * 320 + tid]; s3 += slab1[(size_t)(b + 3) * 320 + tid];
+  }
+  for (; b < nblocks; ++b) s0 += slab1[(size_t)b * 320 + tid];
+  const float v = (s0 + s1) + (s2 + s3);
+  if (q < 9) dw1[c * 9 + q] = v; else db1[c] = v;
+}
+
 }  // namespace c2
 }  // namespace mlhot
 #endif  // !MLHOT_HOSTSIM

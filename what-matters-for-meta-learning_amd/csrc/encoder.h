@@ -20,7 +20,7 @@ namespace mlhot {
 
 // Run-time switches (mlhot_set_option): which implementation of a hot-path row runs.  The
 // generic igemm problems are always available as the A/B reference of the specialised kernels.
-struct Options { int conv2_tc; int tail_fused; };
+struct Options { int conv2_tc; int tail_fused; int materialize_a1; };
 extern Options g_opt;
 constexpr int C2_GRID = 256;   // one persistent workgroup per CU
 
@@ -61,7 +61,7 @@ inline size_t enc_slab_floats(int n, int dim_w) {
   v = (size_t)conv3w_split(n) * 64 * 433;       if (v > m) m = v;
   v = (size_t)conv2w_split(n) * 48 * 289;       if (v > m) m = v;
   v = (size_t)conv1w_split(n) * 32 * 10;        if (v > m) m = v;
-  v = (size_t)2 * C2_GRID * 48 * 288 + (size_t)C2_GRID * 48; if (v > m) m = v;   // conv_tc wgrad partials
+  v = (size_t)2 * C2_GRID * 48 * 288 + (size_t)C2_GRID * 48 + (size_t)C2_GRID * 320; if (v > m) m = v;   // conv_tc partials
   return m;
 }
 inline EncScratch enc_scratch_carve(int n, int dim_w, void* base, size_t cap) {
@@ -90,18 +90,21 @@ inline int enc_forward(const float* img0, int n0, const float* img1, int n1, con
   EncScratch sc = enc_scratch_carve(n, dim_w, scratch, scratch_bytes);
   if (!sc.ok) { set_error("enc_vanilla_fwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
   const Src2 x{img0, n0, img1, (size_t)128 * 128};
-  MLHOT_TRY(run_foreach(Conv1Fwd<Src2>{x, p.w1, p.b1, sv.a1}, (size_t)n * 4096, s, "enc.conv1"));
 #ifndef MLHOT_HOSTSIM
   if (g_opt.conv2_tc) {
+    // conv1 + conv2 + pool in one kernel: a1 is recomputed band by band in LDS and never stored
+    if (g_opt.materialize_a1) MLHOT_TRY(run_foreach(Conv1Fwd<Src2>{x, p.w1, p.b1, sv.a1}, (size_t)n * 4096, s, "enc.conv1.debug"));
     const int grid = n * 8 < C2_GRID ? n * 8 : C2_GRID;
     {
-      ProfScope ps("enc.conv2", s);
-      hipLaunchKernelGGL(c2::conv2_fwd_pool_kernel, dim3(grid), dim3(c2::NT), 0, s, sv.a1, p.w2, p.b2, sv.p2, sv.am2, n);
+      ProfScope ps("enc.conv12", s);
+      hipLaunchKernelGGL(c2::conv12_fwd_pool_kernel, dim3(grid), dim3(c2::NT), 0, s, c2::ImgSrc{img0, n0, img1}, p.w1, p.b1,
+                         p.w2, p.b2, sv.p2, sv.am2, n);
     }
-    MLHOT_TRY(check_launch("enc.conv2"));
+    MLHOT_TRY(check_launch("enc.conv12"));
   } else
 #endif
   {
+    MLHOT_TRY(run_foreach(Conv1Fwd<Src2>{x, p.w1, p.b1, sv.a1}, (size_t)n * 4096, s, "enc.conv1"));
     typedef ConvFwd<32, 64, 64, 48, Src1> C2;
     C2 c2{n * 1024, 48, 288, Src1{sv.a1, (size_t)32 * 4096}, p.w2, p.b2, sc.a2};
     MLHOT_TRY((run_igemm<C2, 128, 48, 16, 4, 1>(c2, 1, nullptr, s, "enc.conv2")));
@@ -161,11 +164,13 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     const int grid = n * 8 < C2_GRID ? n * 8 : C2_GRID;
     float* slab_w = sc.slab;
     float* slab_b = sc.slab + (size_t)2 * C2_GRID * 48 * 288;
+    float* slab_1 = slab_b + (size_t)C2_GRID * 48;
+    const c2::ImgSrc xs{img0, n0, img1};
     {
-      ProfScope ps("enc.bwd.conv2.wgrad", s);
-      hipLaunchKernelGGL(c2::conv2_wgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, sv.a1, sc.dp2, sv.p2, sv.am2, slab_w, slab_b, n);
+      ProfScope ps("enc.bwd.conv12.wgrad", s);
+      hipLaunchKernelGGL(c2::conv12_wgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, xs, p.w1, p.b1, sc.dp2, sv.p2, sv.am2, slab_w, slab_b, n);
     }
-    MLHOT_TRY(check_launch("enc.bwd.conv2.wgrad"));
+    MLHOT_TRY(check_launch("enc.bwd.conv12.wgrad"));
     {
       ProfScope ps("slab_reduce", s);
       hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(432), dim3(256), 0, s, slab_w, 2 * grid, 48 * 288, g.w2);
@@ -173,10 +178,15 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     }
     MLHOT_TRY(check_launch("enc.bwd.conv2.wgrad.reduce"));
     {
-      ProfScope ps("enc.bwd.conv2.dgrad", s);
-      hipLaunchKernelGGL(c2::conv2_dgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, sc.dp2, sv.p2, sv.am2, p.w2, sv.a1, sc.dy1, n);
+      ProfScope ps("enc.bwd.conv12.dgrad", s);
+      hipLaunchKernelGGL(c2::conv12_dgrad_kernel, dim3(grid), dim3(c2::NT2), 0, s, xs, p.w1, p.b1, sc.dp2, sv.p2, sv.am2, p.w2, slab_1, n);
     }
-    MLHOT_TRY(check_launch("enc.bwd.conv2.dgrad"));
+    MLHOT_TRY(check_launch("enc.bwd.conv12.dgrad"));
+    {
+      ProfScope ps("slab_reduce", s);
+      hipLaunchKernelGGL(c2::conv1_grads_kernel, dim3(1), dim3(320), 0, s, slab_1, grid, g.w1, g.b1);
+    }
+    return check_launch("enc.bwd.conv1.grads");     // conv1's gradients came out of the dgrad kernel
   } else
 #endif
   {
