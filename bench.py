@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--dbg", type=int, default=0, help="kernel timing experiments (results become WRONG; never a bench line)")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
 
@@ -106,6 +107,8 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     mlhot.build_product()
+    if args.dbg:
+        mlhot.lib().set_option("dbg", args.dbg)
 
     model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(make_cfg(w, device)).to(device)
     loss_fn = LossFunc("mse", "shapenet_1d")

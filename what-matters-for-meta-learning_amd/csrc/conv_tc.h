@@ -432,13 +432,13 @@ __device__ __forceinline__ void conv1_to_patch(const Conv1Taps& tp, const float*
 
 __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                                             float* __restrict__ p2, uint8_t* __restrict__ amax, int n_img) {
+                                                             float* __restrict__ p2, uint8_t* __restrict__ amax, int n_img, int dbg) {
   __shared__ float patch2[2 * PATCH_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
   const int lr = lane & 15, lq = lane >> 4;
   const int n = nt * 16 + lr;
-  const bool cact = tid < 576;
+  const bool cact = tid < 576 && !(dbg & 1);
   const int cr = tid >> 6, cc = tid & 63;
 
   float wr[72];
@@ -509,14 +509,14 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
 __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const float* __restrict__ dp2, const float* __restrict__ p2,
                                                           const uint8_t* __restrict__ amax, float* __restrict__ slab_w,
-                                                          float* __restrict__ slab_b, int n_img) {
+                                                          float* __restrict__ slab_b, int n_img, int dbg) {
   __shared__ float lds[PATCH_FLOATS + DYT_FLOATS];
   float* patch = lds;
   float* dyt = lds + PATCH_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mg = wave % 6, ph = wave / 6;
   const int lr = lane & 15, lq = lane >> 4;
-  const bool cact = tid < 576;
+  const bool cact = tid < 576 && !(dbg & 1);
   const int cr = tid >> 6, cc = tid & 63;
 
   f32x4_t acc[3][3];

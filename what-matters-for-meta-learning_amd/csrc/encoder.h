@@ -20,7 +20,7 @@ namespace mlhot {
 
 // Run-time switches (mlhot_set_option): which implementation of a hot-path row runs.  The
 // generic igemm problems are always available as the A/B reference of the specialised kernels.
-struct Options { int conv2_tc; int tail_fused; int materialize_a1; };
+struct Options { int conv2_tc; int tail_fused; int materialize_a1; int dbg; };
 extern Options g_opt;
 constexpr int C2_GRID = 256;   // one persistent workgroup per CU
 
@@ -98,7 +98,7 @@ inline int enc_forward(const float* img0, int n0, const float* img1, int n1, con
     {
       ProfScope ps("enc.conv12", s);
       hipLaunchKernelGGL(c2::conv12_fwd_pool_kernel, dim3(grid), dim3(c2::NT), 0, s, c2::ImgSrc{img0, n0, img1}, p.w1, p.b1,
-                         p.w2, p.b2, sv.p2, sv.am2, n);
+                         p.w2, p.b2, sv.p2, sv.am2, n, g_opt.dbg);
     }
     MLHOT_TRY(check_launch("enc.conv12"));
   } else
@@ -168,7 +168,7 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     const c2::ImgSrc xs{img0, n0, img1};
     {
       ProfScope ps("enc.bwd.conv12.wgrad", s);
-      hipLaunchKernelGGL(c2::conv12_wgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, xs, p.w1, p.b1, sc.dp2, sv.p2, sv.am2, slab_w, slab_b, n);
+      hipLaunchKernelGGL(c2::conv12_wgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, xs, p.w1, p.b1, sc.dp2, sv.p2, sv.am2, slab_w, slab_b, n, g_opt.dbg);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv12.wgrad"));
     {

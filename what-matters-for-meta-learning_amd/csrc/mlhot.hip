@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-Options g_opt = {1, 1, 0};
+Options g_opt = {1, 1, 0, 0};
 
 #ifndef MLHOT_HOSTSIM
 // ---- per-launch event profiler -------------------------------------------------------------------
@@ -55,6 +55,7 @@ int mlhot_set_option(const char* name, int value) {
   if (!strcmp(name, "conv2_tc")) { g_opt.conv2_tc = value; return MLHOT_OK; }
   if (!strcmp(name, "tail_fused")) { g_opt.tail_fused = value; return MLHOT_OK; }
   if (!strcmp(name, "materialize_a1")) { g_opt.materialize_a1 = value; return MLHOT_OK; }
+  if (!strcmp(name, "dbg")) { g_opt.dbg = value; return MLHOT_OK; }   // timing experiments only (results become wrong)
   set_error("mlhot_set_option: unknown option %s", name);
   return MLHOT_ERR_ARG;
 }
