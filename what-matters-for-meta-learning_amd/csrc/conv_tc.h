@@ -468,7 +468,11 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ p2, uint8_t* __restrict__ amax, int n_img, int dbg) {
   (void)dbg;
-  __shared__ float patch2[2 * PATCH_FLOATS];
+  // conv1's 288 weights + 32 biases live in LDS: read from global they would be scalar loads, whose
+  // out-of-order lgkmcnt forces a full LDS drain before every use and stalls the MFMA operand stream
+  __shared__ float patch2[2 * PATCH_FLOATS + 320];
+  float* c1w = patch2 + 2 * PATCH_FLOATS;
+  for (int i = threadIdx.x; i < 320; i += NT) c1w[i] = i < 288 ? w1[i] : b1[i - 288];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
   const int lr = lane & 15, lq = lane >> 4;
@@ -490,10 +494,12 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   float tp[3][9];
   if (tile < ntiles) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      c1_taps(tp[i], x, tile, irow[i], cc);
-      c1_compute8(tp[i], w1, b1, patch2, tile, irow[i], igrp[i], cc);
-    }
+    for (int i = 0; i < 3; ++i) c1_taps(tp[i], x, tile, irow[i], cc);
+  }
+  __syncthreads();                       // c1w and the zero pads are in place
+  if (tile < ntiles) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c1_compute8(tp[i], c1w, c1w + 288, patch2, tile, irow[i], igrp[i], cc);
     if (tile + (int)gridDim.x < ntiles) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) c1_taps(tp[i], x, tile + gridDim.x, irow[i], cc);
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int seg = 0; seg < 6; ++seg) {
-      if (seg < 3) c1_compute8(tp[seg], w1, b1, nb, next, irow[seg], igrp[seg], cc);
+      if (seg < 3) c1_compute8(tp[seg], c1w, c1w + 288, nb, next, irow[seg], igrp[seg], cc);
 #pragma unroll
       for (int q = 0; q < 12; ++q) {
         const int ks = seg * 12 + q;
@@ -521,15 +527,6 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
         const float x1 = ab[cg * 4 * PS + (2 + ky) * RS + kx];
         acc0 = mfma4(x0, wr[ks], acc0);
         acc1 = mfma4(x1, wr[ks], acc1);
-      }
-      if (seg < 3) {
-        // weave: per MFMA one pair of operand reads and ~4 of the segment's ~100 conv1 VALU ops
-#pragma unroll
-        for (int q = 0; q < 24; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU
-        }
       }
       if (seg == 4 && next + (int)gridDim.x < ntiles) {
 #pragma unroll
