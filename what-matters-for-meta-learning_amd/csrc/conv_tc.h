@@ -430,57 +430,16 @@ __device__ __forceinline__ void conv1_to_patch(const Conv1Taps& tp, const float*
   }
 }
 
-// conv1 work items of the forward kernel, balanced over all 12 waves and branch-free so the
-// scheduler can weave them between the MFMAs: wave `slot` = tid>>6 handles 3 items of (patch row,
-// 8-channel group) for its 64 columns: slots 0..8 -> (row = slot, groups 0,1,2); slots 9..11 ->
-// (rows 3(slot-9)+{0,1,2}, group 3).  Everything about an item is wave-uniform.
-__device__ __forceinline__ void c1_item(int slot, int item, int& row, int& grp) {
-  if (slot < 9) { row = slot; grp = item; } else { row = 3 * (slot - 9) + item; grp = 3; }
-}
-__device__ __forceinline__ void c1_taps(float (&t)[9], const ImgSrc& x, int tile, int row, int cc) {
-  const int img = tile >> 3, band = tile & 7;
-  const float* xi = x.img(img);
-  const int iy1 = 8 * band - 1 + row;
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int iy = 2 * iy1 + ky - 1, ix = 2 * cc + kx - 1;
-      t[ky * 3 + kx] = (iy1 >= 0 && iy >= 0 && ix >= 0) ? xi[iy * 128 + ix] : 0.f;
-    }
-}
-__device__ __forceinline__ void c1_compute8(const float (&t)[9], const float* __restrict__ w1, const float* __restrict__ b1,
-                                            float* patch, int tile, int row, int grp, int cc) {
-  const bool valid = 8 * (tile & 7) - 1 + row >= 0;
-  float* d = patch + (grp * 8) * PS + row * RS + 1 + cc;
-  const float* wg = w1 + grp * 72;
-  const float* bg = b1 + grp * 8;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    float sacc = bg[c];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) sacc = fmaf(t[q], wg[c * 9 + q], sacc);
-    d[c * PS] = valid ? fmaxf(sacc, 0.f) : 0.f;
-  }
-}
-
 __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ p2, uint8_t* __restrict__ amax, int n_img, int dbg) {
-  (void)dbg;
-  // conv1's 288 weights + 32 biases live in LDS: read from global they would be scalar loads, whose
-  // out-of-order lgkmcnt forces a full LDS drain before every use and stalls the MFMA operand stream
-  __shared__ float patch2[2 * PATCH_FLOATS + 320];
-  float* c1w = patch2 + 2 * PATCH_FLOATS;
-  for (int i = threadIdx.x; i < 320; i += NT) c1w[i] = i < 288 ? w1[i] : b1[i - 288];
+  __shared__ float patch2[2 * PATCH_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
   const int lr = lane & 15, lq = lane >> 4;
   const int n = nt * 16 + lr;
-  const int slot = __builtin_amdgcn_readfirstlane(wave), cc = tid & 63;
-  int irow[3], igrp[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) c1_item(slot, i, irow[i], igrp[i]);
+  const bool cact = tid < 576 && !(dbg & 1);
+  const int cr = tid >> 6, cc = tid & 63;
 
   float wr[72];
 #pragma unroll
@@ -491,34 +450,24 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   patch_zero_pad(patch2 + PATCH_FLOATS, tid);
   const int ntiles = n_img * 8;
   int tile = blockIdx.x;
-  float tp[3][9];
-  if (tile < ntiles) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) c1_taps(tp[i], x, tile, irow[i], cc);
-  }
-  __syncthreads();                       // c1w and the zero pads are in place
-  if (tile < ntiles) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) c1_compute8(tp[i], c1w, c1w + 288, patch2, tile, irow[i], igrp[i], cc);
-    if (tile + (int)gridDim.x < ntiles) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) c1_taps(tp[i], x, tile + gridDim.x, irow[i], cc);
-    }
+  Conv1Taps tp;
+  if (tile < ntiles && cact) {
+    taps_fetch(tp, x, tile, cr, cc);
+    conv1_to_patch<0, 32>(tp, w1, b1, patch2, tile, cr, cc);
+    if (tile + (int)gridDim.x < ntiles) taps_fetch(tp, x, tile + gridDim.x, cr, cc);
   }
   __syncthreads();
   const int aoff = lq * PS + (4 * rp) * RS + 2 * (16 * ch + lr);
   int cur = 0;
   for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
     const float* ab = patch2 + cur * PATCH_FLOATS + aoff;
-    // the last band of a workgroup has nothing to stage: it recomputes into the idle buffer anyway
-    // (branch-free code is what lets the scheduler interleave), from taps that are simply stale
     float* nb = patch2 + (cur ^ 1) * PATCH_FLOATS;
     const int next = tile + (int)gridDim.x;
+    const bool stage = next < ntiles && cact;
 
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int seg = 0; seg < 6; ++seg) {
-      if (seg < 3) c1_compute8(tp[seg], c1w, c1w + 288, nb, next, irow[seg], igrp[seg], cc);
 #pragma unroll
       for (int q = 0; q < 12; ++q) {
         const int ks = seg * 12 + q;
@@ -528,10 +477,14 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
         acc0 = mfma4(x0, wr[ks], acc0);
         acc1 = mfma4(x1, wr[ks], acc1);
       }
-      if (seg == 4 && next + (int)gridDim.x < ntiles) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) c1_taps(tp[i], x, next + gridDim.x, irow[i], cc);
+      // the next band's a1 slice, 8 channels per segment, on the VALU between the MFMAs
+      if (stage) {
+        if (seg == 0) conv1_to_patch<0, 8>(tp, w1, b1, nb, next, cr, cc);
+        if (seg == 1) conv1_to_patch<8, 16>(tp, w1, b1, nb, next, cr, cc);
+        if (seg == 2) conv1_to_patch<16, 24>(tp, w1, b1, nb, next, cr, cc);
+        if (seg == 3) conv1_to_patch<24, 32>(tp, w1, b1, nb, next, cr, cc);
       }
+      if (seg == 4 && cact && next + (int)gridDim.x < ntiles) taps_fetch(tp, x, next + gridDim.x, cr, cc);
     }
     const int img = tile >> 3, band = tile & 7;
     float pv[2]; unsigned pa[2];
