@@ -168,7 +168,7 @@ inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   FavorDims f{d.T, MLHOT_HEADS, d.Nq, d.Nc, d.dim_w, d.m_feat};
   FavorWs w = favor_carve(f, b.favor, b.favor_bytes);
   if (!w.ok) { set_error("tail_fused: favor workspace"); return MLHOT_ERR_WORKSPACE; }
-  tf::PhaseAArgs a{td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, b.vh, b.qh, w.pc, w.max_k, w.arg_k};
+  tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, b.vh, b.qh, w.pc, w.max_k, w.arg_k};
   MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
   tf::PhaseBArgs bb{td, b.qh, b.kh, b.vh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged};
   MLHOT_TRY(tail_launch(tf::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 256, tf::phaseB_lds_bytes(td), bb, s, "tail.B"));

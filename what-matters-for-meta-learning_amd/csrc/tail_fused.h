@@ -37,54 +37,97 @@ struct WB {            // weight given as `nb` row blocks [rows][K] (nb = 1 for 
 
 // ---- Y[16 x N] = act(X[16 x K] W^T + b).  X in LDS (row stride ldx, finite everywhere), W from
 // global: lane (n = lr, k-group lq) loads W[n][k0+4lq .. +3] as one float4 and X[lr][k0+4lq..+3] from
-// LDS, feeding 4 MFMAs whose k order is permuted identically on both operands.  N-tiles round-robin
-// over the NW waves.  Output goes to LDS (ys) and/or global (yg, first nrows rows).
+// LDS, feeding 4 MFMAs whose k order is permuted identically on both operands.
+// The chain is latency-bound (weights come from L2/HBM), so each wave works on up to 4 N-tiles AT ONCE
+// (their weight loads are all in flight together and share the A operand), and when there are fewer
+// N-tiles than waves the K range is split over the idle waves and folded through `red` (LDS,
+// NW*256 floats; may be nullptr when N >= 16*NW).  Contains barriers when it splits: call from all waves.
 template <int NW>
 __device__ __forceinline__ void wg_linear(const float* xs, int ldx, int K, const WB& wb, int N, int act,
-                                          float* ys, int ldy, float* yg, int ldg, int nrows, int wave, int lane) {
+                                          float* ys, int ldy, float* yg, int ldg, int nrows, float* red, int wave, int lane) {
   const int lr = lane & 15, lq = lane >> 4;
-  for (int nt = wave; nt * 16 < N; nt += NW) {
-    const int n = nt * 16 + lr;
-    const bool vn = n < N;
-    // block of this N-tile (wave-uniform: block rows are multiples of 16 whenever nb > 1); selected
-    // with an unrolled compare chain so the pointer table never becomes a runtime-indexed array
-    const int blk = (nt * 16) / wb.rows, rr = vn ? n - blk * wb.rows : 0;
-    const float* wsel = wb.w[0];
-    const float* bsel = wb.b[0];
+  const int ntile = (N + 15) / 16;
+  int nchunk = 1;
+  if (red != nullptr && ntile * 2 <= NW) nchunk = NW / ntile;
+  const int kblocks = (K + 15) / 16, per = (kblocks + nchunk - 1) / nchunk;
+  const bool vec = (K & 3) == 0;
+  int tpw = (ntile + NW - 1) / NW;               // N-tiles a wave handles together
+  if (tpw > 4) tpw = 4;
+  if (nchunk > 1) tpw = 1;
+  for (int it0 = 0; it0 < ntile * nchunk; it0 += NW * tpw) {
+    const int it = it0 + wave * tpw;
+    const int tile0 = nchunk > 1 ? it % ntile : it, chunk = nchunk > 1 ? it / ntile : 0;
+    const bool active = it < ntile * nchunk;
+    f32x4_t acc[4];
+    const float* wrow[4]; bool vn[4]; const float* bsel[4]; int rr[4];
 #pragma unroll
-    for (int i = 1; i < H; ++i)
-      if (blk == i) { wsel = wb.w[i]; bsel = wb.b[i]; }
-    const float* wrow = wsel + (size_t)rr * K;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const bool vec = (K & 3) == 0;
-#pragma unroll 4
-    for (int k0 = 0; k0 < K; k0 += 16) {
-      const int kk = k0 + 4 * lq;
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (vn) {
-        if (vec) { if (kk < K) b = *reinterpret_cast<const float4*>(wrow + kk); }
-        else {
-          if (kk < K) b.x = wrow[kk];
-          if (kk + 1 < K) b.y = wrow[kk + 1];
-          if (kk + 2 < K) b.z = wrow[kk + 2];
-          if (kk + 3 < K) b.w = wrow[kk + 3];
+    for (int q = 0; q < 4; ++q) {
+      acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int tile = tile0 + q, n = tile * 16 + lr;
+      vn[q] = active && q < tpw && n < N;
+      const int blk = (tile * 16) / wb.rows;       // wave-uniform (block rows are multiples of 16 when nb > 1)
+      rr[q] = vn[q] ? n - blk * wb.rows : 0;
+      const float* wsel = wb.w[0]; bsel[q] = wb.b[0];
+#pragma unroll
+      for (int i = 1; i < H; ++i)
+        if (blk == i) { wsel = wb.w[i]; bsel[q] = wb.b[i]; }
+      wrow[q] = wsel + (size_t)rr[q] * K;
+    }
+    const int kb0 = chunk * per, kb1 = active ? (kb0 + per < kblocks ? kb0 + per : kblocks) : kb0;
+#pragma unroll 2
+    for (int kb = kb0; kb < kb1; ++kb) {
+      const int kk = kb * 16 + 4 * lq;
+      float4 b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        b[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vn[q]) {
+          if (vec) { if (kk < K) b[q] = *reinterpret_cast<const float4*>(wrow[q] + kk); }
+          else {
+            if (kk < K) b[q].x = wrow[q][kk];
+            if (kk + 1 < K) b[q].y = wrow[q][kk + 1];
+            if (kk + 2 < K) b[q].z = wrow[q][kk + 2];
+            if (kk + 3 < K) b[q].w = wrow[q][kk + 3];
+          }
         }
       }
       const float* xp = xs + lr * ldx + kk;
-      acc = mfma4(xp[0], b.x, acc);
-      acc = mfma4(xp[1], b.y, acc);
-      acc = mfma4(xp[2], b.z, acc);
-      acc = mfma4(xp[3], b.w, acc);
-    }
-    float bias = 0.f;
-    if (vn && bsel) bias = bsel[rr];
-    if (vn) {
+      const float a0 = xp[0], a1 = xp[1], a2 = xp[2], a3 = xp[3];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * lq + r;
-        const float v = act_apply(act, acc[r] + bias);
-        if (ys) ys[row * ldy + n] = v;
-        if (yg && row < nrows) yg[(size_t)row * ldg + n] = v;
+      for (int q = 0; q < 4; ++q) {
+        acc[q] = mfma4(a0, b[q].x, acc[q]);
+        acc[q] = mfma4(a1, b[q].y, acc[q]);
+        acc[q] = mfma4(a2, b[q].z, acc[q]);
+        acc[q] = mfma4(a3, b[q].w, acc[q]);
+      }
+    }
+    if (nchunk > 1) {                              // fold the K chunks (fixed order); tpw == 1 here
+      if (active && chunk > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[0][r];
+      }
+      __syncthreads();
+      if (active && chunk == 0) {
+        for (int c = 1; c < nchunk; ++c) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[0][r] += red[((wave + c * ntile) * 4 + r) * 64 + lane];
+        }
+      }
+      __syncthreads();
+    }
+    if (chunk == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!vn[q]) continue;
+        const int n = (tile0 + q) * 16 + lr;
+        const float bias = bsel[q] ? bsel[q][rr[q]] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * lq + r;
+          const float v = act_apply(act, acc[q][r] + bias);
+          if (ys) ys[row * ldy + n] = v;
+          if (yg && row < nrows) yg[(size_t)row * ldg + n] = v;
+        }
       }
     }
   }
@@ -136,6 +179,7 @@ __host__ __device__ constexpr int ldpad(int w) { return (w + 15) / 16 * 16 + 4; 
 //   qh = W_q(x_qry); pc = c * P (task 0); per-task max / arg-max of ddk = kh_h pc^T over (row, head, j).
 // ==================================================================================================
 struct PhaseAArgs {
+  int dbg;              // timing experiments: early exits (results become wrong)
   TailDims d; TailParams p;
   const float* ctx_y;
   float *cat_in, *h0, *h1, *rs, *dec_in, *kh, *vh, *qh;   // saved activations (global)
@@ -156,8 +200,8 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   float* s_kh = s_rs + 16 * Lrs;         // [16][Lkh]
   float* s_xq = s_kh + 16 * Lkh;
   float* s_y = s_xq + 16 * Lxq;
-  float* s_red = s_y + 16 * Ly;          // [8 waves][2]
-  const int total = 16 * (Lcat + Lh0 + Lh1 + Lrs + Lkh + Lxq + Ly) + 32;
+  float* s_red = s_y + 16 * Ly;          // [8 waves][256] K-split partials of wg_linear; later the max reduction
+  const int total = 16 * (Lcat + Lh0 + Lh1 + Lrs + Lkh + Lxq + Ly) + 8 * 256;
   lds_zero(lds, total, tid, 512);
   __syncthreads();
   float* g_cat = a.cat_in + (size_t)t * d.Nc * ldc;
@@ -170,53 +214,65 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
     for (int i = tid; i < d.m * d.dw; i += 512) a.pc[i] = c * a.p.proj[i];
   }
   __syncthreads();
+  if (a.dbg & 2) return;
   // transform_y -> cat[:, dw:]
-  wg_linear<8>(s_y, Ly, d.label_dim, wb1(a.p.ty_w, a.p.ty_b, d.dw / 4), d.dw / 4, ACT_NONE, s_cat + d.dw, Lcat, g_cat + d.dw, ldc, d.Nc, wave, lane);
+  wg_linear<8>(s_y, Ly, d.label_dim, wb1(a.p.ty_w, a.p.ty_b, d.dw / 4), d.dw / 4, ACT_NONE, s_cat + d.dw, Lcat, g_cat + d.dw, ldc, d.Nc, nullptr, wave, lane);
   // Q projection only needs x_qry: issue it alongside
-  wg_linear<8>(s_xq, Lxq, d.dw, wb8(a.p.wq_w, a.p.wq_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, a.qh + (size_t)t * d.Nq * H * d.dw, H * d.dw, d.Nq, wave, lane);
+  wg_linear<8>(s_xq, Lxq, d.dw, wb8(a.p.wq_w, a.p.wq_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, a.qh + (size_t)t * d.Nq * H * d.dw, H * d.dw, d.Nq, nullptr, wave, lane);
   // K projection needs x_ctx only
-  wg_linear<8>(s_cat, Lcat, d.dw, wb8(a.p.wk_w, a.p.wk_b, d.dw), H * d.dw, ACT_NONE, s_kh, Lkh, a.kh + (size_t)t * d.Nc * H * d.dw, H * d.dw, d.Nc, wave, lane);
+  wg_linear<8>(s_cat, Lcat, d.dw, wb8(a.p.wk_w, a.p.wk_b, d.dw), H * d.dw, ACT_NONE, s_kh, Lkh, a.kh + (size_t)t * d.Nc * H * d.dw, H * d.dw, d.Nc, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_cat, Lcat, ldc, wb1(a.p.er_w[0], a.p.er_b[0], d.h0), d.h0, ACT_RELU, s_h0, Lh0, a.h0 + (size_t)t * d.Nc * d.h0, d.h0, d.Nc, wave, lane);
+  if (a.dbg & 4) return;
+  wg_linear<8>(s_cat, Lcat, ldc, wb1(a.p.er_w[0], a.p.er_b[0], d.h0), d.h0, ACT_RELU, s_h0, Lh0, a.h0 + (size_t)t * d.Nc * d.h0, d.h0, d.Nc, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_h0, Lh0, d.h0, wb1(a.p.er_w[1], a.p.er_b[1], d.h1), d.h1, ACT_RELU, s_h1, Lh1, a.h1 + (size_t)t * d.Nc * d.h1, d.h1, d.Nc, wave, lane);
+  wg_linear<8>(s_h0, Lh0, d.h0, wb1(a.p.er_w[1], a.p.er_b[1], d.h1), d.h1, ACT_RELU, s_h1, Lh1, a.h1 + (size_t)t * d.Nc * d.h1, d.h1, d.Nc, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_h1, Lh1, d.h1, wb1(a.p.er_w[2], a.p.er_b[2], d.dw), d.dw, ACT_NONE, s_rs, Lrs, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, wave, lane);
+  wg_linear<8>(s_h1, Lh1, d.h1, wb1(a.p.er_w[2], a.p.er_b[2], d.dw), d.dw, ACT_NONE, s_rs, Lrs, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, s_red, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_rs, Lrs, d.dw, wb8(a.p.wv_w, a.p.wv_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, a.vh + (size_t)t * d.Nc * H * d.dw, H * d.dw, d.Nc, wave, lane);
+  wg_linear<8>(s_rs, Lrs, d.dw, wb8(a.p.wv_w, a.p.wv_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, a.vh + (size_t)t * d.Nc * H * d.dw, H * d.dw, d.Nc, nullptr, wave, lane);
 
+  if (a.dbg & 8) return;
   // key-stabiliser share: max over (row < Nc, head, feature j) of ddk = c * kh_h . P[j]   (fast_attention.py:97)
   // (c * P is recomputed from proj here so this phase does not depend on task 0's pc write)
   const int lr = lane & 15, lq = lane >> 4;
   const float c = powf((float)d.dw, -0.25f);
   float best = -INFINITY; int brow = 0, bcol = 0;
   const int ntile = (d.m + 15) / 16;
-  for (int it = wave; it < ntile * H; it += 8) {
-    const int jt = it % ntile, h = it / ntile;
+  // feature tiles round-robin over the waves; a tile's slice of c*P is loaded ONCE (dw/16 float4 per
+  // lane, all in flight together) and reused by all 8 heads (8 accumulators)
+  for (int jt = wave; jt < ntile; jt += 8) {
     const int j = jt * 16 + lr;
     const bool vj = j < d.m;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int k0 = 0; k0 < d.dw; k0 += 16) {
       const int kk = k0 + 4 * lq;
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
       if (vj) b = *reinterpret_cast<const float4*>(a.p.proj + (size_t)j * d.dw + kk);
-      const float* xp = s_kh + lr * Lkh + h * d.dw + kk;
-      acc = mfma4(xp[0], c * b.x, acc);
-      acc = mfma4(xp[1], c * b.y, acc);
-      acc = mfma4(xp[2], c * b.z, acc);
-      acc = mfma4(xp[3], c * b.w, acc);
+      b.x *= c; b.y *= c; b.z *= c; b.w *= c;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float* xp = s_kh + lr * Lkh + h * d.dw + kk;
+        acc[h] = mfma4(xp[0], b.x, acc[h]);
+        acc[h] = mfma4(xp[1], b.y, acc[h]);
+        acc[h] = mfma4(xp[2], b.z, acc[h]);
+        acc[h] = mfma4(xp[3], b.w, acc[h]);
+      }
     }
     if (vj) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * lq + r;
-        if (row < d.Nc) {
-          const int grow = (t * d.Nc + row) * H + h;      // row index of the [T*Nc*H, m] view
-          const float v = acc[r];
-          if (v > best || (v == best && (grow < brow || (grow == brow && j < bcol)))) { best = v; brow = grow; bcol = j; }
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * lq + r;
+          if (row < d.Nc) {
+            const int grow = (t * d.Nc + row) * H + h;      // row index of the [T*Nc*H, m] view
+            const float v = acc[h][r];
+            if (v > best || (v == best && (grow < brow || (grow == brow && j < bcol)))) { best = v; brow = grow; bcol = j; }
+          }
         }
-      }
     }
   }
   // reduce (max, first arg-max in (row, col) order) over the workgroup
@@ -241,7 +297,7 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
 
 __host__ inline size_t phaseA_lds_bytes(const TailDims& d) {
   const int ldc = d.dw + d.dw / 4;
-  return sizeof(float) * (16 * (ldpad(ldc) + ldpad(d.h0) + ldpad(d.h1) + ldpad(d.dw) + ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.label_dim)) + 32);
+  return sizeof(float) * (16 * (ldpad(ldc) + ldpad(d.h0) + ldpad(d.h1) + ldpad(d.dw) + ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.label_dim)) + 8 * 256);
 }
 
 // ==================================================================================================
@@ -284,28 +340,28 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   for (int i = 1; i < d.T; ++i) if (a.tmax[i] > gm) { gm = a.tmax[i]; gt = i; }
   if (blockIdx.x == 0 && tid == 0) { a.gmax[0] = gm; a.gpos[0] = a.targ[2 * gt]; a.gpos[1] = a.targ[2 * gt + 1]; }
   __syncthreads();
-  // dd tiles: q and k against pc (B operand streamed from L2)
+  // dd tiles: q and k against pc; a feature tile's pc slice is loaded once (all float4 in flight
+  // together) and feeds both the query and the key accumulator
   const int ntile = (d.m + 15) / 16;
-  for (int it = wave; it < 2 * ntile; it += 4) {
-    const int isk = it >= ntile, jt = isk ? it - ntile : it;
-    const float* xs = isk ? s_k : s_q;
-    float* fs = isk ? s_kf : s_qf;
+  for (int jt = wave; jt < ntile; jt += 4) {
     const int j = jt * 16 + lr;
     const bool vj = j < d.m;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t accq = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int k0 = 0; k0 < d.dw; k0 += 16) {
       const int kk = k0 + 4 * lq;
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
       if (vj) b = *reinterpret_cast<const float4*>(a.pc + (size_t)j * d.dw + kk);
-      const float* xp = xs + lr * Lx + kk;
-      acc = mfma4(xp[0], b.x, acc);
-      acc = mfma4(xp[1], b.y, acc);
-      acc = mfma4(xp[2], b.z, acc);
-      acc = mfma4(xp[3], b.w, acc);
+      const float* xq = s_q + lr * Lx + kk;
+      const float* xk = s_k + lr * Lx + kk;
+      accq = mfma4(xq[0], b.x, accq); acck = mfma4(xk[0], b.x, acck);
+      accq = mfma4(xq[1], b.y, accq); acck = mfma4(xk[1], b.y, acck);
+      accq = mfma4(xq[2], b.z, accq); acck = mfma4(xk[2], b.z, acck);
+      accq = mfma4(xq[3], b.w, accq); acck = mfma4(xk[3], b.w, acck);
     }
     if (vj) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) fs[(4 * lq + r) * Lf + j] = acc[r];
+      for (int r = 0; r < 4; ++r) { s_qf[(4 * lq + r) * Lf + j] = accq[r]; s_kf[(4 * lq + r) * Lf + j] = acck[r]; }
     }
   }
   // diag = c^2/2 |x|^2 : 32 rows (16 q + 16 k), 8 threads per row
@@ -421,25 +477,26 @@ __global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
   float* s_dec = s_rr + 16 * Lr;
   float* s_d1 = s_dec + 16 * Ld;
   float* s_d2 = s_d1 + 16 * Lh;
+  float* s_red = s_d2 + 16 * Lh;    // [8 waves][256] K-split partials of wg_linear
   lds_zero(lds, 16 * (Lm + Lr + Ld + 2 * Lh), tid, 512);
   __syncthreads();
   float* g_dec = a.dec_in + (size_t)t * d.Nq * ldd;
   lds_load(s_m, Lm, a.merged + (size_t)t * d.Nq * HD, HD, d.Nq, HD, tid, 512);
   lds_load(s_dec, Ld, g_dec, ldd, d.Nq, d.dw, tid, 512);          // x_qry
   __syncthreads();
-  wg_linear<8>(s_m, Lm, HD, wb1(a.p.wo_w, a.p.wo_b, d.dw), d.dw, ACT_NONE, s_rr, Lr, a.rr + (size_t)t * d.Nq * d.dw, d.dw, d.Nq, wave, lane);
+  wg_linear<8>(s_m, Lm, HD, wb1(a.p.wo_w, a.p.wo_b, d.dw), d.dw, ACT_NONE, s_rr, Lr, a.rr + (size_t)t * d.Nq * d.dw, d.dw, d.Nq, s_red, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_rr, Lr, d.dw, wb1(a.p.r2z_w, a.p.r2z_b, d.dz), d.dz, ACT_NONE, s_dec + d.dw, Ld, g_dec + d.dw, ldd, d.Nq, wave, lane);
+  wg_linear<8>(s_rr, Lr, d.dw, wb1(a.p.r2z_w, a.p.r2z_b, d.dz), d.dz, ACT_NONE, s_dec + d.dw, Ld, g_dec + d.dw, ldd, d.Nq, s_red, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_dec, Ld, ldd, wb1(a.p.dec_w[0], a.p.dec_b[0], d.dec_h), d.dec_h, ACT_RELU, s_d1, Lh, a.d1 + (size_t)t * d.Nq * d.dec_h, d.dec_h, d.Nq, wave, lane);
+  wg_linear<8>(s_dec, Ld, ldd, wb1(a.p.dec_w[0], a.p.dec_b[0], d.dec_h), d.dec_h, ACT_RELU, s_d1, Lh, a.d1 + (size_t)t * d.Nq * d.dec_h, d.dec_h, d.Nq, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_d1, Lh, d.dec_h, wb1(a.p.dec_w[1], a.p.dec_b[1], d.dec_h), d.dec_h, ACT_RELU, s_d2, Lh, a.d2 + (size_t)t * d.Nq * d.dec_h, d.dec_h, d.Nq, wave, lane);
+  wg_linear<8>(s_d1, Lh, d.dec_h, wb1(a.p.dec_w[1], a.p.dec_b[1], d.dec_h), d.dec_h, ACT_RELU, s_d2, Lh, a.d2 + (size_t)t * d.Nq * d.dec_h, d.dec_h, d.Nq, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_d2, Lh, d.dec_h, wb1(a.p.dec_w[2], a.p.dec_b[2], d.y_dim), d.y_dim, d.out_act, nullptr, 0, a.mu + (size_t)t * d.Nq * d.y_dim, d.y_dim, d.Nq, wave, lane);
+  wg_linear<8>(s_d2, Lh, d.dec_h, wb1(a.p.dec_w[2], a.p.dec_b[2], d.y_dim), d.y_dim, d.out_act, nullptr, 0, a.mu + (size_t)t * d.Nq * d.y_dim, d.y_dim, d.Nq, s_red, wave, lane);
 }
 
 __host__ inline size_t phaseC_lds_bytes(const TailDims& d) {
-  return sizeof(float) * 16 * (ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.dw + d.dz) + 2 * ldpad(d.dec_h));
+  return sizeof(float) * (16 * (ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.dw + d.dz) + 2 * ldpad(d.dec_h)) + 8 * 256);
 }
 
 // ==================================================================================================
