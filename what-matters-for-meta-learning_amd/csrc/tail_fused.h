@@ -42,8 +42,11 @@ struct WB {            // weight given as `nb` row blocks [rows][K] (nb = 1 for 
 // (their weight loads are all in flight together and share the A operand), and when there are fewer
 // N-tiles than waves the K range is split over the idle waves and folded through `red` (LDS,
 // NW*256 floats; may be nullptr when N >= 16*NW).  Contains barriers when it splits: call from all waves.
+// NOT inlined on purpose: these kernels run each layer exactly once per workgroup, so with every
+// layer's unrolled body inlined the kernel was 56 KB of straight-line code and was bound by cold
+// instruction fetch (~3 us per layer whatever its size); as one shared function the code stays hot.
 template <int NW>
-__device__ __forceinline__ void wg_linear(const float* xs, int ldx, int K, const WB& wb, int N, int act,
+__device__ __attribute__((noinline)) void wg_linear(const float* xs, int ldx, int K, const WB& wb, int N, int act,
                                           float* ys, int ldy, float* yg, int ldg, int nrows, float* red, int wave, int lane) {
   const int lr = lane & 15, lq = lane >> 4;
   const int ntile = (N + 15) / 16;
@@ -506,7 +509,7 @@ __host__ inline size_t phaseC_lds_bytes(const TailDims& d) {
 // dW[Nout][Kin] = dY^T X (sum over the 16 rows; padded rows of dY are zero), db = column sums of dY.
 // Output tiles (16 j x 16 i) round-robin over the waves, 4 MFMAs each; results go to the task's slab.
 template <int NW>
-__device__ __forceinline__ void wg_wgrad(const float* dys, int ldy, int Nout, const float* xs, int ldx, int Kin,
+__device__ __attribute__((noinline)) void wg_wgrad(const float* dys, int ldy, int Nout, const float* xs, int ldx, int Kin,
                                          float* dw, float* db, int wave, int lane, int tid) {
   const int lr = lane & 15, lq = lane >> 4;
   const int nj = (Nout + 15) / 16, ni = (Kin + 15) / 16;
@@ -544,7 +547,7 @@ __device__ __forceinline__ void wg_wgrad(const float* dys, int ldy, int Nout, co
 // float4 of dY from LDS, B = 4 coalesced dwords of W.  Result to LDS (dxs) and/or global (dxg: rows
 // < nrows; accumulate adds to what is there).  Contains barriers: call from all waves.
 template <int NW>
-__device__ __forceinline__ void wg_dgrad(const float* dys, int ldy, int Nout, const WB& wb, int Kin,
+__device__ __attribute__((noinline)) void wg_dgrad(const float* dys, int ldy, int Nout, const WB& wb, int Kin,
                                          float* dxs, int ldxs, float* dxg, int ldg, int nrows, bool accumulate,
                                          float* red, int wave, int lane) {
   const int lr = lane & 15, lq = lane >> 4;
