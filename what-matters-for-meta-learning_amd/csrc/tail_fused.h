@@ -212,9 +212,11 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   lds_load(s_cat, Lcat, g_cat, ldc, d.Nc, d.dw, tid, 512);                       // x_ctx (encoder output)
   lds_load(s_xq, Lxq, g_dec, ldd, d.Nq, d.dw, tid, 512);                         // x_qry
   lds_load(s_y, Ly, a.ctx_y + (size_t)t * d.Nc * d.label_dim, d.label_dim, d.Nc, d.label_dim, tid, 512);
-  if (t == 0) {
+  {   // pc = c * P for the later phases: each task writes its slice (one workgroup doing all of it
+      // was a 16 us serial tail on the whole kernel)
     const float c = powf((float)d.dw, -0.25f);
-    for (int i = tid; i < d.m * d.dw; i += 512) a.pc[i] = c * a.p.proj[i];
+    const int n = d.m * d.dw, per = (n + d.T - 1) / d.T, lo = t * per, hi = lo + per < n ? lo + per : n;
+    for (int i = lo + tid; i < hi; i += 512) a.pc[i] = c * a.p.proj[i];
   }
   __syncthreads();
   if (a.dbg & 2) return;
