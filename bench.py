@@ -36,7 +36,12 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = 
 def alg_flops(label, n_img):
     """Algorithmic FLOPs of ONE launch carrying `label` (2 x MACs of the layer)."""
     pos2 = n_img * 1024
+    conv1 = 2.0 * n_img * 4096 * 32 * 9
     table = {
+        # conv1-fused kernels: conv2's work plus conv1's own (the halo recompute is not algorithmic work)
+        "enc.conv12": 2.0 * pos2 * 48 * 288 + conv1,
+        "enc.bwd.conv12.wgrad": 2.0 * pos2 * 48 * 288,
+        "enc.bwd.conv12.dgrad": 2.0 * pos2 * 32 * 48 * 9 + conv1,   # conv2 data gradient + conv1 weight gradient
         "enc.conv2": 2.0 * pos2 * 48 * 288,
         "enc.bwd.conv2.wgrad": 2.0 * pos2 * 48 * 288,
         "enc.bwd.conv2.dgrad": 2.0 * pos2 * 32 * 48 * 9,          # all 4 parity classes in one launch
