@@ -12,6 +12,7 @@
 #pragma once
 #include "encoder.h"
 #include "tail_fused.h"
+#include "tail_cnp.h"
 
 namespace mlhot {
 
@@ -85,6 +86,12 @@ inline NpScratch np_scratch_carve(const mlhot_np_dims& d, void* base, size_t cap
     } else {
       s.dzt = a.take<float>((size_t)d.T * d.dim_z); s.dr = a.take<float>((size_t)d.T * d.dim_r);
       if (d.agg_mode == MLHOT_AGG_BACO) { s.d_mu_l = a.take<float>(Rc * d.dim_r); s.d_lv = a.take<float>(Rc * d.dim_r); }
+#ifndef MLHOT_HOSTSIM
+      if (d.n_hidden == 2 && d.agg_mode != MLHOT_AGG_BACO) {
+        const tf::CnpDims cd{d.T, d.Nc, d.Nq, d.label_dim, d.y_dim, dw, d.dim_r, d.dim_z, d.hidden[0], d.hidden[1], d.dec_hidden, 0, d.agg_mode};
+        s.tail_slab = a.take<float>((size_t)d.T * tf::cnp_slab_layout(cd).total);
+      }
+#endif
     }
   }
   s.ok = a.ok; s.bytes = a.off + 256;
@@ -177,6 +184,54 @@ inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   return MLHOT_OK;
 }
 
+// ---- fused CNP tail (csrc/tail_cnp.h) ---------------------------------------------------------------
+inline bool cnp_fused_applies(const mlhot_np_dims& d) {
+  return g_opt.tail_fused && (d.agg_mode == MLHOT_AGG_MEAN || d.agg_mode == MLHOT_AGG_MAX) && d.Nc >= 1 && d.Nc <= 16 &&
+         d.Nq <= 16 && d.n_hidden == 2 && d.dim_w % 16 == 0 && d.dim_r <= 128;
+}
+inline tf::CnpDims cnp_dims(const mlhot_np_dims& d) {
+  return tf::CnpDims{d.T, d.Nc, d.Nq, d.label_dim, d.y_dim, d.dim_w, d.dim_r, d.dim_z, d.hidden[0], d.hidden[1], d.dec_hidden,
+                     d.out_tanh ? ACT_TANH : ACT_NONE, d.agg_mode};
+}
+inline tf::CnpParams cnp_params(const mlhot_np_params& p) {
+  tf::CnpParams q;
+  q.ty_w = p.ty_w; q.ty_b = p.ty_b; q.r2z_w = p.r2z_w; q.r2z_b = p.r2z_b;
+  for (int i = 0; i < 3; ++i) { q.er_w[i] = p.er_w[i]; q.er_b[i] = p.er_b[i]; q.dec_w[i] = p.dec_w[i]; q.dec_b[i] = p.dec_b[i]; }
+  return q;
+}
+inline int cnp_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, float* mu, const NpBuf& b, hipStream_t s) {
+  const tf::CnpDims cd = cnp_dims(d);
+  tf::CnpFwdArgs a{cd, cnp_params(p), ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.r, b.zt, b.dec_in, b.d1, b.d2, mu, b.amax};
+  return tail_launch(tf::cnp_fwd_kernel, d.T, 512, tf::cnp_fwd_lds_bytes(cd), a, s, "tail.cnp");
+}
+inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu, const float* dmu,
+                              const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s) {
+  const tf::CnpDims cd = cnp_dims(d);
+  const tf::CnpSlab sl = tf::cnp_slab_layout(cd);
+  if (!sc.tail_slab) { set_error("cnp_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
+  tf::CnpBwdArgs a{cd, cnp_params(p), sl, ctx_y, dmu, mu, b.d2, b.d1, b.dec_in, b.r, b.rs, b.h[1], b.h[0], b.cat_in, b.amax,
+                   sc.d_dec_in, sc.d_cat_in, sc.tail_slab};
+  MLHOT_TRY(tail_launch(tf::cnp_bwd_kernel, d.T, 512, tf::cnp_bwd_lds_bytes(cd), a, s, "tail.bwd.cnp"));
+  tf::SlabReduce r{};
+  int ns = 0, maxlen = 0;
+  auto seg = [&](float* dst, int off, int len) { r.dst[ns] = dst; r.off[ns] = off; r.len[ns] = len; if (len > maxlen) maxlen = len; ++ns; };
+  const int dw = d.dim_w, ldc = dw + dw / 4, ldd = dw + d.dim_z;
+  seg(g.ty_w, sl.ty_w, dw / 4 * d.label_dim); seg(g.ty_b, sl.ty_b, dw / 4);
+  seg(g.er_w[0], sl.er_w[0], cd.h0 * ldc); seg(g.er_b[0], sl.er_b[0], cd.h0);
+  seg(g.er_w[1], sl.er_w[1], cd.h1 * cd.h0); seg(g.er_b[1], sl.er_b[1], cd.h1);
+  seg(g.er_w[2], sl.er_w[2], cd.dr * cd.h1); seg(g.er_b[2], sl.er_b[2], cd.dr);
+  seg(g.r2z_w, sl.r2z_w, d.dim_z * cd.dr); seg(g.r2z_b, sl.r2z_b, d.dim_z);
+  seg(g.dec_w[0], sl.dec_w[0], cd.dec_h * ldd); seg(g.dec_b[0], sl.dec_b[0], cd.dec_h);
+  seg(g.dec_w[1], sl.dec_w[1], cd.dec_h * cd.dec_h); seg(g.dec_b[1], sl.dec_b[1], cd.dec_h);
+  seg(g.dec_w[2], sl.dec_w[2], d.y_dim * cd.dec_h); seg(g.dec_b[2], sl.dec_b[2], d.y_dim);
+  r.nseg = ns; r.T = d.T; r.total = sl.total; r.slab = sc.tail_slab;
+  {
+    ProfScope ps("tail.bwd.reduce", s);
+    hipLaunchKernelGGL(tf::slab_to_grads_kernel, dim3((maxlen + 255) / 256, ns), dim3(256), 0, s, r);
+  }
+  return check_launch("tail.bwd.reduce");
+}
+
 inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu,
                                const float* dmu, const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s) {
   const tf::TailDims td = tail_dims(d);
@@ -234,6 +289,7 @@ inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const fl
   MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s));
 #ifndef MLHOT_HOSTSIM
   if (tail_fused_applies(d)) return tail_forward_fused(d, p, ctx_y, mu, b, s);
+  if (cnp_fused_applies(d)) return cnp_forward_fused(d, p, ctx_y, mu, b, s);
 #endif
 
   if (d.Nc > 0) {
@@ -286,8 +342,9 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
   const int out_act = d.out_tanh ? ACT_TANH : ACT_NONE;
 
 #ifndef MLHOT_HOSTSIM
-  if (tail_fused_applies(d)) {
-    MLHOT_TRY(tail_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s));
+  if (tail_fused_applies(d) || cnp_fused_applies(d)) {
+    if (tail_fused_applies(d)) MLHOT_TRY(tail_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s));
+    else MLHOT_TRY(cnp_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s));
     return enc_backward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{sc.d_cat_in, ldc, Rc, sc.d_dec_in, ldd}, b.enc, g.enc, sc.enc, sc.enc_bytes, s);
   }
 #endif
