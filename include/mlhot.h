@@ -118,6 +118,30 @@ int mlhot_loss_fwd(int kind, const float* mu, const float* gt, int rows, int y_d
 int mlhot_loss_bwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim,
                    const float* dloss, float* dmu, void* stream);
 
+/* ---- E2 / D2: ResNet encoder building blocks --------------------------------------------------
+ * nn.Conv2d (cross-correlation, zero padding, NCHW, weight [Cout,Cin,k,k], optional fused ReLU) for
+ * the 5x5 s2 p2 stem, the 3x3 s2 / s1 p1 block convs and the 1x1 s2 (3x3 in the BBB twin) skip of
+ * ImageEncoder / NPDecoder (networks/models.py:63-192, networks/ResNet.py:25-74).  Backward: `y` is
+ * the forward output (used for the ReLU mask when relu=1); dx / dw / db may be NULL.               */
+size_t mlhot_conv2d_bwd_scratch_bytes(int N, int Cin, int H, int W, int Cout, int k, int stride, int pad);
+int mlhot_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W, int Cout, int k,
+                     int stride, int pad, int relu, void* stream);
+int mlhot_conv2d_bwd(const float* x, const float* w, const float* y, const float* dy, int N, int Cin, int H, int W, int Cout, int k,
+                     int stride, int pad, int relu, float* dx, float* dw, float* db, void* scratch, size_t scratch_bytes, void* stream);
+/* residual join y = relu(a + b) (ResNet.py:69-72); backward g = dy * (y > 0) is the gradient of both inputs */
+int mlhot_add_relu_fwd(const float* a, const float* b, float* y, size_t n, void* stream);
+int mlhot_add_relu_bwd(const float* y, const float* dy, float* g, size_t n, void* stream);
+/* 2x2 max-pool over `planes` maps of H x W (nn.AdaptiveMaxPool2d((2,2)) on 4x4 maps, models.py:107-110) */
+int mlhot_pool2_fwd(const float* x, float* y, uint8_t* amax, int planes, int H, int W, void* stream);
+int mlhot_pool2_bwd(const float* dy, const uint8_t* amax, float* dx, int planes, int H, int W, void* stream);
+
+/* ---- B1: Bayes-by-backprop weight sample + KL (bbb/BBBConv.py:86-108, bbb/BBBLinear.py:79-101) ----
+ * w = mu + eps * log1p(exp(rho)); kl = sum 0.5*(2 log(sigma/0.1) - 1 + (0.1/sigma)^2 + (mu/sigma)^2).
+ * eps is drawn by the caller on the torch CPU generator (parity with BBBConv.py:88). klterm: n floats. */
+int mlhot_bbb_sample_fwd(const float* mu, const float* rho, const float* eps, float* w, float* klterm, float* kl, size_t n, void* stream);
+int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, const float* dw, const float* dkl, float* dmu, float* drho,
+                         size_t n, void* stream);
+
 /* ---- whole vanilla CNP/ANP model: forward + backward in one call each --------------------
  * replaces <Model>.forward for CNPVanillaPascal1D / CNPShapeNet1D / ANPVanillaPascal1D /
  * ANPShapeNet1D (CNPShapeNet1D.py:96-140, ANPShapeNet1D.py:93-157) and its autograd backward. */

@@ -225,6 +225,64 @@ def vanilla_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, tanh, taps=None):
 
 
 # --------------------------------------------------------------------------------------
+# E2 / D2  ResNet encoder, NPDecoder and the ResNet-based CNP / ANP   (models.py:63-192,
+#          ResNet.py:58-74, CondNeuralProcess.py:77-119, ANP.py:100-130; Appendix A.5)
+# --------------------------------------------------------------------------------------
+
+
+def resnet_features(img, p, prefix, img_agg, skip_pad=0):
+    """5x5 s2 p2 stem + ReLU; 4 x {conv3x3 s2 + ReLU, conv3x3 s1, + skip conv (1x1 s2, or 3x3 p1 s2
+    in the BBB twin), ReLU}; then img_agg.  img [n,C,H,W] -> [n,F]."""
+    x = F.relu(F.conv2d(img, p[prefix + "conv1.weight"], p[prefix + "conv1.bias"], stride=2, padding=2))
+    for i in range(1, 5):
+        q = f"{prefix}resnet.layer{i}.0."
+        out = F.relu(F.conv2d(x, p[q + "conv1.weight"], p[q + "conv1.bias"], stride=2, padding=1))
+        out = F.conv2d(out, p[q + "conv2.weight"], p[q + "conv2.bias"], stride=1, padding=1)
+        idn = F.conv2d(x, p[q + "downsample.0.weight"], p[q + "downsample.0.bias"], stride=2, padding=skip_pad)
+        x = F.relu(out + idn)
+    if img_agg in ("max", "baco"):
+        x = F.adaptive_max_pool2d(x, (2, 2))
+    elif img_agg == "mean":
+        x = F.adaptive_avg_pool2d(x, (1, 1))
+    return x.reshape(x.shape[0], -1)
+
+
+def resnet_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, img_agg, n_heads=8):
+    """CondNeuralProcess / ANP forward.  ctx_x [T,Nc,C,H,W], ctx_y [T,Nc,L], qry_x [T,Nq,C,H,W] -> mu [T,Nq,y]."""
+    T, Nq = qry_x.shape[:2]
+    Nc = ctx_x.shape[1]
+    flat = lambda t: t.reshape(-1, *t.shape[2:])
+    if Nc:
+        x_ctx = resnet_features(flat(ctx_x), p, "img_encoder.", img_agg).reshape(T, Nc, -1)
+        h = torch.cat([x_ctx, ctx_y], dim=2)
+        for i in (0, 2, 4):
+            h = F.relu(F.linear(h, p[f"task_encoder.{i}.weight"], p[f"task_encoder.{i}.bias"]))
+        if agg_mode == "attention":
+            x_tgt = resnet_features(flat(qry_x), p, "img_encoder.", img_agg).reshape(T, Nq, -1)
+            r = multihead_attention(x_ctx, h, x_tgt, p, n_heads=n_heads)
+            sample = F.linear(r, p["mu.weight"], p["mu.bias"])
+        else:
+            if agg_mode == "mean":
+                r = agg_mean(h)
+            elif agg_mode == "max":
+                r = agg_max(h)
+            elif agg_mode == "baco":
+                mu_l = F.linear(h, p["latent_mu.weight"], p["latent_mu.bias"])
+                var = 1e-5 + F.softplus(F.linear(h, p["latent_var.weight"], p["latent_var.bias"]))
+                r, _ = agg_baco(mu_l, var)
+            else:
+                raise TypeError(agg_mode)
+            sample = F.linear(r, p["mu.weight"], p["mu.bias"])[:, None, :].expand(T, Nq, -1)
+    else:
+        sample = torch.zeros(T, Nq, 256, dtype=qry_x.dtype)
+    x_dec = resnet_features(flat(qry_x), p, "decoder.", img_agg).reshape(T, Nq, -1)
+    h = torch.cat([x_dec, sample], dim=-1)
+    h = F.relu(F.linear(h, p["decoder.fc_mu.0.weight"], p["decoder.fc_mu.0.bias"]))
+    h = F.relu(F.linear(h, p["decoder.fc_mu.2.weight"], p["decoder.fc_mu.2.bias"]))
+    return F.linear(h, p["decoder.fc_mu.4.weight"], p["decoder.fc_mu.4.bias"])
+
+
+# --------------------------------------------------------------------------------------
 # L1  losses                                                   (trainer/losses.py:32-80)
 # --------------------------------------------------------------------------------------
 

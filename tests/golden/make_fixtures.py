@@ -110,6 +110,56 @@ MODEL_CASES = {
 }
 
 
+# ResNet-encoder family: name -> (method, cfg, Nc, Nq, image channels fed to forward)
+RESNET_CASES = {
+    "r_anp_shapenet3d": ("ANP", dict(task="shapenet_3d", img_size=[64, 64, 4], tasks_per_batch=2, input_dim=4, output_dim=4,
+                                     agg_mode="attention", img_agg="reshape", seed=2578, temperature=0.07), 3, 4, 3),
+    "r_cnp_shapenet3d_max": ("CondNeuralProcess", dict(task="shapenet_3d", img_size=[64, 64, 4], tasks_per_batch=2, input_dim=4,
+                                                       output_dim=4, agg_mode="max", img_agg="reshape", seed=2578), 4, 3, 3),
+    "r_cnp_distractor_baco": ("CondNeuralProcess", dict(task="distractor", img_size=[128, 128, 1], tasks_per_batch=1, input_dim=2,
+                                                        output_dim=2, agg_mode="baco", img_agg="max", seed=2578), 3, 2, 1),
+    "r_cnp_shapenet3d_nc0": ("CondNeuralProcess", dict(task="shapenet_3d", img_size=[64, 64, 4], tasks_per_batch=1, input_dim=4,
+                                                       output_dim=4, agg_mode="mean", img_agg="reshape", seed=2578), 0, 2, 3),
+}
+
+
+def run_resnet_case(name, method, cfgd, Nc, Nq, C, LossFunc):
+    cfg = types.SimpleNamespace(device=torch.device("cpu"), **cfgd)
+    model = getattr(importlib.import_module(f"networks.{method}"), method)(cfg)
+    T = cfg.tasks_per_batch
+    H, W, _ = cfg.img_size
+    cx, qx, cy, qy = make_inputs(T, Nc, Nq, C, H, W, cfg.input_dim)
+    if cfg.task == "shapenet_3d":                       # unit quaternions with q[1] >= 0 (shapenet_3d.py:226-227)
+        qy = torch.nn.functional.normalize(qy - 0.5, dim=-1)
+        qy = torch.where(qy[..., 1:2] < 0, -qy, qy)
+    model.train()
+    mu, var, kl = model(cx, cy, qx)
+    assert var is None
+    loss = LossFunc("mse", cfg.task).calc_loss(mu, var, qy)
+    loss.backward()
+    out = {"mu": np32(mu), "loss": np.float64(loss.item()), "qy": np32(qy)}
+    state_sha, grad_norm = {k: sha(v) for k, v in model.state_dict().items()}, {}
+    if hasattr(model, "attn"):
+        out["projection_matrix"] = np32(model.attn.projection_matrix)
+    for k, prm in model.named_parameters():
+        if prm.grad is None:
+            grad_norm[k] = None
+            continue
+        gnp = np32(prm.grad)
+        grad_norm[k] = float(np.linalg.norm(gnp.astype(np.float64)))
+        if gnp.nbytes <= 16 * 1024:
+            out["grad/" + k] = gnp
+        else:
+            flat = gnp.reshape(-1)
+            out["gradhead/" + k] = flat[:1024].copy()
+            out["gradstride/" + k] = flat[1::61][:4096].copy()
+    meta = dict(name=name, method=method, cfg=cfgd, Nc=Nc, Nq=Nq, C=C, input_seed=1234, state_sha=state_sha, grad_norm=grad_norm,
+                input_sha=dict(cx=sha(cx), qx=sha(qx), cy=sha(cy)), n_params=sum(p.numel() for p in model.parameters()))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.8f} sum(mu)={mu.sum().item():.8f} params={meta['n_params']}")
+
+
 def make_inputs(T, Nc, Nq, C, H, W, L):
     g = torch.Generator().manual_seed(1234)
     cx = torch.rand(T, Nc, C, H, W, generator=g)
@@ -287,6 +337,10 @@ def main():
         if only and name not in only:
             continue
         run_model_case(name, method, over, Nc, Nq, LossFunc)
+    for name, (method, cfgd, Nc, Nq, C) in RESNET_CASES.items():
+        if only and name not in only:
+            continue
+        run_resnet_case(name, method, cfgd, Nc, Nq, C, LossFunc)
     if not only or "favor" in only:
         run_favor_cases()
     if not only or "losses" in only:

@@ -15,7 +15,7 @@ from tests import util as U
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", U.model_case_names())
+@pytest.mark.parametrize("name", U.model_case_names() + U.resnet_case_names())
 def test_plugin_lookup_and_state_dict(name):
     """train.py:41-45: importlib.import_module(f"networks.{method}") + getattr(module, method)(config)."""
     fx, meta = U.load_case(name)

@@ -216,6 +216,24 @@ def test_model_baseline_configs_vs_reference(gpulib, tail_impl, name):
     _run_case(name, grad_tol=U.RTOL if name.startswith("c1") else FULL_SIZE_GRAD_TOL)
 
 
+@pytest.mark.parametrize("name", U.resnet_case_names())
+def test_resnet_models_vs_reference(gpulib, name):
+    """ResNet-encoder CondNeuralProcess / ANP (ShapeNet3D 64x64x3 quaternions, Distractor 128x128x1)
+    through the plugin boundary: run-time-shaped conv kernels, linears, aggregators, FAVOR+ (d=256, m=1419)."""
+    fx, meta = U.load_case(name)
+    model = U.build_model(meta, DEV, fx=fx).to(DEV)
+    cx, qx, cy, qy = (t.to(DEV) for t in U.resnet_case_inputs(meta, fx))
+    from trainer.losses import LossFunc
+    mu, var, kl = model(cx, cy, qx)
+    assert var is None and kl == 0
+    loss = LossFunc("mse", meta["cfg"]["task"]).calc_loss(mu, var, qy)
+    loss.backward()
+    assert U.rel_err(mu, fx["mu"]) <= U.RTOL
+    assert abs(loss.item() - float(fx["loss"])) <= U.RTOL * max(1.0, abs(float(fx["loss"])))
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
+
+
 def test_forward_is_deterministic_and_task_independent(gpulib):
     """Size-independent properties at the full c3 size: bitwise run-to-run determinism, and
     (tasks are independent apart from the FAVOR+ global key stabiliser) a task's output does not

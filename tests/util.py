@@ -80,11 +80,28 @@ def case_inputs(meta):
     return cx, qx, cy, qy
 
 
+def resnet_case_names():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "r_*.npz")))
+
+
+def resnet_case_inputs(meta, fx):
+    c = meta["cfg"]
+    T, Nc, Nq, C = c["tasks_per_batch"], meta["Nc"], meta["Nq"], meta["C"]
+    H, W, _ = c["img_size"]
+    g = torch.Generator().manual_seed(meta["input_seed"])
+    cx = torch.rand(T, Nc, C, H, W, generator=g)
+    qx = torch.rand(T, Nq, C, H, W, generator=g)
+    cy = torch.rand(T, Nc, c["input_dim"], generator=g)
+    for k, t in (("cx", cx), ("qx", qx), ("cy", cy)):
+        assert sha(t) == meta["input_sha"][k], f"input {k} does not regenerate from the seed"
+    return cx, qx, cy, torch.from_numpy(fx["qy"])
+
+
 def loss_kind(task):
     return {"shapenet_1d": "azimuth", "pascal_1d": "mse", "shapenet_3d": "quaternion", "distractor": "distractor"}[task]
 
 
-def check_grads_against_fixture(grads, fx, meta, tol=RTOL):
+def check_grads_against_fixture(grads, fx, meta, tol=RTOL, head=4096, stride_cap=None):
     """grads: dict key -> tensor (or None).  Compares with the fixture's full / sampled grads."""
     gmax = 0.0
     for k in grads:
@@ -105,7 +122,8 @@ def check_grads_against_fixture(grads, fx, meta, tol=RTOL):
             e = rel_err(g, fx["grad/" + k], floor)
         else:
             flat = g.reshape(-1)
-            e = max(rel_err(flat[:4096], fx["gradhead/" + k], floor), rel_err(flat[1::61], fx["gradstride/" + k], floor))
+            strided = flat[1::61] if stride_cap is None else flat[1::61][:stride_cap]
+            e = max(rel_err(flat[:head], fx["gradhead/" + k], floor), rel_err(strided, fx["gradstride/" + k], floor))
             assert abs(float(flat.double().norm()) - want_norm) <= tol * max(want_norm, floor), f"{k}: grad norm"
         if e > worst[0]:
             worst = (e, k)

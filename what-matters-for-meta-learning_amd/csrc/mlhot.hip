@@ -10,6 +10,7 @@
 #include "favor.h"
 #include "encoder.h"
 #include "np_vanilla.h"
+#include "conv_rt.h"
 #include "../../include/mlhot.h"
 
 namespace mlhot {
@@ -172,6 +173,46 @@ int mlhot_loss_bwd(int kind, const float* mu, const float* gt, int rows, int y_d
                    float* dmu, void* stream) {
   if (kind < 0 || kind > 4 || rows <= 0 || y_dim <= 0 || y_dim > 8 || gt_dim < 1) { set_error("loss_bwd: bad argument"); return MLHOT_ERR_ARG; }
   return run_foreach(LossBwd{kind, y_dim, gt_dim, rows, mu, gt, dloss, dmu}, (size_t)rows, (hipStream_t)stream, "loss_bwd");
+}
+
+// ---- E2 / D2 building blocks: run-time-shaped conv, residual join, 2x2 max-pool; B1: BBB sample -------
+size_t mlhot_conv2d_bwd_scratch_bytes(int N, int Cin, int H, int W, int Cout, int k, int stride, int pad) {
+  return conv_bwd_scratch_bytes(conv_shape(N, Cin, H, W, Cout, k, stride, pad));
+}
+int mlhot_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W, int Cout, int k,
+                     int stride, int pad, int relu, void* stream) {
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0 || pad < 0 || H + 2 * pad < k || W + 2 * pad < k) {
+    set_error("conv2d_fwd: bad argument"); return MLHOT_ERR_ARG;
+  }
+  return conv_rt_forward(conv_shape(N, Cin, H, W, Cout, k, stride, pad), x, w, b, y, relu, (hipStream_t)stream);
+}
+int mlhot_conv2d_bwd(const float* x, const float* w, const float* y, const float* dy, int N, int Cin, int H, int W, int Cout, int k,
+                     int stride, int pad, int relu, float* dx, float* dw, float* db, void* scratch, size_t scratch_bytes, void* stream) {
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0 || pad < 0) { set_error("conv2d_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  return conv_rt_backward(conv_shape(N, Cin, H, W, Cout, k, stride, pad), x, w, relu ? y : nullptr, dy, dx, dw, db, scratch, scratch_bytes,
+                          (hipStream_t)stream);
+}
+int mlhot_add_relu_fwd(const float* a, const float* b, float* y, size_t n, void* stream) {
+  return run_foreach(AddRelu{a, b, y}, n, (hipStream_t)stream, "add_relu.fwd");
+}
+int mlhot_add_relu_bwd(const float* y, const float* dy, float* g, size_t n, void* stream) {
+  return run_foreach(AddReluBwd{y, dy, g}, n, (hipStream_t)stream, "add_relu.bwd");
+}
+int mlhot_pool2_fwd(const float* x, float* y, uint8_t* amax, int planes, int H, int W, void* stream) {
+  if (planes <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) { set_error("pool2_fwd: bad argument"); return MLHOT_ERR_ARG; }
+  return run_foreach(Pool2Fwd{x, y, amax, H, W}, (size_t)planes * (H / 2) * (W / 2), (hipStream_t)stream, "pool2.fwd");
+}
+int mlhot_pool2_bwd(const float* dy, const uint8_t* amax, float* dx, int planes, int H, int W, void* stream) {
+  if (planes <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) { set_error("pool2_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  return run_foreach(Pool2Bwd{dy, amax, dx, H, W}, (size_t)planes * H * W, (hipStream_t)stream, "pool2.bwd");
+}
+int mlhot_bbb_sample_fwd(const float* mu, const float* rho, const float* eps, float* w, float* klterm, float* kl, size_t n, void* stream) {
+  MLHOT_TRY(run_foreach(BbbSample{mu, rho, eps, w, klterm}, n, (hipStream_t)stream, "bbb.sample"));
+  return run_reduce1(SumRed{klterm, kl}, (int)n, (hipStream_t)stream, "bbb.kl");
+}
+int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, const float* dw, const float* dkl, float* dmu, float* drho,
+                         size_t n, void* stream) {
+  return run_foreach(BbbSampleBwd{mu, rho, eps, dw, dkl, dmu, drho}, n, (hipStream_t)stream, "bbb.sample.bwd");
 }
 
 // ---- whole model ------------------------------------------------------------------------------

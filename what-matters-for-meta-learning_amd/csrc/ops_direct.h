@@ -63,6 +63,42 @@ struct Pool2Fwd {
   }
 };
 
+// residual join of a BasicBlock: y = relu(a + b)  (ResNet.py:69-72) and its backward g = dy * (y > 0)
+struct AddRelu { const float* a; const float* b; float* y; MLHOT_HD void operator()(size_t i) const { const float v = a[i] + b[i]; y[i] = v > 0.f ? v : 0.f; } };
+struct AddReluBwd { const float* y; const float* dy; float* g; MLHOT_HD void operator()(size_t i) const { g[i] = y[i] > 0.f ? dy[i] : 0.f; } };
+// max-pool backward: route dp to the window arg-max (dx must be pre-zeroed by construction: every element written)
+struct Pool2Bwd {
+  const float* dp; const uint8_t* amax; float* dx; int H, W;   // H, W: input size
+  MLHOT_HD void operator()(size_t i) const {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const size_t plane = i / ((size_t)W * H);
+    const size_t o = plane * (H / 2) * (W / 2) + (size_t)(y >> 1) * (W / 2) + (x >> 1);
+    dx[i] = amax[o] == (((y & 1) << 1) | (x & 1)) ? dp[o] : 0.f;
+  }
+};
+// Bayes-by-backprop weight sample W = mu + eps * softplus(rho) and its KL term per element
+// (bbb/BBBConv.py:86-108; calculate_kl is called as (mu_q=0, sig_q=0.1, mu_p=mu, sig_p=sigma)):
+//   kl_i = 0.5 * (2 log(sigma/0.1) - 1 + (0.1/sigma)^2 + (mu/sigma)^2)
+struct BbbSample {
+  const float* mu; const float* rho; const float* eps; float* w; float* klterm;
+  MLHOT_HD void operator()(size_t i) const {
+    const float sg = log1pf(expf(rho[i]));
+    w[i] = mu[i] + eps[i] * sg;
+    const float q = 0.1f / sg, z = mu[i] / sg;
+    klterm[i] = 0.5f * (2.f * logf(sg / 0.1f) - 1.f + q * q + z * z);
+  }
+};
+struct BbbSampleBwd {   // dmu = dw + dkl * mu/sigma^2 ; drho = (dw*eps + dkl * (1/sigma - 0.01/sigma^3 - mu^2/sigma^3)) * sigmoid(rho)
+  const float* mu; const float* rho; const float* eps; const float* dw; const float* dkl; float* dmu; float* drho;
+  MLHOT_HD void operator()(size_t i) const {
+    const float sg = log1pf(expf(rho[i])), g = dkl[0];
+    const float inv = 1.f / sg;
+    dmu[i] = dw[i] + g * mu[i] * inv * inv;
+    const float dsig = dw[i] * eps[i] + g * (inv - 0.01f * inv * inv * inv - mu[i] * mu[i] * inv * inv * inv);
+    drho[i] = dsig / (1.f + expf(-rho[i]));
+  }
+};
+
 struct FillF { float* p; float v; MLHOT_HD void operator()(size_t i) const { p[i] = v; } };
 
 // strided 2-D fill: rows x cols window of a [rows][ld] matrix

@@ -139,6 +139,90 @@ struct ConvWgrad {
 };
 
 // ------------------------------------------------------------------------------------------
+// Run-time-shaped convolution (any k, stride, padding; NCHW) for the ResNet encoders of the
+// ShapeNet3D / Distractor models: 5x5 s2 p2 stem, 3x3 s2 / s1 p1 block convs, 1x1 s2 (3x3 in the
+// BBB twin) skip (networks/models.py:87-115, networks/ResNet.py:25-74).  Same three GEMM views
+// as the templated problems above; shapes are ordinary members so one instantiation serves every
+// layer (index arithmetic costs more - these layers are functional in round 1, not yet tuned).
+// ------------------------------------------------------------------------------------------
+struct ConvShape {
+  int N, Cin, H, W, Cout, k, s, p, HO, WO;
+};
+
+struct ConvFwdRT {
+  static constexpr bool A_ALONG_K = false, B_ALONG_K = true;
+  int M, N, K;
+  ConvShape c;
+  const float* x; const float* w; const float* b; float* y; int relu;
+  MLHOT_HD float A(int m, int k) const {
+    const int hw = c.HO * c.WO, img = m / hw, r = m % hw, oy = r / c.WO, ox = r % c.WO;
+    const int kk = c.k * c.k, ci = k / kk, t = k % kk, ky = t / c.k, kx = t % c.k;
+    const int iy = oy * c.s + ky - c.p, ix = ox * c.s + kx - c.p;
+    if (iy < 0 || iy >= c.H || ix < 0 || ix >= c.W) return 0.f;
+    return x[(((size_t)img * c.Cin + ci) * c.H + iy) * c.W + ix];
+  }
+  MLHOT_HD float B(int k, int n) const { return w[(size_t)n * K + k]; }
+  MLHOT_HD void store(int m, int n, float v) const {
+    const int hw = c.HO * c.WO, img = m / hw, r = m % hw;
+    if (b) v += b[n];
+    if (relu && v < 0.f) v = 0.f;
+    y[((size_t)img * c.Cout + n) * hw + r] = v;
+  }
+};
+
+// data gradient for the class of input positions y = s*y' + py, x = s*x' + px: only taps with
+// ky = ky0 + s*ty (ky0 = (py + p) mod s) reach them, from output row oy = (y + p - ky) / s.
+struct ConvDgradRT {
+  static constexpr bool A_ALONG_K = false, B_ALONG_K = false;
+  int M, N, K;
+  ConvShape c;
+  int py, px, ky0, kx0, nty, ntx, ny, nx;     // class geometry (ny x nx positions per image)
+  const float* dy; const float* yact;         // yact: forward output, for the ReLU mask (or nullptr)
+  const float* w; float* dx;
+  MLHOT_HD float A(int m, int k) const {
+    const int img = m / (ny * nx), r = m % (ny * nx), yp = r / nx, xp = r % nx;
+    const int co = k % c.Cout, tt = k / c.Cout, tx = tt % ntx, ty = tt / ntx;
+    const int ky = ky0 + c.s * ty, kx = kx0 + c.s * tx;
+    const int oy = (c.s * yp + py + c.p - ky) / c.s, ox = (c.s * xp + px + c.p - kx) / c.s;
+    if (oy < 0 || oy >= c.HO || ox < 0 || ox >= c.WO) return 0.f;
+    const size_t o = (((size_t)img * c.Cout + co) * c.HO + oy) * c.WO + ox;
+    return (yact == nullptr || yact[o] > 0.f) ? dy[o] : 0.f;
+  }
+  MLHOT_HD float B(int k, int n) const {
+    const int co = k % c.Cout, tt = k / c.Cout, tx = tt % ntx, ty = tt / ntx;
+    return w[(((size_t)co * c.Cin + n) * c.k + ky0 + c.s * ty) * c.k + kx0 + c.s * tx];
+  }
+  MLHOT_HD void store(int m, int n, float v) const {
+    const int img = m / (ny * nx), r = m % (ny * nx), yp = r / nx, xp = r % nx;
+    dx[(((size_t)img * c.Cin + n) * c.H + c.s * yp + py) * c.W + c.s * xp + px] = v;
+  }
+};
+
+struct ConvWgradRT {
+  static constexpr bool A_ALONG_K = true, B_ALONG_K = true;
+  int M, N, K;            // M = Cout, N = Cin*k*k + 1, K = N*HO*WO
+  ConvShape c;
+  const float* dy; const float* yact; const float* x; float* dw; float* db;
+  MLHOT_HD float A(int m, int k) const {
+    const int hw = c.HO * c.WO, img = k / hw, r = k % hw;
+    const size_t o = ((size_t)img * c.Cout + m) * hw + r;
+    return (yact == nullptr || yact[o] > 0.f) ? dy[o] : 0.f;
+  }
+  MLHOT_HD float B(int k, int n) const {
+    if (n == N - 1) return 1.f;
+    const int hw = c.HO * c.WO, img = k / hw, r = k % hw, oy = r / c.WO, ox = r % c.WO;
+    const int kk = c.k * c.k, ci = n / kk, t = n % kk, ky = t / c.k, kx = t % c.k;
+    const int iy = oy * c.s + ky - c.p, ix = ox * c.s + kx - c.p;
+    if (iy < 0 || iy >= c.H || ix < 0 || ix >= c.W) return 0.f;
+    return x[(((size_t)img * c.Cin + ci) * c.H + iy) * c.W + ix];
+  }
+  MLHOT_HD void store(int m, int n, float v) const {
+    if (n == N - 1) { if (db) db[m] = v; }
+    else dw[(size_t)m * (N - 1) + n] = v;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
 // Linear layers:  Y = act(X W^T + b)   (nn.Linear, A.1).  The weight may be given as up to
 // 8 row blocks (the 8 per-head AttnLinear matrices of _multihead_attention) so the head
 // projections run as ONE GEMM without packing the parameters.

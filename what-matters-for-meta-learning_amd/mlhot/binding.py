@@ -126,6 +126,16 @@ class MlhotLib:
         c.mlhot_favor_bwd.argtypes = [P, P, P, P, i, i, i, i, i, i, P, P, P, P, P, P, z, P]
         c.mlhot_loss_fwd.argtypes = [i, P, P, i, i, i, P, P]
         c.mlhot_loss_bwd.argtypes = [i, P, P, i, i, i, P, P, P]
+        c.mlhot_conv2d_bwd_scratch_bytes.restype = C.c_size_t
+        c.mlhot_conv2d_bwd_scratch_bytes.argtypes = [i] * 8
+        c.mlhot_conv2d_fwd.argtypes = [P, P, P, P] + [i] * 9 + [P]
+        c.mlhot_conv2d_bwd.argtypes = [P, P, P, P] + [i] * 9 + [P, P, P, P, z, P]
+        c.mlhot_add_relu_fwd.argtypes = [P, P, P, z, P]
+        c.mlhot_add_relu_bwd.argtypes = [P, P, P, z, P]
+        c.mlhot_pool2_fwd.argtypes = [P, P, P, i, i, i, P]
+        c.mlhot_pool2_bwd.argtypes = [P, P, P, i, i, i, P]
+        c.mlhot_bbb_sample_fwd.argtypes = [P, P, P, P, P, P, z, P]
+        c.mlhot_bbb_sample_bwd.argtypes = [P, P, P, P, P, P, P, z, P]
         c.mlhot_np_vanilla_fwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, P, z, P]
         c.mlhot_np_vanilla_bwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, C.POINTER(NpGrads), P, P, z, P]
         for which, st in ((0, NpDims), (1, NpParams), (2, NpGrads)):
@@ -215,6 +225,72 @@ class MlhotLib:
                                               _ptr(dfeat1), dim_w, _ptr(saved), C.byref(gs), _ptr(scratch), sb, _stream(img0)),
                  "mlhot_enc_vanilla_bwd")
         return grads
+
+    # ---- E2 / D2 / B1 building blocks ----------------------------------------------------------
+    def conv2d_fwd(self, x, w, b, stride, pad, relu):
+        _chk(x, w, b)
+        N, Cin, H, W = x.shape
+        Cout, _, k, _ = w.shape
+        HO, WO = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        y = torch.empty(N, Cout, HO, WO, device=x.device)
+        self._rc(self.c.mlhot_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), N, Cin, H, W, Cout, k, stride, pad, int(relu), _stream(x)),
+                 "mlhot_conv2d_fwd")
+        return y
+
+    def conv2d_bwd(self, x, w, y, dy, stride, pad, relu, need_dx=True, has_bias=True):
+        _chk(x, w, y, dy)
+        N, Cin, H, W = x.shape
+        Cout, _, k, _ = w.shape
+        dx = torch.empty_like(x) if need_dx else None
+        dw = torch.empty_like(w)
+        db = torch.empty(Cout, device=x.device) if has_bias else None
+        sb = self.c.mlhot_conv2d_bwd_scratch_bytes(N, Cin, H, W, Cout, k, stride, pad)
+        scratch = self._bytes(sb, x)
+        self._rc(self.c.mlhot_conv2d_bwd(_ptr(x), _ptr(w), _ptr(y), _ptr(dy), N, Cin, H, W, Cout, k, stride, pad, int(relu),
+                                         _ptr(dx), _ptr(dw), _ptr(db), _ptr(scratch), sb, _stream(x)), "mlhot_conv2d_bwd")
+        return dx, dw, db
+
+    def add_relu_fwd(self, a, b):
+        _chk(a, b)
+        y = torch.empty_like(a)
+        self._rc(self.c.mlhot_add_relu_fwd(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream(a)), "mlhot_add_relu_fwd")
+        return y
+
+    def add_relu_bwd(self, y, dy):
+        _chk(y, dy)
+        g = torch.empty_like(y)
+        self._rc(self.c.mlhot_add_relu_bwd(_ptr(y), _ptr(dy), _ptr(g), y.numel(), _stream(y)), "mlhot_add_relu_bwd")
+        return g
+
+    def pool2_fwd(self, x):
+        _chk(x)
+        N, Cc, H, W = x.shape
+        y = torch.empty(N, Cc, H // 2, W // 2, device=x.device)
+        amax = torch.empty(N, Cc, H // 2, W // 2, dtype=torch.uint8, device=x.device)
+        self._rc(self.c.mlhot_pool2_fwd(_ptr(x), _ptr(y), _ptr(amax), N * Cc, H, W, _stream(x)), "mlhot_pool2_fwd")
+        return y, amax
+
+    def pool2_bwd(self, dy, amax, H, W):
+        _chk(dy, amax)
+        N, Cc = dy.shape[:2]
+        dx = torch.empty(N, Cc, H, W, device=dy.device)
+        self._rc(self.c.mlhot_pool2_bwd(_ptr(dy), _ptr(amax), _ptr(dx), N * Cc, H, W, _stream(dy)), "mlhot_pool2_bwd")
+        return dx
+
+    def bbb_sample_fwd(self, mu, rho, eps):
+        _chk(mu, rho, eps)
+        w, klterm = torch.empty_like(mu), torch.empty_like(mu)
+        kl = torch.empty((), device=mu.device)
+        self._rc(self.c.mlhot_bbb_sample_fwd(_ptr(mu), _ptr(rho), _ptr(eps), _ptr(w), _ptr(klterm), _ptr(kl), mu.numel(), _stream(mu)),
+                 "mlhot_bbb_sample_fwd")
+        return w, kl
+
+    def bbb_sample_bwd(self, mu, rho, eps, dw, dkl):
+        _chk(dw, dkl)
+        dmu, drho = torch.empty_like(mu), torch.empty_like(mu)
+        self._rc(self.c.mlhot_bbb_sample_bwd(_ptr(mu), _ptr(rho), _ptr(eps), _ptr(dw), _ptr(dkl), _ptr(dmu), _ptr(drho), mu.numel(), _stream(mu)),
+                 "mlhot_bbb_sample_bwd")
+        return dmu, drho
 
     # ---- linear --------------------------------------------------------------------------------
     def linear_fwd(self, x, w, b, act="none"):

@@ -150,3 +150,81 @@ class LossFunction(torch.autograd.Function):
     def backward(ctx, dloss):
         mu, gt = ctx.saved_tensors
         return None, lib().loss_bwd(ctx.kind, mu, gt, _c(dloss.float())), None
+
+
+class Conv2dFunction(torch.autograd.Function):
+    """nn.Conv2d (+ optional fused ReLU): mlhot_conv2d_fwd / _bwd (generic run-time-shaped conv)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, relu):
+        _need_gpu(x, w, b)
+        x, w = _c(x.float()), _c(w)
+        bb = _c(b) if b is not None else None
+        y = lib().conv2d_fwd(x, w.detach(), bb.detach() if bb is not None else None, stride, pad, relu)
+        ctx.cfg = (stride, pad, relu, b is not None)
+        ctx.save_for_backward(x, w.detach(), y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, relu, has_b = ctx.cfg
+        dx, dw, db = lib().conv2d_bwd(x, w, y, _c(dy), stride, pad, relu, need_dx=ctx.needs_input_grad[0], has_bias=has_b)
+        return dx, dw, db, None, None, None
+
+
+class AddReluFunction(torch.autograd.Function):
+    """Residual join relu(a + b) of a BasicBlock."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, b)
+        y = lib().add_relu_fwd(_c(a), _c(b))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        g = lib().add_relu_bwd(y, _c(dy))
+        return g, g
+
+
+class MaxPool2Function(torch.autograd.Function):
+    """2x2 max-pool (AdaptiveMaxPool2d((2,2)) on a 4x4 map)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = _c(x)
+        y, amax = lib().pool2_fwd(x)
+        ctx.hw = x.shape[2:]
+        ctx.save_for_backward(amax)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (amax,) = ctx.saved_tensors
+        return lib().pool2_bwd(_c(dy), amax, *ctx.hw)
+
+
+class BBBSampleFunction(torch.autograd.Function):
+    """(mu, rho, eps) -> (w = mu + eps*softplus(rho), kl): mlhot_bbb_sample_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, mu, rho, eps):
+        _need_gpu(mu, rho, eps)
+        mu, rho, eps = _c(mu.detach()), _c(rho.detach()), _c(eps)
+        w, kl = lib().bbb_sample_fwd(mu, rho, eps)
+        ctx.save_for_backward(mu, rho, eps)
+        return w, kl
+
+    @staticmethod
+    def backward(ctx, dw, dkl):
+        mu, rho, eps = ctx.saved_tensors
+        if dw is None:
+            dw = torch.zeros_like(mu)
+        if dkl is None:
+            dkl = torch.zeros((), device=mu.device)
+        dmu, drho = lib().bbb_sample_bwd(mu, rho, eps, _c(dw), _c(dkl.float()))
+        return dmu, drho, None

@@ -1,0 +1,88 @@
+"""Common implementation of the ResNet-encoder neural processes for ShapeNet3D / Distractor
+(reference: networks/CondNeuralProcess.py, networks/ANP.py).
+
+Same construction order / state_dict keys as the reference; the forward composes the mlhot HIP
+operators (run-time-shaped convolutions, linears, shot-axis aggregators, FAVOR+ attention).
+"""
+import torch
+from torch import nn
+
+from mlhot.ops import AggFunction, FavorFunction, LinearFunction
+from networks.fast_attention import FastAttention
+from networks.models import AttnLinear, ImageEncoder, NPDecoder, _mlp3
+
+
+class ResNetNP(nn.Module):
+    ATTENTION = False
+    N_HEADS = 8
+
+    def __init__(self, config):
+        super().__init__()
+        self.device = config.device
+        self.img_size = config.img_size
+        self.img_channels = self.img_size[2] - 1 if config.task == "shapenet_3d" else self.img_size[2]
+        self.task_num = config.tasks_per_batch
+        self.label_dim = config.input_dim
+        self.agg_mode = config.agg_mode
+        self.img_agg = config.img_agg
+        self.y_dim = config.output_dim
+        if self.ATTENTION:
+            self.temperature = getattr(config, "temperature", 0.07)
+        torch.manual_seed(config.seed)
+
+        self.img_encoder = ImageEncoder(aggregate=self.img_agg, task_num=self.task_num, img_channels=self.img_channels)
+        self.task_encoder = nn.Sequential(nn.Linear(256 + self.label_dim, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                          nn.Linear(256, 256), nn.ReLU())
+        if not self.ATTENTION and self.agg_mode == "baco":
+            self.latent_mu = nn.Linear(256, 256)
+            self.latent_var = nn.Linear(256, 256)
+        self.mu = nn.Linear(256, 256)
+        self.decoder = NPDecoder(aggregate=self.img_agg, output_dim=self.y_dim, task_num=self.task_num,
+                                 img_channels=self.img_channels, img_size=self.img_size)
+        if self.ATTENTION:
+            h = 256
+            self._W_k = nn.ModuleList([AttnLinear(h, h) for _ in range(self.N_HEADS)])
+            self._W_v = nn.ModuleList([AttnLinear(h, h) for _ in range(self.N_HEADS)])
+            self._W_q = nn.ModuleList([AttnLinear(h, h) for _ in range(self.N_HEADS)])
+            self._W = AttnLinear(self.N_HEADS * h, h)
+            self.attn = FastAttention(dim_heads=256, causal=False)
+            self.n_heads = self.N_HEADS
+
+    # the 8 per-head AttnLinear layers run as ONE linear over the stacked weights; rows come out
+    # token-major / head-minor, which is the layout the FAVOR+ kernels take
+    def _heads(self, x, mods):
+        w = torch.cat([m.linear.weight for m in mods], dim=0)
+        b = torch.cat([m.linear.bias for m in mods], dim=0)
+        T, N, _ = x.shape
+        return LinearFunction.apply(x, w, b, "none").view(T, N, self.N_HEADS, -1)
+
+    def _multihead_attention(self, k, v, q):
+        merged = FavorFunction.apply(self._heads(q, self._W_q), self._heads(k, self._W_k), self._heads(v, self._W_v),
+                                     self.attn.projection_matrix)
+        return self._W(merged)
+
+    def forward(self, batch_train_images, label_train, batch_test_images, test=False):
+        self.test_num = batch_test_images.shape[1]
+        self.ctx_num = batch_train_images.shape[1]
+        C, H, W = self.img_channels, self.img_size[0], self.img_size[1]
+        if self.ctx_num:
+            x_ctx = self.img_encoder(batch_train_images.reshape(-1, C, H, W))
+            feats = _mlp3(torch.cat([x_ctx, label_train], dim=2), self.task_encoder, last_relu=True)
+            if self.ATTENTION:
+                x_tgt = self.img_encoder(batch_test_images.reshape(-1, C, H, W))
+                sample = LinearFunction.apply(self._multihead_attention(x_ctx, feats, x_tgt), self.mu.weight, self.mu.bias, "none")
+            else:
+                if self.agg_mode in ("mean", "max"):
+                    r, _ = AggFunction.apply(self.agg_mode, feats, None)
+                elif self.agg_mode == "baco":
+                    mu_l = LinearFunction.apply(feats, self.latent_mu.weight, self.latent_mu.bias, "none")
+                    lv = LinearFunction.apply(feats, self.latent_var.weight, self.latent_var.bias, "none")
+                    r, _ = AggFunction.apply("baco", mu_l, lv)
+                else:
+                    raise TypeError("agg_mode is not applicable for CNP, choose from ['mean', 'max', 'baco']")
+                mu = LinearFunction.apply(r, self.mu.weight, self.mu.bias, "none")
+                sample = mu[:, None, :].expand(-1, self.test_num, -1)
+        else:
+            sample = torch.zeros(self.task_num, self.test_num, 256, device=batch_test_images.device)
+        out, var = self.decoder(batch_test_images, sample)
+        return out, var, 0

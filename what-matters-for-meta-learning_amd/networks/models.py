@@ -7,7 +7,8 @@ runs the mlhot HIP linear kernels, while the fused model path reads the paramete
 import torch
 from torch import nn
 
-from mlhot.ops import LinearFunction
+from mlhot.ops import LinearFunction, MaxPool2Function
+from networks.ResNet import BasicBlock, ResNet, run_conv
 
 
 class EncoderFC(nn.Module):
@@ -43,3 +44,64 @@ class AttnLinear(nn.Module):
 
     def forward(self, x):
         return LinearFunction.apply(x, self.linear.weight, self.linear.bias, "none")
+
+
+def _aggregate_feature_map(x, aggregate):
+    """img_agg of ImageEncoder / NPDecoder (models.py:105-113): [n,64,h,w] -> [n,F]."""
+    if aggregate in ("max", "baco"):                    # AdaptiveMaxPool2d((2,2))
+        if x.shape[-1] == 4:
+            x = MaxPool2Function.apply(x)
+        elif x.shape[-1] != 2:
+            raise NotImplementedError("adaptive max pool to 2x2 is implemented for 2x2 and 4x4 maps (64/128 px inputs)")
+    elif aggregate == "mean":
+        x = x.mean(dim=(2, 3))                          # 64 features; no shipped config uses it (SURVEY App. B)
+    elif aggregate != "reshape":
+        raise TypeError(f"img_agg {aggregate!r} is not supported")
+    return x.reshape(x.size(0), -1)
+
+
+def _mlp3(x, seq, last_relu):
+    """Sequential(Linear, ReLU, Linear, ReLU, Linear[, ReLU]) through the HIP linear kernels."""
+    lins = [m for m in seq if isinstance(m, nn.Linear)]
+    for i, lin in enumerate(lins):
+        act = "relu" if (i < len(lins) - 1 or last_relu) else "none"
+        x = LinearFunction.apply(x, lin.weight, lin.bias, act)
+    return x
+
+
+class ImageEncoder(nn.Module):
+    """5x5 s2 stem + ReLU, four BN-free BasicBlocks, img_agg  (models.py:63-117) -> [T, N, F]."""
+
+    def __init__(self, aggregate, task_num, img_channels):
+        super().__init__()
+        self.img_channels, self.task_num, self.aggregate = img_channels, task_num, aggregate
+        self.conv1 = nn.Conv2d(img_channels, 64, kernel_size=5, stride=2, padding=2, bias=True)
+        self.resnet = ResNet(BasicBlock, [1, 1, 1, 1], pretrained=False, progress=True)
+
+    def forward(self, img):
+        x = self.resnet.trunk(run_conv(self.conv1, img, relu=True))
+        x = _aggregate_feature_map(x, self.aggregate)
+        return x.view(self.task_num, -1, x.size(1))
+
+
+class NPDecoder(nn.Module):
+    """Second ResNet over the target images, cat with the sampled latent, fc_mu  (models.py:120-192)."""
+
+    def __init__(self, aggregate, output_dim, task_num, img_channels, img_size, pr_unc=False):
+        super().__init__()
+        self.img_channels, self.task_num, self.img_size, self.output_dim = img_channels, task_num, img_size, output_dim
+        self.aggregate = aggregate
+        self.conv1 = nn.Conv2d(img_channels, 64, kernel_size=5, stride=2, padding=2, bias=True)
+        self.resnet = ResNet(BasicBlock, [1, 1, 1, 1], pretrained=False, progress=True)
+        self.fc_mu = nn.Sequential(nn.Linear(256 + 256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                   nn.Linear(256, output_dim))
+        if pr_unc:
+            raise NotImplementedError("pr_unc / fc_var is never enabled by the reference models (models.py:185-190)")
+
+    def forward(self, test_images, sample_features, log_variance=None):
+        n_per_task = sample_features.size(1)
+        imgs = test_images.reshape(self.task_num * n_per_task, self.img_channels, self.img_size[0], self.img_size[1])
+        x = self.resnet.trunk(run_conv(self.conv1, imgs, relu=True))
+        x = _aggregate_feature_map(x, self.aggregate).reshape(self.task_num, n_per_task, -1)
+        mu = _mlp3(torch.cat([x, sample_features], dim=-1), self.fc_mu, last_relu=False)
+        return mu, None
