@@ -230,16 +230,26 @@ def vanilla_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, tanh, taps=None):
 # --------------------------------------------------------------------------------------
 
 
-def resnet_features(img, p, prefix, img_agg, skip_pad=0):
+def resnet_features(img, p, prefix, img_agg, skip_pad=0, route=None, pre=None):
     """5x5 s2 p2 stem + ReLU; 4 x {conv3x3 s2 + ReLU, conv3x3 s1, + skip conv (1x1 s2, or 3x3 p1 s2
-    in the BBB twin), ReLU}; then img_agg.  img [n,C,H,W] -> [n,F]."""
-    x = F.relu(F.conv2d(img, p[prefix + "conv1.weight"], p[prefix + "conv1.bias"], stride=2, padding=2))
+    in the BBB twin), ReLU}; then img_agg.  img [n,C,H,W] -> [n,F].
+    `route`: optional list of 9 {0,1} masks (stem, then per block: conv1 output, block output) that
+    REPLACE the ReLU decisions (pinned routing, see vanilla_encoder_routed); `pre`: optional list that
+    receives the 9 pre-activations."""
+    masks = iter(route) if route is not None else None
+
+    def act(v):
+        if pre is not None:
+            pre.append(v.detach())
+        return v * next(masks) if masks is not None else F.relu(v)
+
+    x = act(F.conv2d(img, p[prefix + "conv1.weight"], p[prefix + "conv1.bias"], stride=2, padding=2))
     for i in range(1, 5):
         q = f"{prefix}resnet.layer{i}.0."
-        out = F.relu(F.conv2d(x, p[q + "conv1.weight"], p[q + "conv1.bias"], stride=2, padding=1))
+        out = act(F.conv2d(x, p[q + "conv1.weight"], p[q + "conv1.bias"], stride=2, padding=1))
         out = F.conv2d(out, p[q + "conv2.weight"], p[q + "conv2.bias"], stride=1, padding=1)
         idn = F.conv2d(x, p[q + "downsample.0.weight"], p[q + "downsample.0.bias"], stride=2, padding=skip_pad)
-        x = F.relu(out + idn)
+        x = act(out + idn)
     if img_agg in ("max", "baco"):
         x = F.adaptive_max_pool2d(x, (2, 2))
     elif img_agg == "mean":
@@ -247,11 +257,22 @@ def resnet_features(img, p, prefix, img_agg, skip_pad=0):
     return x.reshape(x.shape[0], -1)
 
 
-def resnet_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, img_agg, n_heads=8):
-    """CondNeuralProcess / ANP forward.  ctx_x [T,Nc,C,H,W], ctx_y [T,Nc,L], qry_x [T,Nq,C,H,W] -> mu [T,Nq,y]."""
+def resnet_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, img_agg, n_heads=8, routes=None, pres=None):
+    """CondNeuralProcess / ANP forward.  ctx_x [T,Nc,C,H,W], ctx_y [T,Nc,L], qry_x [T,Nq,C,H,W] -> mu [T,Nq,y].
+    `routes` / `pres`: per encoder pass (context, [target,] decoder - in that order) the pinned ReLU
+    masks / a list receiving the pre-activations (see resnet_features)."""
     T, Nq = qry_x.shape[:2]
     Nc = ctx_x.shape[1]
     flat = lambda t: t.reshape(-1, *t.shape[2:])
+    passes = iter(routes) if routes is not None else None
+
+    def resnet_features(img, p_, prefix, agg):      # noqa: F811 - routed wrapper around the module-level function
+        pre = None
+        if pres is not None:
+            pre = []
+            pres.append(pre)
+        return globals()["resnet_features"](img, p_, prefix, agg, route=next(passes) if passes is not None else None, pre=pre)
+
     if Nc:
         x_ctx = resnet_features(flat(ctx_x), p, "img_encoder.", img_agg).reshape(T, Nc, -1)
         h = torch.cat([x_ctx, ctx_y], dim=2)

@@ -128,7 +128,11 @@ def run_resnet_case(name, method, cfgd, Nc, Nq, C, LossFunc):
     model = getattr(importlib.import_module(f"networks.{method}"), method)(cfg)
     T = cfg.tasks_per_batch
     H, W, _ = cfg.img_size
-    cx, qx, cy, qy = make_inputs(T, Nc, Nq, C, H, W, cfg.input_dim)
+    # With 2-5 images a single ReLU whose pre-activation is a rounding-level tie (|v| ~ 1e-7 of scale)
+    # moves the upstream gradients by ~1e-2 between ANY two fp32 evaluation orders; the
+    # seed-1234 draw of the distractor case contains such a tie in layer3.conv1, so that case uses 4321.
+    input_seed = 4321 if name == "r_cnp_distractor_baco" else 1234
+    cx, qx, cy, qy = make_inputs(T, Nc, Nq, C, H, W, cfg.input_dim, seed=input_seed)
     if cfg.task == "shapenet_3d":                       # unit quaternions with q[1] >= 0 (shapenet_3d.py:226-227)
         qy = torch.nn.functional.normalize(qy - 0.5, dim=-1)
         qy = torch.where(qy[..., 1:2] < 0, -qy, qy)
@@ -153,15 +157,15 @@ def run_resnet_case(name, method, cfgd, Nc, Nq, C, LossFunc):
             flat = gnp.reshape(-1)
             out["gradhead/" + k] = flat[:1024].copy()
             out["gradstride/" + k] = flat[1::61][:4096].copy()
-    meta = dict(name=name, method=method, cfg=cfgd, Nc=Nc, Nq=Nq, C=C, input_seed=1234, state_sha=state_sha, grad_norm=grad_norm,
+    meta = dict(name=name, method=method, cfg=cfgd, Nc=Nc, Nq=Nq, C=C, input_seed=input_seed, state_sha=state_sha, grad_norm=grad_norm,
                 input_sha=dict(cx=sha(cx), qx=sha(qx), cy=sha(cy)), n_params=sum(p.numel() for p in model.parameters()))
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"{name}: loss={loss.item():.8f} sum(mu)={mu.sum().item():.8f} params={meta['n_params']}")
 
 
-def make_inputs(T, Nc, Nq, C, H, W, L):
-    g = torch.Generator().manual_seed(1234)
+def make_inputs(T, Nc, Nq, C, H, W, L, seed=1234):
+    g = torch.Generator().manual_seed(seed)
     cx = torch.rand(T, Nc, C, H, W, generator=g)
     qx = torch.rand(T, Nq, C, H, W, generator=g)
     cy = torch.rand(T, Nc, L, generator=g)

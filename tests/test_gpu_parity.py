@@ -219,19 +219,43 @@ def test_model_baseline_configs_vs_reference(gpulib, tail_impl, name):
 @pytest.mark.parametrize("name", U.resnet_case_names())
 def test_resnet_models_vs_reference(gpulib, name):
     """ResNet-encoder CondNeuralProcess / ANP (ShapeNet3D 64x64x3 quaternions, Distractor 128x128x1)
-    through the plugin boundary: run-time-shaped conv kernels, linears, aggregators, FAVOR+ (d=256, m=1419)."""
+    through the plugin boundary: run-time-shaped conv kernels, linears, aggregators, FAVOR+ (d=256, m=1419).
+    Outputs and loss are held to 1e-4 against the reference's vectors.  Gradients: these models have ~1e6
+    ReLU decisions per pass and every batch contains pre-activations within 1e-7 of zero, so the check is
+    made with the oracle evaluated under the KERNELS' routing (each disagreement with the oracle's own sign
+    must sit on a <=1e-5 tie); when no decision flipped, the reference's gradients are compared as well."""
     fx, meta = U.load_case(name)
     model = U.build_model(meta, DEV, fx=fx).to(DEV)
-    cx, qx, cy, qy = (t.to(DEV) for t in U.resnet_case_inputs(meta, fx))
+    cx, qx, cy, qy = U.resnet_case_inputs(meta, fx)
     from trainer.losses import LossFunc
-    mu, var, kl = model(cx, cy, qx)
+    model.img_encoder.tap_log, model.decoder.tap_log = [], []
+    mu, var, kl = model(cx.to(DEV), cy.to(DEV), qx.to(DEV))
     assert var is None and kl == 0
-    loss = LossFunc("mse", meta["cfg"]["task"]).calc_loss(mu, var, qy)
+    loss = LossFunc("mse", meta["cfg"]["task"]).calc_loss(mu, var, qy.to(DEV))
     loss.backward()
     assert U.rel_err(mu, fx["mu"]) <= U.RTOL
     assert abs(loss.item() - float(fx["loss"])) <= U.RTOL * max(1.0, abs(float(fx["loss"])))
     grads = {k: p.grad for k, p in model.named_parameters()}
-    U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
+    # oracle under the kernels' routing
+    routes = [[(t.detach().cpu() > 0).float() for t in taps] for taps in model.img_encoder.tap_log + model.decoder.tap_log]
+    p = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+    pres = []
+    mu_r = O.resnet_np_forward(p, cx, cy, qx, meta["cfg"]["agg_mode"], meta["cfg"]["img_agg"], routes=routes, pres=pres)
+    O.calc_loss(meta["cfg"]["task"], mu_r, qy).backward()
+    flips = 0
+    for masks, pre in zip(routes, pres):
+        for m, v in zip(masks, pre):
+            bad = (m > 0) != (v > 0)
+            flips += int(bad.sum())
+            assert not bool((bad & (v.abs() > 1e-5 * v.abs().max())).any()), "routing differs away from a tie"
+    gmax = max(p[k].grad.abs().max().item() for k, _ in model.named_parameters() if p[k].grad is not None)
+    for k, prm in model.named_parameters():
+        if p[k].grad is None:
+            assert grads[k] is None, k
+            continue
+        assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= U.RTOL, k
+    if flips == 0:
+        U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
 
 
 def test_forward_is_deterministic_and_task_independent(gpulib):

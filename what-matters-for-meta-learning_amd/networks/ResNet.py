@@ -37,11 +37,16 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
+    def forward(self, x, taps=None):
         out = run_conv(self.conv1, x, relu=True)
+        if taps is not None:
+            taps.append(out)
         out = run_conv(self.conv2, out)
         identity = run_conv(self.downsample[0], x) if self.downsample is not None else x
-        return AddReluFunction.apply(out, identity)
+        y = AddReluFunction.apply(out, identity)
+        if taps is not None:
+            taps.append(y)
+        return y
 
 
 class ResNet(nn.Module):
@@ -74,8 +79,11 @@ class ResNet(nn.Module):
             layers.append(block(self.inplanes, planes))
         return nn.Sequential(*layers)
 
-    def trunk(self, x):
+    def trunk(self, x, taps=None):
+        """taps: optional list that receives every post-ReLU activation (diagnostics / routing tests)."""
+        if taps is not None:
+            taps.append(x)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
-                x = blk(x)
+                x = blk(x, taps)
         return x

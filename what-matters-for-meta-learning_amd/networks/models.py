@@ -77,9 +77,16 @@ class ImageEncoder(nn.Module):
         self.img_channels, self.task_num, self.aggregate = img_channels, task_num, aggregate
         self.conv1 = nn.Conv2d(img_channels, 64, kernel_size=5, stride=2, padding=2, bias=True)
         self.resnet = ResNet(BasicBlock, [1, 1, 1, 1], pretrained=False, progress=True)
+        self.tap_log = None      # set to a list to record, per call, the post-ReLU activations (tests)
+
+    def _taps(self):
+        if self.tap_log is None:
+            return None
+        self.tap_log.append([])
+        return self.tap_log[-1]
 
     def forward(self, img):
-        x = self.resnet.trunk(run_conv(self.conv1, img, relu=True))
+        x = self.resnet.trunk(run_conv(self.conv1, img, relu=True), self._taps())
         x = _aggregate_feature_map(x, self.aggregate)
         return x.view(self.task_num, -1, x.size(1))
 
@@ -97,11 +104,16 @@ class NPDecoder(nn.Module):
                                    nn.Linear(256, output_dim))
         if pr_unc:
             raise NotImplementedError("pr_unc / fc_var is never enabled by the reference models (models.py:185-190)")
+        self.tap_log = None
 
     def forward(self, test_images, sample_features, log_variance=None):
         n_per_task = sample_features.size(1)
         imgs = test_images.reshape(self.task_num * n_per_task, self.img_channels, self.img_size[0], self.img_size[1])
-        x = self.resnet.trunk(run_conv(self.conv1, imgs, relu=True))
+        taps = None
+        if self.tap_log is not None:
+            self.tap_log.append([])
+            taps = self.tap_log[-1]
+        x = self.resnet.trunk(run_conv(self.conv1, imgs, relu=True), taps)
         x = _aggregate_feature_map(x, self.aggregate).reshape(self.task_num, n_per_task, -1)
         mu = _mlp3(torch.cat([x, sample_features], dim=-1), self.fc_mu, last_relu=False)
         return mu, None
