@@ -304,6 +304,76 @@ def resnet_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, img_agg, n_heads=8, rout
 
 
 # --------------------------------------------------------------------------------------
+# B1  Bayes-by-backprop encoder of ANPMRShapeNet3D      (bbb/BBBConv.py:86-108, bbb/misc.py:36-45,
+#     ANPMRShapeNet3D.py:40-90,185-218; Appendix A.6)
+# --------------------------------------------------------------------------------------
+
+
+def bbb_sample(mu, rho):
+    """W = mu + eps * log1p(exp(rho)), eps ~ N(0,1) from the torch CPU generator; and the layer's KL as
+    the reference literally computes it: calculate_kl(0, 0.1, mu, sigma)."""
+    eps = torch.empty(mu.size()).normal_(0, 1).to(mu.dtype)
+    sigma = torch.log1p(torch.exp(rho))
+    kl = 0.5 * (2 * torch.log(sigma / 0.1) - 1 + (0.1 / sigma).pow(2) + (mu / sigma).pow(2)).sum()
+    return mu + eps * sigma, kl
+
+
+def bbb_resnet_features(img, p, prefix="img_encoder.net.", route=None, pre=None):
+    """BBB twin of resnet_features: every conv samples (weight, then bias) on each call, the skip is a
+    3x3 p1 s2 conv, output flattened to [n,256].  Returns (features, kl summed over the 13 convs)."""
+    masks = iter(route) if route is not None else None
+    kls = []
+
+    def act(v):
+        if pre is not None:
+            pre.append(v.detach())
+        return v * next(masks) if masks is not None else F.relu(v)
+
+    def conv(x, q, stride, pad):
+        w, klw = bbb_sample(p[q + "W_mu"], p[q + "W_rho"])
+        b, klb = bbb_sample(p[q + "bias_mu"], p[q + "bias_rho"])
+        kls.append(klw + klb)
+        return F.conv2d(x, w, b, stride=stride, padding=pad)
+
+    x = act(conv(img, prefix + "layer1.conv.", 2, 2))
+    for i in range(2, 6):
+        q = f"{prefix}layer{i}."
+        out = act(conv(x, q + "conv1.", 2, 1))
+        out = conv(out, q + "conv2.", 1, 1)
+        idn = conv(x, q + "downsample.0.", 2, 1)
+        x = act(out + idn)
+    return x.reshape(-1, 256), sum(kls)
+
+
+def anpmr3d_forward(p, ctx_x, ctx_y, qry_x, img_agg="reshape", n_heads=8, routes=None, pres=None):
+    """ANPMRShapeNet3D.forward with a non-empty context -> (mu [T,Nq,y], kl)."""
+    T, Nq = qry_x.shape[:2]
+    Nc = ctx_x.shape[1]
+    flat = lambda t: t.reshape(-1, *t.shape[2:])
+    passes = iter(routes) if routes is not None else None
+
+    def nxt():
+        pre = None
+        if pres is not None:
+            pre = []
+            pres.append(pre)
+        return dict(route=next(passes) if passes is not None else None, pre=pre)
+
+    x_ctx, _ = bbb_resnet_features(flat(ctx_x), p, **nxt())
+    x_tgt, kl = bbb_resnet_features(flat(qry_x), p, **nxt())      # second, independent sample; its kl is returned
+    x_ctx, x_tgt = x_ctx.reshape(T, Nc, -1), x_tgt.reshape(T, Nq, -1)
+    h = torch.cat([x_ctx, ctx_y], dim=2)
+    for i in (0, 2, 4):
+        h = F.relu(F.linear(h, p[f"task_encoder.{i}.weight"], p[f"task_encoder.{i}.bias"]))
+    sample = F.linear(multihead_attention(x_ctx, h, x_tgt, p, n_heads=n_heads), p["mu.weight"], p["mu.bias"])
+    x_dec = resnet_features(flat(qry_x), p, "decoder.", img_agg, **nxt()).reshape(T, Nq, -1)
+    h = torch.cat([x_dec, sample], dim=-1)
+    h = F.relu(F.linear(h, p["decoder.fc_mu.0.weight"], p["decoder.fc_mu.0.bias"]))
+    h = F.relu(F.linear(h, p["decoder.fc_mu.2.weight"], p["decoder.fc_mu.2.bias"]))
+    return F.linear(h, p["decoder.fc_mu.4.weight"], p["decoder.fc_mu.4.bias"]), kl
+
+
+# --------------------------------------------------------------------------------------
 # L1  losses                                                   (trainer/losses.py:32-80)
 # --------------------------------------------------------------------------------------
 

@@ -118,6 +118,10 @@ RESNET_CASES = {
                                                        output_dim=4, agg_mode="max", img_agg="reshape", seed=2578), 4, 3, 3),
     "r_cnp_distractor_baco": ("CondNeuralProcess", dict(task="distractor", img_size=[128, 128, 1], tasks_per_batch=1, input_dim=2,
                                                         output_dim=2, agg_mode="baco", img_agg="max", seed=2578), 3, 2, 1),
+    # BASELINE config c5: Bayes-by-backprop encoder; torch.manual_seed(99) right before the forward fixes the eps draws,
+    # backward on loss + 1e-7 * kl (beta of cfg/train/ANPMR_ShapeNet3D.yaml)
+    "r_anpmr_shapenet3d": ("ANPMRShapeNet3D", dict(task="shapenet_3d", img_size=[64, 64, 4], tasks_per_batch=2, input_dim=4, output_dim=4,
+                                                   agg_mode="attention", img_agg="reshape", seed=2578, temperature=0.07), 3, 4, 3),
     "r_cnp_shapenet3d_nc0": ("CondNeuralProcess", dict(task="shapenet_3d", img_size=[64, 64, 4], tasks_per_batch=1, input_dim=4,
                                                        output_dim=4, agg_mode="mean", img_agg="reshape", seed=2578), 0, 2, 3),
 }
@@ -137,11 +141,12 @@ def run_resnet_case(name, method, cfgd, Nc, Nq, C, LossFunc):
         qy = torch.nn.functional.normalize(qy - 0.5, dim=-1)
         qy = torch.where(qy[..., 1:2] < 0, -qy, qy)
     model.train()
+    torch.manual_seed(99)
     mu, var, kl = model(cx, cy, qx)
     assert var is None
     loss = LossFunc("mse", cfg.task).calc_loss(mu, var, qy)
-    loss.backward()
-    out = {"mu": np32(mu), "loss": np.float64(loss.item()), "qy": np32(qy)}
+    (loss + 1e-7 * kl if torch.is_tensor(kl) else loss).backward()
+    out = {"mu": np32(mu), "loss": np.float64(loss.item()), "qy": np32(qy), "kl": np.float64(float(kl))}
     state_sha, grad_norm = {k: sha(v) for k, v in model.state_dict().items()}, {}
     if hasattr(model, "attn"):
         out["projection_matrix"] = np32(model.attn.projection_matrix)

@@ -48,11 +48,17 @@ def test_oracle_resnet_models_match_reference(name):
     assert list(sd.keys()) == list(meta["state_sha"].keys())
     cx, qx, cy, qy = U.resnet_case_inputs(meta, fx)
     p = {k: v.clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in sd.items()}
-    mu = O.resnet_np_forward(p, cx, cy, qx, meta["cfg"]["agg_mode"], meta["cfg"]["img_agg"])
+    if meta["method"] == "ANPMRShapeNet3D":
+        torch.manual_seed(99)            # the fixture's eps draws
+        mu, kl = O.anpmr3d_forward(p, cx, cy, qx, meta["cfg"]["img_agg"])
+        assert abs(kl.item() - float(fx["kl"])) <= 1e-5 * float(fx["kl"])
+        assert abs(float(fx["kl"]) - 1383162.5) < 2.0          # SURVEY §8c known answer (kl does not depend on the batch)
+    else:
+        mu, kl = O.resnet_np_forward(p, cx, cy, qx, meta["cfg"]["agg_mode"], meta["cfg"]["img_agg"]), 0.0
     assert U.rel_err(mu, fx["mu"]) <= 1e-5
     loss = O.calc_loss(meta["cfg"]["task"], mu, qy)
     assert abs(loss.item() - float(fx["loss"])) <= 1e-5
-    loss.backward()
+    (loss + 1e-7 * kl).backward()
     grads = {k: p[k].grad for k, _ in model.named_parameters()}
     U.check_grads_against_fixture(grads, fx, meta, tol=1e-4, head=1024, stride_cap=4096)
 

@@ -1,0 +1,101 @@
+"""Plugin `networks.ANPMRShapeNet3D` (reference: networks/ANPMRShapeNet3D.py; BASELINE config c5):
+the ResNet-encoder ANP whose context/target image encoder is Bayes-by-backprop (weights re-sampled on
+every call, KL returned as `kl`), with a deterministic NPDecoder ResNet over the targets."""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from mlhot.ops import AddReluFunction, LinearFunction
+from networks._resnet_np import ResNetNP
+from networks.bbb.BBBConv import BBBConv2d
+from networks.bbb.misc import FlattenLayer, ModuleWrapper
+from networks.fast_attention import FastAttention
+from networks.models import AttnLinear, NPDecoder, _aggregate_feature_map, _mlp3
+
+
+class BasicBlock(nn.Module):
+    """BBB twin of the residual block: 3x3 s2 + ReLU, 3x3 s1, 3x3 s2 skip (ANPMRShapeNet3D.py:38-62)."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, **kwargs):
+        super().__init__()
+        self.conv1 = BBBConv2d(inplanes, planes, stride=stride, **kwargs)
+        self.conv1.fuse_relu = True
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = BBBConv2d(planes, planes, **kwargs)
+        if stride != 1:
+            downsample = nn.Sequential(BBBConv2d(inplanes, inplanes, stride=stride, **kwargs))
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.conv2(self.conv1(x))                       # eps order: conv1, conv2, then the skip
+        identity = self.downsample(x) if self.downsample is not None else x
+        return AddReluFunction.apply(out, identity)
+
+
+def conv_block(in_channels, out_channels, **kwargs):
+    conv = BBBConv2d(in_channels, out_channels, **kwargs)
+    conv.fuse_relu = True
+    return nn.Sequential(OrderedDict([("conv", conv), ("relu", nn.Identity())]))   # ReLU is fused into the conv kernel
+
+
+class BBBEncoder(ModuleWrapper):
+    def __init__(self, img_channels, device):
+        super().__init__()
+        kw = dict(kernel_size=3, padding=1, bias=True)
+        self.net = nn.Sequential(OrderedDict([
+            ("layer1", conv_block(img_channels, 64, kernel_size=5, stride=2, padding=2, bias=True)),
+            ("layer2", BasicBlock(64, 64, stride=2, **kw)), ("layer3", BasicBlock(64, 64, stride=2, **kw)),
+            ("layer4", BasicBlock(64, 64, stride=2, **kw)), ("layer5", BasicBlock(64, 64, stride=2, **kw)),
+            ("flatten", FlattenLayer(256))]))
+
+
+class ANPMRShapeNet3D(ResNetNP):
+    ATTENTION = True
+
+    def __init__(self, config):
+        nn.Module.__init__(self)
+        self.device = config.device
+        self.img_size = config.img_size
+        self.img_channels = self.img_size[2] - 1 if config.task == "shapenet_3d" else self.img_size[2]
+        self.task_num = config.tasks_per_batch
+        self.label_dim = config.input_dim
+        self.agg_mode, self.img_agg, self.y_dim = config.agg_mode, config.img_agg, config.output_dim
+        torch.manual_seed(config.seed)
+        self.img_encoder = BBBEncoder(img_channels=self.img_channels, device=self.device)
+        self.task_encoder = nn.Sequential(nn.Linear(256 + self.label_dim, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                          nn.Linear(256, 256), nn.ReLU())
+        self.mu = nn.Linear(256, 256)
+        self.decoder = NPDecoder(aggregate=self.img_agg, output_dim=self.y_dim, task_num=self.task_num,
+                                 img_channels=self.img_channels, img_size=self.img_size)
+        h = 256
+        self._W_k = nn.ModuleList([AttnLinear(h, h) for _ in range(self.N_HEADS)])
+        self._W_v = nn.ModuleList([AttnLinear(h, h) for _ in range(self.N_HEADS)])
+        self._W_q = nn.ModuleList([AttnLinear(h, h) for _ in range(self.N_HEADS)])
+        self._W = AttnLinear(self.N_HEADS * h, h)
+        self.attn = FastAttention(dim_heads=256, causal=False)
+        self.n_heads = self.N_HEADS
+
+    def pixel_agg(self, x):
+        # the BBB encoder already flattened to [n, 256]; only "reshape" is shape-consistent with it
+        if self.img_agg not in ("reshape", "max", "baco", "mean"):
+            raise TypeError("Non-valid img_agg!")
+        x = x.reshape(x.size(0), -1)
+        return x.view(self.task_num, -1, x.size(1))
+
+    def forward(self, batch_train_images, label_train, batch_test_images, test=False):
+        self.test_num = batch_test_images.shape[1]
+        self.ctx_num = batch_train_images.shape[1]
+        C, H, W = self.img_channels, self.img_size[0], self.img_size[1]
+        if self.ctx_num:
+            x_ctx, _ = self.img_encoder(batch_train_images.reshape(-1, C, H, W))
+            x_tgt, kl = self.img_encoder(batch_test_images.reshape(-1, C, H, W))     # a second, independent weight sample
+            x_ctx, x_tgt = self.pixel_agg(x_ctx), self.pixel_agg(x_tgt)
+            feats = _mlp3(torch.cat([x_ctx, label_train], dim=2), self.task_encoder, last_relu=True)
+            sample = LinearFunction.apply(self._multihead_attention(x_ctx, feats, x_tgt), self.mu.weight, self.mu.bias, "none")
+        else:
+            sample = torch.zeros(self.task_num, self.test_num, 256, device=batch_test_images.device)
+            kl = 0
+        out, var = self.decoder(batch_test_images, sample)
+        return out, var, kl
