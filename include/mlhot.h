@@ -142,6 +142,19 @@ int mlhot_bbb_sample_fwd(const float* mu, const float* rho, const float* eps, fl
 int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, const float* dw, const float* dkl, float* dmu, float* drho,
                          size_t n, void* stream);
 
+/* ---- X1: ConvEmbeddingModel building blocks (networks/conv_embedding_model.py:99-184) -------------
+ * Train-mode batch norm over the shots of ONE task, fused with the ReLU that follows it:
+ * y = relu(gamma * (x - mean_c) / sqrt(var_c + eps) + beta) with per-channel batch statistics; like
+ * F.batch_norm(training=True) it updates run_mean / run_var in place (momentum, unbiased variance).
+ * mean / var [C] are returned for the backward.  x, y: [N, C, HW].                                 */
+int mlhot_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                      int N, int C, int HW, float* y, float* mean, float* var, void* stream);
+int mlhot_bn_relu_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* mean, const float* var, float eps,
+                      int N, int C, int HW, float* dx, float* dgamma, float* dbeta, void* stream);
+/* mean over the HW axis of `planes` maps (torch.mean(x.view(n, c, -1), dim=2), conv_embedding_model.py:119-123) */
+int mlhot_spatial_mean_fwd(const float* x, float* y, int planes, int HW, void* stream);
+int mlhot_spatial_mean_bwd(const float* dy, float* dx, int planes, int HW, void* stream);
+
 /* ---- whole vanilla CNP/ANP model: forward + backward in one call each --------------------
  * replaces <Model>.forward for CNPVanillaPascal1D / CNPShapeNet1D / ANPVanillaPascal1D /
  * ANPShapeNet1D (CNPShapeNet1D.py:96-140, ANPShapeNet1D.py:93-157) and its autograd backward. */

@@ -295,6 +295,38 @@ def test_anpmr_shapenet3d_vs_reference(gpulib):
         U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
 
 
+def test_conv_embedding_model_vs_reference(gpulib):
+    """X1: ConvEmbeddingModel (MMAML task embedding) on one task's shots: the four embedding vectors, every
+    gradient and the in-place running-stat update against the reference's vectors."""
+    fx = np.load(os.path.join(U.GOLDEN, "conv_embedding.npz"))
+    meta = json.loads(str(fx["meta"]))
+    from networks.conv_embedding_model import ConvEmbeddingModel
+    torch.manual_seed(meta["seed"])
+    model = ConvEmbeddingModel(input_size=128 * 128, output_size=2, embedding_dims=[64, 128, 256, 512], hidden_size=128,
+                               num_layers=2, convolutional=True, num_conv=4, num_channels=32, rnn_aggregation=False,
+                               linear_before_rnn=False, embedding_pooling="avg", batch_norm=True, avgpool_after_conv=True,
+                               img_size=(1, 128, 128))
+    for k, v in model.state_dict().items():
+        assert U.sha(v) == meta["state_sha"][k], k
+    assert model.to(DEV) is model
+    x = torch.rand(6, 1, 128, 128, generator=torch.Generator().manual_seed(meta["input_seed"]))
+    embs = model(x.to(DEV))
+    for i, e in enumerate(embs):
+        assert U.rel_err(e, fx[f"emb{i}"]) <= U.RTOL
+    sum((e * (i + 1)).sum() for i, e in enumerate(embs)).backward()
+    grads = dict(model.named_parameters())
+    gmax = max(float(np.abs(fx[k]).max()) for k in fx.files if k.startswith("grad/"))
+    for k in fx.files:
+        if k.startswith("grad/"):
+            got = grads[k[5:]].grad
+            if k.startswith("grad/conv.conv") and k.endswith(".bias"):      # analytically zero (bias before a batch norm)
+                assert got.abs().max().item() <= 1e-4 * gmax
+                continue
+            assert U.rel_err(got, fx[k], floor=U.GRAD_FLOOR * gmax) <= U.RTOL, k
+        if k.startswith("after/"):
+            assert U.rel_err(model.state_dict()[k[6:]], fx[k]) <= U.RTOL, k
+
+
 def test_forward_is_deterministic_and_task_independent(gpulib):
     """Size-independent properties at the full c3 size: bitwise run-to-run determinism, and
     (tasks are independent apart from the FAVOR+ global key stabiliser) a task's output does not

@@ -30,6 +30,41 @@ __global__ __launch_bounds__(256) void reduce1_kernel(const R r, int n) {
 }
 #endif
 
+// One 256-thread workgroup per "segment" g: acc = combine over i < n of r.load(g, i) in a fixed-order
+// LDS tree, then r.finish(g, acc).  Used for per-channel batch-norm statistics (a segment = a channel).
+#ifndef MLHOT_HOSTSIM
+template <class R>
+__global__ __launch_bounds__(256) void reduce_seg_kernel(const R r, int n) {
+  __shared__ typename R::T sm[256];
+  const int g = blockIdx.x;
+  typename R::T acc = r.identity();
+  for (int i = threadIdx.x; i < n; i += 256) acc = r.combine(acc, r.load(g, i));
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = r.combine(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) r.finish(g, sm[0]);
+}
+#endif
+template <class R>
+int run_reduce_seg(const R& r, int nseg, int n, hipStream_t stream, const char* what) {
+#ifdef MLHOT_HOSTSIM
+  (void)stream; (void)what;
+  for (int g = 0; g < nseg; ++g) {
+    typename R::T acc = r.identity();
+    for (int i = 0; i < n; ++i) acc = r.combine(acc, r.load(g, i));
+    r.finish(g, acc);
+  }
+  return MLHOT_OK;
+#else
+  ProfScope ps(what, stream);
+  hipLaunchKernelGGL((reduce_seg_kernel<R>), dim3(nseg), dim3(256), 0, stream, r, n);
+  return check_launch(what);
+#endif
+}
+
 template <class F>
 int run_foreach(const F& f, size_t n, hipStream_t stream, const char* what) {
   if (n == 0) return MLHOT_OK;

@@ -215,6 +215,29 @@ int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, co
   return run_foreach(BbbSampleBwd{mu, rho, eps, dw, dkl, dmu, drho}, n, (hipStream_t)stream, "bbb.sample.bwd");
 }
 
+// ---- X1 building blocks: train-mode batch norm (+ReLU) over one task's shots, spatial mean ----------
+int mlhot_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
+                      int N, int C, int HW, float* y, float* mean, float* var, void* stream) {
+  if (N <= 0 || C <= 0 || HW <= 0) { set_error("bn_relu_fwd: bad argument"); return MLHOT_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  MLHOT_TRY(run_reduce_seg(BnStats{x, C, HW, mean, N * HW}, C, N * HW, s, "bn.mean"));
+  MLHOT_TRY(run_reduce_seg(BnVar{x, C, HW, mean, var, run_mean, run_var, momentum, N * HW}, C, N * HW, s, "bn.var"));
+  return run_foreach(BnApplyRelu{x, mean, var, gamma, beta, eps, C, HW, y}, (size_t)N * C * HW, s, "bn.apply");
+}
+int mlhot_bn_relu_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* mean, const float* var, float eps,
+                      int N, int C, int HW, float* dx, float* dgamma, float* dbeta, void* stream) {
+  if (N <= 0 || C <= 0 || HW <= 0) { set_error("bn_relu_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  MLHOT_TRY(run_reduce_seg(BnBwdSums{x, y, dy, mean, var, eps, C, HW, dgamma, dbeta}, C, N * HW, s, "bn.bwd.sums"));
+  return run_foreach(BnBwdApply{x, y, dy, mean, var, gamma, dgamma, dbeta, eps, C, HW, N * HW, dx}, (size_t)N * C * HW, s, "bn.bwd.apply");
+}
+int mlhot_spatial_mean_fwd(const float* x, float* y, int planes, int HW, void* stream) {
+  return run_foreach(SpatialMean{x, HW, y}, (size_t)planes, (hipStream_t)stream, "spatial_mean.fwd");
+}
+int mlhot_spatial_mean_bwd(const float* dy, float* dx, int planes, int HW, void* stream) {
+  return run_foreach(SpatialMeanBwd{dy, HW, dx}, (size_t)planes * HW, (hipStream_t)stream, "spatial_mean.bwd");
+}
+
 // ---- whole model ------------------------------------------------------------------------------
 size_t mlhot_np_struct_bytes(int which) {
   return which == 0 ? sizeof(mlhot_np_dims) : which == 1 ? sizeof(mlhot_np_params) : sizeof(mlhot_np_grads);

@@ -99,6 +99,73 @@ struct BbbSampleBwd {   // dmu = dw + dkl * mu/sigma^2 ; drho = (dw*eps + dkl * 
   }
 };
 
+// ------------------------------------------------------------------------------------------
+// X1: train-mode batch norm of ConvEmbeddingModel (conv_embedding_model.py:113-117): the batch is the
+// shots of ONE task; statistics per channel over (n, h, w); F.batch_norm(training=True) also updates the
+// running buffers in place with momentum 0.1 and the UNBIASED variance.
+// ------------------------------------------------------------------------------------------
+struct Pair2 { float a, b; };
+struct BnStats {     // per channel: mean and biased variance (two-pass: sum, then centred squares via sum/sumsq in fp32 is avoided)
+  typedef Pair2 T;
+  const float* x; int C, HW; float* mean;    // pass 1: mean
+  MLHOT_HD T identity() const { return T{0.f, 0.f}; }
+  MLHOT_HD T load(int c, int i) const { const int n = i / HW, r = i % HW; return T{x[((size_t)n * C + c) * HW + r], 0.f}; }
+  MLHOT_HD T combine(T u, T v) const { return T{u.a + v.a, 0.f}; }
+  int count;
+  MLHOT_HD void finish(int c, T s) const { mean[c] = s.a / (float)count; }
+};
+struct BnVar {       // pass 2: biased variance around the mean; updates the running buffers
+  typedef Pair2 T;
+  const float* x; int C, HW; const float* mean; float* var; float* run_mean; float* run_var; float momentum; int count;
+  MLHOT_HD T identity() const { return T{0.f, 0.f}; }
+  MLHOT_HD T load(int c, int i) const { const int n = i / HW, r = i % HW; const float d = x[((size_t)n * C + c) * HW + r] - mean[c]; return T{d * d, 0.f}; }
+  MLHOT_HD T combine(T u, T v) const { return T{u.a + v.a, 0.f}; }
+  MLHOT_HD void finish(int c, T s) const {
+    var[c] = s.a / (float)count;
+    if (run_mean) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[c];
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (count > 1 ? s.a / (float)(count - 1) : var[c]);
+    }
+  }
+};
+// y = relu(gamma * (x - mean) / sqrt(var + eps) + beta)
+struct BnApplyRelu {
+  const float* x; const float* mean; const float* var; const float* gamma; const float* beta; float eps; int C, HW; float* y;
+  MLHOT_HD void operator()(size_t i) const {
+    const int c = (int)((i / HW) % C);
+    const float v = gamma[c] * (x[i] - mean[c]) / sqrtf(var[c] + eps) + beta[c];
+    y[i] = v > 0.f ? v : 0.f;
+  }
+};
+// backward sums per channel: a = sum g, b = sum g * xhat, with g = dy * (y > 0)
+struct BnBwdSums {
+  typedef Pair2 T;
+  const float* x; const float* y; const float* dy; const float* mean; const float* var; float eps; int C, HW;
+  float* dgamma; float* dbeta;
+  MLHOT_HD T identity() const { return T{0.f, 0.f}; }
+  MLHOT_HD T load(int c, int i) const {
+    const int n = i / HW, r = i % HW; const size_t o = ((size_t)n * C + c) * HW + r;
+    const float g = y[o] > 0.f ? dy[o] : 0.f;
+    return T{g, g * (x[o] - mean[c]) / sqrtf(var[c] + eps)};
+  }
+  MLHOT_HD T combine(T u, T v) const { return T{u.a + v.a, u.b + v.b}; }
+  MLHOT_HD void finish(int c, T s) const { dbeta[c] = s.a; dgamma[c] = s.b; }
+};
+// dx = gamma / sqrt(var+eps) * (g - mean(g) - xhat * mean(g * xhat))
+struct BnBwdApply {
+  const float* x; const float* y; const float* dy; const float* mean; const float* var; const float* gamma;
+  const float* dgamma; const float* dbeta; float eps; int C, HW, count; float* dx;
+  MLHOT_HD void operator()(size_t i) const {
+    const int c = (int)((i / HW) % C);
+    const float inv = 1.f / sqrtf(var[c] + eps), xh = (x[i] - mean[c]) * inv;
+    const float g = y[i] > 0.f ? dy[i] : 0.f;
+    dx[i] = gamma[c] * inv * (g - dbeta[c] / (float)count - xh * dgamma[c] / (float)count);
+  }
+};
+// spatial mean over HW: [n][C][HW] -> [n][C], and its backward
+struct SpatialMean { const float* x; int HW; float* y; MLHOT_HD void operator()(size_t i) const { float s = 0.f; for (int r = 0; r < HW; ++r) s += x[i * HW + r]; y[i] = s / (float)HW; } };
+struct SpatialMeanBwd { const float* dy; int HW; float* dx; MLHOT_HD void operator()(size_t i) const { dx[i] = dy[i / HW] / (float)HW; } };
+
 struct FillF { float* p; float v; MLHOT_HD void operator()(size_t i) const { p[i] = v; } };
 
 // strided 2-D fill: rows x cols window of a [rows][ld] matrix

@@ -136,6 +136,11 @@ class MlhotLib:
         c.mlhot_pool2_bwd.argtypes = [P, P, P, i, i, i, P]
         c.mlhot_bbb_sample_fwd.argtypes = [P, P, P, P, P, P, z, P]
         c.mlhot_bbb_sample_bwd.argtypes = [P, P, P, P, P, P, P, z, P]
+        f32 = C.c_float
+        c.mlhot_bn_relu_fwd.argtypes = [P, P, P, P, P, f32, f32, i, i, i, P, P, P, P]
+        c.mlhot_bn_relu_bwd.argtypes = [P, P, P, P, P, P, f32, i, i, i, P, P, P, P]
+        c.mlhot_spatial_mean_fwd.argtypes = [P, P, i, i, P]
+        c.mlhot_spatial_mean_bwd.argtypes = [P, P, i, i, P]
         c.mlhot_np_vanilla_fwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, P, z, P]
         c.mlhot_np_vanilla_bwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, C.POINTER(NpGrads), P, P, z, P]
         for which, st in ((0, NpDims), (1, NpParams), (2, NpGrads)):
@@ -291,6 +296,41 @@ class MlhotLib:
         self._rc(self.c.mlhot_bbb_sample_bwd(_ptr(mu), _ptr(rho), _ptr(eps), _ptr(dw), _ptr(dkl), _ptr(dmu), _ptr(drho), mu.numel(), _stream(mu)),
                  "mlhot_bbb_sample_bwd")
         return dmu, drho
+
+    # ---- X1 building blocks --------------------------------------------------------------------
+    def bn_relu_fwd(self, x, gamma, beta, run_mean, run_var, momentum=0.1, eps=1e-5):
+        _chk(x, gamma, beta, run_mean, run_var)
+        N, Cc = x.shape[:2]
+        HW = x.numel() // (N * Cc)
+        y = torch.empty_like(x)
+        mean, var = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
+        self._rc(self.c.mlhot_bn_relu_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(run_mean), _ptr(run_var), momentum, eps, N, Cc, HW,
+                                          _ptr(y), _ptr(mean), _ptr(var), _stream(x)), "mlhot_bn_relu_fwd")
+        return y, mean, var
+
+    def bn_relu_bwd(self, x, y, dy, gamma, mean, var, eps=1e-5):
+        _chk(dy)
+        N, Cc = x.shape[:2]
+        HW = x.numel() // (N * Cc)
+        dx, dgamma, dbeta = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+        self._rc(self.c.mlhot_bn_relu_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(gamma), _ptr(mean), _ptr(var), eps, N, Cc, HW,
+                                          _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream(x)), "mlhot_bn_relu_bwd")
+        return dx, dgamma, dbeta
+
+    def spatial_mean_fwd(self, x):
+        _chk(x)
+        N, Cc = x.shape[:2]
+        HW = x.numel() // (N * Cc)
+        y = torch.empty(N, Cc, device=x.device)
+        self._rc(self.c.mlhot_spatial_mean_fwd(_ptr(x), _ptr(y), N * Cc, HW, _stream(x)), "mlhot_spatial_mean_fwd")
+        return y
+
+    def spatial_mean_bwd(self, dy, shape):
+        _chk(dy)
+        dx = torch.empty(shape, device=dy.device)
+        N, Cc = shape[:2]
+        self._rc(self.c.mlhot_spatial_mean_bwd(_ptr(dy), _ptr(dx), N * Cc, dx.numel() // (N * Cc), _stream(dy)), "mlhot_spatial_mean_bwd")
+        return dx
 
     # ---- linear --------------------------------------------------------------------------------
     def linear_fwd(self, x, w, b, act="none"):

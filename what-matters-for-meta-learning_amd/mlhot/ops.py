@@ -228,3 +228,38 @@ class BBBSampleFunction(torch.autograd.Function):
             dkl = torch.zeros((), device=mu.device)
         dmu, drho = lib().bbb_sample_bwd(mu, rho, eps, _c(dw), _c(dkl.float()))
         return dmu, drho, None
+
+
+class BatchNormReluFunction(torch.autograd.Function):
+    """Train-mode batch norm over dim 0 (+ fused ReLU), updating the running buffers in place like
+    F.batch_norm(training=True): mlhot_bn_relu_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, momentum, eps):
+        _need_gpu(x, gamma, beta, run_mean, run_var)
+        x = _c(x)
+        y, mean, var = lib().bn_relu_fwd(x, _c(gamma.detach()), _c(beta.detach()), run_mean, run_var, momentum, eps)
+        ctx.eps = eps
+        ctx.save_for_backward(x, y, _c(gamma.detach()), mean, var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, var = ctx.saved_tensors
+        dx, dgamma, dbeta = lib().bn_relu_bwd(x, y, _c(dy), gamma, mean, var, ctx.eps)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+class SpatialMeanFunction(torch.autograd.Function):
+    """[n, C, H, W] -> [n, C] mean over the spatial axes."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = _c(x)
+        ctx.shape = tuple(x.shape)
+        return lib().spatial_mean_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return lib().spatial_mean_bwd(_c(dy), ctx.shape)

@@ -9,6 +9,8 @@ from collections import OrderedDict
 
 import torch
 
+from mlhot.ops import AggFunction, BatchNormReluFunction, Conv2dFunction, LinearFunction, SpatialMeanFunction
+
 
 class ConvEmbeddingModel(torch.nn.Module):
     def __init__(self, input_size, output_size, embedding_dims, hidden_size=128, num_layers=1, convolutional=False,
@@ -37,8 +39,24 @@ class ConvEmbeddingModel(torch.nn.Module):
         self._embeddings = torch.nn.ModuleList([torch.nn.Linear(hidden_size, d) for d in embedding_dims])
 
     def forward(self, x, params=None, return_task_embedding=False):
-        raise NotImplementedError("ConvEmbeddingModel.forward: HIP kernels for this module are scheduled after "
-                                  "the CNP/ANP path (SURVEY.md §8a row X1)")
+        """x: the shots of ONE task [n, C, H, W] -> list of 4 embedding vectors [1, dim]
+        (conv_embedding_model.py:99-184; `params` may override the module's own parameters)."""
+        if params is None:
+            params = OrderedDict(self.named_parameters())
+        for i in range(1, self._num_conv + 1):
+            x = Conv2dFunction.apply(x, params[f"conv.conv{i}.weight"], params[f"conv.conv{i}.bias"], 2, 1, False)
+            bn = getattr(self.conv, f"bn{i}")
+            # F.batch_norm(training=True) in the reference: batch statistics, default momentum 0.1, in-place running update
+            x = BatchNormReluFunction.apply(x, params[f"conv.bn{i}.weight"], params[f"conv.bn{i}.bias"], bn.running_mean,
+                                            bn.running_var, 0.1, 1e-5)
+        x = SpatialMeanFunction.apply(x)
+        hid = LinearFunction.apply(x, params["linear.weight"], params["linear.bias"], "relu")
+        if self._embedding_pooling not in ("avg", "max"):
+            raise NotImplementedError
+        pooled, _ = AggFunction.apply("mean" if self._embedding_pooling == "avg" else "max", hid[None], None)   # over the shot axis
+        out = [LinearFunction.apply(pooled, params[f"_embeddings.{j}.weight"], params[f"_embeddings.{j}.bias"], "none")
+               for j in range(len(self._embeddings))]
+        return (out, pooled) if return_task_embedding else out
 
     def to(self, device, **kwargs):
         self._device = device
