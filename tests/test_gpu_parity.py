@@ -343,6 +343,30 @@ def test_forward_is_deterministic_and_task_independent(gpulib):
         assert U.rel_err(c[perm], a) <= 1e-6
 
 
+def test_model_trainer_loop_on_synthetic_data(gpulib, tmp_path, monkeypatch):
+    """T1: the reference's train / validate loop (trainer/model_trainer.py:33-139) end to end on the HIP path,
+    with the reference's random context size per iteration (3..15 shots) and Adam."""
+    import types
+    from mlhot.synth import SyntheticData
+    from networks.ANPShapeNet1D import ANPShapeNet1D
+    from trainer.losses import LossFunc
+    from trainer.model_trainer import ModelTrainer
+    monkeypatch.chdir(tmp_path)
+    cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[128, 128, 1], tasks_per_batch=4, input_dim=3,
+                                output_dim=2, agg_mode="attention", img_agg="", dim_w=64, n_hidden_units_r=[100, 100], dim_r=64,
+                                dim_z=64, task="shapenet_1d", iterations=6, val_freq=3, val_iters=2, bg_gen_freq=1000, gen_bg=False,
+                                max_ctx_num=15, beta=0, contrastive=False, save_path=str(tmp_path / "run"), logger=None)
+    model = ANPShapeNet1D(cfg).to(cfg.device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    trainer = ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=opt, config=cfg, data=SyntheticData())
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    trainer.train()
+    assert os.path.exists(tmp_path / "run" / "models" / "model_end_6.pt")
+    assert os.path.exists(tmp_path / "run" / "models" / "best_validation_model.pt")
+    moved = sum(float((v - before[k]).abs().sum()) for k, v in model.state_dict().items() if "projection" not in k)
+    assert moved > 0 and all(torch.isfinite(v).all() for v in model.state_dict().values())
+
+
 def test_cpu_tensors_are_refused(gpulib):
     from mlhot.binding import MlhotError
     from mlhot.ops import LinearFunction

@@ -23,3 +23,25 @@ def get_batch(task, tasks_per_batch, n_ctx, n_qry, seed=1234, device="cpu"):
     else:
         raise ValueError(task)
     return tuple(t.to(device) for t in (xs, xq, ys, yq))
+
+
+class SyntheticData:
+    """Minimal stand-in for dataset.ShapeNet1D / Pascal1D with the reference's `get_batch` contract
+    (dataset/shapenet_1d.py:113-196): train batches draw a random context size in [3, shot], validation /
+    test batches use `shot` context images; the target count is always `shot`."""
+
+    def __init__(self, task="shapenet_1d", seed=42):
+        import numpy as np
+        self.task, self.test_counter = task, 0
+        self.rng = np.random.RandomState(seed)
+        self.val_rng, self.test_rng = np.random.RandomState(seed), np.random.RandomState(seed)
+        self._step = 0
+
+    def gen_bg(self, config, data="all"):
+        pass
+
+    def get_batch(self, source, tasks_per_batch, shot):
+        rng = {"train": self.rng, "validation": self.val_rng, "test": self.test_rng}[source]
+        n_ctx = int(rng.randint(3, shot + 1)) if source == "train" else shot
+        self._step += 1
+        return get_batch(self.task, tasks_per_batch, n_ctx, shot, seed=int(rng.randint(0, 2 ** 31 - 1)))

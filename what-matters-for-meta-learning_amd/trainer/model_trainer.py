@@ -1,0 +1,99 @@
+"""CNP / ANP trainer with the reference's loop (trainer/model_trainer.py:33-143): per iteration one
+meta-batch -> forward -> loss (+ beta * kl) -> backward -> optimizer step; periodic validation with
+best-model saving; intermediate / final checkpoints (`state_dict` only, like the reference).
+
+Differences that matter on MI355X: the loss value is fetched from the device once per iteration (one host
+sync instead of three), and with more than one rank the gradients are averaged by ONE flat-bucket
+all-reduce (mlhot.dist.GradBucket) before the optimizer step.
+"""
+import math
+import os
+import sys
+
+import torch
+
+from mlhot.dist import GradBucket
+from trainer.base_trainer import BaseTrainer
+
+
+class ModelTrainer(BaseTrainer):
+    def __init__(self, model, loss, optimizer, config, data):
+        super().__init__(model=model, loss=loss, optimizer=optimizer, config=config)
+        self.data = data
+        self.bucket = GradBucket(model.parameters())
+
+    def _log(self, msg):
+        logger = getattr(self.config, "logger", None)
+        if logger is not None:
+            logger.info(msg)
+
+    def train(self):
+        self._log("\\n================== Start training ===================")
+        it = self.start_iter
+        for it in range(self.start_iter, self.iterations + 1):
+            if it % self.config.bg_gen_freq == 0 and self.config.gen_bg:
+                self.data.gen_bg(self.config, data="train")
+            self._train_iter(it)
+            if it % self.config.val_freq == 0:
+                self._validate_iter(it, source="validation")
+                if self.config.task != "pascal_1d":
+                    self._validate_iter(it, source="test")
+            if it % 1000 == 0:
+                self.save_intermediate_model(it)
+        torch.save(self.model.state_dict(), f"{self.config.save_path}/models/model_end_{it}.pt")
+        self._log("================= Training finished =================\\n")
+
+    def _batch(self, source):
+        ctx_x, qry_x, ctx_y, qry_y = self.data.get_batch(source=source, tasks_per_batch=self.config.tasks_per_batch,
+                                                         shot=self.config.max_ctx_num)
+        dev = self.config.device
+        return ctx_x.to(dev), qry_x.to(dev), ctx_y.to(dev), qry_y.to(dev)
+
+    def _train_iter(self, it):
+        self.model.train()
+        self.optimizer.zero_grad()
+        ctx_x, qry_x, ctx_y, qry_y = self._batch("train")
+        if getattr(self.config, "contrastive", False):
+            raise NotImplementedError("the functional-contrastive (FCL) models are out of scope (SURVEY.md §2.1 row 9)")
+        pr_mu, pr_var, kl = self.model(ctx_x, ctx_y, qry_x)
+        losses = self.loss.calc_loss(pr_mu, pr_var, qry_y)
+        losses = losses + kl * self.config.beta
+        losses.backward()
+        self.bucket.sync()
+        self.optimizer.step()
+        value = losses.item()                                     # the iteration's only host sync
+        if self.writer is not None:
+            self.writer.add_scalar("Loss/train", value, it)
+        self._log(f"Train Iteration {it} loss: {value:.4f}\\n")
+        if not math.isfinite(value):
+            self._log(f"Loss is {value}, stopping training")
+            sys.exit(1)
+        return value
+
+    def _validate_iter(self, it, source):
+        self.model.eval()
+        with torch.no_grad():
+            self.data.test_counter = 0
+            rng = getattr(self.data, "test_rng" if source == "test" else "val_rng", None)
+            if rng is not None:
+                rng.seed(42)
+            vals = []
+            for _ in range(self.config.val_iters):
+                ctx_x, qry_x, ctx_y, qry_y = self._batch(source)
+                pr_mu, pr_var, _ = self.model(ctx_x, ctx_y, qry_x, test=True)
+                vals.append(self.loss.calc_loss(pr_mu, pr_var, qry_y, test=True).view(1))
+            vals = torch.cat(vals)
+            loss, std = vals.mean(), (vals.std() if vals.numel() > 1 else vals.new_zeros(()))
+            if self.writer is not None:
+                self.writer.add_scalar(f"Loss/{source}", loss, it)
+            self._log(f"{source} {it} loss: {loss.item():.4f}")
+            if loss < self.best_loss[source]:
+                self.best_loss[source] = loss
+                torch.save(self.model.state_dict(), f"{self.config.save_path}/models/best_{source}_model.pt")
+                with open(os.path.join(self.config.save_path, f"best_{source}_error.txt"), "a") as f:
+                    f.write(f"Best Step: {it} \\nBest {source} Loss: \\n{loss}\\nBest {source} Loss std: \\n{std}\\n")
+        return loss.item()
+
+    def save_intermediate_model(self, it):
+        torch.save(self.model.state_dict(), f"{self.config.save_path}/models/model_intermediate.pt")
+        self._log(f"save intermediate model iter: {it}")
