@@ -415,11 +415,14 @@ __device__ __forceinline__ void taps_fetch(Conv1Taps& tp, const ImgSrc& x, int t
     }
 }
 // a1[ci][row][col] = relu(b1 + w1 . taps) for ci in [c0, c1) -> patch; rows above the image are conv2's zero padding
+// returns bit ci = (a1[ci] > 0) for its channels: the forward keeps these 32 bits per a1 position (16 KiB per
+// image instead of the 512 KiB map) as conv1's ReLU mask for the backward
 template <int C0, int C1>
-__device__ __forceinline__ void conv1_to_patch(const Conv1Taps& tp, const float* __restrict__ w1, const float* __restrict__ b1,
-                                               float* patch, int tile, int cr, int cc) {
+__device__ __forceinline__ unsigned conv1_to_patch(const Conv1Taps& tp, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                   float* patch, int tile, int cr, int cc) {
   const bool valid = 8 * (tile & 7) - 1 + cr >= 0;
   float* d = patch + cr * RS + 1 + cc;
+  unsigned bits = 0;
 #pragma unroll
   for (int ci = C0; ci < C1; ++ci) {
     float sacc = 0.f;
@@ -427,12 +430,15 @@ __device__ __forceinline__ void conv1_to_patch(const Conv1Taps& tp, const float*
     for (int q = 0; q < 9; ++q) sacc = fmaf(tp.t[q], w1[ci * 9 + q], sacc);
     sacc += b1[ci];
     d[ci * PS] = valid ? fmaxf(sacc, 0.f) : 0.f;
+    bits |= (sacc > 0.f ? 1u : 0u) << ci;
   }
+  return bits;
 }
 
 __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                                             float* __restrict__ p2, uint8_t* __restrict__ amax, int n_img, int dbg) {
+                                                             float* __restrict__ p2, uint8_t* __restrict__ amax,
+                                                             unsigned* __restrict__ m1, int n_img, int dbg) {
   __shared__ float patch2[2 * PATCH_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
@@ -451,9 +457,13 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   const int ntiles = n_img * 8;
   int tile = blockIdx.x;
   Conv1Taps tp;
+  // mask row of patch row cr: a1 row 8*band - 1 + cr; row 0 is the previous band's (stored there)
+  auto mask_store = [&](int t, unsigned bits) {
+    if (cr >= 1) m1[((size_t)(t >> 3) * 64 + 8 * (t & 7) - 1 + cr) * 64 + cc] = bits;
+  };
   if (tile < ntiles && cact) {
     taps_fetch(tp, x, tile, cr, cc);
-    conv1_to_patch<0, 32>(tp, w1, b1, patch2, tile, cr, cc);
+    mask_store(tile, conv1_to_patch<0, 32>(tp, w1, b1, patch2, tile, cr, cc));
     if (tile + (int)gridDim.x < ntiles) taps_fetch(tp, x, tile + gridDim.x, cr, cc);
   }
   __syncthreads();
@@ -466,6 +476,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     const bool stage = next < ntiles && cact;
 
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    unsigned mbits = 0;
 #pragma unroll
     for (int seg = 0; seg < 6; ++seg) {
 #pragma unroll
@@ -479,10 +490,10 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
       }
       // the next band's a1 slice, 8 channels per segment, on the VALU between the MFMAs
       if (stage) {
-        if (seg == 0) conv1_to_patch<0, 8>(tp, w1, b1, nb, next, cr, cc);
-        if (seg == 1) conv1_to_patch<8, 16>(tp, w1, b1, nb, next, cr, cc);
-        if (seg == 2) conv1_to_patch<16, 24>(tp, w1, b1, nb, next, cr, cc);
-        if (seg == 3) conv1_to_patch<24, 32>(tp, w1, b1, nb, next, cr, cc);
+        if (seg == 0) mbits |= conv1_to_patch<0, 8>(tp, w1, b1, nb, next, cr, cc);
+        if (seg == 1) mbits |= conv1_to_patch<8, 16>(tp, w1, b1, nb, next, cr, cc);
+        if (seg == 2) mbits |= conv1_to_patch<16, 24>(tp, w1, b1, nb, next, cr, cc);
+        if (seg == 3) { mbits |= conv1_to_patch<24, 32>(tp, w1, b1, nb, next, cr, cc); mask_store(next, mbits); }
       }
       if (seg == 4 && cact && next + (int)gridDim.x < ntiles) taps_fetch(tp, x, next + gridDim.x, cr, cc);
     }
@@ -604,21 +615,29 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
 
 // ---- data gradient of conv2 + conv1 ReLU mask + conv1 weight/bias gradient ------------------------
 // 512 threads (8 waves, 2 per SIMD): wave w owns input channels 16*(w&1)..+15 and the band's a1 rows
-// {2pg, 2pg+1} (pg = w>>1): 72 + 144 = 216 MFMAs per band for every wave.  After each row's two
-// parity tiles the lane holds d a1 for 8 consecutive x of one channel; it recomputes a1 there from the
-// image strip staged in LDS (mask), and accumulates dW1[ci][3][3] / db1[ci] in registers.
+// {2pg, 2pg+1} (pg = w>>1): 72 + 144 = 216 MFMAs per band for every wave.  After a row's two parity
+// tiles the lane holds d a1 for 8 consecutive x of one channel: it masks them with the forward's
+// ReLU bits and feeds the two accumulators STRAIGHT BACK into the matrix core as the A operand of
+// conv1's weight gradient  Z[ci][tap] += sum_pos g[pos][ci] * T[pos][tap]  (an accumulator tile is a
+// valid operand for a product that sums over its row index, cdna guide §3): 8 MFMAs + 8 LDS reads
+// per row-half instead of ~150 VALU FMAs.  T comes from the image strip staged in LDS; tap column 9
+// is all ones and yields the bias gradient.  The dY patch and the strip are double-buffered, so
+// there is one barrier per band.
 constexpr int NT2 = 512;
 constexpr int SRS = 132, STRIP_FLOATS = 17 * SRS;     // image strip rows 16b-1 .. 16b+15, col c <-> ix = c - 1
+constexpr int D12_BUF = DYP_FLOATS + STRIP_FLOATS;
 
 template <int PY>
 __device__ __forceinline__ void dgrad12_row(const float* dyp, const float* strip, const float (&wr)[9][12],
-                                            const float (&w1r)[9], float b1r, float (&dw1)[9], float& db1,
-                                            int yl, int lr, int lq) {
+                                            const unsigned* __restrict__ mrow, f32x4_t& z, int toff, int yl, int ci, int lr, int lq) {
   const int yp = yl >> 1;
   // xh stays a real loop and every 12-MFMA group is fenced for the scheduler: fully unrolled and
   // unfenced, hipcc hoists all ~150 LDS operand reads of a row to the top (408 registers).
 #pragma unroll 1
   for (int xh = 0; xh < 2; ++xh) {
+    // conv1 ReLU bits of the 8 positions this lane will hold (x0 .. x0+7, x0 = 32xh + 8lq)
+    const uint4 mb0 = *reinterpret_cast<const uint4*>(mrow + 32 * xh + 8 * lq);
+    const uint4 mb1 = *reinterpret_cast<const uint4*>(mrow + 32 * xh + 8 * lq + 4);
     f32x4_t e = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
     const float* base = dyp + lq * DPS + yp * DRS + 16 * xh + lr;
     constexpr int NTY = PY ? 2 : 1;
@@ -636,62 +655,32 @@ __device__ __forceinline__ void dgrad12_row(const float* dyp, const float* strip
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // this lane: channel ci, a1 row yl of the band, columns x0 .. x0+7 (x0 = 32xh + 8lq)
-    // image strip rows 2yl + ky, columns 2*x0 + 2i + kx  (17 values per row)
-    // Two passes over the 3 strip rows (re-read from LDS) keep only one row of 17 values live.
-    const float* sp = strip + (2 * yl) * SRS + 2 * (32 * xh + 8 * lq);
-    float pre[8];
+    // lane: channel ci, positions x = x0 + 2r + px.  Mask, then Z += g^T T on the matrix core:
+    // MFMA r of parity px has A = g[row 4lq+r][ci] (this lane's register) and needs
+    // B[k = lq][n = tap lr] = T[position x' = 16xh + 4lq + r][tap] = strip[(2yl+ky)][2x + kx], x = 2x' + px.
+    const unsigned bit = 1u << ci;
+    e[0] = (mb0.x & bit) ? e[0] : 0.f; d[0] = (mb0.y & bit) ? d[0] : 0.f;
+    e[1] = (mb0.z & bit) ? e[1] : 0.f; d[1] = (mb0.w & bit) ? d[1] : 0.f;
+    e[2] = (mb1.x & bit) ? e[2] : 0.f; d[2] = (mb1.y & bit) ? d[2] : 0.f;
+    e[3] = (mb1.z & bit) ? e[3] : 0.f; d[3] = (mb1.w & bit) ? d[3] : 0.f;
+    const float* tp = strip + (2 * yl) * SRS + toff + 4 * (16 * xh + 4 * lq);      // + 4r + 2px below
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pre[i] = b1r;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      float t[17];
-#pragma unroll
-      for (int v4 = 0; v4 < 4; ++v4) {
-        const float4 q = *reinterpret_cast<const float4*>(sp + ky * SRS + 4 * v4);
-        t[4 * v4] = q.x; t[4 * v4 + 1] = q.y; t[4 * v4 + 2] = q.z; t[4 * v4 + 3] = q.w;
-      }
-      t[16] = sp[ky * SRS + 16];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) pre[i] = fmaf(t[2 * i + kx], w1r[ky * 3 + kx], pre[i]);
+    for (int r = 0; r < 4; ++r) {
+      const float t0 = lr < 9 ? tp[4 * r] : (lr == 9 ? 1.f : 0.f);
+      const float t1 = lr < 9 ? tp[4 * r + 2] : (lr == 9 ? 1.f : 0.f);
+      z = mfma4(e[r], t0, z);
+      z = mfma4(d[r], t1, z);
     }
-    float g[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float gv = (i & 1) ? d[i >> 1] : e[i >> 1];
-      g[i] = pre[i] > 0.f ? gv : 0.f;
-      db1 += g[i];
-    }
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      float t[17];
-#pragma unroll
-      for (int v4 = 0; v4 < 4; ++v4) {
-        const float4 q = *reinterpret_cast<const float4*>(sp + ky * SRS + 4 * v4);
-        t[4 * v4] = q.x; t[4 * v4 + 1] = q.y; t[4 * v4 + 2] = q.z; t[4 * v4 + 3] = q.w;
-      }
-      t[16] = sp[ky * SRS + 16];
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        float sacc = dw1[ky * 3 + kx];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sacc = fmaf(g[i], t[2 * i + kx], sacc);
-        dw1[ky * 3 + kx] = sacc;
-      }
-    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-__global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
+__global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const unsigned* __restrict__ m1,
                                                            const float* __restrict__ dp2, const float* __restrict__ p2,
                                                            const uint8_t* __restrict__ amax, const float* __restrict__ w,
                                                            float* __restrict__ slab1, int n_img) {
-  __shared__ float lds[DYP_FLOATS + STRIP_FLOATS + 8 * 16 * 10];
-  float* dyp = lds;
-  float* strip = lds + DYP_FLOATS;
-  float* red = strip + STRIP_FLOATS;
+  __shared__ float lds[2 * D12_BUF + 8 * 16 * 16];
+  float* red = lds + 2 * D12_BUF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave & 1, pg = wave >> 1;
   const int lr = lane & 15, lq = lane >> 4;
@@ -702,14 +691,16 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
     for (int ks = 0; ks < 12; ++ks) wr[tap][ks] = w[((size_t)(4 * ks + lq) * CIN + ci) * 9 + tap];
-  float w1r[9], dw1[9];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) { w1r[q] = w1[ci * 9 + q]; dw1[q] = 0.f; }
-  const float b1r = b1[ci];
-  float db1 = 0.f;
+  // this lane's tap (as B-operand column lr of the conv1 weight gradient): strip offset ky*SRS + kx
+  const int toff = lr < 9 ? (lr / 3) * SRS + lr % 3 : 0;
+  f32x4_t z = {0.f, 0.f, 0.f, 0.f};          // Z[ci = 16nt + 4lq + r][tap lr], summed over this wave's positions
 
-  for (int i = tid; i < COUT * 5; i += NT2) dyp[(i / 5) * DPS + (i % 5) * DRS + 32] = 0.f;   // halo column
-  for (int i = tid; i < 17; i += NT2) strip[i * SRS] = 0.f;                                   // ix = -1 column
+  for (int bsel = 0; bsel < 2; ++bsel) {
+    float* dypb = lds + bsel * D12_BUF;
+    float* stripb = dypb + DYP_FLOATS;
+    for (int i = tid; i < COUT * 5; i += NT2) dypb[(i / 5) * DPS + (i % 5) * DRS + 32] = 0.f;   // halo column
+    for (int i = tid; i < 17; i += NT2) stripb[i * SRS] = 0.f;                                   // ix = -1 column
+  }
   const int ntiles = n_img * 8;
   float cdp[5], cp[5]; unsigned cam[5];
   float4 sv[2];
@@ -725,8 +716,7 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
         cdp[j] = dp2[o]; cp[j] = p2[o]; cam[j] = amax[o];
       }
     }
-    // image strip: 17 rows x 32 float4
-    const float* xi = x.img(img);
+    const float* xi = x.img(img);       // image strip: 17 rows x 32 float4
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int e = tid + j * NT2, row = e >> 5, x4 = e & 31;
@@ -735,16 +725,13 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
       if (e < 17 * 32 && iy >= 0) sv[j] = *reinterpret_cast<const float4*>(xi + iy * 128 + 4 * x4);
     }
   };
-  int tile = blockIdx.x;
-  if (tile < ntiles) cells_fetch(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();
+  auto cells_store = [&](float* dypb, float* stripb) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int e = tid + j * NT2, px = e & 15, pyl = (e >> 4) % 3, co = e / 48;
       if (e < 2304) {
         const float g = cp[j] > 0.f ? cdp[j] : 0.f;
-        float* d = dyp + co * DPS + (2 * pyl) * DRS + 2 * px;
+        float* d = dypb + co * DPS + (2 * pyl) * DRS + 2 * px;
         d[0] = cam[j] == 0u ? g : 0.f;
         d[1] = cam[j] == 1u ? g : 0.f;
         if (pyl < 2) {
@@ -757,32 +744,42 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
     for (int j = 0; j < 2; ++j) {
       const int e = tid + j * NT2, row = e >> 5, x4 = e & 31;
       if (e < 17 * 32) {
-        float* d = strip + row * SRS + 1 + 4 * x4;
+        float* d = stripb + row * SRS + 1 + 4 * x4;
         d[0] = sv[j].x; d[1] = sv[j].y; d[2] = sv[j].z; d[3] = sv[j].w;
       }
     }
+  };
+  int tile = blockIdx.x;
+  __syncthreads();
+  if (tile < ntiles) { cells_fetch(tile); cells_store(lds, lds + DYP_FLOATS); }
+  if (tile + (int)gridDim.x < ntiles) cells_fetch(tile + gridDim.x);
+  __syncthreads();
+  int cur = 0;
+  for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+    const float* dyp = lds + cur * D12_BUF;
+    const float* strip = dyp + DYP_FLOATS;
+    const int img = tile >> 3, band = tile & 7;
+    const unsigned* mrow = m1 + ((size_t)img * 64 + 8 * band + 2 * pg) * 64;
+    dgrad12_row<0>(dyp, strip, wr, mrow, z, toff, 2 * pg, ci, lr, lq);
+    // stage the next band into the idle buffers between the two rows; prefetch the one after it
+    const int next = tile + (int)gridDim.x;
+    if (next < ntiles) {
+      cells_store(lds + (cur ^ 1) * D12_BUF, lds + (cur ^ 1) * D12_BUF + DYP_FLOATS);
+      if (next + (int)gridDim.x < ntiles) cells_fetch(next + gridDim.x);
+    }
+    dgrad12_row<1>(dyp, strip, wr, mrow + 64, z, toff, 2 * pg + 1, ci, lr, lq);
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) cells_fetch(tile + gridDim.x);
-    dgrad12_row<0>(dyp, strip, wr, w1r, b1r, dw1, db1, 2 * pg, lr, lq);
-    dgrad12_row<1>(dyp, strip, wr, w1r, b1r, dw1, db1, 2 * pg + 1, lr, lq);
   }
-  // conv1 gradient partials: fold the 4 lq lanes of a channel, then the 4 row-group waves
+  // conv1 gradient partials: fold the 4 row-group waves of each channel half, write [block][ci][16 tap columns]
 #pragma unroll
-  for (int q = 0; q < 9; ++q) { dw1[q] += __shfl_xor(dw1[q], 16, 64); dw1[q] += __shfl_xor(dw1[q], 32, 64); }
-  db1 += __shfl_xor(db1, 16, 64); db1 += __shfl_xor(db1, 32, 64);
+  for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * lq + r) * 16 + lr] = z[r];
   __syncthreads();
-  if (lq == 0) {
-#pragma unroll
-    for (int q = 0; q < 9; ++q) red[(wave * 16 + lr) * 10 + q] = dw1[q];
-    red[(wave * 16 + lr) * 10 + 9] = db1;
-  }
-  __syncthreads();
-  if (tid < 320) {
-    const int c = tid / 10, q = tid % 10, ntc = c >> 4, lrc = c & 15;
+  if (tid < 512) {
+    const int c = tid >> 4, q = tid & 15, ntc = c >> 4, cl = c & 15;     // channel c, tap column q
     float sacc = 0.f;
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) sacc += red[((2 * g4 + ntc) * 16 + lrc) * 10 + q];
-    slab1[(size_t)blockIdx.x * 320 + tid] = sacc;      // [block][ci][9 weights | bias]
+    for (int g4 = 0; g4 < 4; ++g4) sacc += red[((2 * g4 + ntc) * 16 + cl) * 16 + q];
+    if (q < 10) slab1[(size_t)blockIdx.x * 320 + c * 10 + q] = sacc;     // [block][ci][9 weights | bias]
   }
 }
 

@@ -25,7 +25,7 @@ extern Options g_opt;
 constexpr int C2_GRID = 256;   // one persistent workgroup per CU
 
 struct EncSaved {
-  float* a1; float* p2; uint8_t* am2; float* a3; bool ok; size_t bytes;
+  float* a1; float* p2; uint8_t* am2; float* a3; unsigned* m1; bool ok; size_t bytes;
 };
 inline EncSaved enc_saved_carve(int n, void* base, size_t cap) {
   Arena a(base, cap);
@@ -34,6 +34,7 @@ inline EncSaved enc_saved_carve(int n, void* base, size_t cap) {
   s.p2 = a.take<float>((size_t)n * 48 * 16 * 16);
   s.am2 = a.take<uint8_t>((size_t)n * 48 * 16 * 16);
   s.a3 = a.take<float>((size_t)n * 4096);
+  s.m1 = a.take<unsigned>((size_t)n * 64 * 64);     // conv1 ReLU bits (bit ci of word [y][x]), written by the fused forward
   s.ok = a.ok; s.bytes = a.off + 256;
   return s;
 }
@@ -98,7 +99,7 @@ inline int enc_forward(const float* img0, int n0, const float* img1, int n1, con
     {
       ProfScope ps("enc.conv12", s);
       hipLaunchKernelGGL(c2::conv12_fwd_pool_kernel, dim3(grid), dim3(c2::NT), 0, s, c2::ImgSrc{img0, n0, img1}, p.w1, p.b1,
-                         p.w2, p.b2, sv.p2, sv.am2, n, g_opt.dbg);
+                         p.w2, p.b2, sv.p2, sv.am2, sv.m1, n, g_opt.dbg);
     }
     MLHOT_TRY(check_launch("enc.conv12"));
   } else
@@ -179,7 +180,7 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     MLHOT_TRY(check_launch("enc.bwd.conv2.wgrad.reduce"));
     {
       ProfScope ps("enc.bwd.conv12.dgrad", s);
-      hipLaunchKernelGGL(c2::conv12_dgrad_kernel, dim3(grid), dim3(c2::NT2), 0, s, xs, p.w1, p.b1, sc.dp2, sv.p2, sv.am2, p.w2, slab_1, n);
+      hipLaunchKernelGGL(c2::conv12_dgrad_kernel, dim3(grid), dim3(c2::NT2), 0, s, xs, sv.m1, sc.dp2, sv.p2, sv.am2, p.w2, slab_1, n);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv12.dgrad"));
     {
