@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Stage timestamps inside the fused tail kernels (latency hunting, not a benchmark).
+
+Needs the instrumented build:  hipcc ... -DMLHOT_TS mlhot.hip -o csrc/libmlhot_ts.so, then
+    MLHOT_LIB=.../libmlhot_ts.so python scripts/tail_ts.py
+Workgroup 0 / thread 0 of each instrumented kernel stores wall_clock64() (100 MHz) at stage boundaries.
+"""
+import ctypes
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "what-matters-for-meta-learning_amd"), ROOT]
+import torch  # noqa: E402
+import bench  # noqa: E402
+import mlhot  # noqa: E402
+from mlhot import synth  # noqa: E402
+from trainer.losses import LossFunc  # noqa: E402
+
+dev = torch.device("cuda", 0)
+w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(bench.make_cfg(w, dev)).to(dev)
+loss_fn = LossFunc("mse", "shapenet_1d")
+cx, qx, cy, qy = synth.get_batch("shapenet_1d", 16, 15, 15, seed=1234, device=dev)
+ts = torch.zeros(512, dtype=torch.int64, device=dev)
+L = mlhot.lib()
+L.c.mlhot_dbg_tsbuf.argtypes = [ctypes.c_void_p]
+assert L.c.mlhot_dbg_tsbuf(ts.data_ptr()) == 0
+acc = None
+N = 10
+for it in range(N + 3):
+    model.zero_grad(set_to_none=True)
+    loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+    torch.cuda.synchronize()
+    if it >= 3:
+        v = ts.cpu().double()
+        acc = v if acc is None else acc + v
+v = (acc / N).tolist()
+for base, name in ((0, "A.fwd"), (32, "B.fwd"), (64, "C.fwd"), (96, "C.bwd"), (128, "B.bwd"), (160, "A.bwd")):
+    seg = [(i, v[base + i]) for i in range(32) if v[base + i] > 0]
+    if len(seg) < 2:
+        continue
+    print(name, "total %.1f us:" % ((seg[-1][1] - seg[0][1]) / 100.0),
+          " ".join("%d:%.1f" % (i, (t - seg[k - 1][1]) / 100.0) for k, (i, t) in enumerate(seg) if k))

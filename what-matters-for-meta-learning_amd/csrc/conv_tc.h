@@ -388,10 +388,10 @@ __global__ __launch_bounds__(NT) void conv2_dgrad_kernel(const float* __restrict
 // ==================================================================================================
 // conv1-fused variants ("c12"): the conv1 output `a1` (512 KiB / image, the largest tensor of the
 // model) is never written to HBM.  Each band's 32 x 9 x 64 slice of a1 is recomputed from the
-// 19-row image strip (9.7 KB, L1/L2 resident) straight into the LDS patch, on the VALU, in the
-// issue gaps of the MFMA loop; in the backward the same recompute supplies conv1's ReLU mask and
-// the conv1 weight gradient is accumulated in registers right where d a1 is produced, so `d a1`
-// (another 512 KiB / image) is never written either.  conv1 adds 6.8 % FLOPs and removes
+// 19-row image strip (9.7 KB, L1/L2 resident) straight into the LDS patch as a small K = 12 GEMM
+// on the matrix core; the forward keeps conv1's ReLU sign bits (16 KiB / image) for the backward,
+// where the conv1 weight gradient is accumulated in registers right where d a1 is produced, so
+// `d a1` (another 512 KiB / image) is never written either.  conv1 adds 6.8 % FLOPs and removes
 // ~1.5 GB of HBM traffic per step at 480 images.
 // ==================================================================================================
 
@@ -400,39 +400,77 @@ struct ImgSrc {           // two-segment image batch (context | target), [n][1][
   __device__ __forceinline__ const float* img(int i) const { return i < n0 ? p0 + (size_t)i * 16384 : p1 + (size_t)(i - n0) * 16384; }
 };
 
-// one thread = one a1 position (patch row cr, column cc) of the band; 576 of the 768 threads
-struct Conv1Taps { float t[9]; };
-__device__ __forceinline__ void taps_fetch(Conv1Taps& tp, const ImgSrc& x, int tile, int cr, int cc) {
-  const int img = tile >> 3, band = tile & 7;
-  const float* xi = x.img(img);
-  const int iy1 = 8 * band - 1 + cr;
+// ---- conv1 on the matrix core ----------------------------------------------------------------------
+// conv1 of a band is a [576 positions] x [32 channels] x [K = 9 taps + bias] GEMM: 36 M-tiles of 16
+// consecutive columns of one patch row, 3 per wave, 6 MFMAs each (K padded to 12).  The A operand
+// (image pixels, lane = position x tap) comes straight from the L1/L2-resident strip, the B operand
+// (w1 | b1) lives in 6 registers, and the accumulator lane layout (4 consecutive columns of one
+// channel) writes into the [ci][row][col] patch directly.  ~12 % extra MFMA issue replaces ~300 VALU
+// ops per thread and band and the scalar weight loads that drained the LDS prefetch queue.
+struct Conv1W { float b[3][2]; };
+struct Conv1A { float a[3][3]; };
+__device__ __forceinline__ void conv1w_load(Conv1W& cw, const float* __restrict__ w1, const float* __restrict__ b1, int lr, int lq) {
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
+  for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int iy = 2 * iy1 + ky - 1, ix = 2 * cc + kx - 1;
-      tp.t[ky * 3 + kx] = (iy1 >= 0 && iy >= 0 && ix >= 0) ? xi[iy * 128 + ix] : 0.f;
+    for (int h = 0; h < 2; ++h) {
+      const int k = 4 * ks + lq, n = 16 * h + lr;
+      cw.b[ks][h] = k < 9 ? w1[n * 9 + k] : (k == 9 ? b1[n] : 0.f);
     }
 }
-// a1[ci][row][col] = relu(b1 + w1 . taps) for ci in [c0, c1) -> patch; rows above the image are conv2's zero padding
-// returns bit ci = (a1[ci] > 0) for its channels: the forward keeps these 32 bits per a1 position (16 KiB per
-// image instead of the 512 KiB map) as conv1's ReLU mask for the backward
-template <int C0, int C1>
-__device__ __forceinline__ unsigned conv1_to_patch(const Conv1Taps& tp, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                   float* patch, int tile, int cr, int cc) {
-  const bool valid = 8 * (tile & 7) - 1 + cr >= 0;
-  float* d = patch + cr * RS + 1 + cc;
-  unsigned bits = 0;
+__device__ __forceinline__ void conv1a_fetch1(Conv1A& ca, int j, const ImgSrc& x, int tile, int wave, int lr, int lq) {
+  const int img = tile >> 3, band = tile & 7;
+  const float* xi = x.img(img);
+  const int t = wave + 12 * j, row = t >> 2, cg = t & 3;
+  const int iy1 = 8 * band - 1 + row;
 #pragma unroll
-  for (int ci = C0; ci < C1; ++ci) {
-    float sacc = 0.f;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) sacc = fmaf(tp.t[q], w1[ci * 9 + q], sacc);
-    sacc += b1[ci];
-    d[ci * PS] = valid ? fmaxf(sacc, 0.f) : 0.f;
-    bits |= (sacc > 0.f ? 1u : 0u) << ci;
+  for (int ks = 0; ks < 3; ++ks) {
+    const int k = 4 * ks + lq, ky = k / 3, kx = k - 3 * ky;
+    const int iy = 2 * iy1 + ky - 1, ix = 2 * (16 * cg + lr) + kx - 1;
+    const bool ok = k < 9 && iy1 >= 0 && iy >= 0 && ix >= 0;
+    const float v = xi[ok ? iy * 128 + ix : 0];          // unconditional load: no exec-mask branch in the MFMA stream
+    ca.a[j][ks] = ok ? v : (k == 9 ? 1.f : 0.f);
   }
-  return bits;
+}
+__device__ __forceinline__ void conv1a_fetch(Conv1A& ca, const ImgSrc& x, int tile, int wave, int lr, int lq) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) conv1a_fetch1(ca, j, x, tile, wave, lr, lq);
+}
+// M-tile j of this wave -> patch (+ ReLU bits of the 16 positions -> m1 when MASK)
+template <bool MASK>
+__device__ __forceinline__ void conv1_tile(const Conv1A& ca, const Conv1W& cw, int j, float* patch, int tile, int wave, int lane,
+                                           unsigned* __restrict__ m1) {
+  const int lr = lane & 15, lq = lane >> 4;
+  const int t = wave + 12 * j, row = t >> 2, cg = t & 3;
+  const int iy1 = 8 * (tile & 7) - 1 + row;
+  const bool valid = iy1 >= 0;
+  f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    c0 = mfma4(ca.a[j][ks], cw.b[ks][0], c0);
+    c1 = mfma4(ca.a[j][ks], cw.b[ks][1], c1);
+  }
+  float* d = patch + lr * PS + row * RS + 1 + 16 * cg + 4 * lq;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    d[r] = valid ? fmaxf(c0[r], 0.f) : 0.f;
+    d[16 * PS + r] = valid ? fmaxf(c1[r], 0.f) : 0.f;
+  }
+  if (MASK) {
+    // ballot bit 16*lq + lr of register r = (channel lr (+16) of position 4*lq + r) > 0; lane p < 16 assembles
+    // the 32 channel bits of position p = 4*lq' + r'
+    unsigned long long lo = 0, hi = 0;
+    const int rsel = lane & 3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned long long b0 = __builtin_amdgcn_ballot_w64(c0[r] > 0.f);
+      const unsigned long long b1v = __builtin_amdgcn_ballot_w64(c1[r] > 0.f);
+      if (rsel == r) { lo = b0; hi = b1v; }
+    }
+    const int sh = 16 * ((lane >> 2) & 3);
+    const unsigned word = (unsigned)((lo >> sh) & 0xffffull) | ((unsigned)((hi >> sh) & 0xffffull) << 16);
+    if (lane < 16 && row >= 1) m1[((size_t)(tile >> 3) * 64 + iy1) * 64 + 16 * cg + lane] = word;
+  }
 }
 
 __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -444,27 +482,24 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
   const int lr = lane & 15, lq = lane >> 4;
   const int n = nt * 16 + lr;
-  const bool cact = tid < 576 && !(dbg & 1);
-  const int cr = tid >> 6, cc = tid & 63;
+  const bool cact = !(dbg & 1);
 
   float wr[72];
 #pragma unroll
   for (int ks = 0; ks < 72; ++ks) wr[ks] = w[((size_t)n * CIN + (ks & 7) * 4 + lq) * 9 + (ks >> 3)];
   const float bn = bias[n];
+  Conv1W cw;
+  conv1w_load(cw, w1, b1, lr, lq);
 
   patch_zero_pad(patch2, tid);
   patch_zero_pad(patch2 + PATCH_FLOATS, tid);
   const int ntiles = n_img * 8;
   int tile = blockIdx.x;
-  Conv1Taps tp;
-  // mask row of patch row cr: a1 row 8*band - 1 + cr; row 0 is the previous band's (stored there)
-  auto mask_store = [&](int t, unsigned bits) {
-    if (cr >= 1) m1[((size_t)(t >> 3) * 64 + 8 * (t & 7) - 1 + cr) * 64 + cc] = bits;
-  };
+  Conv1A ca;
   if (tile < ntiles && cact) {
-    taps_fetch(tp, x, tile, cr, cc);
-    mask_store(tile, conv1_to_patch<0, 32>(tp, w1, b1, patch2, tile, cr, cc));
-    if (tile + (int)gridDim.x < ntiles) taps_fetch(tp, x, tile + gridDim.x, cr, cc);
+    conv1a_fetch(ca, x, tile, wave, lr, lq);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) conv1_tile<true>(ca, cw, j, patch2, tile, wave, lane, m1);
   }
   __syncthreads();
   const int aoff = lq * PS + (4 * rp) * RS + 2 * (16 * ch + lr);
@@ -476,9 +511,10 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     const bool stage = next < ntiles && cact;
 
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    unsigned mbits = 0;
+    // 6 segments of 24 MFMAs; the next band's a1 slice (3 M-tiles per wave): pixels fetched before segments 0, 2, 4, tiles produced after 1, 3, 5
 #pragma unroll
     for (int seg = 0; seg < 6; ++seg) {
+      if (stage && !(seg & 1)) conv1a_fetch1(ca, seg >> 1, x, next, wave, lr, lq);
 #pragma unroll
       for (int q = 0; q < 12; ++q) {
         const int ks = seg * 12 + q;
@@ -488,14 +524,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
         acc0 = mfma4(x0, wr[ks], acc0);
         acc1 = mfma4(x1, wr[ks], acc1);
       }
-      // the next band's a1 slice, 8 channels per segment, on the VALU between the MFMAs
-      if (stage) {
-        if (seg == 0) mbits |= conv1_to_patch<0, 8>(tp, w1, b1, nb, next, cr, cc);
-        if (seg == 1) mbits |= conv1_to_patch<8, 16>(tp, w1, b1, nb, next, cr, cc);
-        if (seg == 2) mbits |= conv1_to_patch<16, 24>(tp, w1, b1, nb, next, cr, cc);
-        if (seg == 3) { mbits |= conv1_to_patch<24, 32>(tp, w1, b1, nb, next, cr, cc); mask_store(next, mbits); }
-      }
-      if (seg == 4 && cact && next + (int)gridDim.x < ntiles) taps_fetch(tp, x, next + gridDim.x, cr, cc);
+      if (stage && (seg & 1)) conv1_tile<true>(ca, cw, seg >> 1, nb, next, wave, lane, m1);
     }
     const int img = tile >> 3, band = tile & 7;
     float pv[2]; unsigned pa[2];
@@ -527,8 +556,9 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mg = wave % 6, ph = wave / 6;
   const int lr = lane & 15, lq = lane >> 4;
-  const bool cact = tid < 576 && !(dbg & 1);
-  const int cr = tid >> 6, cc = tid & 63;
+  const bool cact = !(dbg & 1);
+  Conv1W cw;
+  conv1w_load(cw, w1, b1, lr, lq);
 
   f32x4_t acc[3][3];
 #pragma unroll
@@ -539,7 +569,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
 
   patch_zero_pad(patch, tid);
   const int ntiles = n_img * 8;
-  Conv1Taps tp;
+  Conv1A ca;
   float cdp[2], cp[2]; unsigned cam[2];
   auto cells_fetch = [&](int t) {
     const int img = t >> 3, band = t & 7;
@@ -551,7 +581,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
     }
   };
   int tile = blockIdx.x;
-  if (tile < ntiles) { if (cact) taps_fetch(tp, x, tile, cr, cc); cells_fetch(tile); }
+  if (tile < ntiles) { if (cact) conv1a_fetch(ca, x, tile, wave, lr, lq); cells_fetch(tile); }
   int aoff[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -562,7 +592,10 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
 
   for (; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
-    if (cact) conv1_to_patch<0, 32>(tp, w1, b1, patch, tile, cr, cc);
+    if (cact) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) conv1_tile<false>(ca, cw, j, patch, tile, wave, lane, nullptr);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int e = tid + j * NT, px = e & 15, pyl = (e >> 4) & 1, co = e >> 5;
@@ -573,7 +606,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
         dyt[((2 * pyl + (q >> 1)) * 32 + 2 * px + (q & 1)) * DS + co] = (cam[j] == (unsigned)q) ? g : 0.f;
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) { if (cact) taps_fetch(tp, x, tile + gridDim.x, cr, cc); cells_fetch(tile + gridDim.x); }
+    if (tile + (int)gridDim.x < ntiles) { if (cact) conv1a_fetch(ca, x, tile + gridDim.x, wave, lr, lq); cells_fetch(tile + gridDim.x); }
 
 #pragma unroll
     for (int s = 0; s < 16; ++s) {

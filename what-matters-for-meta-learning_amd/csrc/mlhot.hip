@@ -258,3 +258,11 @@ int mlhot_np_vanilla_bwd(const mlhot_np_dims* d, const mlhot_np_params* p, const
 }
 
 }  // extern "C"
+
+#ifdef MLHOT_TS
+// latency-hunting builds only (-DMLHOT_TS): device buffer of int64 stage timestamps, see tail_fused.h
+extern "C" int mlhot_dbg_tsbuf(void* dev_ptr) {
+  long long* p = static_cast<long long*>(dev_ptr);
+  return hipMemcpyToSymbol(HIP_SYMBOL(mlhot::tf::g_ts_dev), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -29,6 +29,14 @@ __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return _
 
 constexpr int H = 8;
 
+// stage timestamps for latency hunting (build with -DMLHOT_TS; see scripts/tail_ts.py).  Compiled out otherwise.
+#ifdef MLHOT_TS
+__device__ long long* g_ts_dev = nullptr;
+#define MLHOT_TSTAMP(i) do { if (g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0) g_ts_dev[i] = wall_clock64(); } while (0)
+#else
+#define MLHOT_TSTAMP(i) do {} while (0)
+#endif
+
 struct WB {            // weight given as `nb` row blocks [rows][K] (nb = 1 for a plain Linear)
   const float* w[H];
   const float* b[H];
@@ -205,8 +213,10 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   float* s_y = s_xq + 16 * Lxq;
   float* s_red = s_y + 16 * Ly;          // [8 waves][256] K-split partials of wg_linear; later the max reduction
   const int total = 16 * (Lcat + Lh0 + Lh1 + Lrs + Lkh + Lxq + Ly) + 8 * 256;
+  MLHOT_TSTAMP(0);
   lds_zero(lds, total, tid, 512);
   __syncthreads();
+  MLHOT_TSTAMP(1);
   float* g_cat = a.cat_in + (size_t)t * d.Nc * ldc;
   float* g_dec = a.dec_in + (size_t)t * d.Nq * ldd;
   lds_load(s_cat, Lcat, g_cat, ldc, d.Nc, d.dw, tid, 512);                       // x_ctx (encoder output)
@@ -219,22 +229,30 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
     for (int i = lo + tid; i < hi; i += 512) a.pc[i] = c * a.p.proj[i];
   }
   __syncthreads();
+  MLHOT_TSTAMP(2);
   if (a.dbg & 2) return;
   // transform_y -> cat[:, dw:]
   wg_linear<8>(s_y, Ly, d.label_dim, wb1(a.p.ty_w, a.p.ty_b, d.dw / 4), d.dw / 4, ACT_NONE, s_cat + d.dw, Lcat, g_cat + d.dw, ldc, d.Nc, nullptr, wave, lane);
+  MLHOT_TSTAMP(3);
   // Q projection only needs x_qry: issue it alongside
   wg_linear<8>(s_xq, Lxq, d.dw, wb8(a.p.wq_w, a.p.wq_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, a.qh + (size_t)t * d.Nq * H * d.dw, H * d.dw, d.Nq, nullptr, wave, lane);
+  MLHOT_TSTAMP(4);
   // K projection needs x_ctx only
   wg_linear<8>(s_cat, Lcat, d.dw, wb8(a.p.wk_w, a.p.wk_b, d.dw), H * d.dw, ACT_NONE, s_kh, Lkh, a.kh + (size_t)t * d.Nc * H * d.dw, H * d.dw, d.Nc, nullptr, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(5);
   if (a.dbg & 4) return;
   wg_linear<8>(s_cat, Lcat, ldc, wb1(a.p.er_w[0], a.p.er_b[0], d.h0), d.h0, ACT_RELU, s_h0, Lh0, a.h0 + (size_t)t * d.Nc * d.h0, d.h0, d.Nc, nullptr, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(6);
   wg_linear<8>(s_h0, Lh0, d.h0, wb1(a.p.er_w[1], a.p.er_b[1], d.h1), d.h1, ACT_RELU, s_h1, Lh1, a.h1 + (size_t)t * d.Nc * d.h1, d.h1, d.Nc, nullptr, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(7);
   wg_linear<8>(s_h1, Lh1, d.h1, wb1(a.p.er_w[2], a.p.er_b[2], d.dw), d.dw, ACT_NONE, s_rs, Lrs, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(8);
   wg_linear<8>(s_rs, Lrs, d.dw, wb8(a.p.wv_w, a.p.wv_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, a.vh + (size_t)t * d.Nc * H * d.dw, H * d.dw, d.Nc, nullptr, wave, lane);
+  MLHOT_TSTAMP(9);
 
   if (a.dbg & 8) return;
   // key-stabiliser share: max over (row < Nc, head, feature j) of ddk = c * kh_h . P[j]   (fast_attention.py:97)
@@ -280,6 +298,7 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
         }
     }
   }
+  MLHOT_TSTAMP(10);
   // reduce (max, first arg-max in (row, col) order) over the workgroup
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -298,6 +317,7 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
     }
     a.tmax[t] = best; a.targ[2 * t] = brow; a.targ[2 * t + 1] = bcol;
   }
+  MLHOT_TSTAMP(11);
 }
 
 __host__ inline size_t phaseA_lds_bytes(const TailDims& d) {
@@ -906,8 +926,10 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   float* s_dh0 = s_dh1 + 16 * Lh1;
   float* s_dcat = s_dh0 + 16 * Lh0;
   float* s_red = s_dcat + 16 * Lcat;   // [8 waves][256] partial tiles of wg_dgrad
+  MLHOT_TSTAMP(160);
   lds_zero(lds, 16 * (2 * Lcat + 2 * Lh0 + 2 * Lh1 + 4 * Lw + Ly + Lhd), tid, 512);
   __syncthreads();
+  MLHOT_TSTAMP(161);
   const size_t rc = (size_t)t * d.Nc, rq = (size_t)t * d.Nq;
   lds_load(s_cat, Lcat, a.cat_in + rc * ldc, ldc, d.Nc, ldc, tid, 512);
   lds_load(s_h0, Lh0, a.h0 + rc * d.h0, d.h0, d.Nc, d.h0, tid, 512);
@@ -918,18 +940,24 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   lds_load(s_dq, Lhd, a.dqh + rq * HD, HD, d.Nq, HD, tid, 512);
   float* sl = a.slab + (size_t)t * a.sl.total;
   __syncthreads();
+  MLHOT_TSTAMP(162);
   // W_q: weight gradient and the attention share of d x_qry (accumulated onto the decoder's)
   wg_wgrad<8>(s_dq, Lhd, HD, s_xq, Lw, d.dw, sl + a.sl.wq_w, sl + a.sl.wq_b, wave, lane, tid);
+  MLHOT_TSTAMP(163);
   wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wq_w, nullptr, d.dw), d.dw, nullptr, 0, a.d_dec_in + rq * ldd, ldd, d.Nq, true, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(164);
   // W_v
   lds_zero(s_dq, 16 * Lhd, tid, 512);
   __syncthreads();
   lds_load(s_dq, Lhd, a.dvh + rc * HD, HD, d.Nc, HD, tid, 512);
   __syncthreads();
+  MLHOT_TSTAMP(165);
   wg_wgrad<8>(s_dq, Lhd, HD, s_rs, Lw, d.dw, sl + a.sl.wv_w, sl + a.sl.wv_b, wave, lane, tid);
+  MLHOT_TSTAMP(166);
   wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wv_w, nullptr, d.dw), d.dw, s_drs, Lw, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(167);
   // W_k, with the batch-global key arg-max correction: that ONE element's d(dd) carries minus the
   // sum of G over every key row of the batch (fast_attention.py:97), i.e. dk[row] -= total * pc[col]
   lds_zero(s_dq, 16 * Lhd, tid, 512);
@@ -947,22 +975,28 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(168);
   wg_wgrad<8>(s_dq, Lhd, HD, s_cat, Lcat, d.dw, sl + a.sl.wk_w, sl + a.sl.wk_b, wave, lane, tid);
+  MLHOT_TSTAMP(169);
   wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wk_w, nullptr, d.dw), d.dw, s_dxc, Lw, nullptr, 0, 0, false, s_red, wave, lane);
+  MLHOT_TSTAMP(170);
   // EncoderFC, last layer first
   wg_wgrad<8>(s_drs, Lw, d.dw, s_h1, Lh1, d.h1, sl + a.sl.er_w[2], sl + a.sl.er_b[2], wave, lane, tid);
   wg_dgrad<8>(s_drs, Lw, d.dw, wb1(a.p.er_w[2], nullptr, d.dw), d.h1, s_dh1, Lh1, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(171);
   lds_actgrad(s_dh1, Lh1, s_h1, Lh1, d.h1, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dh1, Lh1, d.h1, s_h0, Lh0, d.h0, sl + a.sl.er_w[1], sl + a.sl.er_b[1], wave, lane, tid);
   wg_dgrad<8>(s_dh1, Lh1, d.h1, wb1(a.p.er_w[1], nullptr, d.h1), d.h0, s_dh0, Lh0, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(172);
   lds_actgrad(s_dh0, Lh0, s_h0, Lh0, d.h0, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dh0, Lh0, d.h0, s_cat, Lcat, ldc, sl + a.sl.er_w[0], sl + a.sl.er_b[0], wave, lane, tid);
   wg_dgrad<8>(s_dh0, Lh0, d.h0, wb1(a.p.er_w[0], nullptr, d.h0), ldc, s_dcat, Lcat, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(173);
   // d_cat_in = EncoderFC input gradient (+ K-projection share on the x_ctx columns)
   for (int i = tid; i < d.Nc * ldc; i += 512) {
     const int r = i / ldc, c = i % ldc;
@@ -970,6 +1004,7 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   }
   // transform_y: dW = d_cat[:, dw:]^T ctx_y, db
   wg_wgrad<8>(s_dcat + d.dw, Lcat, d.dw / 4, s_y, Ly, d.label_dim, sl + a.sl.ty_w, sl + a.sl.ty_b, wave, lane, tid);
+  MLHOT_TSTAMP(174);
 }
 __host__ inline size_t phaseA_bwd_lds_bytes(const TailDims& d) {
   const int ldc = d.dw + d.dw / 4;

@@ -2,7 +2,9 @@
 
 `lib()` returns the ctypes binding of csrc/libmlhot.so.  There is no fallback: if the
 HIP library is missing, or a tensor is not on a HIP device, the call raises.
+MLHOT_LIB=<path> selects another build of the same library (e.g. the -DMLHOT_TS instrumented one).
 """
+import os
 import threading
 
 from .binding import MlhotError, MlhotLib  # noqa: F401
@@ -17,5 +19,5 @@ def lib():
     if _lib is None:
         with _lock:
             if _lib is None:
-                _lib = MlhotLib(PRODUCT_SO)
+                _lib = MlhotLib(os.environ.get("MLHOT_LIB") or PRODUCT_SO)
     return _lib
