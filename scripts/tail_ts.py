@@ -35,7 +35,9 @@ for it in range(N + 3):
     torch.cuda.synchronize()
     if it >= 3:
         v = ts.cpu().double()
+        calls = ts.cpu()[200:200 + 8 * 36].view(36, 8).tolist()
         acc = v if acc is None else acc + v
+    ts[199] = 0
 v = (acc / N).tolist()
 for base, name in ((0, "A.fwd"), (32, "B.fwd"), (64, "C.fwd"), (96, "C.bwd"), (128, "B.bwd"), (160, "A.bwd")):
     seg = [(i, v[base + i]) for i in range(32) if v[base + i] > 0]
@@ -43,3 +45,8 @@ for base, name in ((0, "A.fwd"), (32, "B.fwd"), (64, "C.fwd"), (96, "C.bwd"), (1
         continue
     print(name, "total %.1f us:" % ((seg[-1][1] - seg[0][1]) / 100.0),
           " ".join("%d:%.1f" % (i, (t - seg[k - 1][1]) / 100.0) for k, (i, t) in enumerate(seg) if k))
+
+print("layer-function calls of workgroup 0 (cycles between stamps: entry | setup | k-loop | fold | epilogue | exit)")
+for c, row in enumerate(calls):
+    if row[0] and row[5]:
+        print(c, [row[i + 1] - row[i] for i in range(5)], "total", row[5] - row[0])

@@ -41,38 +41,42 @@ struct CnpFwdArgs {
 
 __global__ __launch_bounds__(512) void cnp_fwd_kernel(const CnpFwdArgs a) {
   extern __shared__ float lds[];
+  lptr L0 = (lptr)lds;
   const CnpDims& d = a.d;
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldc = d.dw + d.dw / 4, ldd = d.dw + d.dz;
   const int Lcat = ldpad(ldc), Lh0 = ldpad(d.h0), Lh1 = ldpad(d.h1), Lr = ldpad(d.dr), Lz = ldpad(d.dz), Ld = ldpad(ldd),
             Lh = ldpad(d.dec_h), Ly = ldpad(d.label_dim);
-  float* s_cat = lds;
-  float* s_h0 = s_cat + 16 * Lcat;
-  float* s_h1 = s_h0 + 16 * Lh0;
-  float* s_rs = s_h1 + 16 * Lh1;
-  float* s_r = s_rs + 16 * Lr;        // row 0 = aggregated r, rows 1.. = 0
-  float* s_zt = s_r + 16 * Lr;        // row 0 = r_to_z(r)
-  float* s_dec = s_zt + 16 * Lz;
-  float* s_d1 = s_dec + 16 * Ld;
-  float* s_d2 = s_d1 + 16 * Lh;
-  float* s_y = s_d2 + 16 * Lh;
-  float* s_red = s_y + 16 * Ly;
-  lds_zero(lds, 16 * (Lcat + Lh0 + Lh1 + 2 * Lr + Lz + Ld + 2 * Lh + Ly), tid, 512);
+  lptr s_cat = L0;
+  lptr s_h0 = s_cat + 16 * Lcat;
+  lptr s_h1 = s_h0 + 16 * Lh0;
+  lptr s_rs = s_h1 + 16 * Lh1;
+  lptr s_r = s_rs + 16 * Lr;        // row 0 = aggregated r, rows 1.. = 0
+  lptr s_zt = s_r + 16 * Lr;        // row 0 = r_to_z(r)
+  lptr s_dec = s_zt + 16 * Lz;
+  lptr s_d1 = s_dec + 16 * Ld;
+  lptr s_d2 = s_d1 + 16 * Lh;
+  lptr s_y = s_d2 + 16 * Lh;
+  lptr s_red = s_y + 16 * Ly;
+  using PRM = CnpParams;
+  lu64 ptab = reinterpret_cast<lu64>(s_red + 8 * 256);
+  ptab_fill(ptab, a.p, tid);
+  lds_zero(L0, 16 * (Lcat + Lh0 + Lh1 + 2 * Lr + Lz + Ld + 2 * Lh + Ly), tid, 512);
   __syncthreads();
   const size_t rc = (size_t)t * d.Nc, rq = (size_t)t * d.Nq;
-  float* g_cat = a.cat_in + rc * ldc;
-  float* g_dec = a.dec_in + rq * ldd;
+  gptr g_cat = G(a.cat_in) + rc * ldc;
+  gptr g_dec = G(a.dec_in) + rq * ldd;
   lds_load(s_cat, Lcat, g_cat, ldc, d.Nc, d.dw, tid, 512);
   lds_load(s_dec, Ld, g_dec, ldd, d.Nq, d.dw, tid, 512);
   lds_load(s_y, Ly, a.ctx_y + rc * d.label_dim, d.label_dim, d.Nc, d.label_dim, tid, 512);
   __syncthreads();
-  wg_linear<8>(s_y, Ly, d.label_dim, wb1(a.p.ty_w, a.p.ty_b, d.dw / 4), d.dw / 4, ACT_NONE, s_cat + d.dw, Lcat, g_cat + d.dw, ldc, d.Nc, nullptr, wave, lane);
+  wg_linear<8>(s_y, Ly, d.label_dim, WB1(ty_w, ty_b, d.dw / 4), d.dw / 4, ACT_NONE, s_cat + d.dw, Lcat, g_cat + d.dw, ldc, d.Nc, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_cat, Lcat, ldc, wb1(a.p.er_w[0], a.p.er_b[0], d.h0), d.h0, ACT_RELU, s_h0, Lh0, a.h0 + rc * d.h0, d.h0, d.Nc, nullptr, wave, lane);
+  wg_linear<8>(s_cat, Lcat, ldc, WB1(er_w[0], er_b[0], d.h0), d.h0, ACT_RELU, s_h0, Lh0, G(a.h0 + rc * d.h0), d.h0, d.Nc, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_h0, Lh0, d.h0, wb1(a.p.er_w[1], a.p.er_b[1], d.h1), d.h1, ACT_RELU, s_h1, Lh1, a.h1 + rc * d.h1, d.h1, d.Nc, nullptr, wave, lane);
+  wg_linear<8>(s_h0, Lh0, d.h0, WB1(er_w[1], er_b[1], d.h1), d.h1, ACT_RELU, s_h1, Lh1, G(a.h1 + rc * d.h1), d.h1, d.Nc, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_h1, Lh1, d.h1, wb1(a.p.er_w[2], a.p.er_b[2], d.dr), d.dr, ACT_NONE, s_rs, Lr, a.rs + rc * d.dr, d.dr, d.Nc, nullptr, wave, lane);
+  wg_linear<8>(s_h1, Lh1, d.h1, WB1(er_w[2], er_b[2], d.dr), d.dr, ACT_NONE, s_rs, Lr, G(a.rs + rc * d.dr), d.dr, d.Nc, nullptr, wave, lane);
   __syncthreads();
   // aggregate over the shot axis: one lane per feature, the shots of a task are the tile's rows
   for (int j = tid; j < d.dr; j += 512) {
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(512) void cnp_fwd_kernel(const CnpFwdArgs a) {
     a.amax[(size_t)t * d.dr + j] = arg;
   }
   __syncthreads();
-  wg_linear<8>(s_r, Lr, d.dr, wb1(a.p.r2z_w, a.p.r2z_b, d.dz), d.dz, ACT_NONE, s_zt, Lz, a.zt + (size_t)t * d.dz, d.dz, 1, s_red, wave, lane);
+  wg_linear<8>(s_r, Lr, d.dr, WB1(r2z_w, r2z_b, d.dz), d.dz, ACT_NONE, s_zt, Lz, G(a.zt + (size_t)t * d.dz), d.dz, 1, s_red, wave, lane);
   __syncthreads();
   for (int i = tid; i < d.Nq * d.dz; i += 512) {          // z broadcast over the target rows
     const int r = i / d.dz, j = i % d.dz;
@@ -98,15 +102,15 @@ __global__ __launch_bounds__(512) void cnp_fwd_kernel(const CnpFwdArgs a) {
     g_dec[(size_t)r * ldd + d.dw + j] = s_zt[j];
   }
   __syncthreads();
-  wg_linear<8>(s_dec, Ld, ldd, wb1(a.p.dec_w[0], a.p.dec_b[0], d.dec_h), d.dec_h, ACT_RELU, s_d1, Lh, a.d1 + rq * d.dec_h, d.dec_h, d.Nq, nullptr, wave, lane);
+  wg_linear<8>(s_dec, Ld, ldd, WB1(dec_w[0], dec_b[0], d.dec_h), d.dec_h, ACT_RELU, s_d1, Lh, G(a.d1 + rq * d.dec_h), d.dec_h, d.Nq, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_d1, Lh, d.dec_h, wb1(a.p.dec_w[1], a.p.dec_b[1], d.dec_h), d.dec_h, ACT_RELU, s_d2, Lh, a.d2 + rq * d.dec_h, d.dec_h, d.Nq, nullptr, wave, lane);
+  wg_linear<8>(s_d1, Lh, d.dec_h, WB1(dec_w[1], dec_b[1], d.dec_h), d.dec_h, ACT_RELU, s_d2, Lh, G(a.d2 + rq * d.dec_h), d.dec_h, d.Nq, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_d2, Lh, d.dec_h, wb1(a.p.dec_w[2], a.p.dec_b[2], d.y_dim), d.y_dim, d.out_act, nullptr, 0, a.mu + rq * d.y_dim, d.y_dim, d.Nq, s_red, wave, lane);
+  wg_linear<8>(s_d2, Lh, d.dec_h, WB1(dec_w[2], dec_b[2], d.y_dim), d.y_dim, d.out_act, nullptr, 0, G(a.mu + rq * d.y_dim), d.y_dim, d.Nq, s_red, wave, lane);
 }
 __host__ inline size_t cnp_fwd_lds_bytes(const CnpDims& d) {
   return sizeof(float) * (16 * (ldpad(d.dw + d.dw / 4) + ldpad(d.h0) + ldpad(d.h1) + 2 * ldpad(d.dr) + ldpad(d.dz) + ldpad(d.dw + d.dz) +
-                                2 * ldpad(d.dec_h) + ldpad(d.label_dim)) + 8 * 256);
+                                2 * ldpad(d.dec_h) + ldpad(d.label_dim)) + 8 * 256 + ptab_floats<CnpParams>());
 }
 
 struct CnpBwdArgs {
@@ -117,20 +121,24 @@ struct CnpBwdArgs {
 
 __global__ __launch_bounds__(512) void cnp_bwd_kernel(const CnpBwdArgs a) {
   extern __shared__ float lds[];
+  lptr L0 = (lptr)lds;
   const CnpDims& d = a.d;
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldc = d.dw + d.dw / 4, ldd = d.dw + d.dz;
   const int Lcat = ldpad(ldc), Lh0 = ldpad(d.h0), Lh1 = ldpad(d.h1), Lr = ldpad(d.dr), Lz = ldpad(d.dz), Ld = ldpad(ldd),
             Lh = ldpad(d.dec_h), Ly = ldpad(d.y_dim), Lyl = ldpad(d.label_dim);
-  float* p = lds;
-  auto take = [&](int n) { float* r = p; p += n; return r; };
-  float* s_g = take(16 * Ly);      float* s_d2 = take(16 * Lh);    float* s_d1 = take(16 * Lh);   float* s_dec = take(16 * Ld);
-  float* s_dd2 = take(16 * Lh);    float* s_dd1 = take(16 * Lh);   float* s_ddec = take(16 * Ld);
-  float* s_r = take(16 * Lr);      float* s_dzt = take(16 * Lz);   float* s_dr = take(16 * Lr);
-  float* s_rs = take(16 * Lr);     float* s_h1 = take(16 * Lh1);   float* s_h0 = take(16 * Lh0);  float* s_cat = take(16 * Lcat);
-  float* s_drs = take(16 * Lr);    float* s_dh1 = take(16 * Lh1);  float* s_dh0 = take(16 * Lh0); float* s_dcat = take(16 * Lcat);
-  float* s_yl = take(16 * Lyl);    float* s_red = take(8 * 256);
-  lds_zero(lds, (int)(s_red - lds), tid, 512);
+  lptr p = L0;
+  auto take = [&](int n) { lptr r = p; p += n; return r; };
+  lptr s_g = take(16 * Ly);      lptr s_d2 = take(16 * Lh);    lptr s_d1 = take(16 * Lh);   lptr s_dec = take(16 * Ld);
+  lptr s_dd2 = take(16 * Lh);    lptr s_dd1 = take(16 * Lh);   lptr s_ddec = take(16 * Ld);
+  lptr s_r = take(16 * Lr);      lptr s_dzt = take(16 * Lz);   lptr s_dr = take(16 * Lr);
+  lptr s_rs = take(16 * Lr);     lptr s_h1 = take(16 * Lh1);   lptr s_h0 = take(16 * Lh0);  lptr s_cat = take(16 * Lcat);
+  lptr s_drs = take(16 * Lr);    lptr s_dh1 = take(16 * Lh1);  lptr s_dh0 = take(16 * Lh0); lptr s_dcat = take(16 * Lcat);
+  lptr s_yl = take(16 * Lyl);    lptr s_red = take(8 * 256);
+  lds_zero(L0, (int)(s_red - L0), tid, 512);
+  using PRM = CnpParams;
+  lu64 ptab = reinterpret_cast<lu64>(s_red + 8 * 256);
+  ptab_fill(ptab, a.p, tid);
   __syncthreads();
   const size_t rc = (size_t)t * d.Nc, rq = (size_t)t * d.Nq;
   for (int i = tid; i < d.Nq * d.y_dim; i += 512) {
@@ -147,20 +155,20 @@ __global__ __launch_bounds__(512) void cnp_bwd_kernel(const CnpBwdArgs a) {
   lds_load(s_cat, Lcat, a.cat_in + rc * ldc, ldc, d.Nc, ldc, tid, 512);
   lds_load(s_yl, Lyl, a.ctx_y + rc * d.label_dim, d.label_dim, d.Nc, d.label_dim, tid, 512);
   __syncthreads();
-  float* sl = a.slab + (size_t)t * a.sl.total;
+  gptr sl = G(a.slab) + (size_t)t * a.sl.total;
   // decoder0
   wg_wgrad<8>(s_g, Ly, d.y_dim, s_d2, Lh, d.dec_h, sl + a.sl.dec_w[2], sl + a.sl.dec_b[2], wave, lane, tid);
-  wg_dgrad<8>(s_g, Ly, d.y_dim, wb1(a.p.dec_w[2], nullptr, d.y_dim), d.dec_h, s_dd2, Lh, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_g, Ly, d.y_dim, WB1N(dec_w[2], d.y_dim), d.dec_h, s_dd2, Lh, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   lds_actgrad(s_dd2, Lh, s_d2, Lh, d.dec_h, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dd2, Lh, d.dec_h, s_d1, Lh, d.dec_h, sl + a.sl.dec_w[1], sl + a.sl.dec_b[1], wave, lane, tid);
-  wg_dgrad<8>(s_dd2, Lh, d.dec_h, wb1(a.p.dec_w[1], nullptr, d.dec_h), d.dec_h, s_dd1, Lh, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dd2, Lh, d.dec_h, WB1N(dec_w[1], d.dec_h), d.dec_h, s_dd1, Lh, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   lds_actgrad(s_dd1, Lh, s_d1, Lh, d.dec_h, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dd1, Lh, d.dec_h, s_dec, Ld, ldd, sl + a.sl.dec_w[0], sl + a.sl.dec_b[0], wave, lane, tid);
-  wg_dgrad<8>(s_dd1, Lh, d.dec_h, wb1(a.p.dec_w[0], nullptr, d.dec_h), ldd, s_ddec, Ld, a.d_dec_in + rq * ldd, ldd, d.Nq, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dd1, Lh, d.dec_h, WB1N(dec_w[0], d.dec_h), ldd, s_ddec, Ld, G(a.d_dec_in + rq * ldd), ldd, d.Nq, false, s_red, wave, lane);
   __syncthreads();
   // broadcast backward: dz_t = sum over the target rows
   for (int j = tid; j < d.dz; j += 512) {
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(512) void cnp_bwd_kernel(const CnpBwdArgs a) {
   }
   __syncthreads();
   wg_wgrad<8>(s_dzt, Lz, d.dz, s_r, Lr, d.dr, sl + a.sl.r2z_w, sl + a.sl.r2z_b, wave, lane, tid);
-  wg_dgrad<8>(s_dzt, Lz, d.dz, wb1(a.p.r2z_w, nullptr, d.dz), d.dr, s_dr, Lr, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dzt, Lz, d.dz, WB1N(r2z_w, d.dz), d.dr, s_dr, Lr, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   // aggregator backward: mean spreads dr / Nc over the shots, max routes it to the arg-max shot
   for (int i = tid; i < d.Nc * d.dr; i += 512) {
@@ -181,24 +189,24 @@ __global__ __launch_bounds__(512) void cnp_bwd_kernel(const CnpBwdArgs a) {
   __syncthreads();
   // EncoderFC, last layer first
   wg_wgrad<8>(s_drs, Lr, d.dr, s_h1, Lh1, d.h1, sl + a.sl.er_w[2], sl + a.sl.er_b[2], wave, lane, tid);
-  wg_dgrad<8>(s_drs, Lr, d.dr, wb1(a.p.er_w[2], nullptr, d.dr), d.h1, s_dh1, Lh1, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_drs, Lr, d.dr, WB1N(er_w[2], d.dr), d.h1, s_dh1, Lh1, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   lds_actgrad(s_dh1, Lh1, s_h1, Lh1, d.h1, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dh1, Lh1, d.h1, s_h0, Lh0, d.h0, sl + a.sl.er_w[1], sl + a.sl.er_b[1], wave, lane, tid);
-  wg_dgrad<8>(s_dh1, Lh1, d.h1, wb1(a.p.er_w[1], nullptr, d.h1), d.h0, s_dh0, Lh0, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dh1, Lh1, d.h1, WB1N(er_w[1], d.h1), d.h0, s_dh0, Lh0, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   lds_actgrad(s_dh0, Lh0, s_h0, Lh0, d.h0, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dh0, Lh0, d.h0, s_cat, Lcat, ldc, sl + a.sl.er_w[0], sl + a.sl.er_b[0], wave, lane, tid);
-  wg_dgrad<8>(s_dh0, Lh0, d.h0, wb1(a.p.er_w[0], nullptr, d.h0), ldc, s_dcat, Lcat, a.d_cat_in + rc * ldc, ldc, d.Nc, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dh0, Lh0, d.h0, WB1N(er_w[0], d.h0), ldc, s_dcat, Lcat, G(a.d_cat_in + rc * ldc), ldc, d.Nc, false, s_red, wave, lane);
   __syncthreads();
   wg_wgrad<8>(s_dcat + d.dw, Lcat, d.dw / 4, s_yl, Lyl, d.label_dim, sl + a.sl.ty_w, sl + a.sl.ty_b, wave, lane, tid);
 }
 __host__ inline size_t cnp_bwd_lds_bytes(const CnpDims& d) {
   const int Lcat = ldpad(d.dw + d.dw / 4), Lh0 = ldpad(d.h0), Lh1 = ldpad(d.h1), Lr = ldpad(d.dr), Lz = ldpad(d.dz), Ld = ldpad(d.dw + d.dz),
             Lh = ldpad(d.dec_h), Ly = ldpad(d.y_dim), Lyl = ldpad(d.label_dim);
-  return sizeof(float) * (16 * (Ly + 4 * Lh + 2 * Ld + 4 * Lr + Lz + 2 * Lh1 + 2 * Lh0 + 2 * Lcat + Lyl) + 8 * 256);
+  return sizeof(float) * (16 * (Ly + 4 * Lh + 2 * Ld + 4 * Lr + Lz + 2 * Lh1 + 2 * Lh0 + 2 * Lcat + Lyl) + 8 * 256 + ptab_floats<CnpParams>());
 }
 
 }  // namespace tf

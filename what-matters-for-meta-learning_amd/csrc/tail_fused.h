@@ -33,85 +33,167 @@ constexpr int H = 8;
 #ifdef MLHOT_TS
 __device__ long long* g_ts_dev = nullptr;
 #define MLHOT_TSTAMP(i) do { if (g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0) g_ts_dev[i] = wall_clock64(); } while (0)
+// inside a layer function: cycle stamps of call number g_ts_dev[199] (slots 200 + 8 * call + i)
+#define MLHOT_TSCALL_BEGIN() long long* tsc_ = nullptr; do { if (g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0) { \
+    const long long c_ = g_ts_dev[199]; g_ts_dev[199] = c_ + 1; if (c_ < 36) tsc_ = g_ts_dev + 200 + 8 * c_; } } while (0)
+#define MLHOT_TSC(i) do { if (tsc_) tsc_[i] = clock64(); } while (0)
 #else
 #define MLHOT_TSTAMP(i) do {} while (0)
+#define MLHOT_TSCALL_BEGIN() do {} while (0)
+#define MLHOT_TSC(i) do {} while (0)
 #endif
 
-struct WB {            // weight given as `nb` row blocks [rows][K] (nb = 1 for a plain Linear)
-  const float* w[H];
-  const float* b[H];
-  int rows;
+// ---- address spaces ----------------------------------------------------------------------------
+// The layer functions below are shared, NOT inlined (see wg_linear), so their pointer parameters
+// carry explicit address spaces: with plain `float*` parameters every LDS and weight access in them
+// compiled to FLAT instructions (slow path, and each wait drains both memory counters), which made
+// every layer of the chain cost 6-10 us.  Typed, the same code is ds_read_b128 / global_load_dwordx4.
+#define MLHOT_LDS __attribute__((address_space(3)))
+#define MLHOT_GLB __attribute__((address_space(1)))
+typedef MLHOT_LDS float* lptr;
+typedef const MLHOT_LDS float* lcptr;
+typedef MLHOT_GLB float* gptr;
+typedef const MLHOT_GLB float* gcptr;
+typedef MLHOT_LDS unsigned long long* lu64;
+typedef const MLHOT_LDS f32x4_t* lc4ptr;
+typedef const MLHOT_GLB f32x4_t* gc4ptr;
+#define G(p) ((::mlhot::tf::gptr)(p))
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Pointer table: a kernel copies its parameter struct (nothing but pointers) into LDS once; a layer
+// is handed table slots, so a head-blocked weight (8 separately allocated [dw][dw] blocks) is a
+// ds_read_b64 of slot `blk` instead of a by-reference struct living in scratch memory.
+template <class P>
+__device__ __forceinline__ void ptab_fill(lu64 tab, const P& p, int tid) {
+  constexpr int n = sizeof(P) / 8;
+  unsigned long long v = 0;
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    unsigned long long e;
+    __builtin_memcpy(&e, reinterpret_cast<const char*>(&p) + 8 * i, 8);
+    if (tid == i) v = e;
+  }
+  if (tid < n) tab[tid] = v;
+}
+struct WB {            // weight given as row blocks [rows][K] (one block for a plain Linear): table slots
+  lu64 w, b;
+  int rows, hasb;
 };
+// PRM (the kernel's parameter struct type) and ptab (its LDS table) are in scope at every use
+#define WB1(wm, bm, rows_) ::mlhot::tf::WB{ptab + offsetof(PRM, wm) / 8, ptab + offsetof(PRM, bm) / 8, (rows_), 1}
+template <class P> __host__ __device__ constexpr int ptab_floats() { return (int)((sizeof(P) / 8 * 2 + 3) / 4 * 4); }
+#define WB1N(wm, rows_) ::mlhot::tf::WB{ptab + offsetof(PRM, wm) / 8, ptab + offsetof(PRM, wm) / 8, (rows_), 0}
+
+// a pointer every lane holds identically (a table slot, a kernel argument) as a scalar register pair,
+// so accesses through it use the scalar-base + 32-bit-offset addressing form
+template <class T>
+__device__ __forceinline__ T uniptr(T p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ gcptr uniptr(unsigned long long v) { return uniptr(reinterpret_cast<gcptr>(v)); }
+__device__ __forceinline__ f32x4_t lds_read4(lcptr p, bool vec) {
+  if (vec) return *reinterpret_cast<lc4ptr>(p);
+  return f32x4_t{p[0], p[1], p[2], p[3]};
+}
 
 // ---- Y[16 x N] = act(X[16 x K] W^T + b).  X in LDS (row stride ldx, finite everywhere), W from
 // global: lane (n = lr, k-group lq) loads W[n][k0+4lq .. +3] as one float4 and X[lr][k0+4lq..+3] from
 // LDS, feeding 4 MFMAs whose k order is permuted identically on both operands.
-// The chain is latency-bound (weights come from L2/HBM), so each wave works on up to 4 N-tiles AT ONCE
-// (their weight loads are all in flight together and share the A operand), and when there are fewer
-// N-tiles than waves the K range is split over the idle waves and folded through `red` (LDS,
-// NW*256 floats; may be nullptr when N >= 16*NW).  Contains barriers when it splits: call from all waves.
+// The chain is latency-bound, so each wave works on up to 4 N-tiles AT ONCE and on 4 K-blocks per
+// trip (up to 16 weight float4 in flight, sharing the A operands), and when there are fewer N-tiles
+// than waves the K range is split over the idle waves and folded through `red` (LDS, NW*256 floats;
+// nullptr forbids the split).  Contains barriers when it splits: call from all waves.
 // NOT inlined on purpose: these kernels run each layer exactly once per workgroup, so with every
 // layer's unrolled body inlined the kernel was 56 KB of straight-line code and was bound by cold
-// instruction fetch (~3 us per layer whatever its size); as one shared function the code stays hot.
+// instruction fetch; as one shared function the code stays hot.  Every scalar argument is made
+// wave-uniform on entry so loop control and the null checks are scalar branches.
 template <int NW>
-__device__ __attribute__((noinline)) void wg_linear(const float* xs, int ldx, int K, const WB& wb, int N, int act,
-                                          float* ys, int ldy, float* yg, int ldg, int nrows, float* red, int wave, int lane) {
+__device__ __attribute__((noinline)) void wg_linear(lcptr xs, int ldx, int K, WB wb, int N, int act,
+                                                    lptr ys, int ldy, gptr yg, int ldg, int nrows, lptr red, int wave, int lane) {
+  MLHOT_TSCALL_BEGIN();
+  MLHOT_TSC(0);
+  ldx = uni(ldx); K = uni(K); N = uni(N); act = uni(act); ldy = uni(ldy); ldg = uni(ldg); nrows = uni(nrows); wave = uni(wave);
+  const int rows = uni(wb.rows), hasb = uni(wb.hasb);
+  const bool has_ys = uni(ys != nullptr), has_yg = uni(yg != nullptr), has_red = uni(red != nullptr);
+  const bool avec = uni((((unsigned)(size_t)xs & 15u) == 0u) && (ldx & 3) == 0);
+  gptr ygu = uniptr(yg);
   const int lr = lane & 15, lq = lane >> 4;
-  const int ntile = (N + 15) / 16;
-  int nchunk = 1;
-  if (red != nullptr && ntile * 2 <= NW) nchunk = NW / ntile;
-  const int kblocks = (K + 15) / 16, per = (kblocks + nchunk - 1) / nchunk;
+  const int ntile = (N + 15) >> 4;
+  // K split over idle waves: NW / ntile chunks, a power of two for NW = 8 (ntile 1..4 -> 8, 4, 2, 2)
+  int csh = 0;
+  if (has_red && ntile * 2 <= NW) csh = ntile == 1 ? 3 : ntile == 2 ? 2 : 1;
+  const int nchunk = 1 << csh;
+  const int kblocks = (K + 15) >> 4, per = (kblocks + nchunk - 1) >> csh;
   const bool vec = (K & 3) == 0;
-  int tpw = (ntile + NW - 1) / NW;               // N-tiles a wave handles together
+  int tpw = (ntile + NW - 1) / NW;               // N-tiles a wave handles together (NW is a compile-time power of two)
   if (tpw > 4) tpw = 4;
   if (nchunk > 1) tpw = 1;
+  // The padding columns of X (k >= K) are zero and columns n >= N of the result are never stored, so
+  // out-of-range operand addresses are only CLAMPED to something finite - no selects, no branches.
+  const int kmax = vec ? K - 4 : K - 1;
   for (int it0 = 0; it0 < ntile * nchunk; it0 += NW * tpw) {
     const int it = it0 + wave * tpw;
-    const int tile0 = nchunk > 1 ? it % ntile : it, chunk = nchunk > 1 ? it / ntile : 0;
     const bool active = it < ntile * nchunk;
+    int tile0 = it, chunk = 0;
+    if (nchunk > 1) { while (tile0 >= ntile) { tile0 -= ntile; ++chunk; } }
+    if (!active) { tile0 = 0; chunk = 0; }
+    int blk = 0, boff = tile0 * 16;               // row block of tile0 and the tile's first row inside it (scalar, no division)
+    while (boff >= rows) { boff -= rows; ++blk; }
     f32x4_t acc[4];
-    const float* wrow[4]; bool vn[4]; const float* bsel[4]; int rr[4];
+    gcptr wbase[4]; int woff[4]; float bias[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      const int tile = tile0 + q, n = tile * 16 + lr;
-      vn[q] = active && q < tpw && n < N;
-      const int blk = (tile * 16) / wb.rows;       // wave-uniform (block rows are multiples of 16 when nb > 1)
-      rr[q] = vn[q] ? n - blk * wb.rows : 0;
-      const float* wsel = wb.w[0]; bsel[q] = wb.b[0];
-#pragma unroll
-      for (int i = 1; i < H; ++i)
-        if (blk == i) { wsel = wb.w[i]; bsel[q] = wb.b[i]; }
-      wrow[q] = wsel + (size_t)rr[q] * K;
+      const bool tile_ok = active && q < tpw && tile0 + q < ntile;      // wave-uniform
+      if (q > 0 && tile_ok) { boff += 16; if (boff >= rows) { boff -= rows; ++blk; } }
+      const int n = (tile0 + q) * 16 + lr;
+      const int rr = (tile_ok && n < N) ? boff + lr : 0;
+      const int bsel = tile_ok ? blk : 0;
+      wbase[q] = uniptr(wb.w[bsel]);
+      woff[q] = rr * K + 4 * lq;
+      bias[q] = hasb ? uniptr(wb.b[bsel])[rr] : 0.f;
     }
     const int kb0 = chunk * per, kb1 = active ? (kb0 + per < kblocks ? kb0 + per : kblocks) : kb0;
-#pragma unroll 2
-    for (int kb = kb0; kb < kb1; ++kb) {
-      const int kk = kb * 16 + 4 * lq;
-      float4 b[4];
+    lcptr xrow = xs + lr * ldx + 4 * lq;
+    MLHOT_TSC(1);
+    for (int kb = kb0; kb < kb1; kb += 4) {
+      f32x4_t b[4][4], a4[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        b[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vn[q]) {
-          if (vec) { if (kk < K) b[q] = *reinterpret_cast<const float4*>(wrow[q] + kk); }
-          else {
-            if (kk < K) b[q].x = wrow[q][kk];
-            if (kk + 1 < K) b[q].y = wrow[q][kk + 1];
-            if (kk + 2 < K) b[q].z = wrow[q][kk + 2];
-            if (kk + 3 < K) b[q].w = wrow[q][kk + 3];
+      for (int u = 0; u < 4; ++u) {
+        if (kb + u < kb1) {
+          const int k16 = (kb + u) * 16;
+          a4[u] = lds_read4(xrow + k16, avec);
+          const int kc = k16 + 4 * lq <= kmax ? k16 : kmax - 4 * lq;       // clamp this lane's 4 k's into the row
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (q < tpw) {
+              if (vec) b[u][q] = *reinterpret_cast<gc4ptr>(wbase[q] + woff[q] + kc);
+              else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int ko = woff[q] + k16 + e; b[u][q][e] = wbase[q][k16 + 4 * lq + e <= kmax ? ko : woff[q] - 4 * lq + kmax]; }
+              }
+            }
           }
         }
       }
-      const float* xp = xs + lr * ldx + kk;
-      const float a0 = xp[0], a1 = xp[1], a2 = xp[2], a3 = xp[3];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[q] = mfma4(a0, b[q].x, acc[q]);
-        acc[q] = mfma4(a1, b[q].y, acc[q]);
-        acc[q] = mfma4(a2, b[q].z, acc[q]);
-        acc[q] = mfma4(a3, b[q].w, acc[q]);
+      for (int u = 0; u < 4; ++u) {
+        if (kb + u < kb1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (q < tpw) {
+              acc[q] = mfma4(a4[u][0], b[u][q][0], acc[q]);
+              acc[q] = mfma4(a4[u][1], b[u][q][1], acc[q]);
+              acc[q] = mfma4(a4[u][2], b[u][q][2], acc[q]);
+              acc[q] = mfma4(a4[u][3], b[u][q][3], acc[q]);
+            }
+          }
+        }
       }
     }
+    MLHOT_TSC(2);
     if (nchunk > 1) {                              // fold the K chunks (fixed order); tpw == 1 here
       if (active && chunk > 0) {
 #pragma unroll
@@ -126,30 +208,47 @@ __device__ __attribute__((noinline)) void wg_linear(const float* xs, int ldx, in
       }
       __syncthreads();
     }
-    if (chunk == 0) {
+    MLHOT_TSC(3);
+    if (active && chunk == 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (!vn[q]) continue;
+        if (q >= tpw || tile0 + q >= ntile) continue;
         const int n = (tile0 + q) * 16 + lr;
-        const float bias = bsel[q] ? bsel[q][rr[q]] : 0.f;
+        float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 4 * lq + r;
-          const float v = act_apply(act, acc[q][r] + bias);
-          if (ys) ys[row * ldy + n] = v;
-          if (yg && row < nrows) yg[(size_t)row * ldg + n] = v;
+        for (int r = 0; r < 4; ++r) v[r] = acc[q][r] + bias[q];
+        if (act == ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (act == ACT_TANH) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+        }
+        if (n < N) {
+          if (has_ys) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ys[(4 * lq + r) * ldy + n] = v[r];
+          }
+          if (has_yg) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (4 * lq + r < nrows) ygu[(4 * lq + r) * ldg + n] = v[r];
+          }
         }
       }
     }
+    MLHOT_TSC(4);
   }
+  MLHOT_TSC(5);
 }
 
 // zero a [16 x ld] LDS tile
-__device__ __forceinline__ void lds_zero(float* p, int n, int tid, int nthreads) {
+__device__ __forceinline__ void lds_zero(lptr p, int n, int tid, int nthreads) {
   for (int i = tid; i < n; i += nthreads) p[i] = 0.f;
 }
 // global [nrows x width] (row stride ldg) -> LDS [16 x ld] (rows >= nrows left as they are)
-__device__ __forceinline__ void lds_load(float* dst, int ld, const float* src, int ldg, int nrows, int width, int tid, int nthreads) {
+template <class SrcPtr>
+__device__ __forceinline__ void lds_load(lptr dst, int ld, SrcPtr src, int ldg, int nrows, int width, int tid, int nthreads) {
   for (int i = tid; i < nrows * width; i += nthreads) {
     const int r = i / width, c = i % width;
     dst[r * ld + c] = src[(size_t)r * ldg + c];
@@ -164,21 +263,6 @@ struct TailParams {
   const float *ty_w, *ty_b, *er_w[3], *er_b[3], *r2z_w, *r2z_b, *dec_w[3], *dec_b[3];
   const float *wk_w[H], *wk_b[H], *wv_w[H], *wv_b[H], *wq_w[H], *wq_b[H], *wo_w, *wo_b, *proj;
 };
-
-__device__ __forceinline__ WB wb1(const float* w, const float* b, int rows) {
-  WB x;
-#pragma unroll
-  for (int i = 0; i < H; ++i) { x.w[i] = w; x.b[i] = b; }
-  x.rows = rows;
-  return x;
-}
-__device__ __forceinline__ WB wb8(const float* const* w, const float* const* b, int rows) {
-  WB x;
-#pragma unroll
-  for (int i = 0; i < H; ++i) { x.w[i] = w[i]; x.b[i] = b ? b[i] : nullptr; }
-  x.rows = rows;
-  return x;
-}
 
 // LDS row strides (floats): width rounded up to a multiple of 16, +4 (keeps float4 alignment and
 // moves consecutive rows to different banks)
@@ -200,25 +284,29 @@ struct PhaseAArgs {
 
 __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   extern __shared__ float lds[];
+  lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldc = d.dw + d.dw / 4, ldd = d.dw + d.dz;
   const int Lcat = ldpad(ldc), Lh0 = ldpad(d.h0), Lh1 = ldpad(d.h1), Lrs = ldpad(d.dw), Lkh = ldpad(H * d.dw), Lxq = ldpad(d.dw), Ly = ldpad(d.label_dim);
-  float* s_cat = lds;                    // [16][Lcat]
-  float* s_h0 = s_cat + 16 * Lcat;
-  float* s_h1 = s_h0 + 16 * Lh0;
-  float* s_rs = s_h1 + 16 * Lh1;
-  float* s_kh = s_rs + 16 * Lrs;         // [16][Lkh]
-  float* s_xq = s_kh + 16 * Lkh;
-  float* s_y = s_xq + 16 * Lxq;
-  float* s_red = s_y + 16 * Ly;          // [8 waves][256] K-split partials of wg_linear; later the max reduction
+  lptr s_cat = L0;                    // [16][Lcat]
+  lptr s_h0 = s_cat + 16 * Lcat;
+  lptr s_h1 = s_h0 + 16 * Lh0;
+  lptr s_rs = s_h1 + 16 * Lh1;
+  lptr s_kh = s_rs + 16 * Lrs;         // [16][Lkh]
+  lptr s_xq = s_kh + 16 * Lkh;
+  lptr s_y = s_xq + 16 * Lxq;
+  lptr s_red = s_y + 16 * Ly;          // [8 waves][256] K-split partials of wg_linear; later the max reduction
+  using PRM = TailParams;
+  lu64 ptab = reinterpret_cast<lu64>(s_red + 8 * 256);
+  ptab_fill(ptab, a.p, tid);
   const int total = 16 * (Lcat + Lh0 + Lh1 + Lrs + Lkh + Lxq + Ly) + 8 * 256;
   MLHOT_TSTAMP(0);
-  lds_zero(lds, total, tid, 512);
+  lds_zero(L0, total, tid, 512);
   __syncthreads();
   MLHOT_TSTAMP(1);
-  float* g_cat = a.cat_in + (size_t)t * d.Nc * ldc;
-  float* g_dec = a.dec_in + (size_t)t * d.Nq * ldd;
+  gptr g_cat = G(a.cat_in) + (size_t)t * d.Nc * ldc;
+  gptr g_dec = G(a.dec_in) + (size_t)t * d.Nq * ldd;
   lds_load(s_cat, Lcat, g_cat, ldc, d.Nc, d.dw, tid, 512);                       // x_ctx (encoder output)
   lds_load(s_xq, Lxq, g_dec, ldd, d.Nq, d.dw, tid, 512);                         // x_qry
   lds_load(s_y, Ly, a.ctx_y + (size_t)t * d.Nc * d.label_dim, d.label_dim, d.Nc, d.label_dim, tid, 512);
@@ -232,26 +320,26 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   MLHOT_TSTAMP(2);
   if (a.dbg & 2) return;
   // transform_y -> cat[:, dw:]
-  wg_linear<8>(s_y, Ly, d.label_dim, wb1(a.p.ty_w, a.p.ty_b, d.dw / 4), d.dw / 4, ACT_NONE, s_cat + d.dw, Lcat, g_cat + d.dw, ldc, d.Nc, nullptr, wave, lane);
+  wg_linear<8>(s_y, Ly, d.label_dim, WB1(ty_w, ty_b, d.dw / 4), d.dw / 4, ACT_NONE, s_cat + d.dw, Lcat, g_cat + d.dw, ldc, d.Nc, nullptr, wave, lane);
   MLHOT_TSTAMP(3);
   // Q projection only needs x_qry: issue it alongside
-  wg_linear<8>(s_xq, Lxq, d.dw, wb8(a.p.wq_w, a.p.wq_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, a.qh + (size_t)t * d.Nq * H * d.dw, H * d.dw, d.Nq, nullptr, wave, lane);
+  wg_linear<8>(s_xq, Lxq, d.dw, WB1(wq_w, wq_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, G(a.qh + (size_t)t * d.Nq * H * d.dw), H * d.dw, d.Nq, nullptr, wave, lane);
   MLHOT_TSTAMP(4);
   // K projection needs x_ctx only
-  wg_linear<8>(s_cat, Lcat, d.dw, wb8(a.p.wk_w, a.p.wk_b, d.dw), H * d.dw, ACT_NONE, s_kh, Lkh, a.kh + (size_t)t * d.Nc * H * d.dw, H * d.dw, d.Nc, nullptr, wave, lane);
+  wg_linear<8>(s_cat, Lcat, d.dw, WB1(wk_w, wk_b, d.dw), H * d.dw, ACT_NONE, s_kh, Lkh, G(a.kh + (size_t)t * d.Nc * H * d.dw), H * d.dw, d.Nc, nullptr, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(5);
   if (a.dbg & 4) return;
-  wg_linear<8>(s_cat, Lcat, ldc, wb1(a.p.er_w[0], a.p.er_b[0], d.h0), d.h0, ACT_RELU, s_h0, Lh0, a.h0 + (size_t)t * d.Nc * d.h0, d.h0, d.Nc, nullptr, wave, lane);
+  wg_linear<8>(s_cat, Lcat, ldc, WB1(er_w[0], er_b[0], d.h0), d.h0, ACT_RELU, s_h0, Lh0, G(a.h0 + (size_t)t * d.Nc * d.h0), d.h0, d.Nc, nullptr, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(6);
-  wg_linear<8>(s_h0, Lh0, d.h0, wb1(a.p.er_w[1], a.p.er_b[1], d.h1), d.h1, ACT_RELU, s_h1, Lh1, a.h1 + (size_t)t * d.Nc * d.h1, d.h1, d.Nc, nullptr, wave, lane);
+  wg_linear<8>(s_h0, Lh0, d.h0, WB1(er_w[1], er_b[1], d.h1), d.h1, ACT_RELU, s_h1, Lh1, G(a.h1 + (size_t)t * d.Nc * d.h1), d.h1, d.Nc, nullptr, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(7);
-  wg_linear<8>(s_h1, Lh1, d.h1, wb1(a.p.er_w[2], a.p.er_b[2], d.dw), d.dw, ACT_NONE, s_rs, Lrs, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, s_red, wave, lane);
+  wg_linear<8>(s_h1, Lh1, d.h1, WB1(er_w[2], er_b[2], d.dw), d.dw, ACT_NONE, s_rs, Lrs, G(a.rs + (size_t)t * d.Nc * d.dw), d.dw, d.Nc, s_red, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(8);
-  wg_linear<8>(s_rs, Lrs, d.dw, wb8(a.p.wv_w, a.p.wv_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, a.vh + (size_t)t * d.Nc * H * d.dw, H * d.dw, d.Nc, nullptr, wave, lane);
+  wg_linear<8>(s_rs, Lrs, d.dw, WB1(wv_w, wv_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, G(a.vh + (size_t)t * d.Nc * H * d.dw), H * d.dw, d.Nc, nullptr, wave, lane);
   MLHOT_TSTAMP(9);
 
   if (a.dbg & 8) return;
@@ -277,7 +365,7 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
       b.x *= c; b.y *= c; b.z *= c; b.w *= c;
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        const float* xp = s_kh + lr * Lkh + h * d.dw + kk;
+        lcptr xp = s_kh + lr * Lkh + h * d.dw + kk;
         acc[h] = mfma4(xp[0], b.x, acc[h]);
         acc[h] = mfma4(xp[1], b.y, acc[h]);
         acc[h] = mfma4(xp[2], b.z, acc[h]);
@@ -307,7 +395,7 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
     if (ov > best || (ov == best && (orow < brow || (orow == brow && ocol < bcol)))) { best = ov; brow = orow; bcol = ocol; }
   }
   __syncthreads();
-  int* s_redi = reinterpret_cast<int*>(s_red + 8);
+  MLHOT_LDS int* s_redi = reinterpret_cast<MLHOT_LDS int*>(s_red + 8);
   if (lane == 0) { s_red[wave] = best; s_redi[2 * wave] = brow; s_redi[2 * wave + 1] = bcol; }
   __syncthreads();
   if (tid == 0) {
@@ -322,7 +410,8 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
 
 __host__ inline size_t phaseA_lds_bytes(const TailDims& d) {
   const int ldc = d.dw + d.dw / 4;
-  return sizeof(float) * (16 * (ldpad(ldc) + ldpad(d.h0) + ldpad(d.h1) + ldpad(d.dw) + ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.label_dim)) + 8 * 256);
+  return sizeof(float) * (16 * (ldpad(ldc) + ldpad(d.h0) + ldpad(d.h1) + ldpad(d.dw) + ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.label_dim)) + 8 * 256 +
+                          ptab_floats<TailParams>());
 }
 
 // ==================================================================================================
@@ -341,20 +430,21 @@ struct PhaseBArgs {
 
 __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   extern __shared__ float lds[];
+  lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
   const int t = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int Lx = ldpad(d.dw), Lf = ldpad(d.m);
-  float* s_q = lds;                    // [16][Lx]
-  float* s_k = s_q + 16 * Lx;
-  float* s_v = s_k + 16 * Lx;
-  float* s_qf = s_v + 16 * Lx;         // [16][Lf]  dd -> E
-  float* s_kf = s_qf + 16 * Lf;
-  float* s_S = s_kf + 16 * Lf;         // [4 waves][16][17] partials, then final in wave 0's slot
-  float* s_st = s_S + 4 * 16 * 17;     // diag_q[16], diag_k[16], max_q[16], D[16]
-  int* s_arg = reinterpret_cast<int*>(s_st + 64);   // arg_q[16]
+  lptr s_q = L0;                    // [16][Lx]
+  lptr s_k = s_q + 16 * Lx;
+  lptr s_v = s_k + 16 * Lx;
+  lptr s_qf = s_v + 16 * Lx;         // [16][Lf]  dd -> E
+  lptr s_kf = s_qf + 16 * Lf;
+  lptr s_S = s_kf + 16 * Lf;         // [4 waves][16][17] partials, then final in wave 0's slot
+  lptr s_st = s_S + 4 * 16 * 17;     // diag_q[16], diag_k[16], max_q[16], D[16]
+  MLHOT_LDS int* s_arg = reinterpret_cast<MLHOT_LDS int*>(s_st + 64);   // arg_q[16]
   const int total = 16 * (3 * Lx + 2 * Lf) + 4 * 16 * 17 + 64 + 16;
-  lds_zero(lds, total, tid, 256);
+  lds_zero(L0, total, tid, 256);
   __syncthreads();
   const int HD = H * d.dw;
   lds_load(s_q, Lx, a.qh + (size_t)t * d.Nq * HD + h * d.dw, HD, d.Nq, d.dw, tid, 256);
@@ -377,8 +467,8 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
       const int kk = k0 + 4 * lq;
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
       if (vj) b = *reinterpret_cast<const float4*>(a.pc + (size_t)j * d.dw + kk);
-      const float* xq = s_q + lr * Lx + kk;
-      const float* xk = s_k + lr * Lx + kk;
+      lcptr xq = s_q + lr * Lx + kk;
+      lcptr xk = s_k + lr * Lx + kk;
       accq = mfma4(xq[0], b.x, accq); acck = mfma4(xk[0], b.x, acck);
       accq = mfma4(xq[1], b.y, accq); acck = mfma4(xk[1], b.y, acck);
       accq = mfma4(xq[2], b.z, accq); acck = mfma4(xk[2], b.z, acck);
@@ -393,7 +483,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   {
     const float half_c2 = 0.5f / sqrtf((float)d.dw);
     const int row = tid >> 3, part = tid & 7;
-    const float* xr = (row < 16 ? s_q + row * Lx : s_k + (row - 16) * Lx);
+    lcptr xr = (row < 16 ? s_q + row * Lx : s_k + (row - 16) * Lx);
     float s = 0.f;
     for (int e = part; e < d.dw; e += 8) s += xr[e] * xr[e];
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
@@ -493,35 +583,39 @@ struct PhaseCArgs {
 
 __global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
   extern __shared__ float lds[];
+  lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldd = d.dw + d.dz, HD = H * d.dw;
   const int Lm = ldpad(HD), Lr = ldpad(d.dw), Ld = ldpad(ldd), Lh = ldpad(d.dec_h);
-  float* s_m = lds;                 // [16][Lm]
-  float* s_rr = s_m + 16 * Lm;
-  float* s_dec = s_rr + 16 * Lr;
-  float* s_d1 = s_dec + 16 * Ld;
-  float* s_d2 = s_d1 + 16 * Lh;
-  float* s_red = s_d2 + 16 * Lh;    // [8 waves][256] K-split partials of wg_linear
-  lds_zero(lds, 16 * (Lm + Lr + Ld + 2 * Lh), tid, 512);
+  lptr s_m = L0;                 // [16][Lm]
+  lptr s_rr = s_m + 16 * Lm;
+  lptr s_dec = s_rr + 16 * Lr;
+  lptr s_d1 = s_dec + 16 * Ld;
+  lptr s_d2 = s_d1 + 16 * Lh;
+  lptr s_red = s_d2 + 16 * Lh;    // [8 waves][256] K-split partials of wg_linear
+  using PRM = TailParams;
+  lu64 ptab = reinterpret_cast<lu64>(s_red + 8 * 256);
+  ptab_fill(ptab, a.p, tid);
+  lds_zero(L0, 16 * (Lm + Lr + Ld + 2 * Lh), tid, 512);
   __syncthreads();
-  float* g_dec = a.dec_in + (size_t)t * d.Nq * ldd;
+  gptr g_dec = G(a.dec_in) + (size_t)t * d.Nq * ldd;
   lds_load(s_m, Lm, a.merged + (size_t)t * d.Nq * HD, HD, d.Nq, HD, tid, 512);
   lds_load(s_dec, Ld, g_dec, ldd, d.Nq, d.dw, tid, 512);          // x_qry
   __syncthreads();
-  wg_linear<8>(s_m, Lm, HD, wb1(a.p.wo_w, a.p.wo_b, d.dw), d.dw, ACT_NONE, s_rr, Lr, a.rr + (size_t)t * d.Nq * d.dw, d.dw, d.Nq, s_red, wave, lane);
+  wg_linear<8>(s_m, Lm, HD, WB1(wo_w, wo_b, d.dw), d.dw, ACT_NONE, s_rr, Lr, G(a.rr + (size_t)t * d.Nq * d.dw), d.dw, d.Nq, s_red, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_rr, Lr, d.dw, wb1(a.p.r2z_w, a.p.r2z_b, d.dz), d.dz, ACT_NONE, s_dec + d.dw, Ld, g_dec + d.dw, ldd, d.Nq, s_red, wave, lane);
+  wg_linear<8>(s_rr, Lr, d.dw, WB1(r2z_w, r2z_b, d.dz), d.dz, ACT_NONE, s_dec + d.dw, Ld, g_dec + d.dw, ldd, d.Nq, s_red, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_dec, Ld, ldd, wb1(a.p.dec_w[0], a.p.dec_b[0], d.dec_h), d.dec_h, ACT_RELU, s_d1, Lh, a.d1 + (size_t)t * d.Nq * d.dec_h, d.dec_h, d.Nq, nullptr, wave, lane);
+  wg_linear<8>(s_dec, Ld, ldd, WB1(dec_w[0], dec_b[0], d.dec_h), d.dec_h, ACT_RELU, s_d1, Lh, G(a.d1 + (size_t)t * d.Nq * d.dec_h), d.dec_h, d.Nq, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_d1, Lh, d.dec_h, wb1(a.p.dec_w[1], a.p.dec_b[1], d.dec_h), d.dec_h, ACT_RELU, s_d2, Lh, a.d2 + (size_t)t * d.Nq * d.dec_h, d.dec_h, d.Nq, nullptr, wave, lane);
+  wg_linear<8>(s_d1, Lh, d.dec_h, WB1(dec_w[1], dec_b[1], d.dec_h), d.dec_h, ACT_RELU, s_d2, Lh, G(a.d2 + (size_t)t * d.Nq * d.dec_h), d.dec_h, d.Nq, nullptr, wave, lane);
   __syncthreads();
-  wg_linear<8>(s_d2, Lh, d.dec_h, wb1(a.p.dec_w[2], a.p.dec_b[2], d.y_dim), d.y_dim, d.out_act, nullptr, 0, a.mu + (size_t)t * d.Nq * d.y_dim, d.y_dim, d.Nq, s_red, wave, lane);
+  wg_linear<8>(s_d2, Lh, d.dec_h, WB1(dec_w[2], dec_b[2], d.y_dim), d.y_dim, d.out_act, nullptr, 0, G(a.mu + (size_t)t * d.Nq * d.y_dim), d.y_dim, d.Nq, s_red, wave, lane);
 }
 
 __host__ inline size_t phaseC_lds_bytes(const TailDims& d) {
-  return sizeof(float) * (16 * (ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.dw + d.dz) + 2 * ldpad(d.dec_h)) + 8 * 256);
+  return sizeof(float) * (16 * (ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.dw + d.dz) + 2 * ldpad(d.dec_h)) + 8 * 256 + ptab_floats<TailParams>());
 }
 
 // ==================================================================================================
@@ -531,10 +625,12 @@ __host__ inline size_t phaseC_lds_bytes(const TailDims& d) {
 // dW[Nout][Kin] = dY^T X (sum over the 16 rows; padded rows of dY are zero), db = column sums of dY.
 // Output tiles (16 j x 16 i) round-robin over the waves, 4 MFMAs each; results go to the task's slab.
 template <int NW>
-__device__ __attribute__((noinline)) void wg_wgrad(const float* dys, int ldy, int Nout, const float* xs, int ldx, int Kin,
-                                         float* dw, float* db, int wave, int lane, int tid) {
+__device__ __attribute__((noinline)) void wg_wgrad(lcptr dys, int ldy, int Nout, lcptr xs, int ldx, int Kin,
+                                                   gptr dw, gptr db, int wave, int lane, int tid) {
+  ldy = uni(ldy); Nout = uni(Nout); ldx = uni(ldx); Kin = uni(Kin); wave = uni(wave);
+  const bool has_db = uni(db != nullptr);
   const int lr = lane & 15, lq = lane >> 4;
-  const int nj = (Nout + 15) / 16, ni = (Kin + 15) / 16;
+  const int nj = (Nout + 15) >> 4, ni = (Kin + 15) >> 4;
   for (int it = wave; it < nj * ni; it += NW) {
     const int j0 = (it / ni) * 16, i0 = (it % ni) * 16;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -552,7 +648,7 @@ __device__ __attribute__((noinline)) void wg_wgrad(const float* dys, int ldy, in
       }
     }
   }
-  if (db) {
+  if (has_db) {
     for (int j = tid; j < Nout; j += NW * 64) {
       float sum = 0.f;
 #pragma unroll
@@ -566,47 +662,66 @@ __device__ __attribute__((noinline)) void wg_wgrad(const float* dys, int ldy, in
 // (16-column tile of i) x (chunk of the reduction index j): when Kin has fewer tiles than there are
 // waves (the head projections: Kin = 64, Nout = 512) the j range is split over the idle waves and
 // the partial tiles are folded through `red` (LDS, NW*256 floats).  Per 16-wide j block: A = one
-// float4 of dY from LDS, B = 4 coalesced dwords of W.  Result to LDS (dxs) and/or global (dxg: rows
-// < nrows; accumulate adds to what is there).  Contains barriers: call from all waves.
+// float4 of dY from LDS, B = 4 coalesced dwords of W; 4 j blocks (16 weight loads) are in flight per
+// trip.  Result to LDS (dxs) and/or global (dxg: rows < nrows; accumulate adds to what is there).
+// Contains barriers: call from all waves.
 template <int NW>
-__device__ __attribute__((noinline)) void wg_dgrad(const float* dys, int ldy, int Nout, const WB& wb, int Kin,
-                                         float* dxs, int ldxs, float* dxg, int ldg, int nrows, bool accumulate,
-                                         float* red, int wave, int lane) {
+__device__ __attribute__((noinline)) void wg_dgrad(lcptr dys, int ldy, int Nout, WB wb, int Kin,
+                                                   lptr dxs, int ldxs, gptr dxg, int ldg, int nrows, bool accumulate,
+                                                   lptr red, int wave, int lane) {
+  ldy = uni(ldy); Nout = uni(Nout); Kin = uni(Kin); ldxs = uni(ldxs); ldg = uni(ldg); nrows = uni(nrows); wave = uni(wave);
+  const int rows = uni(wb.rows);
+  const bool has_dxs = uni(dxs != nullptr), has_dxg = uni(dxg != nullptr), acc_out = uni((int)accumulate);
+  const bool avec = uni((((unsigned)(size_t)dys & 15u) == 0u) && (ldy & 3) == 0);
+  gptr dxgu = uniptr(dxg);
   const int lr = lane & 15, lq = lane >> 4;
-  const int ntile = (Kin + 15) / 16;
-  int nchunk = 1;
-  if (ntile * 2 <= NW) nchunk = NW / ntile;
-  const int jblocks = (Nout + 15) / 16, per = (jblocks + nchunk - 1) / nchunk;
+  const int ntile = (Kin + 15) >> 4;
+  int csh = 0;                                              // NW / ntile chunks of the j range (a power of two for NW = 8)
+  if (ntile * 2 <= NW) csh = ntile == 1 ? 3 : ntile == 2 ? 2 : 1;
+  const int nchunk = 1 << csh;
+  const int jblocks = (Nout + 15) >> 4, per = (jblocks + nchunk - 1) >> csh;
+  // dY's padding columns (j >= Nout) are zero and columns i >= Kin of the result are never stored:
+  // out-of-range weight addresses are only clamped
   for (int it0 = 0; it0 < ntile * nchunk; it0 += NW) {
     const int it = it0 + wave;
     const bool active = it < ntile * nchunk;
-    const int tile = active ? it % ntile : 0, chunk = active ? it / ntile : 0;
+    int tile = it, chunk = 0;
+    while (tile >= ntile) { tile -= ntile; ++chunk; }
+    if (!active) { tile = 0; chunk = 0; }
     const int i = tile * 16 + lr;
     const bool vi = active && i < Kin;
+    const int ic = i < Kin ? i : Kin - 1;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     const int jb0 = chunk * per, jb1 = active ? (jb0 + per < jblocks ? jb0 + per : jblocks) : jb0;
-#pragma unroll 4
-    for (int jb = jb0; jb < jb1; ++jb) {
-      const int j0 = jb * 16;
-      const int blk = j0 / wb.rows;
-      const float* wsel = wb.w[0];
+    int blk = 0, boff = jb0 * 16;                           // row block of j block jb0 and its first row inside it
+    while (boff >= rows) { boff -= rows; ++blk; }
+    lcptr arow = dys + lr * ldy + 4 * lq;
+    for (int jb = jb0; jb < jb1; jb += 4) {
+      f32x4_t b[4], a4[4];
 #pragma unroll
-      for (int q = 1; q < H; ++q)
-        if (blk == q) wsel = wb.w[q];
-      const int jr = j0 + 4 * lq - blk * wb.rows;          // row inside the block
-      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-      if (vi) {
-        const int j = j0 + 4 * lq;
-        if (j < Nout) b0 = wsel[(size_t)jr * Kin + i];
-        if (j + 1 < Nout) b1 = wsel[(size_t)(jr + 1) * Kin + i];
-        if (j + 2 < Nout) b2 = wsel[(size_t)(jr + 2) * Kin + i];
-        if (j + 3 < Nout) b3 = wsel[(size_t)(jr + 3) * Kin + i];
+      for (int u = 0; u < 4; ++u) {
+        if (jb + u < jb1) {
+          const int j0 = (jb + u) * 16;
+          gcptr wsel = uniptr(wb.w[blk]);
+          a4[u] = lds_read4(arow + j0, avec);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int jl = j0 + 4 * lq + e < Nout ? boff + 4 * lq + e : 0;      // row inside the block
+            b[u][e] = wsel[jl * Kin + ic];
+          }
+          boff += 16;
+          if (boff >= rows) { boff -= rows; ++blk; }
+        }
       }
-      const float* ap = dys + lr * ldy + j0 + 4 * lq;
-      acc = mfma4(ap[0], b0, acc);
-      acc = mfma4(ap[1], b1, acc);
-      acc = mfma4(ap[2], b2, acc);
-      acc = mfma4(ap[3], b3, acc);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (jb + u < jb1) {
+          acc = mfma4(a4[u][0], b[u][0], acc);
+          acc = mfma4(a4[u][1], b[u][1], acc);
+          acc = mfma4(a4[u][2], b[u][2], acc);
+          acc = mfma4(a4[u][3], b[u][3], acc);
+        }
+      }
     }
     if (nchunk > 1) {                                       // fold the j chunks (fixed order)
       if (active && chunk > 0) {
@@ -624,13 +739,18 @@ __device__ __attribute__((noinline)) void wg_dgrad(const float* dys, int ldy, in
       __syncthreads();
     }
     if (vi && chunk == 0) {
+      if (has_dxs) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * lq + r;
-        if (dxs) dxs[row * ldxs + i] = acc[r];
-        if (dxg && row < nrows) {
-          float* o = dxg + (size_t)row * ldg + i;
-          *o = accumulate ? *o + acc[r] : acc[r];
+        for (int r = 0; r < 4; ++r) dxs[(4 * lq + r) * ldxs + i] = acc[r];
+      }
+      if (has_dxg) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * lq + r;
+          if (row < nrows) {
+            gptr o = dxgu + row * ldg + i;
+            *o = acc_out ? *o + acc[r] : acc[r];
+          }
         }
       }
     }
@@ -638,7 +758,7 @@ __device__ __attribute__((noinline)) void wg_dgrad(const float* dys, int ldy, in
 }
 
 // g[row][c] *= act'(y[row][c]) on the valid columns
-__device__ __forceinline__ void lds_actgrad(float* g, int ldg_, const float* y, int ldy, int width, int act, int tid, int nthreads) {
+__device__ __forceinline__ void lds_actgrad(lptr g, int ldg_, lcptr y, int ldy, int width, int act, int tid, int nthreads) {
   for (int i = tid; i < 16 * width; i += nthreads) {
     const int r = i / width, c = i % width;
     g[r * ldg_ + c] *= act_grad_from_out(act, y[r * ldy + c]);
@@ -682,22 +802,26 @@ struct PhaseCBwdArgs {
 
 __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) {
   extern __shared__ float lds[];
+  lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldd = d.dw + d.dz, HD = H * d.dw;
   const int Ly = ldpad(d.y_dim), Lh = ldpad(d.dec_h), Ld = ldpad(ldd), Lr = ldpad(d.dw), Lm = ldpad(HD);
-  float* s_g = lds;                  // [16][Ly]   dmu * act'(mu)
-  float* s_d2 = s_g + 16 * Ly;       // saved activations
-  float* s_d1 = s_d2 + 16 * Lh;
-  float* s_dec = s_d1 + 16 * Lh;
-  float* s_rr = s_dec + 16 * Ld;
-  float* s_m = s_rr + 16 * Lr;
-  float* s_dd2 = s_m + 16 * Lm;      // gradients
-  float* s_dd1 = s_dd2 + 16 * Lh;
-  float* s_ddec = s_dd1 + 16 * Lh;
-  float* s_drr = s_ddec + 16 * Ld;
-  float* s_red = s_drr + 16 * Lr;    // [8 waves][256] partial tiles of wg_dgrad
-  lds_zero(lds, 16 * (Ly + 4 * Lh + 2 * Ld + 2 * Lr + Lm), tid, 512);
+  lptr s_g = L0;                  // [16][Ly]   dmu * act'(mu)
+  lptr s_d2 = s_g + 16 * Ly;       // saved activations
+  lptr s_d1 = s_d2 + 16 * Lh;
+  lptr s_dec = s_d1 + 16 * Lh;
+  lptr s_rr = s_dec + 16 * Ld;
+  lptr s_m = s_rr + 16 * Lr;
+  lptr s_dd2 = s_m + 16 * Lm;      // gradients
+  lptr s_dd1 = s_dd2 + 16 * Lh;
+  lptr s_ddec = s_dd1 + 16 * Lh;
+  lptr s_drr = s_ddec + 16 * Ld;
+  lptr s_red = s_drr + 16 * Lr;    // [8 waves][256] partial tiles of wg_dgrad
+  using PRM = TailParams;
+  lu64 ptab = reinterpret_cast<lu64>(s_red + 8 * 256);
+  ptab_fill(ptab, a.p, tid);
+  lds_zero(L0, 16 * (Ly + 4 * Lh + 2 * Ld + 2 * Lr + Lm), tid, 512);
   __syncthreads();
   const size_t rq = (size_t)t * d.Nq;
   for (int i = tid; i < d.Nq * d.y_dim; i += 512) {
@@ -710,33 +834,34 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   lds_load(s_rr, Lr, a.rr + rq * d.dw, d.dw, d.Nq, d.dw, tid, 512);
   lds_load(s_m, Lm, a.merged + rq * HD, HD, d.Nq, HD, tid, 512);
   __syncthreads();
-  float* sl = a.slab + (size_t)t * a.sl.total;
+  gptr sl = G(a.slab) + (size_t)t * a.sl.total;
   // decoder0.4
   wg_wgrad<8>(s_g, Ly, d.y_dim, s_d2, Lh, d.dec_h, sl + a.sl.dec_w[2], sl + a.sl.dec_b[2], wave, lane, tid);
-  wg_dgrad<8>(s_g, Ly, d.y_dim, wb1(a.p.dec_w[2], nullptr, d.y_dim), d.dec_h, s_dd2, Lh, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_g, Ly, d.y_dim, WB1N(dec_w[2], d.y_dim), d.dec_h, s_dd2, Lh, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   lds_actgrad(s_dd2, Lh, s_d2, Lh, d.dec_h, ACT_RELU, tid, 512);
   __syncthreads();
   // decoder0.2
   wg_wgrad<8>(s_dd2, Lh, d.dec_h, s_d1, Lh, d.dec_h, sl + a.sl.dec_w[1], sl + a.sl.dec_b[1], wave, lane, tid);
-  wg_dgrad<8>(s_dd2, Lh, d.dec_h, wb1(a.p.dec_w[1], nullptr, d.dec_h), d.dec_h, s_dd1, Lh, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dd2, Lh, d.dec_h, WB1N(dec_w[1], d.dec_h), d.dec_h, s_dd1, Lh, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   lds_actgrad(s_dd1, Lh, s_d1, Lh, d.dec_h, ACT_RELU, tid, 512);
   __syncthreads();
   // decoder0.0: input gradient = [d x_qry | dz]
   wg_wgrad<8>(s_dd1, Lh, d.dec_h, s_dec, Ld, ldd, sl + a.sl.dec_w[0], sl + a.sl.dec_b[0], wave, lane, tid);
-  wg_dgrad<8>(s_dd1, Lh, d.dec_h, wb1(a.p.dec_w[0], nullptr, d.dec_h), ldd, s_ddec, Ld, a.d_dec_in + rq * ldd, ldd, d.Nq, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dd1, Lh, d.dec_h, WB1N(dec_w[0], d.dec_h), ldd, s_ddec, Ld, G(a.d_dec_in + rq * ldd), ldd, d.Nq, false, s_red, wave, lane);
   __syncthreads();
   // r_to_z (dz = s_ddec[:, dw:])
   wg_wgrad<8>(s_ddec + d.dw, Ld, d.dz, s_rr, Lr, d.dw, sl + a.sl.r2z_w, sl + a.sl.r2z_b, wave, lane, tid);
-  wg_dgrad<8>(s_ddec + d.dw, Ld, d.dz, wb1(a.p.r2z_w, nullptr, d.dz), d.dw, s_drr, Lr, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_ddec + d.dw, Ld, d.dz, WB1N(r2z_w, d.dz), d.dw, s_drr, Lr, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   // _W
   wg_wgrad<8>(s_drr, Lr, d.dw, s_m, Lm, HD, sl + a.sl.wo_w, sl + a.sl.wo_b, wave, lane, tid);
-  wg_dgrad<8>(s_drr, Lr, d.dw, wb1(a.p.wo_w, nullptr, d.dw), HD, nullptr, 0, a.d_merged + rq * HD, HD, d.Nq, false, s_red, wave, lane);
+  wg_dgrad<8>(s_drr, Lr, d.dw, WB1N(wo_w, d.dw), HD, nullptr, 0, G(a.d_merged + rq * HD), HD, d.Nq, false, s_red, wave, lane);
 }
 __host__ inline size_t phaseC_bwd_lds_bytes(const TailDims& d) {
-  return sizeof(float) * (16 * (ldpad(d.y_dim) + 4 * ldpad(d.dec_h) + 2 * ldpad(d.dw + d.dz) + 2 * ldpad(d.dw) + ldpad(H * d.dw)) + 8 * 256);
+  return sizeof(float) * (16 * (ldpad(d.y_dim) + 4 * ldpad(d.dec_h) + 2 * ldpad(d.dw + d.dz) + 2 * ldpad(d.dw) + ldpad(H * d.dw)) + 8 * 256 +
+                          ptab_floats<TailParams>());
 }
 
 // ==================================================================================================
@@ -751,23 +876,24 @@ struct PhaseBBwdArgs {
 
 __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) {
   extern __shared__ float lds[];
+  lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
   const int t = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int Lx = ldpad(d.dw), Lf = ldpad(d.m), HD = H * d.dw;
-  float* s_q = lds;                    // [16][Lx]
-  float* s_k = s_q + 16 * Lx;
-  float* s_v = s_k + 16 * Lx;
-  float* s_do = s_v + 16 * Lx;         // dO
-  float* s_qf = s_do + 16 * Lx;        // [16][Lf] E features, later d(dd)
-  float* s_kf = s_qf + 16 * Lf;
-  float* s_gq = s_kf + 16 * Lf;        // G
-  float* s_gk = s_gq + 16 * Lf;
-  float* s_S = s_gk + 16 * Lf;         // [16][17]  S / D
-  float* s_dS = s_S + 16 * 17;         // [16][17]
-  float* s_st = s_dS + 16 * 17;        // wv[16], D[16], rsum_q[16], rsum_k[16]
+  lptr s_q = L0;                    // [16][Lx]
+  lptr s_k = s_q + 16 * Lx;
+  lptr s_v = s_k + 16 * Lx;
+  lptr s_do = s_v + 16 * Lx;         // dO
+  lptr s_qf = s_do + 16 * Lx;        // [16][Lf] E features, later d(dd)
+  lptr s_kf = s_qf + 16 * Lf;
+  lptr s_gq = s_kf + 16 * Lf;        // G
+  lptr s_gk = s_gq + 16 * Lf;
+  lptr s_S = s_gk + 16 * Lf;         // [16][17]  S / D
+  lptr s_dS = s_S + 16 * 17;         // [16][17]
+  lptr s_st = s_dS + 16 * 17;        // wv[16], D[16], rsum_q[16], rsum_k[16]
   const int total = 16 * (4 * Lx + 4 * Lf) + 2 * 16 * 17 + 64;
-  lds_zero(lds, total, tid, 256);
+  lds_zero(L0, total, tid, 256);
   __syncthreads();
   lds_load(s_q, Lx, a.qh + (size_t)t * d.Nq * HD + h * d.dw, HD, d.Nq, d.dw, tid, 256);
   lds_load(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
@@ -842,8 +968,8 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
       acc = mfma4(av, bv, acc);
     }
     if (vj) {
-      float* g = isk ? s_gk : s_gq;
-      const float* f = isk ? s_kf : s_qf;
+      lptr g = isk ? s_gk : s_gq;
+      lcptr f = isk ? s_kf : s_qf;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int row = 4 * lq + r; g[row * Lf + j] = acc[r] * f[row * Lf + j]; }
     }
@@ -852,7 +978,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   // row sums of G (32 rows x 8 threads), then d(dd): queries subtract the row sum at the arg-max
   {
     const int row = tid >> 3, part = tid & 7;
-    const float* g = row < 16 ? s_gq + row * Lf : s_gk + (row - 16) * Lf;
+    lcptr g = row < 16 ? s_gq + row * Lf : s_gk + (row - 16) * Lf;
     float s = 0.f;
     for (int j = part; j < d.m; j += 8) s += g[j];
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
@@ -872,7 +998,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     const int net = d.dw / 16;
     for (int it = wave; it < 2 * net; it += 4) {
       const int isk = it >= net, et = isk ? it - net : it;
-      const float* g = isk ? s_gk : s_gq;
+      lcptr g = isk ? s_gk : s_gq;
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
       for (int j0 = 0; j0 < d.m; j0 += 4) {
@@ -880,7 +1006,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
         const float bv = j < d.m ? a.pc[(size_t)j * d.dw + et * 16 + lr] : 0.f;
         acc = mfma4(g[lr * Lf + j], bv, acc);
       }
-      const float* xs = isk ? s_k : s_q;
+      lcptr xs = isk ? s_k : s_q;
       float* dst = isk ? a.dkh : a.dqh;
       const int nrows = isk ? d.Nc : d.Nq;
 #pragma unroll
@@ -909,25 +1035,29 @@ struct PhaseABwdArgs {
 
 __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) {
   extern __shared__ float lds[];
+  lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldc = d.dw + d.dw / 4, ldd = d.dw + d.dz, HD = H * d.dw;
   const int Lcat = ldpad(ldc), Lh0 = ldpad(d.h0), Lh1 = ldpad(d.h1), Lw = ldpad(d.dw), Lhd = ldpad(HD), Ly = ldpad(d.label_dim);
-  float* s_cat = lds;                  // saved activations
-  float* s_h0 = s_cat + 16 * Lcat;
-  float* s_h1 = s_h0 + 16 * Lh0;
-  float* s_rs = s_h1 + 16 * Lh1;
-  float* s_xq = s_rs + 16 * Lw;
-  float* s_y = s_xq + 16 * Lw;
-  float* s_dq = s_y + 16 * Ly;         // [16][Lhd] head-space gradients (one buffer, reused q -> v -> k)
-  float* s_drs = s_dq + 16 * Lhd;      // gradients
-  float* s_dxc = s_drs + 16 * Lw;
-  float* s_dh1 = s_dxc + 16 * Lw;
-  float* s_dh0 = s_dh1 + 16 * Lh1;
-  float* s_dcat = s_dh0 + 16 * Lh0;
-  float* s_red = s_dcat + 16 * Lcat;   // [8 waves][256] partial tiles of wg_dgrad
+  lptr s_cat = L0;                  // saved activations
+  lptr s_h0 = s_cat + 16 * Lcat;
+  lptr s_h1 = s_h0 + 16 * Lh0;
+  lptr s_rs = s_h1 + 16 * Lh1;
+  lptr s_xq = s_rs + 16 * Lw;
+  lptr s_y = s_xq + 16 * Lw;
+  lptr s_dq = s_y + 16 * Ly;         // [16][Lhd] head-space gradients (one buffer, reused q -> v -> k)
+  lptr s_drs = s_dq + 16 * Lhd;      // gradients
+  lptr s_dxc = s_drs + 16 * Lw;
+  lptr s_dh1 = s_dxc + 16 * Lw;
+  lptr s_dh0 = s_dh1 + 16 * Lh1;
+  lptr s_dcat = s_dh0 + 16 * Lh0;
+  lptr s_red = s_dcat + 16 * Lcat;   // [8 waves][256] partial tiles of wg_dgrad
+  using PRM = TailParams;
+  lu64 ptab = reinterpret_cast<lu64>(s_red + 8 * 256);
+  ptab_fill(ptab, a.p, tid);
   MLHOT_TSTAMP(160);
-  lds_zero(lds, 16 * (2 * Lcat + 2 * Lh0 + 2 * Lh1 + 4 * Lw + Ly + Lhd), tid, 512);
+  lds_zero(L0, 16 * (2 * Lcat + 2 * Lh0 + 2 * Lh1 + 4 * Lw + Ly + Lhd), tid, 512);
   __syncthreads();
   MLHOT_TSTAMP(161);
   const size_t rc = (size_t)t * d.Nc, rq = (size_t)t * d.Nq;
@@ -938,13 +1068,13 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   lds_load(s_xq, Lw, a.dec_in + rq * ldd, ldd, d.Nq, d.dw, tid, 512);
   lds_load(s_y, Ly, a.ctx_y + rc * d.label_dim, d.label_dim, d.Nc, d.label_dim, tid, 512);
   lds_load(s_dq, Lhd, a.dqh + rq * HD, HD, d.Nq, HD, tid, 512);
-  float* sl = a.slab + (size_t)t * a.sl.total;
+  gptr sl = G(a.slab) + (size_t)t * a.sl.total;
   __syncthreads();
   MLHOT_TSTAMP(162);
   // W_q: weight gradient and the attention share of d x_qry (accumulated onto the decoder's)
   wg_wgrad<8>(s_dq, Lhd, HD, s_xq, Lw, d.dw, sl + a.sl.wq_w, sl + a.sl.wq_b, wave, lane, tid);
   MLHOT_TSTAMP(163);
-  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wq_w, nullptr, d.dw), d.dw, nullptr, 0, a.d_dec_in + rq * ldd, ldd, d.Nq, true, s_red, wave, lane);
+  wg_dgrad<8>(s_dq, Lhd, HD, WB1N(wq_w, d.dw), d.dw, nullptr, 0, G(a.d_dec_in + rq * ldd), ldd, d.Nq, true, s_red, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(164);
   // W_v
@@ -955,7 +1085,7 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   MLHOT_TSTAMP(165);
   wg_wgrad<8>(s_dq, Lhd, HD, s_rs, Lw, d.dw, sl + a.sl.wv_w, sl + a.sl.wv_b, wave, lane, tid);
   MLHOT_TSTAMP(166);
-  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wv_w, nullptr, d.dw), d.dw, s_drs, Lw, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dq, Lhd, HD, WB1N(wv_w, d.dw), d.dw, s_drs, Lw, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(167);
   // W_k, with the batch-global key arg-max correction: that ONE element's d(dd) carries minus the
@@ -978,23 +1108,23 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   MLHOT_TSTAMP(168);
   wg_wgrad<8>(s_dq, Lhd, HD, s_cat, Lcat, d.dw, sl + a.sl.wk_w, sl + a.sl.wk_b, wave, lane, tid);
   MLHOT_TSTAMP(169);
-  wg_dgrad<8>(s_dq, Lhd, HD, wb8(a.p.wk_w, nullptr, d.dw), d.dw, s_dxc, Lw, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dq, Lhd, HD, WB1N(wk_w, d.dw), d.dw, s_dxc, Lw, nullptr, 0, 0, false, s_red, wave, lane);
   MLHOT_TSTAMP(170);
   // EncoderFC, last layer first
   wg_wgrad<8>(s_drs, Lw, d.dw, s_h1, Lh1, d.h1, sl + a.sl.er_w[2], sl + a.sl.er_b[2], wave, lane, tid);
-  wg_dgrad<8>(s_drs, Lw, d.dw, wb1(a.p.er_w[2], nullptr, d.dw), d.h1, s_dh1, Lh1, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_drs, Lw, d.dw, WB1N(er_w[2], d.dw), d.h1, s_dh1, Lh1, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(171);
   lds_actgrad(s_dh1, Lh1, s_h1, Lh1, d.h1, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dh1, Lh1, d.h1, s_h0, Lh0, d.h0, sl + a.sl.er_w[1], sl + a.sl.er_b[1], wave, lane, tid);
-  wg_dgrad<8>(s_dh1, Lh1, d.h1, wb1(a.p.er_w[1], nullptr, d.h1), d.h0, s_dh0, Lh0, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dh1, Lh1, d.h1, WB1N(er_w[1], d.h1), d.h0, s_dh0, Lh0, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(172);
   lds_actgrad(s_dh0, Lh0, s_h0, Lh0, d.h0, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dh0, Lh0, d.h0, s_cat, Lcat, ldc, sl + a.sl.er_w[0], sl + a.sl.er_b[0], wave, lane, tid);
-  wg_dgrad<8>(s_dh0, Lh0, d.h0, wb1(a.p.er_w[0], nullptr, d.h0), ldc, s_dcat, Lcat, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_dh0, Lh0, d.h0, WB1N(er_w[0], d.h0), ldc, s_dcat, Lcat, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(173);
   // d_cat_in = EncoderFC input gradient (+ K-projection share on the x_ctx columns)
@@ -1008,7 +1138,8 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
 }
 __host__ inline size_t phaseA_bwd_lds_bytes(const TailDims& d) {
   const int ldc = d.dw + d.dw / 4;
-  return sizeof(float) * (16 * (2 * ldpad(ldc) + 2 * ldpad(d.h0) + 2 * ldpad(d.h1) + 4 * ldpad(d.dw) + ldpad(d.label_dim) + ldpad(H * d.dw)) + 8 * 256);
+  return sizeof(float) * (16 * (2 * ldpad(ldc) + 2 * ldpad(d.h0) + 2 * ldpad(d.h1) + 4 * ldpad(d.dw) + ldpad(d.label_dim) + ldpad(H * d.dw)) + 8 * 256 +
+                          ptab_floats<TailParams>());
 }
 
 // ---- sum the per-task slabs into the parameter gradients (fixed task order) -------------------------
