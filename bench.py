@@ -47,7 +47,7 @@ def alg_flops(label, n_img):
         "enc.bwd.conv2.dgrad": 2.0 * pos2 * 32 * 48 * 9,          # all 4 parity classes in one launch
         "enc.conv3": 2.0 * n_img * 64 * 64 * 432,
         "enc.bwd.conv3.wgrad": 2.0 * n_img * 64 * 64 * 432,
-        "enc.bwd.conv3.dgrad": 2.0 * n_img * 64 * 48 * 64 * 9 / 4,
+        "enc.bwd.conv3.dgrad": 2.0 * n_img * 64 * 48 * 64 * 9,          # all 4 parity classes in one launch
         "enc.conv1": 2.0 * n_img * 4096 * 32 * 9,
         "enc.bwd.conv1.wgrad": 2.0 * n_img * 4096 * 32 * 9,
         "enc.linear": 2.0 * n_img * 4096 * 64,

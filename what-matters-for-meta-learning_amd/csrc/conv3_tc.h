@@ -1,0 +1,325 @@
+// conv3 of the vanilla image encoder (48 -> 64 channels, 3x3, stride 2, pad 1, 16x16 -> 8x8, + ReLU)
+// as three weight-stationary MFMA kernels, the same scheme as conv2's (conv_tc.h):
+// one persistent workgroup per CU keeps its share of the [64][432] weight matrix in registers, images
+// stream through LDS, and the matrix core runs v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate).
+//   forward : unit = half an image (4 output rows); double-buffered [48][9][24] input patch
+//   wgrad   : unit = image; accumulators = the whole 432 x 64 gradient (18 tiles per wave), position
+//             halves on two wave groups folded through LDS at the end, one slab per workgroup
+//   dgrad   : unit = image; one wave per (parity class, 16-channel tile): a class only carries the
+//             taps that reach it (1, 2, 2 or 4 of the 9), waves are placed so every SIMD gets ~equal work
+// All LDS strides are chosen so the 32 lanes of a half-wave hit 32 different banks (comments inline).
+// GPU build only.  Reference: networks/conv_embedding_model.py-style encoder used by
+// CondNeuralProcess.py / ANP*.py (`encoder_w0`), third conv block.
+#pragma once
+#include "common.h"
+
+#ifndef MLHOT_HOSTSIM
+namespace mlhot {
+namespace c3 {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+constexpr int CIN = 48, COUT = 64, KW = 432;
+
+// ---- forward ---------------------------------------------------------------------------------------
+// 512 threads: wave = (nt = wave & 3: output channels 16nt..+15) x (mg = wave >> 2: output rows 2mg, 2mg+1
+// of the unit's 4).  Lane (lr, lq) of an MFMA: A = input[ci = 4cg + lq][2oy + ky - 1][2ox + kx - 1] of
+// position lr = (oy & 1) * 8 + ox, B = W[16nt + lr][ci][tap] from registers (108 per lane).
+// Patch [ci][r = iy - (8hf - 1)][c = ix + 1]: row stride 24 (2 * 24 = 48 = 16 mod 32: the tile's second
+// row lands on banks 16..30), plane stride 217 (odd: lq = 1 lands on the odd banks).
+constexpr int F_RS = 24, F_PS = 9 * F_RS + 1, F_PATCH = CIN * F_PS;
+constexpr int F_NT = 512;
+
+__global__ __launch_bounds__(F_NT) void conv3_fwd_kernel(const float* __restrict__ p2, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ a3, int n_img) {
+  __shared__ float patch2[2 * F_PATCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = wave & 3, mg = wave >> 2;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int co = nt * 16 + lr;
+
+  float wr[108];
+#pragma unroll
+  for (int ks = 0; ks < 108; ++ks) wr[ks] = w[((size_t)co * CIN + (ks % 12) * 4 + lq) * 9 + ks / 12];
+  const float bn = bias[co];
+
+  for (int i = tid; i < 2 * F_PATCH; i += F_NT) patch2[i] = 0.f;       // halo column 0 stays zero for good
+  const int nunits = n_img * 2;
+  // staging: 48 x 9 rows x 4 float4 = 1728 float4 per unit, up to 4 per thread
+  float4 st[4];
+  auto fetch = [&](int u) {
+    const int img = u >> 1, hf = u & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + j * F_NT;
+      const int ci = e / 36, rem = e - ci * 36, r = rem >> 2, c4 = rem & 3;
+      const int iy = 8 * hf - 1 + r;
+      st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < 1728 && iy >= 0) st[j] = *reinterpret_cast<const float4*>(p2 + (((size_t)img * CIN + ci) * 16 + iy) * 16 + 4 * c4);
+    }
+  };
+  auto stash = [&](float* buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + j * F_NT;
+      if (e < 1728) {
+        const int ci = e / 36, rem = e - ci * 36, r = rem >> 2, c4 = rem & 3;
+        float* d = buf + ci * F_PS + r * F_RS + 1 + 4 * c4;
+        d[0] = st[j].x; d[1] = st[j].y; d[2] = st[j].z; d[3] = st[j].w;
+      }
+    }
+  };
+  int unit = blockIdx.x;
+  __syncthreads();
+  if (unit < nunits) { fetch(unit); stash(patch2); }
+  if (unit + (int)gridDim.x < nunits) fetch(unit + gridDim.x);
+  __syncthreads();
+  const int aoff = lq * F_PS + (2 * (2 * mg + (lr >> 3))) * F_RS + 2 * (lr & 7);
+  int cur = 0;
+  for (; unit < nunits; unit += gridDim.x, cur ^= 1) {
+    const float* ab = patch2 + cur * F_PATCH + aoff;
+    const int next = unit + (int)gridDim.x;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 54; ks += 2) {
+      const int t0 = ks / 12, c0 = ks % 12, t1 = (ks + 1) / 12, c1 = (ks + 1) % 12;
+      acc0 = mfma4(ab[c0 * 4 * F_PS + (t0 / 3) * F_RS + t0 % 3], wr[ks], acc0);
+      acc1 = mfma4(ab[c1 * 4 * F_PS + (t1 / 3) * F_RS + t1 % 3], wr[ks + 1], acc1);
+    }
+    if (next < nunits) {                       // the other buffer was released by the barrier that ended the previous unit
+      stash(patch2 + (cur ^ 1) * F_PATCH);
+      if (next + (int)gridDim.x < nunits) fetch(next + gridDim.x);
+    }
+#pragma unroll
+    for (int ks = 54; ks < 108; ks += 2) {
+      const int t0 = ks / 12, c0 = ks % 12, t1 = (ks + 1) / 12, c1 = (ks + 1) % 12;
+      acc0 = mfma4(ab[c0 * 4 * F_PS + (t0 / 3) * F_RS + t0 % 3], wr[ks], acc0);
+      acc1 = mfma4(ab[c1 * 4 * F_PS + (t1 / 3) * F_RS + t1 % 3], wr[ks + 1], acc1);
+    }
+    // lane holds positions 4lq..4lq+3 of the tile = row (lq >> 1), columns 4(lq & 1)..+3 of channel co
+    const int img = unit >> 1, hf = unit & 1;
+    const int oy = 4 * hf + 2 * mg + (lq >> 1);
+    float4 o;
+    o.x = fmaxf(acc0[0] + acc1[0] + bn, 0.f); o.y = fmaxf(acc0[1] + acc1[1] + bn, 0.f);
+    o.z = fmaxf(acc0[2] + acc1[2] + bn, 0.f); o.w = fmaxf(acc0[3] + acc1[3] + bn, 0.f);
+    *reinterpret_cast<float4*>(a3 + (((size_t)img * COUT + co) * 8 + oy) * 8 + 4 * (lq & 1)) = o;
+    __syncthreads();
+  }
+}
+
+// ---- weight + bias gradient -----------------------------------------------------------------------
+// 768 threads: wave = (job = wave % 6) x (ph = wave / 6: output rows 4ph..4ph+3); job = (tg = job % 3: taps
+// ky = tg, kx = 0..2) x (np = job / 3: output-channel tiles 2np, 2np+1).  18 accumulator tiles per wave:
+// dW[ci = 16cig + .][tap (tg, kx)] x [co tile].  One k-step = 4 positions (oy = 4ph + lq, ox = ks):
+// A = patch[ci = 16cig + lr][2oy + ky][2ox + kx], B = dY^T[pos][co].
+// Patch [ci][r = iy + 1][c = ix + 1]: row stride 24, plane stride 409 (odd); dY^T [pos][66] (8 * 66 = 16 mod 32).
+constexpr int W_RS = 24, W_PS = 17 * W_RS + 1, W_PATCH = CIN * W_PS, W_DS = 66, W_DYT = 64 * W_DS;
+constexpr int W_NT = 768;
+constexpr int W_LDS = (W_PATCH + W_DYT) > 6 * 18 * 256 ? (W_PATCH + W_DYT) : 6 * 18 * 256;
+
+__global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restrict__ p2, const float* __restrict__ dy3,
+                                                           float* __restrict__ slab_w, float* __restrict__ slab_b, int n_img) {
+  __shared__ float lds[W_LDS];
+  float* patch = lds;
+  float* dyt = lds + W_PATCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int job = wave % 6, ph = wave / 6, tg = job % 3, np = job / 3;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  f32x4_t acc[3][3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[a][b][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+
+  for (int i = tid; i < W_LDS; i += W_NT) lds[i] = 0.f;          // halo row 0 / column 0 stay zero
+  float4 sx[4], sd[2];
+  auto fetch = [&](int img) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sx[j] = *reinterpret_cast<const float4*>(p2 + (size_t)img * (CIN * 256) + 4 * (tid + j * W_NT));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * W_NT;
+      sd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < 1024) sd[j] = *reinterpret_cast<const float4*>(dy3 + (size_t)img * 4096 + 4 * e);
+    }
+  };
+  int img = blockIdx.x;
+  if (img < n_img) fetch(img);
+  const int aoff = lr * W_PS + (2 * (4 * ph + lq) + tg) * W_RS;
+  const int boff = (8 * (4 * ph + lq)) * W_DS + 32 * np + lr;
+  for (; img < n_img; img += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                 // image: float4 e -> ci = e / 64, iy = (e / 4) % 16, ix = 4 (e % 4)
+      const int e = tid + j * W_NT;
+      float* d = patch + (e >> 6) * W_PS + (((e >> 2) & 15) + 1) * W_RS + 1 + 4 * (e & 3);
+      d[0] = sx[j].x; d[1] = sx[j].y; d[2] = sx[j].z; d[3] = sx[j].w;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                 // dY: float4 e -> co = e / 16, pos = 4 (e % 16) .. +3  (transposed into [pos][co])
+      const int e = tid + j * W_NT;
+      if (e < 1024) {
+        float* d = dyt + (4 * (e & 15)) * W_DS + (e >> 4);
+        d[0] = sd[j].x; d[W_DS] = sd[j].y; d[2 * W_DS] = sd[j].z; d[3 * W_DS] = sd[j].w;
+        bsum[j] += (sd[j].x + sd[j].y) + (sd[j].z + sd[j].w);
+      }
+    }
+    __syncthreads();
+    if (img + (int)gridDim.x < n_img) fetch(img + gridDim.x);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      float a[3][3], b[2];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int cig = 0; cig < 3; ++cig) a[kx][cig] = patch[aoff + cig * 16 * W_PS + 2 * ks + kx];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) b[c] = dyt[boff + ks * W_DS + 16 * c];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int cig = 0; cig < 3; ++cig)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[kx][cig][c] = mfma4(a[kx][cig], b[c], acc[kx][cig][c]);
+    }
+  }
+  // fold the two position halves through LDS, then one slab per workgroup
+  __syncthreads();
+  if (ph == 1) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int cig = 0; cig < 3; ++cig)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[((job * 18 + (kx * 3 + cig) * 2 + c) * 4 + r) * 64 + lane] = acc[kx][cig][c][r];
+  }
+  __syncthreads();
+  if (ph == 0) {
+    float* sw = slab_w + (size_t)blockIdx.x * (COUT * KW);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int cig = 0; cig < 3; ++cig)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[kx][cig][c][r] + lds[((job * 18 + (kx * 3 + cig) * 2 + c) * 4 + r) * 64 + lane];
+            const int ci = 16 * cig + 4 * lq + r, co = 16 * (2 * np + c) + lr;
+            sw[((size_t)co * CIN + ci) * 9 + 3 * tg + kx] = v;
+          }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                   // 16 consecutive threads share an output channel
+    float v = bsum[j];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int e = tid + j * W_NT;
+    if ((lane & 15) == 0 && e < 1024) slab_b[(size_t)blockIdx.x * COUT + (e >> 4)] = v;
+  }
+}
+
+// ---- data gradient ----------------------------------------------------------------------------------
+// 768 threads, one wave per (parity class of the input position, 16-channel tile of ci).  With k = 3,
+// s = 2, p = 1 an even input coordinate is reached by tap 1 only (from output y'), an odd one by tap 0
+// (from y' + 1) and tap 2 (from y'): class (PY, PX) carries (1 + PY)(1 + PX) taps.
+// M = 64 positions (y', x') of the class, N = 16 ci, K = 64 co x taps; B = W[co = 4ks + lq][ci][tap] in
+// registers (16 per tap), A = dY[co][y' + doy][x' + dox] from the LDS patch [co][9][16] (row 8 / column 8
+// are the zero halo; plane stride 168 = 8 mod 32: lq = 1 lands on banks 8..15 / 24..31).
+constexpr int D_RS = 16, D_PS = 168, D_PATCH = COUT * D_PS;
+constexpr int D_NT = 768;
+
+template <int PY, int PX>
+__device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const float* __restrict__ dy3, float* __restrict__ dp2,
+                                            float* patch2, int n_img, int nt, int tid, int lane) {
+  constexpr int NTY = PY ? 2 : 1, NTX = PX ? 2 : 1, T = NTY * NTX;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ci = 16 * nt + lr;
+  float wr[T][16];
+#pragma unroll
+  for (int ty = 0; ty < NTY; ++ty)
+#pragma unroll
+    for (int tx = 0; tx < NTX; ++tx) {
+      const int ky = PY ? (ty == 0 ? 0 : 2) : 1, kx = PX ? (tx == 0 ? 0 : 2) : 1;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) wr[ty * NTX + tx][ks] = w[((size_t)(4 * ks + lq) * CIN + ci) * 9 + ky * 3 + kx];
+    }
+  float4 sd[2];
+  auto fetch = [&](int img) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * D_NT;
+      sd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < 1024) sd[j] = *reinterpret_cast<const float4*>(dy3 + (size_t)img * 4096 + 4 * e);
+    }
+  };
+  auto stash = [&](float* buf) {                   // float4 e -> co = e / 16, row = (e / 2) % 8, column 4 (e % 2)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * D_NT;
+      if (e < 1024) *reinterpret_cast<float4*>(buf + (e >> 4) * D_PS + ((e >> 1) & 7) * D_RS + 4 * (e & 1)) = sd[j];
+    }
+  };
+  int img = blockIdx.x;
+  if (img < n_img) { fetch(img); stash(patch2); }
+  if (img + (int)gridDim.x < n_img) fetch(img + gridDim.x);
+  __syncthreads();
+  const int aoff = lq * D_PS + (lr >> 3) * D_RS + (lr & 7);
+  int cur = 0;
+  for (; img < n_img; img += gridDim.x, cur ^= 1) {
+    const float* ab = patch2 + cur * D_PATCH + aoff;
+    const int next = img + (int)gridDim.x;
+    if (next < n_img) {
+      stash(patch2 + (cur ^ 1) * D_PATCH);
+      if (next + (int)gridDim.x < n_img) fetch(next + gridDim.x);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ty = 0; ty < NTY; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < NTX; ++tx) {
+          const int doy = (PY && ty == 0) ? 1 : 0, dox = (PX && tx == 0) ? 1 : 0;
+          const float* at = ab + (2 * mt + doy) * D_RS + dox;
+#pragma unroll
+          for (int ks = 0; ks < 16; ks += 2) {
+            acc0 = mfma4(at[ks * 4 * D_PS], wr[ty * NTX + tx][ks], acc0);
+            acc1 = mfma4(at[(ks + 1) * 4 * D_PS], wr[ty * NTX + tx][ks + 1], acc1);
+          }
+        }
+      // lane holds positions 4lq..+3 of the tile: y' = 2mt + (lq >> 1), x' = 4(lq & 1) + r, channel ci
+      const int y = 2 * (2 * mt + (lq >> 1)) + PY;
+      float* o = dp2 + (((size_t)img * CIN + ci) * 16 + y) * 16 + 8 * (lq & 1) + PX;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[2 * r] = acc0[r] + acc1[r];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dy3,
+                                                           float* __restrict__ dp2, int n_img) {
+  __shared__ float patch2[2 * D_PATCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 2 * D_PATCH; i += D_NT) patch2[i] = 0.f;      // halo row 8 / columns 8.. stay zero
+  __syncthreads();
+  // per image a class costs 64 MFMAs per tap and tile: 256 / 128 / 128 / 64.  Waves w, w + 4, w + 8 share a SIMD:
+  // SIMDs 0..2 get {256, 128, 64} (classes 11, 01, 00 of tile w), SIMD 3 gets the three 128s of class 10.
+  const int s = wave & 3, g = wave >> 2;
+  if (s == 3) dgrad_class<1, 0>(w, dy3, dp2, patch2, n_img, g, tid, lane);
+  else if (g == 0) dgrad_class<1, 1>(w, dy3, dp2, patch2, n_img, s, tid, lane);
+  else if (g == 1) dgrad_class<0, 1>(w, dy3, dp2, patch2, n_img, s, tid, lane);
+  else dgrad_class<0, 0>(w, dy3, dp2, patch2, n_img, s, tid, lane);
+}
+
+}  // namespace c3
+}  // namespace mlhot
+#endif  // !MLHOT_HOSTSIM

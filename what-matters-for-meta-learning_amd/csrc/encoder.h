@@ -14,6 +14,7 @@
 #include "problems.h"
 #include "favor.h"   // MLHOT_TRY
 #include "conv_tc.h"
+#include "conv3_tc.h"
 #include "../../include/mlhot.h"
 
 namespace mlhot {
@@ -63,6 +64,7 @@ inline size_t enc_slab_floats(int n, int dim_w) {
   v = (size_t)conv2w_split(n) * 48 * 289;       if (v > m) m = v;
   v = (size_t)conv1w_split(n) * 32 * 10;        if (v > m) m = v;
   v = (size_t)2 * C2_GRID * 48 * 288 + (size_t)C2_GRID * 48 + (size_t)C2_GRID * 320; if (v > m) m = v;   // conv_tc partials
+  v = (size_t)C2_GRID * 64 * 433;                                                   if (v > m) m = v;   // conv3_tc partials
   return m;
 }
 inline EncScratch enc_scratch_carve(int n, int dim_w, void* base, size_t cap) {
@@ -111,9 +113,21 @@ inline int enc_forward(const float* img0, int n0, const float* img1, int n1, con
     MLHOT_TRY((run_igemm<C2, 128, 48, 16, 4, 1>(c2, 1, nullptr, s, "enc.conv2")));
     MLHOT_TRY(run_foreach(Pool2Fwd{sc.a2, sv.p2, sv.am2, 32, 32}, (size_t)n * 48 * 256, s, "enc.pool"));
   }
-  typedef ConvFwd<48, 16, 16, 64, Src1> C3;
-  C3 c3{n * 64, 64, 432, Src1{sv.p2, (size_t)48 * 256}, p.w3, p.b3, sv.a3};
-  MLHOT_TRY((run_igemm<C3, 64, 64, 16, 2, 2>(c3, 1, nullptr, s, "enc.conv3")));
+#ifndef MLHOT_HOSTSIM
+  if (g_opt.conv2_tc) {
+    const int grid = n * 2 < C2_GRID ? n * 2 : C2_GRID;
+    {
+      ProfScope ps("enc.conv3", s);
+      hipLaunchKernelGGL(c3::conv3_fwd_kernel, dim3(grid), dim3(c3::F_NT), 0, s, sv.p2, p.w3, p.b3, sv.a3, n);
+    }
+    MLHOT_TRY(check_launch("enc.conv3"));
+  } else
+#endif
+  {
+    typedef ConvFwd<48, 16, 16, 64, Src1> C3;
+    C3 c3{n * 64, 64, 432, Src1{sv.p2, (size_t)48 * 256}, p.w3, p.b3, sv.a3};
+    MLHOT_TRY((run_igemm<C3, 64, 64, 16, 2, 2>(c3, 1, nullptr, s, "enc.conv3")));
+  }
   EncLinFwd lf{n, dim_w, 4096, sv.a3, p.wl, p.bl, feat};
   MLHOT_TRY((run_igemm<EncLinFwd, 64, 64, 16, 2, 2>(lf, enc_lin_split(n), sc.slab, s, "enc.linear")));
   return MLHOT_OK;
@@ -150,13 +164,38 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
   MLHOT_TRY((run_igemm<EncLinWgrad, 64, 64, 16, 2, 2>(lw, enc_linw_split(n), sc.slab, s, "enc.bwd.linear.wgrad")));
 
   // conv3
-  typedef ConvWgrad<48, 16, 16, 64, DyPlain<64, 8, 8>, Src1> W3;
-  W3 w3{64, 433, n * 64, DyPlain<64, 8, 8>{sc.dy3}, Src1{sv.p2, (size_t)48 * 256}, g.w3, g.b3};
-  MLHOT_TRY((run_igemm<W3, 64, 64, 16, 2, 2>(w3, conv3w_split(n), sc.slab, s, "enc.bwd.conv3.wgrad")));
-  MLHOT_TRY((enc_conv3_dgrad<0, 0>(n, sc.dy3, p.w3, sc.dp2, s)));
-  MLHOT_TRY((enc_conv3_dgrad<0, 1>(n, sc.dy3, p.w3, sc.dp2, s)));
-  MLHOT_TRY((enc_conv3_dgrad<1, 0>(n, sc.dy3, p.w3, sc.dp2, s)));
-  MLHOT_TRY((enc_conv3_dgrad<1, 1>(n, sc.dy3, p.w3, sc.dp2, s)));
+#ifndef MLHOT_HOSTSIM
+  if (g_opt.conv2_tc) {
+    const int grid = n < C2_GRID ? n : C2_GRID;
+    float* slab_w = sc.slab;
+    float* slab_b = sc.slab + (size_t)C2_GRID * 64 * 432;
+    {
+      ProfScope ps("enc.bwd.conv3.wgrad", s);
+      hipLaunchKernelGGL(c3::conv3_wgrad_kernel, dim3(grid), dim3(c3::W_NT), 0, s, sv.p2, sc.dy3, slab_w, slab_b, n);
+    }
+    MLHOT_TRY(check_launch("enc.bwd.conv3.wgrad"));
+    {
+      ProfScope ps("slab_reduce", s);
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(864), dim3(256), 0, s, slab_w, grid, 64 * 432, g.w3);
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(2), dim3(256), 0, s, slab_b, grid, 64, g.b3);
+    }
+    MLHOT_TRY(check_launch("enc.bwd.conv3.wgrad.reduce"));
+    {
+      ProfScope ps("enc.bwd.conv3.dgrad", s);
+      hipLaunchKernelGGL(c3::conv3_dgrad_kernel, dim3(grid), dim3(c3::D_NT), 0, s, p.w3, sc.dy3, sc.dp2, n);
+    }
+    MLHOT_TRY(check_launch("enc.bwd.conv3.dgrad"));
+  } else
+#endif
+  {
+    typedef ConvWgrad<48, 16, 16, 64, DyPlain<64, 8, 8>, Src1> W3;
+    W3 w3{64, 433, n * 64, DyPlain<64, 8, 8>{sc.dy3}, Src1{sv.p2, (size_t)48 * 256}, g.w3, g.b3};
+    MLHOT_TRY((run_igemm<W3, 64, 64, 16, 2, 2>(w3, conv3w_split(n), sc.slab, s, "enc.bwd.conv3.wgrad")));
+    MLHOT_TRY((enc_conv3_dgrad<0, 0>(n, sc.dy3, p.w3, sc.dp2, s)));
+    MLHOT_TRY((enc_conv3_dgrad<0, 1>(n, sc.dy3, p.w3, sc.dp2, s)));
+    MLHOT_TRY((enc_conv3_dgrad<1, 0>(n, sc.dy3, p.w3, sc.dp2, s)));
+    MLHOT_TRY((enc_conv3_dgrad<1, 1>(n, sc.dy3, p.w3, sc.dp2, s)));
+  }
 
   // conv2 (pool + ReLU backward are folded into the dY gather)
   const DyPooled<48, 32, 32> dy2{sc.dp2, sv.p2, sv.am2};
