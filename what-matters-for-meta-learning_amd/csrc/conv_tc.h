@@ -262,20 +262,34 @@ __global__ __launch_bounds__(NT) void conv2_wgrad_kernel(const float* __restrict
   }
 }
 
-// out[e] = sum_p slab[p][e]  (fixed order -> bitwise reproducible)
+// out[e] = sum_p slab[p][e]  (fixed order -> bitwise reproducible).  256 threads = 16 float4 column groups x
+// 16 slab lanes; a lane walks its slabs 4 at a time (4 independent float4 loads in flight), then a
+// fixed-order LDS fold of the 16 lanes.  grid = ceil(len / 64); len must be a multiple of 4.
 __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ slab, int nparts, int len, float* __restrict__ out) {
-  __shared__ float sm[8][32];
-  const int ex = threadIdx.x & 31, zl = threadIdx.x >> 5;
-  for (int e0 = blockIdx.x * 32; e0 < len; e0 += gridDim.x * 32) {
-    const int e = e0 + ex;
-    float s = 0.f;
-    if (e < len)
-      for (int z = zl; z < nparts; z += 8) s += slab[(size_t)z * len + e];
-    sm[zl][ex] = s;
-    __syncthreads();
-    if (zl == 0 && e < len)
-      out[e] = ((sm[0][ex] + sm[1][ex]) + (sm[2][ex] + sm[3][ex])) + ((sm[4][ex] + sm[5][ex]) + (sm[6][ex] + sm[7][ex]));
-    __syncthreads();
+  __shared__ float4 sm[16][16];
+  const int cx = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const int e = (blockIdx.x * 16 + cx) * 4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+  if (e < len) {
+    int z = zl;
+    for (; z + 48 < nparts; z += 64) {
+      const float4 v0 = *reinterpret_cast<const float4*>(slab + (size_t)z * len + e);
+      const float4 v1 = *reinterpret_cast<const float4*>(slab + (size_t)(z + 16) * len + e);
+      const float4 v2 = *reinterpret_cast<const float4*>(slab + (size_t)(z + 32) * len + e);
+      const float4 v3 = *reinterpret_cast<const float4*>(slab + (size_t)(z + 48) * len + e);
+      add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3);
+    }
+    for (; z < nparts; z += 16) add(s0, *reinterpret_cast<const float4*>(slab + (size_t)z * len + e));
+  }
+  add(s0, s1); add(s2, s3); add(s0, s2);
+  sm[zl][cx] = s0;
+  __syncthreads();
+  if (zl == 0 && e < len) {
+    float4 t = sm[0][cx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) add(t, sm[k][cx]);
+    *reinterpret_cast<float4*>(out + e) = t;
   }
 }
 
@@ -625,17 +639,30 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
     }
   }
 
-  float* sw = slab_w + (size_t)(2 * blockIdx.x + ph) * (COUT * CIN * 9);
+  // fold the two position halves through LDS (the patch is free now): one slab per workgroup
+  __syncthreads();
+  if (ph == 1) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int mt = 3 * mg + i, tap = mt >> 1;
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+      for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = 16 * (mt & 1) + 4 * lq + r, co = 16 * j + lr;
-        sw[((size_t)co * CIN + ci) * 9 + tap] = acc[i][j][r];
-      }
+        for (int r = 0; r < 4; ++r) lds[((mg * 9 + i * 3 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (ph == 0) {
+    float* sw = slab_w + (size_t)blockIdx.x * (COUT * CIN * 9);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int mt = 3 * mg + i, tap = mt >> 1;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = 16 * (mt & 1) + 4 * lq + r, co = 16 * j + lr;
+          sw[((size_t)co * CIN + ci) * 9 + tap] = acc[i][j][r] + lds[((mg * 9 + i * 3 + j) * 4 + r) * 64 + lane];
+        }
+    }
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {

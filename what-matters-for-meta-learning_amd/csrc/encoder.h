@@ -176,8 +176,8 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     MLHOT_TRY(check_launch("enc.bwd.conv3.wgrad"));
     {
       ProfScope ps("slab_reduce", s);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(864), dim3(256), 0, s, slab_w, grid, 64 * 432, g.w3);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(2), dim3(256), 0, s, slab_b, grid, 64, g.b3);
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(64 * 432 / 64), dim3(256), 0, s, slab_w, grid, 64 * 432, g.w3);
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 64, g.b3);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv3.wgrad.reduce"));
     {
@@ -213,8 +213,8 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     MLHOT_TRY(check_launch("enc.bwd.conv12.wgrad"));
     {
       ProfScope ps("slab_reduce", s);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(432), dim3(256), 0, s, slab_w, 2 * grid, 48 * 288, g.w2);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(2), dim3(256), 0, s, slab_b, grid, 48, g.b2);
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(48 * 288 / 64), dim3(256), 0, s, slab_w, grid, 48 * 288, g.w2);
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 48, g.b2);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv2.wgrad.reduce"));
     {
