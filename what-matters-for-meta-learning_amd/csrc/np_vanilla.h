@@ -227,7 +227,8 @@ inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   r.nseg = ns; r.T = d.T; r.total = sl.total; r.slab = sc.tail_slab;
   {
     ProfScope ps("tail.bwd.reduce", s);
-    hipLaunchKernelGGL(tf::slab_to_grads_kernel, dim3((maxlen + 255) / 256, ns), dim3(256), 0, s, r);
+    (void)maxlen;
+    hipLaunchKernelGGL(tf::slab_to_grads_kernel, dim3((sl.total + 1023) / 1024), dim3(256), 0, s, r);
   }
   return check_launch("tail.bwd.reduce");
 }
@@ -270,7 +271,8 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   r.nseg = ns; r.T = d.T; r.total = sl.total; r.slab = sc.tail_slab;
   {
     ProfScope ps("tail.bwd.reduce", s);
-    hipLaunchKernelGGL(tf::slab_to_grads_kernel, dim3((maxlen + 255) / 256, ns), dim3(256), 0, s, r);
+    (void)maxlen;
+    hipLaunchKernelGGL(tf::slab_to_grads_kernel, dim3((sl.total + 1023) / 1024), dim3(256), 0, s, r);
   }
   return check_launch("tail.bwd.reduce");
 }

@@ -429,6 +429,7 @@ struct PhaseBArgs {
 };
 
 __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
+  MLHOT_TSTAMP(32);
   extern __shared__ float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   const int total = 16 * (3 * Lx + 2 * Lf) + 4 * 16 * 17 + 64 + 16;
   lds_zero(L0, total, tid, 256);
   __syncthreads();
+  MLHOT_TSTAMP(33);
   const int HD = H * d.dw;
   lds_load(s_q, Lx, a.qh + (size_t)t * d.Nq * HD + h * d.dw, HD, d.Nq, d.dw, tid, 256);
   lds_load(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   for (int i = 1; i < d.T; ++i) if (a.tmax[i] > gm) { gm = a.tmax[i]; gt = i; }
   if (blockIdx.x == 0 && tid == 0) { a.gmax[0] = gm; a.gpos[0] = a.targ[2 * gt]; a.gpos[1] = a.targ[2 * gt + 1]; }
   __syncthreads();
+  MLHOT_TSTAMP(34);
   // dd tiles: q and k against pc; a feature tile's pc slice is loaded once (all float4 in flight
   // together) and feeds both the query and the key accumulator
   const int ntile = (d.m + 15) / 16;
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
     if (part == 0) s_st[row] = s * half_c2;
   }
   __syncthreads();
+  MLHOT_TSTAMP(35);
   // query row max / first arg-max: 16 rows x 16 threads
   {
     const int row = tid >> 4, part = tid & 15;
@@ -503,6 +507,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
     if (part == 0) { s_st[32 + row] = best; s_arg[row] = arg; }
   }
   __syncthreads();
+  MLHOT_TSTAMP(36);
   // E features in place (padding columns j >= m stay exactly 0 -> they are skipped below via `re` masking)
   const float ratio = 1.0f / sqrtf((float)d.m), re = ratio * 1e-4f;
   for (int i = tid; i < 16 * d.m; i += 256) {
@@ -511,6 +516,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
     s_kf[row * Lf + j] = ratio * expf(s_kf[row * Lf + j] - s_st[16 + row] - gm);
   }
   __syncthreads();
+  MLHOT_TSTAMP(37);
   // save E features and arg_q for the backward (rows of the [T*N*H, m] views)
   for (int i = tid; i < d.Nq * d.m; i += 256) {
     const int row = i / d.m, j = i % d.m;
@@ -535,6 +541,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
     for (int r = 0; r < 4; ++r) s_S[(wave * 16 + 4 * lq + r) * 17 + lr] = acc[r];
   }
   __syncthreads();
+  MLHOT_TSTAMP(38);
   {
     const int n = tid >> 4, np = tid & 15;
     float s = (s_S[n * 17 + np] + s_S[(16 + n) * 17 + np]) + (s_S[(32 + n) * 17 + np] + s_S[(48 + n) * 17 + np]);
@@ -544,6 +551,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
     if (n < d.Nq && np < d.Nc) a.S[(((size_t)t * H + h) * d.Nq + n) * d.Nc + np] = s;
   }
   __syncthreads();
+  MLHOT_TSTAMP(39);
   if (tid < 16) {
     float s = 0.f;
     for (int np = 0; np < d.Nc; ++np) s += s_S[tid * 17 + np];
@@ -551,6 +559,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
     if (tid < d.Nq) a.D[((size_t)t * H + h) * d.Nq + tid] = s;
   }
   __syncthreads();
+  MLHOT_TSTAMP(40);
   // out[n][e] = sum_n' S[n][n'] v[n'][e] / D[n]: N-tiles of e over the waves, K = 16 k rows
   for (int et = wave; et * 16 < d.dw; et += 4) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -565,6 +574,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
       if (n < d.Nq) a.merged[(size_t)(t * d.Nq + n) * (d.dw * H) + e * H + h] = acc[r] / s_st[48 + n];
     }
   }
+  MLHOT_TSTAMP(41);
 }
 
 __host__ inline size_t phaseB_lds_bytes(const TailDims& d) {
@@ -582,6 +592,7 @@ struct PhaseCArgs {
 };
 
 __global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
+  MLHOT_TSTAMP(64);
   extern __shared__ float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
@@ -599,19 +610,26 @@ __global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
   ptab_fill(ptab, a.p, tid);
   lds_zero(L0, 16 * (Lm + Lr + Ld + 2 * Lh), tid, 512);
   __syncthreads();
+  MLHOT_TSTAMP(65);
   gptr g_dec = G(a.dec_in) + (size_t)t * d.Nq * ldd;
   lds_load(s_m, Lm, a.merged + (size_t)t * d.Nq * HD, HD, d.Nq, HD, tid, 512);
   lds_load(s_dec, Ld, g_dec, ldd, d.Nq, d.dw, tid, 512);          // x_qry
   __syncthreads();
+  MLHOT_TSTAMP(66);
   wg_linear<8>(s_m, Lm, HD, WB1(wo_w, wo_b, d.dw), d.dw, ACT_NONE, s_rr, Lr, G(a.rr + (size_t)t * d.Nq * d.dw), d.dw, d.Nq, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(67);
   wg_linear<8>(s_rr, Lr, d.dw, WB1(r2z_w, r2z_b, d.dz), d.dz, ACT_NONE, s_dec + d.dw, Ld, g_dec + d.dw, ldd, d.Nq, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(68);
   wg_linear<8>(s_dec, Ld, ldd, WB1(dec_w[0], dec_b[0], d.dec_h), d.dec_h, ACT_RELU, s_d1, Lh, G(a.d1 + (size_t)t * d.Nq * d.dec_h), d.dec_h, d.Nq, nullptr, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(69);
   wg_linear<8>(s_d1, Lh, d.dec_h, WB1(dec_w[1], dec_b[1], d.dec_h), d.dec_h, ACT_RELU, s_d2, Lh, G(a.d2 + (size_t)t * d.Nq * d.dec_h), d.dec_h, d.Nq, nullptr, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(70);
   wg_linear<8>(s_d2, Lh, d.dec_h, WB1(dec_w[2], dec_b[2], d.y_dim), d.y_dim, d.out_act, nullptr, 0, G(a.mu + (size_t)t * d.Nq * d.y_dim), d.y_dim, d.Nq, s_red, wave, lane);
+  MLHOT_TSTAMP(71);
 }
 
 __host__ inline size_t phaseC_lds_bytes(const TailDims& d) {
@@ -801,6 +819,7 @@ struct PhaseCBwdArgs {
 };
 
 __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) {
+  MLHOT_TSTAMP(96);
   extern __shared__ float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
@@ -823,6 +842,7 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   ptab_fill(ptab, a.p, tid);
   lds_zero(L0, 16 * (Ly + 4 * Lh + 2 * Ld + 2 * Lr + Lm), tid, 512);
   __syncthreads();
+  MLHOT_TSTAMP(97);
   const size_t rq = (size_t)t * d.Nq;
   for (int i = tid; i < d.Nq * d.y_dim; i += 512) {
     const int r = i / d.y_dim, c = i % d.y_dim;
@@ -834,30 +854,38 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   lds_load(s_rr, Lr, a.rr + rq * d.dw, d.dw, d.Nq, d.dw, tid, 512);
   lds_load(s_m, Lm, a.merged + rq * HD, HD, d.Nq, HD, tid, 512);
   __syncthreads();
+  MLHOT_TSTAMP(98);
   gptr sl = G(a.slab) + (size_t)t * a.sl.total;
   // decoder0.4
   wg_wgrad<8>(s_g, Ly, d.y_dim, s_d2, Lh, d.dec_h, sl + a.sl.dec_w[2], sl + a.sl.dec_b[2], wave, lane, tid);
   wg_dgrad<8>(s_g, Ly, d.y_dim, WB1N(dec_w[2], d.y_dim), d.dec_h, s_dd2, Lh, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(99);
   lds_actgrad(s_dd2, Lh, s_d2, Lh, d.dec_h, ACT_RELU, tid, 512);
   __syncthreads();
+  MLHOT_TSTAMP(100);
   // decoder0.2
   wg_wgrad<8>(s_dd2, Lh, d.dec_h, s_d1, Lh, d.dec_h, sl + a.sl.dec_w[1], sl + a.sl.dec_b[1], wave, lane, tid);
   wg_dgrad<8>(s_dd2, Lh, d.dec_h, WB1N(dec_w[1], d.dec_h), d.dec_h, s_dd1, Lh, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(101);
   lds_actgrad(s_dd1, Lh, s_d1, Lh, d.dec_h, ACT_RELU, tid, 512);
   __syncthreads();
+  MLHOT_TSTAMP(102);
   // decoder0.0: input gradient = [d x_qry | dz]
   wg_wgrad<8>(s_dd1, Lh, d.dec_h, s_dec, Ld, ldd, sl + a.sl.dec_w[0], sl + a.sl.dec_b[0], wave, lane, tid);
   wg_dgrad<8>(s_dd1, Lh, d.dec_h, WB1N(dec_w[0], d.dec_h), ldd, s_ddec, Ld, G(a.d_dec_in + rq * ldd), ldd, d.Nq, false, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(103);
   // r_to_z (dz = s_ddec[:, dw:])
   wg_wgrad<8>(s_ddec + d.dw, Ld, d.dz, s_rr, Lr, d.dw, sl + a.sl.r2z_w, sl + a.sl.r2z_b, wave, lane, tid);
   wg_dgrad<8>(s_ddec + d.dw, Ld, d.dz, WB1N(r2z_w, d.dz), d.dw, s_drr, Lr, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(104);
   // _W
   wg_wgrad<8>(s_drr, Lr, d.dw, s_m, Lm, HD, sl + a.sl.wo_w, sl + a.sl.wo_b, wave, lane, tid);
   wg_dgrad<8>(s_drr, Lr, d.dw, WB1N(wo_w, d.dw), HD, nullptr, 0, G(a.d_merged + rq * HD), HD, d.Nq, false, s_red, wave, lane);
+  MLHOT_TSTAMP(105);
 }
 __host__ inline size_t phaseC_bwd_lds_bytes(const TailDims& d) {
   return sizeof(float) * (16 * (ldpad(d.y_dim) + 4 * ldpad(d.dec_h) + 2 * ldpad(d.dw + d.dz) + 2 * ldpad(d.dw) + ldpad(H * d.dw)) + 8 * 256 +
@@ -875,6 +903,7 @@ struct PhaseBBwdArgs {
 };
 
 __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) {
+  MLHOT_TSTAMP(128);
   extern __shared__ float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
@@ -895,6 +924,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   const int total = 16 * (4 * Lx + 4 * Lf) + 2 * 16 * 17 + 64;
   lds_zero(L0, total, tid, 256);
   __syncthreads();
+  MLHOT_TSTAMP(129);
   lds_load(s_q, Lx, a.qh + (size_t)t * d.Nq * HD + h * d.dw, HD, d.Nq, d.dw, tid, 256);
   lds_load(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
   lds_load(s_v, Lx, a.vh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
@@ -913,6 +943,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   }
   if (tid < d.Nq) s_st[16 + tid] = a.D[((size_t)t * H + h) * d.Nq + tid];
   __syncthreads();
+  MLHOT_TSTAMP(130);
   {
     const int n = tid >> 4, part = tid & 15;
     float s = 0.f;
@@ -927,6 +958,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     s_S[n * 17 + part] = sd;
   }
   __syncthreads();
+  MLHOT_TSTAMP(131);
   // dS[n][n'] = (dO[n] . v[n'] - wv[n]) / D[n]   (wave 0), valid entries only
   if (wave == 0) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -938,6 +970,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(132);
   // dV[n'][e] = sum_n (S/D)[n][n'] dO[n][e]  -> dvh
   for (int et = wave; et * 16 < d.dw; et += 4) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -975,6 +1008,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(133);
   // row sums of G (32 rows x 8 threads), then d(dd): queries subtract the row sum at the arg-max
   {
     const int row = tid >> 3, part = tid & 7;
@@ -985,6 +1019,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     if (part == 0) s_st[32 + row] = s;
   }
   __syncthreads();
+  MLHOT_TSTAMP(134);
   if (tid < d.Nq) s_gq[tid * Lf + a.arg_q[(t * d.Nq + tid) * H + h]] -= s_st[32 + tid];
   if (tid == 0) {
     float s = 0.f;
@@ -992,6 +1027,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     a.part_k[t * H + h] = s;
   }
   __syncthreads();
+  MLHOT_TSTAMP(135);
   // dx[row][e] = sum_j d(dd)[row][j] pc[j][e] - rsum[row] c^2 x[row][e]: waves 0,1 -> q (e tiles 0..), 2,3 -> k
   {
     const float c2 = 1.0f / sqrtf((float)d.dw);
@@ -1017,6 +1053,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
       }
     }
   }
+  MLHOT_TSTAMP(136);
 }
 __host__ inline size_t phaseB_bwd_lds_bytes(const TailDims& d) {
   return sizeof(float) * (16 * (4 * ldpad(d.dw) + 4 * ldpad(d.m)) + 2 * 16 * 17 + 64);
@@ -1148,18 +1185,39 @@ struct SlabReduce {
   float* dst[MAX_SEG]; int off[MAX_SEG]; int len[MAX_SEG];
   int nseg, T, total; const float* slab;
 };
+// One flat pass over the slab: a thread sums float4 `q` of all T task slabs (T loads in flight), finds
+// the parameter segment the float4 belongs to (segments start and end on multiples of 4 floats, so a
+// float4 never straddles two) and stores into that parameter's gradient.  grid = ceil(total / 1024).
 __global__ __launch_bounds__(256) void slab_to_grads_kernel(const SlabReduce a) {
-  const int seg = blockIdx.y;
-  // compare chain instead of a[seg]: a runtime-indexed by-value kernel argument would be copied to scratch
-  float* dst = a.dst[0]; int off = a.off[0], len = a.len[0];
+  __shared__ float* s_dst[MAX_SEG];
+  __shared__ int s_off[MAX_SEG], s_len[MAX_SEG];
+  {
+    // compare chain instead of a.dst[tid]: a runtime-indexed by-value kernel argument would be copied to scratch
+    float* dst = nullptr; int off = 0, len = 0;
 #pragma unroll
-  for (int i = 1; i < MAX_SEG; ++i)
-    if (i == seg) { dst = a.dst[i]; off = a.off[i]; len = a.len[i]; }
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < len; e += gridDim.x * 256) {
-    float s = 0.f;
-    for (int t = 0; t < a.T; ++t) s += a.slab[(size_t)t * a.total + off + e];
-    dst[e] = s;
+    for (int i = 0; i < MAX_SEG; ++i)
+      if (i == (int)threadIdx.x) { dst = a.dst[i]; off = a.off[i]; len = a.len[i]; }
+    if (threadIdx.x < MAX_SEG) { s_dst[threadIdx.x] = dst; s_off[threadIdx.x] = off; s_len[threadIdx.x] = len; }
   }
+  __syncthreads();
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= a.total) return;
+  int seg = -1;
+  for (int i = 0; i < a.nseg; ++i)
+    if (e >= s_off[i] && e < s_off[i] + s_len[i]) seg = i;
+  if (seg < 0) return;                              // alignment padding between two segments
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int t = 0; t < a.T; ++t) {
+    const float4 v = *reinterpret_cast<const float4*>(a.slab + (size_t)t * a.total + e);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float* d = s_dst[seg] + (e - s_off[seg]);
+  const int left = s_len[seg] - (e - s_off[seg]);   // a segment's length need not be a multiple of 4
+  d[0] = s.x;
+  if (left > 1) d[1] = s.y;
+  if (left > 2) d[2] = s.z;
+  if (left > 3) d[3] = s.w;
 }
 
 }  // namespace tf
