@@ -140,7 +140,8 @@ inline int lin_wgrad(const float* dy, int lddy, const float* y, int ldy, int act
 // ---- fused tail (csrc/tail_fused.h) ---------------------------------------------------------------
 inline bool tail_fused_applies(const mlhot_np_dims& d) {
   return g_opt.tail_fused && d.agg_mode == MLHOT_AGG_ATTENTION && d.Nc >= 1 && d.Nc <= 16 && d.Nq <= 16 &&
-         d.n_hidden == 2 && d.dim_w % 16 == 0 && d.dim_r == d.dim_w;
+         d.n_hidden == 2 && d.dim_w % 16 == 0 && d.dim_r == d.dim_w && d.m_feat <= 4096 &&
+         (long long)d.T * d.Nc * MLHOT_HEADS < (1ll << 19);      // key arg-max positions are packed row * 4096 + col
 }
 inline tf::TailDims tail_dims(const mlhot_np_dims& d) {
   return tf::TailDims{d.T, d.Nc, d.Nq, d.label_dim, d.y_dim, d.dim_w, d.dim_z, d.hidden[0], d.hidden[1], d.dec_hidden,
@@ -175,9 +176,9 @@ inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   FavorDims f{d.T, MLHOT_HEADS, d.Nq, d.Nc, d.dim_w, d.m_feat};
   FavorWs w = favor_carve(f, b.favor, b.favor_bytes);
   if (!w.ok) { set_error("tail_fused: favor workspace"); return MLHOT_ERR_WORKSPACE; }
-  tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, b.vh, b.qh, w.pc, w.max_k, w.arg_k};
-  MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
-  tf::PhaseBArgs bb{td, b.qh, b.kh, b.vh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged};
+  tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, w.pc, w.max_k, w.arg_k};
+  MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
+  tf::PhaseBArgs bb{td, tp, b.dec_in, b.rs, b.qh, b.vh, b.kh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged};
   MLHOT_TRY(tail_launch(tf::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 256, tf::phaseB_lds_bytes(td), bb, s, "tail.B"));
   tf::PhaseCArgs c{td, tp, b.merged, b.rr, b.dec_in, b.d1, b.d2, mu};
   MLHOT_TRY(tail_launch(tf::phaseC_fwd_kernel, d.T, 512, tf::phaseC_lds_bytes(td), c, s, "tail.C"));
@@ -244,9 +245,11 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   float* part_k = w.rsum_k;   // [T*H]
   tf::PhaseCBwdArgs c{td, tp, sl, dmu, mu, b.d2, b.d1, b.dec_in, b.rr, b.merged, sc.d_dec_in, sc.d_merged, sc.tail_slab};
   MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
-  tf::PhaseBBwdArgs bb{td, b.qh, b.kh, b.vh, w.pc, w.qf, w.kf, w.S, w.D, b.merged, sc.d_merged, w.arg_q, sc.dqh, sc.dkh, sc.dvh, part_k};
+  // sc.dqh / dkh / dvh double as the heads' input-gradient shares [T*H][N][dw] (same sizes)
+  tf::PhaseBBwdArgs bb{td, tp, sl, b.qh, b.kh, b.vh, w.pc, w.qf, w.kf, w.S, w.D, b.merged, sc.d_merged, w.arg_q,
+                       b.dec_in, b.cat_in, b.rs, sc.dqh, sc.dkh, sc.dvh, part_k, sc.tail_slab};
   MLHOT_TRY(tail_launch(tf::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 256, tf::phaseB_bwd_lds_bytes(td), bb, s, "tail.bwd.B"));
-  tf::PhaseABwdArgs a{td, tp, sl, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, sc.dqh, sc.dkh, sc.dvh, w.pc, part_k, w.gpos,
+  tf::PhaseABwdArgs a{td, tp, sl, ctx_y, b.cat_in, b.h[0], b.h[1], sc.dqh, sc.dkh, sc.dvh, w.pc, part_k, w.gpos,
                       sc.d_dec_in, sc.d_cat_in, sc.tail_slab};
   MLHOT_TRY(tail_launch(tf::phaseA_bwd_kernel, d.T, 512, tf::phaseA_bwd_lds_bytes(td), a, s, "tail.bwd.A"));
   // per-task slabs -> parameter gradients

@@ -269,49 +269,135 @@ struct TailParams {
 __host__ __device__ constexpr int ldpad(int w) { return (w + 15) / 16 * 16 + 4; }
 
 // ==================================================================================================
-// phase A forward, one workgroup (512 threads) per task:
-//   cat_in[:, dw:] = transform_y(ctx_y); h0, h1 = EncoderFC hidden; rs; kh = W_k(x_ctx); vh = W_v(rs);
-//   qh = W_q(x_qry); pc = c * P (task 0); per-task max / arg-max of ddk = kh_h pc^T over (row, head, j).
+// phase A forward, ONE launch with two kinds of 512-thread workgroups:
+//   blocks [0, T)         one per task: cat_in[:, dw:] = transform_y(ctx_y); h0, h1 = EncoderFC hidden; rs;
+//                         the task's slice of pc = c * P
+//   blocks [T, T + T*H)   one per (task, head): kh = W_k,h(x_ctx) and this head's share of the batch-global
+//                         key stabiliser, max / first arg-max of ddk = c * kh . P[j]  (fast_attention.py:97)
+// The key-head blocks need nothing from the chain, so the 16-CU-wide dependent chain and the 128 blocks
+// of projection / feature-map work run side by side (they used to be serial stages of the task block).
+// The query and value projections moved into phase B.
 // ==================================================================================================
 struct PhaseAArgs {
   int dbg;              // timing experiments: early exits (results become wrong)
   TailDims d; TailParams p;
   const float* ctx_y;
-  float *cat_in, *h0, *h1, *rs, *dec_in, *kh, *vh, *qh;   // saved activations (global)
+  float *cat_in, *h0, *h1, *rs, *dec_in, *kh;             // saved activations (global)
   float* pc;                                              // [m][dw]  c * projection
-  float* tmax; int* targ;                                 // per task: max of ddk, {row, col}
+  float* tmax; int* targ;                                 // per (task, head): max of ddk, packed (row * 4096 + col)
 };
+
+// (value, packed position): larger value first, then the smaller position (row-major first occurrence)
+__device__ __forceinline__ bool kmax_better(float v, int code, float bv, int bcode) { return v > bv || (v == bv && code < bcode); }
+
+__device__ __forceinline__ void phaseA_keyhead(const PhaseAArgs& a, lptr L0, int th, int tid) {
+  const TailDims& d = a.d;
+  const int t = th / H, h = th - t * H, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ldc = d.dw + d.dw / 4, HD = H * d.dw, Lx = ldpad(d.dw);
+  lptr s_x = L0;                      // [16][Lx] x_ctx
+  lptr s_k = s_x + 16 * Lx;           // [16][Lx] kh
+  lptr s_red = s_k + 16 * Lx;         // [8] max, [8] packed position
+  using PRM = TailParams;
+  lu64 ptab = reinterpret_cast<lu64>(s_red + 16);
+  ptab_fill(ptab, a.p, tid);
+  lds_zero(L0, 32 * Lx, tid, 512);
+  __syncthreads();
+  lds_load(s_x, Lx, a.cat_in + (size_t)t * d.Nc * ldc, ldc, d.Nc, d.dw, tid, 512);
+  __syncthreads();
+  // kh tile: waves 0 .. dw/16-1, one 16-column tile each; the others go straight to the feature tiles
+  if (wave * 16 < d.dw) {
+    gcptr wk = uniptr(ptab[offsetof(PRM, wk_w) / 8 + h]);
+    gcptr bk = uniptr(ptab[offsetof(PRM, wk_b) / 8 + h]);
+    const int n = wave * 16 + lr;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < d.dw; k0 += 16) {
+      const int kk = k0 + 4 * lq;
+      const f32x4_t b = *reinterpret_cast<gc4ptr>(wk + n * d.dw + kk);
+      lcptr xp = s_x + lr * Lx + kk;
+      acc = mfma4(xp[0], b[0], acc); acc = mfma4(xp[1], b[1], acc);
+      acc = mfma4(xp[2], b[2], acc); acc = mfma4(xp[3], b[3], acc);
+    }
+    const float bias = bk[n];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * lq + r;
+      if (row < d.Nc) {                 // rows >= Nc stay zero: they must not enter the max below
+        s_k[row * Lx + n] = acc[r] + bias;
+        a.kh[(size_t)(t * d.Nc + row) * HD + h * d.dw + n] = acc[r] + bias;
+      }
+    }
+  }
+  __syncthreads();
+  const float c = powf((float)d.dw, -0.25f);
+  float best = -INFINITY; int bcode = 0x7fffffff;
+  const int ntile = (d.m + 15) / 16;
+  for (int jt = wave; jt < ntile; jt += 8) {
+    const int j = jt * 16 + lr;
+    const int jc = j < d.m ? j : d.m - 1;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k0 = 0; k0 < d.dw; k0 += 16) {
+      const int kk = k0 + 4 * lq;
+      const float4 b = *reinterpret_cast<const float4*>(a.p.proj + (size_t)jc * d.dw + kk);
+      lcptr xp = s_k + lr * Lx + kk;
+      acc = mfma4(xp[0], b.x * c, acc); acc = mfma4(xp[1], b.y * c, acc);
+      acc = mfma4(xp[2], b.z * c, acc); acc = mfma4(xp[3], b.w * c, acc);
+    }
+    if (j < d.m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * lq + r;
+        if (row < d.Nc) {
+          const int code = ((t * d.Nc + row) * H + h) * 4096 + j;      // row index of the [T*Nc*H, m] view, column
+          if (kmax_better(acc[r], code, best, bcode)) { best = acc[r]; bcode = code; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int oc = __shfl_xor(bcode, off, 64);
+    if (kmax_better(ov, oc, best, bcode)) { best = ov; bcode = oc; }
+  }
+  MLHOT_LDS int* s_redi = reinterpret_cast<MLHOT_LDS int*>(s_red + 8);
+  if (lane == 0) { s_red[wave] = best; s_redi[wave] = bcode; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 8; ++w)
+      if (kmax_better(s_red[w], s_redi[w], best, bcode)) { best = s_red[w]; bcode = s_redi[w]; }
+    a.tmax[th] = best; a.targ[th] = bcode;
+  }
+}
 
 __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   extern __shared__ float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
-  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ldc = d.dw + d.dw / 4, ldd = d.dw + d.dz;
-  const int Lcat = ldpad(ldc), Lh0 = ldpad(d.h0), Lh1 = ldpad(d.h1), Lrs = ldpad(d.dw), Lkh = ldpad(H * d.dw), Lxq = ldpad(d.dw), Ly = ldpad(d.label_dim);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= d.T) { phaseA_keyhead(a, L0, blockIdx.x - d.T, tid); return; }
+  const int t = blockIdx.x;
+  const int ldc = d.dw + d.dw / 4;
+  const int Lcat = ldpad(ldc), Lh0 = ldpad(d.h0), Lh1 = ldpad(d.h1), Lrs = ldpad(d.dw), Ly = ldpad(d.label_dim);
   lptr s_cat = L0;                    // [16][Lcat]
   lptr s_h0 = s_cat + 16 * Lcat;
   lptr s_h1 = s_h0 + 16 * Lh0;
   lptr s_rs = s_h1 + 16 * Lh1;
-  lptr s_kh = s_rs + 16 * Lrs;         // [16][Lkh]
-  lptr s_xq = s_kh + 16 * Lkh;
-  lptr s_y = s_xq + 16 * Lxq;
-  lptr s_red = s_y + 16 * Ly;          // [8 waves][256] K-split partials of wg_linear; later the max reduction
+  lptr s_y = s_rs + 16 * Lrs;
+  lptr s_red = s_y + 16 * Ly;          // [8 waves][256] K-split partials of wg_linear
   using PRM = TailParams;
   lu64 ptab = reinterpret_cast<lu64>(s_red + 8 * 256);
   ptab_fill(ptab, a.p, tid);
-  const int total = 16 * (Lcat + Lh0 + Lh1 + Lrs + Lkh + Lxq + Ly) + 8 * 256;
+  const int total = 16 * (Lcat + Lh0 + Lh1 + Lrs + Ly) + 8 * 256;
   MLHOT_TSTAMP(0);
   lds_zero(L0, total, tid, 512);
   __syncthreads();
   MLHOT_TSTAMP(1);
   gptr g_cat = G(a.cat_in) + (size_t)t * d.Nc * ldc;
-  gptr g_dec = G(a.dec_in) + (size_t)t * d.Nq * ldd;
   lds_load(s_cat, Lcat, g_cat, ldc, d.Nc, d.dw, tid, 512);                       // x_ctx (encoder output)
-  lds_load(s_xq, Lxq, g_dec, ldd, d.Nq, d.dw, tid, 512);                         // x_qry
   lds_load(s_y, Ly, a.ctx_y + (size_t)t * d.Nc * d.label_dim, d.label_dim, d.Nc, d.label_dim, tid, 512);
-  {   // pc = c * P for the later phases: each task writes its slice (one workgroup doing all of it
-      // was a 16 us serial tail on the whole kernel)
+  {   // pc = c * P for the later phases: each task writes its slice
     const float c = powf((float)d.dw, -0.25f);
     const int n = d.m * d.dw, per = (n + d.T - 1) / d.T, lo = t * per, hi = lo + per < n ? lo + per : n;
     for (int i = lo + tid; i < hi; i += 512) a.pc[i] = c * a.p.proj[i];
@@ -321,97 +407,23 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   if (a.dbg & 2) return;
   // transform_y -> cat[:, dw:]
   wg_linear<8>(s_y, Ly, d.label_dim, WB1(ty_w, ty_b, d.dw / 4), d.dw / 4, ACT_NONE, s_cat + d.dw, Lcat, g_cat + d.dw, ldc, d.Nc, nullptr, wave, lane);
-  MLHOT_TSTAMP(3);
-  // Q projection only needs x_qry: issue it alongside
-  wg_linear<8>(s_xq, Lxq, d.dw, WB1(wq_w, wq_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, G(a.qh + (size_t)t * d.Nq * H * d.dw), H * d.dw, d.Nq, nullptr, wave, lane);
-  MLHOT_TSTAMP(4);
-  // K projection needs x_ctx only
-  wg_linear<8>(s_cat, Lcat, d.dw, WB1(wk_w, wk_b, d.dw), H * d.dw, ACT_NONE, s_kh, Lkh, G(a.kh + (size_t)t * d.Nc * H * d.dw), H * d.dw, d.Nc, nullptr, wave, lane);
   __syncthreads();
-  MLHOT_TSTAMP(5);
-  if (a.dbg & 4) return;
+  MLHOT_TSTAMP(3);
   wg_linear<8>(s_cat, Lcat, ldc, WB1(er_w[0], er_b[0], d.h0), d.h0, ACT_RELU, s_h0, Lh0, G(a.h0 + (size_t)t * d.Nc * d.h0), d.h0, d.Nc, nullptr, wave, lane);
   __syncthreads();
-  MLHOT_TSTAMP(6);
+  MLHOT_TSTAMP(4);
   wg_linear<8>(s_h0, Lh0, d.h0, WB1(er_w[1], er_b[1], d.h1), d.h1, ACT_RELU, s_h1, Lh1, G(a.h1 + (size_t)t * d.Nc * d.h1), d.h1, d.Nc, nullptr, wave, lane);
   __syncthreads();
-  MLHOT_TSTAMP(7);
-  wg_linear<8>(s_h1, Lh1, d.h1, WB1(er_w[2], er_b[2], d.dw), d.dw, ACT_NONE, s_rs, Lrs, G(a.rs + (size_t)t * d.Nc * d.dw), d.dw, d.Nc, s_red, wave, lane);
-  __syncthreads();
-  MLHOT_TSTAMP(8);
-  wg_linear<8>(s_rs, Lrs, d.dw, WB1(wv_w, wv_b, d.dw), H * d.dw, ACT_NONE, nullptr, 0, G(a.vh + (size_t)t * d.Nc * H * d.dw), H * d.dw, d.Nc, nullptr, wave, lane);
-  MLHOT_TSTAMP(9);
-
-  if (a.dbg & 8) return;
-  // key-stabiliser share: max over (row < Nc, head, feature j) of ddk = c * kh_h . P[j]   (fast_attention.py:97)
-  // (c * P is recomputed from proj here so this phase does not depend on task 0's pc write)
-  const int lr = lane & 15, lq = lane >> 4;
-  const float c = powf((float)d.dw, -0.25f);
-  float best = -INFINITY; int brow = 0, bcol = 0;
-  const int ntile = (d.m + 15) / 16;
-  // feature tiles round-robin over the waves; a tile's slice of c*P is loaded ONCE (dw/16 float4 per
-  // lane, all in flight together) and reused by all 8 heads (8 accumulators)
-  for (int jt = wave; jt < ntile; jt += 8) {
-    const int j = jt * 16 + lr;
-    const bool vj = j < d.m;
-    f32x4_t acc[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) acc[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k0 = 0; k0 < d.dw; k0 += 16) {
-      const int kk = k0 + 4 * lq;
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (vj) b = *reinterpret_cast<const float4*>(a.p.proj + (size_t)j * d.dw + kk);
-      b.x *= c; b.y *= c; b.z *= c; b.w *= c;
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        lcptr xp = s_kh + lr * Lkh + h * d.dw + kk;
-        acc[h] = mfma4(xp[0], b.x, acc[h]);
-        acc[h] = mfma4(xp[1], b.y, acc[h]);
-        acc[h] = mfma4(xp[2], b.z, acc[h]);
-        acc[h] = mfma4(xp[3], b.w, acc[h]);
-      }
-    }
-    if (vj) {
-#pragma unroll
-      for (int h = 0; h < H; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 4 * lq + r;
-          if (row < d.Nc) {
-            const int grow = (t * d.Nc + row) * H + h;      // row index of the [T*Nc*H, m] view
-            const float v = acc[h][r];
-            if (v > best || (v == best && (grow < brow || (grow == brow && j < bcol)))) { best = v; brow = grow; bcol = j; }
-          }
-        }
-    }
-  }
-  MLHOT_TSTAMP(10);
-  // reduce (max, first arg-max in (row, col) order) over the workgroup
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ov = __shfl_xor(best, off, 64);
-    const int orow = __shfl_xor(brow, off, 64), ocol = __shfl_xor(bcol, off, 64);
-    if (ov > best || (ov == best && (orow < brow || (orow == brow && ocol < bcol)))) { best = ov; brow = orow; bcol = ocol; }
-  }
-  __syncthreads();
-  MLHOT_LDS int* s_redi = reinterpret_cast<MLHOT_LDS int*>(s_red + 8);
-  if (lane == 0) { s_red[wave] = best; s_redi[2 * wave] = brow; s_redi[2 * wave + 1] = bcol; }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < 8; ++w) {
-      const float ov = s_red[w]; const int orow = s_redi[2 * w], ocol = s_redi[2 * w + 1];
-      if (ov > best || (ov == best && (orow < brow || (orow == brow && ocol < bcol)))) { best = ov; brow = orow; bcol = ocol; }
-    }
-    a.tmax[t] = best; a.targ[2 * t] = brow; a.targ[2 * t + 1] = bcol;
-  }
-  MLHOT_TSTAMP(11);
+  MLHOT_TSTAMP(5);
+  wg_linear<8>(s_h1, Lh1, d.h1, WB1(er_w[2], er_b[2], d.dw), d.dw, ACT_NONE, nullptr, 0, G(a.rs + (size_t)t * d.Nc * d.dw), d.dw, d.Nc, s_red, wave, lane);
+  MLHOT_TSTAMP(6);
 }
 
 __host__ inline size_t phaseA_lds_bytes(const TailDims& d) {
   const int ldc = d.dw + d.dw / 4;
-  return sizeof(float) * (16 * (ldpad(ldc) + ldpad(d.h0) + ldpad(d.h1) + ldpad(d.dw) + ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.label_dim)) + 8 * 256 +
-                          ptab_floats<TailParams>());
+  const size_t chain = 16 * (ldpad(ldc) + ldpad(d.h0) + ldpad(d.h1) + ldpad(d.dw) + ldpad(d.label_dim)) + 8 * 256;
+  const size_t keyhead = 32 * ldpad(d.dw) + 16;
+  return sizeof(float) * ((chain > keyhead ? chain : keyhead) + ptab_floats<TailParams>());
 }
 
 // ==================================================================================================
@@ -421,9 +433,11 @@ __host__ inline size_t phaseA_lds_bytes(const TailDims& d) {
 // Fills the same workspace fields as the generic path (qf, kf, S, D, arg_q, gmax, gpos).
 // ==================================================================================================
 struct PhaseBArgs {
-  TailDims d;
-  const float *qh, *kh, *vh, *pc;          // [T*N][H*dw] rows, pc [m][dw]
-  const float* tmax; const int* targ;      // per-task key max shares
+  TailDims d; TailParams p;
+  const float *dec_in, *rs;                // x_qry = dec_in[:, :dw] (row stride dw + dz), rs [T*Nc][dw]
+  float *qh, *vh;                          // [T*N][H*dw] rows: written here (saved for the backward)
+  const float *kh, *pc;                    // kh from phase A's key-head blocks, pc [m][dw]
+  const float* tmax; const int* targ;      // per (task, head) key max shares
   float *qf, *kf, *S, *D, *gmax; int *arg_q, *gpos;
   float* merged;                           // [T*Nq][dw*H], column e*H + h
 };
@@ -444,20 +458,74 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   lptr s_S = s_kf + 16 * Lf;         // [4 waves][16][17] partials, then final in wave 0's slot
   lptr s_st = s_S + 4 * 16 * 17;     // diag_q[16], diag_k[16], max_q[16], D[16]
   MLHOT_LDS int* s_arg = reinterpret_cast<MLHOT_LDS int*>(s_st + 64);   // arg_q[16]
-  const int total = 16 * (3 * Lx + 2 * Lf) + 4 * 16 * 17 + 64 + 16;
+  lptr s_xq = s_st + 64 + 16;        // [16][Lx] x_qry
+  lptr s_rs = s_xq + 16 * Lx;        // [16][Lx] rs
+  const int total = 16 * (5 * Lx + 2 * Lf) + 4 * 16 * 17 + 64 + 16;
   lds_zero(L0, total, tid, 256);
   __syncthreads();
   MLHOT_TSTAMP(33);
   const int HD = H * d.dw;
-  lds_load(s_q, Lx, a.qh + (size_t)t * d.Nq * HD + h * d.dw, HD, d.Nq, d.dw, tid, 256);
+  lds_load(s_xq, Lx, a.dec_in + (size_t)t * d.Nq * (d.dw + d.dz), d.dw + d.dz, d.Nq, d.dw, tid, 256);
+  lds_load(s_rs, Lx, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, d.dw, tid, 256);
   lds_load(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
-  lds_load(s_v, Lx, a.vh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
-  // batch-global key stabiliser (identical in every workgroup: first maximum in task order)
-  float gm = a.tmax[0]; int gt = 0;
-  for (int i = 1; i < d.T; ++i) if (a.tmax[i] > gm) { gm = a.tmax[i]; gt = i; }
-  if (blockIdx.x == 0 && tid == 0) { a.gmax[0] = gm; a.gpos[0] = a.targ[2 * gt]; a.gpos[1] = a.targ[2 * gt + 1]; }
+  // batch-global key stabiliser (identical in every workgroup): largest share, first position on ties
+  float gm = -INFINITY; int gcode = 0x7fffffff;
+  for (int i = tid; i < d.T * H; i += 256) {
+    const float v = a.tmax[i]; const int cd = a.targ[i];
+    if (kmax_better(v, cd, gm, gcode)) { gm = v; gcode = cd; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(gm, off, 64);
+    const int oc = __shfl_xor(gcode, off, 64);
+    if (kmax_better(ov, oc, gm, gcode)) { gm = ov; gcode = oc; }
+  }
+  if (lane == 0) { s_st[wave] = gm; s_arg[wave] = gcode; }
+  __syncthreads();
+  gm = s_st[0]; gcode = s_arg[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (kmax_better(s_st[w], s_arg[w], gm, gcode)) { gm = s_st[w]; gcode = s_arg[w]; }
+  if (blockIdx.x == 0 && tid == 0) { a.gmax[0] = gm; a.gpos[0] = gcode >> 12; a.gpos[1] = gcode & 4095; }
   __syncthreads();
   MLHOT_TSTAMP(34);
+  // this head's query and value projections: qh = W_q,h(x_qry), vh = W_v,h(rs); one 16-column tile per wave and trip
+  {
+    const float *wq = a.p.wq_w[0], *bq = a.p.wq_b[0], *wv = a.p.wv_w[0], *bv = a.p.wv_b[0];
+#pragma unroll
+    for (int i = 1; i < H; ++i)
+      if (h == i) { wq = a.p.wq_w[i]; bq = a.p.wq_b[i]; wv = a.p.wv_w[i]; bv = a.p.wv_b[i]; }
+    for (int nt = wave; nt * 16 < d.dw; nt += 4) {
+      const int n = nt * 16 + lr;
+      f32x4_t accq = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int k0 = 0; k0 < d.dw; k0 += 16) {
+        const int kk = k0 + 4 * lq;
+        const float4 b1 = *reinterpret_cast<const float4*>(wq + (size_t)n * d.dw + kk);
+        const float4 b2 = *reinterpret_cast<const float4*>(wv + (size_t)n * d.dw + kk);
+        lcptr x1 = s_xq + lr * Lx + kk;
+        lcptr x2 = s_rs + lr * Lx + kk;
+        accq = mfma4(x1[0], b1.x, accq); accv = mfma4(x2[0], b2.x, accv);
+        accq = mfma4(x1[1], b1.y, accq); accv = mfma4(x2[1], b2.y, accv);
+        accq = mfma4(x1[2], b1.z, accq); accv = mfma4(x2[2], b2.z, accv);
+        accq = mfma4(x1[3], b1.w, accq); accv = mfma4(x2[3], b2.w, accv);
+      }
+      const float biasq = bq[n], biasv = bv[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * lq + r;
+        if (row < d.Nq) {
+          s_q[row * Lx + n] = accq[r] + biasq;
+          a.qh[(size_t)(t * d.Nq + row) * HD + h * d.dw + n] = accq[r] + biasq;
+        }
+        if (row < d.Nc) {
+          s_v[row * Lx + n] = accv[r] + biasv;
+          a.vh[(size_t)(t * d.Nc + row) * HD + h * d.dw + n] = accv[r] + biasv;
+        }
+      }
+    }
+  }
+  __syncthreads();
   // dd tiles: q and k against pc; a feature tile's pc slice is loaded once (all float4 in flight
   // together) and feeds both the query and the key accumulator
   const int ntile = (d.m + 15) / 16;
@@ -578,7 +646,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
 }
 
 __host__ inline size_t phaseB_lds_bytes(const TailDims& d) {
-  return sizeof(float) * (16 * (3 * ldpad(d.dw) + 2 * ldpad(d.m)) + 4 * 16 * 17 + 64 + 16);
+  return sizeof(float) * (16 * (5 * ldpad(d.dw) + 2 * ldpad(d.m)) + 4 * 16 * 17 + 64 + 16);
 }
 
 // ==================================================================================================
@@ -894,12 +962,16 @@ __host__ inline size_t phaseC_bwd_lds_bytes(const TailDims& d) {
 
 // ==================================================================================================
 // phase B backward, one workgroup per (task, head): FAVOR+ backward (S-form, see favor.h).
-//   out: dqh / dkh (without the global arg-max correction) / dvh, part_k[t*H+h] = sum of rsum_k
+// followed, still per head, by the backward of this head's three projections: dq / dk / dv never leave LDS.
+//   out: slab entries of W_q,h / W_k,h / W_v,h (weight + bias gradients, dk WITHOUT the batch-global arg-max
+//        correction, which phase A applies as a rank-1 fix-up), the head's shares pxq / pxc / prs
+//        [T*H][N][dw] of d x_qry / d x_ctx / d rs, and part_k[t*H+h] = sum of rsum_k
 // ==================================================================================================
 struct PhaseBBwdArgs {
-  TailDims d;
+  TailDims d; TailParams p; TailSlab sl;
   const float *qh, *kh, *vh, *pc, *qf, *kf, *S, *D, *merged, *d_merged; const int* arg_q;
-  float *dqh, *dkh, *dvh, *part_k;
+  const float *dec_in, *cat_in, *rs;       // x_qry = dec_in[:, :dw], x_ctx = cat_in[:, :dw]
+  float *pxq, *pxc, *prs, *part_k, *slab;
 };
 
 __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) {
@@ -921,13 +993,22 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   lptr s_S = s_gk + 16 * Lf;         // [16][17]  S / D
   lptr s_dS = s_S + 16 * 17;         // [16][17]
   lptr s_st = s_dS + 16 * 17;        // wv[16], D[16], rsum_q[16], rsum_k[16]
-  const int total = 16 * (4 * Lx + 4 * Lf) + 2 * 16 * 17 + 64;
+  lptr s_xq = s_st + 64;             // [16][Lx] projection inputs ...
+  lptr s_xc = s_xq + 16 * Lx;
+  lptr s_rs = s_xc + 16 * Lx;
+  lptr s_dq = s_rs + 16 * Lx;        // ... and head-space gradients
+  lptr s_dk = s_dq + 16 * Lx;
+  lptr s_dv = s_dk + 16 * Lx;
+  const int total = 16 * (10 * Lx + 4 * Lf) + 2 * 16 * 17 + 64;
   lds_zero(L0, total, tid, 256);
   __syncthreads();
   MLHOT_TSTAMP(129);
   lds_load(s_q, Lx, a.qh + (size_t)t * d.Nq * HD + h * d.dw, HD, d.Nq, d.dw, tid, 256);
   lds_load(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
   lds_load(s_v, Lx, a.vh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
+  lds_load(s_xq, Lx, a.dec_in + (size_t)t * d.Nq * (d.dw + d.dz), d.dw + d.dz, d.Nq, d.dw, tid, 256);
+  lds_load(s_xc, Lx, a.cat_in + (size_t)t * d.Nc * (d.dw + d.dw / 4), d.dw + d.dw / 4, d.Nc, d.dw, tid, 256);
+  lds_load(s_rs, Lx, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, d.dw, tid, 256);
   for (int i = tid; i < d.Nq * d.m; i += 256) {
     const int row = i / d.m, j = i % d.m;
     s_qf[row * Lf + j] = a.qf[((size_t)(t * d.Nq + row) * H + h) * d.m + j];
@@ -982,7 +1063,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int np = 4 * lq + r;
-      if (np < d.Nc) a.dvh[(size_t)(t * d.Nc + np) * HD + h * d.dw + et * 16 + lr] = acc[r];
+      s_dv[np * Lx + et * 16 + lr] = np < d.Nc ? acc[r] : 0.f;
     }
   }
   // G = dF (.) E with dQ' = dS (Ek + re), dK' = dS^T (Eq + re): feature tiles over the waves
@@ -1028,45 +1109,114 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   }
   __syncthreads();
   MLHOT_TSTAMP(135);
-  // dx[row][e] = sum_j d(dd)[row][j] pc[j][e] - rsum[row] c^2 x[row][e]: waves 0,1 -> q (e tiles 0..), 2,3 -> k
+  // dx[row][e] = sum_j d(dd)[row][j] pc[j][e] - rsum[row] c^2 x[row][e].  A wave owns an e tile for BOTH the
+  // query and the key rows (they share the pc operand), 16 k-steps of pc loads in flight per trip.
   {
     const float c2 = 1.0f / sqrtf((float)d.dw);
     const int net = d.dw / 16;
-    for (int it = wave; it < 2 * net; it += 4) {
-      const int isk = it >= net, et = isk ? it - net : it;
-      lcptr g = isk ? s_gk : s_gq;
-      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int j0 = 0; j0 < d.m; j0 += 4) {
-        const int j = j0 + lq;
-        const float bv = j < d.m ? a.pc[(size_t)j * d.dw + et * 16 + lr] : 0.f;
-        acc = mfma4(g[lr * Lf + j], bv, acc);
+    for (int et = wave; et < net; et += 4) {
+      f32x4_t accq = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
+      const float* pcol = a.pc + et * 16 + lr;
+      for (int j0 = 0; j0 < d.m; j0 += 64) {
+        float bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = j0 + 4 * u + lq;
+          const float v = pcol[(size_t)(j < d.m ? j : d.m - 1) * d.dw];
+          bv[u] = j < d.m ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (j0 + 4 * u < d.m) {
+            const int j = j0 + 4 * u + lq;
+            accq = mfma4(s_gq[lr * Lf + j], bv[u], accq);
+            acck = mfma4(s_gk[lr * Lf + j], bv[u], acck);
+          }
+        }
       }
-      lcptr xs = isk ? s_k : s_q;
-      float* dst = isk ? a.dkh : a.dqh;
-      const int nrows = isk ? d.Nc : d.Nq;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * lq + r, e = et * 16 + lr;
-        if (row < nrows)
-          dst[(size_t)(t * nrows + row) * HD + h * d.dw + e] = acc[r] - s_st[32 + (isk ? 16 : 0) + row] * c2 * xs[row * Lx + e];
+        s_dq[row * Lx + e] = row < d.Nq ? accq[r] - s_st[32 + row] * c2 * s_q[row * Lx + e] : 0.f;
+        s_dk[row * Lx + e] = row < d.Nc ? acck[r] - s_st[48 + row] * c2 * s_k[row * Lx + e] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- this head's W_q / W_k / W_v backward ------------------------------------------------------
+  {
+    const float *wq = a.p.wq_w[0], *wk = a.p.wk_w[0], *wv = a.p.wv_w[0];
+#pragma unroll
+    for (int i = 1; i < H; ++i)
+      if (h == i) { wq = a.p.wq_w[i]; wk = a.p.wk_w[i]; wv = a.p.wv_w[i]; }
+    float* sl = a.slab + (size_t)t * a.sl.total;
+    const int nt = d.dw / 16, ww = d.dw * d.dw;
+    // weight gradients dW[n][i] = sum_row dY[row][n] X[row][i]: 3 nt^2 tiles of 4 MFMAs over the waves
+    for (int it = wave; it < 3 * nt * nt; it += 4) {
+      const int pj = it / (nt * nt), rem = it - pj * nt * nt, j0 = (rem / nt) * 16, i0 = (rem % nt) * 16;
+      lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
+      lcptr x = pj == 0 ? s_xq : pj == 1 ? s_xc : s_rs;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(dy[(4 * s4 + lq) * Lx + j0 + lr], x[(4 * s4 + lq) * Lx + i0 + lr], acc);
+      float* dst = sl + (pj == 0 ? a.sl.wq_w : pj == 1 ? a.sl.wk_w : a.sl.wv_w) + h * ww;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(j0 + 4 * lq + r) * d.dw + i0 + lr] = acc[r];
+    }
+    // bias gradients: column sums
+    for (int i = tid; i < 3 * d.dw; i += 256) {
+      const int pj = i / d.dw, n = i - pj * d.dw;
+      lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
+      float sum = 0.f;
+#pragma unroll
+      for (int row = 0; row < 16; ++row) sum += dy[row * Lx + n];
+      sl[(pj == 0 ? a.sl.wq_b : pj == 1 ? a.sl.wk_b : a.sl.wv_b) + h * d.dw + n] = sum;
+    }
+    // input-gradient shares P[16][dw] = dY[16][dw] W_h[dw][dw]: 3 nt tiles, 16 weight loads in flight per trip
+    for (int it = wave; it < 3 * nt; it += 4) {
+      const int pj = it / nt, i0 = (it - pj * nt) * 16;
+      lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
+      const float* wsel = (pj == 0 ? wq : pj == 1 ? wk : wv) + i0 + lr;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      for (int j0 = 0; j0 < d.dw; j0 += 64) {
+        float bw[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = j0 + 4 * (u >> 2) * 4 + 4 * lq + (u & 3);        // k-step u >> 2, element u & 3
+          bw[u] = wsel[(size_t)(j < d.dw ? j : d.dw - 1) * d.dw];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (j0 + 16 * ks < d.dw) {
+            lcptr ap = dy + lr * Lx + j0 + 16 * ks + 4 * lq;
+            acc = mfma4(ap[0], bw[4 * ks], acc); acc = mfma4(ap[1], bw[4 * ks + 1], acc);
+            acc = mfma4(ap[2], bw[4 * ks + 2], acc); acc = mfma4(ap[3], bw[4 * ks + 3], acc);
+          }
+        }
+      }
+      float* dst = pj == 0 ? a.pxq : pj == 1 ? a.pxc : a.prs;
+      const int nrows = pj == 0 ? d.Nq : d.Nc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * lq + r;
+        if (row < nrows) dst[((size_t)(t * H + h) * nrows + row) * d.dw + i0 + lr] = acc[r];
       }
     }
   }
   MLHOT_TSTAMP(136);
 }
 __host__ inline size_t phaseB_bwd_lds_bytes(const TailDims& d) {
-  return sizeof(float) * (16 * (4 * ldpad(d.dw) + 4 * ldpad(d.m)) + 2 * 16 * 17 + 64);
+  return sizeof(float) * (16 * (10 * ldpad(d.dw) + 4 * ldpad(d.m)) + 2 * 16 * 17 + 64);
 }
 
 // ==================================================================================================
-// phase A backward, one workgroup per task: global key arg-max correction, W_q / W_v / W_k backward,
-// EncoderFC backward, transform_y weight gradient.
+// phase A backward, one workgroup per task: sums the 8 heads' input-gradient shares from phase B,
+// applies the batch-global key arg-max correction, EncoderFC backward, transform_y weight gradient.
 //   out: d_dec_in[:, :dw] += d x_qry (attention share), d_cat_in, slab entries
 // ==================================================================================================
 struct PhaseABwdArgs {
   TailDims d; TailParams p; TailSlab sl;
-  const float *ctx_y, *cat_in, *h0, *h1, *rs, *dec_in, *dqh, *dkh, *dvh, *pc, *part_k; const int* gpos;
+  const float *ctx_y, *cat_in, *h0, *h1, *pxq, *pxc, *prs, *pc, *part_k; const int* gpos;
   float *d_dec_in, *d_cat_in, *slab;
 };
 
@@ -1075,95 +1225,100 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ldc = d.dw + d.dw / 4, ldd = d.dw + d.dz, HD = H * d.dw;
-  const int Lcat = ldpad(ldc), Lh0 = ldpad(d.h0), Lh1 = ldpad(d.h1), Lw = ldpad(d.dw), Lhd = ldpad(HD), Ly = ldpad(d.label_dim);
+  const int ldc = d.dw + d.dw / 4, ldd = d.dw + d.dz;
+  const int Lcat = ldpad(ldc), Lh0 = ldpad(d.h0), Lh1 = ldpad(d.h1), Lw = ldpad(d.dw), Ly = ldpad(d.label_dim);
   lptr s_cat = L0;                  // saved activations
   lptr s_h0 = s_cat + 16 * Lcat;
   lptr s_h1 = s_h0 + 16 * Lh0;
-  lptr s_rs = s_h1 + 16 * Lh1;
-  lptr s_xq = s_rs + 16 * Lw;
-  lptr s_y = s_xq + 16 * Lw;
-  lptr s_dq = s_y + 16 * Ly;         // [16][Lhd] head-space gradients (one buffer, reused q -> v -> k)
-  lptr s_drs = s_dq + 16 * Lhd;      // gradients
+  lptr s_y = s_h1 + 16 * Lh1;
+  lptr s_drs = s_y + 16 * Ly;       // gradients
   lptr s_dxc = s_drs + 16 * Lw;
   lptr s_dh1 = s_dxc + 16 * Lw;
   lptr s_dh0 = s_dh1 + 16 * Lh1;
   lptr s_dcat = s_dh0 + 16 * Lh0;
-  lptr s_red = s_dcat + 16 * Lcat;   // [8 waves][256] partial tiles of wg_dgrad
+  lptr s_red = s_dcat + 16 * Lcat;   // [8 waves][256] partial tiles of wg_dgrad; first the correction vector
   using PRM = TailParams;
   lu64 ptab = reinterpret_cast<lu64>(s_red + 8 * 256);
   ptab_fill(ptab, a.p, tid);
   MLHOT_TSTAMP(160);
-  lds_zero(L0, 16 * (2 * Lcat + 2 * Lh0 + 2 * Lh1 + 4 * Lw + Ly + Lhd), tid, 512);
+  lds_zero(L0, 16 * (2 * Lcat + 2 * Lh0 + 2 * Lh1 + 2 * Lw + Ly), tid, 512);
   __syncthreads();
   MLHOT_TSTAMP(161);
   const size_t rc = (size_t)t * d.Nc, rq = (size_t)t * d.Nq;
   lds_load(s_cat, Lcat, a.cat_in + rc * ldc, ldc, d.Nc, ldc, tid, 512);
   lds_load(s_h0, Lh0, a.h0 + rc * d.h0, d.h0, d.Nc, d.h0, tid, 512);
   lds_load(s_h1, Lh1, a.h1 + rc * d.h1, d.h1, d.Nc, d.h1, tid, 512);
-  lds_load(s_rs, Lw, a.rs + rc * d.dw, d.dw, d.Nc, d.dw, tid, 512);
-  lds_load(s_xq, Lw, a.dec_in + rq * ldd, ldd, d.Nq, d.dw, tid, 512);
   lds_load(s_y, Ly, a.ctx_y + rc * d.label_dim, d.label_dim, d.Nc, d.label_dim, tid, 512);
-  lds_load(s_dq, Lhd, a.dqh + rq * HD, HD, d.Nq, HD, tid, 512);
+  // sum the heads' shares (fixed order): d rs, the K-projection share of d x_ctx, the attention share of d x_qry
+  for (int i = tid; i < d.Nc * d.dw; i += 512) {
+    const int row = i / d.dw, e = i - row * d.dw;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      s1 += a.prs[((size_t)(t * H + h) * d.Nc + row) * d.dw + e];
+      s2 += a.pxc[((size_t)(t * H + h) * d.Nc + row) * d.dw + e];
+    }
+    s_drs[row * Lw + e] = s1;
+    s_dxc[row * Lw + e] = s2;
+  }
+  for (int i = tid; i < d.Nq * d.dw; i += 512) {
+    const int row = i / d.dw, e = i - row * d.dw;
+    float s1 = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) s1 += a.pxq[((size_t)(t * H + h) * d.Nq + row) * d.dw + e];
+    a.d_dec_in[(rq + row) * ldd + e] += s1;
+  }
   gptr sl = G(a.slab) + (size_t)t * a.sl.total;
+  // The batch-global key arg-max: that ONE element's d(dd) carries minus the sum of G over every key row
+  // of the batch (fast_attention.py:97), i.e. dk[row n, head hh] += delta, delta = -total * pc[col].  Phase B
+  // ran W_k,hh's backward without it; it enters linearly, so it is added here as a rank-1 fix-up:
+  //   dW_k,hh += delta (x) x_ctx[n],  db_k,hh += delta,  d x_ctx[n] += delta . W_k,hh
+  const int grow = a.gpos[0], gcol = a.gpos[1];
+  const bool fix = grow / (d.Nc * H) == t;
+  const int fn = (grow / H) % d.Nc, fh = grow % H;
+  if (fix && tid < d.dw) {
+    float total = 0.f;
+    for (int i = 0; i < d.T * H; ++i) total += a.part_k[i];
+    s_red[tid] = -total * a.pc[(size_t)gcol * d.dw + tid];
+  }
   __syncthreads();
   MLHOT_TSTAMP(162);
-  // W_q: weight gradient and the attention share of d x_qry (accumulated onto the decoder's)
-  wg_wgrad<8>(s_dq, Lhd, HD, s_xq, Lw, d.dw, sl + a.sl.wq_w, sl + a.sl.wq_b, wave, lane, tid);
-  MLHOT_TSTAMP(163);
-  wg_dgrad<8>(s_dq, Lhd, HD, WB1N(wq_w, d.dw), d.dw, nullptr, 0, G(a.d_dec_in + rq * ldd), ldd, d.Nq, true, s_red, wave, lane);
-  __syncthreads();
-  MLHOT_TSTAMP(164);
-  // W_v
-  lds_zero(s_dq, 16 * Lhd, tid, 512);
-  __syncthreads();
-  lds_load(s_dq, Lhd, a.dvh + rc * HD, HD, d.Nc, HD, tid, 512);
-  __syncthreads();
-  MLHOT_TSTAMP(165);
-  wg_wgrad<8>(s_dq, Lhd, HD, s_rs, Lw, d.dw, sl + a.sl.wv_w, sl + a.sl.wv_b, wave, lane, tid);
-  MLHOT_TSTAMP(166);
-  wg_dgrad<8>(s_dq, Lhd, HD, WB1N(wv_w, d.dw), d.dw, s_drs, Lw, nullptr, 0, 0, false, s_red, wave, lane);
-  __syncthreads();
-  MLHOT_TSTAMP(167);
-  // W_k, with the batch-global key arg-max correction: that ONE element's d(dd) carries minus the
-  // sum of G over every key row of the batch (fast_attention.py:97), i.e. dk[row] -= total * pc[col]
-  lds_zero(s_dq, 16 * Lhd, tid, 512);
-  __syncthreads();
-  lds_load(s_dq, Lhd, a.dkh + rc * HD, HD, d.Nc, HD, tid, 512);
-  __syncthreads();
-  {
-    const int grow = a.gpos[0], gcol = a.gpos[1];
-    const int gt = grow / (d.Nc * H);
-    if (gt == t && tid < d.dw) {
-      float total = 0.f;
-      for (int i = 0; i < d.T * H; ++i) total += a.part_k[i];
-      const int n = (grow / H) % d.Nc, hh = grow % H;
-      s_dq[n * Lhd + hh * d.dw + tid] -= total * a.pc[(size_t)gcol * d.dw + tid];
+  if (fix) {
+    const float* wk = a.p.wk_w[0];
+#pragma unroll
+    for (int i = 1; i < H; ++i)
+      if (fh == i) wk = a.p.wk_w[i];
+    gptr gw = sl + a.sl.wk_w + fh * d.dw * d.dw;
+    for (int i = tid; i < d.dw * d.dw; i += 512) {
+      const int e = i / d.dw, c = i - e * d.dw;
+      gw[i] += s_red[e] * s_cat[fn * Lcat + c];
+    }
+    if (tid < d.dw) {
+      sl[a.sl.wk_b + fh * d.dw + tid] += s_red[tid];
+      float acc = 0.f;
+      for (int e = 0; e < d.dw; ++e) acc += s_red[e] * wk[(size_t)e * d.dw + tid];
+      s_dxc[fn * Lw + tid] += acc;
     }
   }
   __syncthreads();
-  MLHOT_TSTAMP(168);
-  wg_wgrad<8>(s_dq, Lhd, HD, s_cat, Lcat, d.dw, sl + a.sl.wk_w, sl + a.sl.wk_b, wave, lane, tid);
-  MLHOT_TSTAMP(169);
-  wg_dgrad<8>(s_dq, Lhd, HD, WB1N(wk_w, d.dw), d.dw, s_dxc, Lw, nullptr, 0, 0, false, s_red, wave, lane);
-  MLHOT_TSTAMP(170);
+  MLHOT_TSTAMP(163);
   // EncoderFC, last layer first
   wg_wgrad<8>(s_drs, Lw, d.dw, s_h1, Lh1, d.h1, sl + a.sl.er_w[2], sl + a.sl.er_b[2], wave, lane, tid);
   wg_dgrad<8>(s_drs, Lw, d.dw, WB1N(er_w[2], d.dw), d.h1, s_dh1, Lh1, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
-  MLHOT_TSTAMP(171);
+  MLHOT_TSTAMP(164);
   lds_actgrad(s_dh1, Lh1, s_h1, Lh1, d.h1, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dh1, Lh1, d.h1, s_h0, Lh0, d.h0, sl + a.sl.er_w[1], sl + a.sl.er_b[1], wave, lane, tid);
   wg_dgrad<8>(s_dh1, Lh1, d.h1, WB1N(er_w[1], d.h1), d.h0, s_dh0, Lh0, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
-  MLHOT_TSTAMP(172);
+  MLHOT_TSTAMP(165);
   lds_actgrad(s_dh0, Lh0, s_h0, Lh0, d.h0, ACT_RELU, tid, 512);
   __syncthreads();
   wg_wgrad<8>(s_dh0, Lh0, d.h0, s_cat, Lcat, ldc, sl + a.sl.er_w[0], sl + a.sl.er_b[0], wave, lane, tid);
   wg_dgrad<8>(s_dh0, Lh0, d.h0, WB1N(er_w[0], d.h0), ldc, s_dcat, Lcat, nullptr, 0, 0, false, s_red, wave, lane);
   __syncthreads();
-  MLHOT_TSTAMP(173);
+  MLHOT_TSTAMP(166);
   // d_cat_in = EncoderFC input gradient (+ K-projection share on the x_ctx columns)
   for (int i = tid; i < d.Nc * ldc; i += 512) {
     const int r = i / ldc, c = i % ldc;
@@ -1171,11 +1326,11 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   }
   // transform_y: dW = d_cat[:, dw:]^T ctx_y, db
   wg_wgrad<8>(s_dcat + d.dw, Lcat, d.dw / 4, s_y, Ly, d.label_dim, sl + a.sl.ty_w, sl + a.sl.ty_b, wave, lane, tid);
-  MLHOT_TSTAMP(174);
+  MLHOT_TSTAMP(167);
 }
 __host__ inline size_t phaseA_bwd_lds_bytes(const TailDims& d) {
   const int ldc = d.dw + d.dw / 4;
-  return sizeof(float) * (16 * (2 * ldpad(ldc) + 2 * ldpad(d.h0) + 2 * ldpad(d.h1) + 4 * ldpad(d.dw) + ldpad(d.label_dim) + ldpad(H * d.dw)) + 8 * 256 +
+  return sizeof(float) * (16 * (2 * ldpad(ldc) + 2 * ldpad(d.h0) + 2 * ldpad(d.h1) + 2 * ldpad(d.dw) + ldpad(d.label_dim)) + 8 * 256 +
                           ptab_floats<TailParams>());
 }
 
