@@ -247,13 +247,75 @@ __device__ __forceinline__ void lds_zero(lptr p, int n, int tid, int nthreads) {
   for (int i = tid; i < n; i += nthreads) p[i] = 0.f;
 }
 // global [nrows x width] (row stride ldg) -> LDS [16 x ld] (rows >= nrows left as they are)
+// A wave walks whole rows (no division per element, coalesced), 4 rows x 4 column chunks = up to 16 loads in
+// flight per lane before the first LDS store; out-of-range slots load a clamped address and are not stored.
+// cstride: distance between consecutive columns in the source (1 = dense rows).
 template <class SrcPtr>
-__device__ __forceinline__ void lds_load(lptr dst, int ld, SrcPtr src, int ldg, int nrows, int width, int tid, int nthreads) {
-  for (int i = tid; i < nrows * width; i += nthreads) {
-    const int r = i / width, c = i % width;
-    dst[r * ld + c] = src[(size_t)r * ldg + c];
-  }
+__device__ __forceinline__ void lds_load(lptr dst, int ld, SrcPtr src, int ldg, int nrows, int width, int tid, int nthreads, int cstride = 1) {
+  const int lane = tid & 63, nw = nthreads >> 6;
+  for (int r0 = tid >> 6; r0 < nrows; r0 += 4 * nw)
+    for (int c0 = lane; c0 < width; c0 += 256) {
+      float v[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + k * nw, c = c0 + 64 * u;
+          const bool ok = r < nrows && c < width;
+          v[k][u] = src[ok ? (size_t)r * ldg + (size_t)c * cstride : 0];
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + k * nw, c = c0 + 64 * u;
+          if (r < nrows && c < width) dst[r * ld + c] = v[k][u];
+        }
+    }
 }
+
+// Several tiles at once: every job's loads are issued before the first LDS store, so a kernel prologue
+// pays ONE memory round trip instead of one per tile.  The register window covers rows wave + k*nw (k < KR)
+// and columns lane + 64u (u < KU) of every job; whatever a job has beyond it goes through lds_load.
+struct LoadJob { lptr dst; int ld; const float* src; int ldg, nrows, width, cstride; };
+__device__ __forceinline__ LoadJob load_job(lptr dst, int ld, const float* src, int ldg, int nrows, int width, int cstride = 1) {
+  return LoadJob{dst, ld, src, ldg, nrows, width, cstride};
+}
+template <int NJ, int KR, int KU>
+struct LoadBatch {
+  float v[NJ][KR][KU];
+  __device__ __forceinline__ void fetch(const LoadJob (&jobs)[NJ], int tid, int nw) {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int k = 0; k < KR; ++k)
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          const int r = w + k * nw, c = lane + 64 * u;
+          const bool ok = r < jobs[j].nrows && c < jobs[j].width;
+          v[j][k][u] = jobs[j].src[ok ? (size_t)r * jobs[j].ldg + (size_t)c * jobs[j].cstride : 0];
+        }
+  }
+  __device__ __forceinline__ void stash(const LoadJob (&jobs)[NJ], int tid, int nw) {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int k = 0; k < KR; ++k)
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          const int r = w + k * nw, c = lane + 64 * u;
+          if (r < jobs[j].nrows && c < jobs[j].width) jobs[j].dst[r * jobs[j].ld + c] = v[j][k][u];
+        }
+      if (jobs[j].nrows > KR * nw || jobs[j].width > 64 * KU) {          // beyond the window (large shapes): plain loops
+        for (int r = w; r < jobs[j].nrows; r += nw)
+          for (int c = lane; c < jobs[j].width; c += 64)
+            if (r >= KR * nw || c >= 64 * KU) jobs[j].dst[r * jobs[j].ld + c] = jobs[j].src[(size_t)r * jobs[j].ldg + (size_t)c * jobs[j].cstride];
+      }
+    }
+  }
+};
 
 struct TailDims {
   int T, Nc, Nq, label_dim, y_dim, dw, dz, h0, h1, dec_h, out_act, m;
@@ -395,8 +457,14 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   __syncthreads();
   MLHOT_TSTAMP(1);
   gptr g_cat = G(a.cat_in) + (size_t)t * d.Nc * ldc;
-  lds_load(s_cat, Lcat, g_cat, ldc, d.Nc, d.dw, tid, 512);                       // x_ctx (encoder output)
-  lds_load(s_y, Ly, a.ctx_y + (size_t)t * d.Nc * d.label_dim, d.label_dim, d.Nc, d.label_dim, tid, 512);
+  {
+    const LoadJob xj[2] = {
+        load_job(s_cat, Lcat, a.cat_in + (size_t)t * d.Nc * ldc, ldc, d.Nc, d.dw),                       // x_ctx (encoder output)
+        load_job(s_y, Ly, a.ctx_y + (size_t)t * d.Nc * d.label_dim, d.label_dim, d.Nc, d.label_dim)};
+    LoadBatch<2, 2, 1> xb;
+    xb.fetch(xj, tid, 8);
+    xb.stash(xj, tid, 8);
+  }
   {   // pc = c * P for the later phases: each task writes its slice
     const float c = powf((float)d.dw, -0.25f);
     const int n = d.m * d.dw, per = (n + d.T - 1) / d.T, lo = t * per, hi = lo + per < n ? lo + per : n;
@@ -465,9 +533,15 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   __syncthreads();
   MLHOT_TSTAMP(33);
   const int HD = H * d.dw;
-  lds_load(s_xq, Lx, a.dec_in + (size_t)t * d.Nq * (d.dw + d.dz), d.dw + d.dz, d.Nq, d.dw, tid, 256);
-  lds_load(s_rs, Lx, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, d.dw, tid, 256);
-  lds_load(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
+  {
+    const LoadJob xj[3] = {
+        load_job(s_xq, Lx, a.dec_in + (size_t)t * d.Nq * (d.dw + d.dz), d.dw + d.dz, d.Nq, d.dw),
+        load_job(s_rs, Lx, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, d.dw),
+        load_job(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw)};
+    LoadBatch<3, 4, 1> xb;
+    xb.fetch(xj, tid, 4);
+    xb.stash(xj, tid, 4);
+  }
   // batch-global key stabiliser (identical in every workgroup): largest share, first position on ties
   float gm = -INFINITY; int gcode = 0x7fffffff;
   for (int i = tid; i < d.T * H; i += 256) {
@@ -578,22 +652,22 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   MLHOT_TSTAMP(36);
   // E features in place (padding columns j >= m stay exactly 0 -> they are skipped below via `re` masking)
   const float ratio = 1.0f / sqrtf((float)d.m), re = ratio * 1e-4f;
-  for (int i = tid; i < 16 * d.m; i += 256) {
-    const int row = i / d.m, j = i % d.m;
-    s_qf[row * Lf + j] = ratio * expf(s_qf[row * Lf + j] - s_st[row] - s_st[32 + row]);
-    s_kf[row * Lf + j] = ratio * expf(s_kf[row * Lf + j] - s_st[16 + row] - gm);
+  // a wave owns rows wave, wave + 4, ..: E in place, and the valid rows saved for the backward right away
+  // (rows of the [T*N*H, m] views)
+  for (int row = wave; row < 16; row += 4) {
+    const float sq = s_st[row] + s_st[32 + row], sk = s_st[16 + row] + gm;
+    float* gq = a.qf + ((size_t)(t * d.Nq + row) * H + h) * d.m;
+    float* gk = a.kf + ((size_t)(t * d.Nc + row) * H + h) * d.m;
+    for (int j = lane; j < d.m; j += 64) {
+      const float eq = ratio * expf(s_qf[row * Lf + j] - sq), ek = ratio * expf(s_kf[row * Lf + j] - sk);
+      s_qf[row * Lf + j] = eq;
+      s_kf[row * Lf + j] = ek;
+      if (row < d.Nq) gq[j] = eq;
+      if (row < d.Nc) gk[j] = ek;
+    }
   }
   __syncthreads();
   MLHOT_TSTAMP(37);
-  // save E features and arg_q for the backward (rows of the [T*N*H, m] views)
-  for (int i = tid; i < d.Nq * d.m; i += 256) {
-    const int row = i / d.m, j = i % d.m;
-    a.qf[((size_t)(t * d.Nq + row) * H + h) * d.m + j] = s_qf[row * Lf + j];
-  }
-  for (int i = tid; i < d.Nc * d.m; i += 256) {
-    const int row = i / d.m, j = i % d.m;
-    a.kf[((size_t)(t * d.Nc + row) * H + h) * d.m + j] = s_kf[row * Lf + j];
-  }
   if (tid < d.Nq) a.arg_q[(t * d.Nq + tid) * H + h] = s_arg[tid];
   // S = (Eq + re)(Ek + re)^T : M = 16 q rows, N = 16 k rows, K = m split over the 4 waves
   {
@@ -680,8 +754,16 @@ __global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
   __syncthreads();
   MLHOT_TSTAMP(65);
   gptr g_dec = G(a.dec_in) + (size_t)t * d.Nq * ldd;
-  lds_load(s_m, Lm, a.merged + (size_t)t * d.Nq * HD, HD, d.Nq, HD, tid, 512);
-  lds_load(s_dec, Ld, g_dec, ldd, d.Nq, d.dw, tid, 512);          // x_qry
+  {
+    const LoadJob mj[1] = {load_job(s_m, Lm, a.merged + (size_t)t * d.Nq * HD, HD, d.Nq, HD)};
+    const LoadJob xj[1] = {load_job(s_dec, Ld, a.dec_in + (size_t)t * d.Nq * ldd, ldd, d.Nq, d.dw)};     // x_qry
+    LoadBatch<1, 2, 8> mb;
+    LoadBatch<1, 2, 1> xb;
+    mb.fetch(mj, tid, 8);
+    xb.fetch(xj, tid, 8);
+    mb.stash(mj, tid, 8);
+    xb.stash(xj, tid, 8);
+  }
   __syncthreads();
   MLHOT_TSTAMP(66);
   wg_linear<8>(s_m, Lm, HD, WB1(wo_w, wo_b, d.dw), d.dw, ACT_NONE, s_rr, Lr, G(a.rr + (size_t)t * d.Nq * d.dw), d.dw, d.Nq, s_red, wave, lane);
@@ -845,10 +927,9 @@ __device__ __attribute__((noinline)) void wg_dgrad(lcptr dys, int ldy, int Nout,
 
 // g[row][c] *= act'(y[row][c]) on the valid columns
 __device__ __forceinline__ void lds_actgrad(lptr g, int ldg_, lcptr y, int ldy, int width, int act, int tid, int nthreads) {
-  for (int i = tid; i < 16 * width; i += nthreads) {
-    const int r = i / width, c = i % width;
-    g[r * ldg_ + c] *= act_grad_from_out(act, y[r * ldy + c]);
-  }
+  const int lane = tid & 63, nw = nthreads >> 6;
+  for (int r = tid >> 6; r < 16; r += nw)
+    for (int c = lane; c < width; c += 64) g[r * ldg_ + c] *= act_grad_from_out(act, y[r * ldy + c]);
 }
 
 // per-task gradient slab: offsets (floats) of every tail parameter, in reduce order
@@ -916,11 +997,20 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
     const int r = i / d.y_dim, c = i % d.y_dim;
     s_g[r * Ly + c] = a.dmu[(rq + r) * d.y_dim + c] * act_grad_from_out(d.out_act, a.mu[(rq + r) * d.y_dim + c]);
   }
-  lds_load(s_d2, Lh, a.d2 + rq * d.dec_h, d.dec_h, d.Nq, d.dec_h, tid, 512);
-  lds_load(s_d1, Lh, a.d1 + rq * d.dec_h, d.dec_h, d.Nq, d.dec_h, tid, 512);
-  lds_load(s_dec, Ld, a.dec_in + rq * ldd, ldd, d.Nq, ldd, tid, 512);
-  lds_load(s_rr, Lr, a.rr + rq * d.dw, d.dw, d.Nq, d.dw, tid, 512);
-  lds_load(s_m, Lm, a.merged + rq * HD, HD, d.Nq, HD, tid, 512);
+  {
+    const LoadJob xj[4] = {
+        load_job(s_d2, Lh, a.d2 + rq * d.dec_h, d.dec_h, d.Nq, d.dec_h),
+        load_job(s_d1, Lh, a.d1 + rq * d.dec_h, d.dec_h, d.Nq, d.dec_h),
+        load_job(s_dec, Ld, a.dec_in + rq * ldd, ldd, d.Nq, ldd),
+        load_job(s_rr, Lr, a.rr + rq * d.dw, d.dw, d.Nq, d.dw)};
+    const LoadJob mj[1] = {load_job(s_m, Lm, a.merged + rq * HD, HD, d.Nq, HD)};
+    LoadBatch<4, 2, 2> xb;
+    LoadBatch<1, 2, 8> mb;
+    xb.fetch(xj, tid, 8);
+    mb.fetch(mj, tid, 8);
+    xb.stash(xj, tid, 8);
+    mb.stash(mj, tid, 8);
+  }
   __syncthreads();
   MLHOT_TSTAMP(98);
   gptr sl = G(a.slab) + (size_t)t * a.sl.total;
@@ -1003,24 +1093,25 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   lds_zero(L0, total, tid, 256);
   __syncthreads();
   MLHOT_TSTAMP(129);
-  lds_load(s_q, Lx, a.qh + (size_t)t * d.Nq * HD + h * d.dw, HD, d.Nq, d.dw, tid, 256);
-  lds_load(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
-  lds_load(s_v, Lx, a.vh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw, tid, 256);
-  lds_load(s_xq, Lx, a.dec_in + (size_t)t * d.Nq * (d.dw + d.dz), d.dw + d.dz, d.Nq, d.dw, tid, 256);
-  lds_load(s_xc, Lx, a.cat_in + (size_t)t * d.Nc * (d.dw + d.dw / 4), d.dw + d.dw / 4, d.Nc, d.dw, tid, 256);
-  lds_load(s_rs, Lx, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, d.dw, tid, 256);
-  for (int i = tid; i < d.Nq * d.m; i += 256) {
-    const int row = i / d.m, j = i % d.m;
-    s_qf[row * Lf + j] = a.qf[((size_t)(t * d.Nq + row) * H + h) * d.m + j];
-  }
-  for (int i = tid; i < d.Nc * d.m; i += 256) {
-    const int row = i / d.m, j = i % d.m;
-    s_kf[row * Lf + j] = a.kf[((size_t)(t * d.Nc + row) * H + h) * d.m + j];
-  }
-  // dO[n][e] = d_merged[(t,n)][e*H + h];  wv[n] = sum_e dO * O
-  for (int i = tid; i < d.Nq * d.dw; i += 256) {
-    const int n = i / d.dw, e = i % d.dw;
-    s_do[n * Lx + e] = a.d_merged[(size_t)(t * d.Nq + n) * HD + e * H + h];
+  {
+    const LoadJob xj[7] = {
+        load_job(s_q, Lx, a.qh + (size_t)t * d.Nq * HD + h * d.dw, HD, d.Nq, d.dw),
+        load_job(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw),
+        load_job(s_v, Lx, a.vh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw),
+        load_job(s_xq, Lx, a.dec_in + (size_t)t * d.Nq * (d.dw + d.dz), d.dw + d.dz, d.Nq, d.dw),
+        load_job(s_xc, Lx, a.cat_in + (size_t)t * d.Nc * (d.dw + d.dw / 4), d.dw + d.dw / 4, d.Nc, d.dw),
+        load_job(s_rs, Lx, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, d.dw),
+        // dO[n][e] = d_merged[(t,n)][e*H + h]
+        load_job(s_do, Lx, a.d_merged + (size_t)t * d.Nq * HD + h, HD, d.Nq, d.dw, H)};
+    const LoadJob ej[2] = {
+        load_job(s_qf, Lf, a.qf + ((size_t)t * d.Nq * H + h) * d.m, H * d.m, d.Nq, d.m),
+        load_job(s_kf, Lf, a.kf + ((size_t)t * d.Nc * H + h) * d.m, H * d.m, d.Nc, d.m)};
+    LoadBatch<7, 4, 1> xb;
+    LoadBatch<2, 4, 5> eb;
+    xb.fetch(xj, tid, 4);
+    eb.fetch(ej, tid, 4);
+    xb.stash(xj, tid, 4);
+    eb.stash(ej, tid, 4);
   }
   if (tid < d.Nq) s_st[16 + tid] = a.D[((size_t)t * H + h) * d.Nq + tid];
   __syncthreads();
@@ -1245,10 +1336,16 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   __syncthreads();
   MLHOT_TSTAMP(161);
   const size_t rc = (size_t)t * d.Nc, rq = (size_t)t * d.Nq;
-  lds_load(s_cat, Lcat, a.cat_in + rc * ldc, ldc, d.Nc, ldc, tid, 512);
-  lds_load(s_h0, Lh0, a.h0 + rc * d.h0, d.h0, d.Nc, d.h0, tid, 512);
-  lds_load(s_h1, Lh1, a.h1 + rc * d.h1, d.h1, d.Nc, d.h1, tid, 512);
-  lds_load(s_y, Ly, a.ctx_y + rc * d.label_dim, d.label_dim, d.Nc, d.label_dim, tid, 512);
+  {
+    const LoadJob xj[4] = {
+        load_job(s_cat, Lcat, a.cat_in + rc * ldc, ldc, d.Nc, ldc),
+        load_job(s_h0, Lh0, a.h0 + rc * d.h0, d.h0, d.Nc, d.h0),
+        load_job(s_h1, Lh1, a.h1 + rc * d.h1, d.h1, d.Nc, d.h1),
+        load_job(s_y, Ly, a.ctx_y + rc * d.label_dim, d.label_dim, d.Nc, d.label_dim)};
+    LoadBatch<4, 2, 2> xb;
+    xb.fetch(xj, tid, 8);
+    xb.stash(xj, tid, 8);
+  }
   // sum the heads' shares (fixed order): d rs, the K-projection share of d x_ctx, the attention share of d x_qry
   for (int i = tid; i < d.Nc * d.dw; i += 512) {
     const int row = i / d.dw, e = i - row * d.dw;
@@ -1276,9 +1373,18 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   const int grow = a.gpos[0], gcol = a.gpos[1];
   const bool fix = grow / (d.Nc * H) == t;
   const int fn = (grow / H) % d.Nc, fh = grow % H;
+  {   // total = sum of part_k over every (task, head): lanes, then waves, in a fixed order
+    float pv = 0.f;
+    for (int i = tid; i < d.T * H; i += 512) pv += a.part_k[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pv += __shfl_xor(pv, off, 64);
+    if (lane == 0) s_red[1024 + wave] = pv;
+  }
+  __syncthreads();
   if (fix && tid < d.dw) {
     float total = 0.f;
-    for (int i = 0; i < d.T * H; ++i) total += a.part_k[i];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) total += s_red[1024 + w];
     s_red[tid] = -total * a.pc[(size_t)gcol * d.dw + tid];
   }
   __syncthreads();
