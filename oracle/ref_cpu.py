@@ -275,6 +275,8 @@ def resnet_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, img_agg, n_heads=8, rout
 
     if Nc:
         x_ctx = resnet_features(flat(ctx_x), p, "img_encoder.", img_agg).reshape(T, Nc, -1)
+        if "transform_y.weight" in p:      # *Distractor plugins (CNPDistractor.py:43,89 / ANPDistractor.py:46,114)
+            ctx_y = F.linear(ctx_y, p["transform_y.weight"], p["transform_y.bias"])
         h = torch.cat([x_ctx, ctx_y], dim=2)
         for i in (0, 2, 4):
             h = F.relu(F.linear(h, p[f"task_encoder.{i}.weight"], p[f"task_encoder.{i}.bias"]))
@@ -371,6 +373,59 @@ def anpmr3d_forward(p, ctx_x, ctx_y, qry_x, img_agg="reshape", n_heads=8, routes
     h = F.relu(F.linear(h, p["decoder.fc_mu.0.weight"], p["decoder.fc_mu.0.bias"]))
     h = F.relu(F.linear(h, p["decoder.fc_mu.2.weight"], p["decoder.fc_mu.2.bias"]))
     return F.linear(h, p["decoder.fc_mu.4.weight"], p["decoder.fc_mu.4.bias"]), kl
+
+
+def bbb_vanilla_encoder(img, p, prefix="encoder_w0.net."):
+    """MR twin of vanilla_encoder (ANPMR.py:40-53): the same stack with every weight and bias re-sampled
+    (layer1.conv, layer2.conv, layer3.conv, linear; weight then bias).  Returns (features, kl of the call)."""
+    kls, w = [], {}
+    for name in ("layer1.conv.", "layer2.conv.", "layer3.conv.", "linear."):
+        w[name + "w"], kw = bbb_sample(p[prefix + name + "W_mu"], p[prefix + name + "W_rho"])
+        w[name + "b"], kb = bbb_sample(p[prefix + name + "bias_mu"], p[prefix + name + "bias_rho"])
+        kls.append(kw + kb)
+    a1 = F.relu(F.conv2d(img, w["layer1.conv.w"], w["layer1.conv.b"], stride=2, padding=1))
+    a2 = F.relu(F.conv2d(a1, w["layer2.conv.w"], w["layer2.conv.b"], stride=2, padding=1))
+    a3 = F.relu(F.conv2d(F.max_pool2d(a2, 2), w["layer3.conv.w"], w["layer3.conv.b"], stride=2, padding=1))
+    return F.linear(a3.reshape(a3.shape[0], -1), w["linear.w"], w["linear.b"]), sum(kls)
+
+
+def vanilla_mr_forward(p, ctx_x, ctx_y, qry_x, agg_mode, attention, tanh):
+    """ANPMR / ANPMRShapeNet1D (attention=True: targets encoded first, ANPMR.py:183-186) and CNPMR /
+    CNPMRShapeNet1D (context first, targets last, CNPMR.py:136-166).  Returns (mu, kl of the target pass)."""
+    T, Nq = qry_x.shape[:2]
+    Nc = ctx_x.shape[1]
+    dim_w = p["encoder_w0.net.linear.W_mu"].shape[0]
+    dim_z = p["r_to_z.weight"].shape[0]
+
+    def enc(x, n):
+        f, kl_ = bbb_vanilla_encoder(x.reshape(T * n, *x.shape[2:]), p)
+        return f.reshape(T, n, dim_w), kl_
+
+    if attention:
+        x_qry, kl = enc(qry_x, Nq)
+    if Nc:
+        x_ctx, _ = enc(ctx_x, Nc)
+        ly = F.linear(ctx_y, p["transform_y.weight"], p["transform_y.bias"])
+        n_hidden = sum(1 for k_ in p if k_.startswith("encoder_r.layers.") and k_.endswith(".weight")) - 1
+        rs = encoder_fc(torch.cat([x_ctx, ly], dim=2), p, n_hidden=n_hidden)
+        if attention:
+            z = F.linear(multihead_attention(x_ctx, rs, x_qry, p), p["r_to_z.weight"], p["r_to_z.bias"])
+        else:
+            if agg_mode == "mean":
+                r = agg_mean(rs)
+            elif agg_mode == "max":
+                r = agg_max(rs)
+            elif agg_mode == "baco":
+                r, _ = agg_baco(F.linear(rs, p["rs_to_mu.weight"], p["rs_to_mu.bias"]),
+                                1e-5 + F.softplus(F.linear(rs, p["rs_to_var.weight"], p["rs_to_var.bias"])))
+            else:
+                raise TypeError(f"agg_mode {agg_mode!r} is not applicable")
+            z = F.linear(r, p["r_to_z.weight"], p["r_to_z.bias"])[:, None, :].expand(T, Nq, dim_z)
+    else:
+        z = torch.zeros(T, Nq, dim_z)
+    if not attention:
+        x_qry, kl = enc(qry_x, Nq)
+    return decoder_mlp(torch.cat([x_qry, z], dim=-1), p, tanh=tanh), kl
 
 
 # --------------------------------------------------------------------------------------

@@ -122,8 +122,28 @@ RESNET_CASES = {
     # backward on loss + 1e-7 * kl (beta of cfg/train/ANPMR_ShapeNet3D.yaml)
     "r_anpmr_shapenet3d": ("ANPMRShapeNet3D", dict(task="shapenet_3d", img_size=[64, 64, 4], tasks_per_batch=2, input_dim=4, output_dim=4,
                                                    agg_mode="attention", img_agg="reshape", seed=2578, temperature=0.07), 3, 4, 3),
+    # Distractor plugins: labels pass through transform_y = Linear(2 -> dim_w=16) (cfg/train/ANP_Distractor.yaml)
+    "r_anp_distractor": ("ANPDistractor", dict(task="distractor", img_size=[128, 128, 1], tasks_per_batch=1, input_dim=2, output_dim=2,
+                                               agg_mode="attention", img_agg="max", dim_w=16, seed=2578), 3, 2, 1),
+    "r_cnp_distractor_mean": ("CNPDistractor", dict(task="distractor", img_size=[128, 128, 1], tasks_per_batch=2, input_dim=2, output_dim=2,
+                                                    agg_mode="mean", img_agg="max", dim_w=16, seed=2578), 2, 2, 1),
     "r_cnp_shapenet3d_nc0": ("CondNeuralProcess", dict(task="shapenet_3d", img_size=[64, 64, 4], tasks_per_batch=1, input_dim=4,
                                                        output_dim=4, agg_mode="mean", img_agg="reshape", seed=2578), 0, 2, 3),
+}
+
+
+# Meta-regularised twins of the vanilla models (SURVEY.md §8a E1 "MR twin" / B1): Bayes-by-backprop vanilla encoder.
+# Same runner as the ResNet family: torch.manual_seed(99) right before the forward, backward on loss + 1e-7 * kl.
+MR1D = dict(img_size=[128, 128, 1], img_agg="", dim_w=64, n_hidden_units_r=[100, 100], dim_r=64, dim_z=64, seed=2578, temperature=0.07)
+MR_CASES = {
+    "m_anpmr_shapenet1d": ("ANPMRShapeNet1D", dict(MR1D, task="shapenet_1d", tasks_per_batch=2, input_dim=3, output_dim=2,
+                                                    agg_mode="attention"), 3, 4, 1),
+    "m_anpmr_pascal1d": ("ANPMR", dict(MR1D, task="pascal_1d", tasks_per_batch=1, input_dim=1, output_dim=1,
+                                       agg_mode="attention"), 4, 2, 1),
+    "m_cnpmr_pascal1d_max": ("CNPMR", dict(MR1D, task="pascal_1d", tasks_per_batch=2, input_dim=1, output_dim=1,
+                                           agg_mode="max"), 3, 2, 1),
+    "m_cnpmr_shapenet1d_mean": ("CNPMRShapeNet1D", dict(MR1D, task="shapenet_1d", tasks_per_batch=2, input_dim=3, output_dim=2,
+                                                         agg_mode="mean"), 2, 3, 1),
 }
 
 
@@ -347,6 +367,10 @@ def main():
             continue
         run_model_case(name, method, over, Nc, Nq, LossFunc)
     for name, (method, cfgd, Nc, Nq, C) in RESNET_CASES.items():
+        if only and name not in only:
+            continue
+        run_resnet_case(name, method, cfgd, Nc, Nq, C, LossFunc)
+    for name, (method, cfgd, Nc, Nq, C) in MR_CASES.items():
         if only and name not in only:
             continue
         run_resnet_case(name, method, cfgd, Nc, Nq, C, LossFunc)

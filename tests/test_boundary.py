@@ -59,6 +59,12 @@ def test_bad_agg_mode_raises_typeerror():
         model(cx, cy, qx)
 
 
+IN_SCOPE = {"ANP", "ANPDistractor", "ANPMR", "ANPMRShapeNet1D", "ANPMRShapeNet3D", "ANPShapeNet1D", "ANPVanillaPascal1D",
+            "CNPDistractor", "CNPMR", "CNPMRShapeNet1D", "CNPShapeNet1D", "CNPVanillaPascal1D", "CondNeuralProcess"}
+OUT_OF_SCOPE = {"FCLANP", "FCLCNPDistractor", "FCLCNPShapeNet1D", "MAMLMR", "MAMLMRShapeNet1D", "MAMLShapeNet1D", "MMAMLShapeNet1D", "VanillaMAML",
+                "SingleTaskDistractor", "SingleTaskShapeNet1D", "SingleTaskShapeNet3D"}
+
+
 def test_config_surface(tmp_path, monkeypatch):
     """configs/config.py:33-109: required / optional keys, derived img_size / input_dim / output_dim."""
     from configs.config import Config
@@ -77,6 +83,7 @@ def test_every_reference_yaml_parses(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     files = sorted(glob.glob("/root/reference/cfg/**/*.yaml", recursive=True))
     assert len(files) == 59
+    constructed = set()
     for path in files:
         with open(path, "rb") as f:
             raw = yaml.safe_load(f)
@@ -84,3 +91,13 @@ def test_every_reference_yaml_parses(tmp_path, monkeypatch):
         cfg = Config()
         cfg.set_init_values(raw, side_effects=False)
         assert cfg.method == raw["method"]
+        # train.py:41-45: the plugin lookup.  In-scope methods construct; the others fail loudly and clearly.
+        cls = getattr(importlib.import_module(f"networks.{cfg.method}"), cfg.method)
+        if cfg.method in OUT_OF_SCOPE:
+            with pytest.raises(NotImplementedError, match="not part of the MI355X hot-path build"):
+                cls(cfg)
+        else:
+            model = cls(cfg)
+            assert model.to("cpu") is model and len(list(model.parameters())) > 0
+            constructed.add(cfg.method)
+    assert constructed == IN_SCOPE

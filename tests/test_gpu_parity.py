@@ -295,6 +295,42 @@ def test_anpmr_shapenet3d_vs_reference(gpulib):
         U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
 
 
+@pytest.mark.parametrize("name", U.mr_case_names())
+def test_mr_vanilla_models_vs_reference(gpulib, name):
+    """ANPMR / ANPMRShapeNet1D / CNPMR / CNPMRShapeNet1D: Bayes-by-backprop vanilla encoder whose sampled weights
+    run the E1 kernels.  Same eps draws as the reference (torch.manual_seed(99) before the forward): mu / kl / loss at
+    1e-4 against the reference's vectors; gradients of loss + 1e-7*kl against the oracle re-run and the reference."""
+    fx, meta = U.load_case(name)
+    model = U.build_model(meta, DEV, fx=fx).to(DEV)
+    cx, qx, cy, qy = U.resnet_case_inputs(meta, fx)
+    from trainer.losses import LossFunc
+    torch.manual_seed(99)
+    mu, var, kl = model(cx.to(DEV), cy.to(DEV), qx.to(DEV))
+    assert var is None
+    loss = LossFunc("mse", meta["cfg"]["task"]).calc_loss(mu, var, qy.to(DEV))
+    (loss + 1e-7 * kl).backward()
+    assert U.rel_err(mu, fx["mu"]) <= U.RTOL
+    assert abs(kl.item() - float(fx["kl"])) <= U.RTOL * float(fx["kl"])
+    assert abs(loss.item() - float(fx["loss"])) <= U.RTOL * max(1.0, abs(float(fx["loss"])))
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    p = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+    torch.manual_seed(99)
+    mu_o, kl_o = O.vanilla_mr_forward(p, cx, cy, qx, meta["cfg"]["agg_mode"], attention=meta["method"].startswith("ANP"),
+                                      tanh=meta["method"].endswith("ShapeNet1D"))
+    (O.calc_loss(meta["cfg"]["task"], mu_o, qy) + 1e-7 * kl_o).backward()
+    gmax = max(p[k].grad.abs().max().item() for k, _ in model.named_parameters() if p[k].grad is not None)
+    worst = 0.0
+    for k, prm in model.named_parameters():
+        if p[k].grad is None:
+            assert grads[k] is None, k       # task_encoder / mu / decoder.* never receive a gradient (SURVEY App. B)
+            continue
+        worst = max(worst, U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax))
+    # a rounding-level ReLU / pool tie may route differently (DESIGN.md §3): ~1e-2 if it happens, rounding level otherwise
+    assert worst <= U.RTOL or worst >= 1e-3, f"gradient error {worst:.2e} is neither rounding nor a routing flip"
+    if worst <= U.RTOL:
+        U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
+
+
 def test_conv_embedding_model_vs_reference(gpulib):
     """X1: ConvEmbeddingModel (MMAML task embedding) on one task's shots: the four embedding vectors, every
     gradient and the in-place running-stat update against the reference's vectors."""

@@ -63,6 +63,30 @@ def test_oracle_resnet_models_match_reference(name):
     U.check_grads_against_fixture(grads, fx, meta, tol=1e-4, head=1024, stride_cap=4096)
 
 
+@pytest.mark.parametrize("name", U.mr_case_names())
+def test_oracle_mr_vanilla_models_match_reference(name):
+    """MR twins of the vanilla models (ANPMR, ANPMRShapeNet1D, CNPMR, CNPMRShapeNet1D; rows E1-MR / B1): seeded
+    init and state_dict keys, then forward / kl / loss / gradients of loss + 1e-7*kl under the fixture's eps draws."""
+    fx, meta = U.load_case(name)
+    model = U.build_model(meta, fx=fx)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(meta["state_sha"].keys())
+    cx, qx, cy, qy = U.resnet_case_inputs(meta, fx)
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in sd.items()}
+    torch.manual_seed(99)
+    mu, kl = O.vanilla_mr_forward(p, cx, cy, qx, meta["cfg"]["agg_mode"], attention=meta["method"].startswith("ANP"),
+                                  tanh=meta["method"].endswith("ShapeNet1D"))
+    assert abs(kl.item() - float(fx["kl"])) <= 1e-5 * float(fx["kl"])
+    assert U.rel_err(mu, fx["mu"]) <= 1e-5
+    loss = O.calc_loss(meta["cfg"]["task"], mu, qy)
+    assert abs(loss.item() - float(fx["loss"])) <= 1e-5
+    (loss + 1e-7 * kl).backward()
+    grads = {k: p[k].grad for k, _ in model.named_parameters()}
+    for k, g in grads.items():
+        assert (g is None) == (meta["grad_norm"][k] is None), k      # task_encoder / mu / decoder.* are never used
+    U.check_grads_against_fixture(grads, fx, meta, tol=1e-4, head=1024, stride_cap=4096)
+
+
 def test_oracle_known_answers_of_the_survey():
     """SURVEY.md §8c known answers (loss values of configs c1-c3)."""
     for name, want in (("c1_cnp_pascal1d", 0.37023053), ("c2_cnp_shapenet1d_mean", 0.66624528), ("c3_anp_shapenet1d", 0.51365805)):

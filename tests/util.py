@@ -84,6 +84,10 @@ def resnet_case_names():
     return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "r_*.npz")))
 
 
+def mr_case_names():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "m_*.npz")))
+
+
 def resnet_case_inputs(meta, fx):
     c = meta["cfg"]
     T, Nc, Nq, C = c["tasks_per_batch"], meta["Nc"], meta["Nq"], meta["C"]

@@ -1,0 +1,9 @@
+"""`networks.SingleTaskShapeNet3D` of the reference is OUTSIDE the accelerated hot path (the task-batched CNP/ANP
+forward+backward): single-task supervised baseline.  The module exists so a config naming it fails loudly and clearly."""
+from torch import nn
+
+
+class SingleTaskShapeNet3D(nn.Module):
+    def __init__(self, config=None, *args, **kwargs):
+        raise NotImplementedError("method 'SingleTaskShapeNet3D' (single-task supervised baseline) is not part of the MI355X hot-path build; "
+                                  "in scope: CNP*/ANP* (vanilla, ResNet, MR and Distractor variants) - see INTEGRATION.md")

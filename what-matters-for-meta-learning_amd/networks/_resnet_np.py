@@ -14,6 +14,7 @@ from networks.models import AttnLinear, ImageEncoder, NPDecoder, _mlp3
 
 class ResNetNP(nn.Module):
     ATTENTION = False
+    TRANSFORM_Y = False   # *Distractor classes: labels go through Linear(label_dim -> dim_w) first (CNPDistractor.py:43,89)
     N_HEADS = 8
 
     def __init__(self, config):
@@ -31,7 +32,12 @@ class ResNetNP(nn.Module):
         torch.manual_seed(config.seed)
 
         self.img_encoder = ImageEncoder(aggregate=self.img_agg, task_num=self.task_num, img_channels=self.img_channels)
-        self.task_encoder = nn.Sequential(nn.Linear(256 + self.label_dim, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+        label_width = self.label_dim
+        if self.TRANSFORM_Y:
+            self.dim_w = config.dim_w
+            self.transform_y = nn.Linear(self.label_dim, self.dim_w)
+            label_width = self.dim_w
+        self.task_encoder = nn.Sequential(nn.Linear(256 + label_width, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
                                           nn.Linear(256, 256), nn.ReLU())
         if not self.ATTENTION and self.agg_mode == "baco":
             self.latent_mu = nn.Linear(256, 256)
@@ -66,6 +72,8 @@ class ResNetNP(nn.Module):
         self.ctx_num = batch_train_images.shape[1]
         C, H, W = self.img_channels, self.img_size[0], self.img_size[1]
         if self.ctx_num:
+            if self.TRANSFORM_Y:
+                label_train = LinearFunction.apply(label_train, self.transform_y.weight, self.transform_y.bias, "none")
             x_ctx = self.img_encoder(batch_train_images.reshape(-1, C, H, W))
             feats = _mlp3(torch.cat([x_ctx, label_train], dim=2), self.task_encoder, last_relu=True)
             if self.ATTENTION:

@@ -46,7 +46,8 @@ class BBBConv2d(ModuleWrapper):
             self.bias_mu.data.normal_(*self.posterior_mu_initial)
             self.bias_rho.data.normal_(*self.posterior_rho_initial)
 
-    def forward(self, x, sample=True):
+    def sample(self):
+        """(weight, bias, kl) with the reference's draw order (weight eps, then bias eps)."""
         dev = self.W_mu.device
         w_eps = torch.empty(self.W_mu.size()).normal_(0, 1).to(dev)
         weight, kl = BBBSampleFunction.apply(self.W_mu, self.W_rho, w_eps)
@@ -56,6 +57,10 @@ class BBBConv2d(ModuleWrapper):
             bias, kl_b = BBBSampleFunction.apply(self.bias_mu, self.bias_rho, b_eps)
             kl = kl + kl_b
         self._kl = kl
+        return weight, bias, kl
+
+    def forward(self, x, sample=True):
+        weight, bias, _ = self.sample()
         return Conv2dFunction.apply(x, weight, bias, self.stride, self.padding, self.fuse_relu)
 
     def kl_loss(self):
