@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): bench lines, rocprofv3 kernel stats and HBM-traffic counters of the headline
+# workload.  Everything lands under gpurun_out/prof/; scripts/summarise_profiles.py turns it into profiles/*.
+# PMC passes are separate runs with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+set -u
+REPO=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$REPO/gpurun_out/prof
+TAG=${1:-r01_final}
+mkdir -p $OUT
+cd $REPO
+python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench_c3.json 2> $OUT/bench_c3.err
+python bench.py --steps 50 --warmup 10 --workload c2 --no-cpu-baseline > $OUT/${TAG}_bench_c2.json 2> $OUT/bench_c2.err
+MLHOT_BENCH_KERNELS=$OUT/${TAG}_kernels_c3.json python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --prof-steps 0 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --prof-steps 0 > $OUT/pmc_write.log 2>&1
+find $OUT -name "*.csv" | head -20
+ls -la $OUT

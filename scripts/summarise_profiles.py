@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof/ (scripts/collect_profiles.sh) -> profiles/<tag>_*: bench lines, rocprofv3 kernel-stats CSV and
+per-launch HBM traffic of the hot kernels (FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 tallies 128-B read
+requests at 64 B; WRITE_SIZE as read; counter unit KiB)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+
+KERNEL_LABEL = {            # kernel-name fragment -> bench.py label
+    "conv12_fwd_pool_kernel": "enc.conv12", "conv12_wgrad_kernel": "enc.bwd.conv12.wgrad", "conv12_dgrad_kernel": "enc.bwd.conv12.dgrad",
+    "conv3_fwd_kernel": "enc.conv3", "conv3_wgrad_kernel": "enc.bwd.conv3.wgrad", "conv3_dgrad_kernel": "enc.bwd.conv3.dgrad",
+}
+
+
+def find(pattern):
+    hits = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True))
+    return hits[0] if hits else None
+
+
+for name in (f"{tag}_bench_c3.json", f"{tag}_bench_c2.json", f"{tag}_kernels_c3.json"):
+    p = os.path.join(SRC, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(DST, name))
+stats = find("stats/**/*kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(DST, f"{tag}_kernel_stats.csv"))
+
+
+def pmc(dirname, counter):
+    path = find(f"{dirname}/**/*counter_collection.csv")
+    per = {}
+    if not path:
+        return per
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            kname = row.get("Kernel_Name", "")
+            for frag, label in KERNEL_LABEL.items():
+                if frag in kname:
+                    a = per.setdefault(label, [0, 0.0])
+                    a[0] += 1
+                    a[1] += float(row["Counter_Value"])
+    return {k: v[1] / v[0] for k, v in per.items()}
+
+
+fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+out = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-graph`, c3 workload, "
+                "480 images. Counter unit KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); "
+                "WRITE_SIZE as read. Bytes per launch (mean over the launches of the run)."}
+for label in sorted(set(fetch) | set(write)):
+    fb, wb = 2.0 * 1024.0 * fetch.get(label, 0.0), 1024.0 * write.get(label, 0.0)
+    out[label] = {"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb,
+                  "fetch_raw_kib": fetch.get(label), "write_raw_kib": write.get(label)}
+if len(out) > 1:
+    for name in (f"{tag}_pmc_traffic.json", "pmc_traffic.json"):
+        with open(os.path.join(DST, name), "w") as f:
+            json.dump(out, f, indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "_note"}, indent=1))
