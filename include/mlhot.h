@@ -202,6 +202,11 @@ typedef struct mlhot_np_grads {
 size_t mlhot_np_struct_bytes(int which); /* 0 dims, 1 params, 2 grads: binding self-check */
 size_t mlhot_np_saved_bytes(const mlhot_np_dims* d);
 size_t mlhot_np_scratch_bytes(const mlhot_np_dims* d);
+/* Recommended gradient layout: ONE flat fp32 buffer (what torch.optim / an all-reduce bucket want anyway,
+ * train.py:52-56).  Fills the pointer fields of `offsets` with BYTE offsets into that buffer (null for parameters the
+ * configuration does not have) and returns its size in floats.  mlhot_np_vanilla_bwd accepts any destination
+ * pointers; when they follow this layout the per-task slab reduce of the fused tails is one contiguous sum. */
+size_t mlhot_np_grads_flat_layout(const mlhot_np_dims* d, mlhot_np_grads* offsets);
 /* ctx_x[T,Nc,1,128,128], ctx_y[T,Nc,label_dim], qry_x[T,Nq,1,128,128] -> mu[T,Nq,y_dim] */
 int mlhot_np_vanilla_fwd(const mlhot_np_dims* d, const mlhot_np_params* p,
                          const float* ctx_x, const float* ctx_y, const float* qry_x, float* mu,

@@ -30,19 +30,32 @@ constexpr int CIN = 48, COUT = 64, KW = 432;
 // row lands on banks 16..30), plane stride 217 (odd: lq = 1 lands on the odd banks).
 constexpr int F_RS = 24, F_PS = 9 * F_RS + 1, F_PATCH = CIN * F_PS;
 constexpr int F_NT = 512;
+constexpr int F_WLD = KW + 1;                       // weight staging rows [co][433]: odd stride, conflict-free lane reads
+constexpr int F_LDS = 2 * F_PATCH > COUT * F_WLD ? 2 * F_PATCH : COUT * F_WLD;
 
 __global__ __launch_bounds__(F_NT) void conv3_fwd_kernel(const float* __restrict__ p2, const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ a3, int n_img) {
-  __shared__ float patch2[2 * F_PATCH];
+  __shared__ float patch2[F_LDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave & 3, mg = wave >> 2;
   const int lr = lane & 15, lq = lane >> 4;
   const int co = nt * 16 + lr;
 
+  // The register-resident weights are a stride-9 gather of the [64][432] matrix: read straight from global every
+  // wave load touches ~32 cache lines for 256 useful bytes.  Stage the matrix through LDS with coalesced float4 loads
+  // (rows padded to 433 words so the lanes of the gather hit different banks), then gather from LDS.
+  for (int i = tid; i < COUT * KW / 4; i += F_NT) {
+    const float4 v = *reinterpret_cast<const float4*>(w + 4 * i);
+    const int r = (4 * i) / KW, c = (4 * i) - r * KW;       // KW % 4 == 0: a float4 stays inside its row
+    float* d = patch2 + r * F_WLD + c;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
   float wr[108];
 #pragma unroll
-  for (int ks = 0; ks < 108; ++ks) wr[ks] = w[((size_t)co * CIN + (ks % 12) * 4 + lq) * 9 + ks / 12];
+  for (int ks = 0; ks < 108; ++ks) wr[ks] = patch2[co * F_WLD + ((ks % 12) * 4 + lq) * 9 + ks / 12];
   const float bn = bias[co];
+  __syncthreads();
 
   for (int i = tid; i < 2 * F_PATCH; i += F_NT) patch2[i] = 0.f;       // halo column 0 stays zero for good
   const int nunits = n_img * 2;

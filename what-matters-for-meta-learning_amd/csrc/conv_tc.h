@@ -843,18 +843,25 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
   }
 }
 
-// slab1 [nblocks][32][10] -> dw1 [32][9], db1 [32]
+// slab1 [nblocks][32][10] -> dw1 [32][9], db1 [32].  One workgroup per 20 outputs: 16 slab lanes x 20 columns...
+// grid = 16 workgroups of 320 threads: thread = (slab lane z = tid / 20, output e = 20 * blockIdx + tid % 20); the 16
+// lanes are folded through LDS in a fixed order (the single-block version walked all slabs serially: 18 us).
 __global__ __launch_bounds__(320) void conv1_grads_kernel(const float* __restrict__ slab1, int nblocks, float* __restrict__ dw1, float* __restrict__ db1) {
-  const int tid = threadIdx.x, c = tid / 10, q = tid % 10;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblocks; b += 4) {
-    s0 += slab1[(size_t)b * 320 + tid]; s1 += slab1[(size_t)(b + 1) * 320 + tid];
-    s2 += slab1[(size_t)(b + 2) * 320 + tid]; s3 += slab1[(size_t)(b + 3) * 320 + tid];
+  __shared__ float sm[16][20];
+  const int tid = threadIdx.x, z = tid / 20, col = tid % 20, e = blockIdx.x * 20 + col;
+  float s0 = 0.f, s1 = 0.f;
+  int b = z;
+  for (; b + 16 < nblocks; b += 32) { s0 += slab1[(size_t)b * 320 + e]; s1 += slab1[(size_t)(b + 16) * 320 + e]; }
+  for (; b < nblocks; b += 16) s0 += slab1[(size_t)b * 320 + e];
+  sm[z][col] = s0 + s1;
+  __syncthreads();
+  if (z == 0) {
+    float v = sm[0][col];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v += sm[k][col];
+    const int c = e / 10, q = e % 10;
+    if (q < 9) dw1[c * 9 + q] = v; else db1[c] = v;
   }
-  for (; b < nblocks; ++b) s0 += slab1[(size_t)b * 320 + tid];
-  const float v = (s0 + s1) + (s2 + s3);
-  if (q < 9) dw1[c * 9 + q] = v; else db1[c] = v;
 }
 
 }  // namespace c2

@@ -224,7 +224,7 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     MLHOT_TRY(check_launch("enc.bwd.conv12.dgrad"));
     {
       ProfScope ps("slab_reduce", s);
-      hipLaunchKernelGGL(c2::conv1_grads_kernel, dim3(1), dim3(320), 0, s, slab_1, grid, g.w1, g.b1);
+      hipLaunchKernelGGL(c2::conv1_grads_kernel, dim3(16), dim3(320), 0, s, slab_1, grid, g.w1, g.b1);
     }
     return check_launch("enc.bwd.conv1.grads");     // conv1's gradients came out of the dgrad kernel
   } else

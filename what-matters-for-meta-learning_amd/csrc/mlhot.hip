@@ -244,6 +244,7 @@ size_t mlhot_np_struct_bytes(int which) {
 }
 size_t mlhot_np_saved_bytes(const mlhot_np_dims* d) { return d ? np_saved_carve(*d, nullptr, 0).bytes : 0; }
 size_t mlhot_np_scratch_bytes(const mlhot_np_dims* d) { return d ? np_scratch_carve(*d, nullptr, 0).bytes : 0; }
+size_t mlhot_np_grads_flat_layout(const mlhot_np_dims* d, mlhot_np_grads* offsets) { return (d && offsets) ? np_grads_flat_layout(*d, *offsets) : 0; }
 
 int mlhot_np_vanilla_fwd(const mlhot_np_dims* d, const mlhot_np_params* p, const float* ctx_x, const float* ctx_y,
                          const float* qry_x, float* mu, void* saved, void* scratch, size_t scratch_bytes, void* stream) {

@@ -205,6 +205,20 @@ inline int cnp_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, c
   tf::CnpFwdArgs a{cd, cnp_params(p), ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.r, b.zt, b.dec_in, b.d1, b.d2, mu, b.amax};
   return tail_launch(tf::cnp_fwd_kernel, d.T, 512, tf::cnp_fwd_lds_bytes(cd), a, s, "tail.cnp");
 }
+// Per-task slabs -> parameter gradients.  When the caller laid the gradient tensors out as ONE flat buffer in slab
+// order (mlhot_np_grads_flat_layout) the reduce is a single contiguous float4 sum; otherwise every element looks up
+// its destination segment.
+inline int tail_slab_reduce(tf::SlabReduce& r, hipStream_t s) {
+  bool flat = r.nseg > 0 && r.off[0] == 0 && (reinterpret_cast<uintptr_t>(r.dst[0]) & 15) == 0 && (r.total & 3) == 0;
+  for (int i = 1; flat && i < r.nseg; ++i) flat = r.dst[i] == r.dst[0] + r.off[i];
+  {
+    ProfScope ps("tail.bwd.reduce", s);
+    if (flat) hipLaunchKernelGGL(c2::sum_parts_kernel, dim3((r.total + 63) / 64), dim3(256), 0, s, r.slab, r.T, r.total, r.dst[0]);
+    else hipLaunchKernelGGL(tf::slab_to_grads_kernel, dim3((r.total + 255) / 256), dim3(256), 0, s, r);
+  }
+  return check_launch("tail.bwd.reduce");
+}
+
 inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu, const float* dmu,
                               const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s) {
   const tf::CnpDims cd = cnp_dims(d);
@@ -226,12 +240,8 @@ inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   seg(g.dec_w[1], sl.dec_w[1], cd.dec_h * cd.dec_h); seg(g.dec_b[1], sl.dec_b[1], cd.dec_h);
   seg(g.dec_w[2], sl.dec_w[2], d.y_dim * cd.dec_h); seg(g.dec_b[2], sl.dec_b[2], d.y_dim);
   r.nseg = ns; r.T = d.T; r.total = sl.total; r.slab = sc.tail_slab;
-  {
-    ProfScope ps("tail.bwd.reduce", s);
-    (void)maxlen;
-    hipLaunchKernelGGL(tf::slab_to_grads_kernel, dim3((sl.total + 1023) / 1024), dim3(256), 0, s, r);
-  }
-  return check_launch("tail.bwd.reduce");
+  (void)maxlen;
+  return tail_slab_reduce(r, s);
 }
 
 inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu,
@@ -272,14 +282,67 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   }
   seg(g.wo_w, sl.wo_w, dw * MLHOT_HEADS * dw); seg(g.wo_b, sl.wo_b, dw);
   r.nseg = ns; r.T = d.T; r.total = sl.total; r.slab = sc.tail_slab;
-  {
-    ProfScope ps("tail.bwd.reduce", s);
-    (void)maxlen;
-    hipLaunchKernelGGL(tf::slab_to_grads_kernel, dim3((sl.total + 1023) / 1024), dim3(256), 0, s, r);
-  }
-  return check_launch("tail.bwd.reduce");
+  (void)maxlen;
+  return tail_slab_reduce(r, s);
 }
 #endif
+
+// Layout of ONE flat gradient buffer: the fused tails' parameters at their slab offsets (so the per-task slabs reduce
+// with a single contiguous sum), everything else packed behind, 4-float aligned.  `o` receives BYTE offsets in its
+// pointer fields (fields of parameters the model does not have stay null); returns the buffer size in floats.
+inline size_t np_grads_flat_layout(const mlhot_np_dims& d, mlhot_np_grads& o) {
+  memset(&o, 0, sizeof(o));
+  const int dw = d.dim_w, ldc = dw + dw / 4, ldd = dw + d.dim_z, H = MLHOT_HEADS;
+  const bool attn = d.agg_mode == MLHOT_AGG_ATTENTION, baco = d.agg_mode == MLHOT_AGG_BACO;
+  size_t next = 0;
+  auto at = [](size_t off_floats) { return reinterpret_cast<float*>(off_floats * sizeof(float)); };
+  auto take = [&](size_t n) { const size_t r = next; next += (n + 3) / 4 * 4; return at(r); };
+  bool tail_done = false;
+#ifndef MLHOT_HOSTSIM
+  if (d.Nc > 0 && tail_fused_applies(d)) {
+    const tf::TailSlab sl = tf::tail_slab_layout(tail_dims(d));
+    o.ty_w = at(sl.ty_w); o.ty_b = at(sl.ty_b);
+    for (int i = 0; i < 3; ++i) { o.er_w[i] = at(sl.er_w[i]); o.er_b[i] = at(sl.er_b[i]); o.dec_w[i] = at(sl.dec_w[i]); o.dec_b[i] = at(sl.dec_b[i]); }
+    o.r2z_w = at(sl.r2z_w); o.r2z_b = at(sl.r2z_b);
+    for (int h = 0; h < H; ++h) {
+      o.wk_w[h] = at(sl.wk_w + (size_t)h * dw * dw); o.wk_b[h] = at(sl.wk_b + (size_t)h * dw);
+      o.wv_w[h] = at(sl.wv_w + (size_t)h * dw * dw); o.wv_b[h] = at(sl.wv_b + (size_t)h * dw);
+      o.wq_w[h] = at(sl.wq_w + (size_t)h * dw * dw); o.wq_b[h] = at(sl.wq_b + (size_t)h * dw);
+    }
+    o.wo_w = at(sl.wo_w); o.wo_b = at(sl.wo_b);
+    next = sl.total; tail_done = true;
+  } else if (d.Nc > 0 && cnp_fused_applies(d)) {
+    const tf::CnpSlab sl = tf::cnp_slab_layout(cnp_dims(d));
+    o.ty_w = at(sl.ty_w); o.ty_b = at(sl.ty_b);
+    for (int i = 0; i < 3; ++i) { o.er_w[i] = at(sl.er_w[i]); o.er_b[i] = at(sl.er_b[i]); o.dec_w[i] = at(sl.dec_w[i]); o.dec_b[i] = at(sl.dec_b[i]); }
+    o.r2z_w = at(sl.r2z_w); o.r2z_b = at(sl.r2z_b);
+    next = sl.total; tail_done = true;
+  }
+#endif
+  if (!tail_done) {
+    o.ty_w = take((size_t)dw / 4 * d.label_dim); o.ty_b = take(dw / 4);
+    int in = ldc;
+    for (int i = 0; i < d.n_hidden; ++i) { o.er_w[i] = take((size_t)d.hidden[i] * in); o.er_b[i] = take(d.hidden[i]); in = d.hidden[i]; }
+    o.er_w[d.n_hidden] = take((size_t)d.dim_r * in); o.er_b[d.n_hidden] = take(d.dim_r);
+    o.r2z_w = take((size_t)d.dim_z * d.dim_r); o.r2z_b = take(d.dim_z);
+    o.dec_w[0] = take((size_t)d.dec_hidden * ldd); o.dec_b[0] = take(d.dec_hidden);
+    o.dec_w[1] = take((size_t)d.dec_hidden * d.dec_hidden); o.dec_b[1] = take(d.dec_hidden);
+    o.dec_w[2] = take((size_t)d.y_dim * d.dec_hidden); o.dec_b[2] = take(d.y_dim);
+    if (attn) {
+      for (int h = 0; h < H; ++h) {
+        o.wk_w[h] = take((size_t)dw * dw); o.wk_b[h] = take(dw); o.wv_w[h] = take((size_t)dw * dw); o.wv_b[h] = take(dw);
+        o.wq_w[h] = take((size_t)dw * dw); o.wq_b[h] = take(dw);
+      }
+      o.wo_w = take((size_t)dw * H * dw); o.wo_b = take(dw);
+    }
+  }
+  if (baco) {
+    o.mu_w = take((size_t)d.dim_r * d.dim_r); o.mu_b = take(d.dim_r); o.var_w = take((size_t)d.dim_r * d.dim_r); o.var_b = take(d.dim_r);
+  }
+  o.enc.w1 = take(32 * 9); o.enc.b1 = take(32); o.enc.w2 = take(48 * 288); o.enc.b2 = take(48);
+  o.enc.w3 = take(64 * 432); o.enc.b3 = take(64); o.enc.wl = take((size_t)dw * 4096); o.enc.bl = take(dw);
+  return next;
+}
 
 inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_x, const float* ctx_y,
                       const float* qry_x, float* mu, void* saved, void* scratch, size_t scratch_bytes, hipStream_t s) {

@@ -1446,9 +1446,8 @@ struct SlabReduce {
   float* dst[MAX_SEG]; int off[MAX_SEG]; int len[MAX_SEG];
   int nseg, T, total; const float* slab;
 };
-// One flat pass over the slab: a thread sums float4 `q` of all T task slabs (T loads in flight), finds
-// the parameter segment the float4 belongs to (segments start and end on multiples of 4 floats, so a
-// float4 never straddles two) and stores into that parameter's gradient.  grid = ceil(total / 1024).
+// One flat pass over the slab: a thread sums element `e` of all T task slabs (T coalesced loads in flight), finds the
+// parameter segment it belongs to and stores into that parameter's gradient.  grid = ceil(total / 256).
 __global__ __launch_bounds__(256) void slab_to_grads_kernel(const SlabReduce a) {
   __shared__ float* s_dst[MAX_SEG];
   __shared__ int s_off[MAX_SEG], s_len[MAX_SEG];
@@ -1461,24 +1460,16 @@ __global__ __launch_bounds__(256) void slab_to_grads_kernel(const SlabReduce a) 
     if (threadIdx.x < MAX_SEG) { s_dst[threadIdx.x] = dst; s_off[threadIdx.x] = off; s_len[threadIdx.x] = len; }
   }
   __syncthreads();
-  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= a.total) return;
+  float s0 = 0.f, s1 = 0.f;
+  int t = 0;
+  for (; t + 1 < a.T; t += 2) { s0 += a.slab[(size_t)t * a.total + e]; s1 += a.slab[(size_t)(t + 1) * a.total + e]; }
+  if (t < a.T) s0 += a.slab[(size_t)t * a.total + e];
   int seg = -1;
   for (int i = 0; i < a.nseg; ++i)
     if (e >= s_off[i] && e < s_off[i] + s_len[i]) seg = i;
-  if (seg < 0) return;                              // alignment padding between two segments
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-  for (int t = 0; t < a.T; ++t) {
-    const float4 v = *reinterpret_cast<const float4*>(a.slab + (size_t)t * a.total + e);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
-  float* d = s_dst[seg] + (e - s_off[seg]);
-  const int left = s_len[seg] - (e - s_off[seg]);   // a segment's length need not be a multiple of 4
-  d[0] = s.x;
-  if (left > 1) d[1] = s.y;
-  if (left > 2) d[2] = s.z;
-  if (left > 3) d[3] = s.w;
+  if (seg >= 0) s_dst[seg][e - s_off[seg]] = s0 + s1;      // else: alignment padding between two segments
 }
 
 }  // namespace tf

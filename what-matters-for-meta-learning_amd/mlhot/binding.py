@@ -83,6 +83,14 @@ def _set(struct, path, ptr):
         setattr(getattr(struct, path[0]), path[1], ptr)
 
 
+def _get(struct, path):
+    if len(path) == 1:
+        return getattr(struct, path[0])
+    if isinstance(path[1], int):
+        return getattr(struct, path[0])[path[1]]
+    return getattr(getattr(struct, path[0]), path[1])
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -107,7 +115,8 @@ class MlhotLib:
         c.mlhot_version.restype = C.c_int
         c.mlhot_last_error.restype = C.c_char_p
         for fn in ("mlhot_enc_vanilla_saved_bytes", "mlhot_enc_vanilla_scratch_bytes", "mlhot_linear_bwd_scratch_bytes",
-                   "mlhot_favor_ws_bytes", "mlhot_np_struct_bytes", "mlhot_np_saved_bytes", "mlhot_np_scratch_bytes"):
+                   "mlhot_favor_ws_bytes", "mlhot_np_struct_bytes", "mlhot_np_saved_bytes", "mlhot_np_scratch_bytes",
+                   "mlhot_np_grads_flat_layout"):
             getattr(c, fn).restype = C.c_size_t
         c.mlhot_enc_vanilla_saved_bytes.argtypes = [C.c_int]
         c.mlhot_enc_vanilla_scratch_bytes.argtypes = [C.c_int, C.c_int]
@@ -115,6 +124,7 @@ class MlhotLib:
         c.mlhot_np_struct_bytes.argtypes = [C.c_int]
         c.mlhot_np_saved_bytes.argtypes = [C.POINTER(NpDims)]
         c.mlhot_np_scratch_bytes.argtypes = [C.POINTER(NpDims)]
+        c.mlhot_np_grads_flat_layout.argtypes = [C.POINTER(NpDims), C.POINTER(NpGrads)]
         i, z, P = C.c_int, C.c_size_t, C.c_void_p
         c.mlhot_enc_vanilla_fwd.argtypes = [P, i, P, i, C.POINTER(EncParams), i, P, i, P, i, P, P, z, P]
         c.mlhot_enc_vanilla_bwd.argtypes = [P, i, P, i, C.POINTER(EncParams), i, P, i, P, i, P, C.POINTER(EncParams), P, z, P]
@@ -443,7 +453,15 @@ class MlhotLib:
 
     def np_vanilla_bwd(self, dims, params, ctx_x, ctx_y, qry_x, mu, dmu, saved, scratch=None, proj=None):
         _chk(dmu, mu)
-        grads = {k: torch.empty_like(v) for k, v in params.items()}
+        # one flat gradient buffer in the library's preferred order; the per-parameter gradients are views of it
+        offs = NpGrads()
+        total = self.c.mlhot_np_grads_flat_layout(C.byref(dims), C.byref(offs))
+        flat = torch.empty(total, dtype=torch.float32, device=qry_x.device)
+        pm = vanilla_param_map(dims.n_hidden, dims.agg_mode == AGG["baco"], dims.agg_mode == AGG["attention"])
+        grads = {}
+        for path, key in pm:
+            off = (_get(offs, path) or 0) // 4
+            grads[key] = flat[off:off + params[key].numel()].view_as(params[key])
         sb = self.c.mlhot_np_scratch_bytes(C.byref(dims))
         if scratch is None or scratch.numel() < sb:
             scratch = self._bytes(sb, qry_x)
