@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, out):
+def _worker(rank, world, port, name, out, shared=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [os.path.join(root, "what-matters-for-meta-learning_amd"), root]
@@ -43,11 +43,26 @@ def _worker(rank, world, port, name, out):
     T = cx.shape[0]
     full = grads_of(slice(0, T))
     local = grads_of(mdist.task_slice(T, rank, world))
-    for k, prm in model.named_parameters():
-        prm.grad = local[k].clone()
+    if shared:
+        # the product hands out every gradient as a view of ONE flat buffer (mlhot_np_grads_flat_layout, with alignment
+        # padding between tensors): the bucket must reduce that buffer in place, without packing
+        sizes = [(k, prm.numel()) for k, prm in model.named_parameters()]
+        flat = torch.full((sum((n + 3) // 4 * 4 for _, n in sizes) + 8,), float("nan"))
+        off = 4
+        for (k, n), (_, prm) in zip(sizes, model.named_parameters()):
+            view = flat[off:off + n].view_as(prm)
+            view.copy_(local[k])
+            prm.grad = view
+            off += (n + 3) // 4 * 4
+    else:
+        for k, prm in model.named_parameters():
+            prm.grad = local[k].clone()
     bucket = mdist.GradBucket(model.parameters())
     bucket.sync()
-    assert bucket.flat.numel() == sum(p.numel() for p in model.parameters())
+    if shared:
+        assert bucket.flat is None and all(prm.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for prm in model.parameters())
+    else:
+        assert bucket.flat.numel() == sum(p.numel() for p in model.parameters())
     floor = U.GRAD_FLOOR * max(g.abs().max().item() for g in full.values())   # same floor as the parity tests
     worst = max(U.rel_err(prm.grad, full[k], floor=floor) for k, prm in model.named_parameters())
     out[rank] = worst
@@ -55,13 +70,13 @@ def _worker(rank, world, port, name, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["s_cnp_shapenet1d_baco", "s_anp_shapenet1d_ragged"])
-def test_two_rank_task_sharding_matches_full_batch(name):
+@pytest.mark.parametrize("name,shared", [("s_cnp_shapenet1d_baco", False), ("s_anp_shapenet1d_ragged", False), ("s_anp_shapenet1d_ragged", True)])
+def test_two_rank_task_sharding_matches_full_batch(name, shared):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         out = mgr.dict()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, name, out)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, name, out, shared)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:

@@ -44,10 +44,33 @@ class GradBucket:
         self.group = group
         self.flat = None
 
+    @staticmethod
+    def _shared_flat(live):
+        """The one fp32 tensor all live gradients are views of, or None."""
+        g0 = live[0].grad
+        st = g0.untyped_storage()
+        lo, hi = None, None
+        for p in live:
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != st.data_ptr():
+                return None
+            a, b = g.storage_offset(), g.storage_offset() + g.numel()
+            lo, hi = (a if lo is None else min(lo, a)), (b if hi is None else max(hi, b))
+        if len(live) < 2:
+            return None
+        return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, lo, (hi - lo,))
+
     def sync(self):
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         live = [p for p in self.params if p.grad is not None]
         if world == 1 or not live:
+            return
+        shared = self._shared_flat(live)
+        if shared is not None:
+            # the library already wrote every gradient into ONE flat buffer (mlhot_np_grads_flat_layout): reduce it in
+            # place, no pack / unpack.  Alignment padding and regions of unused parameters ride along harmlessly.
+            dist.all_reduce(shared, op=dist.ReduceOp.SUM, group=self.group)
+            shared.mul_(1.0 / world)
             return
         n = sum(p.grad.numel() for p in live)
         if self.flat is None or self.flat.numel() != n or self.flat.device != live[0].grad.device:
