@@ -50,3 +50,26 @@ print("layer-function calls of workgroup 0 (cycles between stamps: entry | setup
 for c, row in enumerate(calls):
     if row[0] and row[5]:
         print(c, [row[i + 1] - row[i] for i in range(5)], "total", row[5] - row[0])
+
+if v[500] > 0:
+    print("conv12 fwd main loop of workgroup 0: %.0f shader cycles in %.1f us -> effective clock %.2f GHz" % (v[500], v[501] / 100.0, v[500] / (v[501] * 10.0) ))
+
+# effective clock under back-to-back hipGraph replay (what bench.py times)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3):
+        model.zero_grad(set_to_none=True)
+        loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+graph = torch.cuda.CUDAGraph()
+model.zero_grad(set_to_none=True)
+with torch.cuda.graph(graph):
+    loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+for _ in range(200):
+    graph.replay()
+torch.cuda.synchronize()
+v = ts.cpu().double().tolist()
+if v[500] > 0:
+    print("graph replay: conv12 fwd main loop %.0f shader cycles in %.1f us -> effective clock %.2f GHz" % (v[500], v[501] / 100.0, v[500] / (v[501] * 10.0)))

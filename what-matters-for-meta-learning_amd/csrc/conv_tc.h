@@ -21,6 +21,9 @@
 
 #ifndef MLHOT_HOSTSIM
 namespace mlhot {
+#ifdef MLHOT_TS
+namespace tf { extern __device__ long long* g_ts_dev; }
+#endif
 namespace c2 {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -497,6 +500,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   const int lr = lane & 15, lq = lane >> 4;
   const int n = nt * 16 + lr;
   const bool cact = !(dbg & 1);
+  const int phase = __builtin_amdgcn_readfirstlane(wave >> 2);
 
   float wr[72];
 #pragma unroll
@@ -509,6 +513,9 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   patch_zero_pad(patch2 + PATCH_FLOATS, tid);
   const int ntiles = n_img * 8;
   int tile = blockIdx.x;
+#ifdef MLHOT_TS
+  long long ts_c0 = clock64(), ts_w0 = wall_clock64();
+#endif
   Conv1A ca;
   if (tile < ntiles && cact) {
     conv1a_fetch(ca, x, tile, wave, lr, lq);
@@ -525,20 +532,32 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     const bool stage = next < ntiles && cact;
 
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // 6 segments of 24 MFMAs; the next band's a1 slice (3 M-tiles per wave): pixels fetched before segments 0, 2, 4, tiles produced after 1, 3, 5
+    // 9 segments of 16 MFMAs.  The next band's a1 slice (3 M-tiles per wave) is produced after segments 3j + phase,
+    // phase = wave / 4, so the three waves that share a SIMD (w, w + 4, w + 8) post-process their conv1 tiles (ReLU,
+    // LDS stores, sign bits) in different segments; each tile's pixels are requested two segments ahead.
+    if (stage) {
 #pragma unroll
-    for (int seg = 0; seg < 6; ++seg) {
-      if (stage && !(seg & 1)) conv1a_fetch1(ca, seg >> 1, x, next, wave, lr, lq);
+      for (int j = 0; j < 3; ++j)
+        if (3 * j + phase - 2 < 0) conv1a_fetch1(ca, j, x, next, wave, lr, lq);
+    }
 #pragma unroll
-      for (int q = 0; q < 12; ++q) {
-        const int ks = seg * 12 + q;
+    for (int seg = 0; seg < 9; ++seg) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int ks = seg * 8 + q;
         const int tap = ks >> 3, ky = tap / 3, kx = tap % 3, cg = ks & 7;
         const float x0 = ab[cg * 4 * PS + ky * RS + kx];
         const float x1 = ab[cg * 4 * PS + (2 + ky) * RS + kx];
         acc0 = mfma4(x0, wr[ks], acc0);
         acc1 = mfma4(x1, wr[ks], acc1);
       }
-      if (stage && (seg & 1)) conv1_tile<true>(ca, cw, seg >> 1, nb, next, wave, lane, m1);
+      if (stage) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (seg == 3 * j + phase - 2) conv1a_fetch1(ca, j, x, next, wave, lr, lq);
+          if (seg == 3 * j + phase) conv1_tile<true>(ca, cw, j, nb, next, wave, lane, m1);
+        }
+      }
     }
     const int img = tile >> 3, band = tile & 7;
     float pv[2]; unsigned pa[2];
@@ -557,6 +576,11 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     *reinterpret_cast<unsigned short*>(amax + o) = (unsigned short)(pa[0] | (pa[1] << 8));
     __syncthreads();
   }
+#ifdef MLHOT_TS
+  if (tf::g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0) {       // shader cycles and 100 MHz ticks of the main loop -> effective clock
+    tf::g_ts_dev[500] = clock64() - ts_c0; tf::g_ts_dev[501] = wall_clock64() - ts_w0;
+  }
+#endif
 }
 
 // ---- weight + bias gradient of conv2 with the a1 patch recomputed from the image ------------------
