@@ -1,0 +1,56 @@
+// Microbenchmark of the conv2 forward inner loop in isolation: 12 waves per workgroup, 72 weight registers,
+// A operands from an LDS patch with the kernel's addressing, 2 accumulators, 144 MFMAs per "band".
+//   MODE 0: as the kernel (LDS A, 72 B regs)   1: A from a register (no LDS)   2: LDS A, single B register
+//   3: LDS A with a conflict-free dense addressing (lane*4 bytes)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int RS = 65, PS = 9 * RS, PATCH = 32 * PS;
+template <int MODE>
+__global__ __launch_bounds__(768) void k(float* out, const float* w, int bands) {
+  __shared__ float patch[2 * PATCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1, lr = lane & 15, lq = lane >> 4;
+  for (int i = tid; i < 2 * PATCH; i += 768) patch[i] = 0.001f * (i & 255);
+  float wr[72];
+#pragma unroll
+  for (int ks = 0; ks < 72; ++ks) wr[ks] = w[(nt * 16 + lr) * 288 + ((ks & 7) * 4 + lq) * 9 + (ks >> 3)];
+  __syncthreads();
+  const int aoff = MODE == 3 ? lane : lq * PS + (4 * rp) * RS + 2 * (16 * ch + lr);
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  float areg = (float)tid;
+  for (int b = 0; b < bands; ++b) {
+    const float* ab = patch + (b & 1) * PATCH + aoff;
+#pragma unroll
+    for (int ks = 0; ks < 72; ++ks) {
+      const int tap = ks >> 3, ky = tap / 3, kx = tap % 3, cg = ks & 7;
+      float x0, x1;
+      if (MODE == 1) { x0 = areg; x1 = areg; }
+      else if (MODE == 3) { x0 = ab[ks * 128]; x1 = ab[ks * 128 + 64]; }
+      else { x0 = ab[cg * 4 * PS + ky * RS + kx]; x1 = ab[cg * 4 * PS + (2 + ky) * RS + kx]; }
+      const float bw = MODE == 2 ? wr[0] : wr[ks];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, bw, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, bw, acc1, 0, 0, 0);
+    }
+  }
+  const float s = acc0[0] + acc0[1] + acc0[2] + acc0[3] + acc1[0] + acc1[1] + acc1[2] + acc1[3];
+  if (s == 1.2345f) out[0] = s;
+}
+template <int MODE>
+void run(const float* w, float* d, int bands) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(768), 0, 0, d, w, bands);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  const double flops = 256.0 * 12 * (double)bands * 144 * 2048.0;
+  printf("mode %d: %.1f us for %d bands -> %.1f TFLOP/s\n", MODE, ms * 1e3, bands, flops / (ms * 1e-3) / 1e12);
+}
+int main() {
+  float *w, *d; (void)hipMalloc(&w, 48 * 288 * 4); (void)hipMalloc(&d, 4); (void)hipMemset(w, 0, 48 * 288 * 4);
+  run<0>(w, d, 150); run<1>(w, d, 150); run<2>(w, d, 150); run<3>(w, d, 150);
+  return 0;
+}

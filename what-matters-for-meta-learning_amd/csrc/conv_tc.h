@@ -43,226 +43,8 @@ __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// ---- patch staging shared by forward and wgrad ---------------------------------------------------
-// 32 planes x 9 rows x 16 float4 = 4608 float4 per band, 6 per thread.
-struct PatchRegs { float4 v[6]; };
-
-__device__ __forceinline__ void patch_fetch(PatchRegs& st, const float* __restrict__ a1, int tile, int tid) {
-  const int img = tile >> 3, band = tile & 7;
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int e = tid + j * NT;
-    const int ci = e / 144, rem = e % 144, r = rem >> 4, x4 = rem & 15;
-    const int iy = 8 * band - 1 + r;
-    if (iy >= 0)
-      st.v[j] = *reinterpret_cast<const float4*>(a1 + (((size_t)img * CIN + ci) * 64 + iy) * 64 + 4 * x4);
-    else
-      st.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-__device__ __forceinline__ void patch_store(const PatchRegs& st, float* patch, int tid) {
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int e = tid + j * NT;
-    const int ci = e / 144, rem = e % 144, r = rem >> 4, x4 = rem & 15;
-    float* d = patch + ci * PS + r * RS + 1 + 4 * x4;
-    d[0] = st.v[j].x; d[1] = st.v[j].y; d[2] = st.v[j].z; d[3] = st.v[j].w;
-  }
-}
 __device__ __forceinline__ void patch_zero_pad(float* patch, int tid) {
   for (int i = tid; i < CIN * ROWS; i += NT) patch[(i / ROWS) * PS + (i % ROWS) * RS] = 0.f;
-}
-
-// ==================================================================================================
-// forward: p2 = maxpool2(relu(conv2(a1) + b)), amax = window arg-max     (ANPShapeNet1D.py:49-51)
-// wave w: couts 16*(w%3) .. +15; positions: conv rows {2rp, 2rp+1} (rp = (w/3)>>1) x cols
-// 16*ch .. +15 (ch = (w/3)&1) of the band -> the 2x2 pool windows are lane-local.
-// ==================================================================================================
-__device__ __forceinline__ float4 patch_fetch1(const float* __restrict__ a1, int tile, int e) {
-  const int img = tile >> 3, band = tile & 7;
-  const int ci = e / 144, rem = e % 144, r = rem >> 4, x4 = rem & 15;
-  const int iy = 8 * band - 1 + r;
-  if (iy < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
-  return *reinterpret_cast<const float4*>(a1 + (((size_t)img * CIN + ci) * 64 + iy) * 64 + 4 * x4);
-}
-__device__ __forceinline__ void patch_store1(float4 v, float* patch, int e) {
-  const int ci = e / 144, rem = e % 144, r = rem >> 4, x4 = rem & 15;
-  float* d = patch + ci * PS + r * RS + 1 + 4 * x4;
-  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-}
-
-__global__ __launch_bounds__(NT) void conv2_fwd_pool_kernel(const float* __restrict__ a1, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, float* __restrict__ p2,
-                                                            uint8_t* __restrict__ amax, int n_img) {
-  // two patch buffers: the next band is staged (one float4 per thread per 12-k-step segment)
-  // into the idle buffer while the MFMAs read the other one -> one barrier per band.
-  __shared__ float patch2[2 * PATCH_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int n = nt * 16 + lr;
-
-  float wr[72];   // B[k = tap*32 + ci][n], k-step ks = tap*8 + ci/4, this lane's k = 4*ks + lq
-#pragma unroll
-  for (int ks = 0; ks < 72; ++ks) wr[ks] = w[((size_t)n * CIN + (ks & 7) * 4 + lq) * 9 + (ks >> 3)];
-  const float bn = bias[n];
-
-  patch_zero_pad(patch2, tid);
-  patch_zero_pad(patch2 + PATCH_FLOATS, tid);
-  const int ntiles = n_img * 8;
-  int tile = blockIdx.x;
-  if (tile < ntiles) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j) patch_store1(patch_fetch1(a1, tile, tid + j * NT), patch2, tid + j * NT);
-  }
-  __syncthreads();
-  // this lane's A gather offset: plane lq, conv row 2rp (patch row 4rp + ky), col 2*ox + kx
-  const int aoff = lq * PS + (4 * rp) * RS + 2 * (16 * ch + lr);
-  int cur = 0;
-  for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
-    const float* ab = patch2 + cur * PATCH_FLOATS + aoff;
-    float* nb = patch2 + (cur ^ 1) * PATCH_FLOATS;
-    const int next = tile + (int)gridDim.x;
-    const bool has_next = next < ntiles;
-
-    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int seg = 0; seg < 6; ++seg) {
-      float4 stg = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (has_next) stg = patch_fetch1(a1, next, tid + seg * NT);
-#pragma unroll
-      for (int q = 0; q < 12; ++q) {
-        const int ks = seg * 12 + q;
-        const int tap = ks >> 3, ky = tap / 3, kx = tap % 3, cg = ks & 7;
-        const float x0 = ab[cg * 4 * PS + ky * RS + kx];
-        const float x1 = ab[cg * 4 * PS + (2 + ky) * RS + kx];
-        acc0 = mfma4(x0, wr[ks], acc0);
-        acc1 = mfma4(x1, wr[ks], acc1);
-      }
-      if (has_next) patch_store1(stg, nb, tid + seg * NT);
-    }
-    // epilogue: lane holds conv cols 16ch + 4lq + {0..3} of rows 2rp (acc0) and 2rp+1 (acc1), cout n
-    const int img = tile >> 3, band = tile & 7;
-    float pv[2]; unsigned pa[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float c0 = fmaxf(acc0[2 * j] + bn, 0.f), c1 = fmaxf(acc0[2 * j + 1] + bn, 0.f);
-      const float c2v = fmaxf(acc1[2 * j] + bn, 0.f), c3 = fmaxf(acc1[2 * j + 1] + bn, 0.f);
-      float best = c0; unsigned which = 0;
-      if (c1 > best) { best = c1; which = 1; }
-      if (c2v > best) { best = c2v; which = 2; }
-      if (c3 > best) { best = c3; which = 3; }
-      pv[j] = best; pa[j] = which;
-    }
-    const size_t o = (((size_t)img * COUT + n) * 16 + 2 * band + rp) * 16 + 8 * ch + 2 * lq;
-    *reinterpret_cast<float2*>(p2 + o) = make_float2(pv[0], pv[1]);
-    *reinterpret_cast<unsigned short*>(amax + o) = (unsigned short)(pa[0] | (pa[1] << 8));
-    __syncthreads();     // next buffer complete, this buffer free
-  }
-}
-
-// ==================================================================================================
-// weight + bias gradient.  out[k = tap*32+ci][co] = sum_pos Xcol[pos][k] * dY[pos][co], dY routed on
-// the fly from the pooled gradient (pool + ReLU backward).  wave w: M-tiles 3*(w%6)..+2 (16 k-rows
-// each: tap = mt/2, ci = 16*(mt%2)+i) x all 3 N-tiles, conv rows {2ph, 2ph+1} of the band (ph = w/6).
-// Accumulators persist over all bands of the workgroup; partials go to slab[2*block + ph][48*288].
-// ==================================================================================================
-__global__ __launch_bounds__(NT) void conv2_wgrad_kernel(const float* __restrict__ a1, const float* __restrict__ dp2,
-                                                         const float* __restrict__ p2, const uint8_t* __restrict__ amax,
-                                                         float* __restrict__ slab_w, float* __restrict__ slab_b, int n_img) {
-  __shared__ float lds[PATCH_FLOATS + DYT_FLOATS];
-  float* patch = lds;
-  float* dyt = lds + PATCH_FLOATS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mg = wave % 6, ph = wave / 6;
-  const int lr = lane & 15, lq = lane >> 4;
-
-  f32x4_t acc[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum[2] = {0.f, 0.f};
-
-  patch_zero_pad(patch, tid);
-  const int ntiles = n_img * 8;
-  PatchRegs st;
-  float cdp[2], cp[2]; unsigned cam[2];
-  auto cells_fetch = [&](int t) {       // 48 co x 2 pooled rows x 16 px = 1536 cells, 2 per thread
-    const int img = t >> 3, band = t & 7;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = tid + j * NT, px = e & 15, pyl = (e >> 4) & 1, co = e >> 5;
-      const size_t o = (((size_t)img * COUT + co) * 16 + 2 * band + pyl) * 16 + px;
-      cdp[j] = dp2[o]; cp[j] = p2[o]; cam[j] = amax[o];
-    }
-  };
-  int tile = blockIdx.x;
-  if (tile < ntiles) { patch_fetch(st, a1, tile, tid); cells_fetch(tile); }
-
-  // A gather base per M-tile i: k-row = lane&15 -> ci = 16*(mt%2) + lr, tap = mt/2; position col
-  // ox = oxb + 8*lq.  B gather base: dyt[(orow*32 + ox)*DS + 16j + lr].
-  int aoff[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int mt = 3 * mg + i, tap = mt >> 1, ky = tap / 3, kx = tap % 3;
-    aoff[i] = (16 * (mt & 1) + lr) * PS + ky * RS + kx + 2 * (8 * lq);
-  }
-  const int boff = (8 * lq) * DS + lr;
-
-  for (; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();
-    patch_store(st, patch, tid);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = tid + j * NT, px = e & 15, pyl = (e >> 4) & 1, co = e >> 5;
-      const float g = cp[j] > 0.f ? cdp[j] : 0.f;
-      bsum[j] += g;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        dyt[((2 * pyl + (q >> 1)) * 32 + 2 * px + (q & 1)) * DS + co] = (cam[j] == (unsigned)q) ? g : 0.f;
-    }
-    __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) { patch_fetch(st, a1, tile + gridDim.x, tid); cells_fetch(tile + gridDim.x); }
-
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {          // k-step: conv row 2ph + s/8, cols (s%8) + {0,8,16,24}
-      const int orow_l = s >> 3, oxb = s & 7;
-      float a[3], b[3];
-      const int arow = (2 * (2 * ph + orow_l)) * RS + 2 * oxb;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) a[i] = patch[aoff[i] + arow];
-      const int brow = ((2 * ph + orow_l) * 32 + oxb) * DS;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) b[j] = dyt[boff + brow + 16 * j];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
-    }
-  }
-
-  // partial weight gradients in the final [co][ci*9 + tap] order
-  float* sw = slab_w + (size_t)(2 * blockIdx.x + ph) * (COUT * CIN * 9);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int mt = 3 * mg + i, tap = mt >> 1;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = 16 * (mt & 1) + 4 * lq + r, co = 16 * j + lr;
-        sw[((size_t)co * CIN + ci) * 9 + tap] = acc[i][j][r];
-      }
-  }
-  // bias partials: the 32 threads that share a cout are one half-wave (e>>5 == co)
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    float v = bsum[j];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((lane & 31) == 0) slab_b[(size_t)blockIdx.x * COUT + ((tid + j * NT) >> 5)] = v;
-  }
 }
 
 // out[e] = sum_p slab[p][e]  (fixed order -> bitwise reproducible).  256 threads = 16 float4 column groups x
@@ -295,112 +77,6 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
     *reinterpret_cast<float4*>(out + e) = t;
   }
 }
-
-// ==================================================================================================
-// data gradient:  dy1 = relu'(a1) * conv2^T(dY2), dY2 routed from the pooled gradient.
-// Band = 8 conv1 rows (y = 8b..8b+7) x 64 cols.  Stride-2 transposed conv splits into 4 parity
-// classes (py, px) with 1/2/2/4 taps; a wave owns 16 input channels (nt = w%2) and, balanced to
-// 144 MFMAs per band: w/2 in 0..3 -> odd rows y = 2r+1 (classes (1,0) 24 + (1,1) 48 k-steps, both
-// column halves); w/2 in 4..5 -> even rows y = 4(w/2-4) + {0,2} (classes (0,0) 12 + (0,1) 24).
-// The px=0 / px=1 tiles of one row are computed together so a lane ends up with 8 consecutive x.
-// ==================================================================================================
-// weight slots: odd-row waves hold taps ky in {0,2} as slot (ky/2)*3 + kx, even-row waves hold
-// taps ky = 1 as slot kx.
-template <int PY, int PX>
-__device__ __forceinline__ void dgrad_tile(const float* __restrict__ base, const float (&wr)[6][12], f32x4_t& acc) {
-  // base: &dyp[lq*DPS + yp*DRS + x'] for this lane
-  constexpr int NTY = PY ? 2 : 1, NTX = PX ? 2 : 1;
-#pragma unroll
-  for (int ty = 0; ty < NTY; ++ty)
-#pragma unroll
-    for (int tx = 0; tx < NTX; ++tx) {
-      const int ky = PY ? (ty == 0 ? 0 : 2) : 1, kx = PX ? (tx == 0 ? 0 : 2) : 1;
-      const int doy = (PY && ty == 0) ? 1 : 0, dox = (PX && tx == 0) ? 1 : 0;
-#pragma unroll
-      for (int ks = 0; ks < 12; ++ks) acc = mfma4(base[ks * 4 * DPS + doy * DRS + dox], wr[(PY ? (ky >> 1) * 3 : 0) + kx][ks], acc);
-    }
-}
-
-template <int PY>
-__device__ __forceinline__ void dgrad_row(const float* dyp, const float (&wr)[6][12], const float* __restrict__ a1,
-                                          float* __restrict__ dy1, int img, int y_in_band, int band, int ci, int lr, int lq) {
-  const int yp = y_in_band >> 1;
-#pragma unroll
-  for (int xh = 0; xh < 2; ++xh) {
-    const size_t o = (((size_t)img * CIN + ci) * 64 + 8 * band + y_in_band) * 64 + 32 * xh + 8 * lq;
-    const float4 m0 = *reinterpret_cast<const float4*>(a1 + o), m1 = *reinterpret_cast<const float4*>(a1 + o + 4);
-    f32x4_t e = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
-    const float* base = dyp + lq * DPS + yp * DRS + 16 * xh + lr;
-    dgrad_tile<PY, 0>(base, wr, e);     // x = 2x'   (even columns)
-    dgrad_tile<PY, 1>(base, wr, d);     // x = 2x'+1 (odd columns)
-    float4 o0, o1;
-    o0.x = m0.x > 0.f ? e[0] : 0.f; o0.y = m0.y > 0.f ? d[0] : 0.f; o0.z = m0.z > 0.f ? e[1] : 0.f; o0.w = m0.w > 0.f ? d[1] : 0.f;
-    o1.x = m1.x > 0.f ? e[2] : 0.f; o1.y = m1.y > 0.f ? d[2] : 0.f; o1.z = m1.z > 0.f ? e[3] : 0.f; o1.w = m1.w > 0.f ? d[3] : 0.f;
-    *reinterpret_cast<float4*>(dy1 + o) = o0;
-    *reinterpret_cast<float4*>(dy1 + o + 4) = o1;
-  }
-}
-
-__global__ __launch_bounds__(NT) void conv2_dgrad_kernel(const float* __restrict__ dp2, const float* __restrict__ p2,
-                                                         const uint8_t* __restrict__ amax, const float* __restrict__ w,
-                                                         const float* __restrict__ a1, float* __restrict__ dy1, int n_img) {
-  __shared__ float dyp[DYP_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nt = wave & 1, pg = wave >> 1;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int ci = 16 * nt + lr;
-
-  float wr[6][12];   // B[k = co][n = ci] per held tap, this lane's co = 4*ks + lq
-#pragma unroll
-  for (int slot = 0; slot < 6; ++slot) {
-    const int tap = pg < 4 ? (slot / 3) * 6 + slot % 3 : 3 + slot % 3;     // (ky in {0,2}, kx) | (ky = 1, kx)
-#pragma unroll
-    for (int ks = 0; ks < 12; ++ks) wr[slot][ks] = w[((size_t)(4 * ks + lq) * CIN + ci) * 9 + tap];
-  }
-
-  for (int i = tid; i < COUT * 5; i += NT) dyp[(i / 5) * DPS + (i % 5) * DRS + 32] = 0.f;   // halo column
-  const int ntiles = n_img * 8;
-  float cdp[3], cp[3]; unsigned cam[3];
-  auto cells_fetch = [&](int t) {       // 48 co x 3 pooled rows x 16 px = 2304 cells, 3 per thread
-    const int img = t >> 3, band = t & 7;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int e = tid + j * NT, px = e & 15, pyl = (e >> 4) % 3, co = e / 48;
-      const int py = 2 * band + pyl;
-      if (py < 16) {
-        const size_t o = (((size_t)img * COUT + co) * 16 + py) * 16 + px;
-        cdp[j] = dp2[o]; cp[j] = p2[o]; cam[j] = amax[o];
-      } else { cdp[j] = 0.f; cp[j] = 0.f; cam[j] = 0; }
-    }
-  };
-  int tile = blockIdx.x;
-  if (tile < ntiles) cells_fetch(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int e = tid + j * NT, px = e & 15, pyl = (e >> 4) % 3, co = e / 48;
-      const float g = cp[j] > 0.f ? cdp[j] : 0.f;
-      float* d = dyp + co * DPS + (2 * pyl) * DRS + 2 * px;
-      d[0] = cam[j] == 0u ? g : 0.f;
-      d[1] = cam[j] == 1u ? g : 0.f;
-      if (pyl < 2) {
-        d[DRS] = cam[j] == 2u ? g : 0.f;
-        d[DRS + 1] = cam[j] == 3u ? g : 0.f;
-      }
-    }
-    __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) cells_fetch(tile + gridDim.x);
-    const int img = tile >> 3, band = tile & 7;
-    if (pg < 4) {
-      dgrad_row<1>(dyp, wr, a1, dy1, img, 2 * pg + 1, band, ci, lr, lq);
-    } else {
-      dgrad_row<0>(dyp, wr, a1, dy1, img, 4 * (pg - 4), band, ci, lr, lq);
-      dgrad_row<0>(dyp, wr, a1, dy1, img, 4 * (pg - 4) + 2, band, ci, lr, lq);
-    }
-  }
-}
-
 
 // ==================================================================================================
 // conv1-fused variants ("c12"): the conv1 output `a1` (512 KiB / image, the largest tensor of the
