@@ -89,6 +89,53 @@ def cpu_baseline(w, steps=3):
             "sample": f"{steps} fwd+bwd steps of the same 16-task 15+15 batch after 1 warm-up, median {med * 1e3:.1f} ms/step"}
 
 
+def _time_graph(fn, iters):
+    """Capture fn() once into a hipGraph, replay it `iters` times, return ms per replay."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    for _ in range(5):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        graph.replay()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / iters
+
+
+def measure_extras(w, device, loss_fn, batch, iters):
+    """Not the headline metric: (a) the training forward alone (activations saved, no backward), (b) the full step
+    followed by the fused flat Adam update (mlhot.optim.FlatAdam: one launch over the flat parameter buffer).  The Adam
+    leg is timing only: inside a replayed graph the bias-correction step count is frozen at capture time."""
+    import importlib
+    from mlhot.optim import FlatAdam
+    cx, qx, cy, qy = batch
+    try:
+        model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(make_cfg(w, device)).to(device)
+        opt = FlatAdam(model, lr=1e-4, ctx_num=NC, test_num=NQ)
+
+        def fwd():
+            return loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy)
+
+        def step_adam():
+            model.zero_grad(set_to_none=True)
+            loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+            opt.step()
+
+        return {"fwd_only_ms": _time_graph(fwd, iters), "step_with_flat_adam_ms": _time_graph(step_adam, iters),
+                "note": "hipGraph replays; informational, not the headline metric"}
+    except Exception as e:  # noqa: BLE001 - extras must never break the bench line
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +145,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fwd-only / +Adam timing legs")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing experiments (results become WRONG; never a bench line)")
     args = ap.parse_args()
     w = WORKLOADS[args.workload]
@@ -207,6 +255,10 @@ def main():
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_us": avg_s * 1e6,
                 "alg_flops_per_launch": alg_flops(dom, n_img)}
+    # ---- informational extras (SURVEY §8d "also report fwd-only and +Adam"), rank 0, single-GPU runs only -----------
+    extras = None
+    if world == 1 and not args.no_extras and not args.no_graph:
+        extras = measure_extras(w, device, loss_fn, (cx, qx, cy, qy), max(10, args.steps // 2))
     if world > 1:
         dist.barrier()
 
@@ -220,6 +272,8 @@ def main():
                           "parallelism": f"task-sharded x{world}, one flat grad all-reduce" if world > 1 else "single GPU"},
                "final_loss": final_loss, "hipgraph": graphed, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
                "roofline": roof}
+        if extras:
+            out["extras"] = extras
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
         else:

@@ -142,6 +142,13 @@ int mlhot_bbb_sample_fwd(const float* mu, const float* rho, const float* eps, fl
 int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, const float* dw, const float* dkl, float* dmu, float* drho,
                          size_t n, void* stream);
 
+/* ---- optimizer: torch.optim.Adam (train.py:52-56) as ONE launch over flat buffers -------------------
+ * param / grad / exp_avg / exp_avg_sq: n floats each, laid out alike (e.g. mlhot_np_grads_flat_layout).
+ * step >= 1 is the 1-based update count (bias correction); grad_scale multiplies the gradient first
+ * (1/world after a sum all-reduce); weight_decay is torch's L2 form (added to the gradient); amsgrad off. */
+int mlhot_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float grad_scale, int step, void* stream);
+
 /* ---- X1: ConvEmbeddingModel building blocks (networks/conv_embedding_model.py:99-184) -------------
  * Train-mode batch norm over the shots of ONE task, fused with the ReLU that follows it:
  * y = relu(gamma * (x - mean_c) / sqrt(var_c + eps) + beta) with per-channel batch statistics; like

@@ -331,6 +331,32 @@ def test_mr_vanilla_models_vs_reference(gpulib, name):
         U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
 
 
+def test_flat_adam_matches_torch_adam(gpulib):
+    """mlhot.optim.FlatAdam (parameters re-pointed into ONE flat buffer laid out like the library's
+    flat gradient buffer; one mlhot_adam_step launch) against torch.optim.Adam on an identically seeded model, 3 steps."""
+    from mlhot.optim import FlatAdam
+    from trainer.losses import LossFunc
+    fx, meta = U.load_case("s_anp_shapenet1d_ragged")
+    cx, qx, cy, qy = (t.to(DEV) for t in U.case_inputs(meta))
+    models = [U.build_model(meta, DEV, fx=fx).to(DEV) for _ in range(2)]
+    ref_opt = torch.optim.Adam(models[0].parameters(), lr=1e-3)
+    flat_opt = FlatAdam(models[1], lr=1e-3, ctx_num=meta["Nc"], test_num=meta["Nq"])
+    storages = {p.untyped_storage().data_ptr() for p in models[1].parameters()}
+    assert len(storages) == 1                                  # every parameter is a view of the one flat tensor
+    loss_fn = LossFunc("mse", meta["cfg"]["task"])
+    for _ in range(3):
+        for model, opt in zip(models, (ref_opt, flat_opt)):
+            opt.zero_grad(set_to_none=True)
+            loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+        grads = [p.grad for p in models[1].parameters()]
+        assert len({g.untyped_storage().data_ptr() for g in grads}) == 1     # backward wrote ONE flat gradient buffer
+        ref_opt.step()
+        flat_opt.step()
+    for (k, a), (_, b) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        assert U.rel_err(b, a) <= U.RTOL, k      # (updates are ~1e-2 of the weight scale: 1e-4 of it is 1 % of one update)
+    assert set(models[1].state_dict().keys()) == set(models[0].state_dict().keys())
+
+
 def test_conv_embedding_model_vs_reference(gpulib):
     """X1: ConvEmbeddingModel (MMAML task embedding) on one task's shots: the four embedding vectors, every
     gradient and the in-place running-stat update against the reference's vectors."""

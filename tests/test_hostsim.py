@@ -92,3 +92,21 @@ def test_whole_model_orchestration_vs_reference(hostsim, name):
     from mlhot.ops import used_param_keys
     used = used_param_keys(tuple(params), meta["Nc"])
     U.check_grads_against_fixture({k: (g if k in used else None) for k, g in grads.items()}, fx, meta)
+
+
+def test_adam_step_matches_torch_adam(hostsim):
+    """mlhot_adam_step (one launch over a flat buffer) vs torch.optim.Adam over the same values, incl. weight decay and
+    the 1/world gradient scale, for several steps."""
+    g = torch.Generator().manual_seed(5)
+    n = 1037
+    p0 = torch.randn(n, generator=g)
+    for wd, scale in ((0.0, 1.0), (0.01, 0.5)):
+        ref = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.Adam([ref], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+        for t in range(1, 6):
+            grad = torch.randn(n, generator=g)
+            ref.grad = grad * scale
+            opt.step()
+            hostsim.adam_step(p, grad, m, v, 1e-2, 0.9, 0.999, 1e-8, wd, scale, t)
+            assert U.rel_err(p, ref.detach()) <= 2e-6, (wd, t)

@@ -215,6 +215,15 @@ int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, co
   return run_foreach(BbbSampleBwd{mu, rho, eps, dw, dkl, dmu, drho}, n, (hipStream_t)stream, "bbb.sample.bwd");
 }
 
+// ---- fused Adam over a flat parameter / gradient buffer ------------------------------------------------
+int mlhot_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float grad_scale, int step, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) { set_error("adam_step: bad argument"); return MLHOT_ERR_ARG; }
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  return run_foreach(AdamStep{param, grad, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, grad_scale, (float)(lr / bc1),
+                              (float)(1.0 / sqrt(bc2))}, n, (hipStream_t)stream, "adam.step");
+}
+
 // ---- X1 building blocks: train-mode batch norm (+ReLU) over one task's shots, spatial mean ----------
 int mlhot_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
                       int N, int C, int HW, float* y, float* mean, float* var, void* stream) {

@@ -100,6 +100,25 @@ struct BbbSampleBwd {   // dmu = dw + dkl * mu/sigma^2 ; drho = (dw*eps + dkl * 
 };
 
 // ------------------------------------------------------------------------------------------
+// Optimizer step over ONE flat buffer (train.py:52-56 builds torch.optim.Adam over ~70 small tensors;
+// with the flat gradient layout the whole update is a single launch).  torch.optim.Adam semantics
+// (amsgrad off, L2 weight decay added to the gradient): step t >= 1,
+//   g = grad_scale * grad + wd * p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// ------------------------------------------------------------------------------------------
+struct AdamStep {
+  float* p; const float* g; float* m; float* v;
+  float b1, b2, eps, wd, grad_scale, step_size, inv_sqrt_bc2;
+  MLHOT_HD void operator()(size_t i) const {
+    const float gi = grad_scale * g[i] + wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
 // X1: train-mode batch norm of ConvEmbeddingModel (conv_embedding_model.py:113-117): the batch is the
 // shots of ONE task; statistics per channel over (n, h, w); F.batch_norm(training=True) also updates the
 // running buffers in place with momentum 0.1 and the UNBIASED variance.

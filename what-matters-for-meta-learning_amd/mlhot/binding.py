@@ -418,6 +418,24 @@ class MlhotLib:
                  "mlhot_loss_bwd")
         return dmu
 
+    # ---- fused Adam over flat buffers -------------------------------------------------------------
+    def adam_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+        _chk(param, grad, exp_avg, exp_avg_sq)
+        n = param.numel()
+        if not (grad.numel() == exp_avg.numel() == exp_avg_sq.numel() == n):
+            raise MlhotError("adam_step: buffers differ in size")
+        f = C.c_float
+        self.c.mlhot_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [f] * 6 + [C.c_int, C.c_void_p]
+        self._rc(self.c.mlhot_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, beta1, beta2, eps,
+                                        weight_decay, grad_scale, int(step), _stream(param)), "mlhot_adam_step")
+
+    def np_grads_layout(self, dims):
+        """(total floats, {state_dict key: float offset}) of the library's flat gradient buffer for `dims`."""
+        offs = NpGrads()
+        total = self.c.mlhot_np_grads_flat_layout(C.byref(dims), C.byref(offs))
+        pm = vanilla_param_map(dims.n_hidden, dims.agg_mode == AGG["baco"], dims.agg_mode == AGG["attention"])
+        return total, {key: (_get(offs, path) or 0) // 4 for path, key in pm}
+
     # ---- whole vanilla model -------------------------------------------------------------------
     @staticmethod
     def np_dims(T, Nc, Nq, label_dim, y_dim, dim_w, dim_r, dim_z, hidden, dec_hidden, agg_mode, out_tanh, m_feat):

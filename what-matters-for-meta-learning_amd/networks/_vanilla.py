@@ -75,6 +75,17 @@ class VanillaNP(nn.Module):
             raise TypeError(f"agg_mode is not applicable for {'ANP' if self.ATTENTION else 'CNP'}, "
                             f"choose from {list(ok)}")
 
+    def _dims(self, ctx_num, test_num):
+        proj = self.attn.projection_matrix if self.ATTENTION else None
+        return lib().np_dims(self.task_num, ctx_num, test_num, self.label_dim, self.y_dim, self.dim_w, self.dim_r, self.dim_z,
+                             list(self.n_hidden_units_r), 100, self.agg_mode or "mean", self.OUT_TANH,
+                             proj.shape[0] if proj is not None else 0)
+
+    def flat_layout(self, ctx_num, test_num):
+        """(total floats, {parameter name: offset}) of the flat gradient buffer backward() fills for this batch shape
+        (mlhot_np_grads_flat_layout); mlhot.optim.FlatAdam lays the parameters out the same way."""
+        return lib().np_grads_layout(self._dims(ctx_num, test_num))
+
     def forward(self, batch_train_images, label_train, batch_test_images, test=False):
         """ctx images [T,Nc,1,128,128], ctx labels [T,Nc,L], target images [T,Nq,1,128,128]
         -> (mu [T,Nq,y], None, 0)   (same contract as the reference forward)."""
@@ -88,8 +99,6 @@ class VanillaNP(nn.Module):
             self._keys = tuple(k for k, _ in self.named_parameters())
         params = [p for _, p in self.named_parameters()]
         proj = self.attn.projection_matrix if self.ATTENTION else None
-        dims = lib().np_dims(self.task_num, self.ctx_num, self.test_num, self.label_dim, self.y_dim, self.dim_w,
-                             self.dim_r, self.dim_z, list(self.n_hidden_units_r), 100, self.agg_mode or "mean",
-                             self.OUT_TANH, proj.shape[0] if proj is not None else 0)
+        dims = self._dims(self.ctx_num, self.test_num)
         mu = VanillaNPFunction.apply(dims, self._keys, proj, batch_train_images, label_train, batch_test_images, *params)
         return mu, None, 0
