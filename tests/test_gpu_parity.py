@@ -350,10 +350,16 @@ def test_flat_adam_matches_torch_adam(gpulib):
             loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
         grads = [p.grad for p in models[1].parameters()]
         assert len({g.untyped_storage().data_ptr() for g in grads}) == 1     # backward wrote ONE flat gradient buffer
+        # Some gradients are pure rounding residue (the key bias cancels inside the attention normaliser) and Adam turns
+        # residue into +-lr updates, so two runs drift apart chaotically.  What is under test is the optimizer: give both
+        # the SAME gradient values (in place, the flat buffer stays the flat buffer).
+        with torch.no_grad():
+            for p0, p1 in zip(models[0].parameters(), models[1].parameters()):
+                p1.grad.copy_(p0.grad)
         ref_opt.step()
         flat_opt.step()
     for (k, a), (_, b) in zip(models[0].named_parameters(), models[1].named_parameters()):
-        assert U.rel_err(b, a) <= U.RTOL, k      # (updates are ~1e-2 of the weight scale: 1e-4 of it is 1 % of one update)
+        assert U.rel_err(b, a) <= 1e-5, k
     assert set(models[1].state_dict().keys()) == set(models[0].state_dict().keys())
 
 

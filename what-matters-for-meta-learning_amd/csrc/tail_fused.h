@@ -109,8 +109,8 @@ __device__ __forceinline__ f32x4_t lds_read4(lcptr p, bool vec) {
 // layer's unrolled body inlined the kernel was 56 KB of straight-line code and was bound by cold
 // instruction fetch; as one shared function the code stays hot.  Every scalar argument is made
 // wave-uniform on entry so loop control and the null checks are scalar branches.
-template <int NW>
-__device__ __attribute__((noinline)) void wg_linear(lcptr xs, int ldx, int K, WB wb, int N, int act,
+template <int NW, int TPW>
+__device__ __attribute__((noinline)) void wg_linear_t(lcptr xs, int ldx, int K, WB wb, int N, int act,
                                                     lptr ys, int ldy, gptr yg, int ldg, int nrows, lptr red, int wave, int lane) {
   MLHOT_TSCALL_BEGIN();
   MLHOT_TSC(0);
@@ -127,9 +127,8 @@ __device__ __attribute__((noinline)) void wg_linear(lcptr xs, int ldx, int K, WB
   const int nchunk = 1 << csh;
   const int kblocks = (K + 15) >> 4, per = (kblocks + nchunk - 1) >> csh;
   const bool vec = (K & 3) == 0;
-  int tpw = (ntile + NW - 1) / NW;               // N-tiles a wave handles together (NW is a compile-time power of two)
-  if (tpw > 4) tpw = 4;
-  if (nchunk > 1) tpw = 1;
+  constexpr int tpw = TPW;                        // N-tiles a wave handles together; 16 / TPW k blocks of weights in flight per trip
+  constexpr int KBT = 16 / TPW;
   // The padding columns of X (k >= K) are zero and columns n >= N of the result are never stored, so
   // out-of-range operand addresses are only CLAMPED to something finite - no selects, no branches.
   const int kmax = vec ? K - 4 : K - 1;
@@ -141,10 +140,10 @@ __device__ __attribute__((noinline)) void wg_linear(lcptr xs, int ldx, int K, WB
     if (!active) { tile0 = 0; chunk = 0; }
     int blk = 0, boff = tile0 * 16;               // row block of tile0 and the tile's first row inside it (scalar, no division)
     while (boff >= rows) { boff -= rows; ++blk; }
-    f32x4_t acc[4];
-    gcptr wbase[4]; int woff[4]; float bias[4];
+    f32x4_t acc[TPW];
+    gcptr wbase[TPW]; int woff[TPW]; float bias[TPW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < TPW; ++q) {
       acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       const bool tile_ok = active && q < tpw && tile0 + q < ntile;      // wave-uniform
       if (q > 0 && tile_ok) { boff += 16; if (boff >= rows) { boff -= rows; ++blk; } }
@@ -158,36 +157,38 @@ __device__ __attribute__((noinline)) void wg_linear(lcptr xs, int ldx, int K, WB
     const int kb0 = chunk * per, kb1 = active ? (kb0 + per < kblocks ? kb0 + per : kblocks) : kb0;
     lcptr xrow = xs + lr * ldx + 4 * lq;
     MLHOT_TSC(1);
-    for (int kb = kb0; kb < kb1; kb += 4) {
-      f32x4_t b[4][4], a4[4];
+    for (int kb = kb0; kb < kb1; kb += KBT) {
+      f32x4_t b[KBT][TPW];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < KBT; ++u) {
         if (kb + u < kb1) {
           const int k16 = (kb + u) * 16;
-          a4[u] = lds_read4(xrow + k16, avec);
           const int kc = k16 + 4 * lq <= kmax ? k16 : kmax - 4 * lq;       // clamp this lane's 4 k's into the row
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (q < tpw) {
-              if (vec) b[u][q] = *reinterpret_cast<gc4ptr>(wbase[q] + woff[q] + kc);
-              else {
+          for (int q = 0; q < TPW; ++q) {
+            if (vec) b[u][q] = *reinterpret_cast<gc4ptr>(wbase[q] + woff[q] + kc);
+            else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const int ko = woff[q] + k16 + e; b[u][q][e] = wbase[q][k16 + 4 * lq + e <= kmax ? ko : woff[q] - 4 * lq + kmax]; }
-              }
+              for (int e = 0; e < 4; ++e) { const int ko = woff[q] + k16 + e; b[u][q][e] = wbase[q][k16 + 4 * lq + e <= kmax ? ko : woff[q] - 4 * lq + kmax]; }
             }
           }
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (kb + u < kb1) {
+      for (int u0 = 0; u0 < KBT; u0 += 4) {
+        f32x4_t a4[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (q < tpw) {
-              acc[q] = mfma4(a4[u][0], b[u][q][0], acc[q]);
-              acc[q] = mfma4(a4[u][1], b[u][q][1], acc[q]);
-              acc[q] = mfma4(a4[u][2], b[u][q][2], acc[q]);
-              acc[q] = mfma4(a4[u][3], b[u][q][3], acc[q]);
+        for (int v = 0; v < 4; ++v)
+          if (u0 + v < KBT && kb + u0 + v < kb1) a4[v] = lds_read4(xrow + (kb + u0 + v) * 16, avec);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          if (u0 + v < KBT && kb + u0 + v < kb1) {
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+              acc[q] = mfma4(a4[v][0], b[u0 + v][q][0], acc[q]);
+              acc[q] = mfma4(a4[v][1], b[u0 + v][q][1], acc[q]);
+              acc[q] = mfma4(a4[v][2], b[u0 + v][q][2], acc[q]);
+              acc[q] = mfma4(a4[v][3], b[u0 + v][q][3], acc[q]);
             }
           }
         }
@@ -211,8 +212,8 @@ __device__ __attribute__((noinline)) void wg_linear(lcptr xs, int ldx, int K, WB
     MLHOT_TSC(3);
     if (active && chunk == 0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q >= tpw || tile0 + q >= ntile) continue;
+      for (int q = 0; q < TPW; ++q) {
+        if (tile0 + q >= ntile) continue;
         const int n = (tile0 + q) * 16 + lr;
         float v[4];
 #pragma unroll
@@ -240,6 +241,18 @@ __device__ __attribute__((noinline)) void wg_linear(lcptr xs, int ldx, int K, WB
     MLHOT_TSC(4);
   }
   MLHOT_TSC(5);
+}
+
+// dispatcher: N-tiles per wave (1 when the K range is split over idle waves, else up to 4), see wg_linear_t
+template <int NW>
+__device__ __forceinline__ void wg_linear(lcptr xs, int ldx, int K, WB wb, int N, int act,
+                                          lptr ys, int ldy, gptr yg, int ldg, int nrows, lptr red, int wave, int lane) {
+  const int ntile = (uni(N) + 15) >> 4;
+  const bool split = uni(red != nullptr) && ntile * 2 <= NW;
+  int tpw = (ntile + NW - 1) / NW;
+  if (split || tpw < 2) wg_linear_t<NW, 1>(xs, ldx, K, wb, N, act, ys, ldy, yg, ldg, nrows, red, wave, lane);
+  else if (tpw == 2) wg_linear_t<NW, 2>(xs, ldx, K, wb, N, act, ys, ldy, yg, ldg, nrows, red, wave, lane);
+  else wg_linear_t<NW, 4>(xs, ldx, K, wb, N, act, ys, ldy, yg, ldg, nrows, red, wave, lane);
 }
 
 // zero a [16 x ld] LDS tile
