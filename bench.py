@@ -51,6 +51,7 @@ def alg_flops(label, n_img):
         "enc.conv1": 2.0 * n_img * 4096 * 32 * 9,
         "enc.bwd.conv1.wgrad": 2.0 * n_img * 4096 * 32 * 9,
         "enc.linear": 2.0 * n_img * 4096 * 64,
+        "enc.bwd.linear": 2.0 * 2.0 * n_img * 4096 * 64,           # data + weight gradient in one launch
         "enc.bwd.linear.dgrad": 2.0 * n_img * 4096 * 64,
         "enc.bwd.linear.wgrad": 2.0 * n_img * 4096 * 64,
     }

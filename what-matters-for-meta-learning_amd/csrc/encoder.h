@@ -15,6 +15,7 @@
 #include "favor.h"   // MLHOT_TRY
 #include "conv_tc.h"
 #include "conv3_tc.h"
+#include "enc_linear.h"
 #include "../../include/mlhot.h"
 
 namespace mlhot {
@@ -158,10 +159,21 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
   const Src2 x{img0, n0, img1, (size_t)128 * 128};
 
   // Linear(4096 -> dim_w): input gradient (masked by conv3's ReLU), weight + bias gradient
-  EncLinDgrad ld{n, 4096, dim_w, dfeat, p.wl, sv.a3, sc.dy3};
-  MLHOT_TRY((run_igemm<EncLinDgrad, 64, 64, 16, 2, 2>(ld, 1, nullptr, s, "enc.bwd.linear.dgrad")));
-  EncLinWgrad lw{dim_w, 4097, n, dfeat, sv.a3, g.wl, g.bl};
-  MLHOT_TRY((run_igemm<EncLinWgrad, 64, 64, 16, 2, 2>(lw, enc_linw_split(n), sc.slab, s, "enc.bwd.linear.wgrad")));
+#ifndef MLHOT_HOSTSIM
+  if (g_opt.conv2_tc && dim_w == el::DW) {
+    {
+      ProfScope ps("enc.bwd.linear", s);
+      hipLaunchKernelGGL(el::enc_linear_bwd_kernel, dim3(el::KIN / 16), dim3(el::NTH), 0, s, dfeat, p.wl, sv.a3, sc.dy3, g.wl, g.bl, n);
+    }
+    MLHOT_TRY(check_launch("enc.bwd.linear"));
+  } else
+#endif
+  {
+    EncLinDgrad ld{n, 4096, dim_w, dfeat, p.wl, sv.a3, sc.dy3};
+    MLHOT_TRY((run_igemm<EncLinDgrad, 64, 64, 16, 2, 2>(ld, 1, nullptr, s, "enc.bwd.linear.dgrad")));
+    EncLinWgrad lw{dim_w, 4097, n, dfeat, sv.a3, g.wl, g.bl};
+    MLHOT_TRY((run_igemm<EncLinWgrad, 64, 64, 16, 2, 2>(lw, enc_linw_split(n), sc.slab, s, "enc.bwd.linear.wgrad")));
+  }
 
   // conv3
 #ifndef MLHOT_HOSTSIM
