@@ -131,8 +131,21 @@ def measure_extras(w, device, loss_fn, batch, iters):
             loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
             opt.step()
 
-        return {"fwd_only_ms": _time_graph(fwd, iters), "step_with_flat_adam_ms": _time_graph(step_adam, iters),
-                "note": "hipGraph replays; informational, not the headline metric"}
+        out = {"fwd_only_ms": _time_graph(fwd, iters), "step_with_flat_adam_ms": _time_graph(step_adam, iters),
+               "note": "hipGraph replays; informational, not the headline metric"}
+        # PCIe-inclusive view (the reference hands over HOST batches, model_trainer.py:63-70): pinned host -> device copy of
+        # one batch's images + labels, NOT overlapped with compute; `value` above never includes it
+        host = [t.detach().cpu().pin_memory() for t in (cx, qx, cy, qy)]
+        dst = [torch.empty_like(t) for t in (cx, qx, cy, qy)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            for h, d_ in zip(host, dst):
+                d_.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+        out["h2d_ms_per_batch"] = 1e3 * (time.perf_counter() - t0) / iters
+        out["h2d_mbytes_per_batch"] = sum(t.numel() * 4 for t in host) / 1e6
+        return out
     except Exception as e:  # noqa: BLE001 - extras must never break the bench line
         return {"error": f"{type(e).__name__}: {e}"}
 
