@@ -179,7 +179,7 @@ inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, w.pc, w.max_k, w.arg_k};
   MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
   tf::PhaseBArgs bb{td, tp, b.dec_in, b.rs, b.qh, b.vh, b.kh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged};
-  MLHOT_TRY(tail_launch(tf::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 256, tf::phaseB_lds_bytes(td), bb, s, "tail.B"));
+  MLHOT_TRY(tail_launch(tf::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_lds_bytes(td), bb, s, "tail.B"));
   tf::PhaseCArgs c{td, tp, b.merged, b.rr, b.dec_in, b.d1, b.d2, mu};
   MLHOT_TRY(tail_launch(tf::phaseC_fwd_kernel, d.T, 512, tf::phaseC_lds_bytes(td), c, s, "tail.C"));
   return MLHOT_OK;

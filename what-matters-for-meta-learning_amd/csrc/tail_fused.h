@@ -523,7 +523,7 @@ struct PhaseBArgs {
   float* merged;                           // [T*Nq][dw*H], column e*H + h
 };
 
-__global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
+__global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
   MLHOT_TSTAMP(32);
   extern __shared__ float lds[];
   lptr L0 = (lptr)lds;
@@ -536,13 +536,13 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   lptr s_v = s_k + 16 * Lx;
   lptr s_qf = s_v + 16 * Lx;         // [16][Lf]  dd -> E
   lptr s_kf = s_qf + 16 * Lf;
-  lptr s_S = s_kf + 16 * Lf;         // [4 waves][16][17] partials, then final in wave 0's slot
-  lptr s_st = s_S + 4 * 16 * 17;     // diag_q[16], diag_k[16], max_q[16], D[16]
+  lptr s_S = s_kf + 16 * Lf;         // [8 waves][16][17] partials, then final in wave 0's slot
+  lptr s_st = s_S + 8 * 16 * 17;     // diag_q[16], diag_k[16], max_q[16], D[16]
   MLHOT_LDS int* s_arg = reinterpret_cast<MLHOT_LDS int*>(s_st + 64);   // arg_q[16]
   lptr s_xq = s_st + 64 + 16;        // [16][Lx] x_qry
   lptr s_rs = s_xq + 16 * Lx;        // [16][Lx] rs
-  const int total = 16 * (5 * Lx + 2 * Lf) + 4 * 16 * 17 + 64 + 16;
-  lds_zero(L0, total, tid, 256);
+  const int total = 16 * (5 * Lx + 2 * Lf) + 8 * 16 * 17 + 64 + 16;
+  lds_zero(L0, total, tid, 512);
   __syncthreads();
   MLHOT_TSTAMP(33);
   const int HD = H * d.dw;
@@ -551,13 +551,13 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
         load_job(s_xq, Lx, a.dec_in + (size_t)t * d.Nq * (d.dw + d.dz), d.dw + d.dz, d.Nq, d.dw),
         load_job(s_rs, Lx, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, d.dw),
         load_job(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw)};
-    LoadBatch<3, 4, 1> xb;
-    xb.fetch(xj, tid, 4);
-    xb.stash(xj, tid, 4);
+    LoadBatch<3, 2, 1> xb;
+    xb.fetch(xj, tid, 8);
+    xb.stash(xj, tid, 8);
   }
   // batch-global key stabiliser (identical in every workgroup): largest share, first position on ties
   float gm = -INFINITY; int gcode = 0x7fffffff;
-  for (int i = tid; i < d.T * H; i += 256) {
+  for (int i = tid; i < d.T * H; i += 512) {
     const float v = a.tmax[i]; const int cd = a.targ[i];
     if (kmax_better(v, cd, gm, gcode)) { gm = v; gcode = cd; }
   }
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   __syncthreads();
   gm = s_st[0]; gcode = s_arg[0];
 #pragma unroll
-  for (int w = 1; w < 4; ++w)
+  for (int w = 1; w < 8; ++w)
     if (kmax_better(s_st[w], s_arg[w], gm, gcode)) { gm = s_st[w]; gcode = s_arg[w]; }
   if (blockIdx.x == 0 && tid == 0) { a.gmax[0] = gm; a.gpos[0] = gcode >> 12; a.gpos[1] = gcode & 4095; }
   __syncthreads();
@@ -582,32 +582,36 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
 #pragma unroll
     for (int i = 1; i < H; ++i)
       if (h == i) { wq = a.p.wq_w[i]; bq = a.p.wq_b[i]; wv = a.p.wv_w[i]; bv = a.p.wv_b[i]; }
-    for (int nt = wave; nt * 16 < d.dw; nt += 4) {
-      const int n = nt * 16 + lr;
-      f32x4_t accq = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int k0 = 0; k0 < d.dw; k0 += 16) {
+    const int ntq = d.dw / 16;
+    for (int it = wave; it < 2 * ntq; it += 8) {        // items: (query | value) x 16-column tile
+      const bool isv = it >= ntq;
+      const int n = (isv ? it - ntq : it) * 16 + lr;
+      const float* wsel = isv ? wv : wq;
+      lcptr xs = isv ? s_rs : s_xq;
+      f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int k0 = 0; k0 < d.dw; k0 += 32) {
         const int kk = k0 + 4 * lq;
-        const float4 b1 = *reinterpret_cast<const float4*>(wq + (size_t)n * d.dw + kk);
-        const float4 b2 = *reinterpret_cast<const float4*>(wv + (size_t)n * d.dw + kk);
-        lcptr x1 = s_xq + lr * Lx + kk;
-        lcptr x2 = s_rs + lr * Lx + kk;
-        accq = mfma4(x1[0], b1.x, accq); accv = mfma4(x2[0], b2.x, accv);
-        accq = mfma4(x1[1], b1.y, accq); accv = mfma4(x2[1], b2.y, accv);
-        accq = mfma4(x1[2], b1.z, accq); accv = mfma4(x2[2], b2.z, accv);
-        accq = mfma4(x1[3], b1.w, accq); accv = mfma4(x2[3], b2.w, accv);
+        const float4 b1 = *reinterpret_cast<const float4*>(wsel + (size_t)n * d.dw + kk);
+        const float4 b2 = *reinterpret_cast<const float4*>(wsel + (size_t)n * d.dw + (kk + 16 < d.dw ? kk + 16 : kk));
+        lcptr x1 = xs + lr * Lx + kk;
+        acc0 = mfma4(x1[0], b1.x, acc0); acc0 = mfma4(x1[1], b1.y, acc0);
+        acc0 = mfma4(x1[2], b1.z, acc0); acc0 = mfma4(x1[3], b1.w, acc0);
+        if (k0 + 16 < d.dw) {
+          acc1 = mfma4(x1[16], b2.x, acc1); acc1 = mfma4(x1[17], b2.y, acc1);
+          acc1 = mfma4(x1[18], b2.z, acc1); acc1 = mfma4(x1[19], b2.w, acc1);
+        }
       }
-      const float biasq = bq[n], biasv = bv[n];
+      const float bias = (isv ? bv : bq)[n];
+      lptr ys = isv ? s_v : s_q;
+      float* yg = isv ? a.vh : a.qh;
+      const int nrows = isv ? d.Nc : d.Nq;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * lq + r;
-        if (row < d.Nq) {
-          s_q[row * Lx + n] = accq[r] + biasq;
-          a.qh[(size_t)(t * d.Nq + row) * HD + h * d.dw + n] = accq[r] + biasq;
-        }
-        if (row < d.Nc) {
-          s_v[row * Lx + n] = accv[r] + biasv;
-          a.vh[(size_t)(t * d.Nc + row) * HD + h * d.dw + n] = accv[r] + biasv;
+        if (row < nrows) {
+          ys[row * Lx + n] = acc0[r] + acc1[r] + bias;
+          yg[(size_t)(t * nrows + row) * HD + h * d.dw + n] = acc0[r] + acc1[r] + bias;
         }
       }
     }
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   // dd tiles: q and k against pc; a feature tile's pc slice is loaded once (all float4 in flight
   // together) and feeds both the query and the key accumulator
   const int ntile = (d.m + 15) / 16;
-  for (int jt = wave; jt < ntile; jt += 4) {
+  for (int jt = wave; jt < ntile; jt += 8) {
     const int j = jt * 16 + lr;
     const bool vj = j < d.m;
     f32x4_t accq = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
@@ -637,25 +641,25 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
       for (int r = 0; r < 4; ++r) { s_qf[(4 * lq + r) * Lf + j] = accq[r]; s_kf[(4 * lq + r) * Lf + j] = acck[r]; }
     }
   }
-  // diag = c^2/2 |x|^2 : 32 rows (16 q + 16 k), 8 threads per row
+  // diag = c^2/2 |x|^2 : 32 rows (16 q + 16 k), 16 threads per row
   {
     const float half_c2 = 0.5f / sqrtf((float)d.dw);
-    const int row = tid >> 3, part = tid & 7;
+    const int row = tid >> 4, part = tid & 15;
     lcptr xr = (row < 16 ? s_q + row * Lx : s_k + (row - 16) * Lx);
     float s = 0.f;
-    for (int e = part; e < d.dw; e += 8) s += xr[e] * xr[e];
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    for (int e = part; e < d.dw; e += 16) s += xr[e] * xr[e];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
     if (part == 0) s_st[row] = s * half_c2;
   }
   __syncthreads();
   MLHOT_TSTAMP(35);
-  // query row max / first arg-max: 16 rows x 16 threads
+  // query row max / first arg-max: 16 rows x 32 threads
   {
-    const int row = tid >> 4, part = tid & 15;
+    const int row = tid >> 5, part = tid & 31;
     float best = -INFINITY; int arg = 0x7fffffff;
-    for (int j = part; j < d.m; j += 16) { const float v = s_qf[row * Lf + j]; if (v > best) { best = v; arg = j; } }
+    for (int j = part; j < d.m; j += 32) { const float v = s_qf[row * Lf + j]; if (v > best) { best = v; arg = j; } }
 #pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
+    for (int off = 1; off < 32; off <<= 1) {
       const float ov = __shfl_xor(best, off, 64); const int oa = __shfl_xor(arg, off, 64);
       if (ov > best || (ov == best && oa < arg)) { best = ov; arg = oa; }
     }
@@ -665,9 +669,9 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   MLHOT_TSTAMP(36);
   // E features in place (padding columns j >= m stay exactly 0 -> they are skipped below via `re` masking)
   const float ratio = 1.0f / sqrtf((float)d.m), re = ratio * 1e-4f;
-  // a wave owns rows wave, wave + 4, ..: E in place, and the valid rows saved for the backward right away
+  // a wave owns rows wave, wave + 8: E in place, and the valid rows saved for the backward right away
   // (rows of the [T*N*H, m] views)
-  for (int row = wave; row < 16; row += 4) {
+  for (int row = wave; row < 16; row += 8) {
     const float sq = s_st[row] + s_st[32 + row], sk = s_st[16 + row] + gm;
     float* gq = a.qf + ((size_t)(t * d.Nq + row) * H + h) * d.m;
     float* gk = a.kf + ((size_t)(t * d.Nc + row) * H + h) * d.m;
@@ -682,10 +686,10 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   __syncthreads();
   MLHOT_TSTAMP(37);
   if (tid < d.Nq) a.arg_q[(t * d.Nq + tid) * H + h] = s_arg[tid];
-  // S = (Eq + re)(Ek + re)^T : M = 16 q rows, N = 16 k rows, K = m split over the 4 waves
+  // S = (Eq + re)(Ek + re)^T : M = 16 q rows, N = 16 k rows, K = m split over the 8 waves
   {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = wave * 4; j0 < d.m; j0 += 16) {
+    for (int j0 = wave * 4; j0 < d.m; j0 += 32) {
       const int j = j0 + lq;
       const bool vj = j < d.m;
       const float av = vj ? s_qf[lr * Lf + j] + re : 0.f;
@@ -698,12 +702,16 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   __syncthreads();
   MLHOT_TSTAMP(38);
   {
-    const int n = tid >> 4, np = tid & 15;
-    float s = (s_S[n * 17 + np] + s_S[(16 + n) * 17 + np]) + (s_S[(32 + n) * 17 + np] + s_S[(48 + n) * 17 + np]);
+    const int n = (tid >> 4) & 15, np = tid & 15;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += s_S[(16 * w + n) * 17 + np];
     if (n >= d.Nq || np >= d.Nc) s = 0.f;
     __syncthreads();
-    s_S[n * 17 + np] = s;
-    if (n < d.Nq && np < d.Nc) a.S[(((size_t)t * H + h) * d.Nq + n) * d.Nc + np] = s;
+    if (tid < 256) {
+      s_S[n * 17 + np] = s;
+      if (n < d.Nq && np < d.Nc) a.S[(((size_t)t * H + h) * d.Nq + n) * d.Nc + np] = s;
+    }
   }
   __syncthreads();
   MLHOT_TSTAMP(39);
@@ -716,7 +724,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
   __syncthreads();
   MLHOT_TSTAMP(40);
   // out[n][e] = sum_n' S[n][n'] v[n'][e] / D[n]: N-tiles of e over the waves, K = 16 k rows
-  for (int et = wave; et * 16 < d.dw; et += 4) {
+  for (int et = wave; et * 16 < d.dw; et += 8) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(256) void phaseB_fwd_kernel(const PhaseBArgs a) {
 }
 
 __host__ inline size_t phaseB_lds_bytes(const TailDims& d) {
-  return sizeof(float) * (16 * (5 * ldpad(d.dw) + 2 * ldpad(d.m)) + 4 * 16 * 17 + 64 + 16);
+  return sizeof(float) * (16 * (5 * ldpad(d.dw) + 2 * ldpad(d.m)) + 8 * 16 * 17 + 64 + 16);
 }
 
 // ==================================================================================================
