@@ -1085,7 +1085,7 @@ struct PhaseBBwdArgs {
   float *pxq, *pxc, *prs, *part_k, *slab;
 };
 
-__global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) {
+__global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) {
   MLHOT_TSTAMP(128);
   extern __shared__ float lds[];
   lptr L0 = (lptr)lds;
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   lptr s_dk = s_dq + 16 * Lx;
   lptr s_dv = s_dk + 16 * Lx;
   const int total = 16 * (10 * Lx + 4 * Lf) + 2 * 16 * 17 + 64;
-  lds_zero(L0, total, tid, 256);
+  lds_zero(L0, total, tid, 512);
   __syncthreads();
   MLHOT_TSTAMP(129);
   {
@@ -1127,17 +1127,17 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     const LoadJob ej[2] = {
         load_job(s_qf, Lf, a.qf + ((size_t)t * d.Nq * H + h) * d.m, H * d.m, d.Nq, d.m),
         load_job(s_kf, Lf, a.kf + ((size_t)t * d.Nc * H + h) * d.m, H * d.m, d.Nc, d.m)};
-    LoadBatch<7, 4, 1> xb;
-    LoadBatch<2, 4, 5> eb;
-    xb.fetch(xj, tid, 4);
-    eb.fetch(ej, tid, 4);
-    xb.stash(xj, tid, 4);
-    eb.stash(ej, tid, 4);
+    LoadBatch<7, 2, 1> xb;
+    LoadBatch<2, 2, 5> eb;
+    xb.fetch(xj, tid, 8);
+    eb.fetch(ej, tid, 8);
+    xb.stash(xj, tid, 8);
+    eb.stash(ej, tid, 8);
   }
   if (tid < d.Nq) s_st[16 + tid] = a.D[((size_t)t * H + h) * d.Nq + tid];
   __syncthreads();
   MLHOT_TSTAMP(130);
-  {
+  if (tid < 256) {
     const int n = tid >> 4, part = tid & 15;
     float s = 0.f;
     if (n < d.Nq)
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   __syncthreads();
   MLHOT_TSTAMP(132);
   // dV[n'][e] = sum_n (S/D)[n][n'] dO[n][e]  -> dvh
-  for (int et = wave; et * 16 < d.dw; et += 4) {
+  for (int et = wave; et * 16 < d.dw; et += 8) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   // G = dF (.) E with dQ' = dS (Ek + re), dK' = dS^T (Eq + re): feature tiles over the waves
   const float ratio = 1.0f / sqrtf((float)d.m), re = ratio * 1e-4f;
   const int ntile = (d.m + 15) / 16;
-  for (int it = wave; it < 2 * ntile; it += 4) {
+  for (int it = wave; it < 2 * ntile; it += 8) {
     const int isk = it >= ntile, jt = isk ? it - ntile : it;
     const int j = jt * 16 + lr;
     const bool vj = j < d.m;
@@ -1202,13 +1202,13 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   }
   __syncthreads();
   MLHOT_TSTAMP(133);
-  // row sums of G (32 rows x 8 threads), then d(dd): queries subtract the row sum at the arg-max
+  // row sums of G (32 rows x 16 threads), then d(dd): queries subtract the row sum at the arg-max
   {
-    const int row = tid >> 3, part = tid & 7;
+    const int row = tid >> 4, part = tid & 15;
     lcptr g = row < 16 ? s_gq + row * Lf : s_gk + (row - 16) * Lf;
     float s = 0.f;
-    for (int j = part; j < d.m; j += 8) s += g[j];
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    for (int j = part; j < d.m; j += 16) s += g[j];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
     if (part == 0) s_st[32 + row] = s;
   }
   __syncthreads();
@@ -1226,8 +1226,11 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   {
     const float c2 = 1.0f / sqrtf((float)d.dw);
     const int net = d.dw / 16;
-    for (int et = wave; et < net; et += 4) {
-      f32x4_t accq = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
+    for (int it = wave; it < 2 * net; it += 8) {          // items: e tile x (query rows | key rows)
+      const bool isk = it >= net;
+      const int et = isk ? it - net : it;
+      lcptr g = isk ? s_gk : s_gq;
+      f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const float* pcol = a.pc + et * 16 + lr;
       for (int j0 = 0; j0 < d.m; j0 += 64) {
         float bv[16];
@@ -1238,19 +1241,18 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
           bv[u] = j < d.m ? v : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          if (j0 + 4 * u < d.m) {
-            const int j = j0 + 4 * u + lq;
-            accq = mfma4(s_gq[lr * Lf + j], bv[u], accq);
-            acck = mfma4(s_gk[lr * Lf + j], bv[u], acck);
-          }
+        for (int u = 0; u < 16; u += 2) {
+          if (j0 + 4 * u < d.m) acc0 = mfma4(g[lr * Lf + j0 + 4 * u + lq], bv[u], acc0);
+          if (j0 + 4 * u + 4 < d.m) acc1 = mfma4(g[lr * Lf + j0 + 4 * u + 4 + lq], bv[u + 1], acc1);
         }
       }
+      lcptr xs = isk ? s_k : s_q;
+      lptr dst = isk ? s_dk : s_dq;
+      const int nrows = isk ? d.Nc : d.Nq, so = isk ? 48 : 32;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * lq + r, e = et * 16 + lr;
-        s_dq[row * Lx + e] = row < d.Nq ? accq[r] - s_st[32 + row] * c2 * s_q[row * Lx + e] : 0.f;
-        s_dk[row * Lx + e] = row < d.Nc ? acck[r] - s_st[48 + row] * c2 * s_k[row * Lx + e] : 0.f;
+        dst[row * Lx + e] = row < nrows ? acc0[r] + acc1[r] - s_st[so + row] * c2 * xs[row * Lx + e] : 0.f;
       }
     }
   }
@@ -1264,7 +1266,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     float* sl = a.slab + (size_t)t * a.sl.total;
     const int nt = d.dw / 16, ww = d.dw * d.dw;
     // weight gradients dW[n][i] = sum_row dY[row][n] X[row][i]: 3 nt^2 tiles of 4 MFMAs over the waves
-    for (int it = wave; it < 3 * nt * nt; it += 4) {
+    for (int it = wave; it < 3 * nt * nt; it += 8) {
       const int pj = it / (nt * nt), rem = it - pj * nt * nt, j0 = (rem / nt) * 16, i0 = (rem % nt) * 16;
       lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
       lcptr x = pj == 0 ? s_xq : pj == 1 ? s_xc : s_rs;
@@ -1276,7 +1278,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
       for (int r = 0; r < 4; ++r) dst[(j0 + 4 * lq + r) * d.dw + i0 + lr] = acc[r];
     }
     // bias gradients: column sums
-    for (int i = tid; i < 3 * d.dw; i += 256) {
+    for (int i = tid; i < 3 * d.dw; i += 512) {
       const int pj = i / d.dw, n = i - pj * d.dw;
       lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
       float sum = 0.f;
@@ -1285,7 +1287,7 @@ __global__ __launch_bounds__(256) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
       sl[(pj == 0 ? a.sl.wq_b : pj == 1 ? a.sl.wk_b : a.sl.wv_b) + h * d.dw + n] = sum;
     }
     // input-gradient shares P[16][dw] = dY[16][dw] W_h[dw][dw]: 3 nt tiles, 16 weight loads in flight per trip
-    for (int it = wave; it < 3 * nt; it += 4) {
+    for (int it = wave; it < 3 * nt; it += 8) {
       const int pj = it / nt, i0 = (it - pj * nt) * 16;
       lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
       const float* wsel = (pj == 0 ? wq : pj == 1 ? wk : wv) + i0 + lr;
