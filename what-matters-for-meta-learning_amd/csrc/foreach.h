@@ -2,7 +2,7 @@
 //
 // Memory-bound glue (pool, aggregators, FAVOR+ feature maps, loss) is written as index
 // functors `f(i)`; on the GPU they run under a grid-stride kernel sized for 256 CUs, in the
-// hostsim flavour under a plain loop.  Reductions to a scalar run in ONE 256-thread workgroup
+// hostsim flavour under a plain loop.  Reductions to a scalar run in ONE 1024-thread workgroup
 // with a fixed-order LDS tree, so results are bitwise reproducible run to run.
 #pragma once
 #include "common.h"
@@ -15,14 +15,20 @@ __global__ __launch_bounds__(256) void foreach_kernel(const F f, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) f(i);
 }
 
+// 1024 threads, 4 independent strided accumulators per thread (4 loads in flight), then a fixed-order LDS tree
 template <class R>
-__global__ __launch_bounds__(256) void reduce1_kernel(const R r, int n) {
-  __shared__ typename R::T sm[256];
-  typename R::T acc = r.identity();
-  for (int i = threadIdx.x; i < n; i += 256) acc = r.combine(acc, r.load(i));
-  sm[threadIdx.x] = acc;
+__global__ __launch_bounds__(1024) void reduce1_kernel(const R r, int n) {
+  __shared__ typename R::T sm[1024];
+  typename R::T a0 = r.identity(), a1 = r.identity(), a2 = r.identity(), a3 = r.identity();
+  int i = threadIdx.x;
+  for (; i + 3072 < n; i += 4096) {
+    a0 = r.combine(a0, r.load(i)); a1 = r.combine(a1, r.load(i + 1024));
+    a2 = r.combine(a2, r.load(i + 2048)); a3 = r.combine(a3, r.load(i + 3072));
+  }
+  for (; i < n; i += 1024) a0 = r.combine(a0, r.load(i));
+  sm[threadIdx.x] = r.combine(r.combine(a0, a1), r.combine(a2, a3));
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = 512; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) sm[threadIdx.x] = r.combine(sm[threadIdx.x], sm[threadIdx.x + s]);
     __syncthreads();
   }
@@ -91,7 +97,7 @@ int run_reduce1(const R& r, int n, hipStream_t stream, const char* what) {
   return MLHOT_OK;
 #else
   ProfScope ps(what, stream);
-  hipLaunchKernelGGL((reduce1_kernel<R>), dim3(1), dim3(256), 0, stream, r, n);
+  hipLaunchKernelGGL((reduce1_kernel<R>), dim3(1), dim3(1024), 0, stream, r, n);
   return check_launch(what);
 #endif
 }
