@@ -54,6 +54,14 @@ for c, row in enumerate(calls):
 if v[500] > 0:
     print("conv12 fwd main loop of workgroup 0: %.0f shader cycles in %.1f us -> effective clock %.2f GHz" % (v[500], v[501] / 100.0, v[500] / (v[501] * 10.0) ))
 
+# per-wave band timeline of the forward conv12 kernel (7th band of workgroup 0): cycles from the earliest wave's start
+raw = ts.cpu()[400:448].view(12, 4).tolist()
+if raw[0][0]:
+    t0 = min(r[0] for r in raw)
+    print("per-wave band timeline [start, MFMA+conv1 done, epilogue done, barrier passed] (cycles):")
+    for w, r in enumerate(raw):
+        print("  wave %2d" % w, [x - t0 for x in r])
+
 # effective clock under back-to-back hipGraph replay (what bench.py times)
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())

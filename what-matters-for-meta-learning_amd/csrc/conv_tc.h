@@ -88,6 +88,15 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
 // ~1.5 GB of HBM traffic per step at 480 images.
 // ==================================================================================================
 
+// wave-uniform issue priority 0..2 (s_setprio takes an immediate).  With every wave at priority 0 the OLDEST wave of a
+// SIMD always wins the matrix pipe, finishes its band early and the youngest runs the tail alone; rotating the priority
+// among the waves of a SIMD keeps them in step.
+__device__ __forceinline__ void set_wave_prio(int pr) {
+  if (pr == 0) __builtin_amdgcn_s_setprio(0);
+  else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(2);
+}
+
 struct ImgSrc {           // two-segment image batch (context | target), [n][1][128][128]
   const float* p0; int n0; const float* p1;
   __device__ __forceinline__ const float* img(int i) const { return i < n0 ? p0 + (size_t)i * 16384 : p1 + (size_t)(i - n0) * 16384; }
@@ -207,6 +216,10 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     const int next = tile + (int)gridDim.x;
     const bool stage = next < ntiles && cact;
 
+#ifdef MLHOT_TS
+    const bool tsb = tf::g_ts_dev && blockIdx.x == 0 && (tile - (int)blockIdx.x) / (int)gridDim.x == 6;   // 7th band of workgroup 0
+    if (tsb && (lane == 0)) tf::g_ts_dev[400 + wave * 4 + 0] = clock64();
+#endif
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // 9 segments of 16 MFMAs.  The next band's a1 slice (3 M-tiles per wave) is produced after segments 3j + phase,
     // phase = wave / 4, so the three waves that share a SIMD (w, w + 4, w + 8) post-process their conv1 tiles (ReLU,
@@ -218,6 +231,8 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     }
 #pragma unroll
     for (int seg = 0; seg < 9; ++seg) {
+      // rotate the issue priority among the three waves of a SIMD once per segment
+      set_wave_prio((phase + seg) % 3);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int ks = seg * 8 + q;
@@ -235,6 +250,9 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
         }
       }
     }
+#ifdef MLHOT_TS
+    if (tsb && (lane == 0)) tf::g_ts_dev[400 + wave * 4 + 1] = clock64();
+#endif
     const int img = tile >> 3, band = tile & 7;
     float pv[2]; unsigned pa[2];
 #pragma unroll
@@ -250,7 +268,13 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     const size_t o = (((size_t)img * COUT + n) * 16 + 2 * band + rp) * 16 + 8 * ch + 2 * lq;
     *reinterpret_cast<float2*>(p2 + o) = make_float2(pv[0], pv[1]);
     *reinterpret_cast<unsigned short*>(amax + o) = (unsigned short)(pa[0] | (pa[1] << 8));
+#ifdef MLHOT_TS
+    if (tsb && (lane == 0)) tf::g_ts_dev[400 + wave * 4 + 2] = clock64();
+#endif
     __syncthreads();
+#ifdef MLHOT_TS
+    if (tsb && (lane == 0)) tf::g_ts_dev[400 + wave * 4 + 3] = clock64();
+#endif
   }
 #ifdef MLHOT_TS
   if (tf::g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0) {       // shader cycles and 100 MHz ticks of the main loop -> effective clock
