@@ -16,7 +16,14 @@
 //
 // Split-K: grid.z slices the reduction; partial tiles go to a [split][M][N] slab and a
 // second kernel sums the slab in a fixed order (bitwise reproducible, no atomics).
+//
+// Index hoisting: a gather problem may additionally describe how its indices factor (typedefs KEnt / RCtx / CCtx
+// with kent(k), rctx(m), cctx(n), A2(rctx, kent, m, k), B2(kent, cctx, k, n)).  A thread's staging slots keep the
+// same tile row / column for the whole kernel, so rctx / cctx are evaluated ONCE per slot, and the k-dependent
+// part once per k of a tile by BK threads (through LDS), instead of 5-8 run-time integer divisions for every
+// gathered element of every tile - the run-time-shaped convolutions were bound by that index arithmetic.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace mlhot {
@@ -31,6 +38,12 @@ struct SlabReduceArgs {
 #ifndef MLHOT_HOSTSIM
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class P, class = void> struct igemm_hoists : std::false_type {};
+template <class P> struct igemm_hoists<P, std::void_t<typename P::KEnt>> : std::true_type {};
+struct IgemmNoCtx {};
+template <class P, bool F> struct igemm_ctx { typedef IgemmNoCtx K; typedef IgemmNoCtx R; typedef IgemmNoCtx C; };
+template <class P> struct igemm_ctx<P, true> { typedef typename P::KEnt K; typedef typename P::RCtx R; typedef typename P::CCtx C; };
 
 constexpr int lds_ld16(int b) { return (b % 32 == 16) ? b : b + 16; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -55,6 +68,26 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
 
   constexpr int EA = (BM * BK + NT - 1) / NT, EB = (BN * BK + NT - 1) / NT;
   float ra[EA], rb[EB];
+  constexpr bool FAST = igemm_hoists<P>::value;
+  typedef igemm_ctx<P, FAST> CT;
+  __shared__ typename CT::K ktab[2][FAST ? BK : 1];
+  typename CT::R rctx[EA];
+  typename CT::C cctx[EB];
+  if constexpr (FAST) {
+#pragma unroll
+    for (int i = 0; i < EA; ++i) {
+      const int e = tid + i * NT, mm = AK ? e / BK : e % BM;
+      const int m = m0 + mm;
+      rctx[i] = p.rctx(m < p.M ? m : 0);
+    }
+#pragma unroll
+    for (int i = 0; i < EB; ++i) {
+      const int e = tid + i * NT, nn = BKc ? e / BK : e % BN;
+      const int n = n0 + nn;
+      cctx[i] = p.cctx(n < p.N ? n : 0);
+    }
+  }
+  int kt = 0;                       // which half of ktab the NEXT fetch reads
   f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -67,14 +100,24 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
       const int e = tid + i * NT;
       const int mm = AK ? e / BK : e % BM, kk = AK ? e % BK : e / BM;
       const int m = m0 + mm, k = k0 + kk;
-      ra[i] = (e < BM * BK && m < p.M && k < ke) ? p.A(m, k) : 0.f;
+      const bool ok = e < BM * BK && m < p.M && k < ke;
+      if constexpr (FAST) ra[i] = ok ? p.A2(rctx[i], ktab[kt][kk], m, k) : 0.f;
+      else ra[i] = ok ? p.A(m, k) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < EB; ++i) {
       const int e = tid + i * NT;
       const int nn = BKc ? e / BK : e % BN, kk = BKc ? e % BK : e / BN;
       const int n = n0 + nn, k = k0 + kk;
-      rb[i] = (e < BN * BK && n < p.N && k < ke) ? p.B(k, n) : 0.f;
+      const bool ok = e < BN * BK && n < p.N && k < ke;
+      if constexpr (FAST) rb[i] = ok ? p.B2(ktab[kt][kk], cctx[i], k, n) : 0.f;
+      else rb[i] = ok ? p.B(k, n) : 0.f;
+    }
+  };
+  // k-dependent index parts of the tile starting at k0 -> ktab[half] (BK threads; published by the next barrier)
+  auto ktile = [&](int k0, int half) {
+    if constexpr (FAST) {
+      if (tid < BK) { const int k = k0 + tid; ktab[half][tid] = p.kent(k < ke ? k : (ke > 0 ? ke - 1 : 0)); }
     }
   };
   auto stash = [&]() {
@@ -93,10 +136,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
   };
 
   const int lr = lane & 15, lk = lane >> 4;
+  if constexpr (FAST) {
+    ktile(kb, 0);
+    __syncthreads();
+  }
   if (kb < ke) fetch(kb);
   for (int k0 = kb; k0 < ke; k0 += BK) {
     stash();
+    if (k0 + BK < ke) ktile(k0 + BK, kt ^ 1);
     __syncthreads();
+    kt ^= 1;
     if (k0 + BK < ke) fetch(k0 + BK);  // next tile's gathers fly under this tile's MFMAs
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {

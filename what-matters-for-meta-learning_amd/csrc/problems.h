@@ -168,6 +168,26 @@ struct ConvFwdRT {
     if (relu && v < 0.f) v = 0.f;
     y[((size_t)img * c.Cout + n) * hw + r] = v;
   }
+  // hoisted index parts (igemm.h): same values as A / B above
+  struct KEnt { int off, ky, kx; };            // k -> (ci, ky, kx): ci*H*W + ky*W + kx
+  struct RCtx { int base, iy0, ix0; };         // m -> (img, oy, ox): img*Cin*H*W + iy0*W + ix0
+  struct CCtx { int woff; };
+  MLHOT_HD KEnt kent(int k) const {
+    const int kk = c.k * c.k, ci = k / kk, t = k % kk, ky = t / c.k, kx = t % c.k;
+    return KEnt{(ci * c.H + ky) * c.W + kx, ky, kx};
+  }
+  MLHOT_HD RCtx rctx(int m) const {
+    const int hw = c.HO * c.WO, img = m / hw, r = m % hw, oy = r / c.WO, ox = r % c.WO;
+    const int iy0 = oy * c.s - c.p, ix0 = ox * c.s - c.p;
+    return RCtx{img * c.Cin * c.H * c.W + iy0 * c.W + ix0, iy0, ix0};
+  }
+  MLHOT_HD CCtx cctx(int n) const { return CCtx{n * K}; }
+  MLHOT_HD float A2(const RCtx& r, const KEnt& e, int, int) const {
+    const int iy = r.iy0 + e.ky, ix = r.ix0 + e.kx;
+    if (iy < 0 || iy >= c.H || ix < 0 || ix >= c.W) return 0.f;
+    return x[r.base + e.off];
+  }
+  MLHOT_HD float B2(const KEnt&, const CCtx& cc, int k, int) const { return w[cc.woff + k]; }
 };
 
 // data gradient for the class of input positions y = s*y' + py, x = s*x' + px: only taps with
@@ -196,6 +216,29 @@ struct ConvDgradRT {
     const int img = m / (ny * nx), r = m % (ny * nx), yp = r / nx, xp = r % nx;
     dx[(((size_t)img * c.Cin + n) * c.H + c.s * yp + py) * c.W + c.s * xp + px] = v;
   }
+  // hoisted index parts (igemm.h)
+  struct KEnt { int co, ky, kx, woff; };        // k -> (co, ty, tx); woff = (co*Cin*k + ky)*k + kx
+  struct RCtx { int ibase, yb, xb; };           // m -> (img, y', x'): img*Cout*HO*WO, s*y'+py+p, s*x'+px+p
+  struct CCtx { int noff; };                    // n*k*k
+  MLHOT_HD KEnt kent(int k) const {
+    const int co = k % c.Cout, tt = k / c.Cout, tx = tt % ntx, ty = tt / ntx;
+    const int ky = ky0 + c.s * ty, kx = kx0 + c.s * tx;
+    return KEnt{co, ky, kx, (co * c.Cin * c.k + ky) * c.k + kx};
+  }
+  MLHOT_HD RCtx rctx(int m) const {
+    const int img = m / (ny * nx), r = m % (ny * nx), yp = r / nx, xp = r % nx;
+    return RCtx{img * c.Cout * c.HO * c.WO, c.s * yp + py + c.p, c.s * xp + px + c.p};
+  }
+  MLHOT_HD CCtx cctx(int n) const { return CCtx{n * c.k * c.k}; }
+  MLHOT_HD float A2(const RCtx& r, const KEnt& e, int, int) const {
+    const int ty_ = r.yb - e.ky, tx_ = r.xb - e.kx;           // multiples of s by construction of the class
+    if (ty_ < 0 || tx_ < 0) return 0.f;
+    const int oy = c.s == 1 ? ty_ : (c.s == 2 ? ty_ >> 1 : ty_ / c.s), ox = c.s == 1 ? tx_ : (c.s == 2 ? tx_ >> 1 : tx_ / c.s);
+    if (oy >= c.HO || ox >= c.WO) return 0.f;
+    const int o = r.ibase + (e.co * c.HO + oy) * c.WO + ox;
+    return (yact == nullptr || yact[o] > 0.f) ? dy[o] : 0.f;
+  }
+  MLHOT_HD float B2(const KEnt& e, const CCtx& cc, int, int) const { return w[e.woff + cc.noff]; }
 };
 
 struct ConvWgradRT {
@@ -219,6 +262,31 @@ struct ConvWgradRT {
   MLHOT_HD void store(int m, int n, float v) const {
     if (n == N - 1) { if (db) db[m] = v; }
     else dw[(size_t)m * (N - 1) + n] = v;
+  }
+  // hoisted index parts (igemm.h)
+  struct KEnt { int abase, xbase, iy0, ix0; };  // k -> (img, oy, ox): img*Cout*hw + r, img*Cin*H*W + iy0*W + ix0
+  struct RCtx { int moff; };                    // m*hw
+  struct CCtx { int off, ky, kx, bias; };       // n -> (ci, ky, kx): ci*H*W + ky*W + kx
+  MLHOT_HD KEnt kent(int k) const {
+    const int hw = c.HO * c.WO, img = k / hw, r = k % hw, oy = r / c.WO, ox = r % c.WO;
+    const int iy0 = oy * c.s - c.p, ix0 = ox * c.s - c.p;
+    return KEnt{img * c.Cout * hw + r, img * c.Cin * c.H * c.W + iy0 * c.W + ix0, iy0, ix0};
+  }
+  MLHOT_HD RCtx rctx(int m) const { return RCtx{m * c.HO * c.WO}; }
+  MLHOT_HD CCtx cctx(int n) const {
+    if (n == N - 1) return CCtx{0, 0, 0, 1};
+    const int kk = c.k * c.k, ci = n / kk, t = n % kk, ky = t / c.k, kx = t % c.k;
+    return CCtx{(ci * c.H + ky) * c.W + kx, ky, kx, 0};
+  }
+  MLHOT_HD float A2(const RCtx& r, const KEnt& e, int, int) const {
+    const int o = e.abase + r.moff;
+    return (yact == nullptr || yact[o] > 0.f) ? dy[o] : 0.f;
+  }
+  MLHOT_HD float B2(const KEnt& e, const CCtx& cc, int, int) const {
+    if (cc.bias) return 1.f;
+    const int iy = e.iy0 + cc.ky, ix = e.ix0 + cc.kx;
+    if (iy < 0 || iy >= c.H || ix < 0 || ix >= c.W) return 0.f;
+    return x[e.xbase + cc.off];
   }
 };
 
