@@ -169,8 +169,12 @@ def main():
     import mlhot
     from mlhot import dist as mdist, synth
     from trainer.losses import LossFunc
-    rank, local, world = mdist.init_from_env()
+    # MLHOT_DIST_BACKEND / MLHOT_ONE_DEVICE: test hooks (e.g. two gloo ranks sharing the only GPU of a 1-GPU box, to
+    # exercise the N>1 control flow); the driver's launch uses neither (nccl = RCCL, one rank per GPU)
+    rank, local, world = mdist.init_from_env(os.environ.get("MLHOT_DIST_BACKEND"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("MLHOT_ONE_DEVICE"):
+        local = 0
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     mlhot.build_product()
