@@ -170,17 +170,17 @@ inline int tail_launch(K kernel, int grid, int block, size_t lds, const A& args,
 }
 
 inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, float* mu,
-                              const NpBuf& b, hipStream_t s) {
+                              const NpBuf& b, const NpScratch& sc, hipStream_t s) {
   const tf::TailDims td = tail_dims(d);
   const tf::TailParams tp = tail_params(p);
   FavorDims f{d.T, MLHOT_HEADS, d.Nq, d.Nc, d.dim_w, d.m_feat};
   FavorWs w = favor_carve(f, b.favor, b.favor_bytes);
-  if (!w.ok) { set_error("tail_fused: favor workspace"); return MLHOT_ERR_WORKSPACE; }
+  if (!w.ok || !sc.d_merged) { set_error("tail_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
   tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, w.pc, w.max_k, w.arg_k};
   MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
-  tf::PhaseBArgs bb{td, tp, b.dec_in, b.rs, b.qh, b.vh, b.kh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged};
+  tf::PhaseBArgs bb{td, tp, b.dec_in, b.rs, b.qh, b.vh, b.kh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged, sc.d_merged};   // sc.d_merged: forward scratch for the heads' _W shares
   MLHOT_TRY(tail_launch(tf::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_lds_bytes(td), bb, s, "tail.B"));
-  tf::PhaseCArgs c{td, tp, b.merged, b.rr, b.dec_in, b.d1, b.d2, mu};
+  tf::PhaseCArgs c{td, tp, sc.d_merged, b.rr, b.dec_in, b.d1, b.d2, mu};
   MLHOT_TRY(tail_launch(tf::phaseC_fwd_kernel, d.T, 512, tf::phaseC_lds_bytes(td), c, s, "tail.C"));
   return MLHOT_OK;
 }
@@ -253,10 +253,10 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   FavorWs w = favor_carve(f, b.favor, b.favor_bytes);
   if (!w.ok || !sc.tail_slab) { set_error("tail_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
   float* part_k = w.rsum_k;   // [T*H]
-  tf::PhaseCBwdArgs c{td, tp, sl, dmu, mu, b.d2, b.d1, b.dec_in, b.rr, b.merged, sc.d_dec_in, sc.d_merged, sc.tail_slab};
+  tf::PhaseCBwdArgs c{td, tp, sl, dmu, mu, b.d2, b.d1, b.dec_in, b.rr, sc.d_dec_in, sc.d_rr, sc.tail_slab};
   MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
   // sc.dqh / dkh / dvh double as the heads' input-gradient shares [T*H][N][dw] (same sizes)
-  tf::PhaseBBwdArgs bb{td, tp, sl, b.qh, b.kh, b.vh, w.pc, w.qf, w.kf, w.S, w.D, b.merged, sc.d_merged, w.arg_q,
+  tf::PhaseBBwdArgs bb{td, tp, sl, b.qh, b.kh, b.vh, w.pc, w.qf, w.kf, w.S, w.D, b.merged, sc.d_rr, w.arg_q,
                        b.dec_in, b.cat_in, b.rs, sc.dqh, sc.dkh, sc.dvh, part_k, sc.tail_slab};
   MLHOT_TRY(tail_launch(tf::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_bwd_lds_bytes(td), bb, s, "tail.bwd.B"));
   tf::PhaseABwdArgs a{td, tp, sl, ctx_y, b.cat_in, b.h[0], b.h[1], sc.dqh, sc.dkh, sc.dvh, w.pc, part_k, w.gpos,
@@ -356,7 +356,7 @@ inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const fl
   // E1 on [context | target] images in one pass; rows land in cat_in / dec_in
   MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s));
 #ifndef MLHOT_HOSTSIM
-  if (tail_fused_applies(d)) return tail_forward_fused(d, p, ctx_y, mu, b, s);
+  if (tail_fused_applies(d)) return tail_forward_fused(d, p, ctx_y, mu, b, sc, s);
   if (cnp_fused_applies(d)) return cnp_forward_fused(d, p, ctx_y, mu, b, s);
 #endif
 

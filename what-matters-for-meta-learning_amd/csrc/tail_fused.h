@@ -521,6 +521,7 @@ struct PhaseBArgs {
   const float* tmax; const int* targ;      // per (task, head) key max shares
   float *qf, *kf, *S, *D, *gmax; int *arg_q, *gpos;
   float* merged;                           // [T*Nq][dw*H], column e*H + h
+  float* rrp;                              // [T*H][Nq][dw]: this head's share of _W(merged) (summed by phase C)
 };
 
 __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
@@ -531,6 +532,17 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
   const int t = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int Lx = ldpad(d.dw), Lf = ldpad(d.m);
+  // this head's slice of _W (the Linear(8 dw -> dw) after the head merge, column e*H + h of its weight): waves 0..dw/16-1
+  // request their operands for out[16][dw] . Wo_h[dw][16 j] now; they are consumed at the very end of the kernel
+  float wo_r[16];
+  {
+    const int jt = wave * 16 < d.dw ? wave : 0;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int e = 4 * ks + lq;
+      wo_r[ks] = a.p.wo_w[(size_t)(16 * jt + lr) * (H * d.dw) + (e < d.dw ? e : 0) * H + h];
+    }
+  }
   lptr s_q = L0;                    // [16][Lx]
   lptr s_k = s_q + 16 * Lx;
   lptr s_v = s_k + 16 * Lx;
@@ -734,7 +746,29 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = 4 * lq + r, e = et * 16 + lr;
-      if (n < d.Nq) a.merged[(size_t)(t * d.Nq + n) * (d.dw * H) + e * H + h] = acc[r] / s_st[48 + n];
+      const float o = n < d.Nq ? acc[r] / s_st[48 + n] : 0.f;
+      if (n < d.Nq) a.merged[(size_t)(t * d.Nq + n) * (d.dw * H) + e * H + h] = o;
+      s_xq[n * Lx + e] = o;                          // x_qry is no longer needed: the tile now holds this head's output
+    }
+  }
+  __syncthreads();
+  // share of rr = _W(merged): rrp[n][j] = sum_e out[n][e] Wo[j][e*H + h]
+  for (int jt = wave; jt * 16 < d.dw; jt += 8) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int e0 = 0; e0 < d.dw; e0 += 64) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int e = e0 + 4 * ks + lq;
+        if (e0 + 4 * ks < d.dw) {
+          const float bw = (e0 == 0 && jt == wave) ? wo_r[ks] : a.p.wo_w[(size_t)(16 * jt + lr) * (H * d.dw) + e * H + h];
+          acc = mfma4(s_xq[lr * Lx + e], bw, acc);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 4 * lq + r;
+      if (n < d.Nq) a.rrp[((size_t)(t * H + h) * d.Nq + n) * d.dw + 16 * jt + lr] = acc[r];
     }
   }
   MLHOT_TSTAMP(41);
@@ -750,7 +784,7 @@ __host__ inline size_t phaseB_lds_bytes(const TailDims& d) {
 // ==================================================================================================
 struct PhaseCArgs {
   TailDims d; TailParams p;
-  const float* merged;
+  const float* rrp;                        // [T*H][Nq][dw] per-head shares of _W(merged) from phase B
   float *rr, *dec_in, *d1, *d2, *mu;
 };
 
@@ -760,10 +794,9 @@ __global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ldd = d.dw + d.dz, HD = H * d.dw;
-  const int Lm = ldpad(HD), Lr = ldpad(d.dw), Ld = ldpad(ldd), Lh = ldpad(d.dec_h);
-  lptr s_m = L0;                 // [16][Lm]
-  lptr s_rr = s_m + 16 * Lm;
+  const int ldd = d.dw + d.dz;
+  const int Lr = ldpad(d.dw), Ld = ldpad(ldd), Lh = ldpad(d.dec_h);
+  lptr s_rr = L0;                 // [16][Lr]
   lptr s_dec = s_rr + 16 * Lr;
   lptr s_d1 = s_dec + 16 * Ld;
   lptr s_d2 = s_d1 + 16 * Lh;
@@ -771,24 +804,30 @@ __global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
   using PRM = TailParams;
   lu64 ptab = reinterpret_cast<lu64>(s_red + 8 * 256);
   ptab_fill(ptab, a.p, tid);
-  lds_zero(L0, 16 * (Lm + Lr + Ld + 2 * Lh), tid, 512);
+  lds_zero(L0, 16 * (Lr + Ld + 2 * Lh), tid, 512);
   __syncthreads();
   MLHOT_TSTAMP(65);
   gptr g_dec = G(a.dec_in) + (size_t)t * d.Nq * ldd;
   {
-    const LoadJob mj[1] = {load_job(s_m, Lm, a.merged + (size_t)t * d.Nq * HD, HD, d.Nq, HD)};
     const LoadJob xj[1] = {load_job(s_dec, Ld, a.dec_in + (size_t)t * d.Nq * ldd, ldd, d.Nq, d.dw)};     // x_qry
-    LoadBatch<1, 2, 8> mb;
     LoadBatch<1, 2, 1> xb;
-    mb.fetch(mj, tid, 8);
     xb.fetch(xj, tid, 8);
-    mb.stash(mj, tid, 8);
+    // rr = _W(merged) = bias + the 8 heads' shares (fixed order), all 8 loads of an element in flight together
+    for (int i = tid; i < d.Nq * d.dw; i += 512) {
+      const int n = i / d.dw, j = i - n * d.dw;
+      float v[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) v[h] = a.rrp[((size_t)(t * H + h) * d.Nq + n) * d.dw + j];
+      float sum = a.p.wo_b[j];
+#pragma unroll
+      for (int h = 0; h < H; ++h) sum += v[h];
+      s_rr[n * Lr + j] = sum;
+      a.rr[((size_t)t * d.Nq + n) * d.dw + j] = sum;
+    }
     xb.stash(xj, tid, 8);
   }
   __syncthreads();
   MLHOT_TSTAMP(66);
-  wg_linear<8>(s_m, Lm, HD, WB1(wo_w, wo_b, d.dw), d.dw, ACT_NONE, s_rr, Lr, G(a.rr + (size_t)t * d.Nq * d.dw), d.dw, d.Nq, s_red, wave, lane);
-  __syncthreads();
   MLHOT_TSTAMP(67);
   wg_linear<8>(s_rr, Lr, d.dw, WB1(r2z_w, r2z_b, d.dz), d.dz, ACT_NONE, s_dec + d.dw, Ld, g_dec + d.dw, ldd, d.Nq, s_red, wave, lane);
   __syncthreads();
@@ -804,7 +843,7 @@ __global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
 }
 
 __host__ inline size_t phaseC_lds_bytes(const TailDims& d) {
-  return sizeof(float) * (16 * (ldpad(H * d.dw) + ldpad(d.dw) + ldpad(d.dw + d.dz) + 2 * ldpad(d.dec_h)) + 8 * 256 + ptab_floats<TailParams>());
+  return sizeof(float) * (16 * (ldpad(d.dw) + ldpad(d.dw + d.dz) + 2 * ldpad(d.dec_h)) + 8 * 256 + ptab_floats<TailParams>());
 }
 
 // ==================================================================================================
@@ -980,12 +1019,13 @@ __host__ inline TailSlab tail_slab_layout(const TailDims& d) {
 // ==================================================================================================
 // phase C backward, one workgroup per task: decoder0, r_to_z and _W backward.
 //   in : dmu, saved mu / d2 / d1 / dec_in / rr / merged
-//   out: d_dec_in[:, :dw] (decoder's share of d x_qry), d_merged, weight-gradient slab entries
+//   out: d_dec_in[:, :dw] (decoder's share of d x_qry), d_rr (gradient of _W's output; _W's own backward runs per head in
+//        phase B), weight-gradient slab entries
 // ==================================================================================================
 struct PhaseCBwdArgs {
   TailDims d; TailParams p; TailSlab sl;
-  const float *dmu, *mu, *d2, *d1, *dec_in, *rr, *merged;
-  float *d_dec_in, *d_merged, *slab;
+  const float *dmu, *mu, *d2, *d1, *dec_in, *rr;
+  float *d_dec_in, *d_rr, *slab;
 };
 
 __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) {
@@ -994,15 +1034,14 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ldd = d.dw + d.dz, HD = H * d.dw;
-  const int Ly = ldpad(d.y_dim), Lh = ldpad(d.dec_h), Ld = ldpad(ldd), Lr = ldpad(d.dw), Lm = ldpad(HD);
+  const int ldd = d.dw + d.dz;
+  const int Ly = ldpad(d.y_dim), Lh = ldpad(d.dec_h), Ld = ldpad(ldd), Lr = ldpad(d.dw);
   lptr s_g = L0;                  // [16][Ly]   dmu * act'(mu)
   lptr s_d2 = s_g + 16 * Ly;       // saved activations
   lptr s_d1 = s_d2 + 16 * Lh;
   lptr s_dec = s_d1 + 16 * Lh;
   lptr s_rr = s_dec + 16 * Ld;
-  lptr s_m = s_rr + 16 * Lr;
-  lptr s_dd2 = s_m + 16 * Lm;      // gradients
+  lptr s_dd2 = s_rr + 16 * Lr;     // gradients
   lptr s_dd1 = s_dd2 + 16 * Lh;
   lptr s_ddec = s_dd1 + 16 * Lh;
   lptr s_drr = s_ddec + 16 * Ld;
@@ -1010,7 +1049,7 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   using PRM = TailParams;
   lu64 ptab = reinterpret_cast<lu64>(s_red + 8 * 256);
   ptab_fill(ptab, a.p, tid);
-  lds_zero(L0, 16 * (Ly + 4 * Lh + 2 * Ld + 2 * Lr + Lm), tid, 512);
+  lds_zero(L0, 16 * (Ly + 4 * Lh + 2 * Ld + 2 * Lr), tid, 512);
   __syncthreads();
   MLHOT_TSTAMP(97);
   const size_t rq = (size_t)t * d.Nq;
@@ -1024,13 +1063,9 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
         load_job(s_d1, Lh, a.d1 + rq * d.dec_h, d.dec_h, d.Nq, d.dec_h),
         load_job(s_dec, Ld, a.dec_in + rq * ldd, ldd, d.Nq, ldd),
         load_job(s_rr, Lr, a.rr + rq * d.dw, d.dw, d.Nq, d.dw)};
-    const LoadJob mj[1] = {load_job(s_m, Lm, a.merged + rq * HD, HD, d.Nq, HD)};
     LoadBatch<4, 2, 2> xb;
-    LoadBatch<1, 2, 8> mb;
     xb.fetch(xj, tid, 8);
-    mb.fetch(mj, tid, 8);
     xb.stash(xj, tid, 8);
-    mb.stash(mj, tid, 8);
   }
   __syncthreads();
   MLHOT_TSTAMP(98);
@@ -1058,16 +1093,20 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   MLHOT_TSTAMP(103);
   // r_to_z (dz = s_ddec[:, dw:])
   wg_wgrad<8>(s_ddec + d.dw, Ld, d.dz, s_rr, Lr, d.dw, sl + a.sl.r2z_w, sl + a.sl.r2z_b, wave, lane, tid);
-  wg_dgrad<8>(s_ddec + d.dw, Ld, d.dz, WB1N(r2z_w, d.dz), d.dw, s_drr, Lr, nullptr, 0, 0, false, s_red, wave, lane);
+  wg_dgrad<8>(s_ddec + d.dw, Ld, d.dz, WB1N(r2z_w, d.dz), d.dw, s_drr, Lr, G(a.d_rr + rq * d.dw), d.dw, d.Nq, false, s_red, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(104);
-  // _W
-  wg_wgrad<8>(s_drr, Lr, d.dw, s_m, Lm, HD, sl + a.sl.wo_w, sl + a.sl.wo_b, wave, lane, tid);
-  wg_dgrad<8>(s_drr, Lr, d.dw, WB1N(wo_w, d.dw), HD, nullptr, 0, G(a.d_merged + rq * HD), HD, d.Nq, false, s_red, wave, lane);
+  // _W: only its bias gradient here (column sums of d rr); weight and input gradient run per head in phase B
+  for (int j = tid; j < d.dw; j += 512) {
+    float sum = 0.f;
+#pragma unroll
+    for (int row = 0; row < 16; ++row) sum += s_drr[row * Lr + j];
+    sl[a.sl.wo_b + j] = sum;
+  }
   MLHOT_TSTAMP(105);
 }
 __host__ inline size_t phaseC_bwd_lds_bytes(const TailDims& d) {
-  return sizeof(float) * (16 * (ldpad(d.y_dim) + 4 * ldpad(d.dec_h) + 2 * ldpad(d.dw + d.dz) + 2 * ldpad(d.dw) + ldpad(H * d.dw)) + 8 * 256 +
+  return sizeof(float) * (16 * (ldpad(d.y_dim) + 4 * ldpad(d.dec_h) + 2 * ldpad(d.dw + d.dz) + 2 * ldpad(d.dw)) + 8 * 256 +
                           ptab_floats<TailParams>());
 }
 
@@ -1080,7 +1119,7 @@ __host__ inline size_t phaseC_bwd_lds_bytes(const TailDims& d) {
 // ==================================================================================================
 struct PhaseBBwdArgs {
   TailDims d; TailParams p; TailSlab sl;
-  const float *qh, *kh, *vh, *pc, *qf, *kf, *S, *D, *merged, *d_merged; const int* arg_q;
+  const float *qh, *kh, *vh, *pc, *qf, *kf, *S, *D, *merged, *d_rr; const int* arg_q;
   const float *dec_in, *cat_in, *rs;       // x_qry = dec_in[:, :dw], x_ctx = cat_in[:, :dw]
   float *pxq, *pxc, *prs, *part_k, *slab;
 };
@@ -1110,24 +1149,37 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   lptr s_dq = s_rs + 16 * Lx;        // ... and head-space gradients
   lptr s_dk = s_dq + 16 * Lx;
   lptr s_dv = s_dk + 16 * Lx;
-  const int total = 16 * (10 * Lx + 4 * Lf) + 2 * 16 * 17 + 64;
+  lptr s_o = s_dv + 16 * Lx;         // this head's attention output O (from merged) and d rr of the task (from phase C)
+  lptr s_drr = s_o + 16 * Lx;
+  const int total = 16 * (12 * Lx + 4 * Lf) + 2 * 16 * 17 + 64;
+  // _W's input gradient for this head, dO[n][e] = sum_j d rr[n][j] Wo[j][e*H + h]: waves 0..dw/16-1 request their operands now
+  float wo_r[16];
+  {
+    const int et = wave * 16 < d.dw ? wave : 0;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int j = 4 * ks + lq;
+      wo_r[ks] = a.p.wo_w[(size_t)(j < d.dw ? j : 0) * HD + (16 * et + lr) * H + h];
+    }
+  }
   lds_zero(L0, total, tid, 512);
   __syncthreads();
   MLHOT_TSTAMP(129);
   {
-    const LoadJob xj[7] = {
+    const LoadJob xj[8] = {
         load_job(s_q, Lx, a.qh + (size_t)t * d.Nq * HD + h * d.dw, HD, d.Nq, d.dw),
         load_job(s_k, Lx, a.kh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw),
         load_job(s_v, Lx, a.vh + (size_t)t * d.Nc * HD + h * d.dw, HD, d.Nc, d.dw),
         load_job(s_xq, Lx, a.dec_in + (size_t)t * d.Nq * (d.dw + d.dz), d.dw + d.dz, d.Nq, d.dw),
         load_job(s_xc, Lx, a.cat_in + (size_t)t * d.Nc * (d.dw + d.dw / 4), d.dw + d.dw / 4, d.Nc, d.dw),
         load_job(s_rs, Lx, a.rs + (size_t)t * d.Nc * d.dw, d.dw, d.Nc, d.dw),
-        // dO[n][e] = d_merged[(t,n)][e*H + h]
-        load_job(s_do, Lx, a.d_merged + (size_t)t * d.Nq * HD + h, HD, d.Nq, d.dw, H)};
+        // O[n][e] = merged[(t,n)][e*H + h]
+        load_job(s_o, Lx, a.merged + (size_t)t * d.Nq * HD + h, HD, d.Nq, d.dw, H),
+        load_job(s_drr, Lx, a.d_rr + (size_t)t * d.Nq * d.dw, d.dw, d.Nq, d.dw)};
     const LoadJob ej[2] = {
         load_job(s_qf, Lf, a.qf + ((size_t)t * d.Nq * H + h) * d.m, H * d.m, d.Nq, d.m),
         load_job(s_kf, Lf, a.kf + ((size_t)t * d.Nc * H + h) * d.m, H * d.m, d.Nc, d.m)};
-    LoadBatch<7, 2, 1> xb;
+    LoadBatch<8, 2, 1> xb;
     LoadBatch<2, 2, 5> eb;
     xb.fetch(xj, tid, 8);
     eb.fetch(ej, tid, 8);
@@ -1136,12 +1188,29 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   }
   if (tid < d.Nq) s_st[16 + tid] = a.D[((size_t)t * H + h) * d.Nq + tid];
   __syncthreads();
+  // dO tile (rows >= Nq of d rr are zero, so those rows of dO are zero too)
+  for (int et = wave; et * 16 < d.dw; et += 8) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < d.dw; j0 += 64) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int j = j0 + 4 * ks + lq;
+        if (j0 + 4 * ks < d.dw) {
+          const float bw = (j0 == 0 && et == wave) ? wo_r[ks] : a.p.wo_w[(size_t)j * HD + (16 * et + lr) * H + h];
+          acc = mfma4(s_drr[lr * Lx + j], bw, acc);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_do[(4 * lq + r) * Lx + 16 * et + lr] = acc[r];
+  }
+  __syncthreads();
   MLHOT_TSTAMP(130);
   if (tid < 256) {
     const int n = tid >> 4, part = tid & 15;
     float s = 0.f;
     if (n < d.Nq)
-      for (int e = part; e < d.dw; e += 16) s += s_do[n * Lx + e] * a.merged[(size_t)(t * d.Nq + n) * HD + e * H + h];
+      for (int e = part; e < d.dw; e += 16) s += s_do[n * Lx + e] * s_o[n * Lx + e];
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
     if (part == 0) s_st[n] = s;
@@ -1277,6 +1346,16 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) dst[(j0 + 4 * lq + r) * d.dw + i0 + lr] = acc[r];
     }
+    // _W's weight gradient for this head's columns: dWo[j][e*H + h] = sum_n d rr[n][j] O[n][e]
+    for (int it = wave; it < nt * nt; it += 8) {
+      const int j0 = (it / nt) * 16, e0 = (it % nt) * 16;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(s_drr[(4 * s4 + lq) * Lx + j0 + lr], s_o[(4 * s4 + lq) * Lx + e0 + lr], acc);
+      float* dst = sl + a.sl.wo_w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(size_t)(j0 + 4 * lq + r) * HD + (e0 + lr) * H + h] = acc[r];
+    }
     // bias gradients: column sums
     for (int i = tid; i < 3 * d.dw; i += 512) {
       const int pj = i / d.dw, n = i - pj * d.dw;
@@ -1320,7 +1399,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   MLHOT_TSTAMP(136);
 }
 __host__ inline size_t phaseB_bwd_lds_bytes(const TailDims& d) {
-  return sizeof(float) * (16 * (10 * ldpad(d.dw) + 4 * ldpad(d.m)) + 2 * 16 * 17 + 64);
+  return sizeof(float) * (16 * (12 * ldpad(d.dw) + 4 * ldpad(d.m)) + 2 * 16 * 17 + 64);
 }
 
 // ==================================================================================================
