@@ -20,7 +20,7 @@ struct NpBuf {   // forward activations kept for the backward ("saved")
   void* enc;
   float *cat_in, *h[MLHOT_MAX_HIDDEN], *rs, *dec_in, *d1, *d2;
   float *r, *sigma, *zt, *mu_l, *lv; int32_t* amax;
-  float *kh, *vh, *qh, *merged, *rr; void* favor; size_t favor_bytes;
+  float *kh, *vh, *qh, *merged, *rr, *wot; void* favor; size_t favor_bytes;
   bool ok; size_t bytes;
 };
 
@@ -40,6 +40,7 @@ inline NpBuf np_saved_carve(const mlhot_np_dims& d, void* base, size_t cap) {
     if (d.agg_mode == MLHOT_AGG_ATTENTION) {
       b.kh = a.take<float>(Rc * H * dw); b.vh = a.take<float>(Rc * H * dw); b.qh = a.take<float>(Rq * H * dw);
       b.merged = a.take<float>(Rq * H * dw); b.rr = a.take<float>(Rq * dw);
+      b.wot = a.take<float>((size_t)H * dw * dw);      // head-major copy of _W's weight (fused tail)
       FavorDims f{d.T, H, d.Nq, d.Nc, dw, d.m_feat};
       favor_carve(f, nullptr, 0, &b.favor_bytes);
       b.favor = a.take<char>(b.favor_bytes);
@@ -176,9 +177,9 @@ inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   FavorDims f{d.T, MLHOT_HEADS, d.Nq, d.Nc, d.dim_w, d.m_feat};
   FavorWs w = favor_carve(f, b.favor, b.favor_bytes);
   if (!w.ok || !sc.d_merged) { set_error("tail_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
-  tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, w.pc, w.max_k, w.arg_k};
+  tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, w.pc, w.max_k, w.arg_k, b.wot};
   MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
-  tf::PhaseBArgs bb{td, tp, b.dec_in, b.rs, b.qh, b.vh, b.kh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged, sc.d_merged};   // sc.d_merged: forward scratch for the heads' _W shares
+  tf::PhaseBArgs bb{td, tp, b.dec_in, b.rs, b.qh, b.vh, b.kh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged, sc.d_merged, b.wot};   // sc.d_merged: forward scratch for the heads' _W shares
   MLHOT_TRY(tail_launch(tf::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_lds_bytes(td), bb, s, "tail.B"));
   tf::PhaseCArgs c{td, tp, sc.d_merged, b.rr, b.dec_in, b.d1, b.d2, mu};
   MLHOT_TRY(tail_launch(tf::phaseC_fwd_kernel, d.T, 512, tf::phaseC_lds_bytes(td), c, s, "tail.C"));
@@ -257,7 +258,7 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
   // sc.dqh / dkh / dvh double as the heads' input-gradient shares [T*H][N][dw] (same sizes)
   tf::PhaseBBwdArgs bb{td, tp, sl, b.qh, b.kh, b.vh, w.pc, w.qf, w.kf, w.S, w.D, b.merged, sc.d_rr, w.arg_q,
-                       b.dec_in, b.cat_in, b.rs, sc.dqh, sc.dkh, sc.dvh, part_k, sc.tail_slab};
+                       b.dec_in, b.cat_in, b.rs, b.wot, sc.dqh, sc.dkh, sc.dvh, part_k, sc.tail_slab};
   MLHOT_TRY(tail_launch(tf::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_bwd_lds_bytes(td), bb, s, "tail.bwd.B"));
   tf::PhaseABwdArgs a{td, tp, sl, ctx_y, b.cat_in, b.h[0], b.h[1], sc.dqh, sc.dkh, sc.dvh, w.pc, part_k, w.gpos,
                       sc.d_dec_in, sc.d_cat_in, sc.tail_slab};

@@ -14,9 +14,9 @@
 // Rows of a task (<= 16 context / <= 16 target shots) are exactly one MFMA M-tile.
 //
 // GPU build only; requires Nc <= 16, Nq <= 16, attention mode.  The generic path (np_vanilla.h)
-// stays as the fallback for larger shot counts and as the A/B reference
-// (mlhot_set_option("tail_fused", 0)).  Both paths fill the same `saved` buffers, so forward and
-// backward of either flavour can be mixed (which is how each kernel here is tested in isolation).
+// stays as the fallback for larger shot counts and as the A/B reference of a whole forward+backward
+// (mlhot_set_option("tail_fused", 0)).  The fused backward consumes what the fused forward left behind
+// (packed key arg-max, head-major copy of _W's weight), so one step runs either flavour end to end.
 #pragma once
 #include "common.h"
 
@@ -360,6 +360,7 @@ struct PhaseAArgs {
   float *cat_in, *h0, *h1, *rs, *dec_in, *kh;             // saved activations (global)
   float* pc;                                              // [m][dw]  c * projection
   float* tmax; int* targ;                                 // per (task, head): max of ddk, packed (row * 4096 + col)
+  float* wot;                                             // [H][dw][dw] head-major copy of _W's weight: wot[h][j][e] = Wo[j][e*H + h]
 };
 
 // (value, packed position): larger value first, then the smaller position (row-major first occurrence)
@@ -377,6 +378,14 @@ __device__ __forceinline__ void phaseA_keyhead(const PhaseAArgs& a, lptr L0, int
   lu64 ptab = reinterpret_cast<lu64>(s_red + 16);
   ptab_fill(ptab, a.p, tid);
   lds_zero(L0, 32 * Lx, tid, 512);
+  if (t == 0) {
+    // head-major copy of _W's weight for phase B (forward and backward): the head-merge interleaves the heads in the
+    // column index (e*H + h), so a head's slice is a stride-H gather - done once here instead of in all T*H blocks
+    for (int i = tid; i < d.dw * d.dw; i += 512) {
+      const int j = i / d.dw, e = i - j * d.dw;
+      a.wot[(size_t)h * d.dw * d.dw + i] = a.p.wo_w[(size_t)j * HD + e * H + h];
+    }
+  }
   __syncthreads();
   lds_load(s_x, Lx, a.cat_in + (size_t)t * d.Nc * ldc, ldc, d.Nc, d.dw, tid, 512);
   __syncthreads();
@@ -522,6 +531,7 @@ struct PhaseBArgs {
   float *qf, *kf, *S, *D, *gmax; int *arg_q, *gpos;
   float* merged;                           // [T*Nq][dw*H], column e*H + h
   float* rrp;                              // [T*H][Nq][dw]: this head's share of _W(merged) (summed by phase C)
+  const float* wot;                        // [H][dw][dw] head-major _W weight (phase A)
 };
 
 __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
@@ -532,17 +542,6 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
   const int t = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int Lx = ldpad(d.dw), Lf = ldpad(d.m);
-  // this head's slice of _W (the Linear(8 dw -> dw) after the head merge, column e*H + h of its weight): waves 0..dw/16-1
-  // request their operands for out[16][dw] . Wo_h[dw][16 j] now; they are consumed at the very end of the kernel
-  float wo_r[16];
-  {
-    const int jt = wave * 16 < d.dw ? wave : 0;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int e = 4 * ks + lq;
-      wo_r[ks] = a.p.wo_w[(size_t)(16 * jt + lr) * (H * d.dw) + (e < d.dw ? e : 0) * H + h];
-    }
-  }
   lptr s_q = L0;                    // [16][Lx]
   lptr s_k = s_q + 16 * Lx;
   lptr s_v = s_k + 16 * Lx;
@@ -752,23 +751,24 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
     }
   }
   __syncthreads();
-  // share of rr = _W(merged): rrp[n][j] = sum_e out[n][e] Wo[j][e*H + h]
-  for (int jt = wave; jt * 16 < d.dw; jt += 8) {
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int e0 = 0; e0 < d.dw; e0 += 64) {
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int e = e0 + 4 * ks + lq;
-        if (e0 + 4 * ks < d.dw) {
-          const float bw = (e0 == 0 && jt == wave) ? wo_r[ks] : a.p.wo_w[(size_t)(16 * jt + lr) * (H * d.dw) + e * H + h];
-          acc = mfma4(s_xq[lr * Lx + e], bw, acc);
-        }
+  // share of rr = _W(merged): rrp[n][j] = sum_e out[n][e] Wo[j][e*H + h], Wo_h from the head-major copy (float4 along e)
+  {
+    const float* woh = a.wot + (size_t)h * d.dw * d.dw;
+    for (int jt = wave; jt * 16 < d.dw; jt += 8) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int k0 = 0; k0 < d.dw; k0 += 16) {
+        const int kk = k0 + 4 * lq;
+        const float4 b4 = *reinterpret_cast<const float4*>(woh + (size_t)(16 * jt + lr) * d.dw + kk);
+        lcptr xp = s_xq + lr * Lx + kk;
+        acc = mfma4(xp[0], b4.x, acc); acc = mfma4(xp[1], b4.y, acc);
+        acc = mfma4(xp[2], b4.z, acc); acc = mfma4(xp[3], b4.w, acc);
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = 4 * lq + r;
-      if (n < d.Nq) a.rrp[((size_t)(t * H + h) * d.Nq + n) * d.dw + 16 * jt + lr] = acc[r];
+      for (int r = 0; r < 4; ++r) {
+        const int n = 4 * lq + r;
+        if (n < d.Nq) a.rrp[((size_t)(t * H + h) * d.Nq + n) * d.dw + 16 * jt + lr] = acc[r];
+      }
     }
   }
   MLHOT_TSTAMP(41);
@@ -1121,6 +1121,7 @@ struct PhaseBBwdArgs {
   TailDims d; TailParams p; TailSlab sl;
   const float *qh, *kh, *vh, *pc, *qf, *kf, *S, *D, *merged, *d_rr; const int* arg_q;
   const float *dec_in, *cat_in, *rs;       // x_qry = dec_in[:, :dw], x_ctx = cat_in[:, :dw]
+  const float* wot;                        // [H][dw][dw] head-major _W weight (phase A of the forward)
   float *pxq, *pxc, *prs, *part_k, *slab;
 };
 
@@ -1152,16 +1153,6 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   lptr s_o = s_dv + 16 * Lx;         // this head's attention output O (from merged) and d rr of the task (from phase C)
   lptr s_drr = s_o + 16 * Lx;
   const int total = 16 * (12 * Lx + 4 * Lf) + 2 * 16 * 17 + 64;
-  // _W's input gradient for this head, dO[n][e] = sum_j d rr[n][j] Wo[j][e*H + h]: waves 0..dw/16-1 request their operands now
-  float wo_r[16];
-  {
-    const int et = wave * 16 < d.dw ? wave : 0;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int j = 4 * ks + lq;
-      wo_r[ks] = a.p.wo_w[(size_t)(j < d.dw ? j : 0) * HD + (16 * et + lr) * H + h];
-    }
-  }
   lds_zero(L0, total, tid, 512);
   __syncthreads();
   MLHOT_TSTAMP(129);
@@ -1188,21 +1179,31 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   }
   if (tid < d.Nq) s_st[16 + tid] = a.D[((size_t)t * H + h) * d.Nq + tid];
   __syncthreads();
-  // dO tile (rows >= Nq of d rr are zero, so those rows of dO are zero too)
-  for (int et = wave; et * 16 < d.dw; et += 8) {
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < d.dw; j0 += 64) {
+  // _W's input gradient for this head: dO[n][e] = sum_j d rr[n][j] Wo[j][e*H + h] (head-major copy: coalesced along e);
+  // rows >= Nq of d rr are zero, so those rows of dO are zero too
+  {
+    const float* woh = a.wot + (size_t)h * d.dw * d.dw;
+    for (int et = wave; et * 16 < d.dw; et += 8) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      for (int j0 = 0; j0 < d.dw; j0 += 64) {
+        float bw[16];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int j = j0 + 4 * ks + lq;
-        if (j0 + 4 * ks < d.dw) {
-          const float bw = (j0 == 0 && et == wave) ? wo_r[ks] : a.p.wo_w[(size_t)j * HD + (16 * et + lr) * H + h];
-          acc = mfma4(s_drr[lr * Lx + j], bw, acc);
+        for (int u = 0; u < 16; ++u) {
+          const int j = j0 + 16 * (u >> 2) + 4 * lq + (u & 3);
+          bw[u] = woh[(size_t)(j < d.dw ? j : d.dw - 1) * d.dw + 16 * et + lr];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (j0 + 16 * ks < d.dw) {
+            lcptr ap = s_drr + lr * Lx + j0 + 16 * ks + 4 * lq;
+            acc = mfma4(ap[0], bw[4 * ks], acc); acc = mfma4(ap[1], bw[4 * ks + 1], acc);
+            acc = mfma4(ap[2], bw[4 * ks + 2], acc); acc = mfma4(ap[3], bw[4 * ks + 3], acc);
+          }
         }
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s_do[(4 * lq + r) * Lx + 16 * et + lr] = acc[r];
+      for (int r = 0; r < 4; ++r) s_do[(4 * lq + r) * Lx + 16 * et + lr] = acc[r];
+    }
   }
   __syncthreads();
   MLHOT_TSTAMP(130);
