@@ -215,7 +215,7 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
   }
   __syncthreads();
   if (ph == 0) {
-    float* sw = slab_w + (size_t)blockIdx.x * (COUT * KW);
+    float* sw = slab_w + (size_t)blockIdx.x * (COUT * KW + COUT);      // slab row = [weights | bias]
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     const int e = tid + j * W_NT;
-    if ((lane & 15) == 0 && e < 1024) slab_b[(size_t)blockIdx.x * COUT + (e >> 4)] = v;
+    if ((lane & 15) == 0 && e < 1024) slab_b[(size_t)blockIdx.x * (COUT * KW + COUT) + (e >> 4)] = v;
   }
 }
 

@@ -49,8 +49,8 @@ __device__ __forceinline__ void patch_zero_pad(float* patch, int tid) {
 
 // out[e] = sum_p slab[p][e]  (fixed order -> bitwise reproducible).  256 threads = 16 float4 column groups x
 // 16 slab lanes; a lane walks its slabs 4 at a time (4 independent float4 loads in flight), then a
-// fixed-order LDS fold of the 16 lanes.  grid = ceil(len / 64); len must be a multiple of 4.
-__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ slab, int nparts, int len, float* __restrict__ out) {
+// fixed-order LDS fold of the 16 lanes.  grid = ceil(len / 64); len and the slab row stride must be multiples of 4.
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ slab, int nparts, int len, float* __restrict__ out, int stride) {
   __shared__ float4 sm[16][16];
   const int cx = threadIdx.x & 15, zl = threadIdx.x >> 4;
   const int e = (blockIdx.x * 16 + cx) * 4;
@@ -59,13 +59,13 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
   if (e < len) {
     int z = zl;
     for (; z + 48 < nparts; z += 64) {
-      const float4 v0 = *reinterpret_cast<const float4*>(slab + (size_t)z * len + e);
-      const float4 v1 = *reinterpret_cast<const float4*>(slab + (size_t)(z + 16) * len + e);
-      const float4 v2 = *reinterpret_cast<const float4*>(slab + (size_t)(z + 32) * len + e);
-      const float4 v3 = *reinterpret_cast<const float4*>(slab + (size_t)(z + 48) * len + e);
+      const float4 v0 = *reinterpret_cast<const float4*>(slab + (size_t)z * stride + e);
+      const float4 v1 = *reinterpret_cast<const float4*>(slab + (size_t)(z + 16) * stride + e);
+      const float4 v2 = *reinterpret_cast<const float4*>(slab + (size_t)(z + 32) * stride + e);
+      const float4 v3 = *reinterpret_cast<const float4*>(slab + (size_t)(z + 48) * stride + e);
       add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3);
     }
-    for (; z < nparts; z += 16) add(s0, *reinterpret_cast<const float4*>(slab + (size_t)z * len + e));
+    for (; z < nparts; z += 16) add(s0, *reinterpret_cast<const float4*>(slab + (size_t)z * stride + e));
   }
   add(s0, s1); add(s2, s3); add(s0, s2);
   sm[zl][cx] = s0;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
   }
   __syncthreads();
   if (ph == 0) {
-    float* sw = slab_w + (size_t)blockIdx.x * (COUT * CIN * 9);
+    float* sw = slab_w + (size_t)blockIdx.x * (COUT * CIN * 9 + COUT);      // slab row = [weights | bias]
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int mt = 3 * mg + i, tap = mt >> 1;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
     float v = bsum[j];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((lane & 31) == 0) slab_b[(size_t)blockIdx.x * COUT + ((tid + j * NT) >> 5)] = v;
+    if ((lane & 31) == 0) slab_b[(size_t)blockIdx.x * (COUT * CIN * 9 + COUT) + ((tid + j * NT) >> 5)] = v;
   }
 }
 

@@ -179,8 +179,11 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
 #ifndef MLHOT_HOSTSIM
   if (g_opt.conv2_tc) {
     const int grid = n < C2_GRID ? n : C2_GRID;
+    // one slab row per workgroup = [dW (64*432) | db (64)]: when the caller's gradient tensors are adjacent in that order
+    // (mlhot_np_grads_flat_layout) the weights and the bias reduce in ONE launch
+    constexpr int L3 = 64 * 432, R3 = L3 + 64;
     float* slab_w = sc.slab;
-    float* slab_b = sc.slab + (size_t)C2_GRID * 64 * 432;
+    float* slab_b = sc.slab + L3;
     {
       ProfScope ps("enc.bwd.conv3.wgrad", s);
       hipLaunchKernelGGL(c3::conv3_wgrad_kernel, dim3(grid), dim3(c3::W_NT), 0, s, sv.p2, sc.dy3, slab_w, slab_b, n);
@@ -188,8 +191,12 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     MLHOT_TRY(check_launch("enc.bwd.conv3.wgrad"));
     {
       ProfScope ps("slab_reduce", s);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(64 * 432 / 64), dim3(256), 0, s, slab_w, grid, 64 * 432, g.w3);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 64, g.b3);
+      if (g.b3 == g.w3 + L3 && (reinterpret_cast<uintptr_t>(g.w3) & 15) == 0) {
+        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3((R3 + 63) / 64), dim3(256), 0, s, slab_w, grid, R3, g.w3, R3);
+      } else {
+        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(L3 / 64), dim3(256), 0, s, slab_w, grid, L3, g.w3, R3);
+        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 64, g.b3, R3);
+      }
     }
     MLHOT_TRY(check_launch("enc.bwd.conv3.wgrad.reduce"));
     {
@@ -214,9 +221,10 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
 #ifndef MLHOT_HOSTSIM
   if (g_opt.conv2_tc) {
     const int grid = n * 8 < C2_GRID ? n * 8 : C2_GRID;
+    constexpr int L2 = 48 * 288, R2 = L2 + 48;          // slab row = [dW2 | db2], see conv3 above
     float* slab_w = sc.slab;
-    float* slab_b = sc.slab + (size_t)2 * C2_GRID * 48 * 288;
-    float* slab_1 = slab_b + (size_t)C2_GRID * 48;
+    float* slab_b = sc.slab + L2;
+    float* slab_1 = sc.slab + (size_t)C2_GRID * R2;
     const c2::ImgSrc xs{img0, n0, img1};
     {
       ProfScope ps("enc.bwd.conv12.wgrad", s);
@@ -225,8 +233,12 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     MLHOT_TRY(check_launch("enc.bwd.conv12.wgrad"));
     {
       ProfScope ps("slab_reduce", s);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(48 * 288 / 64), dim3(256), 0, s, slab_w, grid, 48 * 288, g.w2);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 48, g.b2);
+      if (g.b2 == g.w2 + L2 && (reinterpret_cast<uintptr_t>(g.w2) & 15) == 0) {
+        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3((R2 + 63) / 64), dim3(256), 0, s, slab_w, grid, R2, g.w2, R2);
+      } else {
+        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(L2 / 64), dim3(256), 0, s, slab_w, grid, L2, g.w2, R2);
+        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 48, g.b2, R2);
+      }
     }
     MLHOT_TRY(check_launch("enc.bwd.conv2.wgrad.reduce"));
     {

@@ -214,7 +214,7 @@ inline int tail_slab_reduce(tf::SlabReduce& r, hipStream_t s) {
   for (int i = 1; flat && i < r.nseg; ++i) flat = r.dst[i] == r.dst[0] + r.off[i];
   {
     ProfScope ps("tail.bwd.reduce", s);
-    if (flat) hipLaunchKernelGGL(c2::sum_parts_kernel, dim3((r.total + 63) / 64), dim3(256), 0, s, r.slab, r.T, r.total, r.dst[0]);
+    if (flat) hipLaunchKernelGGL(c2::sum_parts_kernel, dim3((r.total + 63) / 64), dim3(256), 0, s, r.slab, r.T, r.total, r.dst[0], r.total);
     else hipLaunchKernelGGL(tf::slab_to_grads_kernel, dim3((r.total + 255) / 256), dim3(256), 0, s, r);
   }
   return check_launch("tail.bwd.reduce");
