@@ -112,6 +112,88 @@ def _time_graph(fn, iters):
     return 1e3 * (time.perf_counter() - t0) / iters
 
 
+def _capture(fn):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    return graph
+
+
+def measure_host_fed(w, device, loss_fn, model, iters):
+    """PCIe-inclusive view of the same step when every batch starts in HOST memory (the reference's loaders hand over host
+    batches, trainer/model_trainer.py:63-70); never the headline `value`.
+      reference route: fp32 channel-first host tensors (converted on the host), `.copy_` from pageable memory, then the step;
+      ingest route   : uint8 channel-last host arrays -> pinned staging -> H2D on a copy stream while the previous step
+                       computes -> mlhot_ingest_u8_nhwc -> the step (mlhot.ingest.BatchIngest)."""
+    from mlhot import synth
+    from mlhot.ingest import BatchIngest
+    hb = synth.get_batch_u8("shapenet_1d", T_LOCAL, NC, NQ, seed=1234)
+    ing = BatchIngest(device)
+    ing.stage(*hb)
+    cx, qx, cy, qy = ing.take()                                    # the fixed device tensors every later take() refills
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+
+    graph = _capture(step)
+    out = {}
+    # ingest route, steady state
+    ing.stage(*hb)
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            ing.take()
+            graph.replay()
+            ing.stage(*hb)                                          # host memcpy into pinned staging + async H2D of the next batch
+        torch.cuda.synchronize()
+        if timed:
+            out["ingest_route_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / iters
+    ing.take()
+    # the ingest kernels alone (2 launches: context + target images)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ing.stage(*hb)
+    torch.cuda.synchronize()
+    import mlhot
+    L, slot = mlhot.lib(), ing._queue[0][1]
+    ev[0].record()
+    for _ in range(iters):
+        L.ingest_u8_nhwc(slot.dev[0], out=cx)
+        L.ingest_u8_nhwc(slot.dev[1], out=qx)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ing.take()
+    ingest_ms = ev[0].elapsed_time(ev[1]) / iters
+    nbytes = 5 * (hb[0].size + hb[1].size)                          # 1 byte read + 4 written per pixel
+    out["ingest_kernels_us_per_batch"] = 1e3 * ingest_ms
+    out["ingest_kernels_GBps"] = nbytes / (ingest_ms * 1e-3) / 1e9
+    # reference route: host conversion done (not timed), pageable fp32 tensors copied synchronously, then the step
+    host = [synth.host_convert(hb[0]), synth.host_convert(hb[1]), hb[2], hb[3]]
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(3, iters // 4)):
+            for d_, h in zip((cx, qx, cy, qy), host):
+                d_.copy_(h)
+            graph.replay()
+        torch.cuda.synchronize()
+        if timed:
+            out["reference_route_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / max(3, iters // 4)
+    out["host_bytes_per_batch"] = {"ingest_route": int(hb[0].size + hb[1].size + 4 * (hb[2].numel() + hb[3].numel())),
+                                   "reference_route": int(sum(4 * t.numel() for t in host))}
+    out["tasks_per_s_host_fed"] = {"ingest_route": 1e3 * T_LOCAL / out["ingest_route_ms_per_step"],
+                                   "reference_route": 1e3 * T_LOCAL / out["reference_route_ms_per_step"]}
+    return out
+
+
 def measure_extras(w, device, loss_fn, batch, iters):
     """Not the headline metric: (a) the training forward alone (activations saved, no backward), (b) the full step
     followed by the fused flat Adam update (mlhot.optim.FlatAdam: one launch over the flat parameter buffer).  The Adam
@@ -145,6 +227,9 @@ def measure_extras(w, device, loss_fn, batch, iters):
         torch.cuda.synchronize()
         out["h2d_ms_per_batch"] = 1e3 * (time.perf_counter() - t0) / iters
         out["h2d_mbytes_per_batch"] = sum(t.numel() * 4 for t in host) / 1e6
+        del opt                                                      # FlatAdam re-pointed the parameters; build a fresh model
+        model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(make_cfg(w, device)).to(device)
+        out["host_fed"] = measure_host_fed(w, device, loss_fn, model, iters)
         return out
     except Exception as e:  # noqa: BLE001 - extras must never break the bench line
         return {"error": f"{type(e).__name__}: {e}"}

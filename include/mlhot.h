@@ -142,6 +142,13 @@ int mlhot_bbb_sample_fwd(const float* mu, const float* rho, const float* eps, fl
 int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, const float* dw, const float* dkl, float* dmu, float* drho,
                          size_t n, void* stream);
 
+/* ---- batch ingest: the host-side image conversion of the data loaders, on the device ----
+ * dst[n][c][y][x] = (float)src[n][y][x][c] / div, i.e. dataset/shapenet_1d.py:189-190 (`xs.astype(np.float32) / 255.0`;
+ * same in dataset/pascal_1d.py, shapenet_3d.py, distractor.py) followed by utils/utils.py:26-30
+ * (convert_channel_last_np_to_tensor: permute(0,1,4,2,3).contiguous()).  Bit-identical to that host arithmetic (IEEE
+ * fp32 divide).  src: n_img*H*W*C bytes packed channel-last (4-byte aligned for the fast path), dst: n_img*C*H*W floats. */
+int mlhot_ingest_u8_nhwc(const uint8_t* src, float* dst, long n_img, int H, int W, int C, float div, void* stream);
+
 /* ---- optimizer: torch.optim.Adam (train.py:52-56) as ONE launch over flat buffers -------------------
  * param / grad / exp_avg / exp_avg_sq: n floats each, laid out alike (e.g. mlhot_np_grads_flat_layout).
  * step >= 1 is the 1-based update count (bias correction); grad_scale multiplies the gradient first

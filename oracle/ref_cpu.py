@@ -21,6 +21,7 @@ Parameters are passed as plain dicts keyed exactly like the reference's
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -493,3 +494,16 @@ def conv_embedding_forward(x, p, num_conv=4, pooling="avg", bn_eps=1e-5):
     emb = hid.mean(dim=0, keepdim=True) if pooling == "avg" else hid.max(dim=0, keepdim=True)[0]
     n_heads = sum(1 for k_ in p if k_.startswith("_embeddings.") and k_.endswith(".weight"))
     return [F.linear(emb, p[f"_embeddings.{i}.weight"], p[f"_embeddings.{i}.bias"]) for i in range(n_heads)]
+
+
+# --------------------------------------------------------------------------------------
+# Batch ingest (the loaders' host-side image conversion)   (dataset/shapenet_1d.py:189-196, utils/utils.py:26-30)
+# --------------------------------------------------------------------------------------
+
+
+def ingest_images(u8, div=255.0):
+    """uint8 [T, N, H, W, C] -> float32 [T, N, C, H, W]: numpy `astype(float32) / 255.0` (shapenet_1d.py:189-190, same
+    line in pascal_1d.py / shapenet_3d.py / distractor.py), then convert_channel_last_np_to_tensor's
+    `permute(0, 1, 4, 2, 3).contiguous()` (utils/utils.py:26-30)."""
+    x = np.asarray(u8).astype(np.float32) / div
+    return torch.from_numpy(x).type(torch.FloatTensor).permute(0, 1, 4, 2, 3).contiguous()

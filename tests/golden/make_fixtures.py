@@ -354,6 +354,22 @@ def run_conv_embedding_case():
     print("conv_embedding: ok", [tuple(e.shape) for e in embs])
 
 
+def run_ingest_case():
+    """Host-side image conversion of the loaders: the divide restates dataset/shapenet_1d.py:189-190 (that method needs the
+    LFS data files to run), the layout change is the reference's own utils.utils.convert_channel_last_np_to_tensor."""
+    conv = importlib.import_module("utils.utils").convert_channel_last_np_to_tensor
+    rng = np.random.RandomState(5)
+    out = {}
+    for C, (H, W) in ((1, (8, 12)), (3, (8, 8)), (4, (6, 10)), (2, (5, 3))):
+        u8 = rng.randint(0, 256, size=(2, 3, H, W, C)).astype(np.uint8)
+        n = min(256, u8.size)
+        u8.reshape(-1)[:n] = np.arange(n, dtype=np.uint8)      # every byte value appears (where the case is large enough)
+        out[f"c{C}/u8"] = u8
+        out[f"c{C}/f32"] = np32(conv(u8.astype(np.float32) / 255.0))
+    np.savez_compressed(os.path.join(OUT, "ingest.npz"), **out)
+    print("ingest", {k: v.shape for k, v in out.items()})
+
+
 def main():
     assert os.path.isdir(REF), "the reference is only available in the build container"
     install_stubs()
@@ -380,6 +396,8 @@ def main():
         run_loss_cases(LossFunc)
     if not only or "conv_embedding" in only:
         run_conv_embedding_case()
+    if not only or "ingest" in only:
+        run_ingest_case()
 
 
 if __name__ == "__main__":

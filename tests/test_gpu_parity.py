@@ -435,6 +435,86 @@ def test_model_trainer_loop_on_synthetic_data(gpulib, tmp_path, monkeypatch):
     assert moved > 0 and all(torch.isfinite(v).all() for v in model.state_dict().values())
 
 
+# ---- batch ingest: uint8 channel-last -> fp32 channel-first on the device ------------
+def test_ingest_kernel_bit_exact_vs_reference_vectors(gpulib):
+    fx = np.load(os.path.join(U.GOLDEN, "ingest.npz"))
+    for C in (1, 2, 3, 4):
+        got = gpulib.ingest_u8_nhwc(torch.from_numpy(fx[f"c{C}/u8"]).to(DEV))
+        assert np.array_equal(got.cpu().numpy(), fx[f"c{C}/f32"]), C
+
+
+@pytest.mark.parametrize("shape", [(16, 15, 128, 128, 1), (8, 15, 64, 64, 4), (2, 3, 64, 64, 3), (3, 1, 7, 5, 3), (1, 2, 9, 9, 1),
+                                   (2, 0, 128, 128, 1), (1, 1, 2, 2, 2), (5, 128, 128, 1)])
+def test_ingest_kernel_bit_exact_vs_oracle(gpulib, shape):
+    """Every byte value, the quad fast path (H*W % 4 == 0, C <= 4) and the any-shape path, an empty batch; full c3 / c5 sizes."""
+    g = torch.Generator().manual_seed(11)
+    u8 = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+    got = gpulib.ingest_u8_nhwc(u8.to(DEV))
+    want = O.ingest_images(u8.numpy().reshape((1,) * (5 - len(shape)) + shape)).reshape(got.shape)
+    assert got.dtype == torch.float32 and torch.equal(got.cpu(), want)
+
+
+def test_batch_ingest_pipeline_matches_host_conversion(gpulib):
+    """Pinned staging + copy stream + ingest kernel: batches come out bit-identical to the reference's host conversion,
+    in ticket order, while later batches are already in flight; slot exhaustion and CPU devices are refused."""
+    from mlhot.binding import MlhotError
+    from mlhot.ingest import BatchIngest
+    from mlhot import synth
+    ing = BatchIngest(DEV)
+    batches = [synth.get_batch_u8("shapenet_1d", 4, nc, 15, seed=100 + i) for i, nc in enumerate((15, 15, 7, 15, 3))]
+    want = [(synth.host_convert(b[0]), synth.host_convert(b[1]), b[2], b[3]) for b in batches]
+    ing.stage(*batches[0])
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            ing.stage(*batches[i + 1])                     # copy of batch i+1 overlaps with the use of batch i
+        got = ing.take()
+        junk = torch.randn(512, 512, device=DEV) @ torch.randn(512, 512, device=DEV)   # keep the compute stream busy
+        for g_, w_ in zip(got, want[i]):
+            assert torch.equal(g_.cpu(), w_), i
+        del junk
+    t0, t1 = ing.stage(*batches[0]), ing.stage(*batches[1])
+    with pytest.raises(MlhotError):
+        ing.stage(*batches[3])                             # a third batch of the same shape: both slots are busy
+    assert torch.equal(ing.take(t1)[0].cpu(), want[1][0])  # out of order by ticket
+    assert torch.equal(ing.take(t0)[0].cpu(), want[0][0])
+    with pytest.raises(MlhotError):
+        ing.take()
+    with pytest.raises(MlhotError):
+        BatchIngest("cpu")
+
+
+def test_trainer_ingest_path_equals_host_path(gpulib, tmp_path, monkeypatch):
+    """The trainer fed through BatchIngest (uint8 over PCIe, prefetched) walks exactly the trajectory of the reference's
+    route (host conversion, `.to(device)`): same draws, bit-identical inputs, identical final weights."""
+    import types
+    from mlhot import synth
+    from networks.CNPShapeNet1D import CNPShapeNet1D
+    from trainer.losses import LossFunc
+    from trainer.model_trainer import ModelTrainer
+    monkeypatch.chdir(tmp_path)
+
+    class HostData(synth.SyntheticData):
+        def get_batch(self, source, tasks_per_batch, shot):
+            xs, xq, ys, yq = synth.SyntheticData.get_batch_u8(self, source, tasks_per_batch, shot)
+            return synth.host_convert(xs), synth.host_convert(xq), ys, yq
+
+    finals = []
+    for use_ingest in (True, False):
+        cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[128, 128, 1], tasks_per_batch=2, input_dim=3,
+                                    output_dim=2, agg_mode="mean", img_agg="", dim_w=64, n_hidden_units_r=[100, 100], dim_r=100,
+                                    dim_z=64, task="shapenet_1d", iterations=5, val_freq=2, val_iters=2, bg_gen_freq=1000,
+                                    gen_bg=False, max_ctx_num=6, beta=0, contrastive=False, ingest_u8=use_ingest,
+                                    save_path=str(tmp_path / f"run{int(use_ingest)}"), logger=None)
+        model = CNPShapeNet1D(cfg).to(cfg.device)
+        trainer = ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=torch.optim.Adam(model.parameters(), lr=1e-3),
+                               config=cfg, data=HostData())
+        assert (trainer.ingest is not None) == use_ingest
+        trainer.train()
+        finals.append({k: v.clone() for k, v in model.state_dict().items()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+
+
 def test_cpu_tensors_are_refused(gpulib):
     from mlhot.binding import MlhotError
     from mlhot.ops import LinearFunction

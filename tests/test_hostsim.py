@@ -110,3 +110,19 @@ def test_adam_step_matches_torch_adam(hostsim):
             opt.step()
             hostsim.adam_step(p, grad, m, v, 1e-2, 0.9, 0.999, 1e-8, wd, scale, t)
             assert U.rel_err(p, ref.detach()) <= 2e-6, (wd, t)
+
+
+def test_ingest_matches_reference_vectors(hostsim):
+    """mlhot_ingest_u8_nhwc argument handling + the element formula (host flavour) against the reference-produced vectors."""
+    import os
+    import numpy as np
+    from mlhot.binding import MlhotError
+    fx = np.load(os.path.join(U.GOLDEN, "ingest.npz"))
+    for C in (1, 2, 3, 4):
+        got = hostsim.ingest_u8_nhwc(torch.from_numpy(fx[f"c{C}/u8"]))
+        assert np.array_equal(got.numpy(), fx[f"c{C}/f32"]), C
+    assert hostsim.ingest_u8_nhwc(torch.zeros(2, 0, 4, 4, 1, dtype=torch.uint8)).shape == (2, 0, 1, 4, 4)
+    with pytest.raises(MlhotError):
+        hostsim.ingest_u8_nhwc(torch.zeros(2, 4, 4, 1))                 # not uint8
+    with pytest.raises(MlhotError):
+        hostsim.ingest_u8_nhwc(torch.zeros(1, 4, 4, 1, dtype=torch.uint8), out=torch.zeros(1, 4, 4, 1))   # out not channel-first

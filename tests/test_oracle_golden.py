@@ -151,3 +151,12 @@ def test_oracle_conv_embedding_matches_reference():
             assert p[k[5:]].grad.abs().max().item() <= 1e-5 * gmax and float(np.abs(fx[k]).max()) <= 1e-5 * gmax
             continue
         assert U.rel_err(p[k[5:]].grad, fx[k], floor=floor) <= 1e-4, k
+
+
+def test_oracle_ingest_matches_reference():
+    """uint8 channel-last -> fp32 channel-first / 255: bit-exact against the reference's own conversion."""
+    fx = np.load(os.path.join(U.GOLDEN, "ingest.npz"))
+    for C in (1, 2, 3, 4):
+        got = O.ingest_images(fx[f"c{C}/u8"]).numpy()
+        assert got.dtype == np.float32 and got.shape == fx[f"c{C}/f32"].shape
+        assert np.array_equal(got, fx[f"c{C}/f32"]), C

@@ -11,6 +11,7 @@
 #include "encoder.h"
 #include "np_vanilla.h"
 #include "conv_rt.h"
+#include "ingest.h"
 #include "../../include/mlhot.h"
 
 namespace mlhot {
@@ -213,6 +214,15 @@ int mlhot_bbb_sample_fwd(const float* mu, const float* rho, const float* eps, fl
 int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, const float* dw, const float* dkl, float* dmu, float* drho,
                          size_t n, void* stream) {
   return run_foreach(BbbSampleBwd{mu, rho, eps, dw, dkl, dmu, drho}, n, (hipStream_t)stream, "bbb.sample.bwd");
+}
+
+// ---- batch ingest: uint8 channel-last images -> fp32 channel-first, divided by `div` -----------------------
+int mlhot_ingest_u8_nhwc(const uint8_t* src, float* dst, long n_img, int H, int W, int C, float div, void* stream) {
+  if (n_img < 0 || H <= 0 || W <= 0 || C <= 0 || !(div > 0.f) || (n_img > 0 && (!src || !dst))) {
+    set_error("ingest_u8_nhwc: bad argument");
+    return MLHOT_ERR_ARG;
+  }
+  return ingest::run(src, dst, n_img, H, W, C, div, (hipStream_t)stream);
 }
 
 // ---- fused Adam over a flat parameter / gradient buffer ------------------------------------------------

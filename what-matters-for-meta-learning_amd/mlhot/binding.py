@@ -418,6 +418,26 @@ class MlhotLib:
                  "mlhot_loss_bwd")
         return dmu
 
+    # ---- batch ingest ---------------------------------------------------------------------------
+    def ingest_u8_nhwc(self, src, out=None, div=255.0):
+        """src: uint8 [..., H, W, C] on the device (channel-last, as the data loaders hold images) ->
+        fp32 [..., C, H, W] = src / div (dataset/shapenet_1d.py:189-190 + utils/utils.py:26-30)."""
+        if src.dtype != torch.uint8 or src.dim() < 3:
+            raise MlhotError(f"ingest_u8_nhwc expects a uint8 [..., H, W, C] tensor, got {src.dtype} {tuple(src.shape)}")
+        _chk(src, out)
+        *lead, H, W, Cc = src.shape
+        shape = (*lead, Cc, H, W)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=src.device)
+        elif out.dtype != torch.float32 or tuple(out.shape) != shape or out.device != src.device:
+            raise MlhotError(f"ingest_u8_nhwc: out must be fp32 {shape} on {src.device}")
+        n_img = 1
+        for v in lead:
+            n_img *= v
+        self.c.mlhot_ingest_u8_nhwc.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        self._rc(self.c.mlhot_ingest_u8_nhwc(_ptr(src), _ptr(out), n_img, H, W, Cc, float(div), _stream(src)), "mlhot_ingest_u8_nhwc")
+        return out
+
     # ---- fused Adam over flat buffers -------------------------------------------------------------
     def adam_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
         _chk(param, grad, exp_avg, exp_avg_sq)

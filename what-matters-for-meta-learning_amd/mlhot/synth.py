@@ -25,6 +25,24 @@ def get_batch(task, tasks_per_batch, n_ctx, n_qry, seed=1234, device="cpu"):
     return tuple(t.to(device) for t in (xs, xq, ys, yq))
 
 
+def get_batch_u8(task, tasks_per_batch, n_ctx, n_qry, seed=1234):
+    """The same batch shapes as the loaders hold them BEFORE their host-side conversion (dataset/shapenet_1d.py:174-188):
+    uint8 channel-last images [T,N,128,128,1] as numpy arrays + the fp32 labels.  Feed to mlhot.ingest.BatchIngest."""
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.randint(0, 256, (tasks_per_batch, n_ctx, 128, 128, 1), generator=g, dtype=torch.uint8)
+    xq = torch.randint(0, 256, (tasks_per_batch, n_qry, 128, 128, 1), generator=g, dtype=torch.uint8)
+    _, _, ys, yq = get_batch(task, tasks_per_batch, n_ctx, n_qry, seed=seed)
+    return xs.numpy(), xq.numpy(), ys, yq
+
+
+def host_convert(u8):
+    """What the reference's loaders do on the host (shapenet_1d.py:189-190 + utils/utils.py:26-30): the pageable-fp32
+    route that `get_batch_u8` + mlhot.ingest.BatchIngest replaces (kept for A/B timing in bench.py)."""
+    import numpy as np
+    x = torch.from_numpy(np.asarray(u8).astype(np.float32) / 255.0).type(torch.FloatTensor)
+    return x.permute(0, 1, 4, 2, 3).contiguous()
+
+
 class SyntheticData:
     """Minimal stand-in for dataset.ShapeNet1D / Pascal1D with the reference's `get_batch` contract
     (dataset/shapenet_1d.py:113-196): train batches draw a random context size in [3, shot], validation /
@@ -45,3 +63,10 @@ class SyntheticData:
         n_ctx = int(rng.randint(3, shot + 1)) if source == "train" else shot
         self._step += 1
         return get_batch(self.task, tasks_per_batch, n_ctx, shot, seed=int(rng.randint(0, 2 ** 31 - 1)))
+
+    def get_batch_u8(self, source, tasks_per_batch, shot):
+        """`get_batch` before the host-side conversion: (ctx uint8 [T,Nc,H,W,C], qry uint8, ctx labels, qry labels)."""
+        rng = {"train": self.rng, "validation": self.val_rng, "test": self.test_rng}[source]
+        n_ctx = int(rng.randint(3, shot + 1)) if source == "train" else shot
+        self._step += 1
+        return get_batch_u8(self.task, tasks_per_batch, n_ctx, shot, seed=int(rng.randint(0, 2 ** 31 - 1)))

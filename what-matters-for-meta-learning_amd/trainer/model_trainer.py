@@ -3,8 +3,10 @@ meta-batch -> forward -> loss (+ beta * kl) -> backward -> optimizer step; perio
 best-model saving; intermediate / final checkpoints (`state_dict` only, like the reference).
 
 Differences that matter on MI355X: the loss value is fetched from the device once per iteration (one host
-sync instead of three), and with more than one rank the gradients are averaged by ONE flat-bucket
-all-reduce (mlhot.dist.GradBucket) before the optimizer step.
+sync instead of three), with more than one rank the gradients are averaged by ONE flat-bucket
+all-reduce (mlhot.dist.GradBucket) before the optimizer step, and a data source that can hand out its
+batches before the host-side conversion (`get_batch_u8`: uint8 channel-last images) is read through
+mlhot.ingest.BatchIngest: the next training batch crosses PCIe as uint8 while the current step computes.
 """
 import math
 import os
@@ -21,6 +23,10 @@ class ModelTrainer(BaseTrainer):
         super().__init__(model=model, loss=loss, optimizer=optimizer, config=config)
         self.data = data
         self.bucket = GradBucket(model.parameters())
+        self.ingest, self._staged = None, None
+        if hasattr(data, "get_batch_u8") and torch.device(config.device).type == "cuda" and getattr(config, "ingest_u8", True):
+            from mlhot.ingest import BatchIngest
+            self.ingest = BatchIngest(config.device)
 
     def _log(self, msg):
         logger = getattr(self.config, "logger", None)
@@ -44,10 +50,24 @@ class ModelTrainer(BaseTrainer):
         self._log("================= Training finished =================\\n")
 
     def _batch(self, source):
-        ctx_x, qry_x, ctx_y, qry_y = self.data.get_batch(source=source, tasks_per_batch=self.config.tasks_per_batch,
-                                                         shot=self.config.max_ctx_num)
-        dev = self.config.device
-        return ctx_x.to(dev), qry_x.to(dev), ctx_y.to(dev), qry_y.to(dev)
+        """One device batch of `source`.  With the ingest path the NEXT training batch starts its host -> device copy as
+        soon as the current one is handed out, so it overlaps with the step the caller is about to run; validation / test
+        batches are staged and taken on the spot (the prefetched training batch keeps its place in the draw order)."""
+        if self.ingest is None:
+            ctx_x, qry_x, ctx_y, qry_y = self.data.get_batch(source=source, tasks_per_batch=self.config.tasks_per_batch,
+                                                             shot=self.config.max_ctx_num)
+            dev = self.config.device
+            return ctx_x.to(dev), qry_x.to(dev), ctx_y.to(dev), qry_y.to(dev)
+
+        def stage(src):
+            return self.ingest.stage(*self.data.get_batch_u8(source=src, tasks_per_batch=self.config.tasks_per_batch,
+                                                             shot=self.config.max_ctx_num))
+        if source != "train":
+            return self.ingest.take(stage(source))
+        ticket, self._staged = (self._staged or stage("train")), None
+        batch = self.ingest.take(ticket)
+        self._staged = stage("train")
+        return batch
 
     def _train_iter(self, it):
         self.model.train()
