@@ -515,6 +515,55 @@ def test_trainer_ingest_path_equals_host_path(gpulib, tmp_path, monkeypatch):
         assert torch.equal(finals[0][k], finals[1][k]), k
 
 
+@pytest.mark.parametrize("method,agg", [("ANPShapeNet1D", "attention"), ("CNPShapeNet1D", "max")])
+def test_evaluator_context_sweep_vs_oracle(gpulib, tmp_path, method, agg):
+    """SURVEY §8f rank 3, the eval path (evaluator/model_evaluator.py:95-179): forward-only test-mode batches for every
+    context size 1..max_ctx_num (Nc = Nq = size), mean / std of the test loss per size against the CPU oracle on the same
+    draws; the ingest route and the host route must agree bit for bit."""
+    import importlib
+    import types
+    from evaluator.model_evaluator import ModelEvaluator
+    from mlhot import synth
+    from trainer.losses import LossFunc
+
+    class HostData(synth.SyntheticData):
+        def get_batch(self, source, tasks_per_batch, shot):
+            xs, xq, ys, yq = synth.SyntheticData.get_batch_u8(self, source, tasks_per_batch, shot)
+            return synth.host_convert(xs), synth.host_convert(xq), ys, yq
+
+    results = {}
+    for use_ingest in (True, False):
+        cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[128, 128, 1], tasks_per_batch=2, input_dim=3,
+                                    output_dim=2, agg_mode=agg, img_agg="", dim_w=64, n_hidden_units_r=[100, 100],
+                                    dim_r=64 if agg == "attention" else 100, dim_z=64, task="shapenet_1d", iterations=0, val_iters=2,
+                                    max_ctx_num=5, contrastive=False, ingest_u8=use_ingest, logger=None,
+                                    save_path=str(tmp_path / f"eval{int(use_ingest)}"))
+        model = getattr(importlib.import_module("networks." + method), method)(cfg).to(cfg.device)
+        ev = ModelEvaluator(model=model, loss=LossFunc("mse", "shapenet_1d"), config=cfg, data=HostData())
+        assert (ev.ingest is not None) == use_ingest
+        results[use_ingest] = ev.evaluate()
+        table = np.loadtxt(tmp_path / f"eval{int(use_ingest)}" / "test_losses.txt")
+        assert table.shape == (5, 3) and list(table[:, 0]) == [1, 2, 3, 4, 5]
+        assert os.path.exists(tmp_path / f"eval{int(use_ingest)}" / "models" / "model.pt")
+    assert results[True] == results[False]
+    # the oracle on the same draws
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    data = HostData()
+    for si, source in enumerate(("validation", "test")):
+        for ctx_num in range(1, 6):
+            getattr(data, "test_rng" if source == "test" else "val_rng").seed(42)
+            vals = []
+            for _ in range(2):
+                cx, qx, cy, qy = data.get_batch(source, 2, ctx_num)
+                assert cx.shape[1] == ctx_num and qx.shape[1] == ctx_num
+                mu = O.vanilla_np_forward(p, cx, cy, qx, agg, tanh=True)
+                vals.append(O.calc_loss("shapenet_1d", mu, qy, test=True).view(1))
+            vals = torch.cat(vals)
+            got_mean, got_std = results[True][si][0][ctx_num - 1], results[True][si][1][ctx_num - 1]
+            assert abs(got_mean - vals.mean().item()) <= 1e-3 * max(1.0, abs(vals.mean().item())), (source, ctx_num)
+            assert abs(got_std - vals.std().item()) <= 2e-3 * max(1.0, abs(vals.std().item())), (source, ctx_num)
+
+
 def test_cpu_tensors_are_refused(gpulib):
     from mlhot.binding import MlhotError
     from mlhot.ops import LinearFunction
