@@ -158,23 +158,23 @@ def measure_host_fed(w, device, loss_fn, model, iters):
         if timed:
             out["ingest_route_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / iters
     ing.take()
-    # the ingest kernels alone (2 launches: context + target images)
+    # the ingest kernel alone (context + target images are one packed run: one launch)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ing.stage(*hb)
     torch.cuda.synchronize()
     import mlhot
-    L, slot = mlhot.lib(), ing._queue[0][1]
+    L = mlhot.lib()
+    src_u8, dst_f32 = ing.device_views()
     ev[0].record()
     for _ in range(iters):
-        L.ingest_u8_nhwc(slot.dev[0], out=cx)
-        L.ingest_u8_nhwc(slot.dev[1], out=qx)
+        L.ingest_u8_nhwc(src_u8, out=dst_f32)
     ev[1].record()
     torch.cuda.synchronize()
     ing.take()
     ingest_ms = ev[0].elapsed_time(ev[1]) / iters
     nbytes = 5 * (hb[0].size + hb[1].size)                          # 1 byte read + 4 written per pixel
-    out["ingest_kernels_us_per_batch"] = 1e3 * ingest_ms
-    out["ingest_kernels_GBps"] = nbytes / (ingest_ms * 1e-3) / 1e9
+    out["ingest_kernel_us_per_batch"] = 1e3 * ingest_ms
+    out["ingest_kernel_GBps"] = nbytes / (ingest_ms * 1e-3) / 1e9
     # reference route: host conversion done (not timed), pageable fp32 tensors copied synchronously, then the step
     host = [synth.host_convert(hb[0]), synth.host_convert(hb[1]), hb[2], hb[3]]
     for timed in (False, True):
@@ -192,6 +192,33 @@ def measure_host_fed(w, device, loss_fn, model, iters):
     out["tasks_per_s_host_fed"] = {"ingest_route": 1e3 * T_LOCAL / out["ingest_route_ms_per_step"],
                                    "reference_route": 1e3 * T_LOCAL / out["reference_route_ms_per_step"]}
     return out
+
+
+def measure_variable_nc(w, device, loss_fn, model, batch, iters):
+    """The reference's TRAINING batches draw the context size per iteration (dataset/shapenet_1d.py:120: 3..shot); the
+    target count stays `shot`.  One captured hipGraph per context size, replayed in a seeded random order."""
+    import numpy as np
+    cx, qx, cy, qy = batch
+    graphs, ins = {}, {}
+    for nc in range(3, NC + 1):
+        ins[nc] = (cx[:, :nc].contiguous(), cy[:, :nc].contiguous())
+
+        def step(nc=nc):
+            model.zero_grad(set_to_none=True)
+            loss_fn.calc_loss(model(ins[nc][0], ins[nc][1], qx)[0], None, qy).backward()
+
+        graphs[nc] = _capture(step)
+    order = np.random.RandomState(0).randint(3, NC + 1, size=4 * iters)
+    for nc in order[:8]:
+        graphs[int(nc)].replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for nc in order:
+        graphs[int(nc)].replay()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / len(order)
+    return {"ms_per_step": ms, "tasks_per_s": 1e3 * T_LOCAL / ms, "mean_context": float(order.mean()), "steps": int(len(order)),
+            "note": "context size ~ U{3..15} per step (the reference's training draw), 15 targets, one hipGraph per size"}
 
 
 def measure_extras(w, device, loss_fn, batch, iters):
@@ -230,6 +257,7 @@ def measure_extras(w, device, loss_fn, batch, iters):
         del opt                                                      # FlatAdam re-pointed the parameters; build a fresh model
         model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(make_cfg(w, device)).to(device)
         out["host_fed"] = measure_host_fed(w, device, loss_fn, model, iters)
+        out["variable_context"] = measure_variable_nc(w, device, loss_fn, model, batch, iters)
         return out
     except Exception as e:  # noqa: BLE001 - extras must never break the bench line
         return {"error": f"{type(e).__name__}: {e}"}

@@ -30,17 +30,46 @@ def _host(a, dtype):
     return t
 
 
-class _Slot:
-    """One staging slot: pinned host buffers + their device twins for one (ctx, qry) shape set."""
+def _layout(key):
+    """Byte layout of one packed staging buffer: [ctx images | qry images | pad to 16 | ctx labels | qry labels]."""
+    n_img = [int(np.prod(key[0])), int(np.prod(key[1]))]
+    n_lab = [int(np.prod(key[2])), int(np.prod(key[3]))]
+    lab_off = (n_img[0] + n_img[1] + 15) // 16 * 16
+    return n_img, n_lab, lab_off, lab_off + 4 * (n_lab[0] + n_lab[1])
 
-    def __init__(self, shapes, device):
-        dts = (torch.uint8, torch.uint8, torch.float32, torch.float32)
-        self.host = [torch.empty(s, dtype=d).pin_memory() for s, d in zip(shapes, dts)]
-        self.host_np = [h.numpy() for h in self.host]
-        self.dev = [torch.empty(s, dtype=d, device=device) for s, d in zip(shapes, dts)]
-        self.copied = torch.cuda.Event()       # H2D of this slot finished (host buffers reusable, device buffers readable)
-        self.consumed = torch.cuda.Event()     # the ingest kernels that read this slot's device buffers finished
+
+class _Slot:
+    """One staging slot: ONE pinned host buffer + its device twin holding a whole batch (images as bytes, labels as fp32),
+    so a batch is one H2D copy."""
+
+    def __init__(self, key, device):
+        n_img, n_lab, lab_off, total = _layout(key)
+        self.host = torch.empty(max(total, 16), dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(max(total, 16), dtype=torch.uint8, device=device)
+        hn = self.host.numpy()
+        self.host_np = [hn[:n_img[0]].reshape(key[0]), hn[n_img[0]:n_img[0] + n_img[1]].reshape(key[1]),
+                        hn[lab_off:lab_off + 4 * n_lab[0]].view(np.float32).reshape(key[2]),
+                        hn[lab_off + 4 * n_lab[0]:total].view(np.float32).reshape(key[3])]
+        self.dev_img = self.dev[:n_img[0] + n_img[1]]
+        self.dev_lab = self.dev[lab_off:total].view(torch.float32)
+        self.copied = torch.cuda.Event()       # H2D of this slot finished (host buffer reusable, device buffer readable)
+        self.consumed = torch.cuda.Event()     # the kernels that read this slot's device buffer finished
         self.busy = False
+
+
+class _Out:
+    """The fixed fp32 tensors batches of one shape are delivered in: images of both sets in one flat buffer (one ingest
+    launch when the image geometry is shared), labels in another (one device copy)."""
+
+    def __init__(self, key, device):
+        (T, Nc, H, W, Cc), (_, Nq, H2, W2, C2) = key[0], key[1]
+        n_img, n_lab, _, _ = _layout(key)
+        self.same_geometry = (H, W, Cc) == (H2, W2, C2)
+        self.img = torch.empty(n_img[0] + n_img[1], device=device)
+        self.lab = torch.empty(n_lab[0] + n_lab[1], device=device)
+        self.n_img = n_img
+        self.tensors = (self.img[:n_img[0]].view(T, Nc, Cc, H, W), self.img[n_img[0]:].view(T, Nq, C2, H2, W2),
+                        self.lab[:n_lab[0]].view(key[2]), self.lab[n_lab[0]:].view(key[3]))
 
 
 class BatchIngest:
@@ -51,7 +80,7 @@ class BatchIngest:
         self.device, self.n_slots, self.div = device, slots, div
         self.copy_stream = torch.cuda.Stream(device)
         self._slots = {}                        # shapes -> [slot, ...]
-        self._out = {}                          # shapes -> fixed fp32 outputs
+        self._out = {}                          # shapes -> _Out (fixed fp32 outputs)
         self._queue = collections.deque()
 
     def stage(self, xs_u8, xq_u8, ys, yq):
@@ -67,18 +96,27 @@ class BatchIngest:
                 raise MlhotError("BatchIngest: more batches staged than slots; call take() first")
             slot = _Slot(key, self.device)
             ring.append(slot)
-        slot.copied.synchronize()               # the previous H2D out of these pinned buffers is done (no-op when fresh)
+        slot.copied.synchronize()               # the previous H2D out of this pinned buffer is done (no-op when fresh)
         for h, t in zip(slot.host_np, src):
             np.copyto(h, t.numpy())             # one thread on purpose: torch's copy_ wakes the whole OpenMP pool, whose
                                                 # spinning workers then starve the HIP runtime's helper threads
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(slot.consumed)      # do not overwrite bytes an ingest kernel still reads
-            for h, d in zip(slot.host, slot.dev):
-                d.copy_(h, non_blocking=True)
+            slot.dev.copy_(slot.host, non_blocking=True)
             slot.copied.record(self.copy_stream)
         slot.busy = True
         self._queue.append((key, slot))
         return slot
+
+    def device_views(self, ticket=None):
+        """(uint8 [n, H, W, C] staged images on the device, fp32 [n, C, H, W] destination) of a staged batch whose two
+        image sets share their geometry - what take() hands to mlhot_ingest_u8_nhwc; for profiling that kernel alone."""
+        key, slot = self._queue[0] if ticket is None else next(e for e in self._queue if e[1] is ticket)
+        out = self._out.setdefault(key, _Out(key, self.device))
+        if not out.same_geometry:
+            raise MlhotError("device_views: context and target images differ in geometry")
+        _, _, H, W, Cc = key[0]
+        return slot.dev_img.view(-1, H, W, Cc), out.img.view(-1, Cc, H, W)
 
     def take(self, ticket=None):
         """A staged batch (the oldest, or the one `ticket` names) as (ctx_x, qry_x, ctx_y, qry_y): fp32, channel-first,
@@ -97,15 +135,17 @@ class BatchIngest:
         cur.wait_event(slot.copied)
         out = self._out.get(key)
         if out is None:
-            (T, Nc, H, W, Cc), (_, Nq, _, _, _) = key[0], key[1]
-            out = self._out[key] = [torch.empty(T, Nc, Cc, H, W, device=self.device), torch.empty(T, Nq, Cc, H, W, device=self.device),
-                                    torch.empty(key[2], device=self.device), torch.empty(key[3], device=self.device)]
+            out = self._out[key] = _Out(key, self.device)
         L = lib()
         with torch.cuda.device(self.device):
-            L.ingest_u8_nhwc(slot.dev[0], out=out[0], div=self.div)
-            L.ingest_u8_nhwc(slot.dev[1], out=out[1], div=self.div)
-            out[2].copy_(slot.dev[2])
-            out[3].copy_(slot.dev[3])
+            if out.same_geometry:               # both image sets are one packed run of (H, W, C) images
+                _, _, H, W, Cc = key[0]
+                L.ingest_u8_nhwc(slot.dev_img.view(-1, H, W, Cc), out=out.img.view(-1, Cc, H, W), div=self.div)
+            else:
+                n0 = out.n_img[0]
+                L.ingest_u8_nhwc(slot.dev_img[:n0].view(key[0]), out=out.tensors[0], div=self.div)
+                L.ingest_u8_nhwc(slot.dev_img[n0:].view(key[1]), out=out.tensors[1], div=self.div)
+            out.lab.copy_(slot.dev_lab)
         slot.consumed.record(cur)
         slot.busy = False
-        return tuple(out)
+        return out.tensors
