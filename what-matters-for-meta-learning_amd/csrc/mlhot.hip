@@ -28,17 +28,16 @@ Options g_opt = {1, 1, 0, 0};
 #ifndef MLHOT_HOSTSIM
 // ---- per-launch event profiler -------------------------------------------------------------------
 bool g_prof_on = false;
-struct ProfRec { const char* what; hipEvent_t a, b; };
+struct ProfRec { const char* what; hipEvent_t a, b; bool open; };
 static ProfRec* g_prof = nullptr;
 static int g_prof_cap = 0, g_prof_n = 0;
+// A failed event call drops that record (the profile then misses a launch; the launch itself is unaffected).
 void prof_record(const char* what, hipStream_t s, bool begin) {
+  if (g_prof_n >= g_prof_cap) return;
   if (begin) {
-    if (g_prof_n >= g_prof_cap) return;
     g_prof[g_prof_n].what = what;
-    hipEventRecord(g_prof[g_prof_n].a, s);
-  } else {
-    if (g_prof_n >= g_prof_cap) return;
-    hipEventRecord(g_prof[g_prof_n].b, s);
+    g_prof[g_prof_n].open = hipEventRecord(g_prof[g_prof_n].a, s) == hipSuccess;
+  } else if (g_prof[g_prof_n].open && hipEventRecord(g_prof[g_prof_n].b, s) == hipSuccess) {
     ++g_prof_n;
   }
 }
@@ -65,10 +64,15 @@ int mlhot_set_option(const char* name, int value) {
 // ---- profiler (bench only) ----------------------------------------------------------------------
 int mlhot_prof_begin(int max_records) {
 #ifndef MLHOT_HOSTSIM
-  if (g_prof) return MLHOT_ERR_ARG;
+  if (g_prof || max_records <= 0) { set_error("prof_begin: already recording, or bad capacity"); return MLHOT_ERR_ARG; }
   g_prof = new ProfRec[max_records];
-  for (int i = 0; i < max_records; ++i) { hipEventCreate(&g_prof[i].a); hipEventCreate(&g_prof[i].b); }
-  g_prof_cap = max_records; g_prof_n = 0; g_prof_on = true;
+  int made = 0;
+  for (; made < max_records; ++made) {
+    g_prof[made].open = false;
+    if (hipEventCreate(&g_prof[made].a) != hipSuccess) break;
+    if (hipEventCreate(&g_prof[made].b) != hipSuccess) { (void)hipEventDestroy(g_prof[made].a); break; }
+  }
+  g_prof_cap = made; g_prof_n = 0; g_prof_on = true;
 #else
   (void)max_records;
 #endif
@@ -81,12 +85,11 @@ int mlhot_prof_end(const char** labels, float* ms, int cap) {
 #ifndef MLHOT_HOSTSIM
   g_prof_on = false;
   for (int i = 0; i < g_prof_n; ++i) {
-    hipEventSynchronize(g_prof[i].b);
     float t = 0.f;
-    hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
+    if (hipEventSynchronize(g_prof[i].b) != hipSuccess || hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) continue;
     if (n < cap) { labels[n] = g_prof[i].what; ms[n] = t; ++n; }
   }
-  for (int i = 0; i < g_prof_cap; ++i) { hipEventDestroy(g_prof[i].a); hipEventDestroy(g_prof[i].b); }
+  for (int i = 0; i < g_prof_cap; ++i) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
   delete[] g_prof; g_prof = nullptr; g_prof_cap = g_prof_n = 0;
 #else
   (void)labels; (void)ms; (void)cap;

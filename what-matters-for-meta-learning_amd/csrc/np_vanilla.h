@@ -141,7 +141,7 @@ inline int lin_wgrad(const float* dy, int lddy, const float* y, int ldy, int act
 // ---- fused tail (csrc/tail_fused.h) ---------------------------------------------------------------
 inline bool tail_fused_applies(const mlhot_np_dims& d) {
   return g_opt.tail_fused && d.agg_mode == MLHOT_AGG_ATTENTION && d.Nc >= 1 && d.Nc <= 16 && d.Nq <= 16 &&
-         d.n_hidden == 2 && d.dim_w % 16 == 0 && d.dim_r == d.dim_w && d.m_feat <= 4096 &&
+         d.n_hidden == 2 && d.dim_w % 64 == 0 && d.dim_r == d.dim_w && d.m_feat <= 4096 &&
          (long long)d.T * d.Nc * MLHOT_HEADS < (1ll << 19);      // key arg-max positions are packed row * 4096 + col
 }
 inline tf::TailDims tail_dims(const mlhot_np_dims& d) {
@@ -162,7 +162,10 @@ inline tf::TailParams tail_params(const mlhot_np_params& p) {
 }
 template <class K, class A>
 inline int tail_launch(K kernel, int grid, int block, size_t lds, const A& args, hipStream_t s, const char* what) {
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    set_error("%s: %zu bytes of LDS refused", what, lds);
+    return MLHOT_ERR_LAUNCH;
+  }
   {
     ProfScope ps(what, s);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, args);

@@ -395,12 +395,15 @@ __device__ __forceinline__ void phaseA_keyhead(const PhaseAArgs& a, lptr L0, int
     gcptr bk = uniptr(ptab[offsetof(PRM, wk_b) / 8 + h]);
     const int n = wave * 16 + lr;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < d.dw; k0 += 16) {
-      const int kk = k0 + 4 * lq;
-      const f32x4_t b = *reinterpret_cast<gc4ptr>(wk + n * d.dw + kk);
-      lcptr xp = s_x + lr * Lx + kk;
-      acc = mfma4(xp[0], b[0], acc); acc = mfma4(xp[1], b[1], acc);
-      acc = mfma4(xp[2], b[2], acc); acc = mfma4(xp[3], b[3], acc);
+    for (int k64 = 0; k64 < d.dw; k64 += 64) {          // dw % 64 == 0
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k64 + 16 * u + 4 * lq;
+        const f32x4_t b = *reinterpret_cast<gc4ptr>(wk + n * d.dw + kk);
+        lcptr xp = s_x + lr * Lx + kk;
+        acc = mfma4(xp[0], b[0], acc); acc = mfma4(xp[1], b[1], acc);
+        acc = mfma4(xp[2], b[2], acc); acc = mfma4(xp[3], b[3], acc);
+      }
     }
     const float bias = bk[n];
 #pragma unroll
@@ -420,13 +423,15 @@ __device__ __forceinline__ void phaseA_keyhead(const PhaseAArgs& a, lptr L0, int
     const int j = jt * 16 + lr;
     const int jc = j < d.m ? j : d.m - 1;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k0 = 0; k0 < d.dw; k0 += 16) {
-      const int kk = k0 + 4 * lq;
-      const float4 b = *reinterpret_cast<const float4*>(a.p.proj + (size_t)jc * d.dw + kk);
-      lcptr xp = s_k + lr * Lx + kk;
-      acc = mfma4(xp[0], b.x * c, acc); acc = mfma4(xp[1], b.y * c, acc);
-      acc = mfma4(xp[2], b.z * c, acc); acc = mfma4(xp[3], b.w * c, acc);
+    for (int k64 = 0; k64 < d.dw; k64 += 64) {          // dw % 64 == 0: the constant inner trip count lets the 4 loads go out together
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k64 + 16 * u + 4 * lq;
+        const float4 b = *reinterpret_cast<const float4*>(a.p.proj + (size_t)jc * d.dw + kk);
+        lcptr xp = s_k + lr * Lx + kk;
+        acc = mfma4(xp[0], b.x * c, acc); acc = mfma4(xp[1], b.y * c, acc);
+        acc = mfma4(xp[2], b.z * c, acc); acc = mfma4(xp[3], b.w * c, acc);
+      }
     }
     if (j < d.m) {
 #pragma unroll
@@ -600,15 +605,15 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
       const float* wsel = isv ? wv : wq;
       lcptr xs = isv ? s_rs : s_xq;
       f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-      for (int k0 = 0; k0 < d.dw; k0 += 32) {
-        const int kk = k0 + 4 * lq;
-        const float4 b1 = *reinterpret_cast<const float4*>(wsel + (size_t)n * d.dw + kk);
-        const float4 b2 = *reinterpret_cast<const float4*>(wsel + (size_t)n * d.dw + (kk + 16 < d.dw ? kk + 16 : kk));
-        lcptr x1 = xs + lr * Lx + kk;
-        acc0 = mfma4(x1[0], b1.x, acc0); acc0 = mfma4(x1[1], b1.y, acc0);
-        acc0 = mfma4(x1[2], b1.z, acc0); acc0 = mfma4(x1[3], b1.w, acc0);
-        if (k0 + 16 < d.dw) {
+      for (int k64 = 0; k64 < d.dw; k64 += 64) {        // dw % 64 == 0
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int kk = k64 + 32 * u + 4 * lq;
+          const float4 b1 = *reinterpret_cast<const float4*>(wsel + (size_t)n * d.dw + kk);
+          const float4 b2 = *reinterpret_cast<const float4*>(wsel + (size_t)n * d.dw + kk + 16);
+          lcptr x1 = xs + lr * Lx + kk;
+          acc0 = mfma4(x1[0], b1.x, acc0); acc0 = mfma4(x1[1], b1.y, acc0);
+          acc0 = mfma4(x1[2], b1.z, acc0); acc0 = mfma4(x1[3], b1.w, acc0);
           acc1 = mfma4(x1[16], b2.x, acc1); acc1 = mfma4(x1[17], b2.y, acc1);
           acc1 = mfma4(x1[18], b2.z, acc1); acc1 = mfma4(x1[19], b2.w, acc1);
         }
@@ -635,17 +640,19 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
     const int j = jt * 16 + lr;
     const bool vj = j < d.m;
     f32x4_t accq = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k0 = 0; k0 < d.dw; k0 += 16) {
-      const int kk = k0 + 4 * lq;
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (vj) b = *reinterpret_cast<const float4*>(a.pc + (size_t)j * d.dw + kk);
-      lcptr xq = s_q + lr * Lx + kk;
-      lcptr xk = s_k + lr * Lx + kk;
-      accq = mfma4(xq[0], b.x, accq); acck = mfma4(xk[0], b.x, acck);
-      accq = mfma4(xq[1], b.y, accq); acck = mfma4(xk[1], b.y, acck);
-      accq = mfma4(xq[2], b.z, accq); acck = mfma4(xk[2], b.z, acck);
-      accq = mfma4(xq[3], b.w, accq); acck = mfma4(xk[3], b.w, acck);
+    for (int k64 = 0; k64 < d.dw; k64 += 64) {          // dw % 64 == 0
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k64 + 16 * u + 4 * lq;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vj) b = *reinterpret_cast<const float4*>(a.pc + (size_t)j * d.dw + kk);
+        lcptr xq = s_q + lr * Lx + kk;
+        lcptr xk = s_k + lr * Lx + kk;
+        accq = mfma4(xq[0], b.x, accq); acck = mfma4(xk[0], b.x, acck);
+        accq = mfma4(xq[1], b.y, accq); acck = mfma4(xk[1], b.y, acck);
+        accq = mfma4(xq[2], b.z, accq); acck = mfma4(xk[2], b.z, acck);
+        accq = mfma4(xq[3], b.w, accq); acck = mfma4(xk[3], b.w, acck);
+      }
     }
     if (vj) {
 #pragma unroll
@@ -756,13 +763,15 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
     const float* woh = a.wot + (size_t)h * d.dw * d.dw;
     for (int jt = wave; jt * 16 < d.dw; jt += 8) {
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int k0 = 0; k0 < d.dw; k0 += 16) {
-        const int kk = k0 + 4 * lq;
-        const float4 b4 = *reinterpret_cast<const float4*>(woh + (size_t)(16 * jt + lr) * d.dw + kk);
-        lcptr xp = s_xq + lr * Lx + kk;
-        acc = mfma4(xp[0], b4.x, acc); acc = mfma4(xp[1], b4.y, acc);
-        acc = mfma4(xp[2], b4.z, acc); acc = mfma4(xp[3], b4.w, acc);
+      for (int k64 = 0; k64 < d.dw; k64 += 64) {        // dw % 64 == 0
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kk = k64 + 16 * u + 4 * lq;
+          const float4 b4 = *reinterpret_cast<const float4*>(woh + (size_t)(16 * jt + lr) * d.dw + kk);
+          lcptr xp = s_xq + lr * Lx + kk;
+          acc = mfma4(xp[0], b4.x, acc); acc = mfma4(xp[1], b4.y, acc);
+          acc = mfma4(xp[2], b4.z, acc); acc = mfma4(xp[3], b4.w, acc);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
