@@ -34,6 +34,33 @@ agg = {}
 for label, ms in recs:
     a = agg.setdefault(label, [0, 0.0]); a[0] += 1; a[1] += ms
 top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]
-print(json.dumps({"workload": "c5 per-GPU: ANPMRShapeNet3D T=8 15+15 3x64x64", "eager_ms_per_step": dt * 1e3, "tasks_per_s": T / dt,
+# ---- the same step as a hipGraph: eps pre-drawn on the CPU generator in the recorded order (networks/bbb/eps.py) ----------
+from networks.bbb.eps import StagedEps
+import bench
+eps = StagedEps(dev)
+with eps.recording():
+    step()
+eps.stage()
+def staged_step():
+    eps.rewind()
+    step()
+
+
+with eps.active():
+    graph = bench._capture(staged_step)
+draw_ms = 0.0
+for timed in (False, True):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        d0 = time.perf_counter()
+        eps.stage()
+        draw_ms += (time.perf_counter() - d0) * 1e3 if timed else 0.0
+        graph.replay()
+    torch.cuda.synchronize()
+    graph_dt = (time.perf_counter() - t0) / N
+print(json.dumps({"workload": "c5 per-GPU: ANPMRShapeNet3D T=8 15+15 3x64x64", "eager_ms_per_step": dt * 1e3, "tasks_per_s_eager": T / dt,
+                  "hipgraph_ms_per_step": graph_dt * 1e3, "tasks_per_s": T / graph_dt, "host_eps_draw_ms_per_step": draw_ms / N,
+                  "eps_floats_per_step": eps._total,
                   "gpu_busy_ms_per_step": sum(v[1] for v in agg.values()) / N, "launches_per_step": sum(v[0] for v in agg.values()) / N,
                   "top_kernels_ms_per_step": {k: round(v[1] / N, 3) for k, v in top}}))

@@ -101,3 +101,30 @@ def test_every_reference_yaml_parses(tmp_path, monkeypatch):
             assert model.to("cpu") is model and len(list(model.parameters())) > 0
             constructed.add(cfg.method)
     assert constructed == IN_SCOPE
+
+
+def test_staged_eps_reproduces_the_lazy_draws():
+    """networks/bbb/eps.py: pre-drawing the recorded shape sequence gives the numbers the reference's lazy per-layer draws
+    (bbb/BBBConv.py:88-95) would have produced from the same generator state - incl. tensors below torch's 16-element
+    vectorisation threshold and odd sizes."""
+    import torch
+    from networks.bbb import eps
+    shapes = [(64, 3, 5, 5), (64,), (7,), (1,), (3, 5), (64, 64, 3, 3), (15,), (16,), (17,), (256, 100), (2,)]
+    st = eps.StagedEps("cpu")
+    torch.manual_seed(7)
+    with st.recording():
+        lazy = [eps.draw(s, "cpu") for s in shapes] + [eps.draw(s, "cpu") for s in shapes]
+    assert st.shapes == shapes + shapes
+    for _ in range(2):                     # two consecutive steps: the staging buffers alternate
+        torch.manual_seed(7)
+        st.stage()
+        with st.active():
+            staged = [eps.draw(s, "cpu") for s in shapes] + [eps.draw(s, "cpu") for s in shapes]
+            with pytest.raises(RuntimeError):
+                eps.draw((3,), "cpu")      # more draws than recorded
+        for a, b in zip(lazy, staged):
+            assert a.shape == b.shape and torch.equal(a, b)
+    st.stage()
+    with st.active(), pytest.raises(RuntimeError):
+        eps.draw((5,), "cpu")              # not the recorded shape
+    assert eps._active is None and eps._recorder is None

@@ -295,6 +295,61 @@ def test_anpmr_shapenet3d_vs_reference(gpulib):
         U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
 
 
+def test_staged_eps_step_equals_lazy_step_and_captures(gpulib):
+    """networks/bbb/eps.py on the device: a Bayes-by-backprop step fed from the pre-drawn eps buffer is bit-identical to the
+    reference's lazy per-layer draws, and the staged step replays from a hipGraph with the same result."""
+    from networks.bbb.eps import StagedEps
+    fx, meta = U.load_case("r_anpmr_shapenet3d")
+    model = U.build_model(meta, DEV, fx=fx).to(DEV)
+    cx, qx, cy, qy = (t.to(DEV) for t in U.resnet_case_inputs(meta, fx))
+    from trainer.losses import LossFunc
+    loss_fn = LossFunc("mse", "shapenet_3d")
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        mu, _, kl = model(cx, cy, qx)
+        (loss_fn.calc_loss(mu, None, qy) + 1e-7 * kl).backward()
+        # detached: a kept autograd graph would pin the parameters' gradient-accumulation nodes to THIS step's stream,
+        # and the capture below must not meet nodes created on the default stream
+        return mu.detach(), kl.detach()
+
+    st = StagedEps(DEV)
+    torch.manual_seed(99)
+    with st.recording():
+        mu0, kl0 = step()
+    g0 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert U.rel_err(mu0, fx["mu"]) <= U.RTOL              # the lazy route is the one pinned to the reference vectors
+    torch.manual_seed(99)
+    st.stage()
+    with st.active():
+        mu1, kl1 = step()
+    assert torch.equal(mu0, mu1) and torch.equal(kl0, kl1)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g0[k]), k
+    # capture, then replay with the same draws
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), st.active():
+        for _ in range(2):
+            st.stage()
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    st.stage()
+    with st.active(), torch.cuda.graph(graph):
+        mu2, kl2 = step()
+    torch.manual_seed(99)
+    st.stage()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(mu2, mu0) and torch.equal(kl2, kl0)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g0[k]), k
+
+
 @pytest.mark.parametrize("name", U.mr_case_names())
 def test_mr_vanilla_models_vs_reference(gpulib, name):
     """ANPMR / ANPMRShapeNet1D / CNPMR / CNPMRShapeNet1D: Bayes-by-backprop vanilla encoder whose sampled weights

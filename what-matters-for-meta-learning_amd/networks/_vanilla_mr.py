@@ -45,6 +45,7 @@ class BBBEncoder(ModuleWrapper):
             w, b, k = layer.sample()           # draw order of ModuleWrapper.forward: layer by layer, weight then bias
             params += [w, b]
             kl = kl + k
+            layer.release_kl_graph()
         return EncVanillaFunction.apply(img, *params), kl
 
 

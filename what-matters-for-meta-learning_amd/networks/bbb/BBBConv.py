@@ -9,6 +9,7 @@ import torch
 from torch.nn import Parameter
 
 from mlhot.ops import BBBSampleFunction, Conv2dFunction
+from . import eps
 from .misc import ModuleWrapper
 
 PRIORS = {"prior_mu": 0, "prior_sigma": 0.1, "posterior_mu_initial": (0, 0.1), "posterior_rho_initial": (-3, 0.1)}
@@ -49,11 +50,11 @@ class BBBConv2d(ModuleWrapper):
     def sample(self):
         """(weight, bias, kl) with the reference's draw order (weight eps, then bias eps)."""
         dev = self.W_mu.device
-        w_eps = torch.empty(self.W_mu.size()).normal_(0, 1).to(dev)
+        w_eps = eps.draw(self.W_mu.size(), dev)
         weight, kl = BBBSampleFunction.apply(self.W_mu, self.W_rho, w_eps)
         bias = None
         if self.use_bias:
-            b_eps = torch.empty(self.bias_mu.size()).normal_(0, 1).to(dev)
+            b_eps = eps.draw(self.bias_mu.size(), dev)
             bias, kl_b = BBBSampleFunction.apply(self.bias_mu, self.bias_rho, b_eps)
             kl = kl + kl_b
         self._kl = kl
@@ -65,3 +66,10 @@ class BBBConv2d(ModuleWrapper):
 
     def kl_loss(self):
         return self._kl
+
+    def release_kl_graph(self):
+        """Keep the value of the last KL but drop its autograd graph.  A layer that held on to the graph would keep the
+        gradient-accumulation nodes of its parameters alive from one forward to the next, pinned to the stream of the
+        FIRST forward - which breaks hipGraph capture of a later step (the engine then syncs with that old stream)."""
+        if self._kl is not None:
+            self._kl = self._kl.detach()

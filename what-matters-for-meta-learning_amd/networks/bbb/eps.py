@@ -1,0 +1,103 @@
+"""Where the Bayes-by-backprop layers get their eps from.
+
+The reference draws eps per layer on the torch CPU generator inside every forward and copies it to the device
+(bbb/BBBConv.py:88-95: `torch.empty(size).normal_(0, 1).to(device)`), weight first, then bias.  `draw()` is that route
+by default.  A `StagedEps` pre-draws the SAME sequence (same generator, same shapes, same order, hence the same numbers)
+before the forward starts, ships it in one pinned host -> device copy and hands the layers slices of a fixed device
+buffer - which is what makes a Bayes-by-backprop training step capturable in a hipGraph:
+
+    eps = StagedEps(device)
+    with eps.recording():  step()         # one eager step with lazy draws; notes the shapes in call order
+    eps.stage()
+    with eps.active():     graph = capture(step)
+    for it in ...:         eps.stage(); graph.replay()
+"""
+import contextlib
+
+import torch
+
+_active = None        # the StagedEps the layers read from (None: the reference's lazy route); callers are single-threaded
+_recorder = None
+
+
+def draw(size, device):
+    """One eps tensor for a Bayes-by-backprop layer, on `device`."""
+    size = tuple(size)
+    if _active is not None:
+        return _active._next(size, device)
+    if _recorder is not None:
+        _recorder.shapes.append(size)
+    return torch.empty(size).normal_(0, 1).to(device)
+
+
+class StagedEps:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.shapes = []
+        self._offsets, self._total, self._cursor = None, 0, 0
+        self._host, self._dev, self._done, self._turn = None, None, None, 0
+
+    @contextlib.contextmanager
+    def recording(self):
+        global _recorder
+        self.shapes, self._offsets = [], None
+        _recorder = self
+        try:
+            yield self
+        finally:
+            _recorder = None
+
+    @contextlib.contextmanager
+    def active(self):
+        global _active
+        _active = self
+        try:
+            yield self
+        finally:
+            _active = None
+
+    def _plan(self):
+        offs, n = [], 0
+        for s in self.shapes:
+            offs.append(n)
+            n += (int(torch.Size(s).numel()) + 3) // 4 * 4          # keep every slice 16-byte aligned
+        self._offsets, self._total = offs, n
+        pin = self.device.type == "cuda"
+        self._host = [torch.empty(n).pin_memory() if pin else torch.empty(n) for _ in range(2)]
+        self._dev = torch.empty(n, device=self.device)
+        self._done = [torch.cuda.Event() if pin else None for _ in range(2)]
+
+    def draw_host(self, out):
+        """The recorded sequence of draws, in order, into the flat host tensor `out` (the numbers the lazy route would see)."""
+        for s, o in zip(self.shapes, self._offsets):
+            n = int(torch.Size(s).numel())
+            out[o:o + n].view(s).normal_(0, 1)
+        return out
+
+    def stage(self):
+        """Draw the next forward's eps on the CPU generator and start its copy to the device (current stream)."""
+        if not self.shapes:
+            raise RuntimeError("StagedEps.stage(): nothing recorded; run one step under recording() first")
+        if self._offsets is None:
+            self._plan()
+        k = self._turn = self._turn ^ 1
+        if self._done[k] is not None:
+            self._done[k].synchronize()            # the copy out of this pinned buffer two steps ago
+        self.draw_host(self._host[k])
+        self._dev.copy_(self._host[k], non_blocking=True)
+        if self._done[k] is not None:
+            self._done[k].record()
+        self._cursor = 0
+
+    def rewind(self):
+        """Start handing out the staged buffer from its first draw again (a step function that runs more than once per
+        stage(), e.g. warm-up iterations before a capture, calls this first)."""
+        self._cursor = 0
+
+    def _next(self, size, device):
+        i = self._cursor
+        if i >= len(self.shapes) or self.shapes[i] != size:
+            raise RuntimeError(f"StagedEps: draw {i} asks for {size}, recorded {self.shapes[i] if i < len(self.shapes) else None}")
+        self._cursor += 1
+        o = self._offsets[i]
+        return self._dev[o:o + int(torch.Size(size).numel())].view(size)

@@ -18,6 +18,9 @@ class ModuleWrapper(nn.Module):
         for module in self.modules():
             if hasattr(module, "kl_loss"):
                 kl = kl + module.kl_loss()
+                release = getattr(module, "release_kl_graph", None)
+                if release is not None:
+                    release()
         return x, kl
 
 
