@@ -23,6 +23,17 @@ typedef void* hipStream_t;
 #define MLHOT_DEV __device__ __forceinline__
 #endif
 
+#ifndef MLHOT_HOSTSIM
+// masked gathers point at these words instead of branching around the load or selecting after it (igemm.h, problems.h)
+static __device__ const float g_zero_one[2] = {0.f, 1.f};
+typedef const __attribute__((address_space(1))) float* gfptr;      // explicit global address space: global_load, not flat_load
+// *(ok ? base + off : &g_zero_one[which]) as one global load, without a branch and without a select on the loaded value
+__device__ __forceinline__ float load_or_const(const float* base, int off, bool ok, int which = 0) {
+  gfptr p = ok ? (gfptr)base + off : (gfptr)g_zero_one + which;
+  return *p;
+}
+#endif
+
 #define MLHOT_OK 0
 #define MLHOT_ERR_ARG 1
 #define MLHOT_ERR_WORKSPACE 2

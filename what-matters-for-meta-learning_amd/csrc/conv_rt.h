@@ -9,6 +9,13 @@
 
 namespace mlhot {
 
+#ifndef MLHOT_CONV_BK
+#define MLHOT_CONV_BK 32
+#endif
+// k-depth of one igemm iteration for the run-time-shaped convolutions (measured on the ShapeNet3D ResNet shapes: 32 and 64
+// within 3 % of each other, both ahead of 16; 32 wastes less of conv1's K = 75 and needs 94 instead of 180 VGPRs).
+constexpr int CONV_BK = MLHOT_CONV_BK;
+
 inline ConvShape conv_shape(int N, int Cin, int H, int W, int Cout, int k, int s, int p) {
   ConvShape c{N, Cin, H, W, Cout, k, s, p, (H + 2 * p - k) / s + 1, (W + 2 * p - k) / s + 1};
   return c;
@@ -27,9 +34,23 @@ inline size_t conv_bwd_scratch_bytes(const ConvShape& c) {
   return (size_t)conv_wgrad_split(c) * c.Cout * (c.Cin * c.k * c.k + 1) * sizeof(float) + 256;
 }
 
+// The late ResNet layers have a few hundred to a few thousand GEMM rows: 64-row tiles would leave most of the 256 CUs idle,
+// so below 128 workgroups the row tile shrinks to 16 (one MFMA tile per wave, 4 waves side by side along N).
+template <class P>
+inline int run_conv_igemm(const P& p, hipStream_t s, const char* what) {
+  const long wgs64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+  if (wgs64 < 128) return run_igemm<P, 16, 64, CONV_BK, 1, 4>(p, 1, nullptr, s, what);
+#ifndef MLHOT_CONV_BM         // large layers: 128 x 64 tiles on 8 waves (50-53 TFLOP/s; 64- and 32-row tiles measured 45-47)
+#define MLHOT_CONV_BM 128
+#define MLHOT_CONV_WM 4
+#define MLHOT_CONV_WN 2
+#endif
+  return run_igemm<P, MLHOT_CONV_BM, 64, CONV_BK, MLHOT_CONV_WM, MLHOT_CONV_WN>(p, 1, nullptr, s, what);
+}
+
 inline int conv_rt_forward(const ConvShape& c, const float* x, const float* w, const float* b, float* y, int relu, hipStream_t s) {
   ConvFwdRT p{c.N * c.HO * c.WO, c.Cout, c.Cin * c.k * c.k, c, x, w, b, y, relu};
-  return run_igemm<ConvFwdRT, 64, 64, 16, 2, 2>(p, 1, nullptr, s, "conv2d.fwd");
+  return run_conv_igemm(p, s, "conv2d.fwd");
 }
 
 inline int conv_rt_backward(const ConvShape& c, const float* x, const float* w, const float* yact, const float* dy,
@@ -37,7 +58,7 @@ inline int conv_rt_backward(const ConvShape& c, const float* x, const float* w, 
   if (dw) {
     if (scratch_bytes < conv_bwd_scratch_bytes(c)) { set_error("conv2d_bwd: scratch too small"); return MLHOT_ERR_WORKSPACE; }
     ConvWgradRT p{c.Cout, c.Cin * c.k * c.k + 1, c.N * c.HO * c.WO, c, dy, yact, x, dw, db};
-    MLHOT_TRY((run_igemm<ConvWgradRT, 64, 64, 16, 2, 2>(p, conv_wgrad_split(c), (float*)scratch, s, "conv2d.wgrad")));
+    MLHOT_TRY((run_igemm<ConvWgradRT, 64, 64, CONV_BK, 2, 2>(p, conv_wgrad_split(c), (float*)scratch, s, "conv2d.wgrad")));
   }
   if (dx) {
     for (int py = 0; py < c.s; ++py)
@@ -48,7 +69,7 @@ inline int conv_rt_backward(const ConvShape& c, const float* x, const float* w, 
         if (ny <= 0 || nx <= 0) continue;
         ConvDgradRT p{c.N * ny * nx, c.Cin, nty * ntx * c.Cout, c, py, px, ky0, kx0, nty, ntx > 0 ? ntx : 1, ny, nx, dy, yact, w, dx};
         if (nty * ntx == 0) p.K = 0;   // no tap reaches this class: the kernel stores zeros
-        MLHOT_TRY((run_igemm<ConvDgradRT, 64, 64, 16, 2, 2>(p, 1, nullptr, s, "conv2d.dgrad")));
+        MLHOT_TRY(run_conv_igemm(p, s, "conv2d.dgrad"));
       }
   }
   return MLHOT_OK;

@@ -42,8 +42,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <class P, class = void> struct igemm_hoists : std::false_type {};
 template <class P> struct igemm_hoists<P, std::void_t<typename P::KEnt>> : std::true_type {};
 struct IgemmNoCtx {};
-template <class P, bool F> struct igemm_ctx { typedef IgemmNoCtx K; typedef IgemmNoCtx R; typedef IgemmNoCtx C; };
-template <class P> struct igemm_ctx<P, true> { typedef typename P::KEnt K; typedef typename P::RCtx R; typedef typename P::CCtx C; };
+template <class P, bool F> struct igemm_ctx { typedef IgemmNoCtx K; typedef IgemmNoCtx R; typedef IgemmNoCtx C; typedef float AR; typedef float BR; };
+template <class P> struct igemm_ctx<P, true> {
+  typedef typename P::KEnt K; typedef typename P::RCtx R; typedef typename P::CCtx C;
+  typedef typename P::ARaw AR; typedef typename P::BRaw BR;    // what a gather leaves in registers until the tile is stashed
+};
+
+// a 16-byte k-entry out of LDS as ONE ds_read_b128 (field-wise reads get sunk into per-element branches by the compiler)
+template <class K>
+__device__ __forceinline__ K lds_ent(const K* p) {
+  if constexpr (sizeof(K) == 16) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 v = *reinterpret_cast<const i32x4*>(p);
+    K k;
+    __builtin_memcpy(&k, &v, 16);
+    return k;
+  } else {
+    return *p;
+  }
+}
 
 constexpr int lds_ld16(int b) { return (b % 32 == 16) ? b : b + 16; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -67,9 +84,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
   const int ke = (kb + k_chunk < p.K) ? kb + k_chunk : p.K;
 
   constexpr int EA = (BM * BK + NT - 1) / NT, EB = (BN * BK + NT - 1) / NT;
-  float ra[EA], rb[EB];
   constexpr bool FAST = igemm_hoists<P>::value;
   typedef igemm_ctx<P, FAST> CT;
+  typename CT::AR ra[EA];
+  typename CT::BR rb[EB];
   __shared__ typename CT::K ktab[2][FAST ? BK : 1];
   typename CT::R rctx[EA];
   typename CT::C cctx[EB];
@@ -101,7 +119,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
       const int mm = AK ? e / BK : e % BM, kk = AK ? e % BK : e / BM;
       const int m = m0 + mm, k = k0 + kk;
       const bool ok = e < BM * BK && m < p.M && k < ke;
-      if constexpr (FAST) ra[i] = ok ? p.A2(rctx[i], ktab[kt][kk], m, k) : 0.f;
+      if constexpr (FAST) ra[i] = p.A2(rctx[i], lds_ent(&ktab[kt][kk]), m, k, ok);
       else ra[i] = ok ? p.A(m, k) : 0.f;
     }
 #pragma unroll
@@ -110,7 +128,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
       const int nn = BKc ? e / BK : e % BN, kk = BKc ? e % BK : e / BN;
       const int n = n0 + nn, k = k0 + kk;
       const bool ok = e < BN * BK && n < p.N && k < ke;
-      if constexpr (FAST) rb[i] = ok ? p.B2(ktab[kt][kk], cctx[i], k, n) : 0.f;
+      if constexpr (FAST) rb[i] = p.B2(lds_ent(&ktab[kt][kk]), cctx[i], k, n, ok);
       else rb[i] = ok ? p.B(k, n) : 0.f;
     }
   };
@@ -125,13 +143,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
     for (int i = 0; i < EA; ++i) {
       const int e = tid + i * NT;
       const int mm = AK ? e / BK : e % BM, kk = AK ? e % BK : e / BM;
-      if (e < BM * BK) As[AK ? mm * LDK + kk : kk * LDA + mm] = ra[i];
+      if constexpr (FAST) { if (e < BM * BK) As[AK ? mm * LDK + kk : kk * LDA + mm] = p.Afin(ra[i]); }
+      else if (e < BM * BK) As[AK ? mm * LDK + kk : kk * LDA + mm] = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < EB; ++i) {
       const int e = tid + i * NT;
       const int nn = BKc ? e / BK : e % BN, kk = BKc ? e % BK : e / BN;
-      if (e < BN * BK) Bs[BKc ? nn * LDK + kk : kk * LDB + nn] = rb[i];
+      if constexpr (FAST) { if (e < BN * BK) Bs[BKc ? nn * LDK + kk : kk * LDB + nn] = p.Bfin(rb[i]); }
+      else if (e < BN * BK) Bs[BKc ? nn * LDK + kk : kk * LDB + nn] = rb[i];
     }
   };
 

@@ -169,12 +169,12 @@ struct ConvFwdRT {
     y[((size_t)img * c.Cout + n) * hw + r] = v;
   }
   // hoisted index parts (igemm.h): same values as A / B above
-  struct KEnt { int off, ky, kx; };            // k -> (ci, ky, kx): ci*H*W + ky*W + kx
+  struct alignas(16) KEnt { int off, ky, kx, pad; };   // k -> (ci, ky, kx): ci*H*W + ky*W + kx (one 16-byte LDS read)
   struct RCtx { int base, iy0, ix0; };         // m -> (img, oy, ox): img*Cin*H*W + iy0*W + ix0
   struct CCtx { int woff; };
   MLHOT_HD KEnt kent(int k) const {
     const int kk = c.k * c.k, ci = k / kk, t = k % kk, ky = t / c.k, kx = t % c.k;
-    return KEnt{(ci * c.H + ky) * c.W + kx, ky, kx};
+    return KEnt{(ci * c.H + ky) * c.W + kx, ky, kx, 0};
   }
   MLHOT_HD RCtx rctx(int m) const {
     const int hw = c.HO * c.WO, img = m / hw, r = m % hw, oy = r / c.WO, ox = r % c.WO;
@@ -182,12 +182,21 @@ struct ConvFwdRT {
     return RCtx{img * c.Cin * c.H * c.W + iy0 * c.W + ix0, iy0, ix0};
   }
   MLHOT_HD CCtx cctx(int n) const { return CCtx{n * K}; }
-  MLHOT_HD float A2(const RCtx& r, const KEnt& e, int, int) const {
+#ifndef MLHOT_HOSTSIM
+  // A2 / B2 are branch-free AND select-free on purpose: a masked element (tile bounds `ok`, padding) loads the zero word of
+  // g_zero_one instead, so the gathers of a tile issue back to back and nothing waits on them until the tile is stashed
+  typedef float ARaw; typedef float BRaw;
+  MLHOT_DEV float A2(const RCtx& r, const KEnt& e, int, int, bool ok) const {
     const int iy = r.iy0 + e.ky, ix = r.ix0 + e.kx;
-    if (iy < 0 || iy >= c.H || ix < 0 || ix >= c.W) return 0.f;
-    return x[r.base + e.off];
+    const bool in = ok & ((unsigned)iy < (unsigned)c.H) & ((unsigned)ix < (unsigned)c.W);
+    return load_or_const(x, r.base + e.off, in);
   }
-  MLHOT_HD float B2(const KEnt&, const CCtx& cc, int k, int) const { return w[cc.woff + k]; }
+  MLHOT_DEV float B2(const KEnt&, const CCtx& cc, int k, int, bool ok) const {
+    return load_or_const(w, cc.woff + k, ok);
+  }
+  MLHOT_DEV float Afin(float v) const { return v; }
+  MLHOT_DEV float Bfin(float v) const { return v; }
+#endif
 };
 
 // data gradient for the class of input positions y = s*y' + py, x = s*x' + px: only taps with
@@ -217,7 +226,7 @@ struct ConvDgradRT {
     dx[(((size_t)img * c.Cin + n) * c.H + c.s * yp + py) * c.W + c.s * xp + px] = v;
   }
   // hoisted index parts (igemm.h)
-  struct KEnt { int co, ky, kx, woff; };        // k -> (co, ty, tx); woff = (co*Cin*k + ky)*k + kx
+  struct alignas(16) KEnt { int co, ky, kx, woff; };   // k -> (co, ty, tx); woff = (co*Cin*k + ky)*k + kx
   struct RCtx { int ibase, yb, xb; };           // m -> (img, y', x'): img*Cout*HO*WO, s*y'+py+p, s*x'+px+p
   struct CCtx { int noff; };                    // n*k*k
   MLHOT_HD KEnt kent(int k) const {
@@ -230,15 +239,24 @@ struct ConvDgradRT {
     return RCtx{img * c.Cout * c.HO * c.WO, c.s * yp + py + c.p, c.s * xp + px + c.p};
   }
   MLHOT_HD CCtx cctx(int n) const { return CCtx{n * c.k * c.k}; }
-  MLHOT_HD float A2(const RCtx& r, const KEnt& e, int, int) const {
+#ifndef MLHOT_HOSTSIM
+  struct ARaw { float g, a; };                  // dY and the forward activation it is masked by (resolved at stash time)
+  typedef float BRaw;
+  MLHOT_DEV ARaw A2(const RCtx& r, const KEnt& e, int, int, bool ok) const {       // select-free, see ConvFwdRT
     const int ty_ = r.yb - e.ky, tx_ = r.xb - e.kx;           // multiples of s by construction of the class
-    if (ty_ < 0 || tx_ < 0) return 0.f;
     const int oy = c.s == 1 ? ty_ : (c.s == 2 ? ty_ >> 1 : ty_ / c.s), ox = c.s == 1 ? tx_ : (c.s == 2 ? tx_ >> 1 : tx_ / c.s);
-    if (oy >= c.HO || ox >= c.WO) return 0.f;
+    const bool in = ok & (ty_ >= 0) & (tx_ >= 0) & (oy < c.HO) & (ox < c.WO);
     const int o = r.ibase + (e.co * c.HO + oy) * c.WO + ox;
-    return (yact == nullptr || yact[o] > 0.f) ? dy[o] : 0.f;
+    ARaw v{load_or_const(dy, o, in), 1.f};
+    if (yact != nullptr) v.a = load_or_const(yact, o, in);
+    return v;
   }
-  MLHOT_HD float B2(const KEnt& e, const CCtx& cc, int, int) const { return w[e.woff + cc.noff]; }
+  MLHOT_DEV float B2(const KEnt& e, const CCtx& cc, int, int, bool ok) const {
+    return load_or_const(w, e.woff + cc.noff, ok);
+  }
+  MLHOT_DEV float Afin(const ARaw& v) const { return v.a > 0.f ? v.g : 0.f; }
+  MLHOT_DEV float Bfin(float v) const { return v; }
+#endif
 };
 
 struct ConvWgradRT {
@@ -264,7 +282,7 @@ struct ConvWgradRT {
     else dw[(size_t)m * (N - 1) + n] = v;
   }
   // hoisted index parts (igemm.h)
-  struct KEnt { int abase, xbase, iy0, ix0; };  // k -> (img, oy, ox): img*Cout*hw + r, img*Cin*H*W + iy0*W + ix0
+  struct alignas(16) KEnt { int abase, xbase, iy0, ix0; };  // k -> (img, oy, ox): img*Cout*hw + r, img*Cin*H*W + iy0*W + ix0
   struct RCtx { int moff; };                    // m*hw
   struct CCtx { int off, ky, kx, bias; };       // n -> (ci, ky, kx): ci*H*W + ky*W + kx
   MLHOT_HD KEnt kent(int k) const {
@@ -278,16 +296,23 @@ struct ConvWgradRT {
     const int kk = c.k * c.k, ci = n / kk, t = n % kk, ky = t / c.k, kx = t % c.k;
     return CCtx{(ci * c.H + ky) * c.W + kx, ky, kx, 0};
   }
-  MLHOT_HD float A2(const RCtx& r, const KEnt& e, int, int) const {
+#ifndef MLHOT_HOSTSIM
+  struct ARaw { float g, a; };
+  typedef float BRaw;
+  MLHOT_DEV ARaw A2(const RCtx& r, const KEnt& e, int, int, bool ok) const {       // select-free, see ConvFwdRT
     const int o = e.abase + r.moff;
-    return (yact == nullptr || yact[o] > 0.f) ? dy[o] : 0.f;
+    ARaw v{load_or_const(dy, o, ok), 1.f};
+    if (yact != nullptr) v.a = load_or_const(yact, o, ok);
+    return v;
   }
-  MLHOT_HD float B2(const KEnt& e, const CCtx& cc, int, int) const {
-    if (cc.bias) return 1.f;
+  MLHOT_DEV float B2(const KEnt& e, const CCtx& cc, int, int, bool ok) const {
     const int iy = e.iy0 + cc.ky, ix = e.ix0 + cc.kx;
-    if (iy < 0 || iy >= c.H || ix < 0 || ix >= c.W) return 0.f;
-    return x[e.xbase + cc.off];
+    const bool in = ok & (cc.bias == 0) & ((unsigned)iy < (unsigned)c.H) & ((unsigned)ix < (unsigned)c.W);
+    return load_or_const(x, e.xbase + cc.off, in, (int)(ok & (cc.bias != 0)));   // the bias column reads the 1.0 word
   }
+  MLHOT_DEV float Afin(const ARaw& v) const { return v.a > 0.f ? v.g : 0.f; }
+  MLHOT_DEV float Bfin(float v) const { return v; }
+#endif
 };
 
 // ------------------------------------------------------------------------------------------
