@@ -112,7 +112,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  static_assert(EA <= 32 && EB <= 32, "tile-bounds masks are one word per operand");
+  unsigned amask = 0, bmask = 0;
   auto fetch = [&](int k0) {
+    amask = bmask = 0;
 #pragma unroll
     for (int i = 0; i < EA; ++i) {
       const int e = tid + i * NT;
@@ -120,7 +123,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
       const int m = m0 + mm, k = k0 + kk;
       const bool ok = e < BM * BK && m < p.M && k < ke;
       if constexpr (FAST) ra[i] = p.A2(rctx[i], lds_ent(&ktab[kt][kk]), m, k, ok);
-      else ra[i] = ok ? p.A(m, k) : 0.f;
+      else {      // in-range indices for every lane, the tile-bounds mask is applied when the tile is stashed: no branch
+        ra[i] = p.A(m < p.M ? m : p.M - 1, k < ke ? k : ke - 1);    // around (and no wait behind) the individual load
+        amask |= (unsigned)ok << i;
+      }
     }
 #pragma unroll
     for (int i = 0; i < EB; ++i) {
@@ -129,7 +135,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
       const int n = n0 + nn, k = k0 + kk;
       const bool ok = e < BN * BK && n < p.N && k < ke;
       if constexpr (FAST) rb[i] = p.B2(lds_ent(&ktab[kt][kk]), cctx[i], k, n, ok);
-      else rb[i] = ok ? p.B(k, n) : 0.f;
+      else {
+        rb[i] = p.B(k < ke ? k : ke - 1, n < p.N ? n : p.N - 1);
+        bmask |= (unsigned)ok << i;
+      }
     }
   };
   // k-dependent index parts of the tile starting at k0 -> ktab[half] (BK threads; published by the next barrier)
@@ -144,14 +153,14 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
       const int e = tid + i * NT;
       const int mm = AK ? e / BK : e % BM, kk = AK ? e % BK : e / BM;
       if constexpr (FAST) { if (e < BM * BK) As[AK ? mm * LDK + kk : kk * LDA + mm] = p.Afin(ra[i]); }
-      else if (e < BM * BK) As[AK ? mm * LDK + kk : kk * LDA + mm] = ra[i];
+      else if (e < BM * BK) As[AK ? mm * LDK + kk : kk * LDA + mm] = (amask >> i) & 1u ? ra[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < EB; ++i) {
       const int e = tid + i * NT;
       const int nn = BKc ? e / BK : e % BN, kk = BKc ? e % BK : e / BN;
       if constexpr (FAST) { if (e < BN * BK) Bs[BKc ? nn * LDK + kk : kk * LDB + nn] = p.Bfin(rb[i]); }
-      else if (e < BN * BK) Bs[BKc ? nn * LDK + kk : kk * LDB + nn] = rb[i];
+      else if (e < BN * BK) Bs[BKc ? nn * LDK + kk : kk * LDB + nn] = (bmask >> i) & 1u ? rb[i] : 0.f;
     }
   };
 
