@@ -58,22 +58,25 @@ inline FavorWs favor_carve(const FavorDims& f, void* ws, size_t bytes, size_t* n
 struct ScaleCopy { const float* s; float* d; float a; MLHOT_HD void operator()(size_t i) const { d[i] = a * s[i]; } };
 
 // per row: diag = c^2/2 |x|^2, max_j dd[row][j] and its (first) arg-max
-struct FavorRowStat {
-  const float* x; const float* dd; int d, m; float half_c2;
-  float* diag; float* mx; int* arg;
-  MLHOT_HD void operator()(size_t row) const {
-    const float* xr = x + row * d;
-    float s = 0.f;
-    for (int e = 0; e < d; ++e) s += xr[e] * xr[e];
-    diag[row] = s * half_c2;
-    const float* r = dd + row * m;
-    float best = r[0]; int a = 0;
-    for (int j = 1; j < m; ++j) if (r[j] > best) { best = r[j]; a = j; }
-    mx[row] = best; arg[row] = a;
-  }
+// Per-row statistics of the projected data, one workgroup per row (segmented reductions, fixed-order trees):
+// diag = 0.5 c^2 |x|^2 (fast_attention.py:86-88) and the row maximum of data_dash with its FIRST position.
+struct FavorRowDiag {
+  typedef float T;
+  const float* x; int d; float half_c2; float* diag;
+  MLHOT_HD T identity() const { return 0.f; }
+  MLHOT_HD T load(int row, int e) const { const float v = x[(size_t)row * d + e]; return v * v; }
+  MLHOT_HD T combine(T a, T b) const { return a + b; }
+  MLHOT_HD void finish(int row, T a) const { diag[row] = a * half_c2; }
 };
-
 struct ArgMaxPair { float v; int i; };
+struct FavorRowMax {
+  typedef ArgMaxPair T;
+  const float* dd; int m; float* mx; int* arg;
+  MLHOT_HD T identity() const { return T{-INFINITY, 0x7fffffff}; }
+  MLHOT_HD T load(int row, int j) const { return T{dd[(size_t)row * m + j], j}; }
+  MLHOT_HD T combine(T a, T b) const { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+  MLHOT_HD void finish(int row, T a) const { mx[row] = a.v; arg[row] = a.i; }
+};
 struct FavorGlobalMax {   // torch.max(data_dash) over every key row (fast_attention.py:97)
   typedef ArgMaxPair T;
   const float* mx; const int* arg; float* gmax; int* gpos;
@@ -185,13 +188,13 @@ struct FavorBwdG {
     G[i] = acc * self_f[i];
   }
 };
-struct RowSum {
+struct RowSum {            // one workgroup per row
+  typedef float T;
   const float* G; int m; float* rs;
-  MLHOT_HD void operator()(size_t row) const {
-    float s = 0.f;
-    for (int j = 0; j < m; ++j) s += G[row * m + j];
-    rs[row] = s;
-  }
+  MLHOT_HD T identity() const { return 0.f; }
+  MLHOT_HD T load(int row, int j) const { return G[(size_t)row * m + j]; }
+  MLHOT_HD T combine(T a, T b) const { return a + b; }
+  MLHOT_HD void finish(int row, T a) const { rs[row] = a; }
 };
 struct SumRed {
   typedef float T;
@@ -214,10 +217,12 @@ inline int favor_forward(const FavorDims& f, const float* q, const float* k, con
   WBlocks pb{}; pb.w[0] = w.pc; pb.b[0] = nullptr; pb.rows = f.m;
   LinearFwd lq{(int)rq, f.m, f.d, q, f.d, pb, w.qf, f.m, ACT_NONE};
   LinearFwd lk{(int)rk, f.m, f.d, k, f.d, pb, w.kf, f.m, ACT_NONE};
-  MLHOT_TRY((run_igemm<LinearFwd, 64, 64, 16, 2, 2>(lq, 1, nullptr, s, "favor.ddq")));
-  MLHOT_TRY((run_igemm<LinearFwd, 64, 64, 16, 2, 2>(lk, 1, nullptr, s, "favor.ddk")));
-  MLHOT_TRY(run_foreach(FavorRowStat{q, w.qf, f.d, f.m, 0.5f * c * c, w.diag_q, w.max_q, w.arg_q}, rq, s, "favor.rowstat_q"));
-  MLHOT_TRY(run_foreach(FavorRowStat{k, w.kf, f.d, f.m, 0.5f * c * c, w.diag_k, w.max_k, w.arg_k}, rk, s, "favor.rowstat_k"));
+  MLHOT_TRY(run_igemm_auto(lq, s, "favor.ddq"));
+  MLHOT_TRY(run_igemm_auto(lk, s, "favor.ddk"));
+  MLHOT_TRY(run_reduce_seg(FavorRowDiag{q, f.d, 0.5f * c * c, w.diag_q}, (int)rq, f.d, s, "favor.rowdiag_q"));
+  MLHOT_TRY(run_reduce_seg(FavorRowDiag{k, f.d, 0.5f * c * c, w.diag_k}, (int)rk, f.d, s, "favor.rowdiag_k"));
+  MLHOT_TRY(run_reduce_seg(FavorRowMax{w.qf, f.m, w.max_q, w.arg_q}, (int)rq, f.m, s, "favor.rowmax_q"));
+  MLHOT_TRY(run_reduce_seg(FavorRowMax{w.kf, f.m, w.max_k, w.arg_k}, (int)rk, f.m, s, "favor.rowmax_k"));
   MLHOT_TRY(run_reduce1(FavorGlobalMax{w.max_k, w.arg_k, w.gmax, w.gpos}, (int)rk, s, "favor.gmax"));
   MLHOT_TRY(run_foreach(FavorFeat{w.qf, w.diag_q, w.max_q, nullptr, f.m, ratio}, rq * f.m, s, "favor.feat_q"));
   MLHOT_TRY(run_foreach(FavorFeat{w.kf, w.diag_k, nullptr, w.gmax, f.m, ratio}, rk * f.m, s, "favor.feat_k"));
@@ -238,13 +243,13 @@ inline int favor_backward(const FavorDims& f, const float* q, const float* k, co
   MLHOT_TRY(run_foreach(FavorBwdDV{f, w.S, w.D, dout, dv}, rk * f.d, s, "favor.bwd.dv"));
   MLHOT_TRY(run_foreach(FavorBwdG{f, 1, w.dS, w.qf, w.kf, ratio * eps, w.Gq}, rq * f.m, s, "favor.bwd.Gq"));
   MLHOT_TRY(run_foreach(FavorBwdG{f, 0, w.dS, w.kf, w.qf, ratio * eps, w.Gk}, rk * f.m, s, "favor.bwd.Gk"));
-  MLHOT_TRY(run_foreach(RowSum{w.Gq, f.m, w.rsum_q}, rq, s, "favor.bwd.rsum_q"));
-  MLHOT_TRY(run_foreach(RowSum{w.Gk, f.m, w.rsum_k}, rk, s, "favor.bwd.rsum_k"));
+  MLHOT_TRY(run_reduce_seg(RowSum{w.Gq, f.m, w.rsum_q}, (int)rq, f.m, s, "favor.bwd.rsum_q"));
+  MLHOT_TRY(run_reduce_seg(RowSum{w.Gk, f.m, w.rsum_k}, (int)rk, f.m, s, "favor.bwd.rsum_k"));
   MLHOT_TRY(run_reduce1(SumRed{w.rsum_k, w.gtotal}, (int)rk, s, "favor.bwd.gtotal"));
   FavorDx xq{(int)rq, f.d, f.m, w.Gq, w.rsum_q, w.arg_q, nullptr, nullptr, w.pc, q, c * c, dq};
   FavorDx xk{(int)rk, f.d, f.m, w.Gk, w.rsum_k, nullptr, w.gpos, w.gtotal, w.pc, k, c * c, dk};
-  MLHOT_TRY((run_igemm<FavorDx, 64, 64, 16, 2, 2>(xq, 1, nullptr, s, "favor.bwd.dq")));
-  MLHOT_TRY((run_igemm<FavorDx, 64, 64, 16, 2, 2>(xk, 1, nullptr, s, "favor.bwd.dk")));
+  MLHOT_TRY(run_igemm_auto(xq, s, "favor.bwd.dq"));
+  MLHOT_TRY(run_igemm_auto(xk, s, "favor.bwd.dk"));
   return MLHOT_OK;
 }
 

@@ -289,4 +289,14 @@ int run_igemm(const P& p, int nsplit, float* slab, hipStream_t stream, const cha
 #endif
 }
 
+// Tile choice for plain GEMM-shaped problems without split-K: 64 x 64 tiles, or 16-row tiles when those would occupy fewer
+// than 128 workgroups (the attention / MLP layers of the ResNet-family models have 120-960 rows: a handful of 64-row tiles
+// on a 256-CU machine); k tiles are 32 deep.
+template <class P>
+int run_igemm_auto(const P& p, hipStream_t s, const char* what) {
+  const long wgs64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+  if (wgs64 < 128) return run_igemm<P, 16, 64, 32, 1, 4>(p, 1, nullptr, s, what);
+  return run_igemm<P, 64, 64, 32, 2, 2>(p, 1, nullptr, s, what);
+}
+
 }  // namespace mlhot

@@ -120,30 +120,21 @@ inline WBlocksMut gb8(float* const* w, float* const* b, int rows) {
   WBlocksMut x{}; for (int i = 0; i < MLHOT_HEADS; ++i) { x.w[i] = w[i]; x.b[i] = b[i]; } x.rows = rows; return x;
 }
 
-// Tile choice for the Linear GEMMs: 64 x 64 tiles, or 16-row tiles when those would occupy fewer than 128 workgroups (the
-// attention / MLP layers of the ResNet-family models have 120-240 rows: two or four 64-row tiles on a 256-CU machine).
-template <class P>
-inline int run_lin_igemm(const P& p, hipStream_t s, const char* what) {
-  const long wgs64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-  if (wgs64 < 128) return run_igemm<P, 16, 64, 32, 1, 4>(p, 1, nullptr, s, what);
-  return run_igemm<P, 64, 64, 32, 2, 2>(p, 1, nullptr, s, what);
-}
-
 inline int lin_fwd(const float* x, int ldx, const WBlocks& wb, float* y, int ldy, int M, int K, int N, int act,
                    hipStream_t s, const char* what) {
   LinearFwd p{M, N, K, x, ldx, wb, y, ldy, act};
-  return run_lin_igemm(p, s, what);
+  return run_igemm_auto(p, s, what);
 }
 // dx[M][Kin] (+)= (dy * act'(y)) W
 inline int lin_dgrad(const float* dy, int lddy, const float* y, int ldy, int act, const WBlocks& wb,
                      float* dx, int lddx, int accumulate, int M, int Kin, int Nout, hipStream_t s, const char* what) {
   LinearDgrad p{M, Kin, Nout, dy, lddy, y, ldy, act, wb, dx, lddx, accumulate};
-  return run_lin_igemm(p, s, what);
+  return run_igemm_auto(p, s, what);
 }
 inline int lin_wgrad(const float* dy, int lddy, const float* y, int ldy, int act, const float* x, int ldx,
                      const WBlocksMut& gb, int M, int Kin, int Nout, hipStream_t s, const char* what) {
   LinearWgrad p{Nout, Kin + 1, M, dy, lddy, y, ldy, act, x, ldx, gb};
-  return run_lin_igemm(p, s, what);
+  return run_igemm_auto(p, s, what);
 }
 
 #ifndef MLHOT_HOSTSIM
