@@ -15,6 +15,11 @@ namespace mlhot {
 // k-depth of one igemm iteration for the run-time-shaped convolutions (measured on the ShapeNet3D ResNet shapes: 32 and 64
 // within 3 % of each other, both ahead of 16; 32 wastes less of conv1's K = 75 and needs 94 instead of 180 VGPRs).
 constexpr int CONV_BK = MLHOT_CONV_BK;
+#ifndef MLHOT_CONV_BM         // large layers: 128 x 64 tiles on 8 waves (50-53 TFLOP/s; 64- and 32-row tiles measured 45-47)
+#define MLHOT_CONV_BM 128
+#define MLHOT_CONV_WM 4
+#define MLHOT_CONV_WN 2
+#endif
 
 inline ConvShape conv_shape(int N, int Cin, int H, int W, int Cout, int k, int s, int p) {
   ConvShape c{N, Cin, H, W, Cout, k, s, p, (H + 2 * p - k) / s + 1, (W + 2 * p - k) / s + 1};
@@ -40,11 +45,6 @@ template <class P>
 inline int run_conv_igemm(const P& p, hipStream_t s, const char* what) {
   const long wgs64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
   if (wgs64 < 128) return run_igemm<P, 16, 64, CONV_BK, 1, 4>(p, 1, nullptr, s, what);
-#ifndef MLHOT_CONV_BM         // large layers: 128 x 64 tiles on 8 waves (50-53 TFLOP/s; 64- and 32-row tiles measured 45-47)
-#define MLHOT_CONV_BM 128
-#define MLHOT_CONV_WM 4
-#define MLHOT_CONV_WN 2
-#endif
   return run_igemm<P, MLHOT_CONV_BM, 64, CONV_BK, MLHOT_CONV_WM, MLHOT_CONV_WN>(p, 1, nullptr, s, what);
 }
 
@@ -61,6 +61,16 @@ inline int conv_rt_backward(const ConvShape& c, const float* x, const float* w, 
     MLHOT_TRY((run_igemm<ConvWgradRT, 64, 64, CONV_BK, 2, 2>(p, conv_wgrad_split(c), (float*)scratch, s, "conv2d.wgrad")));
   }
   if (dx) {
+    // one GEMM per parity class of input positions (s*s of them); up to 4 go out as ONE launch
+    IgemmBatch<ConvDgradRT> batch{};
+    long wgs64 = 0;
+    auto flush = [&]() -> int {
+      if (batch.n == 0) return MLHOT_OK;
+      const int rc = wgs64 < 128 ? run_igemm_batch<ConvDgradRT, 16, 64, CONV_BK, 1, 4>(batch, s, "conv2d.dgrad")
+                                 : run_igemm_batch<ConvDgradRT, MLHOT_CONV_BM, 64, CONV_BK, MLHOT_CONV_WM, MLHOT_CONV_WN>(batch, s, "conv2d.dgrad");
+      batch.n = 0; wgs64 = 0;
+      return rc;
+    };
     for (int py = 0; py < c.s; ++py)
       for (int px = 0; px < c.s; ++px) {
         const int ky0 = (py + c.p) % c.s, kx0 = (px + c.p) % c.s;
@@ -69,8 +79,11 @@ inline int conv_rt_backward(const ConvShape& c, const float* x, const float* w, 
         if (ny <= 0 || nx <= 0) continue;
         ConvDgradRT p{c.N * ny * nx, c.Cin, nty * ntx * c.Cout, c, py, px, ky0, kx0, nty, ntx > 0 ? ntx : 1, ny, nx, dy, yact, w, dx};
         if (nty * ntx == 0) p.K = 0;   // no tap reaches this class: the kernel stores zeros
-        MLHOT_TRY(run_conv_igemm(p, s, "conv2d.dgrad"));
+        batch.p[batch.n++] = p;
+        wgs64 += (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+        if (batch.n == 4) MLHOT_TRY(flush());
       }
+    MLHOT_TRY(flush());
   }
   return MLHOT_OK;
 }

@@ -35,6 +35,8 @@ struct SlabReduceArgs {
   int nsplit;
 };
 
+template <class P> struct IgemmBatch { P p[4]; int n; };      // up to 4 problems of one type for one launch (run_igemm_batch)
+
 #ifndef MLHOT_HOSTSIM
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -65,8 +67,9 @@ __device__ __forceinline__ K lds_ent(const K* p) {
 constexpr int lds_ld16(int b) { return (b % 32 == 16) ? b : b + 16; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// One output tile of problem `p`: tile (blockIdx.x, blockIdx.y), k range [kz * k_chunk, (kz + 1) * k_chunk).
 template <class P, int BM, int BN, int BK, int WM, int WN, bool SPLIT>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __restrict__ slab, int k_chunk) {
+__device__ __forceinline__ void igemm_tile(const P& p, float* __restrict__ slab, int k_chunk, int kz) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && BK % 4 == 0, "tile shape");
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int kb = blockIdx.z * k_chunk;
+  const int kb = kz * k_chunk;
   const int ke = (kb + k_chunk < p.K) ? kb + k_chunk : p.K;
 
   constexpr int EA = (BM * BK + NT - 1) / NT, EB = (BN * BK + NT - 1) / NT;
@@ -208,11 +211,25 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __
         const int n = n0 + (wn * TN + j) * 16 + lr;
         if (m < p.M && n < p.N) {
           if (SPLIT)
-            slab[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+            slab[((size_t)kz * p.M + m) * p.N + n] = acc[i][j][r];
           else
             p.store(m, n, acc[i][j][r]);
         }
       }
+}
+
+template <class P, int BM, int BN, int BK, int WM, int WN, bool SPLIT>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const P p, float* __restrict__ slab, int k_chunk) {
+  igemm_tile<P, BM, BN, BK, WM, WN, SPLIT>(p, slab, k_chunk, blockIdx.z);
+}
+
+// Up to 4 independent problems of one type in ONE launch (blockIdx.z picks the problem, no split-K): the stride-2 data
+// gradients are four small GEMMs, one per input-position parity class.
+template <class P, int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_batch_kernel(const IgemmBatch<P> b) {
+  const P& p = b.p[blockIdx.z];
+  if ((int)blockIdx.x * BM >= p.M || (int)blockIdx.y * BN >= p.N) return;      // the grid is sized for the largest member
+  igemm_tile<P, BM, BN, BK, WM, WN, false>(p, nullptr, (p.K + BK - 1) / BK * BK > 0 ? (p.K + BK - 1) / BK * BK : BK, 0);
 }
 
 // 32 outputs x 8 split-lanes per workgroup: each lane sums every 8th partial (coalesced across the
@@ -285,6 +302,25 @@ int run_igemm(const P& p, int nsplit, float* slab, hipStream_t stream, const cha
   int rb = (int)((total + 31) / 32);
   if (rb > 4096) rb = 4096;
   hipLaunchKernelGGL((slab_reduce_kernel<P>), dim3(rb), dim3(256), 0, stream, a);
+  return check_launch(what);
+#endif
+}
+
+// Launch the members of `b` (same problem type, no split-K) together; hostsim evaluates them one after the other.
+template <class P, int BM, int BN, int BK, int WM, int WN>
+int run_igemm_batch(const IgemmBatch<P>& b, hipStream_t stream, const char* what) {
+#ifdef MLHOT_HOSTSIM
+  for (int i = 0; i < b.n; ++i) { int rc = run_igemm<P, BM, BN, BK, WM, WN>(b.p[i], 1, nullptr, stream, what); if (rc) return rc; }
+  return MLHOT_OK;
+#else
+  int gx = 0, gy = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const int x = (b.p[i].M + BM - 1) / BM, y = (b.p[i].N + BN - 1) / BN;
+    gx = x > gx ? x : gx; gy = y > gy ? y : gy;
+  }
+  if (b.n <= 0 || gx == 0 || gy == 0) return MLHOT_OK;
+  ProfScope ps(what, stream);
+  hipLaunchKernelGGL((igemm_batch_kernel<P, BM, BN, BK, WM, WN>), dim3(gx, gy, b.n), dim3(WM * WN * 64), 0, stream, b);
   return check_launch(what);
 #endif
 }
