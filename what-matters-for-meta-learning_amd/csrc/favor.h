@@ -99,17 +99,18 @@ struct FavorFeat {
 };
 
 // S[t][h][n][n'] = Q'[(t,n,h)] . K'[(t,n',h)]
-struct FavorS {
+struct FavorS {            // S[t,h,n,n'] = Q'[t,h,n,:] . K'[t,h,n',:]: one workgroup per entry, reduction over the m features
+  typedef float T;
   FavorDims f; const float* qf; const float* kf; float re; float* S;
-  MLHOT_HD void operator()(size_t i) const {
-    const int np = (int)(i % f.Nc), n = (int)((i / f.Nc) % f.Nq), h = (int)((i / ((size_t)f.Nc * f.Nq)) % f.H);
-    const size_t t = i / ((size_t)f.Nc * f.Nq * f.H);
-    const float* a = qf + ((t * f.Nq + n) * f.H + h) * f.m;
-    const float* b = kf + ((t * f.Nc + np) * f.H + h) * f.m;
-    float s = 0.f;
-    for (int j = 0; j < f.m; ++j) s = fmaf(a[j] + re, b[j] + re, s);
-    S[i] = s;
+  MLHOT_HD T identity() const { return 0.f; }
+  MLHOT_HD T load(int i, int j) const {
+    const int np = i % f.Nc, n = (i / f.Nc) % f.Nq, h = (i / (f.Nc * f.Nq)) % f.H, t = i / (f.Nc * f.Nq * f.H);
+    const float* a = qf + ((size_t)(t * f.Nq + n) * f.H + h) * f.m;
+    const float* b = kf + ((size_t)(t * f.Nc + np) * f.H + h) * f.m;
+    return (a[j] + re) * (b[j] + re);
   }
+  MLHOT_HD T combine(T a, T b) const { return a + b; }
+  MLHOT_HD void finish(int i, T a) const { S[i] = a; }
 };
 struct FavorD {
   int Nc; const float* S; float* D;
@@ -135,28 +136,34 @@ struct FavorOut {
 
 // ---- backward -------------------------------------------------------------------------------
 // wv[t,h,n] = sum_e dO O
-struct FavorBwdW {
+struct FavorBwdW {          // one workgroup per (t, h, n), reduction over the d channels
+  typedef float T;
   FavorDims f; const float* out; const float* dout; float* wv;
-  MLHOT_HD void operator()(size_t i) const {
-    const int n = (int)(i % f.Nq), h = (int)((i / f.Nq) % f.H); const size_t t = i / ((size_t)f.Nq * f.H);
-    const size_t base = (t * f.Nq + n) * ((size_t)f.d * f.H) + h;
-    float s = 0.f;
-    for (int e = 0; e < f.d; ++e) s = fmaf(dout[base + (size_t)e * f.H], out[base + (size_t)e * f.H], s);
-    wv[i] = s;
+  MLHOT_HD T identity() const { return 0.f; }
+  MLHOT_HD T load(int i, int e) const {
+    const int n = i % f.Nq, h = (i / f.Nq) % f.H, t = i / (f.Nq * f.H);
+    const size_t o = (size_t)(t * f.Nq + n) * ((size_t)f.d * f.H) + h + (size_t)e * f.H;
+    return dout[o] * out[o];
   }
+  MLHOT_HD T combine(T a, T b) const { return a + b; }
+  MLHOT_HD void finish(int i, T a) const { wv[i] = a; }
 };
 // dS[t,h,n,n'] = (dO[t,h,n,:] . v[(t,n',h),:] - wv[t,h,n]) / D[t,h,n]
-struct FavorBwdDS {
+struct FavorBwdDS {         // one workgroup per entry, reduction over the d channels
+  typedef float T;
   FavorDims f; const float* dout; const float* v; const float* wv; const float* D; float* dS;
-  MLHOT_HD void operator()(size_t i) const {
-    const int np = (int)(i % f.Nc), n = (int)((i / f.Nc) % f.Nq), h = (int)((i / ((size_t)f.Nc * f.Nq)) % f.H);
-    const size_t t = i / ((size_t)f.Nc * f.Nq * f.H);
-    const size_t ob = (t * f.Nq + n) * ((size_t)f.d * f.H) + h;
-    const float* vr = v + ((t * f.Nc + np) * f.H + h) * f.d;
-    float s = 0.f;
-    for (int e = 0; e < f.d; ++e) s = fmaf(dout[ob + (size_t)e * f.H], vr[e], s);
-    const size_t sd = (t * f.H + h) * f.Nq + n;
-    dS[i] = (s - wv[sd]) / D[sd];
+  MLHOT_HD T identity() const { return 0.f; }
+  MLHOT_HD T load(int i, int e) const {
+    const int np = i % f.Nc, n = (i / f.Nc) % f.Nq, h = (i / (f.Nc * f.Nq)) % f.H, t = i / (f.Nc * f.Nq * f.H);
+    const size_t ob = (size_t)(t * f.Nq + n) * ((size_t)f.d * f.H) + h;
+    const float* vr = v + ((size_t)(t * f.Nc + np) * f.H + h) * f.d;
+    return dout[ob + (size_t)e * f.H] * vr[e];
+  }
+  MLHOT_HD T combine(T a, T b) const { return a + b; }
+  MLHOT_HD void finish(int i, T a) const {
+    const int n = (i / f.Nc) % f.Nq, h = (i / (f.Nc * f.Nq)) % f.H, t = i / (f.Nc * f.Nq * f.H);
+    const size_t sd = (size_t)(t * f.H + h) * f.Nq + n;
+    dS[i] = (a - wv[sd]) / D[sd];
   }
 };
 // dv[(t,n',h)][e] = sum_n S[t,h,n,n'] dO[t,h,n,e] / D[t,h,n]
@@ -226,7 +233,7 @@ inline int favor_forward(const FavorDims& f, const float* q, const float* k, con
   MLHOT_TRY(run_reduce1(FavorGlobalMax{w.max_k, w.arg_k, w.gmax, w.gpos}, (int)rk, s, "favor.gmax"));
   MLHOT_TRY(run_foreach(FavorFeat{w.qf, w.diag_q, w.max_q, nullptr, f.m, ratio}, rq * f.m, s, "favor.feat_q"));
   MLHOT_TRY(run_foreach(FavorFeat{w.kf, w.diag_k, nullptr, w.gmax, f.m, ratio}, rk * f.m, s, "favor.feat_k"));
-  MLHOT_TRY(run_foreach(FavorS{f, w.qf, w.kf, ratio * eps, w.S}, (size_t)f.T * f.H * f.Nq * f.Nc, s, "favor.S"));
+  MLHOT_TRY(run_reduce_seg(FavorS{f, w.qf, w.kf, ratio * eps, w.S}, f.T * f.H * f.Nq * f.Nc, f.m, s, "favor.S"));
   MLHOT_TRY(run_foreach(FavorD{f.Nc, w.S, w.D}, (size_t)f.T * f.H * f.Nq, s, "favor.D"));
   MLHOT_TRY(run_foreach(FavorOut{f, w.S, w.D, v, out}, (size_t)f.T * f.Nq * f.d * f.H, s, "favor.out"));
   return MLHOT_OK;
@@ -238,8 +245,8 @@ inline int favor_backward(const FavorDims& f, const float* q, const float* k, co
   if (!w.ok) { set_error("favor_bwd: workspace too small"); return MLHOT_ERR_WORKSPACE; }
   const float c = powf((float)f.d, -0.25f), ratio = 1.0f / sqrtf((float)f.m), eps = 1e-4f;
   const size_t rq = f.rows_q(), rk = f.rows_k(), thn = (size_t)f.T * f.H * f.Nq;
-  MLHOT_TRY(run_foreach(FavorBwdW{f, out, dout, w.wv}, thn, s, "favor.bwd.w"));
-  MLHOT_TRY(run_foreach(FavorBwdDS{f, dout, v, w.wv, w.D, w.dS}, thn * f.Nc, s, "favor.bwd.dS"));
+  MLHOT_TRY(run_reduce_seg(FavorBwdW{f, out, dout, w.wv}, (int)thn, f.d, s, "favor.bwd.w"));
+  MLHOT_TRY(run_reduce_seg(FavorBwdDS{f, dout, v, w.wv, w.D, w.dS}, (int)(thn * f.Nc), f.d, s, "favor.bwd.dS"));
   MLHOT_TRY(run_foreach(FavorBwdDV{f, w.S, w.D, dout, dv}, rk * f.d, s, "favor.bwd.dv"));
   MLHOT_TRY(run_foreach(FavorBwdG{f, 1, w.dS, w.qf, w.kf, ratio * eps, w.Gq}, rq * f.m, s, "favor.bwd.Gq"));
   MLHOT_TRY(run_foreach(FavorBwdG{f, 0, w.dS, w.kf, w.qf, ratio * eps, w.Gk}, rk * f.m, s, "favor.bwd.Gk"));

@@ -65,6 +65,7 @@ int run_reduce_seg(const R& r, int nseg, int n, hipStream_t stream, const char* 
   }
   return MLHOT_OK;
 #else
+  if (nseg <= 0) return MLHOT_OK;
   ProfScope ps(what, stream);
   hipLaunchKernelGGL((reduce_seg_kernel<R>), dim3(nseg), dim3(256), 0, stream, r, n);
   return check_launch(what);

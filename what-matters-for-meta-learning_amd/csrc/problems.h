@@ -348,6 +348,20 @@ struct LinearFwd {
     if (bp) v += bp[n % wb.rows];
     y[(size_t)m * ldy + n] = act_apply(act, v);
   }
+#ifndef MLHOT_HOSTSIM
+  // hoisted index parts (igemm.h): the block lookup / division by `rows` happens once per tile column, not per element
+  struct alignas(16) KEnt { int k, p0, p1, p2; };
+  struct RCtx { int off; };
+  struct CCtx { const float* row; };            // &W[n][0] of the block that holds output column n
+  typedef float ARaw; typedef float BRaw;
+  MLHOT_DEV KEnt kent(int k) const { return KEnt{k, 0, 0, 0}; }
+  MLHOT_DEV RCtx rctx(int m) const { return RCtx{m * ldx}; }
+  MLHOT_DEV CCtx cctx(int n) const { return CCtx{wb.w[n / wb.rows] + (size_t)(n % wb.rows) * K}; }
+  MLHOT_DEV float A2(const RCtx& r, const KEnt& e, int, int, bool ok) const { return load_or_const(x, r.off + e.k, ok); }
+  MLHOT_DEV float B2(const KEnt& e, const CCtx& cc, int, int, bool ok) const { return load_or_const(cc.row, e.k, ok); }
+  MLHOT_DEV float Afin(float v) const { return v; }
+  MLHOT_DEV float Bfin(float v) const { return v; }
+#endif
 };
 
 // dX[M][Kin] (+)= (dY * act'(Y))[M][Nout] . W[Nout][Kin]
@@ -370,6 +384,24 @@ struct LinearDgrad {
     float* o = dx + (size_t)m * lddx + n;
     *o = accumulate ? *o + v : v;
   }
+#ifndef MLHOT_HOSTSIM
+  struct alignas(16) KEnt { const float* wrow; int k, pad; };     // &W[k][0] of the block that holds row k
+  struct RCtx { int offdy, offy; };
+  struct CCtx { int n; };
+  struct ARaw { float g, yv; };
+  typedef float BRaw;
+  MLHOT_DEV KEnt kent(int k) const { return KEnt{wb.w[k / wb.rows] + (size_t)(k % wb.rows) * N, k, 0}; }
+  MLHOT_DEV RCtx rctx(int m) const { return RCtx{m * lddy, m * ldy}; }
+  MLHOT_DEV CCtx cctx(int n) const { return CCtx{n}; }
+  MLHOT_DEV ARaw A2(const RCtx& r, const KEnt& e, int, int, bool ok) const {
+    ARaw v{load_or_const(dy, r.offdy + e.k, ok), 0.f};
+    if (act != ACT_NONE) v.yv = load_or_const(y, r.offy + e.k, ok);
+    return v;
+  }
+  MLHOT_DEV float B2(const KEnt& e, const CCtx& cc, int, int, bool ok) const { return load_or_const(e.wrow, cc.n, ok); }
+  MLHOT_DEV float Afin(const ARaw& v) const { return act != ACT_NONE ? v.g * act_grad_from_out(act, v.yv) : v.g; }
+  MLHOT_DEV float Bfin(float v) const { return v; }
+#endif
 };
 
 // dW[Nout][Kin] = (dY*act')^T X, db = column sums (extra all-ones column n = Kin).
@@ -392,6 +424,26 @@ struct LinearWgrad {
     if (n == N - 1) { if (gb.b[blk]) gb.b[blk][r] = v; }
     else gb.w[blk][(size_t)r * (N - 1) + n] = v;
   }
+#ifndef MLHOT_HOSTSIM
+  struct alignas(16) KEnt { int offdy, offy, offx, pad; };        // row k of dY, Y and X
+  struct RCtx { int m; };
+  struct CCtx { int n, bias; };
+  struct ARaw { float g, yv; };
+  typedef float BRaw;
+  MLHOT_DEV KEnt kent(int k) const { return KEnt{k * lddy, k * ldy, k * ldx, 0}; }
+  MLHOT_DEV RCtx rctx(int m) const { return RCtx{m}; }
+  MLHOT_DEV CCtx cctx(int n) const { return CCtx{n, n == N - 1}; }
+  MLHOT_DEV ARaw A2(const RCtx& r, const KEnt& e, int, int, bool ok) const {
+    ARaw v{load_or_const(dy, e.offdy + r.m, ok), 0.f};
+    if (act != ACT_NONE) v.yv = load_or_const(y, e.offy + r.m, ok);
+    return v;
+  }
+  MLHOT_DEV float B2(const KEnt& e, const CCtx& cc, int, int, bool ok) const {
+    return load_or_const(x, e.offx + cc.n, ok & (cc.bias == 0), (int)(ok & (cc.bias != 0)));      // the bias column reads 1.0
+  }
+  MLHOT_DEV float Afin(const ARaw& v) const { return act != ACT_NONE ? v.g * act_grad_from_out(act, v.yv) : v.g; }
+  MLHOT_DEV float Bfin(float v) const { return v; }
+#endif
 };
 
 // ------------------------------------------------------------------------------------------
