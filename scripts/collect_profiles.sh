@@ -12,8 +12,13 @@ python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench_c3.json 2> $OUT/bench
 python bench.py --steps 50 --warmup 10 --workload c2 --no-cpu-baseline > $OUT/${TAG}_bench_c2.json 2> $OUT/bench_c2.err
 MLHOT_BENCH_KERNELS=$OUT/${TAG}_kernels_c3.json python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-steps 0 > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --prof-steps 0 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --prof-steps 0 > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_write.log 2>&1
+# BASELINE config c5's per-GPU step (ANPMRShapeNet3D): informational line + kernel stats
+cd $REPO
+python scripts/bench_c5.py 2> $OUT/bench_c5.err | tail -1 > $OUT/${TAG}_bench_c5.json
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o stats -- python3 $REPO/scripts/bench_c5.py > $OUT/stats_c5.log 2>&1
 find $OUT -name "*.csv" | head -20
 ls -la $OUT

@@ -25,13 +25,16 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-for name in (f"{tag}_bench_c3.json", f"{tag}_bench_c2.json", f"{tag}_kernels_c3.json"):
+for name in (f"{tag}_bench_c3.json", f"{tag}_bench_c2.json", f"{tag}_kernels_c3.json", f"{tag}_bench_c5.json"):
     p = os.path.join(SRC, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(DST, name))
 stats = find("stats/**/*kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(DST, f"{tag}_kernel_stats.csv"))
+stats_c5 = find("stats_c5/**/*kernel_stats.csv")
+if stats_c5:
+    shutil.copy(stats_c5, os.path.join(DST, f"{tag}_kernel_stats_c5.csv"))
 
 
 def pmc(dirname, counter):
