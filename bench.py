@@ -100,7 +100,7 @@ def _time_graph(fn, iters):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=side):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
         fn()
     for _ in range(5):
         graph.replay()
@@ -121,7 +121,7 @@ def _capture(fn):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=side):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
         fn()
     return graph
 
@@ -329,7 +329,7 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             model.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
                 static_loss = loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy)
                 static_loss.backward()
 
