@@ -15,6 +15,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_write.log 2>&1
+# SQ / GRBM pass: MFMA-pipe busy cycles and the wave-cycle split (active / issue-stalled / parked) of the hot kernels
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o sq -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_sq.log 2>&1
 # BASELINE config c5's per-GPU step (ANPMRShapeNet3D): informational line + kernel stats
 cd $REPO
 python scripts/bench_c5.py 2> $OUT/bench_c5.err | tail -1 > $OUT/${TAG}_bench_c5.json

@@ -68,3 +68,29 @@ if len(out) > 1:
         with open(os.path.join(DST, name), "w") as f:
             json.dump(out, f, indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "_note"}, indent=1))
+
+
+# ---- SQ / GRBM counters of the hot kernels: MFMA-pipe utilisation and where the wave cycles go -----------------------------
+SQ = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+      "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE"]
+sq = {c: pmc("pmc_sq", c) for c in SQ}
+labels = sorted(set().union(*[set(v) for v in sq.values()]))
+if labels:
+    N_SIMD, N_XCD = 256 * 4, 8
+    res = {"_note": "rocprofv3 --pmc (one pass, 7 SQ + 1 GRBM counter) of `bench.py --steps 3 --warmup 1 --no-graph`, c3 workload; per-launch means. "
+                    "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): SQ_VALU_MFMA_BUSY_CYCLES is summed over "
+                    "all SIMDs in shader cycles (it equals 32 x the kernel's v_mfma_f32_16x16x4_f32 count: 238.9 M for enc.conv12 = 7.47 M MFMAs), "
+                    "GRBM_GUI_ACTIVE is summed over the 8 XCDs (1/8 of it x 1/2.4 GHz is the kernel's duration). wave-cycle split: WAIT_ANY (parked: s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + "
+                    "ACTIVE_INST_ANY ~ WAVE_CYCLES (quad-cycles, MI355X_MICROARCH.md)."}
+    for lb in labels:
+        v = {c: sq[c].get(lb) for c in SQ}
+        d = dict(v)
+        if v["GRBM_GUI_ACTIVE"]:
+            d["mfma_util"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / N_XCD * N_SIMD)
+        if v["SQ_WAVE_CYCLES"]:
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+                d["frac_" + c[3:].lower()] = v[c] / v["SQ_WAVE_CYCLES"]
+        res[lb] = d
+    with open(os.path.join(DST, f"{tag}_pmc_sq.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({k: {kk: (round(vv, 4) if isinstance(vv, float) and vv < 10 else vv) for kk, vv in v.items()} for k, v in res.items() if k != "_note"}, indent=1))
