@@ -1,0 +1,99 @@
+"""Host logic of the trainer / evaluator mirrors (trainer/model_trainer.py:33-143, evaluator/model_evaluator.py:95-179 of the
+reference) with a stand-in model on the CPU: iteration / validation cadence, files written, draw order of the data source,
+context-size sweep.  The numerics of the real models are the GPU parity tests' business."""
+import os
+import types
+
+import numpy as np
+import torch
+
+from mlhot import synth
+
+
+class LossFunc:
+    """Stand-in with trainer.losses.LossFunc's call contract (the real one is a HIP kernel and refuses CPU tensors)."""
+
+    def __init__(self, *a):
+        pass
+
+    def calc_loss(self, mu, var, gt, test=False):
+        d = ((gt[..., :2] - mu) ** 2).sum(dim=-1)
+        return d.sqrt().mean() if test else d.mean()
+
+
+class TinyModel(torch.nn.Module):
+    """Same call contract as the plugins: (ctx_x, ctx_y, qry_x, test=False) -> (mu [T, Nq, 2], None, 0)."""
+
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(4, 2)
+        self.calls = []
+
+    def forward(self, ctx_x, ctx_y, qry_x, test=False):
+        self.calls.append((ctx_x.shape[1], qry_x.shape[1], bool(test), self.training))
+        feat = torch.stack([qry_x.mean(dim=(2, 3, 4)), qry_x.amax(dim=(2, 3, 4)), ctx_x.mean().expand(qry_x.shape[:2]),
+                            ctx_y[..., 0].mean().expand(qry_x.shape[:2])], dim=-1)
+        return torch.tanh(self.lin(feat)), None, 0
+
+
+class CountingData(synth.SyntheticData):
+    def __init__(self):
+        super().__init__()
+        self.log = []
+
+    def get_batch(self, source, tasks_per_batch, shot):
+        self.log.append((source, shot))
+        xs, xq, ys, yq = super().get_batch(source, tasks_per_batch, shot)
+        return xs[..., ::16, ::16], xq[..., ::16, ::16], ys, yq        # small images: this is a host-logic test
+
+
+def _cfg(tmp_path, **kw):
+    base = dict(device=torch.device("cpu"), tasks_per_batch=2, task="shapenet_1d", iterations=4, val_freq=2, val_iters=2, bg_gen_freq=1000,
+                gen_bg=False, max_ctx_num=5, beta=0, contrastive=False, save_path=str(tmp_path / "run"), logger=None)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def test_trainer_cadence_and_files(tmp_path):
+    from trainer.model_trainer import ModelTrainer
+    model, data = TinyModel(), CountingData()
+    cfg = _cfg(tmp_path)
+    tr = ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=torch.optim.Adam(model.parameters(), lr=1e-2), config=cfg,
+                      data=data)
+    assert tr.ingest is None                                    # CPU device: the reference's host route
+    w0 = model.lin.weight.detach().clone()
+    tr.train()
+    # 4 training iterations, validation + test after iterations 2 and 4, val_iters batches each
+    assert [s for s, _ in data.log] == ["train", "train"] + ["validation"] * 2 + ["test"] * 2 + ["train", "train"] + ["validation"] * 2 + ["test"] * 2
+    train_calls = [c for c in model.calls if c[3]]
+    assert len(train_calls) == 4 and all(3 <= c[0] <= 5 and c[1] == 5 and not c[2] for c in train_calls)     # random context size, fixed targets
+    eval_calls = [c for c in model.calls if not c[3]]
+    assert len(eval_calls) == 8 and all(c[0] == 5 and c[2] for c in eval_calls)
+    for f in ("models/model_end_4.pt", "models/best_validation_model.pt", "models/best_test_model.pt", "best_validation_error.txt"):
+        assert os.path.exists(os.path.join(cfg.save_path, f)), f
+    assert not torch.equal(w0, model.lin.weight)
+
+
+def test_evaluator_sweep_and_files(tmp_path):
+    from evaluator.model_evaluator import ModelEvaluator
+    model, data = TinyModel(), CountingData()
+    cfg = _cfg(tmp_path, iterations=0, val_iters=3, max_ctx_num=4)
+    ev = ModelEvaluator(model=model, loss=LossFunc("mse", "shapenet_1d"), config=cfg, data=data)
+    val, test = ev.evaluate()
+    # context sizes 1..4, validation then test per size (the reference's interleaving), val_iters batches each, Nc = Nq = size
+    assert data.log == [(src, n) for n in range(1, 5) for src in ("validation", "test") for _ in range(3)]
+    assert all(c == (n, n, True, False) for c, n in zip(model.calls, [n for n in range(1, 5) for _ in range(6)]))
+    for name, res in (("val_losses.txt", val), ("test_losses.txt", test)):
+        table = np.loadtxt(os.path.join(cfg.save_path, name))
+        assert table.shape == (4, 3) and list(table[:, 0]) == [1, 2, 3, 4]
+        assert np.allclose(table[:, 1], res[0], atol=1e-4) and np.allclose(table[:, 2], res[1], atol=1e-4)
+    assert os.path.exists(os.path.join(cfg.save_path, "models", "model.pt"))
+    # the sweep re-seeds the split generators per call (model_evaluator.py:152-159): a second sweep sees the same batches
+    val2, _ = ModelEvaluator(model=model, loss=LossFunc("mse", "shapenet_1d"), config=cfg, data=data).evaluate()
+    assert val2 == val
+    # pascal_1d has no test split
+    cfg_p = _cfg(tmp_path, iterations=0, val_iters=1, max_ctx_num=2, task="shapenet_1d", save_path=str(tmp_path / "p"))
+    cfg_p.task = "pascal_1d"
+    data_p = CountingData()
+    ModelEvaluator(model=TinyModel(), loss=LossFunc("mse", "shapenet_1d"), config=cfg_p, data=data_p).evaluate()
+    assert [s for s, _ in data_p.log] == ["validation", "validation"] and not os.path.exists(tmp_path / "p" / "test_losses.txt")
