@@ -78,6 +78,42 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
   }
 }
 
+// Up to 4 independent slab sums in ONE launch (the backward's deferred weight-gradient folds: conv3, conv2, conv1, the tail's
+// per-task slabs): segment i owns blocks [first[i], first[i+1]) and is summed exactly as sum_parts_kernel would.
+struct SumParts { const float* slab; float* out; int nparts, len, stride; };
+struct SumPartsMulti { SumParts seg[4]; int first[5]; int n; };
+inline int sum_parts_blocks(int len) { return (len + 63) / 64; }
+__global__ __launch_bounds__(256) void sum_parts_multi_kernel(const SumPartsMulti mp) {
+  __shared__ float4 sm[16][16];
+  int si = 0;
+  while (si + 1 < mp.n && (int)blockIdx.x >= mp.first[si + 1]) ++si;
+  const SumParts sp = mp.seg[si];
+  const int cx = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const int e = (((int)blockIdx.x - mp.first[si]) * 16 + cx) * 4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+  if (e < sp.len) {
+    int z = zl;
+    for (; z + 48 < sp.nparts; z += 64) {
+      const float4 v0 = *reinterpret_cast<const float4*>(sp.slab + (size_t)z * sp.stride + e);
+      const float4 v1 = *reinterpret_cast<const float4*>(sp.slab + (size_t)(z + 16) * sp.stride + e);
+      const float4 v2 = *reinterpret_cast<const float4*>(sp.slab + (size_t)(z + 32) * sp.stride + e);
+      const float4 v3 = *reinterpret_cast<const float4*>(sp.slab + (size_t)(z + 48) * sp.stride + e);
+      add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3);
+    }
+    for (; z < sp.nparts; z += 16) add(s0, *reinterpret_cast<const float4*>(sp.slab + (size_t)z * sp.stride + e));
+  }
+  add(s0, s1); add(s2, s3); add(s0, s2);
+  sm[zl][cx] = s0;
+  __syncthreads();
+  if (zl == 0 && e < sp.len) {
+    float4 t = sm[0][cx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) add(t, sm[k][cx]);
+    *reinterpret_cast<float4*>(sp.out + e) = t;
+  }
+}
+
 // ==================================================================================================
 // conv1-fused variants ("c12"): the conv1 output `a1` (512 KiB / image, the largest tensor of the
 // model) is never written to HBM.  Each band's 32 x 9 x 64 slice of a1 is recomputed from the
@@ -563,11 +599,12 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
     float sacc = 0.f;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) sacc += red[((2 * g4 + ntc) * 16 + cl) * 16 + q];
-    if (q < 10) slab1[(size_t)blockIdx.x * 320 + c * 10 + q] = sacc;     // [block][ci][9 weights | bias]
+    if (q < 10) slab1[(size_t)blockIdx.x * 320 + (q < 9 ? c * 9 + q : 288 + c)] = sacc;     // [block][32 x 9 weights | 32 biases]
   }
 }
 
-// slab1 [nblocks][32][10] -> dw1 [32][9], db1 [32].  One workgroup per 20 outputs: 16 slab lanes x 20 columns...
+// slab1 [nblocks][288 + 32] -> dw1 [32][9], db1 [32] (used when the two gradient tensors are not adjacent; otherwise the
+// row is summed as one plain segment).  One workgroup per 20 outputs: 16 slab lanes x 20 columns...
 // grid = 16 workgroups of 320 threads: thread = (slab lane z = tid / 20, output e = 20 * blockIdx + tid % 20); the 16
 // lanes are folded through LDS in a fixed order (the single-block version walked all slabs serially: 18 us).
 __global__ __launch_bounds__(320) void conv1_grads_kernel(const float* __restrict__ slab1, int nblocks, float* __restrict__ dw1, float* __restrict__ db1) {
@@ -583,8 +620,7 @@ __global__ __launch_bounds__(320) void conv1_grads_kernel(const float* __restric
     float v = sm[0][col];
 #pragma unroll
     for (int k = 1; k < 16; ++k) v += sm[k][col];
-    const int c = e / 10, q = e % 10;
-    if (q < 9) dw1[c * 9 + q] = v; else db1[c] = v;
+    if (e < 288) dw1[e] = v; else db1[e - 288] = v;
   }
 }
 

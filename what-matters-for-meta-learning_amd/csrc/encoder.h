@@ -64,8 +64,8 @@ inline size_t enc_slab_floats(int n, int dim_w) {
   v = (size_t)conv3w_split(n) * 64 * 433;       if (v > m) m = v;
   v = (size_t)conv2w_split(n) * 48 * 289;       if (v > m) m = v;
   v = (size_t)conv1w_split(n) * 32 * 10;        if (v > m) m = v;
-  v = (size_t)2 * C2_GRID * 48 * 288 + (size_t)C2_GRID * 48 + (size_t)C2_GRID * 320; if (v > m) m = v;   // conv_tc partials
-  v = (size_t)C2_GRID * 64 * 433;                                                   if (v > m) m = v;   // conv3_tc partials
+  // weight-stationary backward: the conv3, conv2 and conv1 partial slabs are all alive until the single deferred reduce
+  v = (size_t)C2_GRID * (64 * 433 + 48 * 289 + 320) + (size_t)2 * C2_GRID * 48 * 288;     if (v > m) m = v;
   return m;
 }
 inline EncScratch enc_scratch_carve(int n, int dim_w, void* base, size_t cap) {
@@ -148,10 +148,40 @@ inline int enc_conv2_dgrad(int n, const DyPooled<48, 32, 32>& dy, const float* w
   return run_igemm<P, 128, 32, 16, 4, 1>(p, 1, nullptr, s, "enc.bwd.conv2.dgrad");
 }
 
+// A slab sum that has not been launched yet: out[e] = sum over parts p < nparts of slab[p * stride + e], e < len.
+struct PendingSum { const float* slab; float* out; int nparts, len, stride; };
+
+// `extra`: a slab sum the caller has pending (the fused tail's per-task gradient slabs); the weight-stationary path folds it
+// into its own final reduce launch, every other path sums it first.
 inline int enc_backward(const float* img0, int n0, const float* img1, int n1, const mlhot_enc_params& p, int dim_w,
                         Rows2 dfeat, const void* saved, const mlhot_enc_grads& g,
-                        void* scratch, size_t scratch_bytes, hipStream_t s) {
+                        void* scratch, size_t scratch_bytes, hipStream_t s, const PendingSum* extra = nullptr) {
   const int n = n0 + n1;
+#ifndef MLHOT_HOSTSIM
+  // deferred slab sums of the weight-stationary path: ONE launch at the very end (4 kernels fewer on the step's critical path)
+  c2::SumPartsMulti mp{};
+  auto pend = [&](const float* slab, float* out, int nparts, int len, int stride) {
+    mp.seg[mp.n] = c2::SumParts{slab, out, nparts, len, stride};
+    mp.first[mp.n + 1] = mp.first[mp.n] + c2::sum_parts_blocks(len);
+    ++mp.n;
+  };
+  auto flush = [&]() -> int {
+    if (mp.n == 0) return MLHOT_OK;
+    {
+      ProfScope ps("slab_reduce", s);
+      hipLaunchKernelGGL(c2::sum_parts_multi_kernel, dim3(mp.first[mp.n]), dim3(256), 0, s, mp);
+    }
+    mp.n = 0;
+    return check_launch("slab_reduce");
+  };
+  const bool defer = g_opt.conv2_tc && n > 0;
+  if (extra != nullptr && extra->slab != nullptr) {
+    pend(extra->slab, extra->out, extra->nparts, extra->len, extra->stride);
+    if (!defer) MLHOT_TRY(flush());
+  }
+#else
+  (void)extra;
+#endif
   if (n <= 0) return MLHOT_OK;
   EncSaved sv = enc_saved_carve(n, (void*)saved, (size_t)-1 / 2);
   EncScratch sc = enc_scratch_carve(n, dim_w, scratch, scratch_bytes);
@@ -182,21 +212,19 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     // one slab row per workgroup = [dW (64*432) | db (64)]: when the caller's gradient tensors are adjacent in that order
     // (mlhot_np_grads_flat_layout) the weights and the bias reduce in ONE launch
     constexpr int L3 = 64 * 432, R3 = L3 + 64;
-    float* slab_w = sc.slab;
+    float* slab_w = sc.slab;                       // conv3's slab region: alive until the deferred reduce
     float* slab_b = sc.slab + L3;
     {
       ProfScope ps("enc.bwd.conv3.wgrad", s);
       hipLaunchKernelGGL(c3::conv3_wgrad_kernel, dim3(grid), dim3(c3::W_NT), 0, s, sv.p2, sc.dy3, slab_w, slab_b, n);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv3.wgrad"));
-    {
+    if (g.b3 == g.w3 + L3 && (reinterpret_cast<uintptr_t>(g.w3) & 15) == 0) {
+      pend(slab_w, g.w3, grid, R3, R3);
+    } else {
       ProfScope ps("slab_reduce", s);
-      if (g.b3 == g.w3 + L3 && (reinterpret_cast<uintptr_t>(g.w3) & 15) == 0) {
-        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3((R3 + 63) / 64), dim3(256), 0, s, slab_w, grid, R3, g.w3, R3);
-      } else {
-        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(L3 / 64), dim3(256), 0, s, slab_w, grid, L3, g.w3, R3);
-        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 64, g.b3, R3);
-      }
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(L3 / 64), dim3(256), 0, s, slab_w, grid, L3, g.w3, R3);
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 64, g.b3, R3);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv3.wgrad.reduce"));
     {
@@ -222,23 +250,21 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
   if (g_opt.conv2_tc) {
     const int grid = n * 8 < C2_GRID ? n * 8 : C2_GRID;
     constexpr int L2 = 48 * 288, R2 = L2 + 48;          // slab row = [dW2 | db2], see conv3 above
-    float* slab_w = sc.slab;
-    float* slab_b = sc.slab + L2;
-    float* slab_1 = sc.slab + (size_t)C2_GRID * R2;
+    float* slab_w = sc.slab + (size_t)C2_GRID * (64 * 433);      // behind conv3's region
+    float* slab_b = slab_w + L2;
+    float* slab_1 = slab_w + (size_t)C2_GRID * R2;
     const c2::ImgSrc xs{img0, n0, img1};
     {
       ProfScope ps("enc.bwd.conv12.wgrad", s);
       hipLaunchKernelGGL(c2::conv12_wgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, xs, p.w1, p.b1, sc.dp2, sv.p2, sv.am2, slab_w, slab_b, n, g_opt.dbg);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv12.wgrad"));
-    {
+    if (g.b2 == g.w2 + L2 && (reinterpret_cast<uintptr_t>(g.w2) & 15) == 0) {
+      pend(slab_w, g.w2, grid, R2, R2);
+    } else {
       ProfScope ps("slab_reduce", s);
-      if (g.b2 == g.w2 + L2 && (reinterpret_cast<uintptr_t>(g.w2) & 15) == 0) {
-        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3((R2 + 63) / 64), dim3(256), 0, s, slab_w, grid, R2, g.w2, R2);
-      } else {
-        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(L2 / 64), dim3(256), 0, s, slab_w, grid, L2, g.w2, R2);
-        hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 48, g.b2, R2);
-      }
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(L2 / 64), dim3(256), 0, s, slab_w, grid, L2, g.w2, R2);
+      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 48, g.b2, R2);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv2.wgrad.reduce"));
     {
@@ -246,11 +272,14 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
       hipLaunchKernelGGL(c2::conv12_dgrad_kernel, dim3(grid), dim3(c2::NT2), 0, s, xs, sv.m1, sc.dp2, sv.p2, sv.am2, p.w2, slab_1, n);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv12.dgrad"));
-    {
+    if (g.b1 == g.w1 + 288 && (reinterpret_cast<uintptr_t>(g.w1) & 15) == 0) {
+      pend(slab_1, g.w1, grid, 320, 320);           // conv1's gradients came out of the dgrad kernel
+    } else {
       ProfScope ps("slab_reduce", s);
       hipLaunchKernelGGL(c2::conv1_grads_kernel, dim3(16), dim3(320), 0, s, slab_1, grid, g.w1, g.b1);
     }
-    return check_launch("enc.bwd.conv1.grads");     // conv1's gradients came out of the dgrad kernel
+    MLHOT_TRY(check_launch("enc.bwd.conv1.grads"));
+    return flush();
   } else
 #endif
   {

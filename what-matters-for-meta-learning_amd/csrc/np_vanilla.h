@@ -212,9 +212,15 @@ inline int cnp_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, c
 // Per-task slabs -> parameter gradients.  When the caller laid the gradient tensors out as ONE flat buffer in slab
 // order (mlhot_np_grads_flat_layout) the reduce is a single contiguous float4 sum; otherwise every element looks up
 // its destination segment.
-inline int tail_slab_reduce(tf::SlabReduce& r, hipStream_t s) {
+// `later`: where a contiguous sum may be parked instead of launched (the encoder backward that follows folds it into its own
+// final reduce launch).
+inline int tail_slab_reduce(tf::SlabReduce& r, hipStream_t s, PendingSum* later = nullptr) {
   bool flat = r.nseg > 0 && r.off[0] == 0 && (reinterpret_cast<uintptr_t>(r.dst[0]) & 15) == 0 && (r.total & 3) == 0;
   for (int i = 1; flat && i < r.nseg; ++i) flat = r.dst[i] == r.dst[0] + r.off[i];
+  if (flat && later != nullptr) {
+    *later = PendingSum{r.slab, r.dst[0], r.T, r.total, r.total};
+    return MLHOT_OK;
+  }
   {
     ProfScope ps("tail.bwd.reduce", s);
     if (flat) hipLaunchKernelGGL(c2::sum_parts_kernel, dim3((r.total + 63) / 64), dim3(256), 0, s, r.slab, r.T, r.total, r.dst[0], r.total);
@@ -224,7 +230,7 @@ inline int tail_slab_reduce(tf::SlabReduce& r, hipStream_t s) {
 }
 
 inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu, const float* dmu,
-                              const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s) {
+                              const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s, PendingSum* later) {
   const tf::CnpDims cd = cnp_dims(d);
   const tf::CnpSlab sl = tf::cnp_slab_layout(cd);
   if (!sc.tail_slab) { set_error("cnp_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
@@ -245,11 +251,12 @@ inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   seg(g.dec_w[2], sl.dec_w[2], d.y_dim * cd.dec_h); seg(g.dec_b[2], sl.dec_b[2], d.y_dim);
   r.nseg = ns; r.T = d.T; r.total = sl.total; r.slab = sc.tail_slab;
   (void)maxlen;
-  return tail_slab_reduce(r, s);
+  return tail_slab_reduce(r, s, later);
 }
 
 inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu,
-                               const float* dmu, const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s) {
+                               const float* dmu, const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s,
+                               PendingSum* later) {
   const tf::TailDims td = tail_dims(d);
   const tf::TailParams tp = tail_params(p);
   const tf::TailSlab sl = tf::tail_slab_layout(td);
@@ -287,7 +294,7 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   seg(g.wo_w, sl.wo_w, dw * MLHOT_HEADS * dw); seg(g.wo_b, sl.wo_b, dw);
   r.nseg = ns; r.T = d.T; r.total = sl.total; r.slab = sc.tail_slab;
   (void)maxlen;
-  return tail_slab_reduce(r, s);
+  return tail_slab_reduce(r, s, later);
 }
 #endif
 
@@ -415,9 +422,11 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
 
 #ifndef MLHOT_HOSTSIM
   if (tail_fused_applies(d) || cnp_fused_applies(d)) {
-    if (tail_fused_applies(d)) MLHOT_TRY(tail_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s));
-    else MLHOT_TRY(cnp_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s));
-    return enc_backward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{sc.d_cat_in, ldc, Rc, sc.d_dec_in, ldd}, b.enc, g.enc, sc.enc, sc.enc_bytes, s);
+    PendingSum tail_sum{};       // the tail's per-task slabs: summed by the encoder backward's final reduce launch when contiguous
+    if (tail_fused_applies(d)) MLHOT_TRY(tail_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum));
+    else MLHOT_TRY(cnp_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum));
+    return enc_backward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{sc.d_cat_in, ldc, Rc, sc.d_dec_in, ldd}, b.enc, g.enc, sc.enc, sc.enc_bytes, s,
+                        &tail_sum);
   }
 #endif
   // decoder0
