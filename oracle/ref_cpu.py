@@ -507,3 +507,116 @@ def ingest_images(u8, div=255.0):
     `permute(0, 1, 4, 2, 3).contiguous()` (utils/utils.py:26-30)."""
     x = np.asarray(u8).astype(np.float32) / div
     return torch.from_numpy(x).type(torch.FloatTensor).permute(0, 1, 4, 2, 3).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# Functional contrastive learning (FCL*): NT-Xent on task embeddings   (trainer/losses.py:82-99, FCLCNPShapeNet1D.py:101-159,
+# FCLCNPDistractor.py:82-147, FCLANP.py:108-137).  The loss itself lives in the un-vendored dependency
+# pytorch_metric_learning (requirements.txt:12, no version pinned; absent from this image): `nt_xent` restates the published
+# NTXentLoss algorithm (cosine similarity, all same-label pairs positive, all different-label pairs negatives of their anchor,
+# mean over positive pairs) literally, pair by pair.  PARITY OF THIS TERM IS UNPINNED: the fixture generator has to stub the
+# missing package with this same restatement; everything around it (embeddings, mu, regression loss) is pinned by the reference.
+# --------------------------------------------------------------------------------------
+
+
+def nt_xent(z, labels, t=0.07):
+    zn = z / z.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    sim = zn @ zn.t()
+    n = z.shape[0]
+    losses = []
+    tiny = torch.finfo(z.dtype).tiny
+    for a in range(n):
+        negs = [sim[a, k] / t for k in range(n) if int(labels[k]) != int(labels[a])]
+        if not negs:
+            continue
+        negs = torch.stack(negs)
+        for q in range(n):
+            if q == a or int(labels[q]) != int(labels[a]):
+                continue
+            pos = sim[a, q] / t
+            m = torch.max(pos, negs.max()).detach()
+            num = torch.exp(pos - m)
+            den = torch.exp(negs - m).sum() + num
+            losses.append(-torch.log(num / den + tiny))
+    return torch.stack(losses).mean() if losses else z.sum() * 0.0
+
+
+def contrastive_loss(z_1, z_2, t=0.07):
+    labels = list(range(z_1.shape[0])) + list(range(z_2.shape[0]))
+    return nt_xent(torch.cat((z_1, z_2), dim=0), labels, t)
+
+
+def contrastive_loss_anp(z, t=0.07):
+    labels = [i for i in range(z.shape[0]) for _ in range(z.shape[1])]
+    return nt_xent(z.reshape(-1, z.shape[-1]), labels, t)
+
+
+def fcl_cnp_vanilla_forward(p, ctx_x, ctx_y, qry_x, qry_y, agg_mode, test=False):
+    """FCLCNPShapeNet1D.forward: the CNPShapeNet1D forward plus the target-set embedding (always max-aggregated, line 147)."""
+    taps = {}
+    mu = vanilla_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, tanh=True, taps=taps)
+    if test:
+        return mu, 0.0
+    n_hidden = sum(1 for k_ in p if k_.startswith("encoder_r.layers.") and k_.endswith(".weight")) - 1
+    z_0 = F.linear(taps["r"], p["r_to_z.weight"], p["r_to_z.bias"])
+    ly = F.linear(qry_y, p["transform_y.weight"], p["transform_y.bias"])
+    rq = agg_max(encoder_fc(torch.cat([taps["x_qry"], ly], dim=2), p, n_hidden=n_hidden))
+    z_q = F.linear(rq, p["r_to_z.weight"], p["r_to_z.bias"])
+    return mu, contrastive_loss(z_0, z_q)
+
+
+def fcl_resnet_forward(p, ctx_x, ctx_y, qry_x, qry_y, agg_mode, img_agg, temperature=0.07, test=False, routes=None, pres=None):
+    """FCLANP.forward / FCLCNPDistractor.forward: the ResNet-encoder ANP / CNP forward plus the contrastive term.
+    Encoder passes in call order: context, target (ANP: attention queries; CNP: the target-set embedding, skipped when `test`),
+    decoder - `routes` / `pres` as in resnet_np_forward."""
+    T, Nq = qry_x.shape[:2]
+    Nc = ctx_x.shape[1]
+    flat = lambda t_: t_.reshape(-1, *t_.shape[2:])
+    passes = iter(routes) if routes is not None else None
+
+    def features(img, prefix):
+        pre = None
+        if pres is not None:
+            pre = []
+            pres.append(pre)
+        return resnet_features(img, p, prefix, img_agg, route=next(passes) if passes is not None else None, pre=pre)
+
+    def task_features(x_img, labels):
+        if "transform_y.weight" in p:
+            labels = F.linear(labels, p["transform_y.weight"], p["transform_y.bias"])
+        h_ = torch.cat([x_img, labels], dim=2)
+        for i in (0, 2, 4):
+            h_ = F.relu(F.linear(h_, p[f"task_encoder.{i}.weight"], p[f"task_encoder.{i}.bias"]))
+        return h_
+
+    def embed(h_, quirk):
+        if agg_mode == "mean":
+            r = agg_mean(h_)
+        elif agg_mode == "max":
+            r = agg_max(h_)
+        else:
+            mu_l = F.linear(h_, p["latent_mu.weight"], p["latent_mu.bias"])
+            # the target-set path applies latent_var to latent_mu's output (FCLCNPDistractor.py:133-134)
+            var = 1e-5 + F.softplus(F.linear(mu_l if quirk else h_, p["latent_var.weight"], p["latent_var.bias"]))
+            r, _ = agg_baco(mu_l, var)
+        return F.linear(r, p["mu.weight"], p["mu.bias"])
+
+    x_ctx = features(flat(ctx_x), "img_encoder.").reshape(T, Nc, -1)
+    h = task_features(x_ctx, ctx_y)
+    contra = 0.0
+    if agg_mode == "attention":
+        x_tgt = features(flat(qry_x), "img_encoder.").reshape(T, Nq, -1)
+        sample = F.linear(multihead_attention(x_ctx, h, x_tgt, p), p["mu.weight"], p["mu.bias"])
+        if not test:
+            contra = contrastive_loss_anp(sample, temperature)
+    else:
+        z_0 = embed(h, False)
+        sample = z_0[:, None, :].expand(T, Nq, -1)
+        if not test:
+            x_qry = features(flat(qry_x), "img_encoder.").reshape(T, Nq, -1)
+            contra = contrastive_loss(z_0, embed(task_features(x_qry, qry_y), True))
+    x_dec = features(flat(qry_x), "decoder.").reshape(T, Nq, -1)
+    hd = torch.cat([x_dec, sample], dim=-1)
+    hd = F.relu(F.linear(hd, p["decoder.fc_mu.0.weight"], p["decoder.fc_mu.0.bias"]))
+    hd = F.relu(F.linear(hd, p["decoder.fc_mu.2.weight"], p["decoder.fc_mu.2.bias"]))
+    return F.linear(hd, p["decoder.fc_mu.4.weight"], p["decoder.fc_mu.4.bias"]), contra

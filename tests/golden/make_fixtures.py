@@ -66,8 +66,17 @@ def install_stubs():
     for n in ["Sometimes", "Sequential", "CropAndPad", "GammaContrast", "AddToBrightness",
               "AverageBlur", "Affine", "OneOf", "Dropout", "CoarseDropout"]:
         setattr(ia.augmenters, n, _Any)
+    class NTXentLoss:                                    # stand-in for the absent package: the restated algorithm (see FCL_CASES)
+        def __init__(self, temperature=0.07):
+            self.temperature = temperature
+
+        def __call__(self, embeddings, labels):
+            sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+            from oracle.ref_cpu import nt_xent
+            return nt_xent(embeddings, labels.tolist(), self.temperature)
+
     pml = mod("pytorch_metric_learning")
-    pml.losses = mod("pytorch_metric_learning.losses", NTXentLoss=_Any)
+    pml.losses = mod("pytorch_metric_learning.losses", NTXentLoss=NTXentLoss)
 
 
 def sha(t):
@@ -132,6 +141,24 @@ RESNET_CASES = {
 }
 
 
+# Functional-contrastive variants: forward(ctx_x, ctx_y, qry_x, qry_y) -> (mu, var, kl, contrastive term).
+# pytorch_metric_learning is not in this image: its NTXentLoss is stubbed with oracle.ref_cpu.nt_xent (the published algorithm
+# restated), so the contrastive VALUE in these fixtures is restatement-vs-restatement ("parity unpinned" for that term);
+# mu, the regression loss and the rest of the graph are the reference's own arithmetic.
+FCL_CASES = {
+    "f_fclcnp_shapenet1d_max": ("FCLCNPShapeNet1D", dict(BASE, task="shapenet_1d", tasks_per_batch=3, input_dim=3, output_dim=2,
+                                                         agg_mode="max", dim_r=100), 4, 5, 1),
+    "f_fclcnp_shapenet1d_mean": ("FCLCNPShapeNet1D", dict(BASE, task="shapenet_1d", tasks_per_batch=2, input_dim=3, output_dim=2,
+                                                          agg_mode="mean", dim_r=100), 3, 3, 1),
+    "f_fclanp_shapenet3d": ("FCLANP", dict(task="shapenet_3d", img_size=[64, 64, 4], tasks_per_batch=2, input_dim=4, output_dim=4,
+                                           agg_mode="attention", img_agg="reshape", seed=2578, temperature=0.07), 3, 4, 3),
+    "f_fclcnp_distractor_max": ("FCLCNPDistractor", dict(task="distractor", img_size=[128, 128, 1], tasks_per_batch=2, input_dim=2,
+                                                         output_dim=2, agg_mode="max", img_agg="max", dim_w=16, seed=2578), 2, 3, 1),
+    "f_fclcnp_distractor_baco": ("FCLCNPDistractor", dict(task="distractor", img_size=[128, 128, 1], tasks_per_batch=2, input_dim=2,
+                                                          output_dim=2, agg_mode="baco", img_agg="max", dim_w=16, seed=2578), 3, 2, 1),
+}
+
+
 # Meta-regularised twins of the vanilla models (SURVEY.md §8a E1 "MR twin" / B1): Bayes-by-backprop vanilla encoder.
 # Same runner as the ResNet family: torch.manual_seed(99) right before the forward, backward on loss + 1e-7 * kl.
 MR1D = dict(img_size=[128, 128, 1], img_agg="", dim_w=64, n_hidden_units_r=[100, 100], dim_r=64, dim_z=64, seed=2578, temperature=0.07)
@@ -187,6 +214,47 @@ def run_resnet_case(name, method, cfgd, Nc, Nq, C, LossFunc):
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"{name}: loss={loss.item():.8f} sum(mu)={mu.sum().item():.8f} params={meta['n_params']}")
+
+
+def run_fcl_case(name, method, cfgd, Nc, Nq, C, LossFunc):
+    cfg = types.SimpleNamespace(device=torch.device("cpu"), **cfgd)
+    model = getattr(importlib.import_module(f"networks.{method}"), method)(cfg)
+    T = cfg.tasks_per_batch
+    H, W, _ = cfg.img_size
+    cx, qx, cy, qy = make_inputs(T, Nc, Nq, C, H, W, cfg.input_dim, seed=1234)
+    if cfg.task == "shapenet_3d":
+        qy = torch.nn.functional.normalize(qy - 0.5, dim=-1)
+        qy = torch.where(qy[..., 1:2] < 0, -qy, qy)
+    model.train()
+    mu, var, kl, contra = model(cx, cy, qx, qy)
+    assert var is None and kl == 0
+    loss = LossFunc("mse", cfg.task).calc_loss(mu, var, qy)
+    (loss + contra).backward()                           # contrastive_rate 1 (model_trainer.py:80-81 scales it by the config's rate)
+    model.eval()
+    with torch.no_grad():
+        mu_t, _, _, contra_t = model(cx, cy, qx, qy, test=True)
+    assert contra_t == 0 and torch.equal(mu_t, mu.detach())
+    out = {"mu": np32(mu), "loss": np.float64(loss.item()), "contra": np.float64(contra.item()), "qy": np32(qy)}
+    state_sha, grad_norm = {k: sha(v) for k, v in model.state_dict().items()}, {}
+    if hasattr(model, "attn"):
+        out["projection_matrix"] = np32(model.attn.projection_matrix)
+    for k, prm in model.named_parameters():
+        if prm.grad is None:
+            grad_norm[k] = None
+            continue
+        gnp = np32(prm.grad)
+        grad_norm[k] = float(np.linalg.norm(gnp.astype(np.float64)))
+        if gnp.nbytes <= 16 * 1024:
+            out["grad/" + k] = gnp
+        else:
+            flat = gnp.reshape(-1)
+            out["gradhead/" + k] = flat[:1024].copy()
+            out["gradstride/" + k] = flat[1::61][:4096].copy()
+    meta = dict(name=name, method=method, cfg=cfgd, Nc=Nc, Nq=Nq, C=C, input_seed=1234, state_sha=state_sha, grad_norm=grad_norm,
+                input_sha=dict(cx=sha(cx), qx=sha(qx), cy=sha(cy)), n_params=sum(p.numel() for p in model.parameters()))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.8f} contra={contra.item():.8f} sum(mu)={mu.sum().item():.8f} params={meta['n_params']}")
 
 
 def make_inputs(T, Nc, Nq, C, H, W, L, seed=1234):
@@ -390,6 +458,10 @@ def main():
         if only and name not in only:
             continue
         run_resnet_case(name, method, cfgd, Nc, Nq, C, LossFunc)
+    for name, (method, cfgd, Nc, Nq, C) in FCL_CASES.items():
+        if only and name not in only:
+            continue
+        run_fcl_case(name, method, cfgd, Nc, Nq, C, LossFunc)
     if not only or "favor" in only:
         run_favor_cases()
     if not only or "losses" in only:

@@ -15,7 +15,7 @@ from tests import util as U
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", U.model_case_names() + U.resnet_case_names())
+@pytest.mark.parametrize("name", U.model_case_names() + U.resnet_case_names() + U.mr_case_names() + U.fcl_case_names())
 def test_plugin_lookup_and_state_dict(name):
     """train.py:41-45: importlib.import_module(f"networks.{method}") + getattr(module, method)(config)."""
     fx, meta = U.load_case(name)
@@ -60,8 +60,9 @@ def test_bad_agg_mode_raises_typeerror():
 
 
 IN_SCOPE = {"ANP", "ANPDistractor", "ANPMR", "ANPMRShapeNet1D", "ANPMRShapeNet3D", "ANPShapeNet1D", "ANPVanillaPascal1D",
-            "CNPDistractor", "CNPMR", "CNPMRShapeNet1D", "CNPShapeNet1D", "CNPVanillaPascal1D", "CondNeuralProcess"}
-OUT_OF_SCOPE = {"FCLANP", "FCLCNPDistractor", "FCLCNPShapeNet1D", "MAMLMR", "MAMLMRShapeNet1D", "MAMLShapeNet1D", "MMAMLShapeNet1D", "VanillaMAML",
+            "CNPDistractor", "CNPMR", "CNPMRShapeNet1D", "CNPShapeNet1D", "CNPVanillaPascal1D", "CondNeuralProcess",
+            "FCLANP", "FCLCNPDistractor", "FCLCNPShapeNet1D"}
+OUT_OF_SCOPE = {"MAMLMR", "MAMLMRShapeNet1D", "MAMLShapeNet1D", "MMAMLShapeNet1D", "VanillaMAML",
                 "SingleTaskDistractor", "SingleTaskShapeNet1D", "SingleTaskShapeNet3D"}
 
 

@@ -292,6 +292,61 @@ def test_anpmr_shapenet3d_vs_reference(gpulib):
         U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
 
 
+@pytest.mark.parametrize("name", U.fcl_case_names())
+def test_fcl_models_vs_reference(gpulib, name):
+    """Functional-contrastive variants (FCLCNPShapeNet1D, FCLCNPDistractor, FCLANP) through the plugin boundary: the 4-tuple
+    forward with the target labels; mu / regression loss / NT-Xent term against the fixtures produced by the reference (NT-Xent
+    restated for the absent pytorch_metric_learning, see tests/golden/make_fixtures.py).  Gradients of (loss + term): the
+    ResNet-family cases are checked against the oracle under the kernels' ReLU routing (see test_resnet_models_vs_reference) and,
+    when no decision flipped, against the reference's gradients; the vanilla-encoder cases directly against the reference's."""
+    from trainer.losses import LossFunc
+    fx, meta = U.load_case(name)
+    c = meta["cfg"]
+    model = U.build_model(meta, DEV, fx=fx).to(DEV)
+    cx, qx, cy, qy = U.resnet_case_inputs(meta, fx)
+    resnet = meta["method"] != "FCLCNPShapeNet1D"
+    if resnet:
+        model.img_encoder.tap_log, model.decoder.tap_log = [], []
+    mu, var, kl, contra = model(cx.to(DEV), cy.to(DEV), qx.to(DEV), qy.to(DEV))
+    assert var is None and kl == 0
+    loss = LossFunc("mse", c["task"]).calc_loss(mu, var, qy.to(DEV))
+    (loss + contra).backward()
+    assert U.rel_err(mu, fx["mu"]) <= U.RTOL
+    assert abs(loss.item() - float(fx["loss"])) <= U.RTOL * max(1.0, abs(float(fx["loss"])))
+    assert abs(contra.item() - float(fx["contra"])) <= U.RTOL * max(1.0, abs(float(fx["contra"])))
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    if not resnet:
+        U.check_grads_against_fixture(grads, fx, meta, tol=FULL_SIZE_GRAD_TOL, head=1024, stride_cap=4096)
+    else:
+        routes = [[(t.detach().cpu() > 0).float() for t in taps] for taps in model.img_encoder.tap_log + model.decoder.tap_log]
+        p = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+        pres = []
+        mu_r, contra_r = O.fcl_resnet_forward(p, cx, cy, qx, qy, c["agg_mode"], c["img_agg"], c.get("temperature", 0.07), routes=routes, pres=pres)
+        (O.calc_loss(c["task"], mu_r, qy) + contra_r).backward()
+        flips = 0
+        for masks, pre in zip(routes, pres):
+            for m, v in zip(masks, pre):
+                bad = (m > 0) != (v > 0)
+                flips += int(bad.sum())
+                assert not bool((bad & (v.abs() > 1e-5 * v.abs().max())).any()), "routing differs away from a tie"
+        gmax = max(p[k].grad.abs().max().item() for k, _ in model.named_parameters() if p[k].grad is not None)
+        for k, prm in model.named_parameters():
+            if p[k].grad is None:
+                assert grads[k] is None, k
+                continue
+            # 3e-4: the NT-Xent term divides cosine similarities by the temperature (0.07), which scales the fp32 rounding
+            # differences of the embeddings ~14x on their way back (measured worst case 1.4e-4, on the attention queries)
+            assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= 3e-4, k
+        if flips == 0:
+            U.check_grads_against_fixture(grads, fx, meta, tol=3e-4, head=1024, stride_cap=4096)
+    with torch.no_grad():
+        model.eval()
+        if resnet:
+            model.img_encoder.tap_log, model.decoder.tap_log = None, None
+        mu_t, _, _, contra_t = model(cx.to(DEV), cy.to(DEV), qx.to(DEV), qy.to(DEV), test=True)
+    assert contra_t == 0 and U.rel_err(mu_t, fx["mu"]) <= U.RTOL
+
+
 def test_staged_eps_step_equals_lazy_step_and_captures(gpulib):
     """networks/bbb/eps.py on the device: a Bayes-by-backprop step fed from the pre-drawn eps buffer is bit-identical to the
     reference's lazy per-layer draws, and the staged step replays from a hipGraph with the same result."""
@@ -614,6 +669,28 @@ def test_evaluator_context_sweep_vs_oracle(gpulib, tmp_path, method, agg):
             got_mean, got_std = results[True][si][0][ctx_num - 1], results[True][si][1][ctx_num - 1]
             assert abs(got_mean - vals.mean().item()) <= 1e-3 * max(1.0, abs(vals.mean().item())), (source, ctx_num)
             assert abs(got_std - vals.std().item()) <= 2e-3 * max(1.0, abs(vals.std().item())), (source, ctx_num)
+
+
+def test_trainer_contrastive_model(gpulib, tmp_path, monkeypatch):
+    """config.contrastive: the trainer hands the target labels to an FCL* model and adds contrastive_rate x the NT-Xent term
+    (trainer/model_trainer.py:72-81 of the reference); validation calls the 4-tuple forward with test=True."""
+    import types
+    from mlhot.synth import SyntheticData
+    from networks.FCLCNPShapeNet1D import FCLCNPShapeNet1D
+    from trainer.losses import LossFunc
+    from trainer.model_trainer import ModelTrainer
+    monkeypatch.chdir(tmp_path)
+    cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[128, 128, 1], tasks_per_batch=3, input_dim=3, output_dim=2,
+                                agg_mode="max", img_agg="", dim_w=64, n_hidden_units_r=[100, 100], dim_r=100, dim_z=64, task="shapenet_1d",
+                                iterations=3, val_freq=3, val_iters=1, bg_gen_freq=1000, gen_bg=False, max_ctx_num=5, beta=0,
+                                contrastive=True, contrastive_rate=0.5, save_path=str(tmp_path / "run"), logger=None)
+    model = FCLCNPShapeNet1D(cfg).to(cfg.device)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=torch.optim.Adam(model.parameters(), lr=1e-3), config=cfg,
+                 data=SyntheticData()).train()
+    assert os.path.exists(tmp_path / "run" / "models" / "model_end_3.pt")
+    assert sum(float((v - before[k]).abs().sum()) for k, v in model.state_dict().items()) > 0
+    assert all(torch.isfinite(v).all() for v in model.state_dict().values())
 
 
 def test_cpu_tensors_are_refused(gpulib):

@@ -97,3 +97,22 @@ def test_evaluator_sweep_and_files(tmp_path):
     data_p = CountingData()
     ModelEvaluator(model=TinyModel(), loss=LossFunc("mse", "shapenet_1d"), config=cfg_p, data=data_p).evaluate()
     assert [s for s, _ in data_p.log] == ["validation", "validation"] and not os.path.exists(tmp_path / "p" / "test_losses.txt")
+
+
+def test_contrastive_models_get_the_target_labels(tmp_path):
+    """config.contrastive (model_trainer.py:72-81, 118-119 of the reference): 4-argument call, 4-tuple return, the contrastive term
+    scaled by contrastive_rate joins the loss; validation passes test=True."""
+    from trainer.model_trainer import ModelTrainer
+    seen = []
+
+    class FclModel(TinyModel):
+        def forward(self, ctx_x, ctx_y, qry_x, qry_y, test=False):
+            seen.append((tuple(qry_y.shape), bool(test)))
+            mu, var, kl = super().forward(ctx_x, ctx_y, qry_x, test=test)
+            return mu, var, kl, (0 if test else (mu ** 2).mean())
+
+    model = FclModel()
+    cfg = _cfg(tmp_path, iterations=2, val_freq=2, val_iters=1, contrastive=True, contrastive_rate=0.25)
+    ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=torch.optim.SGD(model.parameters(), lr=1e-2), config=cfg,
+                 data=CountingData()).train()
+    assert [t for _, t in seen] == [False, False, True, True] and all(s == (2, 5, 3) for s, _ in seen)

@@ -84,6 +84,10 @@ def resnet_case_names():
     return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "r_*.npz")))
 
 
+def fcl_case_names():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "f_*.npz")))
+
+
 def mr_case_names():
     return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "m_*.npz")))
 

@@ -98,8 +98,9 @@ class ModelEvaluator(BaseEvaluator):
                 else:
                     ctx_x, qry_x, ctx_y, qry_y = self.ingest.take(ticket)
                 if getattr(self.config, "contrastive", False):
-                    raise NotImplementedError("the functional-contrastive (FCL) models are out of scope (SURVEY.md §2.1 row 9)")
-                pr_mu, pr_var, _ = self.model(ctx_x, ctx_y, qry_x, test=True)
+                    pr_mu, pr_var, _, _ = self.model(ctx_x, ctx_y, qry_x, qry_y, test=True)
+                else:
+                    pr_mu, pr_var, _ = self.model(ctx_x, ctx_y, qry_x, test=True)
                 vals.append(self.loss.calc_loss(pr_mu, pr_var, qry_y, test=True).view(1))
                 if self.ingest is not None and i + 1 < n:
                     ticket = stage()                       # next batch's copy overlaps with this forward

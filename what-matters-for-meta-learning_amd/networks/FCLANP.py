@@ -1,9 +1,10 @@
-"""`networks.FCLANP` of the reference is OUTSIDE the accelerated hot path (the task-batched CNP/ANP
-forward+backward): functional contrastive learning (NT-Xent loss on a 4-tuple forward).  The module exists so a config naming it fails loudly and clearly."""
-from torch import nn
+"""Plugin `networks.FCLANP` (reference: networks/FCLANP.py): the ResNet-encoder ANP with functional contrastive learning - the
+forward takes the target labels as 4th argument and returns the NT-Xent term over the per-target attention outputs
+(trainer/losses.py:91-99) as 4th value.  Same parameters, construction order and kernels as `networks.ANP`; see
+networks/_resnet_np.py."""
+from networks._resnet_np import ResNetNP
 
 
-class FCLANP(nn.Module):
-    def __init__(self, config=None, *args, **kwargs):
-        raise NotImplementedError("method 'FCLANP' (functional contrastive learning) is not part of the MI355X hot-path build; "
-                                  "in scope: CNP*/ANP* (vanilla, ResNet, MR and Distractor variants) - see INTEGRATION.md")
+class FCLANP(ResNetNP):
+    ATTENTION = True
+    CONTRASTIVE = True

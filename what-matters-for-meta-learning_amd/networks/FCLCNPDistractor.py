@@ -1,9 +1,10 @@
-"""`networks.FCLCNPDistractor` of the reference is OUTSIDE the accelerated hot path (the task-batched CNP/ANP
-forward+backward): functional contrastive learning (NT-Xent loss on a 4-tuple forward).  The module exists so a config naming it fails loudly and clearly."""
-from torch import nn
+"""Plugin `networks.FCLCNPDistractor` (reference: networks/FCLCNPDistractor.py): CNPDistractor with functional contrastive
+learning - the target set goes through the image / task encoders and the aggregator as well, and the NT-Xent term between the
+context-set and the target-set task embeddings (trainer/losses.py:83-88) comes back as 4th value; see networks/_resnet_np.py."""
+from networks._resnet_np import ResNetNP
 
 
-class FCLCNPDistractor(nn.Module):
-    def __init__(self, config=None, *args, **kwargs):
-        raise NotImplementedError("method 'FCLCNPDistractor' (functional contrastive learning) is not part of the MI355X hot-path build; "
-                                  "in scope: CNP*/ANP* (vanilla, ResNet, MR and Distractor variants) - see INTEGRATION.md")
+class FCLCNPDistractor(ResNetNP):
+    ATTENTION = False
+    TRANSFORM_Y = True
+    CONTRASTIVE = True

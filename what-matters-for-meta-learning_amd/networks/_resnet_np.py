@@ -15,6 +15,7 @@ from networks.models import AttnLinear, ImageEncoder, NPDecoder, _mlp3
 class ResNetNP(nn.Module):
     ATTENTION = False
     TRANSFORM_Y = False   # *Distractor classes: labels go through Linear(label_dim -> dim_w) first (CNPDistractor.py:43,89)
+    CONTRASTIVE = False   # FCL* classes: forward takes the target labels too and returns a 4th value, the NT-Xent term
     N_HEADS = 8
 
     def __init__(self, config):
@@ -29,12 +30,13 @@ class ResNetNP(nn.Module):
         self.y_dim = config.output_dim
         if self.ATTENTION:
             self.temperature = getattr(config, "temperature", 0.07)
+        if self.TRANSFORM_Y:
+            self.dim_w = config.dim_w
         torch.manual_seed(config.seed)
 
         self.img_encoder = ImageEncoder(aggregate=self.img_agg, task_num=self.task_num, img_channels=self.img_channels)
         label_width = self.label_dim
         if self.TRANSFORM_Y:
-            self.dim_w = config.dim_w
             self.transform_y = nn.Linear(self.label_dim, self.dim_w)
             label_width = self.dim_w
         self.task_encoder = nn.Sequential(nn.Linear(256 + label_width, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
@@ -67,10 +69,34 @@ class ResNetNP(nn.Module):
                                      self.attn.projection_matrix)
         return self._W(merged)
 
-    def forward(self, batch_train_images, label_train, batch_test_images, test=False):
+    def _aggregate(self, feats, quirk=False):
+        """Shot-axis aggregation of the task-encoder features + `mu` -> task embedding [T, 256].  `quirk`: the target-set path
+        of FCLCNPDistractor feeds latent_var with latent_mu's OUTPUT (FCLCNPDistractor.py:133-134); reproduced as is."""
+        if self.agg_mode in ("mean", "max"):
+            r, _ = AggFunction.apply(self.agg_mode, feats, None)
+        elif self.agg_mode == "baco":
+            mu_l = LinearFunction.apply(feats, self.latent_mu.weight, self.latent_mu.bias, "none")
+            lv = LinearFunction.apply(mu_l if quirk else feats, self.latent_var.weight, self.latent_var.bias, "none")
+            r, _ = AggFunction.apply("baco", mu_l, lv)
+        else:
+            raise TypeError("agg_mode is not applicable for CNP, choose from ['mean', 'max', 'baco']")
+        return LinearFunction.apply(r, self.mu.weight, self.mu.bias, "none")
+
+    def forward(self, batch_train_images, label_train, batch_test_images, *rest, test=False):
+        """(ctx images, ctx labels, target images[, test]) -> (mu, var, 0); the FCL classes take the target labels as 4th
+        positional argument and return (mu, var, 0, contrastive term) like the reference (FCLANP.py:108, FCLCNPDistractor.py:82)."""
+        label_test = None
+        if self.CONTRASTIVE:
+            if not rest:
+                raise TypeError("forward() missing the target labels (label_test)")
+            label_test, rest = rest[0], rest[1:]
+        if rest:
+            test = rest[0]
+        from trainer.losses import LossFunc
         self.test_num = batch_test_images.shape[1]
         self.ctx_num = batch_train_images.shape[1]
         C, H, W = self.img_channels, self.img_size[0], self.img_size[1]
+        z_0 = None
         if self.ctx_num:
             if self.TRANSFORM_Y:
                 label_train = LinearFunction.apply(label_train, self.transform_y.weight, self.transform_y.bias, "none")
@@ -80,17 +106,23 @@ class ResNetNP(nn.Module):
                 x_tgt = self.img_encoder(batch_test_images.reshape(-1, C, H, W))
                 sample = LinearFunction.apply(self._multihead_attention(x_ctx, feats, x_tgt), self.mu.weight, self.mu.bias, "none")
             else:
-                if self.agg_mode in ("mean", "max"):
-                    r, _ = AggFunction.apply(self.agg_mode, feats, None)
-                elif self.agg_mode == "baco":
-                    mu_l = LinearFunction.apply(feats, self.latent_mu.weight, self.latent_mu.bias, "none")
-                    lv = LinearFunction.apply(feats, self.latent_var.weight, self.latent_var.bias, "none")
-                    r, _ = AggFunction.apply("baco", mu_l, lv)
-                else:
-                    raise TypeError("agg_mode is not applicable for CNP, choose from ['mean', 'max', 'baco']")
-                mu = LinearFunction.apply(r, self.mu.weight, self.mu.bias, "none")
-                sample = mu[:, None, :].expand(-1, self.test_num, -1)
+                z_0 = self._aggregate(feats)
+                sample = z_0[:, None, :].expand(-1, self.test_num, -1)
         else:
             sample = torch.zeros(self.task_num, self.test_num, 256, device=batch_test_images.device)
+        contra = 0
+        if self.CONTRASTIVE and not test:
+            if self.ATTENTION:
+                contra = LossFunc.contrastive_loss_ANP(sample, t=self.temperature)
+            else:
+                if z_0 is None:
+                    raise ValueError("the contrastive term needs a non-empty context set (the reference fails here as well: z_0 is unbound)")
+                x_qry = self.img_encoder(batch_test_images.reshape(-1, C, H, W))
+                if self.TRANSFORM_Y:
+                    label_test = LinearFunction.apply(label_test, self.transform_y.weight, self.transform_y.bias, "none")
+                z_q = self._aggregate(_mlp3(torch.cat([x_qry, label_test], dim=2), self.task_encoder, last_relu=True), quirk=True)
+                contra = LossFunc.contrastive_loss(z_0, z_q)
         out, var = self.decoder(batch_test_images, sample)
+        if self.CONTRASTIVE:
+            return out, var, 0, contra
         return out, var, 0

@@ -73,11 +73,15 @@ class ModelTrainer(BaseTrainer):
         self.model.train()
         self.optimizer.zero_grad()
         ctx_x, qry_x, ctx_y, qry_y = self._batch("train")
-        if getattr(self.config, "contrastive", False):
-            raise NotImplementedError("the functional-contrastive (FCL) models are out of scope (SURVEY.md §2.1 row 9)")
-        pr_mu, pr_var, kl = self.model(ctx_x, ctx_y, qry_x)
+        contrastive = getattr(self.config, "contrastive", False)
+        if contrastive:                                   # FCL* models take the target labels and return the NT-Xent term
+            pr_mu, pr_var, kl, contra_loss = self.model(ctx_x, ctx_y, qry_x, qry_y)
+        else:
+            pr_mu, pr_var, kl = self.model(ctx_x, ctx_y, qry_x)
         losses = self.loss.calc_loss(pr_mu, pr_var, qry_y)
         losses = losses + kl * self.config.beta
+        if contrastive:
+            losses = losses + contra_loss * self.config.contrastive_rate
         losses.backward()
         self.bucket.sync()
         self.optimizer.step()
@@ -100,7 +104,10 @@ class ModelTrainer(BaseTrainer):
             vals = []
             for _ in range(self.config.val_iters):
                 ctx_x, qry_x, ctx_y, qry_y = self._batch(source)
-                pr_mu, pr_var, _ = self.model(ctx_x, ctx_y, qry_x, test=True)
+                if getattr(self.config, "contrastive", False):
+                    pr_mu, pr_var, _, _ = self.model(ctx_x, ctx_y, qry_x, qry_y, test=True)
+                else:
+                    pr_mu, pr_var, _ = self.model(ctx_x, ctx_y, qry_x, test=True)
                 vals.append(self.loss.calc_loss(pr_mu, pr_var, qry_y, test=True).view(1))
             vals = torch.cat(vals)
             loss, std = vals.mean(), (vals.std() if vals.numel() > 1 else vals.new_zeros(()))
