@@ -129,3 +129,24 @@ def test_staged_eps_reproduces_the_lazy_draws():
     with st.active(), pytest.raises(RuntimeError):
         eps.draw((5,), "cpu")              # not the recorded shape
     assert eps._active is None and eps._recorder is None
+
+
+def test_committed_bench_line_honours_the_contract():
+    """profiles/r01_final_bench_c3.json is a bench.py line from the MI355X box: the driver's contract fields, the roofline and
+    cpu_baseline objects, metric / unit as BASELINE.json names them."""
+    import json
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench_c3.json")))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "weak" and line["data"] == "synthetic"
+    assert line["dtype"] == "f32" and line["vs_baseline"] is None and "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - 16 * 1e3 / line["ms_per_step"]) <= 1e-6 * line["value"]            # 16 tasks per step on one GPU
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"] and c["sample"]
+    if isinstance(base, dict) and "unit" in base:
+        assert base["unit"].split("/")[0].strip().lower()[:4] in line["unit"].lower() or line["unit"].lower()[:4] in base["unit"].lower()
