@@ -542,6 +542,30 @@ def test_model_trainer_loop_on_synthetic_data(gpulib, tmp_path, monkeypatch):
     assert moved > 0 and all(torch.isfinite(v).all() for v in model.state_dict().values())
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 12, 12, 8, 5, 2, 2), (2, 4, 9, 9, 6, 3, 2, 1), (1, 5, 8, 8, 7, 3, 1, 1), (2, 4, 8, 8, 5, 1, 2, 0),
+                                   (1, 2, 7, 7, 3, 3, 3, 1), (120, 64, 8, 8, 64, 3, 2, 1), (30, 64, 32, 32, 64, 3, 2, 1), (9, 3, 64, 64, 64, 5, 2, 2)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv2d_runtime_shapes_vs_torch(gpulib, shape, relu):
+    """The hoisted / select-free gathers of the run-time-shaped convolution problems (A2 / B2 of ConvFwdRT, ConvWgradRT, ConvDgradRT),
+    the 16-row and 128-row tile variants and the batched parity-class launch against F.conv2d and its autograd on the CPU:
+    odd sizes, strides 1-3, k = 1 / 3 / 5, row counts on both sides of the tile-choice threshold."""
+    N, Cin, H, W, Cout, k, s, p = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, Cin, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    ref = F.relu(ref) if relu else ref
+    xd, wd, bd = dev(x.detach(), w.detach(), b.detach())
+    y = gpulib.conv2d_fwd(xd, wd, bd, s, p, relu)
+    assert U.rel_err(y, ref) <= 1e-5
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    # the backward masks with sign(forward output): hand it the CPU's output so that a rounding-level tie cannot flip one ReLU
+    dx, dw, db = gpulib.conv2d_bwd(xd, wd, ref.detach().to(DEV), dy.to(DEV), s, p, relu)
+    assert U.rel_err(dx, x.grad) <= 2e-5 and U.rel_err(dw, w.grad) <= 2e-5 and U.rel_err(db, b.grad) <= 2e-5
+
+
 # ---- batch ingest (SURVEY §8f rank 2): uint8 channel-last -> fp32 channel-first on the device ------------
 def test_ingest_kernel_bit_exact_vs_reference_vectors(gpulib):
     fx = np.load(os.path.join(U.GOLDEN, "ingest.npz"))

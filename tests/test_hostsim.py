@@ -126,3 +126,24 @@ def test_ingest_matches_reference_vectors(hostsim):
         hostsim.ingest_u8_nhwc(torch.zeros(2, 4, 4, 1))                 # not uint8
     with pytest.raises(MlhotError):
         hostsim.ingest_u8_nhwc(torch.zeros(1, 4, 4, 1, dtype=torch.uint8), out=torch.zeros(1, 4, 4, 1))   # out not channel-first
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 12, 12, 8, 5, 2, 2), (2, 4, 9, 9, 6, 3, 2, 1), (1, 5, 8, 8, 7, 3, 1, 1), (2, 4, 8, 8, 5, 1, 2, 0),
+                                   (1, 2, 7, 7, 3, 3, 3, 1)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv2d_runtime_shapes_vs_torch(hostsim, shape, relu):
+    """Run-time-shaped convolution problems (ConvFwdRT / ConvWgradRT / ConvDgradRT incl. its s*s input-parity classes, batched four
+    per launch on the device): index arithmetic of the functors against F.conv2d and its autograd, odd sizes, strides 1-3, k = 1/3/5."""
+    N, Cin, H, W, Cout, k, s, p = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, Cin, H, W, generator=g).requires_grad_(True)
+    w = torch.randn(Cout, Cin, k, k, generator=g).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    ref = F.relu(ref) if relu else ref
+    y = hostsim.conv2d_fwd(x.detach(), w.detach(), b.detach(), s, p, relu)
+    assert U.rel_err(y, ref) <= 1e-5
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    dx, dw, db = hostsim.conv2d_bwd(x.detach(), w.detach(), y, dy, s, p, relu)
+    assert U.rel_err(dx, x.grad) <= 1e-5 and U.rel_err(dw, w.grad) <= 1e-5 and U.rel_err(db, b.grad) <= 1e-5
