@@ -20,7 +20,8 @@ def dev(*ts):
 
 
 # ---- igemm engine on plain GEMM shapes (MFMA lane maps, LDS images, split-K slab) --------------
-@pytest.mark.parametrize("M,K,N", [(1, 3, 16), (37, 80, 100), (240, 100, 64), (480, 512, 64), (65, 17, 130), (16, 4096, 64)])
+@pytest.mark.parametrize("M,K,N", [(1, 3, 16), (37, 80, 100), (240, 100, 64), (480, 512, 64), (65, 17, 130), (16, 4096, 64),
+                                   (4100, 96, 250)])     # the last one: >= 128 64-row tiles, the 64 x 64 x 32 tile variant
 @pytest.mark.parametrize("act", ["none", "relu", "tanh"])
 def test_linear_fwd_bwd(gpulib, M, K, N, act):
     g = torch.Generator().manual_seed(M * 1000 + K)
