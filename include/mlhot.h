@@ -142,6 +142,21 @@ int mlhot_bbb_sample_fwd(const float* mu, const float* rho, const float* eps, fl
 int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, const float* dw, const float* dkl, float* dmu, float* drho,
                          size_t n, void* stream);
 
+/* The same for up to MLHOT_BBB_MAX_ITEMS tensors in one launch pair (a Bayes-by-backprop encoder samples every layer's weight
+ * and bias once per forward: 26 tensors for ANPMRShapeNet3D.py:40-90): w_i = mu_i + eps_i * softplus(rho_i) for every item,
+ * kl = the sum of ALL items' KL terms.  `partial`: mlhot_bbb_sample_multi_scratch_floats() floats of scratch.  Backward: items
+ * carry dw (may be NULL: no gradient reached that sample), dmu, drho (overwritten); dkl as above. */
+#define MLHOT_BBB_MAX_ITEMS 32
+typedef struct {
+  const float* mu; const float* rho; const float* eps;
+  float* w;                       /* forward output */
+  const float* dw; float* dmu; float* drho;   /* backward */
+  size_t n;
+} mlhot_bbb_item;
+size_t mlhot_bbb_sample_multi_scratch_floats(const mlhot_bbb_item* items, int n_items);
+int mlhot_bbb_sample_multi_fwd(const mlhot_bbb_item* items, int n_items, float* partial, float* kl, void* stream);
+int mlhot_bbb_sample_multi_bwd(const mlhot_bbb_item* items, int n_items, const float* dkl, void* stream);
+
 /* ---- batch ingest: the host-side image conversion of the data loaders, on the device ----
  * dst[n][c][y][x] = (float)src[n][y][x][c] / div, i.e. dataset/shapenet_1d.py:189-190 (`xs.astype(np.float32) / 255.0`;
  * same in dataset/pascal_1d.py, shapenet_3d.py, distractor.py) followed by utils/utils.py:26-30

@@ -12,6 +12,7 @@
 #include "np_vanilla.h"
 #include "conv_rt.h"
 #include "ingest.h"
+#include "bbb_multi.h"
 #include "../../include/mlhot.h"
 
 namespace mlhot {
@@ -217,6 +218,20 @@ int mlhot_bbb_sample_fwd(const float* mu, const float* rho, const float* eps, fl
 int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, const float* dw, const float* dkl, float* dmu, float* drho,
                          size_t n, void* stream) {
   return run_foreach(BbbSampleBwd{mu, rho, eps, dw, dkl, dmu, drho}, n, (hipStream_t)stream, "bbb.sample.bwd");
+}
+
+size_t mlhot_bbb_sample_multi_scratch_floats(const mlhot_bbb_item* items, int n_items) {
+  size_t blocks = 0;
+  for (int i = 0; i < n_items; ++i) blocks += (items[i].n + BBB_CHUNK - 1) / BBB_CHUNK;
+  return blocks > 0 ? blocks : 1;
+}
+int mlhot_bbb_sample_multi_fwd(const mlhot_bbb_item* items, int n_items, float* partial, float* kl, void* stream) {
+  if (!items || !partial || !kl) { set_error("bbb_sample_multi_fwd: bad argument"); return MLHOT_ERR_ARG; }
+  return bbb_sample_multi_fwd(items, n_items, partial, kl, (hipStream_t)stream);
+}
+int mlhot_bbb_sample_multi_bwd(const mlhot_bbb_item* items, int n_items, const float* dkl, void* stream) {
+  if (!items || !dkl) { set_error("bbb_sample_multi_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  return bbb_sample_multi_bwd(items, n_items, dkl, (hipStream_t)stream);
 }
 
 // ---- batch ingest: uint8 channel-last images -> fp32 channel-first, divided by `div` -----------------------

@@ -91,6 +91,11 @@ def _get(struct, path):
     return getattr(getattr(struct, path[0]), path[1])
 
 
+class BbbItem(C.Structure):          # struct mlhot_bbb_item
+    _fields_ = [("mu", C.c_void_p), ("rho", C.c_void_p), ("eps", C.c_void_p), ("w", C.c_void_p), ("dw", C.c_void_p), ("dmu", C.c_void_p),
+                ("drho", C.c_void_p), ("n", C.c_size_t)]
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -306,6 +311,39 @@ class MlhotLib:
         self._rc(self.c.mlhot_bbb_sample_bwd(_ptr(mu), _ptr(rho), _ptr(eps), _ptr(dw), _ptr(dkl), _ptr(dmu), _ptr(drho), mu.numel(), _stream(mu)),
                  "mlhot_bbb_sample_bwd")
         return dmu, drho
+
+    def _bbb_items(self, mus, rhos, epss, ws=None, dws=None, dmus=None, drhos=None):
+        n = len(mus)
+        if n > 32:
+            raise MlhotError("bbb_sample_multi: at most 32 tensors per call")
+        arr = (BbbItem * max(n, 1))()
+        for i in range(n):
+            it = arr[i]
+            it.mu, it.rho, it.eps = mus[i].data_ptr(), rhos[i].data_ptr(), epss[i].data_ptr()
+            it.w = ws[i].data_ptr() if ws is not None else None
+            it.dw = dws[i].data_ptr() if dws is not None and dws[i] is not None else None
+            it.dmu = dmus[i].data_ptr() if dmus is not None else None
+            it.drho = drhos[i].data_ptr() if drhos is not None else None
+            it.n = mus[i].numel()
+        return arr
+
+    def bbb_sample_multi_fwd(self, mus, rhos, epss):
+        """Every (mu, rho, eps) triple sampled in ONE launch: returns ([w_i], kl = sum of all KL terms)."""
+        _chk(*mus, *rhos, *epss)
+        ws = [torch.empty_like(m) for m in mus]
+        kl = torch.empty((), device=mus[0].device)
+        items = self._bbb_items(mus, rhos, epss, ws=ws)
+        self.c.mlhot_bbb_sample_multi_scratch_floats.restype = C.c_size_t
+        partial = torch.empty(self.c.mlhot_bbb_sample_multi_scratch_floats(items, len(mus)), device=mus[0].device)
+        self._rc(self.c.mlhot_bbb_sample_multi_fwd(items, len(mus), _ptr(partial), _ptr(kl), _stream(mus[0])), "mlhot_bbb_sample_multi_fwd")
+        return ws, kl
+
+    def bbb_sample_multi_bwd(self, mus, rhos, epss, dws, dkl):
+        _chk(*[d for d in dws if d is not None], dkl)
+        dmus, drhos = [torch.empty_like(m) for m in mus], [torch.empty_like(m) for m in mus]
+        items = self._bbb_items(mus, rhos, epss, dws=dws, dmus=dmus, drhos=drhos)
+        self._rc(self.c.mlhot_bbb_sample_multi_bwd(items, len(mus), _ptr(dkl), _stream(mus[0])), "mlhot_bbb_sample_multi_bwd")
+        return dmus, drhos
 
     # ---- X1 building blocks --------------------------------------------------------------------
     def bn_relu_fwd(self, x, gamma, beta, run_mean, run_var, momentum=0.1, eps=1e-5):

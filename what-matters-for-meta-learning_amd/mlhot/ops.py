@@ -230,6 +230,37 @@ class BBBSampleFunction(torch.autograd.Function):
         return dmu, drho, None
 
 
+class BBBSampleMultiFunction(torch.autograd.Function):
+    """All weight / bias samples of a Bayes-by-backprop encoder in one launch pair (mlhot_bbb_sample_multi_fwd / _bwd).
+    apply(eps_list, mu_0, rho_0, mu_1, rho_1, ...) -> (w_0, w_1, ..., kl); eps_list[i] is the device tensor of draw i."""
+
+    @staticmethod
+    def forward(ctx, eps_list, *mu_rho):
+        _need_gpu(*mu_rho, *eps_list)
+        mus = [_c(t.detach()) for t in mu_rho[0::2]]
+        rhos = [_c(t.detach()) for t in mu_rho[1::2]]
+        epss = [_c(e) for e in eps_list]
+        ws, kl = lib().bbb_sample_multi_fwd(mus, rhos, epss)
+        ctx.k = len(mus)
+        ctx.save_for_backward(*mus, *rhos, *epss)
+        return (*ws, kl)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        k = ctx.k
+        saved = ctx.saved_tensors
+        mus, rhos, epss = saved[:k], saved[k:2 * k], saved[2 * k:]
+        dws = [(_c(g) if g is not None else None) for g in grads[:k]]
+        dkl = grads[k]
+        if dkl is None:
+            dkl = torch.zeros((), device=mus[0].device)
+        dmus, drhos = lib().bbb_sample_multi_bwd(mus, rhos, epss, dws, _c(dkl.float()))
+        out = [None]
+        for a, b in zip(dmus, drhos):
+            out += [a, b]
+        return tuple(out)
+
+
 class BatchNormReluFunction(torch.autograd.Function):
     """Train-mode batch norm over dim 0 (+ fused ReLU), updating the running buffers in place like
     F.batch_norm(training=True): mlhot_bn_relu_fwd / _bwd."""

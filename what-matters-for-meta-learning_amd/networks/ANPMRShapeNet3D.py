@@ -9,7 +9,7 @@ from torch import nn
 from mlhot.ops import AddReluFunction, LinearFunction
 from networks._resnet_np import ResNetNP
 from networks.bbb.BBBConv import BBBConv2d
-from networks.bbb.misc import FlattenLayer, ModuleWrapper
+from networks.bbb.misc import FlattenLayer, ModuleWrapper, sample_all
 from networks.fast_attention import FastAttention
 from networks.models import AttnLinear, NPDecoder, _aggregate_feature_map, _mlp3
 
@@ -49,6 +49,21 @@ class BBBEncoder(ModuleWrapper):
             ("layer2", BasicBlock(64, 64, stride=2, **kw)), ("layer3", BasicBlock(64, 64, stride=2, **kw)),
             ("layer4", BasicBlock(64, 64, stride=2, **kw)), ("layer5", BasicBlock(64, 64, stride=2, **kw)),
             ("flatten", FlattenLayer(256))]))
+
+    def _bbb_layers(self):
+        """The BBB convolutions in the order their forwards run (= the reference's eps draw order): stem, then per block
+        conv1, conv2, skip."""
+        out = [self.net.layer1.conv]
+        for name in ("layer2", "layer3", "layer4", "layer5"):
+            blk = getattr(self.net, name)
+            out += [blk.conv1, blk.conv2] + ([blk.downsample[0]] if blk.downsample is not None else [])
+        return out
+
+    def forward(self, x):
+        kl = sample_all(self._bbb_layers())          # 26 tensors, one launch pair; each layer picks its sample up below
+        for module in self.children():
+            x = module(x)
+        return x, kl
 
 
 class ANPMRShapeNet3D(ResNetNP):

@@ -19,7 +19,7 @@ from torch import nn
 from mlhot.ops import AggFunction, EncVanillaFunction, FavorFunction, LinearFunction
 from networks.bbb.BBBConv import BBBConv2d
 from networks.bbb.BBBLinear import BBBLinear
-from networks.bbb.misc import FlattenLayer, ModuleWrapper
+from networks.bbb.misc import FlattenLayer, ModuleWrapper, sample_all
 from networks.fast_attention import FastAttention
 from networks.models import AttnLinear, EncoderFC, NPDecoder
 
@@ -40,12 +40,12 @@ class BBBEncoder(ModuleWrapper):
             ("flatten", FlattenLayer(4096)), ("linear", BBBLinear(4096, dim_w, bias=True))]))
 
     def forward(self, img):
-        params, kl = [], 0.0
-        for layer in (self.net.layer1.conv, self.net.layer2.conv, self.net.layer3.conv, self.net.linear):
-            w, b, k = layer.sample()           # draw order of ModuleWrapper.forward: layer by layer, weight then bias
+        layers = (self.net.layer1.conv, self.net.layer2.conv, self.net.layer3.conv, self.net.linear)
+        kl = sample_all(layers)                # draw order of ModuleWrapper.forward: layer by layer, weight then bias; one launch pair
+        params = []
+        for layer in layers:
+            (w, b), layer.presampled = layer.presampled, None
             params += [w, b]
-            kl = kl + k
-            layer.release_kl_graph()
         return EncVanillaFunction.apply(img, *params), kl
 
 

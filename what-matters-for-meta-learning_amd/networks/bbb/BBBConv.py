@@ -38,6 +38,7 @@ class BBBConv2d(ModuleWrapper):
             self.register_parameter("bias_rho", None)
         self.fuse_relu = False
         self._kl = None
+        self.presampled = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -61,7 +62,10 @@ class BBBConv2d(ModuleWrapper):
         return weight, bias, kl
 
     def forward(self, x, sample=True):
-        weight, bias, _ = self.sample()
+        if self.presampled is not None:                    # sample_all() drew this forward's weights already
+            (weight, bias), self.presampled = self.presampled, None
+        else:
+            weight, bias, _ = self.sample()
         return Conv2dFunction.apply(x, weight, bias, self.stride, self.padding, self.fuse_relu)
 
     def kl_loss(self):

@@ -30,6 +30,7 @@ class BBBLinear(ModuleWrapper):
             self.register_parameter("bias_mu", None)
             self.register_parameter("bias_rho", None)
         self._kl = None
+        self.presampled = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -53,7 +54,10 @@ class BBBLinear(ModuleWrapper):
         return weight, bias, kl
 
     def forward(self, x, sample=True):
-        weight, bias, _ = self.sample()
+        if self.presampled is not None:                    # sample_all() drew this forward's weights already
+            (weight, bias), self.presampled = self.presampled, None
+        else:
+            weight, bias, _ = self.sample()
         return LinearFunction.apply(x, weight, bias, "none")
 
     def kl_loss(self):

@@ -1,6 +1,38 @@
 """Containers of the BBB encoders (reference: networks/bbb/misc.py:23-54)."""
 from torch import nn
 
+from . import eps
+
+
+def sample_all(layers):
+    """Weight and bias samples of `layers` (BBBConv2d / BBBLinear, in the order their forwards will run) in ONE launch pair
+    instead of two per tensor.  The eps draws happen here, layer by layer, weight then bias - the order and the generator state the
+    reference's per-layer forwards would see (bbb/BBBConv.py:88-95) - and every layer is handed its sample for its next forward.
+    Returns the summed KL of all layers (what ModuleWrapper.forward adds up, bbb/misc.py:40-44)."""
+    from mlhot.ops import BBBSampleMultiFunction
+    total, todo = 0.0, list(layers)
+    while todo:
+        chunk, todo = todo[:16], todo[16:]                 # <= 32 tensors per call
+        eps_list, mu_rho, slots = [], [], []
+        for layer in chunk:
+            dev = layer.W_mu.device
+            eps_list.append(eps.draw(layer.W_mu.size(), dev))
+            mu_rho += [layer.W_mu, layer.W_rho]
+            slots.append((layer, "w"))
+            if layer.use_bias:
+                eps_list.append(eps.draw(layer.bias_mu.size(), dev))
+                mu_rho += [layer.bias_mu, layer.bias_rho]
+                slots.append((layer, "b"))
+        *ws, kl = BBBSampleMultiFunction.apply(eps_list, *mu_rho)
+        got = {}
+        for (layer, kind), w in zip(slots, ws):
+            got.setdefault(id(layer), [layer, None, None])[1 if kind == "w" else 2] = w
+        for layer, w, b in got.values():
+            layer.presampled = (w, b)
+            layer._kl = None                               # the KL of a batched sample is the caller's total
+        total = total + kl
+    return total
+
 
 class ModuleWrapper(nn.Module):
     """Runs its children in order and returns (output, summed KL of every BBB layer underneath)."""
