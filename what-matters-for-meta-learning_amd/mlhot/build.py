@@ -23,20 +23,36 @@ def _deps():
 
 
 def build_product(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> csrc/libmlhot.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 -> csrc/libmlhot.so (cross-compiles without a GPU).  Safe to call from every rank of a
+    multi-process launch at once: one process builds (into a temporary file, renamed into place), the others wait on a file
+    lock and then find the library fresh."""
     if not force and not _stale(PRODUCT_SO, _deps()):
         return PRODUCT_SO
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        if os.path.exists(PRODUCT_SO):
-            return PRODUCT_SO      # GPU box without a toolchain: use the prebuilt file that travelled
-        raise RuntimeError("mlhot: hipcc not found and no prebuilt libmlhot.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-comment",
-           os.path.join(CSRC, "mlhot.hip"), "-o", PRODUCT_SO]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    return PRODUCT_SO
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale(PRODUCT_SO, _deps()):
+                return PRODUCT_SO              # another process built it while this one waited
+            hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+            if not os.path.exists(hipcc):
+                if os.path.exists(PRODUCT_SO):
+                    return PRODUCT_SO      # GPU box without a toolchain: use the prebuilt file that travelled
+                raise RuntimeError("mlhot: hipcc not found and no prebuilt libmlhot.so")
+            tmp = f"{PRODUCT_SO}.{os.getpid()}.tmp"
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-comment",
+                   os.path.join(CSRC, "mlhot.hip"), "-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.run(cmd, check=True, cwd=CSRC)
+                os.replace(tmp, PRODUCT_SO)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            return PRODUCT_SO
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def build_hostsim(out_dir, force=False):
