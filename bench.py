@@ -221,6 +221,83 @@ def measure_variable_nc(w, device, loss_fn, model, batch, iters):
             "note": "context size ~ U{3..15} per step (the reference's training draw), 15 targets, one hipGraph per size"}
 
 
+def measure_train_loop(w, device, loss_fn, iters):
+    """A whole TRAINING iteration from host batch to updated weights, two ways (informational; `value` is the resident fwd+bwd step):
+      reference-style loop: fp32 host batch `.to(device)`, eager zero_grad / forward / loss / backward on the HIP kernels,
+                            torch.optim.Adam over the ~70 parameter tensors, loss.item() every iteration (trainer/model_trainer.py:59-93);
+      replayed loop       : uint8 batch through mlhot.ingest.BatchIngest, ONE hipGraph holding forward, loss, backward and the
+                            capturable flat Adam step (mlhot.optim.FlatAdam, device-side step count), loss fetched every 50 iterations
+                            (trainer.ModelTrainer with config.graph_steps)."""
+    import importlib
+    from mlhot import synth
+    from mlhot.ingest import BatchIngest
+    from mlhot.optim import FlatAdam
+    cls = getattr(importlib.import_module("networks." + w["method"]), w["method"])
+    hb = synth.get_batch_u8("shapenet_1d", T_LOCAL, NC, NQ, seed=1234)
+    host = [synth.host_convert(hb[0]), synth.host_convert(hb[1]), hb[2], hb[3]]
+    out = {}
+    # reference-style loop
+    model = cls(make_cfg(w, device)).to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    n_ref = max(5, iters // 2)
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_ref):
+            cx, qx, cy, qy = (t.to(device) for t in host)
+            opt.zero_grad()
+            loss = loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy)
+            loss.backward()
+            opt.step()
+            loss.item()
+        torch.cuda.synchronize()
+        if timed:
+            out["reference_style_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_ref
+    # replayed loop
+    model = cls(make_cfg(w, device)).to(device)
+    opt = FlatAdam(model, lr=1e-4, ctx_num=NC, test_num=NQ, capturable=True)
+    ing = BatchIngest(device)
+    ing.stage(*hb)
+    cx, qx, cy, qy = ing.take()
+
+    def it():
+        opt.zero_grad()
+        loss = loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            it()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        static_loss = it()
+    ing.stage(*hb)
+    n_rep = 4 * iters
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_rep):
+            ing.take()
+            graph.replay()
+            ing.stage(*hb)
+            if i % 50 == 49:
+                static_loss.item()
+        torch.cuda.synchronize()
+        if timed:
+            out["replayed_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_rep
+    ing.take()
+    out["tasks_per_s"] = {"reference_style": 1e3 * T_LOCAL / out["reference_style_ms_per_iter"],
+                          "replayed": 1e3 * T_LOCAL / out["replayed_ms_per_iter"]}
+    out["adam_steps_taken"] = int(opt.step_dev.item())
+    return out
+
+
 def measure_extras(w, device, loss_fn, batch, iters):
     """Not the headline metric: (a) the training forward alone (activations saved, no backward), (b) the full step
     followed by the fused flat Adam update (mlhot.optim.FlatAdam: one launch over the flat parameter buffer).  The Adam
@@ -258,6 +335,7 @@ def measure_extras(w, device, loss_fn, batch, iters):
         model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(make_cfg(w, device)).to(device)
         out["host_fed"] = measure_host_fed(w, device, loss_fn, model, iters)
         out["variable_context"] = measure_variable_nc(w, device, loss_fn, model, batch, iters)
+        out["train_loop"] = measure_train_loop(w, device, loss_fn, iters)
         return out
     except Exception as e:  # noqa: BLE001 - extras must never break the bench line
         return {"error": f"{type(e).__name__}: {e}"}

@@ -171,6 +171,11 @@ int mlhot_ingest_u8_nhwc(const uint8_t* src, float* dst, long n_img, int H, int 
 int mlhot_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, float grad_scale, int step, void* stream);
 
+/* The same update with the 1-based step count kept in device memory: *step_counter is incremented on the device first, then
+ * used for the bias corrections.  Capture-safe - a replayed hipGraph of a whole training step advances the count by itself. */
+int mlhot_adam_step_counter(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, float grad_scale, int* step_counter, void* stream);
+
 /* ---- X1: ConvEmbeddingModel building blocks (networks/conv_embedding_model.py:99-184) -------------
  * Train-mode batch norm over the shots of ONE task, fused with the ReLU that follows it:
  * y = relu(gamma * (x - mean_c) / sqrt(var_c + eps) + beta) with per-channel batch statistics; like

@@ -696,6 +696,44 @@ def test_evaluator_context_sweep_vs_oracle(gpulib, tmp_path, method, agg):
             assert abs(got_std - vals.std().item()) <= 2e-3 * max(1.0, abs(vals.std().item())), (source, ctx_num)
 
 
+def test_graph_replayed_training_equals_eager_training(gpulib, tmp_path, monkeypatch):
+    """config.graph_steps: every training iteration replayed from a per-shape hipGraph (forward, loss, backward and the
+    capturable FlatAdam step with its device-side step count) lands on exactly the weights of the same loop run eagerly -
+    same draws, same kernels, incl. iterations whose batch shape appears for the first (eager warm-up), second (capture +
+    replay) and later (replay) time - and the validation cadence / files are untouched."""
+    import types
+    from mlhot.optim import FlatAdam
+    from mlhot.synth import SyntheticData
+    from networks.ANPShapeNet1D import ANPShapeNet1D
+    from trainer.losses import LossFunc
+    from trainer.model_trainer import ModelTrainer
+    monkeypatch.chdir(tmp_path)
+    finals, losses = [], []
+    for graph in (False, True):
+        cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[128, 128, 1], tasks_per_batch=2, input_dim=3,
+                                    output_dim=2, agg_mode="attention", img_agg="", dim_w=64, n_hidden_units_r=[100, 100], dim_r=64,
+                                    dim_z=64, task="shapenet_1d", iterations=12, val_freq=6, val_iters=1, bg_gen_freq=1000, gen_bg=False,
+                                    max_ctx_num=5, beta=0, contrastive=False, graph_steps=graph, log_every=1,
+                                    save_path=str(tmp_path / f"g{int(graph)}"), logger=None)
+        model = ANPShapeNet1D(cfg).to(cfg.device)
+        opt = FlatAdam(model, lr=1e-3, ctx_num=5, test_num=5, capturable=True)
+        tr = ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=opt, config=cfg, data=SyntheticData())
+        seen = []
+        orig = tr._train_iter
+        tr._train_iter = lambda it, _o=orig, _s=seen: _s.append(_o(it))
+        tr.train()
+        losses.append(seen)
+        finals.append({k: v.clone() for k, v in model.state_dict().items()})
+        if graph:
+            kinds = [type(v).__name__ for v in tr._graphs.values()]
+            assert "tuple" in kinds                     # context sizes 3..5 over 12 iterations: at least one shape was captured
+        assert int(opt.step_dev.item()) == 12
+        assert os.path.exists(tmp_path / f"g{int(graph)}" / "models" / "model_end_12.pt")
+    assert losses[0] == losses[1]
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+
+
 def test_trainer_contrastive_model(gpulib, tmp_path, monkeypatch):
     """config.contrastive: the trainer hands the target labels to an FCL* model and adds contrastive_rate x the NT-Xent term
     (trainer/model_trainer.py:72-81 of the reference); validation calls the 4-tuple forward with test=True."""

@@ -147,3 +147,19 @@ def test_conv2d_runtime_shapes_vs_torch(hostsim, shape, relu):
     ref.backward(dy)
     dx, dw, db = hostsim.conv2d_bwd(x.detach(), w.detach(), y, dy, s, p, relu)
     assert U.rel_err(dx, x.grad) <= 1e-5 and U.rel_err(dw, w.grad) <= 1e-5 and U.rel_err(db, b.grad) <= 1e-5
+
+
+def test_adam_step_counter_matches_adam_step(hostsim):
+    """The device-side step count variant (capture-safe) walks the same trajectory as the host-counted one."""
+    g = torch.Generator().manual_seed(9)
+    n = 517
+    p0 = torch.randn(n, generator=g)
+    pa, ma, va = p0.clone(), torch.zeros(n), torch.zeros(n)
+    pb, mb, vb = p0.clone(), torch.zeros(n), torch.zeros(n)
+    counter = torch.zeros(1, dtype=torch.int32)
+    for t in range(1, 8):
+        grad = torch.randn(n, generator=g)
+        hostsim.adam_step(pa, grad, ma, va, 3e-3, 0.9, 0.999, 1e-8, 0.01, 0.5, t)
+        hostsim.adam_step_counter(pb, grad, mb, vb, 3e-3, 0.9, 0.999, 1e-8, 0.01, 0.5, counter)
+        assert int(counter) == t
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), t

@@ -252,6 +252,15 @@ int mlhot_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                               (float)(1.0 / sqrt(bc2))}, n, (hipStream_t)stream, "adam.step");
 }
 
+int mlhot_adam_step_counter(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, float grad_scale, int* step_counter, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !step_counter) { set_error("adam_step_counter: bad argument"); return MLHOT_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  MLHOT_TRY(run_foreach(CounterInc{step_counter}, 1, s, "adam.count"));
+  return run_foreach(AdamStepCounter{param, grad, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, grad_scale, lr, step_counter}, n, s,
+                     "adam.step");
+}
+
 // ---- X1 building blocks: train-mode batch norm (+ReLU) over one task's shots, spatial mean ----------
 int mlhot_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float momentum, float eps,
                       int N, int C, int HW, float* y, float* mean, float* var, void* stream) {

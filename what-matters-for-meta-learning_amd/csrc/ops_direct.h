@@ -118,6 +118,25 @@ struct AdamStep {
   }
 };
 
+// The same update with the step count living ON THE DEVICE (incremented by CounterInc right before): a captured hipGraph of
+// a training step then advances Adam's bias correction on every replay.  The corrections are evaluated in double like the
+// host-side variant, so both produce the same step sizes.
+struct CounterInc { int* c; MLHOT_HD void operator()(size_t) const { c[0] += 1; } };
+struct AdamStepCounter {
+  float* p; const float* g; float* m; float* v;
+  float b1, b2, eps, wd, grad_scale, lr; const int* step;
+  MLHOT_HD void operator()(size_t i) const {
+    const int t = step[0];
+    const float step_size = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
+    const float gi = grad_scale * g[i] + wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
+};
+
 // ------------------------------------------------------------------------------------------
 // X1: train-mode batch norm of ConvEmbeddingModel (conv_embedding_model.py:113-117): the batch is the
 // shots of ONE task; statistics per channel over (n, h, w); F.batch_norm(training=True) also updates the

@@ -487,6 +487,17 @@ class MlhotLib:
         self._rc(self.c.mlhot_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, beta1, beta2, eps,
                                         weight_decay, grad_scale, int(step), _stream(param)), "mlhot_adam_step")
 
+    def adam_step_counter(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step_counter):
+        """adam_step with the step count in device memory (int32 tensor of one element, incremented by the call)."""
+        _chk(param, grad, exp_avg, exp_avg_sq, step_counter)
+        n = param.numel()
+        if not (grad.numel() == exp_avg.numel() == exp_avg_sq.numel() == n) or step_counter.dtype != torch.int32:
+            raise MlhotError("adam_step_counter: buffers differ in size, or the counter is not int32")
+        f = C.c_float
+        self.c.mlhot_adam_step_counter.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [f] * 6 + [C.c_void_p, C.c_void_p]
+        self._rc(self.c.mlhot_adam_step_counter(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, beta1, beta2, eps,
+                                                weight_decay, grad_scale, _ptr(step_counter), _stream(param)), "mlhot_adam_step_counter")
+
     def np_grads_layout(self, dims):
         """(total floats, {state_dict key: float offset}) of the library's flat gradient buffer for `dims`."""
         offs = NpGrads()

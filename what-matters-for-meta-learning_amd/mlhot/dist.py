@@ -60,8 +60,11 @@ class GradBucket:
             return None
         return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, lo, (hi - lo,))
 
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
     def sync(self):
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        world = self.world_size()
         live = [p for p in self.params if p.grad is not None]
         if world == 1 or not live:
             return

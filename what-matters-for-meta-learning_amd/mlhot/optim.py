@@ -12,9 +12,12 @@ from . import lib
 
 
 class FlatAdam:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ctx_num=15, test_num=15):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ctx_num=15, test_num=15, capturable=False):
+        """capturable: keep the step count on the device (mlhot_adam_step_counter) so that step() may sit inside a captured
+        hipGraph and still advance the bias correction on every replay (torch.optim.Adam's `capturable` for the same reason)."""
         self.model, self.lr, self.betas, self.eps, self.weight_decay = model, lr, betas, eps, weight_decay
         self.t = 0
+        self.capturable = capturable
         total, offs = model.flat_layout(ctx_num, test_num)
         params = dict(model.named_parameters())
         if set(offs) != set(params):
@@ -29,6 +32,7 @@ class FlatAdam:
                 p.data = view
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if capturable else None
         self._gather = None
 
     def zero_grad(self, set_to_none=True):
@@ -66,6 +70,10 @@ class FlatAdam:
     def step(self, grad_scale=1.0):
         g = self._flat_grad()
         if g is None:
+            return
+        if self.capturable:
+            lib().adam_step_counter(self.flat, g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
+                                    self.weight_decay, grad_scale, self.step_dev)
             return
         self.t += 1
         lib().adam_step(self.flat, g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,

@@ -7,6 +7,13 @@ sync instead of three), with more than one rank the gradients are averaged by ON
 all-reduce (mlhot.dist.GradBucket) before the optimizer step, and a data source that can hand out its
 batches before the host-side conversion (`get_batch_u8`: uint8 channel-last images) is read through
 mlhot.ingest.BatchIngest: the next training batch crosses PCIe as uint8 while the current step computes.
+
+`config.graph_steps = True` (off by default; needs an optimizer whose step is capture-safe, e.g.
+mlhot.optim.FlatAdam(capturable=True)) replays every training iteration from a hipGraph: the eager host path of one
+iteration (autograd bookkeeping, ~20 launches, the optimizer) costs about twice the GPU time of the step, the replay a few
+tens of microseconds.  One graph per batch shape (the context size is drawn per iteration, dataset/shapenet_1d.py:120); the
+first iteration of a shape runs eagerly and doubles as the warm-up, the second captures.  The loss is then fetched every
+`config.log_every` iterations only (default 1 = the reference's per-iteration log and finiteness check).
 """
 import math
 import os
@@ -24,6 +31,7 @@ class ModelTrainer(BaseTrainer):
         self.data = data
         self.bucket = GradBucket(model.parameters())
         self.ingest, self._staged = None, None
+        self._graphs, self._static_in, self._side = {}, {}, None       # graph_steps: per batch shape
         if hasattr(data, "get_batch_u8") and torch.device(config.device).type == "cuda" and getattr(config, "ingest_u8", True):
             from mlhot.ingest import BatchIngest
             self.ingest = BatchIngest(config.device)
@@ -69,7 +77,74 @@ class ModelTrainer(BaseTrainer):
         self._staged = stage("train")
         return batch
 
+    # ---- graph-replayed training iterations -------------------------------------------------------------------
+    def _step_body(self, ctx_x, qry_x, ctx_y, qry_y, with_optimizer):
+        self.optimizer.zero_grad()
+        if getattr(self.config, "contrastive", False):
+            pr_mu, pr_var, kl, contra_loss = self.model(ctx_x, ctx_y, qry_x, qry_y)
+        else:
+            pr_mu, pr_var, kl = self.model(ctx_x, ctx_y, qry_x)
+            contra_loss = None
+        losses = self.loss.calc_loss(pr_mu, pr_var, qry_y) + kl * self.config.beta
+        if contra_loss is not None:
+            losses = losses + contra_loss * self.config.contrastive_rate
+        losses.backward()
+        if with_optimizer:
+            self.optimizer.step()
+        return losses.detach()
+
+    def _graph_train_iter(self, it):
+        """One training iteration replayed from a hipGraph (see the module docstring).  Returns the device loss tensor."""
+        if not getattr(self.optimizer, "capturable", False):
+            raise ValueError("config.graph_steps needs a capture-safe optimizer (e.g. mlhot.optim.FlatAdam(capturable=True))")
+        self.model.train()
+        batch = self._batch("train")
+        key = tuple(tuple(t.shape) for t in batch)
+        single = self.bucket.world_size() == 1                       # the all-reduce (and the step behind it) stays outside the graph
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.config.device)
+        static = self._static_in.get(key)
+        if static is None:                                           # fixed input addresses for this shape
+            static = self._static_in[key] = batch if self.ingest is not None else tuple(t.clone() for t in batch)
+        if static[0].data_ptr() != batch[0].data_ptr():
+            for d, t in zip(static, batch):
+                d.copy_(t)
+        entry = self._graphs.get(key)
+        cur = torch.cuda.current_stream(self.config.device)
+        if entry is None:                                            # first time: a real, eager iteration on the capture stream
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                loss = self._step_body(*static, with_optimizer=single)
+            cur.wait_stream(self._side)
+            self._graphs[key] = "warm"
+        else:
+            if entry == "warm":                                      # second time: capture (nothing executes), then replay below
+                graph = torch.cuda.CUDAGraph()
+                self._side.wait_stream(cur)
+                with torch.cuda.graph(graph, stream=self._side):
+                    static_loss = self._step_body(*static, with_optimizer=single)
+                entry = self._graphs[key] = (graph, static_loss)
+            entry[0].replay()
+            loss = entry[1]
+        if not single:
+            self.bucket.sync()
+            self.optimizer.step()
+        return loss
+
     def _train_iter(self, it):
+        if getattr(self.config, "graph_steps", False):
+            loss = self._graph_train_iter(it)
+            every = max(1, int(getattr(self.config, "log_every", 1)))
+            if it % every and it != self.iterations:
+                return None                                          # no host sync on this iteration
+            value = loss.item()
+            if self.writer is not None:
+                self.writer.add_scalar("Loss/train", value, it)
+            self._log(f"Train Iteration {it} loss: {value:.4f}\n")
+            if not math.isfinite(value):
+                self._log(f"Loss is {value}, stopping training")
+                sys.exit(1)
+            return value
         self.model.train()
         self.optimizer.zero_grad()
         ctx_x, qry_x, ctx_y, qry_y = self._batch("train")
