@@ -756,6 +756,25 @@ def test_trainer_contrastive_model(gpulib, tmp_path, monkeypatch):
     assert all(torch.isfinite(v).all() for v in model.state_dict().values())
 
 
+def test_bench_two_rank_control_flow_on_one_gpu(gpulib):
+    """bench.py's N > 1 path (per-rank task shards, hipGraph step, flat gradient all-reduce outside the graph, max-over-ranks timing,
+    one JSON line from rank 0) driven by two gloo ranks sharing this box's only GPU - the RCCL launch itself needs an N-GPU node."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MLHOT_DIST_BACKEND="gloo", MLHOT_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak" and out["hipgraph"] is True
+    assert out["config"]["global_tasks"] == 32 and out["cpu_baseline"] is None
+    assert abs(out["value"] - 32 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
+
+
 def test_cpu_tensors_are_refused(gpulib):
     from mlhot.binding import MlhotError
     from mlhot.ops import LinearFunction
