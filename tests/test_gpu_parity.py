@@ -293,6 +293,35 @@ def test_anpmr_shapenet3d_vs_reference(gpulib):
         U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
 
 
+def test_c5_full_size_forward_vs_oracle(gpulib):
+    """BASELINE config c5 at its per-GPU size (ANPMRShapeNet3D, 8 tasks x (15 + 15) 3x64x64 images: 240 + 120 encoder images,
+    FAVOR+ at d = 256 / m = 1419 over 15 x 15 shots): mu, kl and the quaternion loss against the CPU oracle under the same
+    seeded eps draws.  (Gradients at this size are the routed small-case tests' business: 360 images x ~1e6 ReLU decisions.)"""
+    import types
+    from networks.ANPMRShapeNet3D import ANPMRShapeNet3D
+    from trainer.losses import LossFunc
+    T, Nc, Nq = 8, 15, 15
+    cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[64, 64, 4], tasks_per_batch=T, input_dim=4, output_dim=4,
+                                agg_mode="attention", img_agg="reshape", task="shapenet_3d", temperature=0.07)
+    model = ANPMRShapeNet3D(cfg).to(DEV)
+    g = torch.Generator().manual_seed(1234)
+    cx, qx = torch.rand(T, Nc, 3, 64, 64, generator=g), torch.rand(T, Nq, 3, 64, 64, generator=g)
+    cy = F.normalize(torch.randn(T, Nc, 4, generator=g), dim=-1)
+    qy = F.normalize(torch.randn(T, Nq, 4, generator=g), dim=-1)
+    with torch.no_grad():
+        torch.manual_seed(99)
+        mu, var, kl = model(cx.to(DEV), cy.to(DEV), qx.to(DEV))
+        loss = LossFunc("mse", "shapenet_3d").calc_loss(mu, var, qy.to(DEV))
+        p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        torch.manual_seed(99)
+        mu_o, kl_o = O.anpmr3d_forward(p, cx, cy, qx)
+        loss_o = O.calc_loss("shapenet_3d", mu_o, qy)
+    assert var is None and mu.shape == (T, Nq, 4)
+    assert U.rel_err(mu, mu_o) <= U.RTOL
+    assert abs(kl.item() - kl_o.item()) <= U.RTOL * kl_o.item() and abs(kl_o.item() - 1383162.5) < 4.0      # SURVEY §8c known answer
+    assert abs(loss.item() - loss_o.item()) <= U.RTOL * max(1.0, abs(loss_o.item()))
+
+
 @pytest.mark.parametrize("name", U.fcl_case_names())
 def test_fcl_models_vs_reference(gpulib, name):
     """Functional-contrastive variants (FCLCNPShapeNet1D, FCLCNPDistractor, FCLANP) through the plugin boundary: the 4-tuple
