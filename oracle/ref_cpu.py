@@ -71,20 +71,30 @@ def vanilla_encoder_routed(img, p, m1, arg2, m2, m3, prefix="encoder_w0."):
 # --------------------------------------------------------------------------------------
 
 
-def encoder_fc(x, p, prefix="encoder_r.layers.", n_hidden=2):
-    """EncoderFC: (Linear+ReLU) x n_hidden, then Linear without activation."""
+def _act(v, masks, pre):
+    """ReLU, or (pinned routing) multiplication by the next given {0,1} mask; `pre` receives the pre-activation."""
+    if pre is not None:
+        pre.append(v.detach())
+    return F.relu(v) if masks is None else v * next(masks)
+
+
+def encoder_fc(x, p, prefix="encoder_r.layers.", n_hidden=2, masks=None, pre=None):
+    """EncoderFC: (Linear+ReLU) x n_hidden, then Linear without activation.  `masks` (optional): the n_hidden ReLU
+    decisions, given instead of re-derived (see vanilla_encoder_routed); `pre`: a list receiving the pre-activations."""
     idx = 0
+    masks = iter(masks) if masks is not None else None
     for _ in range(n_hidden):
-        x = F.relu(F.linear(x, p[f"{prefix}{idx}.weight"], p[f"{prefix}{idx}.bias"]))
+        x = _act(F.linear(x, p[f"{prefix}{idx}.weight"], p[f"{prefix}{idx}.bias"]), masks, pre)
         idx += 2
     return F.linear(x, p[f"{prefix}{idx}.weight"], p[f"{prefix}{idx}.bias"])
 
 
-def decoder_mlp(x, p, prefix="decoder0.", tanh=True):
+def decoder_mlp(x, p, prefix="decoder0.", tanh=True, masks=None, pre=None):
     """decoder0: L(128->100) ReLU L(100->100) ReLU L(100->y) [tanh]
-    (ANPShapeNet1D.py:65-72; no tanh in CNPVanillaPascal1D.py:67-73)."""
-    x = F.relu(F.linear(x, p[prefix + "0.weight"], p[prefix + "0.bias"]))
-    x = F.relu(F.linear(x, p[prefix + "2.weight"], p[prefix + "2.bias"]))
+    (ANPShapeNet1D.py:65-72; no tanh in CNPVanillaPascal1D.py:67-73).  `masks` / `pre` as in encoder_fc."""
+    masks = iter(masks) if masks is not None else None
+    x = _act(F.linear(x, p[prefix + "0.weight"], p[prefix + "0.bias"]), masks, pre)
+    x = _act(F.linear(x, p[prefix + "2.weight"], p[prefix + "2.bias"]), masks, pre)
     x = F.linear(x, p[prefix + "4.weight"], p[prefix + "4.bias"])
     return torch.tanh(x) if tanh else x
 
@@ -98,8 +108,11 @@ def agg_mean(rs):
     return rs.mean(dim=1)
 
 
-def agg_max(rs):
-    return rs.max(dim=1)[0]
+def agg_max(rs, amax=None):
+    """max over the shot axis; `amax` [T,R] (optional): the winning shot, given instead of re-derived."""
+    if amax is None:
+        return rs.max(dim=1)[0]
+    return torch.gather(rs, 1, amax.long().unsqueeze(1)).squeeze(1)
 
 
 def agg_baco(mu, var):
@@ -186,21 +199,44 @@ def multihead_attention(k, v, q, p, n_heads=8, taps=None):
 # --------------------------------------------------------------------------------------
 
 
-def vanilla_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, tanh, taps=None):
+def vanilla_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, tanh, taps=None, routes=None, pres=None):
     """CNP/ANP vanilla model forward for Pascal1D / ShapeNet1D
     (CNPShapeNet1D.py:96-140, ANPShapeNet1D.py:118-157, CNPVanillaPascal1D.py:98-142,
-    ANPVanillaPascal1D.py:136-176).  Returns mu [T,Nq,y]."""
+    ANPVanillaPascal1D.py:136-176).  Returns mu [T,Nq,y].
+
+    `routes` (optional, pinned routing - see vanilla_encoder_routed): a dict with the piecewise-linear decisions of a
+    particular evaluation (the HIP kernels'): "enc_qry" / "enc_ctx" = (m1, arg2, m2, m3) of the two image sets, "h" = the
+    EncoderFC ReLU masks, "d" = the two decoder0 ReLU masks, "amax" = the winning shot of the max aggregator.  `pres`
+    (a dict) then receives this function's own pre-activations under the same keys, so that a caller can prove every
+    disagreement to sit on a rounding-level tie."""
     T, Nq = qry_x.shape[:2]
     Nc = ctx_x.shape[1]
     dim_w = p["encoder_w0.8.weight"].shape[0]
     dim_z = p["r_to_z.weight"].shape[0]
-    x_qry = vanilla_encoder(qry_x.reshape(T * Nq, *qry_x.shape[2:]), p).reshape(T, Nq, dim_w)
+    routes = routes or {}
+
+    def enc(x, key):
+        x = x.reshape(-1, *x.shape[2:])
+        if key not in routes:
+            return vanilla_encoder(x, p)
+        f, pre = vanilla_encoder_routed(x, p, *routes[key])
+        if pres is not None:
+            pres[key] = {k_: v.detach() for k_, v in pre.items()}
+        return f
+
+    def pre_list(key):
+        if pres is None:
+            return None
+        pres[key] = []
+        return pres[key]
+
+    x_qry = enc(qry_x, "enc_qry").reshape(T, Nq, dim_w)
     t = {}
     if Nc:
-        x_ctx = vanilla_encoder(ctx_x.reshape(T * Nc, *ctx_x.shape[2:]), p).reshape(T, Nc, dim_w)
+        x_ctx = enc(ctx_x, "enc_ctx").reshape(T, Nc, dim_w)
         ly = F.linear(ctx_y, p["transform_y.weight"], p["transform_y.bias"])
         n_hidden = sum(1 for k_ in p if k_.startswith("encoder_r.layers.") and k_.endswith(".weight")) - 1
-        rs = encoder_fc(torch.cat([x_ctx, ly], dim=2), p, n_hidden=n_hidden)
+        rs = encoder_fc(torch.cat([x_ctx, ly], dim=2), p, n_hidden=n_hidden, masks=routes.get("h"), pre=pre_list("h"))
         if agg_mode == "attention":
             r = multihead_attention(x_ctx, rs, x_qry, p, taps=t)
             z = F.linear(r, p["r_to_z.weight"], p["r_to_z.bias"])
@@ -208,7 +244,9 @@ def vanilla_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, tanh, taps=None):
             if agg_mode == "mean":
                 r = agg_mean(rs)
             elif agg_mode == "max":
-                r = agg_max(rs)
+                r = agg_max(rs, routes.get("amax"))
+                if pres is not None:
+                    pres["rs"] = rs.detach()
             elif agg_mode == "baco":
                 mu = F.linear(rs, p["rs_to_mu.weight"], p["rs_to_mu.bias"])
                 var = 1e-5 + F.softplus(F.linear(rs, p["rs_to_var.weight"], p["rs_to_var.bias"]))
@@ -219,7 +257,7 @@ def vanilla_np_forward(p, ctx_x, ctx_y, qry_x, agg_mode, tanh, taps=None):
         t.update(x_ctx=x_ctx, rs=rs, r=r)
     else:
         z = torch.zeros(T, Nq, dim_z)
-    mu = decoder_mlp(torch.cat([x_qry, z], dim=-1), p, tanh=tanh)
+    mu = decoder_mlp(torch.cat([x_qry, z], dim=-1), p, tanh=tanh, masks=routes.get("d"), pre=pre_list("d"))
     if taps is not None:
         taps.update(t, x_qry=x_qry, z=z)
     return mu
@@ -376,30 +414,46 @@ def anpmr3d_forward(p, ctx_x, ctx_y, qry_x, img_agg="reshape", n_heads=8, routes
     return F.linear(h, p["decoder.fc_mu.4.weight"], p["decoder.fc_mu.4.bias"]), kl
 
 
-def bbb_vanilla_encoder(img, p, prefix="encoder_w0.net."):
+def bbb_vanilla_encoder(img, p, prefix="encoder_w0.net.", route=None, pre=None):
     """MR twin of vanilla_encoder (ANPMR.py:40-53): the same stack with every weight and bias re-sampled
-    (layer1.conv, layer2.conv, layer3.conv, linear; weight then bias).  Returns (features, kl of the call)."""
+    (layer1.conv, layer2.conv, layer3.conv, linear; weight then bias).  Returns (features, kl of the call).
+    `route` = (m1, arg2, m2, m3): pinned routing as in vanilla_encoder_routed; `pre` (a dict) receives the pre-activations."""
     kls, w = [], {}
     for name in ("layer1.conv.", "layer2.conv.", "layer3.conv.", "linear."):
         w[name + "w"], kw = bbb_sample(p[prefix + name + "W_mu"], p[prefix + name + "W_rho"])
         w[name + "b"], kb = bbb_sample(p[prefix + name + "bias_mu"], p[prefix + name + "bias_rho"])
         kls.append(kw + kb)
+    if route is not None:
+        q = {"e.0.weight": w["layer1.conv.w"], "e.0.bias": w["layer1.conv.b"], "e.2.weight": w["layer2.conv.w"],
+             "e.2.bias": w["layer2.conv.b"], "e.5.weight": w["layer3.conv.w"], "e.5.bias": w["layer3.conv.b"],
+             "e.8.weight": w["linear.w"], "e.8.bias": w["linear.b"]}
+        f, pr = vanilla_encoder_routed(img, q, *route, prefix="e.")
+        if pre is not None:
+            pre.update({k_: v.detach() for k_, v in pr.items()})
+        return f, sum(kls)
     a1 = F.relu(F.conv2d(img, w["layer1.conv.w"], w["layer1.conv.b"], stride=2, padding=1))
     a2 = F.relu(F.conv2d(a1, w["layer2.conv.w"], w["layer2.conv.b"], stride=2, padding=1))
     a3 = F.relu(F.conv2d(F.max_pool2d(a2, 2), w["layer3.conv.w"], w["layer3.conv.b"], stride=2, padding=1))
     return F.linear(a3.reshape(a3.shape[0], -1), w["linear.w"], w["linear.b"]), sum(kls)
 
 
-def vanilla_mr_forward(p, ctx_x, ctx_y, qry_x, agg_mode, attention, tanh):
+def vanilla_mr_forward(p, ctx_x, ctx_y, qry_x, agg_mode, attention, tanh, routes=None, pres=None):
     """ANPMR / ANPMRShapeNet1D (attention=True: targets encoded first, ANPMR.py:183-186) and CNPMR /
-    CNPMRShapeNet1D (context first, targets last, CNPMR.py:136-166).  Returns (mu, kl of the target pass)."""
+    CNPMRShapeNet1D (context first, targets last, CNPMR.py:136-166).  Returns (mu, kl of the target pass).
+    `routes` / `pres`: per encoder call, in call order, the pinned routing (m1, arg2, m2, m3) / a list receiving one dict
+    of pre-activations per call."""
     T, Nq = qry_x.shape[:2]
     Nc = ctx_x.shape[1]
     dim_w = p["encoder_w0.net.linear.W_mu"].shape[0]
     dim_z = p["r_to_z.weight"].shape[0]
+    passes = iter(routes) if routes is not None else None
 
     def enc(x, n):
-        f, kl_ = bbb_vanilla_encoder(x.reshape(T * n, *x.shape[2:]), p)
+        pre = None
+        if pres is not None:
+            pre = {}
+            pres.append(pre)
+        f, kl_ = bbb_vanilla_encoder(x.reshape(T * n, *x.shape[2:]), p, route=next(passes) if passes is not None else None, pre=pre)
         return f.reshape(T, n, dim_w), kl_
 
     if attention:

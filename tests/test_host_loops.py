@@ -72,6 +72,11 @@ def test_trainer_cadence_and_files(tmp_path):
     for f in ("models/model_end_4.pt", "models/best_validation_model.pt", "models/best_test_model.pt", "best_validation_error.txt"):
         assert os.path.exists(os.path.join(cfg.save_path, f)), f
     assert not torch.equal(w0, model.lin.weight)
+    # best_<source>_error.txt: the reference's three writes per improvement (trainer/model_trainer.py:135-138), real newlines
+    lines = open(os.path.join(cfg.save_path, "best_validation_error.txt")).read().split("\n")
+    assert lines[0] == "Best Step: 2 " and lines[1] == "Best validation Loss: " and lines[2].startswith("tensor(")
+    assert lines[3] == "Best validation Loss std: " and lines[4].startswith("tensor(") and len(lines) % 5 == 1 and lines[-1] == ""
+    assert tr.best_loss["validation"] < 50000 and tr.best_loss["test"] < 20000        # the reference's initial values were beaten
 
 
 def test_evaluator_sweep_and_files(tmp_path):
@@ -116,3 +121,35 @@ def test_contrastive_models_get_the_target_labels(tmp_path):
     ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=torch.optim.SGD(model.parameters(), lr=1e-2), config=cfg,
                  data=CountingData()).train()
     assert [t for _, t in seen] == [False, False, True, True] and all(s == (2, 5, 3) for s, _ in seen)
+
+
+def test_single_validation_batch_writes_nan_std_like_the_reference(tmp_path):
+    """val_iters = 1: torch.std of one value is nan, which is what the reference writes (trainer/model_trainer.py:124,138)."""
+    from trainer.model_trainer import ModelTrainer
+    model = TinyModel()
+    cfg = _cfg(tmp_path, iterations=1, val_freq=1, val_iters=1)
+    ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=torch.optim.SGD(model.parameters(), lr=1e-2), config=cfg,
+                 data=CountingData()).train()
+    text = open(os.path.join(cfg.save_path, "best_test_error.txt")).read()
+    assert "Best test Loss std: \ntensor(nan)\n" in text and "\\n" not in text
+
+
+def test_grad_bucket_deferred_scale_and_overridable_collective():
+    """GradBucket.sync(defer_scale=True) leaves the summed gradients in place and returns 1/world for the optimizer's gradient
+    scale; the collective itself is one overridable method (here: a stand-in for two identical ranks)."""
+    from mlhot.dist import GradBucket
+
+    class TwoRanks(GradBucket):
+        def world_size(self):
+            return 2
+
+        def _all_reduce(self, flat):
+            flat.mul_(2.0)
+
+    lin = torch.nn.Linear(3, 2)
+    for defer in (False, True):
+        lin.weight.grad, lin.bias.grad = torch.ones(2, 3), torch.full((2,), 3.0)
+        b = TwoRanks(lin.parameters())
+        scale = b.sync(defer_scale=defer)
+        assert scale == (0.5 if defer else 1.0)
+        assert torch.equal(lin.weight.grad * scale, torch.ones(2, 3)) and torch.equal(lin.bias.grad * scale, torch.full((2,), 3.0))

@@ -202,3 +202,84 @@ def test_nt_xent_definition():
                 den = math.exp(s[a][q]) + sum(math.exp(s[a][k]) for k in range(6) if labels[k] != labels[a])
                 terms.append(-math.log(math.exp(s[a][q]) / den))
     assert abs(O.nt_xent(z, labels, 0.1).item() - sum(terms) / len(terms)) <= 1e-5
+
+
+# ---- the pinned-routing forms of the oracle (what the GPU gradient tests compare with) against its plain forms ----------
+@pytest.mark.parametrize("name", ["s_anp_shapenet1d_ragged", "s_cnp_shapenet1d_max", "s_cnp_pascal1d_max"])
+def test_oracle_routed_vanilla_model_equals_plain_under_its_own_routing(name):
+    """vanilla_np_forward(routes=...) fed with the decisions of its own plain evaluation is the same function: same mu, same
+    gradients, zero reported flips - so a difference seen by the GPU tests comes from the routing handed in, not from the restatement."""
+    fx, meta = U.load_case(name)
+    model = U.build_model(meta, fx=fx)
+    cx, qx, cy, qy = U.case_inputs(meta)
+    agg, tanh = meta["cfg"]["agg_mode"], model.OUT_TANH
+    T, Nc, Nq = cx.shape[0], cx.shape[1], qx.shape[1]
+    grads = []
+    for routed in (False, True):
+        p = {k: v.clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+        routes, pres = None, None
+        if routed:
+            routes, pres = {"enc_qry": U.self_routes_vanilla(qx.reshape(-1, *qx.shape[2:]), p)}, {}
+            routes["enc_ctx"] = U.self_routes_vanilla(cx.reshape(-1, *cx.shape[2:]), p)
+            plain = {}
+            with torch.no_grad():
+                O.vanilla_np_forward(p, cx, cy, qx, agg, tanh, pres=plain, routes={})
+            routes["h"] = [(v > 0).float() for v in plain["h"]]
+            routes["d"] = [(v > 0).float() for v in plain["d"]]
+            if agg == "max":
+                routes["amax"] = plain["rs"].argmax(dim=1)
+        mu = O.vanilla_np_forward(p, cx, cy, qx, agg, tanh, routes=routes, pres=pres)
+        O.calc_loss(meta["cfg"]["task"], mu, qy).backward()
+        grads.append((mu.detach(), {k: v.grad for k, v in p.items() if v.grad is not None}))
+        if routed:
+            assert U.encoder_flips(routes["enc_qry"], pres["enc_qry"]) == 0 and U.encoder_flips(routes["enc_ctx"], pres["enc_ctx"]) == 0
+            assert sum(U.relu_flips(m, v) for m, v in zip(routes["h"] + routes["d"], pres["h"] + pres["d"])) == 0
+    assert U.rel_err(grads[1][0], grads[0][0]) <= TIGHT
+    for k, g in grads[0][1].items():
+        assert U.rel_err(grads[1][1][k], g) <= TIGHT, k
+
+
+def test_oracle_routed_mr_and_bbb_models_equal_plain_under_their_own_routing():
+    """Same statement for vanilla_mr_forward / anpmr3d_forward (routes per encoder call, in call order)."""
+    fx, meta = U.load_case("m_anpmr_shapenet1d")
+    model = U.build_model(meta, fx=fx)
+    cx, qx, cy, qy = U.resnet_case_inputs(meta, fx)
+    out = []
+    for routed in (False, True):
+        p = {k: v.clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+        routes, pres = None, None
+        if routed:      # ANPMR encodes the targets first; each call samples its own weights, so its routing needs those samples
+            routes, pres = [], []
+            torch.manual_seed(99)
+            for x in (qx, cx):
+                w = {}
+                for name, key in (("layer1.conv.", "0"), ("layer2.conv.", "2"), ("layer3.conv.", "5"), ("linear.", "8")):
+                    w[f"e.{key}.weight"], _ = O.bbb_sample(p["encoder_w0.net." + name + "W_mu"], p["encoder_w0.net." + name + "W_rho"])
+                    w[f"e.{key}.bias"], _ = O.bbb_sample(p["encoder_w0.net." + name + "bias_mu"], p["encoder_w0.net." + name + "bias_rho"])
+                routes.append(U.self_routes_vanilla(x.reshape(-1, *x.shape[2:]), {k: v.detach() for k, v in w.items()}, prefix="e."))
+        torch.manual_seed(99)
+        mu, kl = O.vanilla_mr_forward(p, cx, cy, qx, meta["cfg"]["agg_mode"], attention=True, tanh=True, routes=routes, pres=pres)
+        (O.calc_loss(meta["cfg"]["task"], mu, qy) + 1e-7 * kl).backward()
+        out.append((mu.detach(), {k: v.grad for k, v in p.items() if v.grad is not None}))
+        if routed:
+            assert sum(U.encoder_flips(r, q) for r, q in zip(routes, pres)) == 0
+    assert U.rel_err(out[1][0], out[0][0]) <= TIGHT
+    for k, g in out[0][1].items():
+        assert U.rel_err(out[1][1][k], g) <= TIGHT, k
+
+    fx, meta = U.load_case("r_anpmr_shapenet3d")
+    model = U.build_model(meta, fx=fx)
+    cx, qx, cy, qy = U.resnet_case_inputs(meta, fx)
+    out, routes = [], None
+    for routed in (False, True):
+        p = {k: v.clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+        pres = []
+        torch.manual_seed(99)
+        mu, kl = O.anpmr3d_forward(p, cx, cy, qx, routes=routes, pres=pres)
+        (O.calc_loss("shapenet_3d", mu, qy) + 1e-7 * kl).backward()
+        out.append((mu.detach(), {k: v.grad for k, v in p.items() if v.grad is not None}))
+        routes = [[(v > 0).float() for v in pre] for pre in pres]
+        assert len(pres) == 3 and all(len(pre) == 9 for pre in pres)
+    assert U.rel_err(out[1][0], out[0][0]) <= TIGHT
+    for k, g in out[0][1].items():
+        assert U.rel_err(out[1][1][k], g) <= TIGHT, k

@@ -137,3 +137,43 @@ def check_grads_against_fixture(grads, fx, meta, tol=RTOL, head=4096, stride_cap
             worst = (e, k)
         assert e <= tol, f"{k}: gradient rel err {e:.3e} > {tol}"
     return worst
+
+
+# ---- pinned routing: the kernels' own ReLU / pool decisions, fed to the oracle; every disagreement with the
+# oracle's own decision must sit on a rounding-level tie of the oracle's pre-activations -----------------------------------
+TIE = 1e-5
+
+
+def relu_flips(mask, pre, what=""):
+    """# of ReLU decisions in `mask` that differ from sign(pre); asserts that each of them is a tie (|pre| <= TIE * max|pre|)."""
+    mask, pre = torch.as_tensor(mask).cpu().reshape(pre.shape), pre.detach()
+    bad = (mask > 0) != (pre > 0)
+    n = int(bad.sum())
+    if n:
+        assert not bool((bad & (pre.abs() > TIE * pre.abs().max())).any()), f"{what}: ReLU routing differs away from a tie"
+    return n
+
+
+def encoder_flips(route, pre, what=""):
+    """Vanilla encoder: route = (m1, arg2, m2, m3) against the pre-activations of oracle.vanilla_encoder_routed."""
+    m1, arg2, m2, m3 = route
+    n = relu_flips(m1, pre["y1"], what + " conv1") + relu_flips(m3, pre["y3"], what + " conv3")
+    win = torch.relu(pre["y2win"].detach())               # the pool runs on the post-ReLU map
+    chosen = torch.gather(win, 4, arg2.long().unsqueeze(-1)).squeeze(-1)
+    gap = win.max(dim=4).values - chosen
+    assert not bool((gap > TIE * win.abs().max()).any()), f"{what}: pool arg-max differs away from a tie"
+    n += int((gap > 0).sum())
+    n += relu_flips(m2, torch.gather(pre["y2win"].detach(), 4, arg2.long().unsqueeze(-1)).squeeze(-1), what + " conv2")
+    return n
+
+
+def self_routes_vanilla(x, p, prefix="encoder_w0."):
+    """The oracle's OWN routing decisions on images x, in the form vanilla_encoder_routed takes them."""
+    from oracle import ref_cpu as O
+    taps = {}
+    with torch.no_grad():
+        O.vanilla_encoder(x, p, prefix=prefix, taps=taps)
+    a2 = taps["a2"]
+    n, c, h, w = a2.shape
+    win = a2.reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+    return (taps["a1"] > 0).float(), win.argmax(dim=4).to(torch.uint8), (taps["p2"] > 0).float(), (taps["a3"] > 0).float()

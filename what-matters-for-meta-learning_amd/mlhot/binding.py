@@ -111,11 +111,14 @@ def _chk(*ts):
 
 
 class MlhotLib:
+    _last = None      # the most recently loaded library (size queries of the static test helpers)
+
     def __init__(self, path):
         if not os.path.exists(path):
             raise MlhotError(f"mlhot: shared library not found: {path} (run __graft_entry__.build())")
         self.path = path
         self.c = C.CDLL(path)
+        MlhotLib._last = self
         c = self.c
         c.mlhot_version.restype = C.c_int
         c.mlhot_last_error.restype = C.c_char_p
@@ -232,6 +235,51 @@ class MlhotLib:
         o = al(o + n * 48 * 256)
         a3 = saved[o:o + n * 4096 * 4].view(torch.float32).view(n, 64, 8, 8)
         return a1, p2, am2, a3
+
+    @staticmethod
+    def enc_routes(saved, n):
+        """Test / diagnostic helper: the piecewise-linear routing decisions the fused encoder forward took, in the form
+        oracle.ref_cpu.vanilla_encoder_routed takes them: (conv1 ReLU mask [n,32,64,64] unpacked from the forward's sign-bit
+        words, pool arg-max [n,48,16,16], pooled-conv2 ReLU mask, conv3 ReLU mask) as CPU tensors."""
+        def al(x):
+            return (x + 255) // 256 * 256
+        _, p2, am2, a3 = MlhotLib.enc_saved_views(saved, n)
+        o = al(n * 32 * 4096 * 4)
+        o = al(o + n * 48 * 256 * 4)
+        o = al(o + n * 48 * 256)
+        o = al(o + n * 4096 * 4)
+        words = saved[o:o + n * 4096 * 4].view(torch.int32).view(n, 64, 64).cpu()
+        bits = torch.arange(32, dtype=torch.int32).view(1, 32, 1, 1)
+        m1 = ((words.unsqueeze(1) >> bits) & 1).float()
+        return m1, am2.cpu(), (p2 > 0).float().cpu(), (a3 > 0).float().cpu()
+
+    @staticmethod
+    def np_saved_views(saved, dims):
+        """Test / diagnostic helper: activations mlhot_np_vanilla_fwd kept (csrc/np_vanilla.h np_saved_carve) as tensor views:
+        the encoder blob (first; see enc_routes) and the task-side layers' post-ReLU outputs."""
+        def al(x):
+            return (x + 255) // 256 * 256
+        Rc, Rq = dims.T * dims.Nc, dims.T * dims.Nq
+        n, dw = Rc + Rq, dims.dim_w
+        lib = MlhotLib._last
+        o = al(lib.c.mlhot_enc_vanilla_saved_bytes(n))
+
+        def take(rows, cols, dtype=torch.float32):
+            nonlocal o
+            v = saved[o:o + rows * cols * 4].view(dtype).view(rows, cols)
+            o = al(o + rows * cols * 4)
+            return v
+        out = {"enc": saved, "n": n}
+        out["dec_in"] = take(Rq, dw + dims.dim_z)
+        out["d1"], out["d2"] = take(Rq, dims.dec_hidden), take(Rq, dims.dec_hidden)
+        if dims.Nc > 0:
+            out["cat_in"] = take(Rc, dw + dw // 4)
+            out["h"] = [take(Rc, dims.hidden[i]) for i in range(dims.n_hidden)]
+            out["rs"] = take(Rc, dims.dim_r)
+            if dims.agg_mode != AGG["attention"]:
+                out["r"], out["zt"] = take(dims.T, dims.dim_r), take(dims.T, dims.dim_z)
+                out["amax"] = take(dims.T, dims.dim_r, torch.int32)
+        return out
 
     def enc_vanilla_bwd(self, img0, img1, params, dim_w, dfeat0, dfeat1, saved):
         n0 = img0.shape[0]

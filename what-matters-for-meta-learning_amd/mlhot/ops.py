@@ -10,6 +10,11 @@ from . import lib
 from .binding import MlhotError
 
 
+# Test / diagnostic hook: when set to a list, the whole-model and encoder bridges append (kind, dims | n_images, saved) for every
+# forward, so that a parity test can read the kernels' own ReLU / pool routing decisions (binding.enc_routes, np_saved_views).
+saved_taps = None
+
+
 def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -31,6 +36,8 @@ class VanillaNPFunction(torch.autograd.Function):
         ctx_x, ctx_y, qry_x = _c(ctx_x.float()), _c(ctx_y.float()), _c(qry_x.float())
         pd = {k: _c(p.detach()) for k, p in zip(keys, params)}
         mu, saved, scratch = L.np_vanilla_fwd(dims, pd, ctx_x, ctx_y, qry_x, proj)
+        if saved_taps is not None:
+            saved_taps.append(("np", dims, saved))
         ctx.dims, ctx.keys, ctx.proj = dims, keys, proj
         ctx.scratch = scratch
         ctx.save_for_backward(ctx_x, ctx_y, qry_x, mu, saved, *[pd[k] for k in keys])
@@ -64,6 +71,8 @@ class EncVanillaFunction(torch.autograd.Function):
         ps = [_c(p.detach()) for p in params]
         dim_w = ps[6].shape[0]
         feat, _, saved = lib().enc_vanilla_fwd(img, None, ps, dim_w)
+        if saved_taps is not None:
+            saved_taps.append(("enc", img.shape[0], saved))
         ctx.dim_w = dim_w
         ctx.save_for_backward(img, saved, *ps)
         return feat

@@ -28,10 +28,14 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out = self.conv2(self.conv1(x))                       # eps order: conv1, conv2, then the skip
+    def forward(self, x, taps=None):
+        mid = self.conv1(x)                                   # eps order: conv1, conv2, then the skip
+        out = self.conv2(mid)
         identity = self.downsample(x) if self.downsample is not None else x
-        return AddReluFunction.apply(out, identity)
+        y = AddReluFunction.apply(out, identity)
+        if taps is not None:
+            taps += [mid, y]
+        return y
 
 
 def conv_block(in_channels, out_channels, **kwargs):
@@ -49,6 +53,7 @@ class BBBEncoder(ModuleWrapper):
             ("layer2", BasicBlock(64, 64, stride=2, **kw)), ("layer3", BasicBlock(64, 64, stride=2, **kw)),
             ("layer4", BasicBlock(64, 64, stride=2, **kw)), ("layer5", BasicBlock(64, 64, stride=2, **kw)),
             ("flatten", FlattenLayer(256))]))
+        self.tap_log = None      # set to a list to record, per call, the post-ReLU activations (tests; as models.ImageEncoder)
 
     def _bbb_layers(self):
         """The BBB convolutions in the order their forwards run (= the reference's eps draw order): stem, then per block
@@ -61,9 +66,16 @@ class BBBEncoder(ModuleWrapper):
 
     def forward(self, x):
         kl = sample_all(self._bbb_layers())          # 26 tensors, one launch pair; each layer picks its sample up below
-        for module in self.children():
-            x = module(x)
-        return x, kl
+        taps = None
+        if self.tap_log is not None:
+            taps = []
+            self.tap_log.append(taps)
+        x = self.net.layer1(x)
+        if taps is not None:
+            taps.append(x)
+        for name in ("layer2", "layer3", "layer4", "layer5"):
+            x = getattr(self.net, name)(x, taps)
+        return self.net.flatten(x), kl
 
 
 class ANPMRShapeNet3D(ResNetNP):

@@ -10,14 +10,17 @@ class BaseTrainer:
         self.optimizer = optimizer
         self.iterations = config.iterations
         self.start_iter = 1
-        self.best_loss = {"validation": float("inf"), "test": float("inf")}
+        self.best_loss = {"validation": 50000, "test": 20000}      # the reference's initial values (base_trainer.py:25)
         self.writer = None
-        try:                                           # TensorBoard is optional (not in the MI355X image)
-            from torch.utils.tensorboard import SummaryWriter
-            self.writer = SummaryWriter(config.save_path)
-        except Exception:                              # noqa: BLE001
-            self.writer = None
-        os.makedirs(os.path.join(config.save_path, "models"), exist_ok=True)
+        import torch.distributed as dist
+        rank0 = not dist.is_initialized() or dist.get_rank() == 0
+        if rank0:
+            try:                                       # TensorBoard is optional (not in the MI355X image)
+                from torch.utils.tensorboard import SummaryWriter
+                self.writer = SummaryWriter(config.save_path)
+            except Exception:                          # noqa: BLE001
+                self.writer = None
+            os.makedirs(os.path.join(config.save_path, "models"), exist_ok=True)
 
     def train(self):
         raise NotImplementedError

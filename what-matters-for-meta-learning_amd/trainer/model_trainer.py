@@ -21,7 +21,7 @@ import sys
 
 import torch
 
-from mlhot.dist import GradBucket
+from mlhot.dist import GradBucket, rank as dist_rank
 from trainer.base_trainer import BaseTrainer
 
 
@@ -29,8 +29,10 @@ class ModelTrainer(BaseTrainer):
     def __init__(self, model, loss, optimizer, config, data):
         super().__init__(model=model, loss=loss, optimizer=optimizer, config=config)
         self.data = data
-        self.bucket = GradBucket(model.parameters())
+        self.bucket = GradBucket(model.parameters(), side_stream=torch.device(config.device).type == "cuda")
         self.ingest, self._staged = None, None
+        self._prefetch = False          # set per iteration by train(): may the NEXT training batch be drawn right away?
+        self.rank0 = dist_rank() == 0   # files / logs / TensorBoard are rank 0's business (every rank holds the same weights)
         self._graphs, self._static_in, self._side = {}, {}, None       # graph_steps: per batch shape
         if hasattr(data, "get_batch_u8") and torch.device(config.device).type == "cuda" and getattr(config, "ingest_u8", True):
             from mlhot.ingest import BatchIngest
@@ -38,15 +40,24 @@ class ModelTrainer(BaseTrainer):
 
     def _log(self, msg):
         logger = getattr(self.config, "logger", None)
-        if logger is not None:
+        if logger is not None and self.rank0:
             logger.info(msg)
 
+    def _save(self, name):
+        if self.rank0:
+            torch.save(self.model.state_dict(), f"{self.config.save_path}/models/{name}")
+
     def train(self):
-        self._log("\\n================== Start training ===================")
+        self._log("\n================== Start training ===================")
         it = self.start_iter
         for it in range(self.start_iter, self.iterations + 1):
             if it % self.config.bg_gen_freq == 0 and self.config.gen_bg:
                 self.data.gen_bg(self.config, data="train")
+            # The reference draws train_k, [validation / test batches of k], [gen_bg(k+1)], train_k+1 - and its loaders may share
+            # one global generator.  Batch k+1 is therefore prefetched (drawn while step k computes) only when nothing else
+            # draws or regenerates between the two; otherwise it is drawn at the top of iteration k+1, in the reference's place.
+            self._prefetch = (it < self.iterations and it % self.config.val_freq != 0
+                              and not ((it + 1) % self.config.bg_gen_freq == 0 and self.config.gen_bg))
             self._train_iter(it)
             if it % self.config.val_freq == 0:
                 self._validate_iter(it, source="validation")
@@ -54,13 +65,14 @@ class ModelTrainer(BaseTrainer):
                     self._validate_iter(it, source="test")
             if it % 1000 == 0:
                 self.save_intermediate_model(it)
-        torch.save(self.model.state_dict(), f"{self.config.save_path}/models/model_end_{it}.pt")
-        self._log("================= Training finished =================\\n")
+        self._save(f"model_end_{it}.pt")
+        self._log(f"models have been saved to {self.config.save_path}")
+        self._log("================= Training finished =================\n")
 
     def _batch(self, source):
         """One device batch of `source`.  With the ingest path the NEXT training batch starts its host -> device copy as
-        soon as the current one is handed out, so it overlaps with the step the caller is about to run; validation / test
-        batches are staged and taken on the spot (the prefetched training batch keeps its place in the draw order)."""
+        soon as the current one is handed out (when train() allows it: see `_prefetch`), so it overlaps with the step the
+        caller is about to run; validation / test batches are staged and taken on the spot."""
         if self.ingest is None:
             ctx_x, qry_x, ctx_y, qry_y = self.data.get_batch(source=source, tasks_per_batch=self.config.tasks_per_batch,
                                                              shot=self.config.max_ctx_num)
@@ -74,7 +86,8 @@ class ModelTrainer(BaseTrainer):
             return self.ingest.take(stage(source))
         ticket, self._staged = (self._staged or stage("train")), None
         batch = self.ingest.take(ticket)
-        self._staged = stage("train")
+        if self._prefetch:
+            self._staged = stage("train")
         return batch
 
     # ---- graph-replayed training iterations -------------------------------------------------------------------
@@ -123,13 +136,26 @@ class ModelTrainer(BaseTrainer):
                 self._side.wait_stream(cur)
                 with torch.cuda.graph(graph, stream=self._side):
                     static_loss = self._step_body(*static, with_optimizer=single)
-                entry = self._graphs[key] = (graph, static_loss)
+                # the gradient tensors THIS graph writes (its private pool): a replay does not rebind p.grad, and another
+                # shape's graph or eager warm-up may have re-pointed it since
+                entry = self._graphs[key] = (graph, static_loss, [p.grad for p in self.bucket.params])
             entry[0].replay()
             loss = entry[1]
+            for p, g in zip(self.bucket.params, entry[2]):
+                p.grad = g
         if not single:
-            self.bucket.sync()
-            self.optimizer.step()
+            self._sync_and_step()
         return loss
+
+    def _sync_and_step(self):
+        """Gradient all-reduce + optimizer step of a multi-rank iteration; the 1/world average rides in the optimizer's
+        gradient scale when it has one (mlhot.optim.FlatAdam), instead of a separate pass over the bucket."""
+        fused = hasattr(self.optimizer, "capturable")               # FlatAdam.step(grad_scale=...)
+        scale = self.bucket.sync(defer_scale=fused)
+        if fused:
+            self.optimizer.step(grad_scale=scale)
+        else:
+            self.optimizer.step()
 
     def _train_iter(self, it):
         if getattr(self.config, "graph_steps", False):
@@ -138,7 +164,7 @@ class ModelTrainer(BaseTrainer):
             if it % every and it != self.iterations:
                 return None                                          # no host sync on this iteration
             value = loss.item()
-            if self.writer is not None:
+            if self.writer is not None and self.rank0:
                 self.writer.add_scalar("Loss/train", value, it)
             self._log(f"Train Iteration {it} loss: {value:.4f}\n")
             if not math.isfinite(value):
@@ -158,12 +184,11 @@ class ModelTrainer(BaseTrainer):
         if contrastive:
             losses = losses + contra_loss * self.config.contrastive_rate
         losses.backward()
-        self.bucket.sync()
-        self.optimizer.step()
+        self._sync_and_step()
         value = losses.item()                                     # the iteration's only host sync
-        if self.writer is not None:
+        if self.writer is not None and self.rank0:
             self.writer.add_scalar("Loss/train", value, it)
-        self._log(f"Train Iteration {it} loss: {value:.4f}\\n")
+        self._log(f"Train Iteration {it} loss: {value:.4f}\n")
         if not math.isfinite(value):
             self._log(f"Loss is {value}, stopping training")
             sys.exit(1)
@@ -185,17 +210,22 @@ class ModelTrainer(BaseTrainer):
                     pr_mu, pr_var, _ = self.model(ctx_x, ctx_y, qry_x, test=True)
                 vals.append(self.loss.calc_loss(pr_mu, pr_var, qry_y, test=True).view(1))
             vals = torch.cat(vals)
-            loss, std = vals.mean(), (vals.std() if vals.numel() > 1 else vals.new_zeros(()))
-            if self.writer is not None:
+            # torch.std of a single value is nan (the reference writes that nan when val_iters == 1)
+            loss, std = vals.mean(), (vals.std() if vals.numel() > 1 else vals.new_full((), float("nan")))
+            if self.writer is not None and self.rank0:
                 self.writer.add_scalar(f"Loss/{source}", loss, it)
             self._log(f"{source} {it} loss: {loss.item():.4f}")
             if loss < self.best_loss[source]:
                 self.best_loss[source] = loss
-                torch.save(self.model.state_dict(), f"{self.config.save_path}/models/best_{source}_model.pt")
-                with open(os.path.join(self.config.save_path, f"best_{source}_error.txt"), "a") as f:
-                    f.write(f"Best Step: {it} \\nBest {source} Loss: \\n{loss}\\nBest {source} Loss std: \\n{std}\\n")
+                self._log(f"save best {source} model epoch : {it}\n")
+                self._save(f"best_{source}_model.pt")
+                if self.rank0:       # the reference's three lines (trainer/model_trainer.py:135-138)
+                    with open(os.path.join(self.config.save_path, f"best_{source}_error.txt"), "a") as f:
+                        f.write(f"Best Step: {it} \n")
+                        f.write(f"Best {source} Loss: \n{str(loss)}\n")
+                        f.write(f"Best {source} Loss std: \n{str(std)}\n")
         return loss.item()
 
     def save_intermediate_model(self, it):
-        torch.save(self.model.state_dict(), f"{self.config.save_path}/models/model_intermediate.pt")
+        self._save("model_intermediate.pt")
         self._log(f"save intermediate model iter: {it}")
