@@ -135,6 +135,28 @@ int mlhot_add_relu_bwd(const float* y, const float* dy, float* g, size_t n, void
 int mlhot_pool2_fwd(const float* x, float* y, uint8_t* amax, int planes, int H, int W, void* stream);
 int mlhot_pool2_bwd(const float* dy, const uint8_t* amax, float* dx, int planes, int H, int W, void* stream);
 
+/* ---- E2 / D2 / B1: whole ResNet trunks in one call -------------------------------------------------------------------
+ * The 5x5 s2 stem (+ReLU) and the four BN-free BasicBlocks {conv3x3 s2 + ReLU; conv3x3 s1; skip conv (1x1 s2 in ImageEncoder /
+ * NPDecoder, networks/ResNet.py:32-34,58-74; 3x3 s2 p1 in the Bayes-by-backprop twin, networks/ANPMRShapeNet3D.py:48-51,85);
+ * add; ReLU} of networks/models.py:63-117,156-182 - for EVERY pass of a model step at once (context images, target images,
+ * decoder images; each pass names its weight set, passes may share one).  Weight-stationary fp32-MFMA kernels (csrc/resnet_ws.h);
+ * supported inputs: 3 x 64 x 64 (ShapeNet3D) and 1 x 128 x 128 (Distractor), MLHOT_ERR_UNSUPPORTED otherwise (callers then
+ * compose mlhot_conv2d_* instead).
+ *   w / b [13]: stem, then (conv1, conv2, skip) of blocks 1..4, in the reference's own layouts [Cout][Cin][k][k] / [Cout];
+ *   act [9]   : saved activations, written by the forward, read by the backward: a0 = stem output, then (mid_i, y_i) of the
+ *               blocks (post-ReLU); act[8] is the trunk's output map [n][64][H/32][H/32];
+ *   dfeat     : backward: gradient wrt act[8];  dw / db: gradients (overwritten; summed over the passes that share the set).  */
+#define MLHOT_TRUNK_MAX_PASS 6
+#define MLHOT_TRUNK_MAX_WSET 4
+typedef struct mlhot_trunk_wset { const float* w[13]; const float* b[13]; float* dw[13]; float* db[13]; int skip_k; } mlhot_trunk_wset;
+typedef struct mlhot_trunk_pass { const float* img; int n_img; int wset; float* act[9]; const float* dfeat; } mlhot_trunk_pass;
+size_t mlhot_trunk_act_floats(int C, int H, int n_img, int k);
+size_t mlhot_trunk_scratch_bytes(const mlhot_trunk_pass* passes, int n_pass, const mlhot_trunk_wset* wsets, int n_wset, int C, int H, int backward);
+int mlhot_trunk_fwd(const mlhot_trunk_pass* passes, int n_pass, const mlhot_trunk_wset* wsets, int n_wset, int C, int H,
+                    void* scratch, size_t scratch_bytes, void* stream);
+int mlhot_trunk_bwd(const mlhot_trunk_pass* passes, int n_pass, const mlhot_trunk_wset* wsets, int n_wset, int C, int H,
+                    void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- B1: Bayes-by-backprop weight sample + KL (bbb/BBBConv.py:86-108, bbb/BBBLinear.py:79-101) ----
  * w = mu + eps * log1p(exp(rho)); kl = sum 0.5*(2 log(sigma/0.1) - 1 + (0.1/sigma)^2 + (mu/sigma)^2).
  * eps is drawn by the caller on the torch CPU generator (parity with BBBConv.py:88). klterm: n floats. */
@@ -145,13 +167,17 @@ int mlhot_bbb_sample_bwd(const float* mu, const float* rho, const float* eps, co
 /* The same for up to MLHOT_BBB_MAX_ITEMS tensors in one launch pair (a Bayes-by-backprop encoder samples every layer's weight
  * and bias once per forward: 26 tensors for ANPMRShapeNet3D.py:40-90): w_i = mu_i + eps_i * softplus(rho_i) for every item,
  * kl = the sum of ALL items' KL terms.  `partial`: mlhot_bbb_sample_multi_scratch_floats() floats of scratch.  Backward: items
- * carry dw (may be NULL: no gradient reached that sample), dmu, drho (overwritten); dkl as above. */
+ * carry dw (may be NULL: no gradient reached that sample), dmu, drho (overwritten); dkl as above.
+ * An item may carry a SECOND independent sample of the same posterior (eps2 -> w2; backward dw2): the model encodes the context
+ * and the target images with two samples per step (ANPMRShapeNet3D.py:198-199); both come out of one launch, the KL (which does
+ * not depend on eps) is computed once, and the backward adds both samples' contributions into dmu / drho in one pass. */
 #define MLHOT_BBB_MAX_ITEMS 32
 typedef struct {
   const float* mu; const float* rho; const float* eps;
   float* w;                       /* forward output */
   const float* dw; float* dmu; float* drho;   /* backward */
   size_t n;
+  const float* eps2; float* w2; const float* dw2;   /* optional second sample (all NULL when unused) */
 } mlhot_bbb_item;
 size_t mlhot_bbb_sample_multi_scratch_floats(const mlhot_bbb_item* items, int n_items);
 int mlhot_bbb_sample_multi_fwd(const mlhot_bbb_item* items, int n_items, float* partial, float* kl, void* stream);

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void bbb_sample_multi_kernel(const BbbMulti m,
     if (e < it.n) {
       const float sg = log1pf(expf(it.rho[e]));
       it.w[e] = it.mu[e] + it.eps[e] * sg;
+      if (it.eps2 != nullptr) it.w2[e] = it.mu[e] + it.eps2[e] * sg;      // second, independent sample of the same posterior
       const float q = 0.1f / sg, z = it.mu[e] / sg;
       acc += 0.5f * (2.f * logf(sg / 0.1f) - 1.f + q * q + z * z);
     }
@@ -73,8 +74,10 @@ __global__ __launch_bounds__(256) void bbb_sample_multi_bwd_kernel(const BbbMult
     if (e < it.n) {
       const float sg = log1pf(expf(it.rho[e])), inv = 1.f / sg, mu = it.mu[e];
       const float dwe = it.dw != nullptr ? it.dw[e] : 0.f;          // a sample whose weight got no gradient (KL-only backward)
-      it.dmu[e] = dwe + g * mu * inv * inv;
-      const float dsig = dwe * it.eps[e] + g * (inv - 0.01f * inv * inv * inv - mu * mu * inv * inv * inv);
+      const float dw2 = (it.eps2 != nullptr && it.dw2 != nullptr) ? it.dw2[e] : 0.f;
+      it.dmu[e] = dwe + dw2 + g * mu * inv * inv;
+      float dsig = dwe * it.eps[e] + g * (inv - 0.01f * inv * inv * inv - mu * mu * inv * inv * inv);
+      if (it.eps2 != nullptr) dsig += dw2 * it.eps2[e];
       it.drho[e] = dsig / (1.f + expf(-it.rho[e]));
     }
   }
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void bbb_sample_multi_bwd_kernel(const BbbMult
 inline int bbb_sample_multi_fwd(const mlhot_bbb_item* items, int n_items, float* partial, float* kl, hipStream_t s) {
   BbbMulti m;
   MLHOT_TRY(bbb_multi_plan(items, n_items, m));
-  for (int i = 0; i < n_items; ++i) if (!items[i].w) { set_error("bbb_sample_multi_fwd: null output"); return MLHOT_ERR_ARG; }
+  for (int i = 0; i < n_items; ++i) if (!items[i].w || (items[i].eps2 && !items[i].w2)) { set_error("bbb_sample_multi_fwd: null output"); return MLHOT_ERR_ARG; }
   const int blocks = m.first[m.n];
 #ifdef MLHOT_HOSTSIM
   (void)s; (void)partial;
@@ -94,6 +97,7 @@ inline int bbb_sample_multi_fwd(const mlhot_bbb_item* items, int n_items, float*
     for (size_t e = 0; e < it.n; ++e) {
       const float sg = log1pf(expf(it.rho[e]));
       it.w[e] = it.mu[e] + it.eps[e] * sg;
+      if (it.eps2) it.w2[e] = it.mu[e] + it.eps2[e] * sg;
       const float q = 0.1f / sg, z = it.mu[e] / sg;
       tot += 0.5f * (2.f * logf(sg / 0.1f) - 1.f + q * q + z * z);
     }
@@ -121,9 +125,9 @@ inline int bbb_sample_multi_bwd(const mlhot_bbb_item* items, int n_items, const 
     const mlhot_bbb_item& it = items[i];
     for (size_t e = 0; e < it.n; ++e) {
       const float sg = log1pf(expf(it.rho[e])), inv = 1.f / sg, mu = it.mu[e], g = dkl[0];
-      const float dwe = it.dw ? it.dw[e] : 0.f;
-      it.dmu[e] = dwe + g * mu * inv * inv;
-      it.drho[e] = (dwe * it.eps[e] + g * (inv - 0.01f * inv * inv * inv - mu * mu * inv * inv * inv)) / (1.f + expf(-it.rho[e]));
+      const float dwe = it.dw ? it.dw[e] : 0.f, dw2 = (it.eps2 && it.dw2) ? it.dw2[e] : 0.f;
+      it.dmu[e] = dwe + dw2 + g * mu * inv * inv;
+      it.drho[e] = (dwe * it.eps[e] + (it.eps2 ? dw2 * it.eps2[e] : 0.f) + g * (inv - 0.01f * inv * inv * inv - mu * mu * inv * inv * inv)) / (1.f + expf(-it.rho[e]));
     }
   }
   return MLHOT_OK;

@@ -13,6 +13,7 @@
 #include "conv_rt.h"
 #include "ingest.h"
 #include "bbb_multi.h"
+#include "resnet_trunk.h"
 #include "../../include/mlhot.h"
 
 namespace mlhot {
@@ -232,6 +233,42 @@ int mlhot_bbb_sample_multi_fwd(const mlhot_bbb_item* items, int n_items, float* 
 int mlhot_bbb_sample_multi_bwd(const mlhot_bbb_item* items, int n_items, const float* dkl, void* stream) {
   if (!items || !dkl) { set_error("bbb_sample_multi_bwd: bad argument"); return MLHOT_ERR_ARG; }
   return bbb_sample_multi_bwd(items, n_items, dkl, (hipStream_t)stream);
+}
+
+// ---- whole ResNet trunks (weight-stationary kernels, csrc/resnet_ws.h / resnet_trunk.h) --------------------------------
+size_t mlhot_trunk_act_floats(int C, int H, int n_img, int k) {
+#ifndef MLHOT_HOSTSIM
+  if (k < 0 || k > 8 || n_img < 0) return 0;
+  return rt::act_floats(rt::trunk_levels(C, H), n_img, k);
+#else
+  (void)C; (void)H; (void)n_img; (void)k; return 0;
+#endif
+}
+size_t mlhot_trunk_scratch_bytes(const mlhot_trunk_pass* passes, int n_pass, const mlhot_trunk_wset* wsets, int n_wset, int C, int H, int backward) {
+#ifndef MLHOT_HOSTSIM
+  if (rt::trunk_check(passes, n_pass, wsets, n_wset, C, H)) return 0;
+  return rt::trunk_carve(passes, n_pass, wsets, n_wset, rt::trunk_levels(C, H), backward != 0, nullptr, 0).bytes;
+#else
+  (void)passes; (void)n_pass; (void)wsets; (void)n_wset; (void)C; (void)H; (void)backward; return 0;
+#endif
+}
+int mlhot_trunk_fwd(const mlhot_trunk_pass* passes, int n_pass, const mlhot_trunk_wset* wsets, int n_wset, int C, int H, void* scratch,
+                    size_t scratch_bytes, void* stream) {
+#ifndef MLHOT_HOSTSIM
+  return rt::trunk_forward(passes, n_pass, wsets, n_wset, C, H, scratch, scratch_bytes, (hipStream_t)stream);
+#else
+  (void)passes; (void)n_pass; (void)wsets; (void)n_wset; (void)C; (void)H; (void)scratch; (void)scratch_bytes; (void)stream;
+  set_error("resnet trunk: GPU build only"); return MLHOT_ERR_UNSUPPORTED;
+#endif
+}
+int mlhot_trunk_bwd(const mlhot_trunk_pass* passes, int n_pass, const mlhot_trunk_wset* wsets, int n_wset, int C, int H, void* scratch,
+                    size_t scratch_bytes, void* stream) {
+#ifndef MLHOT_HOSTSIM
+  return rt::trunk_backward(passes, n_pass, wsets, n_wset, C, H, scratch, scratch_bytes, (hipStream_t)stream);
+#else
+  (void)passes; (void)n_pass; (void)wsets; (void)n_wset; (void)C; (void)H; (void)scratch; (void)scratch_bytes; (void)stream;
+  set_error("resnet trunk: GPU build only"); return MLHOT_ERR_UNSUPPORTED;
+#endif
 }
 
 // ---- batch ingest: uint8 channel-last images -> fp32 channel-first, divided by `div` -----------------------

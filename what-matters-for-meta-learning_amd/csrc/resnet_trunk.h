@@ -1,0 +1,278 @@
+// Host orchestration of the ResNet trunks (5x5 s2 stem + four BN-free BasicBlocks; networks/models.py:63-192,
+// networks/ResNet.py:58-74, BBB twin networks/ANPMRShapeNet3D.py:40-90) on the weight-stationary kernels of resnet_ws.h.
+// ONE call runs every pass of a model step (context images, target images, decoder images ...), each pass with its weight set:
+//   forward  : prep (lane-native weight images) -> stem -> per block {conv1 3x3 s2 + ReLU [+ fused 1x1 s2 skip | + 3x3 s2 skip
+//              as a second job of the same launch]} -> {conv2 3x3 s1 + skip + ReLU}                       (14 launches for c5)
+//   backward : prep -> ReLU mask of the incoming gradient -> per block {conv2 data gradient (+ mask), conv2 weight gradient,
+//              conv1 / skip data gradient (stride-2 classes, join + mask fused), conv1 / skip weight gradient} -> stem weight
+//              gradient -> ONE fold of all weight-gradient slabs.  Passes that share a weight set (the deterministic encoder over
+//              context and target images) write into the same slab rows' segment, so their gradients come out already summed.
+// Everything lives in caller-owned buffers: `act` (saved activations per pass) and one scratch arena per call.
+#pragma once
+#include "common.h"
+#include "foreach.h"
+#include "favor.h"          // MLHOT_TRY
+#include "resnet_ws.h"
+#include "../../include/mlhot.h"
+
+namespace mlhot {
+#ifndef MLHOT_HOSTSIM
+namespace rt {
+
+constexpr int NCONV = 13;           // stem, then (conv1, conv2, skip) of the four blocks
+
+struct Levels { int C, H, L[5]; };  // L[0] = stem output size, L[i] = output size of block i
+inline Levels trunk_levels(int C, int H) { Levels v{C, H, {H / 2, H / 4, H / 8, H / 16, H / 32}}; return v; }
+inline bool trunk_supported(int C, int H) { return rw::stem_supported(C, H); }      // (3, 64) and (1, 128): every block geometry below them is instantiated
+inline size_t act_floats(const Levels& lv, int n, int k) {      // k: 0 = a0, 2i-1 = mid_i, 2i = y_i
+  const int l = k == 0 ? lv.L[0] : lv.L[(k + 1) / 2];
+  return (size_t)n * 64 * l * l;
+}
+
+struct MaskJob { const float* g; const float* y; float* out; size_t n; };
+struct MaskJobs { MaskJob j[MLHOT_TRUNK_MAX_PASS]; int n; size_t first[MLHOT_TRUNK_MAX_PASS + 1]; };
+__global__ __launch_bounds__(256) void mask_kernel(const MaskJobs jobs) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < jobs.first[jobs.n]; i += (size_t)gridDim.x * 256) {
+    int k = 0;
+    while (k + 1 < jobs.n && i >= jobs.first[k + 1]) ++k;
+    const size_t e = i - jobs.first[k];
+    jobs.j[k].out[e] = jobs.j[k].y[e] > 0.f ? jobs.j[k].g[e] : 0.f;
+  }
+}
+
+struct TrunkScratch {
+  float* wimg[MLHOT_TRUNK_MAX_WSET][NCONV];       // F images (forward) / D images (backward; stem: unused)
+  float* idn[MLHOT_TRUNK_MAX_PASS];               // forward: skip-path output of the current block
+  float* G[MLHOT_TRUNK_MAX_PASS][5];              // backward: masked gradient wrt a0 / y_1..y_4
+  float* DM[MLHOT_TRUNK_MAX_PASS];                // backward: masked gradient wrt mid_i of the current block
+  float* slab[MLHOT_TRUNK_MAX_WSET][NCONV]; float* slab_b[MLHOT_TRUNK_MAX_WSET][NCONV]; int rows[MLHOT_TRUNK_MAX_WSET][NCONV];
+  bool ok; size_t bytes;
+};
+
+// slab rows (position splits) of one weight-gradient job: the launch aims at ~128 rows (x 4 channel tiles = 512 workgroups)
+// over all its jobs, a row covers at least one band
+inline int wg_rows(int bands, int total_bands, int target = 128) {
+  int nz = total_bands <= target ? bands : (int)((long)target * bands / total_bands);
+  if (nz < 1) nz = 1;
+  if (nz > bands) nz = bands;
+  return nz;
+}
+inline int conv_hin(const Levels& lv, int conv) {        // input size of conv index 1..12: (c1, c2, sk) of block b = (conv - 1) / 3 + 1
+  const int b = (conv - 1) / 3 + 1, r = (conv - 1) % 3;
+  return r == 1 ? lv.L[b] : lv.L[b - 1];
+}
+inline int conv_stride(int conv) { return (conv - 1) % 3 == 1 ? 1 : 2; }
+
+inline TrunkScratch trunk_carve(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk_wset* ws, int n_wset, const Levels& lv, bool backward,
+                                void* base, size_t cap) {
+  Arena a(base, cap);
+  TrunkScratch s{};
+  for (int w = 0; w < n_wset; ++w) {
+    s.wimg[w][0] = a.take<float>((size_t)4 * ((25 * lv.C + 3) / 4) * 64);
+    for (int c = 1; c < NCONV; ++c) s.wimg[w][c] = a.take<float>((c % 3 == 0 && ws[w].skip_k == 1) ? rw::WIMG1 : rw::WIMG);
+  }
+  for (int p = 0; p < n_pass; ++p) {
+    if (!backward) { s.idn[p] = a.take<float>(act_floats(lv, ps[p].n_img, 2)); continue; }
+    for (int l = 0; l < 5; ++l) s.G[p][l] = a.take<float>(act_floats(lv, ps[p].n_img, 2 * l));
+    s.DM[p] = a.take<float>(act_floats(lv, ps[p].n_img, 1));
+  }
+  if (backward) {
+    // slab rows per (weight set, conv): the sum over the passes that use the set
+    for (int c = 0; c < NCONV; ++c) {
+      int bands[MLHOT_TRUNK_MAX_PASS], total = 0;
+      for (int p = 0; p < n_pass; ++p) {
+        bands[p] = c == 0 ? ps[p].n_img * (lv.L[0] * lv.L[0] / 256) : rw::wgrad_bands_rt(conv_hin(lv, c), conv_stride(c), ps[p].n_img);
+        total += bands[p];
+      }
+      for (int w = 0; w < n_wset; ++w) s.rows[w][c] = 0;
+      for (int p = 0; p < n_pass; ++p) s.rows[ps[p].wset][c] += c == 0 ? wg_rows(bands[p], total, 512) : wg_rows(bands[p], total);
+      for (int w = 0; w < n_wset; ++w) {
+        const size_t rowlen = c == 0 ? (size_t)rw::stem_slab_row(lv.C) : ((c % 3 == 0 && ws[w].skip_k == 1) ? rw::SLAB1 : rw::SLAB3);
+        s.slab[w][c] = a.take<float>(rowlen * (s.rows[w][c] > 0 ? s.rows[w][c] : 1));
+        s.slab_b[w][c] = a.take<float>((size_t)64 * (s.rows[w][c] > 0 ? s.rows[w][c] : 1));
+      }
+    }
+  }
+  s.ok = a.ok; s.bytes = a.off + 256;
+  return s;
+}
+
+inline int trunk_check(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk_wset* ws, int n_wset, int C, int H) {
+  if (!ps || !ws || n_pass < 1 || n_pass > MLHOT_TRUNK_MAX_PASS || n_wset < 1 || n_wset > MLHOT_TRUNK_MAX_WSET) { set_error("resnet trunk: bad pass / weight-set count"); return MLHOT_ERR_ARG; }
+  if (!trunk_supported(C, H)) { set_error("resnet trunk: no kernels for %d-channel %dx%d images", C, H, H); return MLHOT_ERR_UNSUPPORTED; }
+  for (int p = 0; p < n_pass; ++p)
+    if (ps[p].n_img < 1 || ps[p].wset < 0 || ps[p].wset >= n_wset || !ps[p].img) { set_error("resnet trunk: bad pass %d", p); return MLHOT_ERR_ARG; }
+  for (int w = 0; w < n_wset; ++w)
+    if (ws[w].skip_k != 1 && ws[w].skip_k != 3) { set_error("resnet trunk: skip kernel must be 1 or 3"); return MLHOT_ERR_ARG; }
+  return MLHOT_OK;
+}
+
+inline int trunk_prep(const mlhot_trunk_wset* ws, int n_wset, const Levels& lv, const TrunkScratch& sc, bool d_images, hipStream_t s) {
+  rw::PrepItems items{};
+  for (int w = 0; w < n_wset; ++w) {
+    if (!d_images) items.it[items.n++] = rw::PrepItem{ws[w].w[0], sc.wimg[w][0], nullptr, 2, 25 * lv.C};
+    for (int c = 1; c < NCONV; ++c) {
+      const int kind = (c % 3 == 0 && ws[w].skip_k == 1) ? 1 : 0;
+      items.it[items.n++] = d_images ? rw::PrepItem{ws[w].w[c], nullptr, sc.wimg[w][c], kind, 0} : rw::PrepItem{ws[w].w[c], sc.wimg[w][c], nullptr, kind, 0};
+    }
+  }
+  {
+    ProfScope ps("trunk.prep", s);
+    hipLaunchKernelGGL(rw::prep_kernel, dim3(16, items.n), dim3(256), 0, s, items);
+  }
+  return check_launch("trunk.prep");
+}
+
+inline int trunk_forward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk_wset* ws, int n_wset, int C, int H, void* scratch,
+                         size_t scratch_bytes, hipStream_t s) {
+  MLHOT_TRY(trunk_check(ps, n_pass, ws, n_wset, C, H));
+  const Levels lv = trunk_levels(C, H);
+  const TrunkScratch sc = trunk_carve(ps, n_pass, ws, n_wset, lv, false, scratch, scratch_bytes);
+  if (!sc.ok) { set_error("resnet trunk fwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
+  MLHOT_TRY(trunk_prep(ws, n_wset, lv, sc, false, s));
+  {
+    rw::StemJobs jobs{};
+    for (int p = 0; p < n_pass; ++p) jobs.j[jobs.n++] = rw::StemJob{ps[p].img, sc.wimg[ps[p].wset][0], ws[ps[p].wset].b[0], ps[p].act[0], ps[p].n_img, 0, 0};
+    MLHOT_TRY(rw::stem_dispatch(C, H, jobs, s, "trunk.stem"));
+  }
+  for (int b = 1; b <= 4; ++b) {
+    const int c1 = 3 * b - 2, c2 = c1 + 1, sk = c1 + 2;
+    // stage A: conv1 (+ReLU) and the skip convolution, both on the block input
+    for (int variant = 0; variant < 2; ++variant) {      // 0: 3x3 skip as a second job; 1: 1x1 skip fused into conv1's kernel
+      rw::FwdJobs jobs{};
+      for (int p = 0; p < n_pass; ++p) {
+        const mlhot_trunk_wset& w = ws[ps[p].wset];
+        if ((w.skip_k == 1) != (variant == 1)) continue;
+        const float* x = ps[p].act[2 * b - 2];
+        if (variant == 1) {
+          jobs.j[jobs.n++] = rw::FwdJob{x, sc.wimg[ps[p].wset][c1], w.b[c1], ps[p].act[2 * b - 1], nullptr, sc.wimg[ps[p].wset][sk], w.b[sk], sc.idn[p],
+                                        ps[p].n_img, rw::EPI_BIAS_RELU, 0, 0, 0};
+        } else {
+          if (jobs.n + 2 > rw::MAX_JOBS) {
+            MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, false, jobs, s, "trunk.conv1"));
+            jobs.n = 0;
+          }
+          jobs.j[jobs.n++] = rw::FwdJob{x, sc.wimg[ps[p].wset][c1], w.b[c1], ps[p].act[2 * b - 1], nullptr, nullptr, nullptr, nullptr, ps[p].n_img,
+                                        rw::EPI_BIAS_RELU, 0, 0, 0};
+          jobs.j[jobs.n++] = rw::FwdJob{x, sc.wimg[ps[p].wset][sk], w.b[sk], sc.idn[p], nullptr, nullptr, nullptr, nullptr, ps[p].n_img, rw::EPI_BIAS, 0, 0, 0};
+        }
+      }
+      MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, variant == 1, jobs, s, "trunk.conv1"));
+    }
+    // stage B: conv2 + skip + ReLU
+    rw::FwdJobs jobs{};
+    for (int p = 0; p < n_pass; ++p)
+      jobs.j[jobs.n++] = rw::FwdJob{ps[p].act[2 * b - 1], sc.wimg[ps[p].wset][c2], ws[ps[p].wset].b[c2], ps[p].act[2 * b], sc.idn[p], nullptr, nullptr, nullptr,
+                                    ps[p].n_img, rw::EPI_BIAS_RES_RELU, 0, 0, 0};
+    MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b], 1, false, jobs, s, "trunk.conv2"));
+  }
+  return MLHOT_OK;
+}
+
+inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk_wset* ws, int n_wset, int C, int H, void* scratch,
+                          size_t scratch_bytes, hipStream_t s) {
+  MLHOT_TRY(trunk_check(ps, n_pass, ws, n_wset, C, H));
+  const Levels lv = trunk_levels(C, H);
+  TrunkScratch sc = trunk_carve(ps, n_pass, ws, n_wset, lv, true, scratch, scratch_bytes);
+  if (!sc.ok) { set_error("resnet trunk bwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
+  for (int p = 0; p < n_pass; ++p) if (!ps[p].dfeat) { set_error("resnet trunk bwd: pass %d has no output gradient", p); return MLHOT_ERR_ARG; }
+  MLHOT_TRY(trunk_prep(ws, n_wset, lv, sc, true, s));
+  {
+    MaskJobs mj{};
+    for (int p = 0; p < n_pass; ++p) {
+      mj.j[p] = MaskJob{ps[p].dfeat, ps[p].act[8], sc.G[p][4], act_floats(lv, ps[p].n_img, 8)};
+      mj.first[p + 1] = mj.first[p] + mj.j[p].n;
+    }
+    mj.n = n_pass;
+    size_t blocks = (mj.first[n_pass] + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    ProfScope pr("trunk.bwd.mask", s);
+    hipLaunchKernelGGL(mask_kernel, dim3((unsigned)blocks), dim3(256), 0, s, mj);
+    MLHOT_TRY(check_launch("trunk.bwd.mask"));
+  }
+  int next_row[MLHOT_TRUNK_MAX_WSET][NCONV] = {};
+  // one weight-gradient launch over `which` convs' jobs (same geometry): returns through `jobs`
+  auto wg_jobs = [&](int conv, bool tap1, bool want_tap1, rw::WgJobs& jobs, const float* const* xs, const float* const* dys) {
+    int bands[MLHOT_TRUNK_MAX_PASS], total = 0;
+    for (int p = 0; p < n_pass; ++p) { bands[p] = rw::wgrad_bands_rt(conv_hin(lv, conv), conv_stride(conv), ps[p].n_img); total += bands[p]; }
+    for (int p = 0; p < n_pass; ++p) {
+      const int w = ps[p].wset;
+      if (conv % 3 == 0 && ((ws[w].skip_k == 1) != want_tap1)) continue;
+      (void)tap1;
+      const int nz = wg_rows(bands[p], total);
+      jobs.j[jobs.n++] = rw::WgJob{xs[p], dys[p], sc.slab[w][conv], sc.slab_b[w][conv], ps[p].n_img, next_row[w][conv], nz, 0};
+      next_row[w][conv] += nz;
+    }
+  };
+  for (int b = 4; b >= 1; --b) {
+    const int c1 = 3 * b - 2, c2 = c1 + 1, sk = c1 + 2;
+    const float *xin[MLHOT_TRUNK_MAX_PASS], *mid[MLHOT_TRUNK_MAX_PASS], *g[MLHOT_TRUNK_MAX_PASS], *dm[MLHOT_TRUNK_MAX_PASS];
+    for (int p = 0; p < n_pass; ++p) { xin[p] = ps[p].act[2 * b - 2]; mid[p] = ps[p].act[2 * b - 1]; g[p] = sc.G[p][b]; dm[p] = sc.DM[p]; }
+    {   // conv2 data gradient: d_mid = conv^T(g, W2) * (mid > 0)
+      rw::FwdJobs jobs{};
+      for (int p = 0; p < n_pass; ++p)
+        jobs.j[jobs.n++] = rw::FwdJob{g[p], sc.wimg[ps[p].wset][c2], nullptr, sc.DM[p], mid[p], nullptr, nullptr, nullptr, ps[p].n_img, rw::EPI_MASK, 1, 0, 0};
+      MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b], 1, false, jobs, s, "trunk.bwd.conv2.dgrad"));
+    }
+    {   // conv2 weight gradient
+      rw::WgJobs jobs{};
+      wg_jobs(c2, false, false, jobs, mid, g);
+      MLHOT_TRY(rw::wgrad_dispatch(lv.L[b], 1, false, jobs, s, "trunk.bwd.conv2.wgrad"));
+    }
+    // data gradient into the block input (not needed for images: block 1's input is the stem output, whose gradient feeds the stem's wgrad)
+    {
+      rw::DgJobs j1{}, j3a{}, j3b{};
+      for (int p = 0; p < n_pass; ++p) {
+        const int w = ps[p].wset;
+        if (ws[w].skip_k == 1) j1.j[j1.n++] = rw::DgJob{dm[p], sc.wimg[w][c1], sc.G[p][b - 1], xin[p], g[p], sc.wimg[w][sk], ps[p].n_img, 0, 0, 0};
+        else {
+          j3a.j[j3a.n++] = rw::DgJob{g[p], sc.wimg[w][sk], sc.G[p][b - 1], nullptr, nullptr, nullptr, ps[p].n_img, 0, 0, 0};
+          j3b.j[j3b.n++] = rw::DgJob{dm[p], sc.wimg[w][c1], sc.G[p][b - 1], xin[p], nullptr, nullptr, ps[p].n_img, 1, 0, 0};
+        }
+      }
+      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], true, j1, s, "trunk.bwd.conv1.dgrad"));
+      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], false, j3a, s, "trunk.bwd.skip.dgrad"));
+      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], false, j3b, s, "trunk.bwd.conv1.dgrad"));
+    }
+    {   // conv1 and 3x3-skip weight gradients (same input, same geometry: one launch); 1x1 skips on their own
+      rw::WgJobs jobs{}, jobs1{};
+      wg_jobs(c1, false, false, jobs, xin, dm);
+      if (jobs.n + n_pass > rw::MAX_JOBS) { MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, "trunk.bwd.conv1.wgrad")); jobs.n = 0; }
+      wg_jobs(sk, false, false, jobs, xin, g);
+      MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, "trunk.bwd.conv1.wgrad"));
+      wg_jobs(sk, true, true, jobs1, xin, g);
+      MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, true, jobs1, s, "trunk.bwd.skip1.wgrad"));
+    }
+  }
+  {   // stem weight gradient
+    rw::StemWgJobs jobs{};
+    int bands[MLHOT_TRUNK_MAX_PASS], total = 0;
+    for (int p = 0; p < n_pass; ++p) { bands[p] = ps[p].n_img * (lv.L[0] * lv.L[0] / 256); total += bands[p]; }
+    for (int p = 0; p < n_pass; ++p) {
+      const int w = ps[p].wset, nz = wg_rows(bands[p], total, 512);    // 512 workgroups in all
+      jobs.j[jobs.n++] = rw::StemWgJob{ps[p].img, sc.G[p][0], sc.slab[w][0], ps[p].n_img, next_row[w][0], nz, 0};
+      next_row[w][0] += nz;
+    }
+    MLHOT_TRY(rw::stem_wgrad_dispatch(C, H, jobs, s, "trunk.bwd.stem.wgrad"));
+  }
+  // fold the slabs: one launch per weight set (all its convolutions' weights and biases)
+  for (int w = 0; w < n_wset; ++w) {
+    rw::WsumSegs segs{};
+    if (next_row[w][0] > 0 && ws[w].dw[0]) rw::wsum_add(segs, sc.slab[w][0], ws[w].dw[0], ws[w].db[0], next_row[w][0], 3, 25 * lv.C);
+    for (int c = 1; c < NCONV; ++c) {
+      if (next_row[w][c] <= 0 || !ws[w].dw[c]) continue;
+      rw::wsum_add(segs, sc.slab[w][c], ws[w].dw[c], nullptr, next_row[w][c], (c % 3 == 0 && ws[w].skip_k == 1) ? 1 : 0);
+      if (ws[w].db[c]) rw::wsum_add(segs, sc.slab_b[w][c], ws[w].db[c], nullptr, next_row[w][c], 2);
+    }
+    if (segs.blocks > 0) {
+      ProfScope pr("trunk.bwd.wsum", s);
+      hipLaunchKernelGGL(rw::wsum_kernel, dim3(segs.blocks), dim3(256), 0, s, segs);
+      MLHOT_TRY(check_launch("trunk.bwd.wsum"));
+    }
+  }
+  return MLHOT_OK;
+}
+
+}  // namespace rt
+#endif  // !MLHOT_HOSTSIM
+}  // namespace mlhot

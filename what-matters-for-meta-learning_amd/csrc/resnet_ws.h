@@ -1,0 +1,981 @@
+// Weight-stationary fp32-MFMA convolutions of the ResNet encoders / decoder (rows E2, D2 and the Bayes-by-backprop twin B1):
+// the 5x5 s2 stem and the 64 -> 64 channel 3x3 block convolutions of ImageEncoder / NPDecoder (networks/models.py:63-192,
+// networks/ResNet.py:58-74) and of the BBB encoder (networks/ANPMRShapeNet3D.py:40-90).  GPU build only; the run-time-shaped
+// implicit-GEMM problems (conv_rt.h) stay as the checked fallback for other geometries and for the hostsim flavour.
+//
+// Shape (MI355X-first; the same scheme as conv_tc.h / conv3_tc.h, generalised over the map size):
+//   * a 256-thread workgroup = 4 waves, wave nt owns output channels 16nt..16nt+15 and keeps its 16-column slice of the
+//     [576][64] weight matrix in 144 registers for its whole life; TWO workgroups share a CU (<= 80 KiB of LDS and <= 256
+//     registers each), so one stages its next band while the other one's waves have the matrix pipe;
+//   * a workgroup walks "bands" of BPOS (16 / 32 / 64) output positions: the band's input patch [ci 64][rows][cols] is staged
+//     HBM -> registers -> LDS once and every MFMA reads ONE LDS dword (its A operand); strides are chosen so that the two
+//     16-lane halves of every ds_read_b32 hit disjoint banks (scripts/lds_layout_search.py, re-checked by static_assert);
+//   * several "jobs" (the passes of a model step: context images, target images, decoder images, each with its own weight
+//     set; or the 3x3 main and 3x3 skip convolution of a BBB block, which read the same input) ride in ONE launch;
+//   * epilogues are fused: bias, ReLU, residual add + ReLU, the 1x1 stride-2 skip convolution of the plain ResNet block (it
+//     reads exactly the centre-tap operand of the 3x3 stride-2 convolution next to it: 16 more registers, no extra LDS read),
+//     and the ReLU mask of a data gradient.
+//   * weights arrive "lane-native" ([wave][k-step][lane], made once per step by prep_kernel), so a wave's 144 registers load
+//     with 144 coalesced 256-byte reads instead of a stride-9 gather.
+// v_mfma_f32_16x16x4_f32 (exact fp32): A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15], C/D lane l reg r = C[4*(l>>4)+r][l&15].
+#pragma once
+#include "common.h"
+
+#ifndef MLHOT_HOSTSIM
+namespace mlhot {
+namespace rw {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+constexpr int CH = 64;                 // channels of every block convolution
+constexpr int NKS = 144;               // k-steps of a 3x3 convolution over 64 channels (9 taps x 16 groups of 4 channels)
+constexpr int WIMG = 4 * NKS * 64;     // floats of one lane-native 3x3 weight image
+constexpr int WIMG1 = 4 * 16 * 64;     // ... of a 1x1 weight image
+constexpr int MAX_JOBS = 6;
+constexpr int WG_SLOTS = 512;          // two 256-thread workgroups per CU
+
+// ---- geometry of one 3x3, pad 1 convolution on square HIN x HIN maps -------------------------------------------
+// BPOS output positions per band; an M-tile = 16 positions = TR x TC block of the output map (or several whole images when an
+// image has fewer than 16 positions); patch = [ci][image-in-band][row][col], col 0 = ix -1, row 0 = iy (S*oy0 - 1).
+// KIND 1 is the patch of the stride-2 DATA GRADIENT: HIN = size of the dy map, positions = the HIN x HIN grid of one parity
+// class of input pixels, taps reach dy[a + {0,1}][b + {0,1}]: a stride-1 gather with a halo row / column at the bottom / right.
+template <int HIN_, int S_, int BPOS_, int TC_, int RS_, int ISZ_, int PS_, int KIND_ = 0>
+struct Geo {
+  static constexpr int HIN = HIN_, S = S_, BPOS = BPOS_, TC = TC_, RS = RS_, ISZ = ISZ_, PS = PS_, KIND = KIND_;
+  static constexpr int HO = HIN / S, WO = HO, PI = HO * WO;
+  static constexpr bool MULTI = PI < BPOS;                   // a band covers NI whole images
+  static constexpr int NI = MULTI ? BPOS / PI : 1;
+  static constexpr int RB = MULTI ? HO : BPOS / WO;          // output rows of a band (per image)
+  static constexpr int PR = KIND == 0 ? S * (RB - 1) + 3 : RB + 1;       // patch rows per image
+  static constexpr int ROW0 = KIND == 0 ? -1 : 0, COL0 = KIND == 0 ? 1 : 0;   // patch row 0 <-> input row S*oy0 + ROW0; input column 0 sits at patch column COL0
+  static constexpr int NACC = BPOS / 16;
+  static constexpr int BANDS_PER_IMG = MULTI ? 1 : PI / BPOS;
+  static constexpr int PATCH = CH * PS;
+  static constexpr int SEGW = HIN >= 4 ? 4 : HIN;            // floats per staging item
+  static constexpr int SEG = HIN / SEGW;
+  static constexpr int ITEMS = CH * NI * PR * SEG, CNT = (ITEMS + 255) / 256;
+  static_assert(RS >= HIN + (KIND == 0 ? (S == 1 ? 2 : 1) : 1) && ISZ >= PR * RS && PS >= NI * ISZ && (KIND == 0 || S == 1), "patch strides");
+  static_assert(PATCH * 4 <= 80 * 1024, "two workgroups per CU");
+  // (image-in-band, output row in band, output column) of row m of M-tile t
+  static constexpr int tile_il(int t, int m) { return PI >= 16 ? (MULTI ? t / (PI / 16) : 0) : t * (16 / PI) + m / PI; }
+  static constexpr int tile_oy(int t, int m) {
+    if (PI >= 16) { const int tt = MULTI ? t % (PI / 16) : t; return (tt / (WO / TC)) * (16 / TC) + m / TC; }
+    return (m % PI) / WO;
+  }
+  static constexpr int tile_ox(int t, int m) {
+    if (PI >= 16) { const int tt = MULTI ? t % (PI / 16) : t; return (tt % (WO / TC)) * TC + m % TC; }
+    return (m % PI) % WO;
+  }
+  static constexpr int posoff(int t, int m) { return tile_il(t, m) * ISZ + S * tile_oy(t, m) * RS + S * tile_ox(t, m); }
+  // both 32-lane halves of the A-operand ds_read_b32 of every M-tile hit 32 distinct banks
+  static constexpr bool conflict_free() {
+    for (int t = 0; t < NACC; ++t)
+      for (int half = 0; half < 4; half += 2) {
+        unsigned seen = 0;
+        for (int q = half; q < half + 2; ++q)
+          for (int m = 0; m < 16; ++m) {
+            const unsigned bit = 1u << ((q * PS + posoff(t, m)) & 31);
+            if (seen & bit) return false;
+            seen |= bit;
+          }
+      }
+    return true;
+  }
+  static_assert(conflict_free(), "LDS layout has bank conflicts");
+};
+// scripts/lds_layout_search.py
+typedef Geo<64, 2, 32, 16, 65, 195, 195> G64s2;
+typedef Geo<32, 1, 64, 16, 34, 136, 144> G32s1;
+typedef Geo<32, 2, 64, 16, 33, 297, 297> G32s2;
+typedef Geo<16, 1, 64, 16, 18, 108, 112> G16s1;
+typedef Geo<16, 2, 64, 2, 18, 306, 307> G16s2;
+typedef Geo<8, 1, 64, 2, 10, 100, 112> G8s1;
+typedef Geo<8, 2, 32, 4, 12, 108, 217> G8s2;
+typedef Geo<4, 1, 64, 4, 8, 48, 196> G4s1;
+typedef Geo<4, 2, 16, 2, 6, 40, 161> G4s2;
+typedef Geo<2, 1, 32, 2, 4, 24, 194> G2s1;
+// stride-2 data gradient, by the size of the dy map
+typedef Geo<32, 1, 32, 16, 33, 66, 80, 1> D32;
+typedef Geo<16, 1, 32, 8, 24, 72, 80, 1> D16;
+typedef Geo<8, 1, 32, 4, 12, 60, 80, 1> D8;
+typedef Geo<4, 1, 32, 4, 8, 40, 84, 1> D4;
+typedef Geo<2, 1, 32, 2, 4, 24, 194, 1> D2;
+
+// ---- lane-native weight images ------------------------------------------------------------------------------------
+// F image (forward operand order)  : [nt][ks][lane] = W[16nt + lr][4(ks % 16) + lq][tap = ks / 16]
+// D image (data-gradient order)    : [nt][ks][lane] = W[4(ks % 16) + lq][16nt + lr][tap = ks / 16]
+// 1x1 weights [64][64] the same with a single tap; stem weights [64][K] (K = C*25): [nt][ks][lane] = W[16nt + lr][4ks + lq] (0 beyond K).
+struct PrepItem { const float* w; float* f; float* d; int kind; int K; };      // kind 0: 3x3, 1: 1x1, 2: stem
+struct PrepItems { PrepItem it[56]; int n; };
+__global__ __launch_bounds__(256) void prep_kernel(const PrepItems items) {
+  const PrepItem it = items.it[blockIdx.y];
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int nks = it.kind == 0 ? NKS : it.kind == 1 ? 16 : (it.K + 3) / 4;
+  for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < 4 * nks; e += gridDim.x * 4) {
+    const int nt = e / nks, ks = e % nks;
+    if (it.kind == 2) {
+      const int k = 4 * ks + lq;
+      it.f[(size_t)e * 64 + lane] = k < it.K ? it.w[(size_t)(16 * nt + lr) * it.K + k] : 0.f;
+      continue;
+    }
+    const int taps = it.kind == 0 ? 9 : 1, tap = ks / 16, c4 = 4 * (ks % 16) + lq, n = 16 * nt + lr;
+    if (it.f) it.f[(size_t)e * 64 + lane] = it.w[((size_t)n * CH + c4) * taps + tap];
+    if (it.d) it.d[(size_t)e * 64 + lane] = it.w[((size_t)c4 * CH + n) * taps + tap];
+  }
+}
+
+// ---- forward-type 3x3 convolution ---------------------------------------------------------------------------------
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_RES_RELU = 2, EPI_MASK = 3 };
+struct FwdJob {
+  const float* x;              // [n_img][64][HIN][HIN]
+  const float* wimg;           // lane-native weights (F image; a D image with `flip` turns the kernel into the stride-1 data gradient)
+  const float* b;              // bias [64] or null
+  float* y;                    // [n_img][64][HO][HO]
+  const float* aux;            // EPI_BIAS_RES_RELU: residual (same shape as y); EPI_MASK: activation whose sign masks the result
+  const float* w1img; const float* b1; float* y1;     // fused 1x1 stride-2 convolution of the same input (SKIP1 kernels)
+  int n_img, epi, flip;        // flip: use tap 8 - t (transposed convolution)
+  int wg0, nwg;                // workgroups [wg0, wg0 + nwg) of the launch belong to this job
+};
+struct FwdJobs { FwdJob j[MAX_JOBS]; int n; };
+
+
+// Stage one band's patch: HBM -> registers -> LDS in chunks of <= 10 vector loads per thread (a barrier in front: every wave is
+// done reading the previous band; one behind: the patch is complete).  Rows outside the map and images beyond n_img become zeros.
+template <class G>
+__device__ __forceinline__ void stage_patch(float* patch, const float* __restrict__ x, int img0, int oy0, int n_img, int tid) {
+  typedef float stage_t __attribute__((ext_vector_type(G::SEGW)));
+  constexpr int CH_ITEMS = 10;
+  __syncthreads();
+#pragma unroll
+  for (int j0 = 0; j0 < G::CNT; j0 += CH_ITEMS) {
+    stage_t st[CH_ITEMS];
+#pragma unroll
+    for (int jj = 0; jj < CH_ITEMS; ++jj) {
+      const int j = j0 + jj;
+      if (j >= G::CNT) break;
+      const int e = tid + j * 256;
+      const int seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, il = (row / G::PR) % G::NI, ci = row / (G::PR * G::NI);
+      const int iy = G::S * oy0 + G::ROW0 + pr;
+      stage_t v;
+#pragma unroll
+      for (int q = 0; q < G::SEGW; ++q) v[q] = 0.f;
+      if (e < G::ITEMS && iy >= 0 && iy < G::HIN && img0 + il < n_img)
+        v = *reinterpret_cast<const stage_t*>(x + (((size_t)(img0 + il) * CH + ci) * G::HIN + iy) * G::HIN + G::SEGW * seg);
+      st[jj] = v;
+    }
+#pragma unroll
+    for (int jj = 0; jj < CH_ITEMS; ++jj) {
+      const int j = j0 + jj;
+      if (j >= G::CNT) break;
+      const int e = tid + j * 256;
+      const int seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, il = (row / G::PR) % G::NI, ci = row / (G::PR * G::NI);
+      if (e < G::ITEMS) {
+        float* d = patch + ci * G::PS + il * G::ISZ + pr * G::RS + G::COL0 + G::SEGW * seg;
+#pragma unroll
+        for (int q = 0; q < G::SEGW; ++q) d[q] = st[jj][q];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <class G, bool SKIP1>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
+  __shared__ float patch[G::PATCH];
+  const int tid = threadIdx.x, lane = tid & 63, nt = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const FwdJob& jb = jobs.j[ji];
+  const int co = 16 * nt + lr;
+
+  float wr[NKS];
+  {
+    const float* wp = jb.wimg + (size_t)nt * NKS * 64 + lane;
+    if (jb.flip) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) wr[ks] = wp[((8 - ks / 16) * 16 + ks % 16) * 64];
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) wr[ks] = wp[ks * 64];
+    }
+  }
+  float w1[SKIP1 ? 16 : 1];
+  float bn1 = 0.f;
+  if (SKIP1) {
+    const float* wp = jb.w1img + (size_t)nt * 16 * 64 + lane;
+#pragma unroll
+    for (int cg = 0; cg < 16; ++cg) w1[cg] = wp[cg * 64];
+    bn1 = jb.b1 ? jb.b1[co] : 0.f;
+  }
+  const float bn = jb.b ? jb.b[co] : 0.f;
+
+  for (int i = tid; i < G::PATCH; i += 256) patch[i] = 0.f;        // halo columns (and pad words) stay zero for good
+
+  // A-operand base of every M-tile: channel lq of the lane's position (row lr of the tile)
+  int aoff[G::NACC];
+#pragma unroll
+  for (int t = 0; t < G::NACC; ++t) {
+    int o = 0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) o = (lr == m) ? G::posoff(t, m) : o;
+    aoff[t] = lq * G::PS + o;
+  }
+
+  const int nbands = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
+#pragma unroll 1
+  for (int band = (int)blockIdx.x - jb.wg0; band < nbands; band += jb.nwg) {
+    const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
+    const int oy0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
+    stage_patch<G>(patch, jb.x, img0, oy0, jb.n_img, tid);
+
+    // ---- 144 k-steps x NACC tiles ----
+    f32x4_t acc[G::NACC], acc1[SKIP1 ? G::NACC : 1];
+#pragma unroll
+    for (int t = 0; t < G::NACC; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (SKIP1) {
+#pragma unroll
+      for (int t = 0; t < G::NACC; ++t) acc1[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int cg = 0; cg < 16; ++cg) {
+        const int off = cg * 4 * G::PS + (tap / 3) * G::RS + tap % 3;
+        float a[G::NACC];
+#pragma unroll
+        for (int t = 0; t < G::NACC; ++t) a[t] = patch[aoff[t] + off];
+#pragma unroll
+        for (int t = 0; t < G::NACC; ++t) acc[t] = mfma4(a[t], wr[tap * 16 + cg], acc[t]);
+        if (SKIP1 && tap == 4) {
+#pragma unroll
+          for (int t = 0; t < G::NACC; ++t) acc1[t] = mfma4(a[t], w1[cg], acc1[t]);
+        }
+        // unfenced, hipcc hoists the LDS operand reads of the whole band to the top and spills
+        if (cg % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- epilogue: lane holds rows 4lq..4lq+3 of every tile for channel co ----
+#pragma unroll
+    for (int t = 0; t < G::NACC; ++t) {
+      // the four rows are contiguous in the NCHW plane in runs of VW (a tile row has TC >= 2 columns; 2x2 maps: a whole plane)
+      constexpr int VW = G::PI < 16 ? 4 : (G::TC >= 4 ? 4 : 2);
+#pragma unroll
+      for (int v = 0; v < 4; v += VW) {
+        int il = 0, oy = 0, ox = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (lq == q) { il = G::tile_il(t, 4 * q + v); oy = G::tile_oy(t, 4 * q + v); ox = G::tile_ox(t, 4 * q + v); }
+        const int img = img0 + il;
+        if (img >= jb.n_img) continue;
+        const size_t o = (((size_t)img * CH + co) * G::HO + oy0 + oy) * G::WO + ox;
+        float r[VW];
+#pragma unroll
+        for (int q = 0; q < VW; ++q) r[q] = acc[t][v + q] + bn;
+        if (jb.epi == EPI_BIAS_RES_RELU || jb.epi == EPI_MASK) {
+          float ax[VW];
+          if (VW == 4) { const float4 u = *reinterpret_cast<const float4*>(jb.aux + o); ax[0] = u.x; ax[1] = u.y; ax[VW - 2] = u.z; ax[VW - 1] = u.w; }
+          else { const float2 u = *reinterpret_cast<const float2*>(jb.aux + o); ax[0] = u.x; ax[1] = u.y; }
+#pragma unroll
+          for (int q = 0; q < VW; ++q) r[q] = jb.epi == EPI_MASK ? (ax[q] > 0.f ? r[q] : 0.f) : r[q] + ax[q];
+        }
+        if (jb.epi == EPI_BIAS_RELU || jb.epi == EPI_BIAS_RES_RELU) {
+#pragma unroll
+          for (int q = 0; q < VW; ++q) r[q] = fmaxf(r[q], 0.f);
+        }
+        if (VW == 4) *reinterpret_cast<float4*>(jb.y + o) = make_float4(r[0], r[1], r[VW - 2], r[VW - 1]);
+        else *reinterpret_cast<float2*>(jb.y + o) = make_float2(r[0], r[1]);
+        if (SKIP1) {
+          if (VW == 4) *reinterpret_cast<float4*>(jb.y1 + o) = make_float4(acc1[t][v] + bn1, acc1[t][v + 1] + bn1, acc1[t][v + VW - 2] + bn1, acc1[t][v + VW - 1] + bn1);
+          else *reinterpret_cast<float2*>(jb.y1 + o) = make_float2(acc1[t][v] + bn1, acc1[t][v + 1] + bn1);
+        }
+      }
+    }
+  }
+}
+
+// Workgroup shares of the jobs of one launch: proportional to their band counts, at least one each, WG_SLOTS in all at most.
+template <class G>
+inline int plan_fwd(FwdJobs& jobs) {
+  int nb[MAX_JOBS], total = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    nb[i] = G::MULTI ? (jobs.j[i].n_img + G::NI - 1) / G::NI : jobs.j[i].n_img * G::BANDS_PER_IMG;
+    total += nb[i];
+  }
+  int wg = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    int share = total <= WG_SLOTS ? nb[i] : (int)((long)WG_SLOTS * nb[i] / total);
+    if (share < 1) share = 1;
+    if (share > nb[i]) share = nb[i];
+    jobs.j[i].wg0 = wg; jobs.j[i].nwg = share;
+    wg += share;
+  }
+  return wg;
+}
+
+template <class G, bool SKIP1>
+inline int launch_conv3x3(FwdJobs& jobs, hipStream_t s, const char* what) {
+  const int grid = plan_fwd<G>(jobs);
+  if (grid <= 0) return MLHOT_OK;
+  {
+    ProfScope ps(what, s);
+    hipLaunchKernelGGL((conv3x3_kernel<G, SKIP1>), dim3(grid), dim3(256), 0, s, jobs);
+  }
+  return check_launch(what);
+}
+
+// -> MLHOT_ERR_UNSUPPORTED when no kernel is instantiated for (HIN, stride)
+inline int conv3x3_dispatch(int HIN, int S, bool skip1, FwdJobs& jobs, hipStream_t s, const char* what) {
+  if (jobs.n <= 0) return MLHOT_OK;
+#define MLHOT_RW_CASE(H, ST, GEO)                                                                   \
+  if (HIN == H && S == ST) return skip1 ? (ST == 2 ? launch_conv3x3<GEO, (ST == 2)>(jobs, s, what) : MLHOT_ERR_UNSUPPORTED) \
+                                        : launch_conv3x3<GEO, false>(jobs, s, what);
+  MLHOT_RW_CASE(64, 2, G64s2) MLHOT_RW_CASE(32, 1, G32s1) MLHOT_RW_CASE(32, 2, G32s2) MLHOT_RW_CASE(16, 1, G16s1)
+  MLHOT_RW_CASE(16, 2, G16s2) MLHOT_RW_CASE(8, 1, G8s1) MLHOT_RW_CASE(8, 2, G8s2) MLHOT_RW_CASE(4, 1, G4s1)
+  MLHOT_RW_CASE(4, 2, G4s2) MLHOT_RW_CASE(2, 1, G2s1)
+#undef MLHOT_RW_CASE
+  return MLHOT_ERR_UNSUPPORTED;
+}
+inline bool conv3x3_supported(int HIN, int S) {
+  return (S == 2 && (HIN == 64 || HIN == 32 || HIN == 16 || HIN == 8 || HIN == 4)) || (S == 1 && (HIN == 32 || HIN == 16 || HIN == 8 || HIN == 4 || HIN == 2));
+}
+
+// ---- data gradient of a 3x3 stride-2 pad-1 convolution -------------------------------------------------------------
+// Input pixel (2a + py, 2b + px) only sees the taps with ky = 1 (py = 0) or ky in {0, 2} (py = 1), same for kx: four parity
+// classes with 1 / 2 / 2 / 4 taps, each a small stride-1 gather dy[a + {0,1}][b + {0,1}] on the HO x HO grid.  A wave keeps all
+// nine taps of its 16 input channels (D image: 144 registers) and one accumulator per (class, M-tile): a band of BPOS grid
+// positions costs 144 * BPOS/16 MFMAs, like the forward.  The epilogue interleaves the two column parities of a row into
+// runs of 8 consecutive dx floats; optionally it adds into dx (second source of a residual join) and / or masks with the
+// ReLU of the layer input.  SKIP1: the plain ResNet block's 1x1 stride-2 skip only reaches class (0, 0); its 16 k-steps (a
+// second dy source g1, 16 more weight registers) ride in the same accumulators.
+struct DgJob {
+  const float* dy;             // [n_img][64][HO][HO] (already masked by its producer)
+  const float* wimg;           // D image of the convolution's weights
+  float* dx;                   // [n_img][64][2HO][2HO]
+  const float* xact;           // when set: dx *= (xact > 0)   (the ReLU that produced the convolution's input)
+  const float* g1; const float* w1img;      // SKIP1: dy and D image of the 1x1 stride-2 convolution on the same input
+  int n_img, accumulate, wg0, nwg;
+};
+struct DgJobs { DgJob j[MAX_JOBS]; int n; };
+
+template <class G, bool SKIP1>
+__global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
+  static_assert(G::KIND == 1 && (G::TC >= 4 || G::PI < 16), "epilogue needs 4 consecutive grid columns per lane (or whole 2x2 maps)");
+  __shared__ float patch[G::PATCH * (SKIP1 ? 2 : 1)];
+  float* patch1 = patch + G::PATCH;
+  const int tid = threadIdx.x, lane = tid & 63, nt = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const DgJob& jb = jobs.j[ji];
+  const int ci = 16 * nt + lr;
+  constexpr int NT = G::NACC, HX = 2 * G::HO;
+
+  float wr[NKS];
+  {
+    const float* wp = jb.wimg + (size_t)nt * NKS * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) wr[ks] = wp[ks * 64];
+  }
+  float w1[SKIP1 ? 16 : 1];
+  if (SKIP1) {
+    const float* wp = jb.w1img + (size_t)nt * 16 * 64 + lane;
+#pragma unroll
+    for (int cg = 0; cg < 16; ++cg) w1[cg] = wp[cg * 64];
+  }
+  for (int i = tid; i < G::PATCH * (SKIP1 ? 2 : 1); i += 256) patch[i] = 0.f;      // halo column / pad words stay zero
+
+  int aoff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    int o = 0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) o = (lr == m) ? G::posoff(t, m) : o;
+    aoff[t] = lq * G::PS + o;
+  }
+  const int nbands = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
+#pragma unroll 1
+  for (int band = (int)blockIdx.x - jb.wg0; band < nbands; band += jb.nwg) {
+    const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
+    const int a0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
+    stage_patch<G>(patch, jb.dy, img0, a0, jb.n_img, tid);
+    if (SKIP1) stage_patch<G>(patch1, jb.g1, img0, a0, jb.n_img, tid);
+
+    f32x4_t acc[4][NT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[c][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int py = c >> 1, px = c & 1;
+#pragma unroll
+      for (int ty = 0; ty < (py ? 2 : 1); ++ty)
+#pragma unroll
+        for (int tx = 0; tx < (px ? 2 : 1); ++tx) {
+          const int ky = py ? (ty ? 2 : 0) : 1, kx = px ? (tx ? 2 : 0) : 1;
+          const int roff = (py && ky == 0) ? 1 : 0, coff = (px && kx == 0) ? 1 : 0;          // dy row a + roff, column b + coff
+#pragma unroll
+          for (int cg = 0; cg < 16; ++cg) {
+            const int off = cg * 4 * G::PS + roff * G::RS + coff;
+            float a[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[t] = patch[aoff[t] + off];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[c][t] = mfma4(a[t], wr[(ky * 3 + kx) * 16 + cg], acc[c][t]);
+            if (cg % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    }
+    if (SKIP1) {
+#pragma unroll
+      for (int cg = 0; cg < 16; ++cg) {
+        float a[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = patch1[aoff[t] + cg * 4 * G::PS];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[0][t] = mfma4(a[t], w1[cg], acc[0][t]);
+        if (cg % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- epilogue: rows 4lq..4lq+3 of tile t = 4 consecutive grid columns (or a whole 2x2 grid) of channel ci ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      int il = 0, a = 0, b = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lq == q) { il = G::tile_il(t, 4 * q); a = G::tile_oy(t, 4 * q); b = G::tile_ox(t, 4 * q); }
+      const int img = img0 + il;
+      if (img >= jb.n_img) continue;
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        if (G::PI >= 16) {
+          // dx row 2(a0 + a) + py, columns 2b .. 2b + 7
+          const size_t o = (((size_t)img * CH + ci) * HX + 2 * (a0 + a) + py) * HX + 2 * b;
+          float r[8];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { r[2 * q] = acc[2 * py][t][q]; r[2 * q + 1] = acc[2 * py + 1][t][q]; }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float4 v = make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]);
+            if (jb.accumulate) { const float4 u = *reinterpret_cast<const float4*>(jb.dx + o + 4 * h); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+            if (jb.xact) {
+              const float4 u = *reinterpret_cast<const float4*>(jb.xact + o + 4 * h);
+              v.x = u.x > 0.f ? v.x : 0.f; v.y = u.y > 0.f ? v.y : 0.f; v.z = u.z > 0.f ? v.z : 0.f; v.w = u.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(jb.dx + o + 4 * h) = v;
+          }
+        } else {
+          // 2x2 grid -> 4x4 dx map: grid row ar in {0,1} -> dx row 2ar + py, all four columns
+#pragma unroll
+          for (int ar = 0; ar < 2; ++ar) {
+            const size_t o = (((size_t)img * CH + ci) * HX + 2 * ar + py) * HX;
+            float4 v = make_float4(acc[2 * py][t][2 * ar], acc[2 * py + 1][t][2 * ar], acc[2 * py][t][2 * ar + 1], acc[2 * py + 1][t][2 * ar + 1]);
+            if (jb.accumulate) { const float4 u = *reinterpret_cast<const float4*>(jb.dx + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+            if (jb.xact) {
+              const float4 u = *reinterpret_cast<const float4*>(jb.xact + o);
+              v.x = u.x > 0.f ? v.x : 0.f; v.y = u.y > 0.f ? v.y : 0.f; v.z = u.z > 0.f ? v.z : 0.f; v.w = u.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(jb.dx + o) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <class G>
+inline int plan_dg(DgJobs& jobs) {
+  int nb[MAX_JOBS], total = 0, wg = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    nb[i] = G::MULTI ? (jobs.j[i].n_img + G::NI - 1) / G::NI : jobs.j[i].n_img * G::BANDS_PER_IMG;
+    total += nb[i];
+  }
+  for (int i = 0; i < jobs.n; ++i) {
+    int share = total <= WG_SLOTS ? nb[i] : (int)((long)WG_SLOTS * nb[i] / total);
+    if (share < 1) share = 1;
+    if (share > nb[i]) share = nb[i];
+    jobs.j[i].wg0 = wg; jobs.j[i].nwg = share; wg += share;
+  }
+  return wg;
+}
+template <class G, bool SKIP1>
+inline int launch_dgrad2(DgJobs& jobs, hipStream_t s, const char* what) {
+  const int grid = plan_dg<G>(jobs);
+  if (grid <= 0) return MLHOT_OK;
+  {
+    ProfScope ps(what, s);
+    hipLaunchKernelGGL((dgrad2_kernel<G, SKIP1>), dim3(grid), dim3(256), 0, s, jobs);
+  }
+  return check_launch(what);
+}
+// HO: size of the dy map (the convolution's OUTPUT); dx is 2HO x 2HO
+inline int dgrad2_dispatch(int HO, bool skip1, DgJobs& jobs, hipStream_t s, const char* what) {
+  if (jobs.n <= 0) return MLHOT_OK;
+#define MLHOT_RW_CASE(H, GEO) if (HO == H) return skip1 ? launch_dgrad2<GEO, true>(jobs, s, what) : launch_dgrad2<GEO, false>(jobs, s, what);
+  MLHOT_RW_CASE(32, D32) MLHOT_RW_CASE(16, D16) MLHOT_RW_CASE(8, D8) MLHOT_RW_CASE(4, D4) MLHOT_RW_CASE(2, D2)
+#undef MLHOT_RW_CASE
+  return MLHOT_ERR_UNSUPPORTED;
+}
+
+// ---- weight gradient of a 3x3 (pad 1, stride 1 / 2) convolution ------------------------------------------------------
+//   dW[co][ci][tap] = sum over positions  dy[co][pos] * x[ci][pos shifted by tap]:   M = co, N = (tap, ci), K = positions.
+// Workgroup (q, z): input-channel tile q (16 channels, so it stages only a quarter of the x patch) and position split z; wave w
+// = output-channel tile.  The nine accumulators of a wave (one per tap, 36 registers) live for the whole kernel; per k-step (4
+// positions) a wave reads ONE dy operand and nine x operands from LDS.  Bands of 128 positions; the x slice uses the forward's
+// patch geometry, dy is staged transposed ([pos][co], stride DS) - strides from scripts/lds_layout_search.py.  The k-step's four
+// positions are Q apart (pb = blk*4Q + lq*Q + j), which is what makes both gathers bank-conflict free.  Results go out in
+// MFMA-native order (one coalesced float4 per lane and tap) into slab row z; wsum_kernel folds the rows and un-permutes.
+// The bias gradient rides along in the q = 0 workgroups as a tenth accumulator against an all-ones operand.
+template <int HIN_, int S_, int Q_, int RS_, int ISZ_, int PS_, int DS_>
+struct GeoW {
+  static constexpr int HIN = HIN_, S = S_, Q = Q_, RS = RS_, ISZ = ISZ_, PS = PS_, DS = DS_, BPOS = 128, NKS_B = BPOS / 4;
+  static constexpr int HO = HIN / S, WO = HO, PI = HO * WO;
+  static constexpr bool MULTI = PI < BPOS;
+  static constexpr int NI = MULTI ? BPOS / PI : 1, RB = MULTI ? HO : BPOS / WO, PR = S * (RB - 1) + 3;
+  static constexpr int BANDS_PER_IMG = MULTI ? 1 : PI / BPOS;
+  static constexpr int XS = 16 * PS, DYT = BPOS * DS, LDS = XS + DYT;
+  static constexpr int SEGW = HIN >= 4 ? 4 : HIN, SEG = HIN / SEGW, ITEMS = 16 * NI * PR * SEG, CNT = (ITEMS + 255) / 256;
+  static constexpr int DSEGW = PI >= 4 ? 4 : PI;                                  // dy staging: runs along the positions of one (image, co) plane
+  static constexpr int DITEMS = 64 * BPOS / 4, DCNT = DITEMS / 256;              // float4 items (PI >= 4 always: 2x2 maps have 4 positions)
+  static_assert(RS >= HIN + (S == 1 ? 2 : 1) && ISZ >= PR * RS && PS >= NI * ISZ && PI >= 4, "strides");
+  static constexpr int pb(int ks, int lq) { return (ks / Q) * 4 * Q + lq * Q + ks % Q; }
+  static constexpr int posoff(int p) { return (MULTI ? p / PI : 0) * ISZ + S * (((MULTI ? p % PI : p)) / WO) * RS + S * ((MULTI ? p % PI : p) % WO); }
+  static constexpr bool conflict_free() {
+    for (int ks = 0; ks < NKS_B; ++ks)
+      for (int half = 0; half < 4; half += 2) {
+        unsigned sb = 0, sa = 0;
+        for (int q = half; q < half + 2; ++q)
+          for (int m = 0; m < 16; ++m) {
+            const unsigned bb = 1u << ((m * PS + posoff(pb(ks, q))) & 31), ba = 1u << ((pb(ks, q) * DS + m) & 31);
+            if ((sb & bb) || (sa & ba)) return false;
+            sb |= bb; sa |= ba;
+          }
+      }
+    return true;
+  }
+  static_assert(conflict_free(), "LDS layout has bank conflicts");
+};
+typedef GeoW<64, 2, 8, 65, 585, 585, 66> W64s2;
+typedef GeoW<32, 1, 16, 34, 204, 205, 65> W32s1;
+typedef GeoW<32, 2, 8, 33, 561, 561, 66> W32s2;
+typedef GeoW<16, 1, 1, 18, 180, 182, 80> W16s1;
+typedef GeoW<16, 2, 16, 20, 340, 681, 65> W16s2;
+typedef GeoW<8, 1, 1, 10, 100, 202, 80> W8s1;
+typedef GeoW<8, 2, 16, 9, 81, 650, 65> W8s2;
+typedef GeoW<4, 1, 1, 6, 36, 290, 80> W4s1;
+typedef GeoW<4, 2, 4, 5, 25, 802, 68> W4s2;
+typedef GeoW<2, 1, 4, 4, 16, 513, 68> W2s1;
+
+constexpr int SLAB3 = 4 * 4 * 9 * 64 * 4;      // floats of one slab row of a 3x3 weight gradient (= 64 * 576), MFMA-native order
+constexpr int SLAB1 = 4 * 4 * 64 * 4;          // ... of a 1x1 weight gradient
+struct WgJob {
+  const float* x; const float* dy;   // x [n_img][64][HIN][HIN] (the convolution's input), dy [n_img][64][HO][HO] (masked by its producer)
+  float* slab; float* slab_b;        // slab rows [z][SLAB3 | SLAB1]; bias rows [z][64] (may be null)
+  int n_img, z0, nz, wg0;            // this job owns slab rows z0 .. z0 + nz - 1 and workgroups wg0 .. wg0 + 4 nz - 1
+};
+struct WgJobs { WgJob j[MAX_JOBS]; int n; };
+
+template <class G, bool TAP1>          // TAP1: only the centre tap (the 1x1 stride-2 skip convolution: x[ci][2oy][2ox])
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
+  __shared__ float lds[G::LDS];
+  float* xs = lds;
+  float* dyt = lds + G::XS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const WgJob& jb = jobs.j[ji];
+  const int rel = (int)blockIdx.x - jb.wg0, q = rel & 3, z = rel >> 2;
+  constexpr int NT = TAP1 ? 1 : 9;
+
+  // per-lane operand offsets of every k-step of a band
+  int aoff[G::NKS_B], boff[G::NKS_B];
+#pragma unroll
+  for (int ks = 0; ks < G::NKS_B; ++ks) {
+    int pa = 0, pbv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lq == k) { pa = G::pb(ks, k) * G::DS; pbv = G::posoff(G::pb(ks, k)); }
+    aoff[ks] = pa + 16 * w + lr;
+    boff[ks] = pbv + lr * G::PS;
+  }
+  f32x4_t acc[NT], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < G::LDS; i += 256) lds[i] = 0.f;
+
+  const int nbands = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
+  typedef float stage_t __attribute__((ext_vector_type(G::SEGW)));
+#pragma unroll 1
+  for (int band = z; band < nbands; band += jb.nz) {
+    const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
+    const int oy0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
+    // ---- stage: x slice (channels 16q .. 16q + 15) and the transposed dy tile ----
+    stage_t st[G::CNT];
+#pragma unroll
+    for (int j = 0; j < G::CNT; ++j) {
+      const int e = tid + j * 256;
+      const int seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, il = (row / G::PR) % G::NI, ci = row / (G::PR * G::NI);
+      const int iy = G::S * oy0 - 1 + pr;
+      stage_t v;
+#pragma unroll
+      for (int k = 0; k < G::SEGW; ++k) v[k] = 0.f;
+      if (e < G::ITEMS && iy >= 0 && iy < G::HIN && img0 + il < jb.n_img)
+        v = *reinterpret_cast<const stage_t*>(jb.x + (((size_t)(img0 + il) * CH + 16 * q + ci) * G::HIN + iy) * G::HIN + G::SEGW * seg);
+      st[j] = v;
+    }
+    float4 sd[G::DCNT];
+#pragma unroll
+    for (int j = 0; j < G::DCNT; ++j) {
+      // item e: 4 consecutive band positions p4 .. p4 + 3 of output channel co (they lie in one image plane: PI % 4 == 0)
+      const int e = tid + j * 256, p4 = 4 * (e % (G::BPOS / 4)), co = e / (G::BPOS / 4);
+      const int il = G::MULTI ? p4 / G::PI : 0, pin = G::MULTI ? p4 % G::PI : oy0 * G::WO + p4;
+      sd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (img0 + il < jb.n_img) sd[j] = *reinterpret_cast<const float4*>(jb.dy + ((size_t)(img0 + il) * CH + co) * G::PI + pin);
+    }
+    __syncthreads();                   // the previous band's operands have been consumed
+#pragma unroll
+    for (int j = 0; j < G::CNT; ++j) {
+      const int e = tid + j * 256;
+      const int seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, il = (row / G::PR) % G::NI, ci = row / (G::PR * G::NI);
+      if (e < G::ITEMS) {
+        float* d = xs + ci * G::PS + il * G::ISZ + pr * G::RS + 1 + G::SEGW * seg;
+#pragma unroll
+        for (int k = 0; k < G::SEGW; ++k) d[k] = st[j][k];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G::DCNT; ++j) {
+      const int e = tid + j * 256, p4 = 4 * (e % (G::BPOS / 4)), co = e / (G::BPOS / 4);
+      float* d = dyt + p4 * G::DS + co;
+      d[0] = sd[j].x; d[G::DS] = sd[j].y; d[2 * G::DS] = sd[j].z; d[3 * G::DS] = sd[j].w;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int ks = 0; ks < G::NKS_B; ++ks) {
+      const float a = dyt[aoff[ks]];
+      const float* bp = xs + boff[ks];
+      if (TAP1) {
+        acc[0] = mfma4(a, bp[G::RS + 1], acc[0]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = mfma4(a, bp[(t / 3) * G::RS + t % 3], acc[t]);
+      }
+      if (q == 0) accb = mfma4(a, 1.f, accb);
+      if (ks % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- slab row z0 + z, MFMA-native: [q][w][tap][lane][4] ----
+  float* row = jb.slab + (size_t)(jb.z0 + z) * (TAP1 ? SLAB1 : SLAB3);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    *reinterpret_cast<float4*>(row + ((((size_t)q * 4 + w) * NT + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  if (q == 0 && jb.slab_b && lr == 0)
+    *reinterpret_cast<float4*>(jb.slab_b + (size_t)(jb.z0 + z) * 64 + 16 * w + 4 * lq) = make_float4(accb[0], accb[1], accb[2], accb[3]);
+}
+
+// out = sum over slab rows, un-permuted from MFMA-native order to the parameter's own layout.
+//   kind 0: 3x3 weight  dW[co][ci][tap]   from rows of SLAB3 floats ([q][w][tap][lane][r]: co = 16w + 4(lane>>4) + r, ci = 16q + (lane&15))
+//   kind 1: 1x1 weight  dW[co][ci]        from rows of SLAB1 floats
+//   kind 2: bias        db[co]            from rows of 64 floats (plain)
+//   kind 3: stem weight dW[co][K] (+ db)  from rows of 4 * NJ * 256 floats ([w][j][lane][r]: co = 16w + 4(lane>>4) + r, n = 16j + (lane&15))
+struct WsumSeg { const float* slab; float* out; float* out_b; int nrows, kind, K, first; };
+struct WsumSegs { WsumSeg s[32]; int n; int blocks; };
+__global__ __launch_bounds__(256) void wsum_kernel(const WsumSegs segs) {
+  int si = 0;
+  while (si + 1 < segs.n && (int)blockIdx.x >= segs.s[si + 1].first) ++si;
+  const WsumSeg sg = segs.s[si];
+  const int nj = sg.kind == 3 ? (sg.K + 1 + 15) / 16 : 0;
+  const int rowlen = sg.kind == 0 ? SLAB3 : sg.kind == 1 ? SLAB1 : sg.kind == 2 ? 64 : 4 * nj * 256;
+  const int e4 = ((int)blockIdx.x - sg.first) * 256 + threadIdx.x;        // float4 index inside a row
+  if (e4 * 4 >= rowlen) return;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+  const float* p = sg.slab + (size_t)e4 * 4;
+  int z = 0;
+  for (; z + 3 < sg.nrows; z += 4) {
+    add(s0, *reinterpret_cast<const float4*>(p + (size_t)z * rowlen));
+    add(s1, *reinterpret_cast<const float4*>(p + (size_t)(z + 1) * rowlen));
+    add(s2, *reinterpret_cast<const float4*>(p + (size_t)(z + 2) * rowlen));
+    add(s3, *reinterpret_cast<const float4*>(p + (size_t)(z + 3) * rowlen));
+  }
+  for (; z < sg.nrows; ++z) add(s0, *reinterpret_cast<const float4*>(p + (size_t)z * rowlen));
+  add(s0, s1); add(s2, s3); add(s0, s2);
+  const float v[4] = {s0.x, s0.y, s0.z, s0.w};
+  if (sg.kind == 2) { *reinterpret_cast<float4*>(sg.out + e4 * 4) = s0; return; }
+  const int lane = e4 & 63, lr = lane & 15, lq = lane >> 4;
+  if (sg.kind == 3) {
+    const int j = (e4 >> 6) % nj, w = (e4 >> 6) / nj, n = 16 * j + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * w + 4 * lq + r;
+      if (n < sg.K) sg.out[(size_t)co * sg.K + n] = v[r];
+      else if (n == sg.K && sg.out_b) sg.out_b[co] = v[r];
+    }
+    return;
+  }
+  const int nt = sg.kind == 0 ? 9 : 1;
+  const int t = (e4 >> 6) % nt, w = ((e4 >> 6) / nt) & 3, q = (e4 >> 6) / (nt * 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sg.out[((size_t)(16 * w + 4 * lq + r) * CH + 16 * q + lr) * nt + t] = v[r];
+}
+inline void wsum_add(WsumSegs& segs, const float* slab, float* out, float* out_b, int nrows, int kind, int K = 0) {
+  const int nj = kind == 3 ? (K + 1 + 15) / 16 : 0;
+  const int rowlen = kind == 0 ? SLAB3 : kind == 1 ? SLAB1 : kind == 2 ? 64 : 4 * nj * 256;
+  WsumSeg& sg = segs.s[segs.n++];
+  sg = WsumSeg{slab, out, out_b, nrows, kind, K, segs.blocks};
+  segs.blocks += (rowlen / 4 + 255) / 256;
+}
+
+// Position splits of one job: enough workgroups to fill the chip twice over all jobs, at least 2 bands per workgroup when there are many
+template <class G>
+inline int wgrad_bands(int n_img) { return G::MULTI ? (n_img + G::NI - 1) / G::NI : n_img * G::BANDS_PER_IMG; }
+template <class G, bool TAP1>
+inline int launch_wgrad(WgJobs& jobs, hipStream_t s, const char* what) {
+  int wg = 0;
+  for (int i = 0; i < jobs.n; ++i) { jobs.j[i].wg0 = wg; wg += 4 * jobs.j[i].nz; }
+  if (wg <= 0) return MLHOT_OK;
+  {
+    ProfScope ps(what, s);
+    hipLaunchKernelGGL((wgrad_kernel<G, TAP1>), dim3(wg), dim3(256), 0, s, jobs);
+  }
+  return check_launch(what);
+}
+// number of slab rows (position splits) a job of n_img images should use when `share` of the chip's 128 (x4 channel tiles) slots are its own
+inline int wgrad_bands_rt(int HIN, int S, int n_img) {
+  const int PI = (HIN / S) * (HIN / S);
+  return PI >= 128 ? n_img * (PI / 128) : (n_img + 128 / PI - 1) / (128 / PI);
+}
+inline int wgrad_dispatch(int HIN, int S, bool tap1, WgJobs& jobs, hipStream_t s, const char* what) {
+  if (jobs.n <= 0) return MLHOT_OK;
+#define MLHOT_RW_CASE(H, ST, GEO) if (HIN == H && S == ST) return tap1 ? launch_wgrad<GEO, true>(jobs, s, what) : launch_wgrad<GEO, false>(jobs, s, what);
+  MLHOT_RW_CASE(64, 2, W64s2) MLHOT_RW_CASE(32, 1, W32s1) MLHOT_RW_CASE(32, 2, W32s2) MLHOT_RW_CASE(16, 1, W16s1) MLHOT_RW_CASE(16, 2, W16s2)
+  MLHOT_RW_CASE(8, 1, W8s1) MLHOT_RW_CASE(8, 2, W8s2) MLHOT_RW_CASE(4, 1, W4s1) MLHOT_RW_CASE(4, 2, W4s2) MLHOT_RW_CASE(2, 1, W2s1)
+#undef MLHOT_RW_CASE
+  return MLHOT_ERR_UNSUPPORTED;
+}
+
+// ---- stem: 5x5 stride-2 pad-2 convolution C -> 64 channels (+ bias + ReLU) -------------------------------------------
+// K = 25 C (75 for the 3-channel ShapeNet3D images, 25 for the Distractor's grey images) padded to a multiple of 4; a band =
+// 256 output positions (16 M-tiles: the accumulators take 64 registers, the weights 19 / 7); lane lq of k-step ks reads
+// patch[ci][2oy + ky][2ox + kx] of k = 4ks + lq = (ci, ky, kx) through a per-lane table of 19 / 7 LDS offsets.
+struct StemJob { const float* x; const float* wimg; const float* b; float* y; int n_img, wg0, nwg; };
+struct StemJobs { StemJob j[MAX_JOBS]; int n; };
+
+template <int C, int HIN>
+struct StemGeo {
+  static constexpr int K = 25 * C, NKS = (K + 3) / 4, HO = HIN / 2, WO = HO, PI = HO * WO;
+  static constexpr int BPOS = 256, RB = BPOS / WO, NACC = 16, BANDS_PER_IMG = PI / BPOS;
+  // col 0 = ix -2.  RS = 5 and PS = 25 (mod 32): consecutive k = (ci, ky, kx) then always sit 1 bank apart (kx + 1; the row wrap
+  // RS - 4; the channel wrap PS - 4 RS - 4), so the forward's (2 lr + k) and the weight gradient's (k, +16 lq) gathers are conflict-free
+  static constexpr int PR = 2 * (RB - 1) + 5, RS = HIN + 5, PS = PR * RS + (25 + 32 - (PR * RS) % 32) % 32, PATCH = C * PS;
+  static_assert(RS % 32 == 5 && PS % 32 == 25, "stem strides");
+  static constexpr int SEG = HIN / 4, ITEMS = C * PR * SEG, CNT = (ITEMS + 255) / 256;
+  static_assert(WO >= 16 && BPOS % WO == 0 && PI % BPOS == 0, "stem geometry");
+};
+
+template <int C, int HIN>
+__global__ __launch_bounds__(256, 2) void stem_kernel(const StemJobs jobs) {
+  typedef StemGeo<C, HIN> G;
+  __shared__ float patch[G::PATCH];
+  const int tid = threadIdx.x, lane = tid & 63, nt = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const StemJob& jb = jobs.j[ji];
+  const int co = 16 * nt + lr;
+  float wr[G::NKS];
+  int koff[G::NKS];
+#pragma unroll
+  for (int ks = 0; ks < G::NKS; ++ks) {
+    wr[ks] = jb.wimg[((size_t)nt * G::NKS + ks) * 64 + lane];
+    const int k = 4 * ks + lq, ci = k / 25, t = k % 25;
+    koff[ks] = 2 * lr + (k < G::K ? ci * G::PS + (t / 5) * G::RS + t % 5 : 0);
+  }
+  const float bn = jb.b ? jb.b[co] : 0.f;
+  for (int i = tid; i < G::PATCH; i += 256) patch[i] = 0.f;
+  const int nbands = jb.n_img * G::BANDS_PER_IMG;
+#pragma unroll 1
+  for (int band = (int)blockIdx.x - jb.wg0; band < nbands; band += jb.nwg) {
+    const int img = band / G::BANDS_PER_IMG, oy0 = (band % G::BANDS_PER_IMG) * G::RB;
+    float4 st[G::CNT];
+#pragma unroll
+    for (int j = 0; j < G::CNT; ++j) {
+      const int e = tid + j * 256, seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, ci = row / G::PR;
+      const int iy = 2 * oy0 - 2 + pr;
+      st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < G::ITEMS && iy >= 0 && iy < HIN) st[j] = *reinterpret_cast<const float4*>(jb.x + (((size_t)img * C + ci) * HIN + iy) * HIN + 4 * seg);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < G::CNT; ++j) {
+      const int e = tid + j * 256, seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, ci = row / G::PR;
+      if (e < G::ITEMS) {
+        float* d = patch + ci * G::PS + pr * G::RS + 2 + 4 * seg;
+        d[0] = st[j].x; d[1] = st[j].y; d[2] = st[j].z; d[3] = st[j].w;
+      }
+    }
+    __syncthreads();
+    f32x4_t acc[G::NACC];
+#pragma unroll
+    for (int t = 0; t < G::NACC; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks) {
+      const float* base = patch + koff[ks];
+#pragma unroll
+      for (int t = 0; t < G::NACC; ++t) {
+        const int row = t / (G::WO / 16), cb = t % (G::WO / 16);
+        acc[t] = mfma4(base[2 * row * G::RS + 32 * cb], wr[ks], acc[t]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < G::NACC; ++t) {
+      const int row = t / (G::WO / 16), cb = t % (G::WO / 16);
+      const size_t o = (((size_t)img * CH + co) * G::HO + oy0 + row) * G::WO + 16 * cb + 4 * lq;
+      *reinterpret_cast<float4*>(jb.y + o) = make_float4(fmaxf(acc[t][0] + bn, 0.f), fmaxf(acc[t][1] + bn, 0.f), fmaxf(acc[t][2] + bn, 0.f),
+                                                         fmaxf(acc[t][3] + bn, 0.f));
+    }
+  }
+}
+
+inline bool stem_supported(int C, int HIN) { return (C == 3 && HIN == 64) || (C == 1 && HIN == 128); }
+inline int stem_dispatch(int C, int HIN, StemJobs& jobs, hipStream_t s, const char* what) {
+  if (jobs.n <= 0) return MLHOT_OK;
+  const int per_img = (HIN / 2) * (HIN / 2) / 256;
+  int nb[MAX_JOBS], total = 0, wg = 0;
+  for (int i = 0; i < jobs.n; ++i) { nb[i] = jobs.j[i].n_img * per_img; total += nb[i]; }
+  for (int i = 0; i < jobs.n; ++i) {
+    int share = total <= WG_SLOTS ? nb[i] : (int)((long)WG_SLOTS * nb[i] / total);
+    if (share < 1) share = 1;
+    if (share > nb[i]) share = nb[i];
+    jobs.j[i].wg0 = wg; jobs.j[i].nwg = share; wg += share;
+  }
+  if (wg <= 0) return MLHOT_OK;
+  {
+    ProfScope ps(what, s);
+    if (C == 3 && HIN == 64) hipLaunchKernelGGL((stem_kernel<3, 64>), dim3(wg), dim3(256), 0, s, jobs);
+    else if (C == 1 && HIN == 128) hipLaunchKernelGGL((stem_kernel<1, 128>), dim3(wg), dim3(256), 0, s, jobs);
+    else return MLHOT_ERR_UNSUPPORTED;
+  }
+  return check_launch(what);
+}
+
+// ---- stem weight gradient: dW[co][(ci, ky, kx)] and db[co] ------------------------------------------------------------
+// M = co (wave w = 16 output channels), N = K + 1 columns (column K = the bias gradient, against an all-ones operand) in NJ
+// tiles of 16, K-dim = positions: a band = the forward's 256 positions (same image patch in LDS); dy staged transposed
+// ([pos][co], stride 66); a k-step's four positions are 8 columns apart (bank offsets 2*8 = 16 for x, 8*66 = 16 mod 32 for dy).
+// Each workgroup owns slab row z (MFMA-native [w][j][lane][4]); wsum_kernel (kind 3) folds and un-permutes.
+struct StemWgJob { const float* x; const float* dy; float* slab; int n_img, z0, nz, wg0; };
+struct StemWgJobs { StemWgJob j[MAX_JOBS]; int n; };
+
+template <int C, int HIN>
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgJobs jobs) {
+  typedef StemGeo<C, HIN> G;
+  constexpr int NJ = (G::K + 1 + 15) / 16, DS = 66, HALF = G::BPOS / 2, NKS_H = HALF / 4;
+  __shared__ float lds[G::PATCH + HALF * DS];       // dy is staged in two halves of 128 positions (two workgroups per CU)
+  float* patch = lds;
+  float* dyt = lds + G::PATCH;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const StemWgJob& jb = jobs.j[ji];
+  const int z = (int)blockIdx.x - jb.wg0;
+  // column n = 16j + lr of this lane: patch offset of (ci, ky, kx), or the ones / zero column
+  int noff[NJ], nkind[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = 16 * j + lr, ci = n / 25, t = n % 25;
+    nkind[j] = n < G::K ? 0 : (n == G::K ? 1 : 2);
+    noff[j] = n < G::K ? ci * G::PS + (t / 5) * G::RS + t % 5 : 0;
+  }
+  f32x4_t acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < G::PATCH + HALF * DS; i += 256) lds[i] = 0.f;
+  const int nbands = jb.n_img * G::BANDS_PER_IMG;
+#pragma unroll 1
+  for (int band = z; band < nbands; band += jb.nz) {
+    const int img = band / G::BANDS_PER_IMG, oy0 = (band % G::BANDS_PER_IMG) * G::RB;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      float4 st[G::CNT], sd[8];
+      if (half == 0) {
+#pragma unroll
+        for (int j = 0; j < G::CNT; ++j) {
+          const int e = tid + j * 256, seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, ci = row / G::PR;
+          const int iy = 2 * oy0 - 2 + pr;
+          st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (e < G::ITEMS && iy >= 0 && iy < HIN) st[j] = *reinterpret_cast<const float4*>(jb.x + (((size_t)img * C + ci) * HIN + iy) * HIN + 4 * seg);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {           // 64 co x 128 positions = 2048 float4
+        const int e = tid + j * 256, p4 = 4 * (e % 32), co = e / 32;
+        sd[j] = *reinterpret_cast<const float4*>(jb.dy + ((size_t)img * CH + co) * G::PI + oy0 * G::WO + half * HALF + p4);
+      }
+      __syncthreads();
+      if (half == 0) {
+#pragma unroll
+        for (int j = 0; j < G::CNT; ++j) {
+          const int e = tid + j * 256, seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, ci = row / G::PR;
+          if (e < G::ITEMS) {
+            float* d = patch + ci * G::PS + pr * G::RS + 2 + 4 * seg;
+            d[0] = st[j].x; d[1] = st[j].y; d[2] = st[j].z; d[3] = st[j].w;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = tid + j * 256, p4 = 4 * (e % 32), co = e / 32;
+        float* d = dyt + p4 * DS + co;
+        d[0] = sd[j].x; d[DS] = sd[j].y; d[2 * DS] = sd[j].z; d[3 * DS] = sd[j].w;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < NKS_H; ++ks) {
+        // positions of this k-step: a run of 32 positions (one or half an output row), lane group lq takes its columns 8lq + j8
+        const int blk = ks / 8, j8 = ks % 8;
+        const int ph = blk * 32 + 8 * lq + j8, pb = half * HALF + ph;
+        const int oy = pb / G::WO, ox = pb % G::WO;
+        const float a = dyt[ph * DS + 16 * w + lr];
+        const float* bp = patch + 2 * oy * G::RS + 2 * ox;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          float b = bp[noff[j]];
+          if (16 * j + 15 >= G::K) b = nkind[j] == 0 ? b : (nkind[j] == 1 ? 1.f : 0.f);
+          acc[j] = mfma4(a, b, acc[j]);
+        }
+        if (ks % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float* row = jb.slab + (size_t)(jb.z0 + z) * (4 * NJ * 256);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    *reinterpret_cast<float4*>(row + (((size_t)w * NJ + j) * 64 + lane) * 4) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+}
+inline int stem_slab_row(int C) { return 4 * ((25 * C + 1 + 15) / 16) * 256; }
+inline int stem_wgrad_dispatch(int C, int HIN, StemWgJobs& jobs, hipStream_t s, const char* what) {
+  if (jobs.n <= 0) return MLHOT_OK;
+  int wg = 0;
+  for (int i = 0; i < jobs.n; ++i) { jobs.j[i].wg0 = wg; wg += jobs.j[i].nz; }
+  if (wg <= 0) return MLHOT_OK;
+  {
+    ProfScope ps(what, s);
+    if (C == 3 && HIN == 64) hipLaunchKernelGGL((stem_wgrad_kernel<3, 64>), dim3(wg), dim3(256), 0, s, jobs);
+    else if (C == 1 && HIN == 128) hipLaunchKernelGGL((stem_wgrad_kernel<1, 128>), dim3(wg), dim3(256), 0, s, jobs);
+    else return MLHOT_ERR_UNSUPPORTED;
+  }
+  return check_launch(what);
+}
+
+}  // namespace rw
+}  // namespace mlhot
+#endif  // !MLHOT_HOSTSIM

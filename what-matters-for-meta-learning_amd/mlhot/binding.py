@@ -93,7 +93,15 @@ def _get(struct, path):
 
 class BbbItem(C.Structure):          # struct mlhot_bbb_item
     _fields_ = [("mu", C.c_void_p), ("rho", C.c_void_p), ("eps", C.c_void_p), ("w", C.c_void_p), ("dw", C.c_void_p), ("dmu", C.c_void_p),
-                ("drho", C.c_void_p), ("n", C.c_size_t)]
+                ("drho", C.c_void_p), ("n", C.c_size_t), ("eps2", C.c_void_p), ("w2", C.c_void_p), ("dw2", C.c_void_p)]
+
+
+class TrunkWset(C.Structure):        # struct mlhot_trunk_wset
+    _fields_ = [("w", C.c_void_p * 13), ("b", C.c_void_p * 13), ("dw", C.c_void_p * 13), ("db", C.c_void_p * 13), ("skip_k", C.c_int)]
+
+
+class TrunkPass(C.Structure):        # struct mlhot_trunk_pass
+    _fields_ = [("img", C.c_void_p), ("n_img", C.c_int), ("wset", C.c_int), ("act", C.c_void_p * 9), ("dfeat", C.c_void_p)]
 
 
 def _ptr(t):
@@ -360,7 +368,7 @@ class MlhotLib:
                  "mlhot_bbb_sample_bwd")
         return dmu, drho
 
-    def _bbb_items(self, mus, rhos, epss, ws=None, dws=None, dmus=None, drhos=None):
+    def _bbb_items(self, mus, rhos, epss, ws=None, dws=None, dmus=None, drhos=None, epss2=None, ws2=None, dws2=None):
         n = len(mus)
         if n > 32:
             raise MlhotError("bbb_sample_multi: at most 32 tensors per call")
@@ -373,25 +381,104 @@ class MlhotLib:
             it.dmu = dmus[i].data_ptr() if dmus is not None else None
             it.drho = drhos[i].data_ptr() if drhos is not None else None
             it.n = mus[i].numel()
+            it.eps2 = epss2[i].data_ptr() if epss2 is not None else None
+            it.w2 = ws2[i].data_ptr() if ws2 is not None else None
+            it.dw2 = dws2[i].data_ptr() if dws2 is not None and dws2[i] is not None else None
         return arr
 
-    def bbb_sample_multi_fwd(self, mus, rhos, epss):
-        """Every (mu, rho, eps) triple sampled in ONE launch: returns ([w_i], kl = sum of all KL terms)."""
-        _chk(*mus, *rhos, *epss)
+    def bbb_sample_multi_fwd(self, mus, rhos, epss, epss2=None):
+        """Every (mu, rho, eps) triple sampled in ONE launch: returns ([w_i], kl = sum of all KL terms); with `epss2` a second
+        independent sample of every tensor as well: ([w_i], [w2_i], kl)."""
+        _chk(*mus, *rhos, *epss, *(epss2 or []))
         ws = [torch.empty_like(m) for m in mus]
+        ws2 = [torch.empty_like(m) for m in mus] if epss2 is not None else None
         kl = torch.empty((), device=mus[0].device)
-        items = self._bbb_items(mus, rhos, epss, ws=ws)
+        items = self._bbb_items(mus, rhos, epss, ws=ws, epss2=epss2, ws2=ws2)
         self.c.mlhot_bbb_sample_multi_scratch_floats.restype = C.c_size_t
         partial = torch.empty(self.c.mlhot_bbb_sample_multi_scratch_floats(items, len(mus)), device=mus[0].device)
         self._rc(self.c.mlhot_bbb_sample_multi_fwd(items, len(mus), _ptr(partial), _ptr(kl), _stream(mus[0])), "mlhot_bbb_sample_multi_fwd")
-        return ws, kl
+        return (ws, kl) if epss2 is None else (ws, ws2, kl)
 
-    def bbb_sample_multi_bwd(self, mus, rhos, epss, dws, dkl):
-        _chk(*[d for d in dws if d is not None], dkl)
+    def bbb_sample_multi_bwd(self, mus, rhos, epss, dws, dkl, epss2=None, dws2=None):
+        _chk(*[d for d in dws if d is not None], dkl, *[d for d in (dws2 or []) if d is not None])
         dmus, drhos = [torch.empty_like(m) for m in mus], [torch.empty_like(m) for m in mus]
-        items = self._bbb_items(mus, rhos, epss, dws=dws, dmus=dmus, drhos=drhos)
+        items = self._bbb_items(mus, rhos, epss, dws=dws, dmus=dmus, drhos=drhos, epss2=epss2, dws2=dws2)
         self._rc(self.c.mlhot_bbb_sample_multi_bwd(items, len(mus), _ptr(dkl), _stream(mus[0])), "mlhot_bbb_sample_multi_bwd")
         return dmus, drhos
+
+    # ---- whole ResNet trunks -------------------------------------------------------------------
+    @staticmethod
+    def trunk_supported(C_, H):
+        return (C_, H) in ((3, 64), (1, 128))
+
+    @staticmethod
+    def _trunk_structs(passes, wsets, grads=None, dfeats=None):
+        """passes: [(img [n,C,H,H], wset index, [9 activation tensors])]; wsets: [([w0, b0, w1, b1, ...], skip_k)]"""
+        wa = (TrunkWset * len(wsets))()
+        for i, (tensors, skip_k) in enumerate(wsets):
+            for c in range(13):
+                wa[i].w[c], wa[i].b[c] = tensors[2 * c].data_ptr(), tensors[2 * c + 1].data_ptr()
+                if grads is not None:
+                    wa[i].dw[c], wa[i].db[c] = grads[i][2 * c].data_ptr(), grads[i][2 * c + 1].data_ptr()
+            wa[i].skip_k = skip_k
+        pa = (TrunkPass * len(passes))()
+        for i, (img, wset, acts) in enumerate(passes):
+            pa[i].img, pa[i].n_img, pa[i].wset = img.data_ptr(), img.shape[0], wset
+            for k in range(9):
+                pa[i].act[k] = acts[k].data_ptr()
+            if dfeats is not None:
+                pa[i].dfeat = dfeats[i].data_ptr()
+        return pa, wa
+
+    def trunk_acts(self, img):
+        """The nine saved-activation tensors of one pass (a0, then (mid_i, y_i) of the four blocks) as views of one buffer."""
+        n, C_, H, _ = img.shape
+        self.c.mlhot_trunk_act_floats.restype = C.c_size_t
+        self.c.mlhot_trunk_act_floats.argtypes = [C.c_int] * 4
+        sizes = [self.c.mlhot_trunk_act_floats(C_, H, n, k) for k in range(9)]
+        offs, tot = [], 0
+        for sz in sizes:
+            offs.append(tot)
+            tot += (sz + 63) // 64 * 64
+        flat = torch.empty(tot, device=img.device)
+        out = []
+        for k, (o, sz) in enumerate(zip(offs, sizes)):
+            side = H // 2 if k == 0 else H >> ((k + 1) // 2 + 1)
+            out.append(flat[o:o + sz].view(n, 64, side, side))
+        return out
+
+    def _trunk_scratch(self, pa, n_pass, wa, n_wset, C_, H, backward, like):
+        self.c.mlhot_trunk_scratch_bytes.restype = C.c_size_t
+        self.c.mlhot_trunk_scratch_bytes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        sb = self.c.mlhot_trunk_scratch_bytes(pa, n_pass, wa, n_wset, C_, H, backward)
+        if sb == 0:
+            raise MlhotError(f"mlhot_trunk: {self.c.mlhot_last_error().decode()}")
+        return sb, self._bytes(sb, like)
+
+    def trunk_fwd(self, passes, wsets):
+        """passes: [(img, wset index)], wsets: [([w0, b0, ..., w12, b12], skip_k)] -> per pass the list of its 9 activations
+        (the last one is the trunk's output map)."""
+        imgs = [p[0] for p in passes]
+        _chk(*imgs, *[t for ts, _ in wsets for t in ts])
+        C_, H = imgs[0].shape[1], imgs[0].shape[2]
+        full = [(img, w, self.trunk_acts(img)) for img, w in passes]
+        pa, wa = self._trunk_structs(full, wsets)
+        sb, scratch = self._trunk_scratch(pa, len(full), wa, len(wsets), C_, H, 0, imgs[0])
+        self.c.mlhot_trunk_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        self._rc(self.c.mlhot_trunk_fwd(pa, len(full), wa, len(wsets), C_, H, _ptr(scratch), sb, _stream(imgs[0])), "mlhot_trunk_fwd")
+        return [acts for _, _, acts in full]
+
+    def trunk_bwd(self, passes, wsets, dfeats):
+        """passes: [(img, wset index, acts)], dfeats: gradient wrt each pass's output map -> per weight set its 26 gradients."""
+        _chk(*dfeats)
+        imgs = [p[0] for p in passes]
+        C_, H = imgs[0].shape[1], imgs[0].shape[2]
+        grads = [[torch.empty_like(t) for t in ts] for ts, _ in wsets]
+        pa, wa = self._trunk_structs(passes, wsets, grads=grads, dfeats=dfeats)
+        sb, scratch = self._trunk_scratch(pa, len(passes), wa, len(wsets), C_, H, 1, imgs[0])
+        self.c.mlhot_trunk_bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        self._rc(self.c.mlhot_trunk_bwd(pa, len(passes), wa, len(wsets), C_, H, _ptr(scratch), sb, _stream(imgs[0])), "mlhot_trunk_bwd")
+        return grads
 
     # ---- X1 building blocks --------------------------------------------------------------------
     def bn_relu_fwd(self, x, gamma, beta, run_mean, run_var, momentum=0.1, eps=1e-5):

@@ -241,17 +241,26 @@ class BBBSampleFunction(torch.autograd.Function):
 
 class BBBSampleMultiFunction(torch.autograd.Function):
     """All weight / bias samples of a Bayes-by-backprop encoder in one launch pair (mlhot_bbb_sample_multi_fwd / _bwd).
-    apply(eps_list, mu_0, rho_0, mu_1, rho_1, ...) -> (w_0, w_1, ..., kl); eps_list[i] is the device tensor of draw i."""
+    apply(eps_list, mu_0, rho_0, mu_1, rho_1, ...) -> (w_0, w_1, ..., kl); eps_list[i] is the device tensor of draw i.
+    With 2k draws for k (mu, rho) pairs, the second k draws make a SECOND independent sample of every tensor in the same launch:
+    -> (w_0 .. w_{k-1}, w2_0 .. w2_{k-1}, kl); the KL does not depend on eps and is computed once, and the backward folds both
+    samples' gradients into d mu / d rho in one pass (no per-tensor accumulation kernels)."""
 
     @staticmethod
     def forward(ctx, eps_list, *mu_rho):
         _need_gpu(*mu_rho, *eps_list)
         mus = [_c(t.detach()) for t in mu_rho[0::2]]
         rhos = [_c(t.detach()) for t in mu_rho[1::2]]
+        k = len(mus)
+        if len(eps_list) not in (k, 2 * k):
+            raise MlhotError(f"BBBSampleMultiFunction: {k} tensors need {k} or {2 * k} eps draws, got {len(eps_list)}")
         epss = [_c(e) for e in eps_list]
-        ws, kl = lib().bbb_sample_multi_fwd(mus, rhos, epss)
-        ctx.k = len(mus)
+        ctx.k, ctx.two = k, len(epss) == 2 * k
         ctx.save_for_backward(*mus, *rhos, *epss)
+        if ctx.two:
+            ws, ws2, kl = lib().bbb_sample_multi_fwd(mus, rhos, epss[:k], epss[k:])
+            return (*ws, *ws2, kl)
+        ws, kl = lib().bbb_sample_multi_fwd(mus, rhos, epss)
         return (*ws, kl)
 
     @staticmethod
@@ -260,14 +269,58 @@ class BBBSampleMultiFunction(torch.autograd.Function):
         saved = ctx.saved_tensors
         mus, rhos, epss = saved[:k], saved[k:2 * k], saved[2 * k:]
         dws = [(_c(g) if g is not None else None) for g in grads[:k]]
-        dkl = grads[k]
+        dws2 = [(_c(g) if g is not None else None) for g in grads[k:2 * k]] if ctx.two else None
+        dkl = grads[-1]
         if dkl is None:
             dkl = torch.zeros((), device=mus[0].device)
-        dmus, drhos = lib().bbb_sample_multi_bwd(mus, rhos, epss, dws, _c(dkl.float()))
+        if ctx.two:
+            dmus, drhos = lib().bbb_sample_multi_bwd(mus, rhos, epss[:k], dws, _c(dkl.float()), epss[k:], dws2)
+        else:
+            dmus, drhos = lib().bbb_sample_multi_bwd(mus, rhos, epss, dws, _c(dkl.float()))
         out = [None]
         for a, b in zip(dmus, drhos):
             out += [a, b]
         return tuple(out)
+
+
+class ResNetTrunkFunction(torch.autograd.Function):
+    """Every ResNet-trunk pass of a model step in ONE call per direction (mlhot_trunk_fwd / _bwd; csrc/resnet_trunk.h).
+    apply(spec, *tensors): spec = (passes, skip_ks, n_imgs, taps) with passes = [(image tensor index, weight-set index)],
+    skip_ks[w] = 1 | 3 the skip convolution of weight set w, n_imgs the number of leading image tensors, taps = None or a list
+    that receives, per pass, the nine post-ReLU activations; tensors = the image batches [n, C, H, H], then 26 tensors per weight
+    set (w, b of the stem and of (conv1, conv2, skip) of the four blocks).  Returns one output map [n, 64, H/32, H/32] per pass.
+    Gradients flow to the weights only (images are leaves of the models)."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        passes, skip_ks, n_imgs, taps = spec
+        _need_gpu(*tensors)
+        imgs = [_c(t.float()) for t in tensors[:n_imgs]]
+        flat_w = [_c(t.detach()) for t in tensors[n_imgs:]]
+        wsets = [(flat_w[26 * i:26 * i + 26], skip_ks[i]) for i in range(len(skip_ks))]
+        acts = lib().trunk_fwd([(imgs[i], w) for i, w in passes], wsets)
+        ctx.spec = (tuple(passes), tuple(skip_ks), n_imgs)
+        ctx.n_acts = [len(a) for a in acts]
+        ctx.save_for_backward(*imgs, *flat_w, *[a for ac in acts for a in ac])
+        if taps is not None:
+            taps.extend([list(ac) for ac in acts])
+        return tuple(ac[8] for ac in acts)
+
+    @staticmethod
+    def backward(ctx, *dfeats):
+        passes, skip_ks, n_imgs = ctx.spec
+        saved = ctx.saved_tensors
+        imgs, nw = saved[:n_imgs], 26 * len(skip_ks)
+        flat_w, flat_a = saved[n_imgs:n_imgs + nw], saved[n_imgs + nw:]
+        wsets = [(list(flat_w[26 * i:26 * i + 26]), skip_ks[i]) for i in range(len(skip_ks))]
+        full, dfs = [], []
+        for pi, (i, w) in enumerate(passes):
+            acts = list(flat_a[9 * pi:9 * pi + 9])
+            full.append((imgs[i], w, acts))
+            df = dfeats[pi]
+            dfs.append(_c(df) if df is not None else torch.zeros_like(acts[8]))
+        grads = lib().trunk_bwd(full, wsets, dfs)
+        return (None,) + (None,) * n_imgs + tuple(g for gs in grads for g in gs)
 
 
 class BatchNormReluFunction(torch.autograd.Function):

@@ -9,9 +9,9 @@ from torch import nn
 from mlhot.ops import AddReluFunction, LinearFunction
 from networks._resnet_np import ResNetNP
 from networks.bbb.BBBConv import BBBConv2d
-from networks.bbb.misc import FlattenLayer, ModuleWrapper, sample_all
+from networks.bbb.misc import FlattenLayer, ModuleWrapper, sample_all, sample_twice
 from networks.fast_attention import FastAttention
-from networks.models import AttnLinear, NPDecoder, _aggregate_feature_map, _mlp3
+from networks.models import AttnLinear, NPDecoder, _aggregate_feature_map, _mlp3, run_trunks
 
 
 class BasicBlock(nn.Module):
@@ -116,13 +116,26 @@ class ANPMRShapeNet3D(ResNetNP):
         self.ctx_num = batch_train_images.shape[1]
         C, H, W = self.img_channels, self.img_size[0], self.img_size[1]
         if self.ctx_num:
-            x_ctx, _ = self.img_encoder(batch_train_images.reshape(-1, C, H, W))
-            x_tgt, kl = self.img_encoder(batch_test_images.reshape(-1, C, H, W))     # a second, independent weight sample
+            ctx_imgs, tgt_imgs = batch_train_images.reshape(-1, C, H, W), batch_test_images.reshape(-1, C, H, W)
+            fmap_dec = None
+            maps = None
+            from mlhot import lib
+            if H == W and lib().trunk_supported(C, H):
+                # both weight samples of the step in one launch pair, then all three ResNet passes (context and target images
+                # through the two samples of the Bayes-by-backprop encoder, target images through the decoder) together
+                w_ctx, w_tgt, kl = sample_twice(self.img_encoder._bbb_layers())
+                log = self.img_encoder.tap_log
+                maps = run_trunks([(ctx_imgs, w_ctx, 3, log), (tgt_imgs, w_tgt, 3, log), self.decoder.trunk_job(tgt_imgs)])
+            if maps is not None:
+                x_ctx, x_tgt, fmap_dec = maps[0].reshape(-1, 256), maps[1].reshape(-1, 256), maps[2]
+            else:
+                x_ctx, _ = self.img_encoder(ctx_imgs)
+                x_tgt, kl = self.img_encoder(tgt_imgs)     # a second, independent weight sample
             x_ctx, x_tgt = self.pixel_agg(x_ctx), self.pixel_agg(x_tgt)
             feats = _mlp3(torch.cat([x_ctx, label_train], dim=2), self.task_encoder, last_relu=True)
             sample = LinearFunction.apply(self._multihead_attention(x_ctx, feats, x_tgt), self.mu.weight, self.mu.bias, "none")
-        else:
-            sample = torch.zeros(self.task_num, self.test_num, 256, device=batch_test_images.device)
-            kl = 0
+            out, var = self.decoder(batch_test_images, sample, fmap=fmap_dec)
+            return out, var, kl
+        sample = torch.zeros(self.task_num, self.test_num, 256, device=batch_test_images.device)
         out, var = self.decoder(batch_test_images, sample)
-        return out, var, kl
+        return out, var, 0

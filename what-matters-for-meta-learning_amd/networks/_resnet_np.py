@@ -9,7 +9,7 @@ from torch import nn
 
 from mlhot.ops import AggFunction, FavorFunction, LinearFunction
 from networks.fast_attention import FastAttention
-from networks.models import AttnLinear, ImageEncoder, NPDecoder, _mlp3
+from networks.models import AttnLinear, ImageEncoder, NPDecoder, _mlp3, run_trunks
 
 
 class ResNetNP(nn.Module):
@@ -96,14 +96,32 @@ class ResNetNP(nn.Module):
         self.test_num = batch_test_images.shape[1]
         self.ctx_num = batch_train_images.shape[1]
         C, H, W = self.img_channels, self.img_size[0], self.img_size[1]
+        tgt_imgs = batch_test_images.reshape(-1, C, H, W)
+        ctx_imgs = batch_train_images.reshape(-1, C, H, W)
+        contra_cnp = self.CONTRASTIVE and not test and not self.ATTENTION
+        # Every ResNet pass of the step goes out together (one launch sequence instead of one per pass): context images and -
+        # for the attention / contrastive models - target images through the encoder, target images through the decoder.  Call
+        # order of the reference (and of the tap logs): context, [target,] decoder.
+        jobs, roles = [], []
+        if self.ctx_num:
+            jobs.append(self.img_encoder.trunk_job(ctx_imgs)); roles.append("ctx")
+            if self.ATTENTION or contra_cnp:
+                jobs.append(self.img_encoder.trunk_job(tgt_imgs)); roles.append("tgt")
+        jobs.append(self.decoder.trunk_job(tgt_imgs)); roles.append("dec")
+        maps = run_trunks(jobs)
+        fm = dict(zip(roles, maps)) if maps is not None else {}
+
+        def encode(imgs, role):
+            return self.img_encoder.features(fm[role]) if role in fm else self.img_encoder(imgs)
+
         z_0 = None
         if self.ctx_num:
             if self.TRANSFORM_Y:
                 label_train = LinearFunction.apply(label_train, self.transform_y.weight, self.transform_y.bias, "none")
-            x_ctx = self.img_encoder(batch_train_images.reshape(-1, C, H, W))
+            x_ctx = encode(ctx_imgs, "ctx")
             feats = _mlp3(torch.cat([x_ctx, label_train], dim=2), self.task_encoder, last_relu=True)
             if self.ATTENTION:
-                x_tgt = self.img_encoder(batch_test_images.reshape(-1, C, H, W))
+                x_tgt = encode(tgt_imgs, "tgt")
                 sample = LinearFunction.apply(self._multihead_attention(x_ctx, feats, x_tgt), self.mu.weight, self.mu.bias, "none")
             else:
                 z_0 = self._aggregate(feats)
@@ -117,12 +135,12 @@ class ResNetNP(nn.Module):
             else:
                 if z_0 is None:
                     raise ValueError("the contrastive term needs a non-empty context set (the reference fails here as well: z_0 is unbound)")
-                x_qry = self.img_encoder(batch_test_images.reshape(-1, C, H, W))
+                x_qry = encode(tgt_imgs, "tgt")
                 if self.TRANSFORM_Y:
                     label_test = LinearFunction.apply(label_test, self.transform_y.weight, self.transform_y.bias, "none")
                 z_q = self._aggregate(_mlp3(torch.cat([x_qry, label_test], dim=2), self.task_encoder, last_relu=True), quirk=True)
                 contra = LossFunc.contrastive_loss(z_0, z_q)
-        out, var = self.decoder(batch_test_images, sample)
+        out, var = self.decoder(batch_test_images, sample, fmap=fm.get("dec"))
         if self.CONTRASTIVE:
             return out, var, 0, contra
         return out, var, 0

@@ -4,6 +4,28 @@ from torch import nn
 from . import eps
 
 
+def sample_twice(layers):
+    """Two independent weight / bias samples of `layers` (a Bayes-by-backprop encoder that runs twice per step: context images,
+    then target images) in ONE launch pair.  Draw order = the reference's: every layer of the first pass (weight, then bias),
+    then every layer of the second pass.  Returns (tensors of sample 1, tensors of sample 2, KL) with the tensors in layer
+    order [w, b, w, b, ...]; the KL does not depend on eps, so it is the KL either pass would report (bbb/misc.py:40-44)."""
+    from mlhot.ops import BBBSampleMultiFunction
+    if any(not layer.use_bias for layer in layers) or 2 * len(layers) > 32:
+        raise ValueError("sample_twice: expects <= 16 layers, all with a bias")
+    mu_rho, eps_list = [], []
+    for _ in range(2):
+        for layer in layers:
+            dev = layer.W_mu.device
+            eps_list.append(eps.draw(layer.W_mu.size(), dev))
+            eps_list.append(eps.draw(layer.bias_mu.size(), dev))
+    for layer in layers:
+        mu_rho += [layer.W_mu, layer.W_rho, layer.bias_mu, layer.bias_rho]
+        layer._kl = None
+    *ws, kl = BBBSampleMultiFunction.apply(eps_list, *mu_rho)
+    k = 2 * len(layers)
+    return list(ws[:k]), list(ws[k:]), kl
+
+
 def sample_all(layers):
     """Weight and bias samples of `layers` (BBBConv2d / BBBLinear, in the order their forwards will run) in ONE launch pair
     instead of two per tensor.  The eps draws happen here, layer by layer, weight then bias - the order and the generator state the

@@ -7,7 +7,8 @@ runs the mlhot HIP linear kernels, while the fused model path reads the paramete
 import torch
 from torch import nn
 
-from mlhot.ops import LinearFunction, MaxPool2Function
+from mlhot import lib
+from mlhot.ops import LinearFunction, MaxPool2Function, ResNetTrunkFunction
 from networks.ResNet import BasicBlock, ResNet, run_conv
 
 
@@ -69,6 +70,47 @@ def _mlp3(x, seq, last_relu):
     return x
 
 
+def trunk_weights(conv1, resnet):
+    """The 26 parameter tensors of a stem + ResNet(BasicBlock, [1,1,1,1]) trunk in the order mlhot_trunk_fwd takes them:
+    (weight, bias) of the stem, then of (conv1, conv2, skip) of the four blocks."""
+    out = [conv1.weight, conv1.bias]
+    for layer in (resnet.layer1, resnet.layer2, resnet.layer3, resnet.layer4):
+        blk = layer[0]
+        out += [blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias, blk.downsample[0].weight, blk.downsample[0].bias]
+    return out
+
+
+def run_trunks(jobs):
+    """Every ResNet-trunk pass of a model step in one call per direction (mlhot.ops.ResNetTrunkFunction).
+    jobs: [(images [n, C, H, W], weights = list of 26 tensors, skip kernel 1 | 3, tap_log or None)]; passes whose `weights` are
+    the same list object share one weight set (their gradients come out summed).  Returns the output maps [n, 64, H/32, W/32].
+    Image sizes without weight-stationary kernels (anything but 3x64x64 / 1x128x128) return None: the caller composes the
+    run-time-shaped convolution operators instead."""
+    C, H, W = jobs[0][0].shape[1:]
+    if H != W or not lib().trunk_supported(C, H) or any(tuple(j[0].shape[1:]) != (C, H, W) for j in jobs):
+        return None
+    imgs, wsets, passes = [], [], []
+    for img, weights, skip_k, _ in jobs:
+        ii = next((k for k, t in enumerate(imgs) if t is img), None)
+        if ii is None:
+            imgs.append(img)
+            ii = len(imgs) - 1
+        wi = next((k for k, (ws, _) in enumerate(wsets) if ws is weights), None)
+        if wi is None:
+            wsets.append((weights, skip_k))
+            wi = len(wsets) - 1
+        passes.append((ii, wi))
+    want_taps = any(j[3] is not None for j in jobs)
+    taps = [] if want_taps else None
+    spec = (passes, [k for _, k in wsets], len(imgs), taps)
+    outs = ResNetTrunkFunction.apply(spec, *imgs, *[t for ws, _ in wsets for t in ws])
+    if want_taps:
+        for (_, _, _, log), acts in zip(jobs, taps):
+            if log is not None:
+                log.append(list(acts))
+    return list(outs)
+
+
 class ImageEncoder(nn.Module):
     """5x5 s2 stem + ReLU, four BN-free BasicBlocks, img_agg  (models.py:63-117) -> [T, N, F]."""
 
@@ -85,10 +127,22 @@ class ImageEncoder(nn.Module):
         self.tap_log.append([])
         return self.tap_log[-1]
 
-    def forward(self, img):
-        x = self.resnet.trunk(run_conv(self.conv1, img, relu=True), self._taps())
-        x = _aggregate_feature_map(x, self.aggregate)
+    def trunk_job(self, img):
+        """This encoder's pass over `img` as a run_trunks job; the weight list is cached so that two passes share one set."""
+        if getattr(self, "_tw", None) is None:
+            self._tw = trunk_weights(self.conv1, self.resnet)
+        return (img, self._tw, 1, self.tap_log)
+
+    def features(self, fmap):
+        """img_agg + reshape of a trunk output map [n, 64, h, w] -> [T, N, F]  (models.py:105-115)."""
+        x = _aggregate_feature_map(fmap, self.aggregate)
         return x.view(self.task_num, -1, x.size(1))
+
+    def forward(self, img):
+        maps = run_trunks([self.trunk_job(img)])
+        if maps is None:                                   # no weight-stationary kernels for this image size: per-operator route
+            maps = [self.resnet.trunk(run_conv(self.conv1, img, relu=True), self._taps())]
+        return self.features(maps[0])
 
 
 class NPDecoder(nn.Module):
@@ -106,14 +160,25 @@ class NPDecoder(nn.Module):
             raise NotImplementedError("pr_unc / fc_var is never enabled by the reference models (models.py:185-190)")
         self.tap_log = None
 
-    def forward(self, test_images, sample_features, log_variance=None):
+    def trunk_job(self, imgs):
+        if getattr(self, "_tw", None) is None:
+            self._tw = trunk_weights(self.conv1, self.resnet)
+        return (imgs, self._tw, 1, self.tap_log)
+
+    def forward(self, test_images, sample_features, log_variance=None, fmap=None):
+        """`fmap`: this decoder's trunk output over the target images when the caller already ran it together with the
+        encoder passes (run_trunks); computed here otherwise."""
         n_per_task = sample_features.size(1)
-        imgs = test_images.reshape(self.task_num * n_per_task, self.img_channels, self.img_size[0], self.img_size[1])
-        taps = None
-        if self.tap_log is not None:
-            self.tap_log.append([])
-            taps = self.tap_log[-1]
-        x = self.resnet.trunk(run_conv(self.conv1, imgs, relu=True), taps)
-        x = _aggregate_feature_map(x, self.aggregate).reshape(self.task_num, n_per_task, -1)
+        if fmap is None:
+            imgs = test_images.reshape(self.task_num * n_per_task, self.img_channels, self.img_size[0], self.img_size[1])
+            maps = run_trunks([self.trunk_job(imgs)])
+            if maps is None:
+                taps = None
+                if self.tap_log is not None:
+                    self.tap_log.append([])
+                    taps = self.tap_log[-1]
+                maps = [self.resnet.trunk(run_conv(self.conv1, imgs, relu=True), taps)]
+            fmap = maps[0]
+        x = _aggregate_feature_map(fmap, self.aggregate).reshape(self.task_num, n_per_task, -1)
         mu = _mlp3(torch.cat([x, sample_features], dim=-1), self.fc_mu, last_relu=False)
         return mu, None
