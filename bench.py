@@ -7,7 +7,11 @@
 A step = zero_grad + forward + loss + backward (+ one flat gradient all-reduce when N>1) of the
 hand-written HIP path on a synthetic meta-batch that is already resident in HBM.  Rank 0 prints ONE
 JSON line; it also carries `roofline` (the dominant kernel, timed live with HIP events on its launch
-stream) and `cpu_baseline` (the CPU oracle - a port of the reference arithmetic - on the host cores).
+stream; `roofline.forward`: the training forward against the MFMA and the HBM roof) and `cpu_baseline`
+(the CPU oracle - a port of the reference arithmetic - on the host's physical cores, plus a 1-thread figure).
+
+    --workload c3 (default, BASELINE configs[2] = the headline metric) | c2 (configs[1]) | c5 (the per-GPU share of configs[4]:
+    ANPMRShapeNet3D, Bayes-by-backprop ResNet encoder; eps drawn on the CPU generator by a host thread, one step ahead)
 """
 import argparse
 import json
@@ -23,14 +27,20 @@ for _p in (os.path.join(ROOT, "what-matters-for-meta-learning_amd"), ROOT):
 
 import torch  # noqa: E402
 
-WORKLOADS = {   # BASELINE.json configs[1] / configs[2]
-    "c3": dict(method="ANPShapeNet1D", agg_mode="attention", dim_r=64,
-               name="ANPShapeNet1D 128x128x1 15-shot context + 15 target, 16 tasks/GPU (BASELINE configs[2])"),
-    "c2": dict(method="CNPShapeNet1D", agg_mode="mean", dim_r=100,
-               name="CNPShapeNet1D mean-agg 128x128x1 15+15-shot, 16 tasks/GPU (BASELINE configs[1])"),
+WORKLOADS = {   # BASELINE.json configs[1] / configs[2] (the headline metric) and the per-GPU share of configs[4]
+    "c3": dict(kind="vanilla", method="ANPShapeNet1D", agg_mode="attention", dim_r=64, T=16, image="128x128x1", task="shapenet_1d",
+               fwd_gflop_per_task=1.062, name="ANPShapeNet1D 128x128x1 15-shot context + 15 target, 16 tasks/GPU (BASELINE configs[2])"),
+    "c2": dict(kind="vanilla", method="CNPShapeNet1D", agg_mode="mean", dim_r=100, T=16, image="128x128x1", task="shapenet_1d",
+               fwd_gflop_per_task=1.044, name="CNPShapeNet1D mean-agg 128x128x1 15+15-shot, 16 tasks/GPU (BASELINE configs[1])"),
+    "c5": dict(kind="resnet3d", method="ANPMRShapeNet3D", agg_mode="attention", T=8, image="64x64x3", task="shapenet_3d", beta=1e-7,
+               fwd_gflop_per_task=3.92,
+               name="ANPMRShapeNet3D (Bayes-by-backprop ResNet encoder) 64x64x3 15+15-shot + task augmentation of the labels, 8 tasks/GPU "
+                    "(the per-GPU share of BASELINE configs[4]: 64 tasks over 8 GPUs)"),
 }
-T_LOCAL, NC, NQ = 16, 15, 15
+NC, NQ = 15, 15
+T_LOCAL = 16                    # vanilla workloads; WORKLOADS[...]["T"] is authoritative
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = fp32 vector rate
+PEAK_HBM_BYTES_S = 8.0e12       # MI355X_MICROARCH.md: HBM3E spec
 
 
 def alg_flops(label, n_img):
@@ -58,36 +68,112 @@ def alg_flops(label, n_img):
     return table.get(label)
 
 
+def trunk_flops_per_step(T):
+    """Algorithmic FLOPs (2 x MACs) one c5 step spends under every ResNet-trunk launch label: two Bayes-by-backprop encoder passes
+    (context, target: 3x3 skip) and the decoder pass (1x1 skip) over 15 images per task each; L = output map sizes."""
+    n, C, L = 15 * T, 3, [32, 16, 8, 4, 2]
+    f = {k: 0.0 for k in ("trunk.stem", "trunk.conv1", "trunk.conv2", "trunk.bwd.conv2.dgrad", "trunk.bwd.conv2.wgrad",
+                          "trunk.bwd.conv1.dgrad", "trunk.bwd.skip.dgrad", "trunk.bwd.conv1.wgrad", "trunk.bwd.skip1.wgrad", "trunk.bwd.stem.wgrad")}
+    for skip_k in (3, 3, 1):                               # the three passes
+        stem = 2.0 * n * L[0] ** 2 * 64 * 25 * C
+        f["trunk.stem"] += stem
+        f["trunk.bwd.stem.wgrad"] += stem
+        for b in range(1, 5):
+            c33 = 2.0 * n * L[b] ** 2 * 64 * 576           # one 3x3 64 -> 64 convolution on the block's output grid
+            c11 = 2.0 * n * L[b] ** 2 * 64 * 64
+            f["trunk.conv1"] += c33 + (c33 if skip_k == 3 else c11)
+            f["trunk.conv2"] += c33
+            f["trunk.bwd.conv2.dgrad"] += c33
+            f["trunk.bwd.conv2.wgrad"] += c33
+            f["trunk.bwd.conv1.dgrad"] += c33 + (0.0 if skip_k == 3 else c11)
+            f["trunk.bwd.skip.dgrad"] += c33 if skip_k == 3 else 0.0
+            f["trunk.bwd.conv1.wgrad"] += c33 + (c33 if skip_k == 3 else 0.0)
+            f["trunk.bwd.skip1.wgrad"] += c11 if skip_k == 1 else 0.0
+    return f
+
+
 def make_cfg(w, device):
-    return types.SimpleNamespace(device=device, seed=2578, img_size=[128, 128, 1], tasks_per_batch=T_LOCAL, input_dim=3,
+    if w["kind"] == "resnet3d":
+        return types.SimpleNamespace(device=device, seed=2578, img_size=[64, 64, 4], tasks_per_batch=w["T"], input_dim=4, output_dim=4,
+                                     agg_mode="attention", img_agg="reshape", task="shapenet_3d", temperature=0.07, method=w["method"])
+    return types.SimpleNamespace(device=device, seed=2578, img_size=[128, 128, 1], tasks_per_batch=w["T"], input_dim=3,
                                  output_dim=2, agg_mode=w["agg_mode"], img_agg="", dim_w=64, n_hidden_units_r=[100, 100],
                                  dim_r=w["dim_r"], dim_z=64, task="shapenet_1d", method=w["method"])
 
 
-def cpu_baseline(w, steps=3):
-    """The CPU oracle (torch-CPU restatement of the reference forward, autograd backward) on the
-    same 16-task batch, all host cores; a bounded sample: 1 warm-up + `steps` timed steps."""
+def make_batch(w, seed, device="cpu"):
+    from mlhot import synth
+    if w["kind"] == "resnet3d":
+        return synth.get_batch_3d(w["T"], NC, NQ, seed=seed, device=device, task_aug=True)
+    return synth.get_batch("shapenet_1d", w["T"], NC, NQ, seed=seed, device=device)
+
+
+def host_cpu():
+    """(physical cores, model string) of the host the baseline runs on."""
+    model, phys = "unknown", None
+    try:
+        cores = set()
+        with open("/proc/cpuinfo") as f:
+            pid = None
+            for ln in f:
+                if ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    pid = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    cores.add((pid, ln.split(":", 1)[1].strip()))
+        phys = len(cores) or None
+    except OSError:
+        pass
+    if not phys:
+        try:
+            import psutil
+            phys = psutil.cpu_count(logical=False)
+        except Exception:  # noqa: BLE001
+            phys = None
+    return phys or os.cpu_count() or 1, model
+
+
+def cpu_baseline(w, steps=5):
+    """The CPU oracle (torch-CPU fp32 restatement of the reference forward, autograd backward; kind "port") on the same synthetic
+    batch: torch threads = the host's PHYSICAL cores, median of `steps` fwd+bwd steps after one warm-up, plus ONE single-thread
+    step - a bounded sample (SURVEY §8d asks for 10 + 3; the default bench run has to finish within minutes)."""
     import importlib
     from oracle import ref_cpu as O
-    from mlhot import synth
     cfg = make_cfg(w, torch.device("cpu"))
     model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(cfg)
     p = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "projection" not in k)
          for k, v in model.state_dict().items()}
-    cx, qx, cy, qy = synth.get_batch("shapenet_1d", T_LOCAL, NC, NQ, seed=1234)
-    times = []
-    for i in range(steps + 1):
+    cx, qx, cy, qy = make_batch(w, 1234)
+    cores, cpu_model = host_cpu()
+    prev = torch.get_num_threads()
+
+    def one():
         for t in p.values():
             t.grad = None
         t0 = time.perf_counter()
-        mu = O.vanilla_np_forward(p, cx, cy, qx, w["agg_mode"], tanh=True)
-        O.calc_loss("shapenet_1d", mu, qy).backward()
-        dt = time.perf_counter() - t0
-        if i:
-            times.append(dt)
-    med = sorted(times)[len(times) // 2]
-    return {"value": T_LOCAL / med, "unit": "meta-tasks/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} fwd+bwd steps of the same 16-task 15+15 batch after 1 warm-up, median {med * 1e3:.1f} ms/step"}
+        if w["kind"] == "resnet3d":
+            torch.manual_seed(99)
+            mu, kl = O.anpmr3d_forward(p, cx, cy, qx)
+            (O.calc_loss("shapenet_3d", mu, qy) + w["beta"] * kl).backward()
+        else:
+            mu = O.vanilla_np_forward(p, cx, cy, qx, w["agg_mode"], tanh=True)
+            O.calc_loss("shapenet_1d", mu, qy).backward()
+        return time.perf_counter() - t0
+
+    try:
+        torch.set_num_threads(cores)
+        one()
+        times = sorted(one() for _ in range(steps))
+        med = times[len(times) // 2]
+        torch.set_num_threads(1)
+        single = one()
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": w["T"] / med, "unit": "meta-tasks/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+            "single_thread_value": w["T"] / single,
+            "sample": f"{steps} fwd+bwd steps of the same {w['T']}-task 15+15 batch after 1 warm-up on {cores} threads (= physical cores), "
+                      f"median {med * 1e3:.1f} ms/step (min {times[0] * 1e3:.1f}); one step on 1 thread: {single * 1e3:.0f} ms"}
 
 
 def _time_graph(fn, iters):
@@ -341,6 +427,31 @@ def measure_extras(w, device, loss_fn, batch, iters):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def forward_roofline(w, fwd_ms):
+    """the training forward against both roofs.  FLOPs: algorithmic (SURVEY's per-task figure).  HBM bytes, twice:
+    compulsory (inputs + parameters once: what a perfectly fused forward has to move) and measured (rocprofv3 FETCH_SIZE x 2 +
+    WRITE_SIZE of the forward's kernels, profiles/pmc_traffic.json, when those passes were collected for this workload)."""
+    t = fwd_ms * 1e-3
+    flops = w["fwd_gflop_per_task"] * 1e9 * w["T"]
+    img_bytes = {"128x128x1": 65536, "64x64x3": 49152}[w["image"]]
+    n_dec = NQ if w["kind"] == "resnet3d" else 0                      # the decoder ResNet re-reads the target images
+    compulsory = w["T"] * (NC + NQ + n_dec) * img_bytes + {"c3": 1.96e6, "c2": 1.45e6, "c5": 17.2e6}.get(w.get("key", ""), 0.0)
+    measured = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            tr = json.load(f)
+        if tr.get("_workload", "c3") == w.get("key"):
+            fw = [v["hbm_bytes"] for k, v in tr.items() if isinstance(v, dict) and ".bwd." not in k and "hbm_bytes" in v]
+            measured = float(sum(fw)) if fw else None
+    except (OSError, ValueError):
+        pass
+    return {"fwd_ms": fwd_ms, "alg_gflop": flops / 1e9, "achieved_tflops": flops / t / 1e12, "achieved_flops_frac": flops / t / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "hbm_compulsory_bytes": compulsory, "achieved_hbm_compulsory_frac": compulsory / t / PEAK_HBM_BYTES_S,
+            "hbm_measured_bytes": measured, "achieved_hbm_measured_frac": (measured / t / PEAK_HBM_BYTES_S) if measured else None,
+            "note": "the fused forward is bound by the fp32 matrix pipe, not by HBM (DESIGN.md §5): north_star's '>= 30 % of the HBM roofline' "
+                    "corresponds to >= 63 % of the fp32 MFMA peak over the whole forward"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -353,12 +464,14 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the fwd-only / +Adam timing legs")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing experiments (results become WRONG; never a bench line)")
     args = ap.parse_args()
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload], key=args.workload)
+    T = w["T"]
+    c5 = w["kind"] == "resnet3d"
 
     import importlib
     import torch.distributed as dist
     import mlhot
-    from mlhot import dist as mdist, synth
+    from mlhot import dist as mdist
     from trainer.losses import LossFunc
     # MLHOT_DIST_BACKEND / MLHOT_ONE_DEVICE: test hooks (e.g. two gloo ranks sharing the only GPU of a 1-GPU box, to
     # exercise the N>1 control flow); the driver's launch uses neither (nccl = RCCL, one rank per GPU)
@@ -371,18 +484,45 @@ def main():
     mlhot.build_product()
     if args.dbg:
         mlhot.lib().set_option("dbg", args.dbg)
+    if world > 1 and rank == 0:
+        print(f"[bench] {world} ranks over {dist.get_backend()} (RCCL when 'nccl'); rank 0 on {torch.cuda.get_device_name(device)}; "
+              f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG', '-')}", file=sys.stderr)
 
     model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(make_cfg(w, device)).to(device)
-    loss_fn = LossFunc("mse", "shapenet_1d")
-    cx, qx, cy, qy = synth.get_batch("shapenet_1d", T_LOCAL, NC, NQ, seed=1234 + rank, device=device)
+    loss_fn = LossFunc("mse", w["task"])
+    cx, qx, cy, qy = make_batch(w, 1234 + rank, device)
     bucket = mdist.GradBucket(model.parameters())
+    beta = w.get("beta", 0.0)
 
-    def step():
+    def fwd_bwd():
         model.zero_grad(set_to_none=True)
         mu, var, kl = model(cx, cy, qx)
         loss = loss_fn.calc_loss(mu, var, qy)
+        if c5:
+            loss = loss + beta * kl          # identical on every rank (same weights, kl does not depend on the batch): averaged, never summed
         loss.backward()
-        bucket.sync()
+        return loss.detach()
+
+    # Bayes-by-backprop eps: the reference draws them on the torch CPU generator inside the forward (bbb/BBBConv.py:88).  Every rank
+    # seeds that generator alike, so all ranks sample the same weights; the draws of step k+1 run on a host
+    # thread while step k is on the GPU (networks/bbb/eps.py).
+    eps = None
+    if c5:
+        from networks.bbb.eps import StagedEps
+        torch.manual_seed(1234)
+        eps = StagedEps(device)
+        with eps.recording():
+            fwd_bwd()
+        torch.cuda.synchronize()
+
+    def step():                              # eager form (also the profiled one)
+        if eps is not None:
+            eps.stage()
+            with eps.active():
+                loss = fwd_bwd()
+        else:
+            loss = fwd_bwd()
+        bucket.sync(defer_scale=True)        # the 1/world average rides in the optimizer's gradient scale (FlatAdam.step(grad_scale=...))
         return loss
 
     def fence():
@@ -397,23 +537,30 @@ def main():
     graphed = False
     if not args.no_graph:
         try:
+            def body():
+                if eps is not None:
+                    eps.rewind()
+                return fwd_bwd()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            if eps is not None:
+                eps.stage()
+            with torch.cuda.stream(side), (eps.active() if eps is not None else contextlib_null()):
                 for _ in range(3):
-                    model.zero_grad(set_to_none=True)
-                    loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+                    body()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             model.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph, stream=side):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
-                static_loss = loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy)
-                static_loss.backward()
+            with (eps.active() if eps is not None else contextlib_null()), torch.cuda.graph(graph, stream=side):   # the warm-up's stream: the parameters' grad-accumulation nodes live there
+                static_loss = body()
 
             def run():
+                if eps is not None:
+                    eps.stage()              # collect the prefetched draws (or draw now) + one pinned H2D copy
+                    eps.prefetch()           # next step's draws, on a host thread, while this step runs
                 graph.replay()
-                bucket.sync()
+                bucket.sync(defer_scale=True)
                 return static_loss
             graphed = True
         except Exception as e:  # noqa: BLE001 - fall back to eager, say so
@@ -423,9 +570,12 @@ def main():
     for _ in range(args.warmup):
         run()
     fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ev[i][0].record()
         loss = run()
+        ev[i][1].record()
     t_enqueue = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
@@ -434,12 +584,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = loss.item()
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)       # device time of each step (events on the replaying stream)
+    if eps is not None and eps._worker is not None:
+        eps.stage()                                          # collect the last prefetch: the CPU generator is free again
 
-    # ---- roofline leg: per-launch HIP-event timing of every kernel over a few more steps ----------
+    # ---- roofline leg: per-launch HIP-event timing of every kernel over a few more (eager) steps ----------
     roof, kernels = None, None
     if args.prof_steps > 0:
         L = mlhot.lib()
-        L.prof_begin(8192)
+        L.prof_begin(16384)
         for _ in range(args.prof_steps):
             step()
         torch.cuda.synchronize()
@@ -449,38 +602,73 @@ def main():
             a = agg.setdefault(label, [0, 0.0])
             a[0] += 1
             a[1] += ms
-        n_img = T_LOCAL * (NC + NQ)
+        n_img = T * (NC + NQ)
         kernels = {k: {"launches_per_step": v[0] / args.prof_steps, "avg_us": 1e3 * v[1] / v[0],
                        "us_per_step": 1e3 * v[1] / args.prof_steps} for k, v in agg.items()}
-        dom = max((k for k in agg if alg_flops(k, n_img)), key=lambda k: agg[k][1])
-        avg_s = agg[dom][1] / agg[dom][0] * 1e-3
-        ach = alg_flops(dom, n_img) / avg_s / 1e12
-        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
+        # algorithmic FLOPs of ALL launches of a label in one step (vanilla: one launch per label)
+        per_step = trunk_flops_per_step(T) if c5 else {k: alg_flops(k, n_img) * kernels[k]["launches_per_step"] for k in agg if alg_flops(k, n_img)}
+        per_step = {k: v for k, v in per_step.items() if k in agg and v}
+        if per_step:
+            dom = max(per_step, key=lambda k: agg[k][1])
+            sec_per_step = agg[dom][1] / args.prof_steps * 1e-3
+            ach = per_step[dom] / sec_per_step / 1e12
+            traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    tr = json.load(f)
+                if tr.get("_workload", "c3") == w["key"]:
+                    traffic = tr.get(dom, {}).get("hbm_bytes")
+            except (OSError, ValueError):
+                pass
+            lps = kernels[dom]["launches_per_step"]
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_us": kernels[dom]["avg_us"],
+                    "launches_per_step": lps, "alg_flops_per_launch": per_step[dom] / lps,
+                    "all_labels_tflops": {k: round(per_step[k] / (agg[k][1] / args.prof_steps * 1e-3) / 1e12, 1) for k in per_step}}
+    # ---- the training forward alone, against both roofs ------------------------------------------------------
+    fwd = None
+    if world == 1 and not args.no_graph:
         try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes")
-        except OSError:
-            pass
-        roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_us": avg_s * 1e6,
-                "alg_flops_per_launch": alg_flops(dom, n_img)}
+            def fwd_only():
+                if eps is not None:
+                    eps.rewind()
+                mu, var, kl = model(cx, cy, qx)
+                return loss_fn.calc_loss(mu, var, qy)
+            if eps is not None:
+                eps.stage()
+            with (eps.active() if eps is not None else contextlib_null()):
+                fwd = forward_roofline(w, _time_graph(fwd_only, max(10, args.steps // 2)))
+        except Exception as e:  # noqa: BLE001
+            fwd = {"error": f"{type(e).__name__}: {e}"}
+    if roof is not None:
+        roof["forward"] = fwd
     # ---- informational extras (SURVEY §8d "also report fwd-only and +Adam"), rank 0, single-GPU runs only -----------
     extras = None
-    if world == 1 and not args.no_extras and not args.no_graph:
+    if world == 1 and not args.no_extras and not args.no_graph and not c5:
         extras = measure_extras(w, device, loss_fn, (cx, qx, cy, qy), max(10, args.steps // 2))
     if world > 1:
         dist.barrier()
 
     if rank == 0:
-        out = {"metric": "meta-tasks/sec (fwd+bwd), ANP ShapeNet1D 15+15-shot 16-task batch",
-               "value": world * T_LOCAL * args.steps / elapsed, "unit": "meta-tasks/s", "n_gpus": world,
+        out = {"metric": "meta-tasks/sec (fwd+bwd), ANP ShapeNet1D 15+15-shot 16-task batch" if not c5 else
+                         "meta-tasks/sec (fwd+bwd), ANPMR ShapeNet3D 15+15-shot, 8 tasks per GPU",
+               "value": world * T * args.steps / elapsed, "unit": "meta-tasks/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": w["name"], "tasks_per_gpu": T_LOCAL, "global_tasks": world * T_LOCAL,
-                          "context_shots": NC, "target_shots": NQ, "image": "128x128x1",
+               "config": {"workload": w["name"], "tasks_per_gpu": T, "global_tasks": world * T,
+                          "context_shots": NC, "target_shots": NQ, "image": w["image"],
                           "parallelism": f"task-sharded x{world}, one flat grad all-reduce" if world > 1 else "single GPU"},
                "final_loss": final_loss, "hipgraph": graphed, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
+               "ms_per_step_event_median": step_ms[len(step_ms) // 2], "ms_per_step_event_min": step_ms[0],
+               "timing": f"value = wall clock over {args.steps} steps between two barrier + synchronize fences (max over ranks); "
+                         "event_median = median of per-step HIP-event durations on the replaying stream",
                "roofline": roof}
+        if eps is not None:
+            d0 = time.perf_counter()
+            eps.stage()
+            out["eps"] = {"floats_per_step": eps._total, "host_draw_ms_per_step": 1e3 * (time.perf_counter() - d0),
+                          "note": "drawn on the torch CPU generator in the reference's order (bit-identical samples), on a host thread while "
+                                  "the previous step runs; a step costs max(GPU time, draw time)"}
         if extras:
             out["extras"] = extras
         if not args.no_cpu_baseline and world == 1:
@@ -489,7 +677,7 @@ def main():
             out["cpu_baseline"] = None
         if kernels:
             top = sorted(kernels.items(), key=lambda kv: -kv[1]["us_per_step"])
-            out["kernel_us_per_step"] = {k: round(v["us_per_step"], 1) for k, v in top[:12]}
+            out["kernel_us_per_step"] = {k: round(v["us_per_step"], 1) for k, v in top[:14]}
             out["gpu_busy_us_per_step"] = round(sum(v["us_per_step"] for v in kernels.values()), 1)
             out["launches_per_step"] = round(sum(v["launches_per_step"] for v in kernels.values()), 1)
             if os.environ.get("MLHOT_BENCH_KERNELS"):
@@ -498,6 +686,11 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def contextlib_null():
+    import contextlib
+    return contextlib.nullcontext()
 
 
 if __name__ == "__main__":

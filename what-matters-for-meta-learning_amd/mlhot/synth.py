@@ -43,6 +43,38 @@ def host_convert(u8):
     return x.permute(0, 1, 4, 2, 3).contiguous()
 
 
+def get_batch_3d(tasks_per_batch, n_ctx, n_qry, seed=1234, device="cpu", task_aug=True):
+    """ShapeNet3D-shaped meta-batch (BASELINE config c5; dataset/shapenet_3d.py:108-122,218-227): images [T, N, 3, 64, 64] in
+    [0, 1) (the alpha channel is dropped by the loader), labels = unit quaternions with q[1] >= 0.  `task_aug`: the loader's
+    task augmentation (utils/utils.py:33-58) - per task one random azimuth / elevation offset added to every label of the task
+    (context and target alike) through Euler angles; host-side label arithmetic, it does not change any device shape.  The
+    image augmentation (imgaug) of the loader is out of scope."""
+    import numpy as np
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.rand(tasks_per_batch, n_ctx, 3, 64, 64, generator=g)
+    xq = torch.rand(tasks_per_batch, n_qry, 3, 64, 64, generator=g)
+
+    def quats(n):
+        q = torch.nn.functional.normalize(torch.randn(tasks_per_batch, n, 4, generator=g), dim=-1)
+        return torch.where(q[..., 1:2] < 0, -q, q)
+    ys, yq = quats(n_ctx), quats(n_qry)
+    if task_aug:
+        from scipy.spatial.transform import Rotation as R
+        rng = np.random.RandomState(seed)
+        out = []
+        for i in range(tasks_per_batch):
+            d_az, d_el = rng.randint(-10, 20), rng.randint(-5, 10)
+            pair = []
+            for q in (ys[i], yq[i]):
+                e = R.from_quat(q.numpy().astype(np.float64)).as_euler("ZYX", degrees=True)
+                e[:, 0] += d_el
+                e[:, 2] -= d_az
+                pair.append(torch.from_numpy(R.from_euler("ZYX", e, degrees=True).as_quat().astype(np.float32)))
+            out.append(pair)
+        ys, yq = torch.stack([p_[0] for p_ in out]), torch.stack([p_[1] for p_ in out])
+    return tuple(t.to(device) for t in (xs, xq, ys, yq))
+
+
 class SyntheticData:
     """Minimal stand-in for dataset.ShapeNet1D / Pascal1D with the reference's `get_batch` contract
     (dataset/shapenet_1d.py:113-196): train batches draw a random context size in [3, shot], validation /

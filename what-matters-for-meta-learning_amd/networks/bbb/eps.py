@@ -10,9 +10,15 @@ buffer - which is what makes a Bayes-by-backprop training step capturable in a h
     with eps.recording():  step()         # one eager step with lazy draws; notes the shapes in call order
     eps.stage()
     with eps.active():     graph = capture(step)
-    for it in ...:         eps.stage(); graph.replay()
+    for it in ...:         eps.stage(); eps.prefetch(); graph.replay()
+
+`prefetch()` takes the draws off the critical path: step k+1's eps are drawn on a worker thread (the torch CPU generator, same
+order, so the numbers are exactly those of the lazy route) into the alternate pinned buffer while step k runs on the GPU; the
+next `stage()` only waits for that thread and starts the copy.  A step then costs max(GPU time, draw time), not their sum.
+Nothing else may use the torch CPU generator between prefetch() and the stage() that collects it.
 """
 import contextlib
+import threading
 
 import torch
 
@@ -36,6 +42,7 @@ class StagedEps:
         self.shapes = []
         self._offsets, self._total, self._cursor = None, 0, 0
         self._host, self._dev, self._done, self._turn = None, None, None, 0
+        self._worker, self._worker_err = None, None
 
     @contextlib.contextmanager
     def recording(self):
@@ -74,16 +81,44 @@ class StagedEps:
             out[o:o + n].view(s).normal_(0, 1)
         return out
 
+    def prefetch(self):
+        """Start drawing the NEXT stage()'s eps on a worker thread (into the pinned buffer that stage() will ship)."""
+        if not self.shapes:
+            raise RuntimeError("StagedEps.prefetch(): nothing recorded; run one step under recording() first")
+        if self._worker is not None:
+            raise RuntimeError("StagedEps.prefetch(): the previous prefetch has not been collected by stage() yet")
+        if self._offsets is None:
+            self._plan()
+        k = self._turn ^ 1
+
+        def work():
+            try:
+                if self._done[k] is not None:
+                    self._done[k].synchronize()    # the copy out of this pinned buffer two steps ago
+                self.draw_host(self._host[k])
+            except BaseException as e:             # noqa: BLE001 - surfaced by the collecting stage()
+                self._worker_err = e
+        self._worker = threading.Thread(target=work, name="mlhot-eps-draw", daemon=True)
+        self._worker.start()
+
     def stage(self):
-        """Draw the next forward's eps on the CPU generator and start its copy to the device (current stream)."""
+        """The next forward's eps on the device: draws them on the CPU generator (or collects the draws a prefetch() made
+        meanwhile) and starts the copy (current stream)."""
         if not self.shapes:
             raise RuntimeError("StagedEps.stage(): nothing recorded; run one step under recording() first")
         if self._offsets is None:
             self._plan()
         k = self._turn = self._turn ^ 1
-        if self._done[k] is not None:
-            self._done[k].synchronize()            # the copy out of this pinned buffer two steps ago
-        self.draw_host(self._host[k])
+        if self._worker is not None:
+            self._worker.join()
+            self._worker = None
+            if self._worker_err is not None:
+                err, self._worker_err = self._worker_err, None
+                raise err
+        else:
+            if self._done[k] is not None:
+                self._done[k].synchronize()        # the copy out of this pinned buffer two steps ago
+            self.draw_host(self._host[k])
         self._dev.copy_(self._host[k], non_blocking=True)
         if self._done[k] is not None:
             self._done[k].record()
