@@ -73,7 +73,7 @@ def trunk_flops_per_step(T):
     (context, target: 3x3 skip) and the decoder pass (1x1 skip) over 15 images per task each; L = output map sizes."""
     n, C, L = 15 * T, 3, [32, 16, 8, 4, 2]
     f = {k: 0.0 for k in ("trunk.stem", "trunk.conv1", "trunk.conv2", "trunk.bwd.conv2.dgrad", "trunk.bwd.conv2.wgrad",
-                          "trunk.bwd.conv1.dgrad", "trunk.bwd.skip.dgrad", "trunk.bwd.conv1.wgrad", "trunk.bwd.skip1.wgrad", "trunk.bwd.stem.wgrad")}
+                          "trunk.bwd.conv1.dgrad", "trunk.bwd.conv1.dgrad2", "trunk.bwd.conv1.wgrad", "trunk.bwd.skip1.wgrad", "trunk.bwd.stem.wgrad")}
     for skip_k in (3, 3, 1):                               # the three passes
         stem = 2.0 * n * L[0] ** 2 * 64 * 25 * C
         f["trunk.stem"] += stem
@@ -85,8 +85,8 @@ def trunk_flops_per_step(T):
             f["trunk.conv2"] += c33
             f["trunk.bwd.conv2.dgrad"] += c33
             f["trunk.bwd.conv2.wgrad"] += c33
-            f["trunk.bwd.conv1.dgrad"] += c33 + (0.0 if skip_k == 3 else c11)
-            f["trunk.bwd.skip.dgrad"] += c33 if skip_k == 3 else 0.0
+            f["trunk.bwd.conv1.dgrad"] += c33 + (0.0 if skip_k == 3 else c11)    # first writers of dx: 3x3 skips; conv1 + fused 1x1 skip
+            f["trunk.bwd.conv1.dgrad2"] += c33 if skip_k == 3 else 0.0          # conv1 of the 3x3-skip blocks, added onto the skip's
             f["trunk.bwd.conv1.wgrad"] += c33 + (c33 if skip_k == 3 else 0.0)
             f["trunk.bwd.skip1.wgrad"] += c11 if skip_k == 1 else 0.0
     return f
@@ -463,6 +463,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-extras", action="store_true", help="skip the fwd-only / +Adam timing legs")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing experiments (results become WRONG; never a bench line)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="mlhot_set_option switches for A/B runs, e.g. c12_split=0")
     args = ap.parse_args()
     w = dict(WORKLOADS[args.workload], key=args.workload)
     T = w["T"]
@@ -484,6 +485,9 @@ def main():
     mlhot.build_product()
     if args.dbg:
         mlhot.lib().set_option("dbg", args.dbg)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        mlhot.lib().set_option(name, int(val))
     if world > 1 and rank == 0:
         print(f"[bench] {world} ranks over {dist.get_backend()} (RCCL when 'nccl'); rank 0 on {torch.cuda.get_device_name(device)}; "
               f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG', '-')}", file=sys.stderr)
@@ -663,6 +667,8 @@ def main():
                "timing": f"value = wall clock over {args.steps} steps between two barrier + synchronize fences (max over ranks); "
                          "event_median = median of per-step HIP-event durations on the replaying stream",
                "roofline": roof}
+        if args.opt:
+            out["options"] = args.opt
         if eps is not None:
             d0 = time.perf_counter()
             eps.stage()

@@ -65,7 +65,15 @@ def test_agg_fwd_bwd(gpulib, mode, T, Nc, R):
         assert U.rel_err(dlv, ll.grad) <= U.RTOL
 
 
-def test_favor_against_reference_vectors(gpulib):
+@pytest.fixture(params=[1, 0], ids=["favor_two_launch", "favor_chain"])
+def favor_impl(gpulib, request):
+    """FAVOR+ as two launches per direction (csrc/favor2.h, up to 32 + 32 shots) and as favor.h's operator chain."""
+    gpulib.set_option("favor2", request.param)
+    yield request.param
+    gpulib.set_option("favor2", 1)
+
+
+def test_favor_against_reference_vectors(gpulib, favor_impl):
     fx = np.load(os.path.join(U.GOLDEN, "favor.npz"))
     meta = json.loads(str(fx["meta"]))
     for tag, mt in meta.items():

@@ -8,6 +8,7 @@
 #include "problems.h"
 #include "ops_direct.h"
 #include "favor.h"
+#include "favor2.h"
 #include "encoder.h"
 #include "np_vanilla.h"
 #include "conv_rt.h"
@@ -26,6 +27,7 @@ void set_error(const char* fmt, ...) {
 }
 
 Options g_opt = {1, 1, 0, 0};
+int g_favor2 = 1;
 
 #ifndef MLHOT_HOSTSIM
 // ---- per-launch event profiler -------------------------------------------------------------------
@@ -59,6 +61,7 @@ int mlhot_set_option(const char* name, int value) {
   if (!strcmp(name, "tail_fused")) { g_opt.tail_fused = value; return MLHOT_OK; }
   if (!strcmp(name, "materialize_a1")) { g_opt.materialize_a1 = value; return MLHOT_OK; }
   if (!strcmp(name, "dbg")) { g_opt.dbg = value; return MLHOT_OK; }   // timing experiments only (results become wrong)
+  if (!strcmp(name, "favor2")) { g_favor2 = value; return MLHOT_OK; }  // FAVOR+: the two-launch kernels (csrc/favor2.h, default) or favor.h's chain
   set_error("mlhot_set_option: unknown option %s", name);
   return MLHOT_ERR_ARG;
 }
@@ -153,21 +156,18 @@ int mlhot_agg_bwd(int mode, const float* rs, const float* lv, const float* r, co
 
 // ---- FAVOR+ -----------------------------------------------------------------------------------
 size_t mlhot_favor_ws_bytes(int T, int H, int Nq, int Nc, int d, int m) {
-  size_t need = 0;
-  favor_carve(FavorDims{T, H, Nq, Nc, d, m}, nullptr, 0, &need);
-  return need;
+  return favor_ws_need(FavorDims{T, H, Nq, Nc, d, m});
 }
 int mlhot_favor_fwd(const float* q, const float* k, const float* v, const float* proj, int T, int H, int Nq, int Nc,
                     int d, int m, float* out, void* ws, size_t ws_bytes, void* stream) {
   if (T <= 0 || H <= 0 || Nq <= 0 || Nc <= 0 || d <= 0 || m <= 0) { set_error("favor_fwd: bad argument"); return MLHOT_ERR_ARG; }
-  return favor_forward(FavorDims{T, H, Nq, Nc, d, m}, q, k, v, proj, out, ws, ws_bytes, (hipStream_t)stream);
+  return favor_fwd_any(FavorDims{T, H, Nq, Nc, d, m}, q, k, v, proj, out, ws, ws_bytes, (hipStream_t)stream);
 }
 int mlhot_favor_bwd(const float* q, const float* k, const float* v, const float* proj, int T, int H, int Nq, int Nc,
                     int d, int m, const float* out, const float* dout, float* dq, float* dk, float* dv, void* ws,
                     size_t ws_bytes, void* stream) {
-  (void)proj;
   if (T <= 0 || H <= 0 || Nq <= 0 || Nc <= 0 || d <= 0 || m <= 0) { set_error("favor_bwd: bad argument"); return MLHOT_ERR_ARG; }
-  return favor_backward(FavorDims{T, H, Nq, Nc, d, m}, q, k, v, out, dout, dq, dk, dv, ws, ws_bytes, (hipStream_t)stream);
+  return favor_bwd_any(FavorDims{T, H, Nq, Nc, d, m}, q, k, v, proj, out, dout, dq, dk, dv, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // ---- losses -----------------------------------------------------------------------------------

@@ -13,6 +13,8 @@
 #include "encoder.h"
 #include "tail_fused.h"
 #include "tail_cnp.h"
+#include "linear_skinny.h"
+#include "favor2.h"
 
 namespace mlhot {
 
@@ -42,7 +44,7 @@ inline NpBuf np_saved_carve(const mlhot_np_dims& d, void* base, size_t cap) {
       b.merged = a.take<float>(Rq * H * dw); b.rr = a.take<float>(Rq * dw);
       b.wot = a.take<float>((size_t)H * dw * dw);      // head-major copy of _W's weight (fused tail)
       FavorDims f{d.T, H, d.Nq, d.Nc, dw, d.m_feat};
-      favor_carve(f, nullptr, 0, &b.favor_bytes);
+      b.favor_bytes = favor_ws_need(f);
       b.favor = a.take<char>(b.favor_bytes);
     } else {
       b.r = a.take<float>((size_t)d.T * d.dim_r); b.zt = a.take<float>((size_t)d.T * d.dim_z);
@@ -120,19 +122,32 @@ inline WBlocksMut gb8(float* const* w, float* const* b, int rows) {
   WBlocksMut x{}; for (int i = 0; i < MLHOT_HEADS; ++i) { x.w[i] = w[i]; x.b[i] = b[i]; } x.rows = rows; return x;
 }
 
+// Few-row layers with a single weight block and 16-byte aligned rows take the direct-from-global kernels (linear_skinny.h).
 inline int lin_fwd(const float* x, int ldx, const WBlocks& wb, float* y, int ldy, int M, int K, int N, int act,
                    hipStream_t s, const char* what) {
+#ifndef MLHOT_HOSTSIM
+  if (M <= sk::MAX_ROWS && wb.w[1] == nullptr && wb.rows >= N && K % 4 == 0 && sk::aligned4(x, ldx) && sk::aligned4(wb.w[0], K))
+    return sk::run_fwd(x, ldx, wb.w[0], wb.b[0], y, ldy, M, K, N, act, s, what);
+#endif
   LinearFwd p{M, N, K, x, ldx, wb, y, ldy, act};
   return run_igemm_auto(p, s, what);
 }
 // dx[M][Kin] (+)= (dy * act'(y)) W
 inline int lin_dgrad(const float* dy, int lddy, const float* y, int ldy, int act, const WBlocks& wb,
                      float* dx, int lddx, int accumulate, int M, int Kin, int Nout, hipStream_t s, const char* what) {
+#ifndef MLHOT_HOSTSIM
+  if (M <= sk::MAX_ROWS && wb.w[1] == nullptr && wb.rows >= Nout && Nout % 4 == 0 && sk::aligned4(dy, lddy) && (act == ACT_NONE || sk::aligned4(y, ldy)))
+    return sk::run_dgrad(dy, lddy, y, ldy, act, wb.w[0], dx, lddx, accumulate, M, Kin, Nout, s, what);
+#endif
   LinearDgrad p{M, Kin, Nout, dy, lddy, y, ldy, act, wb, dx, lddx, accumulate};
   return run_igemm_auto(p, s, what);
 }
 inline int lin_wgrad(const float* dy, int lddy, const float* y, int ldy, int act, const float* x, int ldx,
                      const WBlocksMut& gb, int M, int Kin, int Nout, hipStream_t s, const char* what) {
+#ifndef MLHOT_HOSTSIM
+  if (M <= sk::MAX_ROWS && gb.w[1] == nullptr && gb.rows >= Nout)
+    return sk::run_wgrad(dy, lddy, y, ldy, act, x, ldx, gb.w[0], gb.b[0], M, Kin, Nout, s, what);
+#endif
   LinearWgrad p{Nout, Kin + 1, M, dy, lddy, y, ldy, act, x, ldx, gb};
   return run_igemm_auto(p, s, what);
 }
@@ -385,7 +400,7 @@ inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const fl
       MLHOT_TRY(lin_fwd(b.rs, d.dim_r, wb8(p.wv_w, p.wv_b, dw), b.vh, H * dw, Rc, dw, H * dw, ACT_NONE, s, "np.W_v"));
       MLHOT_TRY(lin_fwd(b.dec_in, ldd, wb8(p.wq_w, p.wq_b, dw), b.qh, H * dw, Rq, dw, H * dw, ACT_NONE, s, "np.W_q"));
       FavorDims f{d.T, H, d.Nq, d.Nc, dw, d.m_feat};
-      MLHOT_TRY(favor_forward(f, b.qh, b.kh, b.vh, p.proj, b.merged, b.favor, b.favor_bytes, s));
+      MLHOT_TRY(favor_fwd_any(f, b.qh, b.kh, b.vh, p.proj, b.merged, b.favor, b.favor_bytes, s));
       MLHOT_TRY(lin_fwd(b.merged, H * dw, wb1(p.wo_w, p.wo_b, dw), b.rr, dw, Rq, H * dw, dw, ACT_NONE, s, "np.W"));
       MLHOT_TRY(lin_fwd(b.rr, dw, wb1(p.r2z_w, p.r2z_b, d.dim_z), b.dec_in + dw, ldd, Rq, d.dim_r, d.dim_z, ACT_NONE, s, "np.r_to_z"));
     } else {
@@ -445,7 +460,7 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
       MLHOT_TRY(lin_wgrad(sc.d_rr, dw, nullptr, 0, ACT_NONE, b.merged, H * dw, gb1(g.wo_w, g.wo_b, dw), Rq, H * dw, dw, s, "np.bwd.W.w"));
       MLHOT_TRY(lin_dgrad(sc.d_rr, dw, nullptr, 0, ACT_NONE, wb1(p.wo_w, nullptr, dw), sc.d_merged, H * dw, 0, Rq, H * dw, dw, s, "np.bwd.W.x"));
       FavorDims f{d.T, H, d.Nq, d.Nc, dw, d.m_feat};
-      MLHOT_TRY(favor_backward(f, b.qh, b.kh, b.vh, b.merged, sc.d_merged, sc.dqh, sc.dkh, sc.dvh, b.favor, b.favor_bytes, s));
+      MLHOT_TRY(favor_bwd_any(f, b.qh, b.kh, b.vh, p.proj, b.merged, sc.d_merged, sc.dqh, sc.dkh, sc.dvh, b.favor, b.favor_bytes, s));
       // Q projection: x_qry gradient accumulates onto the decoder's
       MLHOT_TRY(lin_wgrad(sc.dqh, H * dw, nullptr, 0, ACT_NONE, b.dec_in, ldd, gb8(g.wq_w, g.wq_b, dw), Rq, dw, H * dw, s, "np.bwd.W_q.w"));
       MLHOT_TRY(lin_dgrad(sc.dqh, H * dw, nullptr, 0, ACT_NONE, wb8(p.wq_w, nullptr, dw), sc.d_dec_in, ldd, 1, Rq, dw, H * dw, s, "np.bwd.W_q.x"));

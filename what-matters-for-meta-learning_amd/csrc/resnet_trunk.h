@@ -137,27 +137,29 @@ inline int trunk_forward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tru
   }
   for (int b = 1; b <= 4; ++b) {
     const int c1 = 3 * b - 2, c2 = c1 + 1, sk = c1 + 2;
-    // stage A: conv1 (+ReLU) and the skip convolution, both on the block input
-    for (int variant = 0; variant < 2; ++variant) {      // 0: 3x3 skip as a second job; 1: 1x1 skip fused into conv1's kernel
+    // stage A: conv1 (+ReLU) and the skip convolution, both on the block input - ONE launch for every pass: a 3x3 skip is a
+    // second job on the same input, a 1x1 skip rides in its conv1 job (centre-tap operand)
+    {
       rw::FwdJobs jobs{};
+      bool any1 = false;
       for (int p = 0; p < n_pass; ++p) {
         const mlhot_trunk_wset& w = ws[ps[p].wset];
-        if ((w.skip_k == 1) != (variant == 1)) continue;
         const float* x = ps[p].act[2 * b - 2];
-        if (variant == 1) {
+        if (jobs.n + (w.skip_k == 1 ? 1 : 2) > rw::MAX_JOBS) {
+          MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, any1, jobs, s, "trunk.conv1"));
+          jobs.n = 0; any1 = false;
+        }
+        if (w.skip_k == 1) {
+          any1 = true;
           jobs.j[jobs.n++] = rw::FwdJob{x, sc.wimg[ps[p].wset][c1], w.b[c1], ps[p].act[2 * b - 1], nullptr, sc.wimg[ps[p].wset][sk], w.b[sk], sc.idn[p],
                                         ps[p].n_img, rw::EPI_BIAS_RELU, 0, 0, 0};
         } else {
-          if (jobs.n + 2 > rw::MAX_JOBS) {
-            MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, false, jobs, s, "trunk.conv1"));
-            jobs.n = 0;
-          }
           jobs.j[jobs.n++] = rw::FwdJob{x, sc.wimg[ps[p].wset][c1], w.b[c1], ps[p].act[2 * b - 1], nullptr, nullptr, nullptr, nullptr, ps[p].n_img,
                                         rw::EPI_BIAS_RELU, 0, 0, 0};
           jobs.j[jobs.n++] = rw::FwdJob{x, sc.wimg[ps[p].wset][sk], w.b[sk], sc.idn[p], nullptr, nullptr, nullptr, nullptr, ps[p].n_img, rw::EPI_BIAS, 0, 0, 0};
         }
       }
-      MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, variant == 1, jobs, s, "trunk.conv1"));
+      MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, any1, jobs, s, "trunk.conv1"));
     }
     // stage B: conv2 + skip + ReLU
     rw::FwdJobs jobs{};
@@ -221,18 +223,20 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
     }
     // data gradient into the block input (not needed for images: block 1's input is the stem output, whose gradient feeds the stem's wgrad)
     {
-      rw::DgJobs j1{}, j3a{}, j3b{};
+      // launch 1: every first writer of dx - the 3x3 skips' data gradients and the 1x1-skip blocks' fused conv1 + skip gradient;
+      // launch 2: the 3x3-skip blocks' conv1 gradient, added onto launch 1's result and masked
+      rw::DgJobs ja{}, jb2{};
+      bool any1 = false;
       for (int p = 0; p < n_pass; ++p) {
         const int w = ps[p].wset;
-        if (ws[w].skip_k == 1) j1.j[j1.n++] = rw::DgJob{dm[p], sc.wimg[w][c1], sc.G[p][b - 1], xin[p], g[p], sc.wimg[w][sk], ps[p].n_img, 0, 0, 0};
+        if (ws[w].skip_k == 1) { any1 = true; ja.j[ja.n++] = rw::DgJob{dm[p], sc.wimg[w][c1], sc.G[p][b - 1], xin[p], g[p], sc.wimg[w][sk], ps[p].n_img, 0, 0, 0}; }
         else {
-          j3a.j[j3a.n++] = rw::DgJob{g[p], sc.wimg[w][sk], sc.G[p][b - 1], nullptr, nullptr, nullptr, ps[p].n_img, 0, 0, 0};
-          j3b.j[j3b.n++] = rw::DgJob{dm[p], sc.wimg[w][c1], sc.G[p][b - 1], xin[p], nullptr, nullptr, ps[p].n_img, 1, 0, 0};
+          ja.j[ja.n++] = rw::DgJob{g[p], sc.wimg[w][sk], sc.G[p][b - 1], nullptr, nullptr, nullptr, ps[p].n_img, 0, 0, 0};
+          jb2.j[jb2.n++] = rw::DgJob{dm[p], sc.wimg[w][c1], sc.G[p][b - 1], xin[p], nullptr, nullptr, ps[p].n_img, 1, 0, 0};
         }
       }
-      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], true, j1, s, "trunk.bwd.conv1.dgrad"));
-      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], false, j3a, s, "trunk.bwd.skip.dgrad"));
-      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], false, j3b, s, "trunk.bwd.conv1.dgrad"));
+      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], any1, ja, s, "trunk.bwd.conv1.dgrad"));
+      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], false, jb2, s, "trunk.bwd.conv1.dgrad2"));
     }
     {   // conv1 and 3x3-skip weight gradients (same input, same geometry: one launch); 1x1 skips on their own
       rw::WgJobs jobs{}, jobs1{};

@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
   }
   float w1[SKIP1 ? 16 : 1];
   float bn1 = 0.f;
-  if (SKIP1) {
+  const bool has1 = SKIP1 && jb.w1img != nullptr;      // per job: a launch may mix blocks with and without the fused 1x1 skip
+  if (has1) {
     const float* wp = jb.w1img + (size_t)nt * 16 * 64 + lane;
 #pragma unroll
     for (int cg = 0; cg < 16; ++cg) w1[cg] = wp[cg * 64];
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
         for (int t = 0; t < G::NACC; ++t) a[t] = patch[aoff[t] + off];
 #pragma unroll
         for (int t = 0; t < G::NACC; ++t) acc[t] = mfma4(a[t], wr[tap * 16 + cg], acc[t]);
-        if (SKIP1 && tap == 4) {
+        if (SKIP1 && tap == 4 && has1) {
 #pragma unroll
           for (int t = 0; t < G::NACC; ++t) acc1[t] = mfma4(a[t], w1[cg], acc1[t]);
         }
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
         }
         if (VW == 4) *reinterpret_cast<float4*>(jb.y + o) = make_float4(r[0], r[1], r[VW - 2], r[VW - 1]);
         else *reinterpret_cast<float2*>(jb.y + o) = make_float2(r[0], r[1]);
-        if (SKIP1) {
+        if (has1) {
           if (VW == 4) *reinterpret_cast<float4*>(jb.y1 + o) = make_float4(acc1[t][v] + bn1, acc1[t][v + 1] + bn1, acc1[t][v + VW - 2] + bn1, acc1[t][v + VW - 1] + bn1);
           else *reinterpret_cast<float2*>(jb.y1 + o) = make_float2(acc1[t][v] + bn1, acc1[t][v + 1] + bn1);
         }
@@ -380,7 +381,8 @@ __global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
     for (int ks = 0; ks < NKS; ++ks) wr[ks] = wp[ks * 64];
   }
   float w1[SKIP1 ? 16 : 1];
-  if (SKIP1) {
+  const bool has1 = SKIP1 && jb.w1img != nullptr;      // per job
+  if (has1) {
     const float* wp = jb.w1img + (size_t)nt * 16 * 64 + lane;
 #pragma unroll
     for (int cg = 0; cg < 16; ++cg) w1[cg] = wp[cg * 64];
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
     const int a0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
     stage_patch<G>(patch, jb.dy, img0, a0, jb.n_img, tid);
-    if (SKIP1) stage_patch<G>(patch1, jb.g1, img0, a0, jb.n_img, tid);
+    if (has1) stage_patch<G>(patch1, jb.g1, img0, a0, jb.n_img, tid);
 
     f32x4_t acc[4][NT];
 #pragma unroll
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
           }
         }
     }
-    if (SKIP1) {
+    if (has1) {
 #pragma unroll
       for (int cg = 0; cg < 16; ++cg) {
         float a[NT];
@@ -601,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
     for (int k = 0; k < 4; ++k)
       if (lq == k) { pa = G::pb(ks, k) * G::DS; pbv = G::posoff(G::pb(ks, k)); }
     aoff[ks] = pa + 16 * w + lr;
-    boff[ks] = pbv + lr * G::PS;
+    boff[ks] = TAP1 ? (aoff[ks] - (16 * w + lr)) / G::DS + lr * (G::BPOS + 1) : pbv + lr * G::PS;      // TAP1: compact [ci][position] tile
   }
   f32x4_t acc[NT], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -615,18 +617,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
     const int oy0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
     // ---- stage: x slice (channels 16q .. 16q + 15) and the transposed dy tile ----
-    stage_t st[G::CNT];
+    // TAP1 (1x1 stride-2 convolution) only ever reads x[ci][2 oy][2 ox]: a compact [16 ci][128 positions] gather, 8 loads per thread
+    stage_t st[TAP1 ? 1 : G::CNT];
+    float s1[TAP1 ? 8 : 1];
+    if (TAP1) {
 #pragma unroll
-    for (int j = 0; j < G::CNT; ++j) {
-      const int e = tid + j * 256;
-      const int seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, il = (row / G::PR) % G::NI, ci = row / (G::PR * G::NI);
-      const int iy = G::S * oy0 - 1 + pr;
-      stage_t v;
+      for (int j = 0; j < 8; ++j) {
+        const int e = tid + j * 256, p = e % G::BPOS, ci = e / G::BPOS;
+        const int il = G::MULTI ? p / G::PI : 0, pin = G::MULTI ? p % G::PI : p;
+        const int oy = oy0 + pin / G::WO, ox = pin % G::WO;
+        s1[j] = img0 + il < jb.n_img ? jb.x[(((size_t)(img0 + il) * CH + 16 * q + ci) * G::HIN + 2 * oy) * G::HIN + 2 * ox] : 0.f;
+      }
+    } else {
 #pragma unroll
-      for (int k = 0; k < G::SEGW; ++k) v[k] = 0.f;
-      if (e < G::ITEMS && iy >= 0 && iy < G::HIN && img0 + il < jb.n_img)
-        v = *reinterpret_cast<const stage_t*>(jb.x + (((size_t)(img0 + il) * CH + 16 * q + ci) * G::HIN + iy) * G::HIN + G::SEGW * seg);
-      st[j] = v;
+      for (int j = 0; j < G::CNT; ++j) {
+        const int e = tid + j * 256;
+        const int seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, il = (row / G::PR) % G::NI, ci = row / (G::PR * G::NI);
+        const int iy = G::S * oy0 - 1 + pr;
+        stage_t v;
+#pragma unroll
+        for (int k = 0; k < G::SEGW; ++k) v[k] = 0.f;
+        if (e < G::ITEMS && iy >= 0 && iy < G::HIN && img0 + il < jb.n_img)
+          v = *reinterpret_cast<const stage_t*>(jb.x + (((size_t)(img0 + il) * CH + 16 * q + ci) * G::HIN + iy) * G::HIN + G::SEGW * seg);
+        st[j] = v;
+      }
     }
     float4 sd[G::DCNT];
 #pragma unroll
@@ -638,14 +652,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
       if (img0 + il < jb.n_img) sd[j] = *reinterpret_cast<const float4*>(jb.dy + ((size_t)(img0 + il) * CH + co) * G::PI + pin);
     }
     __syncthreads();                   // the previous band's operands have been consumed
+    if (TAP1) {
 #pragma unroll
-    for (int j = 0; j < G::CNT; ++j) {
-      const int e = tid + j * 256;
-      const int seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, il = (row / G::PR) % G::NI, ci = row / (G::PR * G::NI);
-      if (e < G::ITEMS) {
-        float* d = xs + ci * G::PS + il * G::ISZ + pr * G::RS + 1 + G::SEGW * seg;
+      for (int j = 0; j < 8; ++j) { const int e = tid + j * 256; xs[(e / G::BPOS) * (G::BPOS + 1) + e % G::BPOS] = s1[j]; }
+    } else {
 #pragma unroll
-        for (int k = 0; k < G::SEGW; ++k) d[k] = st[j][k];
+      for (int j = 0; j < G::CNT; ++j) {
+        const int e = tid + j * 256;
+        const int seg = e % G::SEG, row = e / G::SEG, pr = row % G::PR, il = (row / G::PR) % G::NI, ci = row / (G::PR * G::NI);
+        if (e < G::ITEMS) {
+          float* d = xs + ci * G::PS + il * G::ISZ + pr * G::RS + 1 + G::SEGW * seg;
+#pragma unroll
+          for (int k = 0; k < G::SEGW; ++k) d[k] = st[j][k];
+        }
       }
     }
 #pragma unroll
@@ -661,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
       const float a = dyt[aoff[ks]];
       const float* bp = xs + boff[ks];
       if (TAP1) {
-        acc[0] = mfma4(a, bp[G::RS + 1], acc[0]);
+        acc[0] = mfma4(a, bp[0], acc[0]);
       } else {
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[t] = mfma4(a, bp[(t / 3) * G::RS + t % 3], acc[t]);
@@ -687,25 +706,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
 struct WsumSeg { const float* slab; float* out; float* out_b; int nrows, kind, K, first; };
 struct WsumSegs { WsumSeg s[32]; int n; int blocks; };
 __global__ __launch_bounds__(256) void wsum_kernel(const WsumSegs segs) {
+  // 256 threads = 64 float4 columns x 4 row lanes: lane g sums rows g, g + 4, ... (4 loads in flight), fixed-order fold through LDS
+  __shared__ float4 sm[4][64];
   int si = 0;
   while (si + 1 < segs.n && (int)blockIdx.x >= segs.s[si + 1].first) ++si;
   const WsumSeg sg = segs.s[si];
   const int nj = sg.kind == 3 ? (sg.K + 1 + 15) / 16 : 0;
   const int rowlen = sg.kind == 0 ? SLAB3 : sg.kind == 1 ? SLAB1 : sg.kind == 2 ? 64 : 4 * nj * 256;
-  const int e4 = ((int)blockIdx.x - sg.first) * 256 + threadIdx.x;        // float4 index inside a row
-  if (e4 * 4 >= rowlen) return;
+  const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int e4 = ((int)blockIdx.x - sg.first) * 64 + cx;        // float4 index inside a row
+  const bool in = e4 * 4 < rowlen;
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
   auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-  const float* p = sg.slab + (size_t)e4 * 4;
-  int z = 0;
-  for (; z + 3 < sg.nrows; z += 4) {
-    add(s0, *reinterpret_cast<const float4*>(p + (size_t)z * rowlen));
-    add(s1, *reinterpret_cast<const float4*>(p + (size_t)(z + 1) * rowlen));
-    add(s2, *reinterpret_cast<const float4*>(p + (size_t)(z + 2) * rowlen));
-    add(s3, *reinterpret_cast<const float4*>(p + (size_t)(z + 3) * rowlen));
+  if (in) {
+    const float* p = sg.slab + (size_t)e4 * 4;
+    int z = g;
+    for (; z + 12 < sg.nrows; z += 16) {
+      add(s0, *reinterpret_cast<const float4*>(p + (size_t)z * rowlen));
+      add(s1, *reinterpret_cast<const float4*>(p + (size_t)(z + 4) * rowlen));
+      add(s2, *reinterpret_cast<const float4*>(p + (size_t)(z + 8) * rowlen));
+      add(s3, *reinterpret_cast<const float4*>(p + (size_t)(z + 12) * rowlen));
+    }
+    for (; z < sg.nrows; z += 4) add(s0, *reinterpret_cast<const float4*>(p + (size_t)z * rowlen));
   }
-  for (; z < sg.nrows; ++z) add(s0, *reinterpret_cast<const float4*>(p + (size_t)z * rowlen));
   add(s0, s1); add(s2, s3); add(s0, s2);
+  sm[g][cx] = s0;
+  __syncthreads();
+  if (g != 0 || !in) return;
+  add(s0, sm[1][cx]); add(s0, sm[2][cx]); add(s0, sm[3][cx]);
   const float v[4] = {s0.x, s0.y, s0.z, s0.w};
   if (sg.kind == 2) { *reinterpret_cast<float4*>(sg.out + e4 * 4) = s0; return; }
   const int lane = e4 & 63, lr = lane & 15, lq = lane >> 4;
@@ -729,7 +757,7 @@ inline void wsum_add(WsumSegs& segs, const float* slab, float* out, float* out_b
   const int rowlen = kind == 0 ? SLAB3 : kind == 1 ? SLAB1 : kind == 2 ? 64 : 4 * nj * 256;
   WsumSeg& sg = segs.s[segs.n++];
   sg = WsumSeg{slab, out, out_b, nrows, kind, K, segs.blocks};
-  segs.blocks += (rowlen / 4 + 255) / 256;
+  segs.blocks += (rowlen / 4 + 63) / 64;
 }
 
 // Position splits of one job: enough workgroups to fill the chip twice over all jobs, at least 2 bands per workgroup when there are many
