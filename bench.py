@@ -136,8 +136,8 @@ def host_cpu():
 
 def cpu_baseline(w, steps=5):
     """The CPU oracle (torch-CPU fp32 restatement of the reference forward, autograd backward; kind "port") on the same synthetic
-    batch: torch threads = the host's PHYSICAL cores, median of `steps` fwd+bwd steps after one warm-up, plus ONE single-thread
-    step - a bounded sample (SURVEY §8d asks for 10 + 3; the default bench run has to finish within minutes)."""
+    batch, at 1 / 8 / 32 / all physical cores: a bounded sample per thread count (SURVEY §8d asks for median of 10 after 3
+    warm-ups; the default bench run has to finish within minutes).  `value` is the best of them, `cores` its thread count."""
     import importlib
     from oracle import ref_cpu as O
     cfg = make_cfg(w, torch.device("cpu"))
@@ -161,19 +161,24 @@ def cpu_baseline(w, steps=5):
             O.calc_loss("shapenet_1d", mu, qy).backward()
         return time.perf_counter() - t0
 
+    # torch's CPU convolutions do not scale to 128 threads on a 16-task batch (measured: 1 thread beats 128 on the 2 x 64-core
+    # host), so the baseline is taken at the BEST of a few thread counts, each a bounded sample
+    by_threads = {}
     try:
-        torch.set_num_threads(cores)
-        one()
-        times = sorted(one() for _ in range(steps))
-        med = times[len(times) // 2]
-        torch.set_num_threads(1)
-        single = one()
+        for nthr in sorted({1, 8, 32, cores} & set(range(1, cores + 1))):
+            torch.set_num_threads(nthr)
+            one()
+            times = sorted(one() for _ in range(steps if nthr in (cores, 8) else 2))
+            by_threads[nthr] = times[len(times) // 2]
     finally:
         torch.set_num_threads(prev)
-    return {"value": w["T"] / med, "unit": "meta-tasks/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
-            "single_thread_value": w["T"] / single,
-            "sample": f"{steps} fwd+bwd steps of the same {w['T']}-task 15+15 batch after 1 warm-up on {cores} threads (= physical cores), "
-                      f"median {med * 1e3:.1f} ms/step (min {times[0] * 1e3:.1f}); one step on 1 thread: {single * 1e3:.0f} ms"}
+    best = min(by_threads, key=by_threads.get)
+    return {"value": w["T"] / by_threads[best], "unit": "meta-tasks/s", "cores": best, "kind": "port", "cpu_model": cpu_model,
+            "physical_cores": cores, "single_thread_value": w["T"] / by_threads[1],
+            "tasks_per_s_by_threads": {str(k): round(w["T"] / v, 2) for k, v in by_threads.items()},
+            "sample": f"fwd+bwd steps of the same {w['T']}-task 15+15 batch, torch threads in {sorted(by_threads)} (1 warm-up each, median of "
+                      f"{steps} steps at 8 and {cores} threads, of 2 at the others); value = the best thread count ({best}): "
+                      f"{by_threads[best] * 1e3:.0f} ms/step; all {cores} physical cores: {by_threads[cores] * 1e3:.0f} ms/step"}
 
 
 def _time_graph(fn, iters):
@@ -452,6 +457,41 @@ def forward_roofline(w, fwd_ms):
                     "corresponds to >= 63 % of the fp32 MFMA peak over the whole forward"}
 
 
+def timed_region(run, steps, warmup, world, device, sync=None, record=None):
+    """The contract's timing protocol: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by fences (synchronize +
+    barrier + synchronize) on both sides; returns (seconds of the slowest rank, host enqueue seconds, last step's result).
+    `sync`: device synchronisation (torch.cuda.synchronize; a no-op for the CPU control-flow test); `record(i, 0 | 1)`: optional
+    per-step event hooks."""
+    import torch.distributed as dist
+    sync = sync or (lambda: None)
+
+    def fence():
+        sync()
+        if world > 1:
+            dist.barrier()
+            sync()
+
+    for _ in range(warmup):
+        run()
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        if record:
+            record(i, 0)
+        out = run()
+        if record:
+            record(i, 1)
+    t_enqueue = time.perf_counter() - t0
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    return elapsed, t_enqueue, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -529,12 +569,6 @@ def main():
         bucket.sync(defer_scale=True)        # the 1/world average rides in the optimizer's gradient scale (FlatAdam.step(grad_scale=...))
         return loss
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     # The step has static shapes and no host sync, so it is captured once into a hipGraph and replayed
     # (the RCCL all-reduce stays outside the graph).  --no-graph runs it eagerly.
     run = step
@@ -571,22 +605,9 @@ def main():
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             run = step
 
-    for _ in range(args.warmup):
-        run()
-    fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        loss = run()
-        ev[i][1].record()
-    t_enqueue = time.perf_counter() - t0
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed, t_enqueue, loss = timed_region(run, args.steps, args.warmup, world, device, sync=torch.cuda.synchronize,
+                                            record=lambda i, k: ev[i][k].record())
     final_loss = loss.item()
     step_ms = sorted(a.elapsed_time(b) for a, b in ev)       # device time of each step (events on the replaying stream)
     if eps is not None and eps._worker is not None:

@@ -91,3 +91,122 @@ def test_task_slice():
     assert [task_slice(128, r, 8) for r in (0, 7)] == [slice(0, 16), slice(112, 128)]
     with pytest.raises(ValueError):
         task_slice(10, 0, 4)
+
+
+# ---- the Bayes-by-backprop model under task sharding ------------------------------------------------------------
+def _bbb_worker(rank, world, port, out):
+    """Every rank seeds the torch CPU generator alike, so all ranks draw the SAME eps (hence sample the same weights), and the KL
+    term - identical on every rank - is averaged by the flat all-reduce, never summed: the sharded gradient of mean-loss + beta * kl
+    equals the full-batch gradient.  (Per-rank compute = the CPU oracle; under test: seeding rule + sharding + bucket.)"""
+    import hashlib
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "what-matters-for-meta-learning_amd"), root]
+    from oracle import ref_cpu as O
+    from mlhot import dist as mdist
+    from networks.ANPMRShapeNet3D import ANPMRShapeNet3D
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    mdist.init_from_env("gloo")
+    T, Nc, Nq, beta = 2, 2, 2, 1e-5
+    cfg = types.SimpleNamespace(device=torch.device("cpu"), seed=2578, img_size=[64, 64, 4], tasks_per_batch=T // world, input_dim=4, output_dim=4,
+                                agg_mode="attention", img_agg="reshape", task="shapenet_3d", temperature=0.07)
+    model = ANPMRShapeNet3D(cfg)                       # same seed -> same weights on every rank
+    g = torch.Generator().manual_seed(5)
+    cx, qx = torch.rand(T, Nc, 3, 64, 64, generator=g), torch.rand(T, Nq, 3, 64, 64, generator=g)
+    cy = torch.nn.functional.normalize(torch.randn(T, Nc, 4, generator=g), dim=-1)
+    qy = torch.nn.functional.normalize(torch.randn(T, Nq, 4, generator=g), dim=-1)
+
+    def grads_of(sl):
+        p = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+        torch.manual_seed(1234)                        # the rule under test: the same CPU-generator seed on every rank
+        first = torch.empty(5).normal_(0, 1)
+        torch.manual_seed(1234)
+        mu, kl = O.anpmr3d_forward(p, cx[sl], cy[sl], qx[sl])
+        (O.calc_loss("shapenet_3d", mu, qy[sl]) + beta * kl).backward()
+        return {k: p[k].grad for k, _ in model.named_parameters()}, kl.item(), hashlib.sha256(first.numpy().tobytes()).hexdigest()
+
+    full, kl_full, _ = grads_of(slice(0, T))
+    local, kl_local, eps_sha = grads_of(mdist.task_slice(T, rank, world))
+    assert abs(kl_local - kl_full) <= 1e-6 * kl_full          # the KL does not depend on the shard
+    for k, prm in model.named_parameters():
+        prm.grad = local[k].clone() if local[k] is not None else None
+    mdist.GradBucket(model.parameters()).sync()
+    live = [k for k, prm in model.named_parameters() if prm.grad is not None]
+    floor = U.GRAD_FLOOR * max(full[k].abs().max().item() for k in live)
+    # sharded-vs-full differs only through the FAVOR+ batch-global key stabiliser (SURVEY §8e(i))
+    worst = max(U.rel_err(dict(model.named_parameters())[k].grad, full[k], floor=floor) for k in live)
+    # had the KL been SUMMED over the ranks, W_rho's gradient (dominated by beta * dkl at init) would be off by ~2x
+    rho = "img_encoder.net.layer2.conv1.W_rho"
+    out[rank] = (worst, eps_sha, U.rel_err(dict(model.named_parameters())[rho].grad, full[rho]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bbb_model_sharding_same_eps_on_every_rank_and_kl_not_summed():
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_bbb_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        assert len(out) == 2
+        assert out[0][1] == out[1][1]                              # identical eps draws
+        assert max(v[0] for v in out.values()) <= 1e-4 and max(v[2] for v in out.values()) <= 1e-4, dict(out)
+
+
+# ---- bench.py's multi-rank control flow on 8 CPU ranks (the 8-GPU RCCL launch is the driver's; its protocol is checked here) ----
+def _bench_flow_worker(rank, world, port, out):
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "what-matters-for-meta-learning_amd"), root]
+    import bench
+    from mlhot import dist as mdist
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    r, local, w = mdist.init_from_env("gloo")
+    assert (r, local, w) == (rank, rank, world)
+    calls = []
+    grad = torch.full((8,), float(rank + 1))
+
+    class Bucket(mdist.GradBucket):                  # the bench's collective on a stand-in gradient
+        pass
+
+    lin = torch.nn.Linear(7, 1)
+
+    def run():                                         # a step: "compute" (the slowest rank sets the pace), then the flat all-reduce
+        time.sleep(0.002 * (1 + (rank == 3)))
+        lin.weight.grad, lin.bias.grad = grad[:7].clone().view(1, 7), grad[7:].clone()
+        scale = Bucket(lin.parameters()).sync(defer_scale=True)
+        calls.append(scale)
+        return lin.weight.grad
+
+    elapsed, enq, last = bench.timed_region(run, steps=5, warmup=2, world=world, device=torch.device("cpu"))
+    assert len(calls) == 7 and all(abs(c - 1.0 / world) < 1e-12 for c in calls)
+    assert torch.allclose(last, torch.full((1, 7), float(sum(range(1, world + 1)))))          # summed; the 1/world scale is deferred
+    out[rank] = elapsed
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timing_protocol_on_eight_ranks():
+    """bench.timed_region under 8 gloo ranks: W warm-up + exactly K timed steps between fences, the reported time is the MAX over
+    the ranks (every rank returns the same number, at least the slowest rank's compute), one deferred-scale all-reduce per step."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_bench_flow_worker, args=(r, 8, port, out)) for r in range(8)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        vals = [out[r] for r in range(8)]
+        assert max(vals) - min(vals) < 1e-9 and vals[0] >= 5 * 0.004
