@@ -2,6 +2,7 @@
 // A operands from an LDS patch with the kernel's addressing, 2 accumulators, 144 MFMAs per "band".
 //   MODE 0: as the kernel (LDS A, 72 B regs)   1: A from a register (no LDS)   2: LDS A, single B register
 //   3: LDS A with a conflict-free dense addressing (lane*4 bytes)
+//   4 / 5 / 6: as 0 with an explicit operand ring 2 / 4 / 6 k-steps deep, order pinned with sched_group_barrier
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -21,6 +22,23 @@ __global__ __launch_bounds__(768) void k(float* out, const float* w, int bands) 
   float areg = (float)tid;
   for (int b = 0; b < bands; ++b) {
     const float* ab = patch + (b & 1) * PATCH + aoff;
+    if (MODE >= 4) {
+      // explicit register ring: the operands of k-step ks + D are requested right after the MFMAs of k-step ks
+      constexpr int D = MODE == 4 ? 2 : (MODE == 5 ? 4 : 6);
+      float xa0[D], xa1[D];
+      auto off = [](int ks) { const int tap = ks >> 3, ky = tap / 3, kx = tap % 3, cg = ks & 7; return cg * 4 * PS + ky * RS + kx; };
+#pragma unroll
+      for (int d = 0; d < D; ++d) { xa0[d] = ab[off(d)]; xa1[d] = ab[off(d) + 2 * RS]; }
+#pragma unroll
+      for (int ks = 0; ks < 72; ++ks) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0[ks % D], wr[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1[ks % D], wr[ks], acc1, 0, 0, 0);
+        if (ks + D < 72) { xa0[ks % D] = ab[off(ks + D)]; xa1[ks % D] = ab[off(ks + D) + 2 * RS]; }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < 72; ++ks) {
       const int tap = ks >> 3, ky = tap / 3, kx = tap % 3, cg = ks & 7;
@@ -51,6 +69,6 @@ void run(const float* w, float* d, int bands) {
 }
 int main() {
   float *w, *d; (void)hipMalloc(&w, 48 * 288 * 4); (void)hipMalloc(&d, 4); (void)hipMemset(w, 0, 48 * 288 * 4);
-  run<0>(w, d, 150); run<1>(w, d, 150); run<2>(w, d, 150); run<3>(w, d, 150);
+  run<0>(w, d, 150); run<1>(w, d, 150); run<2>(w, d, 150); run<3>(w, d, 150); run<4>(w, d, 150); run<5>(w, d, 150); run<6>(w, d, 150);
   return 0;
 }

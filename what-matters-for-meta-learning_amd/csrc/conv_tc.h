@@ -156,59 +156,94 @@ __device__ __forceinline__ void conv1w_load(Conv1W& cw, const float* __restrict_
       cw.b[ks][h] = k < 9 ? w1[n * 9 + k] : (k == 9 ? b1[n] : 0.f);
     }
 }
-__device__ __forceinline__ void conv1a_fetch1(Conv1A& ca, int j, const ImgSrc& x, int tile, int wave, int lr, int lq) {
+// A operand (k-step ks) of M-tile t (patch row t / 4, 16 columns from 16 * (t % 4)) of band `tile`: the image pixel under
+// tap k = 4 ks + lq of position lr, 1.0 in the bias column k = 9, 0 in the padding.  A patch row above the image
+// (band 0, row 0) gets an all-zero operand row, bias column included, so its a1 comes out as exactly 0 with no select
+// behind the MFMAs.  The pixel is loaded unconditionally (index 0 when masked) and blended arithmetically
+// (v * 1 + 0 | v * 0 + c): written as a select, hipcc sinks the load into an exec-masked branch behind an s_waitcnt vmcnt(0).
+__device__ __forceinline__ float conv1a_pixel(const ImgSrc& x, int tile, int t, int ks, int lr, int lq) {
   const int img = tile >> 3, band = tile & 7;
   const float* xi = x.img(img);
-  const int t = wave + 12 * j, row = t >> 2, cg = t & 3;
+  const int row = t >> 2, cg = t & 3;
   const int iy1 = 8 * band - 1 + row;
+  const int k = 4 * ks + lq, ky = k / 3, kx = k - 3 * ky;
+  const int iy = 2 * iy1 + ky - 1, ix = 2 * (16 * cg + lr) + kx - 1;
+  const bool ok = k < 9 && iy1 >= 0 && iy >= 0 && ix >= 0;
+  const float v = xi[ok ? iy * 128 + ix : 0];
+  return __builtin_fmaf(v, ok ? 1.f : 0.f, (k == 9 && iy1 >= 0) ? 1.f : 0.f);
+}
+__device__ __forceinline__ void conv1a_fetch1(Conv1A& ca, int j, const ImgSrc& x, int tile, int wave, int lr, int lq) {
 #pragma unroll
-  for (int ks = 0; ks < 3; ++ks) {
-    const int k = 4 * ks + lq, ky = k / 3, kx = k - 3 * ky;
-    const int iy = 2 * iy1 + ky - 1, ix = 2 * (16 * cg + lr) + kx - 1;
-    const bool ok = k < 9 && iy1 >= 0 && iy >= 0 && ix >= 0;
-    const float v = xi[ok ? iy * 128 + ix : 0];          // unconditional load: no exec-mask branch in the MFMA stream
-    ca.a[j][ks] = ok ? v : (k == 9 ? 1.f : 0.f);
-  }
+  for (int ks = 0; ks < 3; ++ks) ca.a[j][ks] = conv1a_pixel(x, tile, wave + 12 * j, ks, lr, lq);
 }
 __device__ __forceinline__ void conv1a_fetch(Conv1A& ca, const ImgSrc& x, int tile, int wave, int lr, int lq) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) conv1a_fetch1(ca, j, x, tile, wave, lr, lq);
 }
-// M-tile j of this wave -> patch (+ ReLU bits of the 16 positions -> m1 when MASK)
+
+// conv1's ReLU sign bits, as the forward's accumulator layout yields them (one v_cmp per accumulator register, no
+// shuffling): record [img][a1 row][column group cg of 16] = 16 dwords; dword 4 r + 2 h + g, bit 16 e + c  <->  channel
+// 16 h + c of column 16 cg + 4 (2 g + e) + r.  (v_cmp of register r of channel half h is a 64-bit lane mask whose bit
+// 16 lq + lr is channel lr of column 4 lq + r: its two dwords are g = 0 / 1.)  The four dwords of a register go out as
+// one 16-byte store of wave-uniform values from every lane - no exec masking, no cross-lane assembly (v_writelane needs
+// inline asm, and any inline asm makes hipcc reserve a third of this kernel's 168 registers for AGPRs).  One junk
+// record behind the last image takes the row above the image.
+constexpr int M1_REC = 16;
+__device__ __forceinline__ size_t m1_record(int img, int iy1, int cg, int n_img) {
+  return iy1 >= 0 ? (((size_t)img * 64 + iy1) * 4 + cg) * M1_REC : (size_t)n_img * 4096;
+}
+
+// One conv1 M-tile in flight: 3 pixel loads -> 6 MFMAs -> ReLU + LDS store + sign bits, cut into slices that the
+// forward places between its conv2 MFMAs (every slice is a handful of VALU / LDS instructions).
+struct Conv1Tile {
+  float a[3];
+  f32x4_t c0, c1;
+};
+__device__ __forceinline__ void c1t_mfma(Conv1Tile& t, const Conv1W& cw, int i) {     // i = 0..5
+  const int ks = i >> 1;
+  const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+  if (i & 1) t.c1 = mfma4(t.a[ks], cw.b[ks][1], ks == 0 ? zero : t.c1);
+  else t.c0 = mfma4(t.a[ks], cw.b[ks][0], ks == 0 ? zero : t.c0);
+}
+// accumulator register r of both channel halves: ReLU, patch store, sign bits -> mrec (this tile's record; the halo row
+// 0 of a band rewrites the record the band above writes, with the same bits)
+template <bool MASK>
+__device__ __forceinline__ void c1t_post(Conv1Tile& t, int r, float* d, unsigned* __restrict__ mrec) {
+  const bool p0 = t.c0[r] > 0.f, p1 = t.c1[r] > 0.f;
+  d[r] = p0 ? t.c0[r] : 0.f;
+  d[16 * PS + r] = p1 ? t.c1[r] : 0.f;
+  if (MASK) {
+    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(p0), b1 = __builtin_amdgcn_ballot_w64(p1);
+    *reinterpret_cast<uint4*>(mrec + 4 * r) = make_uint4((unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32));
+  }
+}
+__device__ __forceinline__ float* c1t_dst(float* patch, int t, int lr, int lq) {
+  return patch + lr * PS + (t >> 2) * RS + 1 + 16 * (t & 3) + 4 * lq;
+}
+__device__ __forceinline__ unsigned* c1t_rec(unsigned* __restrict__ m1, int tile, int tt, int n_img) {
+  return m1 + m1_record(tile >> 3, 8 * (tile & 7) - 1 + (tt >> 2), tt & 3, n_img);
+}
+// M-tile j of this wave, start to end (prologue of the forward; the weight-gradient kernel)
 template <bool MASK>
 __device__ __forceinline__ void conv1_tile(const Conv1A& ca, const Conv1W& cw, int j, float* patch, int tile, int wave, int lane,
-                                           unsigned* __restrict__ m1) {
-  const int lr = lane & 15, lq = lane >> 4;
-  const int t = wave + 12 * j, row = t >> 2, cg = t & 3;
-  const int iy1 = 8 * (tile & 7) - 1 + row;
-  const bool valid = iy1 >= 0;
-  f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+                                           unsigned* __restrict__ m1, int n_img) {
+  const int lr = lane & 15, lq = lane >> 4, tt = wave + 12 * j;
+  Conv1Tile t;
 #pragma unroll
-  for (int ks = 0; ks < 3; ++ks) {
-    c0 = mfma4(ca.a[j][ks], cw.b[ks][0], c0);
-    c1 = mfma4(ca.a[j][ks], cw.b[ks][1], c1);
-  }
-  float* d = patch + lr * PS + row * RS + 1 + 16 * cg + 4 * lq;
+  for (int ks = 0; ks < 3; ++ks) t.a[ks] = ca.a[j][ks];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    d[r] = valid ? fmaxf(c0[r], 0.f) : 0.f;
-    d[16 * PS + r] = valid ? fmaxf(c1[r], 0.f) : 0.f;
-  }
-  if (MASK) {
-    // ballot bit 16*lq + lr of register r = (channel lr (+16) of position 4*lq + r) > 0; lane p < 16 assembles
-    // the 32 channel bits of position p = 4*lq' + r'
-    unsigned long long lo = 0, hi = 0;
-    const int rsel = lane & 3;
+  for (int i = 0; i < 6; ++i) c1t_mfma(t, cw, i);
+  float* d = c1t_dst(patch, tt, lr, lq);
+  unsigned* mrec = MASK ? c1t_rec(m1, tile, tt, n_img) : nullptr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned long long b0 = __builtin_amdgcn_ballot_w64(c0[r] > 0.f);
-      const unsigned long long b1v = __builtin_amdgcn_ballot_w64(c1[r] > 0.f);
-      if (rsel == r) { lo = b0; hi = b1v; }
-    }
-    const int sh = 16 * ((lane >> 2) & 3);
-    const unsigned word = (unsigned)((lo >> sh) & 0xffffull) | ((unsigned)((hi >> sh) & 0xffffull) << 16);
-    if (lane < 16 && row >= 1) m1[((size_t)(tile >> 3) * 64 + iy1) * 64 + 16 * cg + lane] = word;
-  }
+  for (int r = 0; r < 4; ++r) c1t_post<MASK>(t, r, d, mrec);
+}
+
+// cache line li (< 76, clamped) of the 19-row image strip under band `tile`: rows 16 band - 3 .. 16 band + 15, 4 lines per row
+__device__ __forceinline__ float strip_line(const ImgSrc& x, int tile, int li) {
+  li = min(li, 75);
+  const int row = min(max(16 * (tile & 7) - 3 + (li >> 2), 0), 127);
+  return x.img(tile >> 3)[row * 128 + 32 * (li & 3)];
 }
 
 __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -220,8 +255,6 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
   const int lr = lane & 15, lq = lane >> 4;
   const int n = nt * 16 + lr;
-  const bool cact = !(dbg & 1);
-  const int phase = __builtin_amdgcn_readfirstlane(wave >> 2);
 
   float wr[72];
 #pragma unroll
@@ -237,54 +270,68 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
 #ifdef MLHOT_TS
   long long ts_c0 = clock64(), ts_w0 = wall_clock64();
 #endif
-  Conv1A ca;
-  if (tile < ntiles && cact) {
+  if (tile < ntiles) {
+    Conv1A ca;
     conv1a_fetch(ca, x, tile, wave, lr, lq);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) conv1_tile<true>(ca, cw, j, patch2, tile, wave, lane, m1);
+    for (int j = 0; j < 3; ++j) conv1_tile<true>(ca, cw, j, patch2, tile, wave, lane, m1, n_img);
   }
   __syncthreads();
   const int aoff = lq * PS + (4 * rp) * RS + 2 * (16 * ch + lr);
   int cur = 0;
+  // The pixels of a conv1 tile are asked for ~1.5 k cycles before its MFMAs: enough for an L1 / L2 hit, not for HBM (the
+  // 8 bands of an image run on 8 workgroups at the same time, so the first touch of a strip is a miss for all of them:
+  // measured: 162.3 us without, 158.9 us with this).  So two waves touch the 76 cache lines of the band after next (19 image rows
+  // x 512 B) once the last pixel request of this band is out, 24 k-steps before the first request for that strip.
+  float warm = 0.f;
+  if (wave < 2 && tile + (int)gridDim.x < ntiles) warm = strip_line(x, tile + (int)gridDim.x, tid);
   for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
     const float* ab = patch2 + cur * PATCH_FLOATS + aoff;
     float* nb = patch2 + (cur ^ 1) * PATCH_FLOATS;
-    const int next = tile + (int)gridDim.x;
-    const bool stage = next < ntiles && cact;
+    // the next band's a1 slice (3 M-tiles per wave) is produced under this band's MFMAs.  The workgroup's last band
+    // produces its own slice once more instead of branching around the slices (same values to the same sign-bit
+    // records, an LDS buffer nobody reads): the band body stays one straight line.
+    const int next = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
 
 #ifdef MLHOT_TS
     const bool tsb = tf::g_ts_dev && blockIdx.x == 0 && (tile - (int)blockIdx.x) / (int)gridDim.x == 6;   // 7th band of workgroup 0
     if (tsb && (lane == 0)) tf::g_ts_dev[400 + wave * 4 + 0] = clock64();
 #endif
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // 9 segments of 16 MFMAs.  The next band's a1 slice (3 M-tiles per wave) is produced after segments 3j + phase,
-    // phase = wave / 4, so the three waves that share a SIMD (w, w + 4, w + 8) post-process their conv1 tiles (ReLU,
-    // LDS stores, sign bits) in different segments; each tile's pixels are requested two segments ahead.
-    if (stage) {
+    // 72 k-steps of 2 MFMAs.  Their A operands run through a register ring RD k-steps deep (left alone, hipcc reads each
+    // pair right before its MFMAs and waits lgkmcnt(0) on it: conv2 loop in isolation 131 -> 142 TF, scripts/micro/conv2_loop).
+    // conv1 tile j of the next band rides along in fixed slots: pixels requested at k-steps 22j .. 22j+2, its 6 MFMAs one per
+    // k-step from 22j+8, ReLU / patch store / sign bits one accumulator register per k-step from 22j+15.  Every k-step is fenced for the scheduler, so each wave's VALU / LDS work sits in the shadow of its own MFMAs
+    // and no wave ever leaves the matrix pipe for a long stretch.
+    constexpr int RD = 4;
+    // two base pointers (channel groups 0-3 | 4-7) keep every operand offset inside ds_read's 16-bit immediate
+    const float* ab4 = ab + 16 * PS;
+    auto aread = [&](int ks, int row2) {
+      const int tap = ks >> 3, ky = tap / 3, kx = tap % 3, cg = ks & 7;
+      return (cg < 4 ? ab : ab4)[(cg & 3) * 4 * PS + (ky + row2) * RS + kx];
+    };
+    float xa0[RD], xa1[RD];
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (3 * j + phase - 2 < 0) conv1a_fetch1(ca, j, x, next, wave, lr, lq);
-    }
+    for (int d = 0; d < RD; ++d) { xa0[d] = aread(d, 0); xa1[d] = aread(d, 2); }
+    Conv1Tile ct;
+    float bnw = bn;
 #pragma unroll
-    for (int seg = 0; seg < 9; ++seg) {
-      // rotate the issue priority among the three waves of a SIMD once per segment
-      set_wave_prio((phase + seg) % 3);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int ks = seg * 8 + q;
-        const int tap = ks >> 3, ky = tap / 3, kx = tap % 3, cg = ks & 7;
-        const float x0 = ab[cg * 4 * PS + ky * RS + kx];
-        const float x1 = ab[cg * 4 * PS + (2 + ky) * RS + kx];
-        acc0 = mfma4(x0, wr[ks], acc0);
-        acc1 = mfma4(x1, wr[ks], acc1);
+    for (int ks = 0; ks < 72; ++ks) {
+      acc0 = mfma4(xa0[ks % RD], wr[ks], acc0);
+      acc1 = mfma4(xa1[ks % RD], wr[ks], acc1);
+      if (ks + RD < 72) { xa0[ks % RD] = aread(ks + RD, 0); xa1[ks % RD] = aread(ks + RD, 2); }
+      const int j = ks / 22, s = ks - 22 * j;          // j = 3 for ks >= 66: no slot
+      if (j < 3) {
+        const int tt = wave + 12 * j;
+        if (s < 3) ct.a[s] = conv1a_pixel(x, next, tt, s, lr, lq);
+        else if (s >= 8 && s < 14) c1t_mfma(ct, cw, s - 8);
+        else if (s >= 15 && s < 19) c1t_post<true>(ct, s - 15, c1t_dst(nb, tt, lr, lq), c1t_rec(m1, next, tt, n_img));
       }
-      if (stage) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          if (seg == 3 * j + phase - 2) conv1a_fetch1(ca, j, x, next, wave, lr, lq);
-          if (seg == 3 * j + phase) conv1_tile<true>(ca, cw, j, nb, next, wave, lane, m1);
-        }
-      }
+      // the warmed line has to be consumed somewhere or the load is dead code: it rides into the epilogue's bias as + 0 * pixel,
+      // at the k-step where the wait for it costs nothing (inline asm would do, but see m1_record's note on AGPRs)
+      if (ks == 7) bnw = __builtin_fmaf(warm, 0.f, bn);
+      if (ks == 48 && wave < 2) warm = strip_line(x, next + (int)gridDim.x < ntiles ? next + (int)gridDim.x : next, tid);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef MLHOT_TS
     if (tsb && (lane == 0)) tf::g_ts_dev[400 + wave * 4 + 1] = clock64();
@@ -293,8 +340,8 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     float pv[2]; unsigned pa[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const float c0 = fmaxf(acc0[2 * j] + bn, 0.f), c1 = fmaxf(acc0[2 * j + 1] + bn, 0.f);
-      const float c2v = fmaxf(acc1[2 * j] + bn, 0.f), c3 = fmaxf(acc1[2 * j + 1] + bn, 0.f);
+      const float c0 = fmaxf(acc0[2 * j] + bnw, 0.f), c1 = fmaxf(acc0[2 * j + 1] + bnw, 0.f);
+      const float c2v = fmaxf(acc1[2 * j] + bnw, 0.f), c3 = fmaxf(acc1[2 * j + 1] + bnw, 0.f);
       float best = c0; unsigned which = 0;
       if (c1 > best) { best = c1; which = 1; }
       if (c2v > best) { best = c2v; which = 2; }
@@ -368,7 +415,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
     __syncthreads();
     if (cact) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) conv1_tile<false>(ca, cw, j, patch, tile, wave, lane, nullptr);
+      for (int j = 0; j < 3; ++j) conv1_tile<false>(ca, cw, j, patch, tile, wave, lane, nullptr, n_img);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -455,9 +502,11 @@ __device__ __forceinline__ void dgrad12_row(const float* dyp, const float* strip
   // unfenced, hipcc hoists all ~150 LDS operand reads of a row to the top (408 registers).
 #pragma unroll 1
   for (int xh = 0; xh < 2; ++xh) {
-    // conv1 ReLU bits of the 8 positions this lane will hold (x0 .. x0+7, x0 = 32xh + 8lq)
-    const uint4 mb0 = *reinterpret_cast<const uint4*>(mrow + 32 * xh + 8 * lq);
-    const uint4 mb1 = *reinterpret_cast<const uint4*>(mrow + 32 * xh + 8 * lq + 4);
+    // conv1 ReLU bits of the 8 positions this lane will hold (x0 .. x0+7, x0 = 32xh + 8lq): column group 2xh + lq/2,
+    // dwords 4 r' + 2 (ci / 16) + lq % 2 of its record, bit 16 e + ci % 16 for column offset 8 (lq % 2) + 4 e + r'
+    const unsigned* mrec = mrow + (2 * xh + (lq >> 1)) * M1_REC + 2 * (ci >> 4) + (lq & 1);
+    uint4 mb;
+    mb.x = mrec[0]; mb.y = mrec[4]; mb.z = mrec[8]; mb.w = mrec[12];
     f32x4_t e = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
     const float* base = dyp + lq * DPS + yp * DRS + 16 * xh + lr;
     constexpr int NTY = PY ? 2 : 1;
@@ -478,11 +527,11 @@ __device__ __forceinline__ void dgrad12_row(const float* dyp, const float* strip
     // lane: channel ci, positions x = x0 + 2r + px.  Mask, then Z += g^T T on the matrix core:
     // MFMA r of parity px has A = g[row 4lq+r][ci] (this lane's register) and needs
     // B[k = lq][n = tap lr] = T[position x' = 16xh + 4lq + r][tap] = strip[(2yl+ky)][2x + kx], x = 2x' + px.
-    const unsigned bit = 1u << ci;
-    e[0] = (mb0.x & bit) ? e[0] : 0.f; d[0] = (mb0.y & bit) ? d[0] : 0.f;
-    e[1] = (mb0.z & bit) ? e[1] : 0.f; d[1] = (mb0.w & bit) ? d[1] : 0.f;
-    e[2] = (mb1.x & bit) ? e[2] : 0.f; d[2] = (mb1.y & bit) ? d[2] : 0.f;
-    e[3] = (mb1.z & bit) ? e[3] : 0.f; d[3] = (mb1.w & bit) ? d[3] : 0.f;
+    const unsigned lo = 1u << (ci & 15), hi = lo << 16;
+    e[0] = (mb.x & lo) ? e[0] : 0.f; d[0] = (mb.y & lo) ? d[0] : 0.f;
+    e[1] = (mb.z & lo) ? e[1] : 0.f; d[1] = (mb.w & lo) ? d[1] : 0.f;
+    e[2] = (mb.x & hi) ? e[2] : 0.f; d[2] = (mb.y & hi) ? d[2] : 0.f;
+    e[3] = (mb.z & hi) ? e[3] : 0.f; d[3] = (mb.w & hi) ? d[3] : 0.f;
     const float* tp = strip + (2 * yl) * SRS + toff + 4 * (16 * xh + 4 * lq);      // + 4r + 2px below
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

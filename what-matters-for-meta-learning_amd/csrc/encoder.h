@@ -36,7 +36,7 @@ inline EncSaved enc_saved_carve(int n, void* base, size_t cap) {
   s.p2 = a.take<float>((size_t)n * 48 * 16 * 16);
   s.am2 = a.take<uint8_t>((size_t)n * 48 * 16 * 16);
   s.a3 = a.take<float>((size_t)n * 4096);
-  s.m1 = a.take<unsigned>((size_t)n * 64 * 64);     // conv1 ReLU bits (bit ci of word [y][x]), written by the fused forward
+  s.m1 = a.take<unsigned>((size_t)n * 64 * 64 + 16);     // conv1 ReLU bits (16-dword records per 16 columns + one junk record, conv_tc.h m1_record), written by the fused forward
   s.ok = a.ok; s.bytes = a.off + 256;
   return s;
 }

@@ -256,9 +256,12 @@ class MlhotLib:
         o = al(o + n * 48 * 256 * 4)
         o = al(o + n * 48 * 256)
         o = al(o + n * 4096 * 4)
-        words = saved[o:o + n * 4096 * 4].view(torch.int32).view(n, 64, 64).cpu()
-        bits = torch.arange(32, dtype=torch.int32).view(1, 32, 1, 1)
-        m1 = ((words.unsqueeze(1) >> bits) & 1).float()
+        # records [img][row][column group cg][dword 4r + 2h + g], bit 16e + c = channel 16h + c of column 16cg + 4(2g + e) + r
+        # (csrc/conv_tc.h m1_record)
+        words = saved[o:o + n * 4096 * 4].view(torch.int32).view(n, 64, 4, 4, 2, 2, 1, 1).cpu()      # n, y, cg, r, h, g
+        shifts = (16 * torch.arange(2, dtype=torch.int32).view(2, 1) + torch.arange(16, dtype=torch.int32).view(1, 16))
+        bits = (words >> shifts) & 1                                                                # n, y, cg, r, h, g, e, c
+        m1 = bits.permute(0, 4, 7, 1, 2, 5, 6, 3).reshape(n, 32, 64, 64).float()                   # n, (h c), y, (cg g e r)
         return m1, am2.cpu(), (p2 > 0).float().cpu(), (a3 > 0).float().cpu()
 
     @staticmethod
