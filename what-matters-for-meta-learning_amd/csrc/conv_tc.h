@@ -181,6 +181,35 @@ __device__ __forceinline__ void conv1a_fetch(Conv1A& ca, const ImgSrc& x, int ti
   for (int j = 0; j < 3; ++j) conv1a_fetch1(ca, j, x, tile, wave, lr, lq);
 }
 
+// The same operand with everything that does not change from band to band folded into three per-lane byte offsets
+// (the forward's in-loop pixel requests: every VALU instruction beside fp32 MFMAs costs ~2.3 matrix-pipe cycles,
+// scripts/micro/conv2_loop modes 7-10, so the ~20 instructions of conv1a_pixel's index arithmetic per request matter).
+// Tile j of a wave is 3 patch rows below tile j - 1 in the same 16 columns, so request (j, ks) of band b sits at byte
+// d[ks] + 4 (768 j + 2048 b) of the image; padding lanes (k > 9, the column left of the image) carry a large negative d,
+// rows above the image come out negative by themselves, and a negative offset is the `masked` test.
+struct Conv1Lane {
+  int d[3];          // byte offset of tile 0's tap k = 4 ks + lq in band 0, or very negative
+  float k9;          // 1.0 in the bias column's lanes (k = 9: ks = 2, lq = 1)
+};
+__device__ __forceinline__ void conv1lane_init(Conv1Lane& cl, int wave, int lr, int lq) {
+  const int row0 = wave >> 2, cg = wave & 3;
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int k = 4 * ks + lq, ky = k / 3, kx = k - 3 * ky;
+    const int ix = 2 * (16 * cg + lr) + kx - 1;
+    cl.d[ks] = (k < 9 && ix >= 0) ? 4 * ((2 * (row0 - 1) + ky - 1) * 128 + ix) : -(1 << 28);
+  }
+  cl.k9 = lq == 1 ? 1.f : 0.f;
+}
+__device__ __forceinline__ float conv1a_pixel_fast(const Conv1Lane& cl, const ImgSrc& x, int tile, int j, int ks, int row0) {
+  const int band = tile & 7;
+  const char* xi = reinterpret_cast<const char*>(x.img(tile >> 3));
+  const int off = cl.d[ks] + 4 * (768 * j + 2048 * band);
+  const float v = *reinterpret_cast<const float*>(xi + max(off, 0));
+  const bool rowok = band > 0 || row0 + 3 * j > 0;              // wave-uniform: the patch row is inside the image
+  return __builtin_fmaf(v, off >= 0 ? 1.f : 0.f, (ks == 2 && rowok) ? cl.k9 : 0.f);
+}
+
 // conv1's ReLU sign bits, as the forward's accumulator layout yields them (one v_cmp per accumulator register, no
 // shuffling): record [img][a1 row][column group cg of 16] = 16 dwords; dword 4 r + 2 h + g, bit 16 e + c  <->  channel
 // 16 h + c of column 16 cg + 4 (2 g + e) + r.  (v_cmp of register r of channel half h is a 64-bit lane mask whose bit
@@ -262,6 +291,8 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   const float bn = bias[n];
   Conv1W cw;
   conv1w_load(cw, w1, b1, lr, lq);
+  Conv1Lane cl;
+  conv1lane_init(cl, wave, lr, lq);
 
   patch_zero_pad(patch2, tid);
   patch_zero_pad(patch2 + PATCH_FLOATS, tid);
@@ -303,7 +334,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     // conv1 tile j of the next band rides along in fixed slots: pixels requested at k-steps 22j .. 22j+2, its 6 MFMAs one per
     // k-step from 22j+8, ReLU / patch store / sign bits one accumulator register per k-step from 22j+15.  Every k-step is fenced for the scheduler, so each wave's VALU / LDS work sits in the shadow of its own MFMAs
     // and no wave ever leaves the matrix pipe for a long stretch.
-    constexpr int RD = 4;
+    constexpr int RD = 4;          // 6 measured 2 us slower
     // two base pointers (channel groups 0-3 | 4-7) keep every operand offset inside ds_read's 16-bit immediate
     const float* ab4 = ab + 16 * PS;
     auto aread = [&](int ks, int row2) {
@@ -323,7 +354,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
       const int j = ks / 22, s = ks - 22 * j;          // j = 3 for ks >= 66: no slot
       if (j < 3) {
         const int tt = wave + 12 * j;
-        if (s < 3) ct.a[s] = conv1a_pixel(x, next, tt, s, lr, lq);
+        if (s < 3) ct.a[s] = conv1a_pixel_fast(cl, x, next, j, s, wave >> 2);
         else if (s >= 8 && s < 14) c1t_mfma(ct, cw, s - 8);
         else if (s >= 15 && s < 19) c1t_post<true>(ct, s - 15, c1t_dst(nb, tt, lr, lq), c1t_rec(m1, next, tt, n_img));
       }
