@@ -217,6 +217,9 @@ __device__ __forceinline__ float conv1a_pixel_fast(const Conv1Lane& cl, const Im
 // one 16-byte store of wave-uniform values from every lane - no exec masking, no cross-lane assembly (v_writelane needs
 // inline asm, and any inline asm makes hipcc reserve a third of this kernel's 168 registers for AGPRs).  One junk
 // record behind the last image takes the row above the image.
+#ifndef C12_PRIO
+#define C12_PRIO 24
+#endif
 constexpr int M1_REC = 16;
 __device__ __forceinline__ size_t m1_record(int img, int iy1, int cg, int n_img) {
   return iy1 >= 0 ? (((size_t)img * 64 + iy1) * 4 + cg) * M1_REC : (size_t)n_img * 4096;
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
   const int lr = lane & 15, lq = lane >> 4;
   const int n = nt * 16 + lr;
+  const int phase = __builtin_amdgcn_readfirstlane(wave >> 2);
 
   float wr[72];
 #pragma unroll
@@ -348,6 +352,11 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     float bnw = bn;
 #pragma unroll
     for (int ks = 0; ks < 72; ++ks) {
+#if C12_PRIO
+      // rotate the issue priority among the three waves of a SIMD (w, w + 4, w + 8): left at equal priority the oldest wave
+      // wins the matrix pipe, finishes its band ~25 % early and idles at the barrier while the youngest runs the tail alone
+      if (ks % C12_PRIO == 0) set_wave_prio((phase + ks / C12_PRIO) % 3);
+#endif
       acc0 = mfma4(xa0[ks % RD], wr[ks], acc0);
       acc1 = mfma4(xa1[ks % RD], wr[ks], acc1);
       if (ks + RD < 72) { xa0[ks % RD] = aread(ks + RD, 0); xa1[ks % RD] = aread(ks + RD, 2); }
