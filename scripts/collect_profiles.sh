@@ -5,7 +5,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof
-TAG=${1:-r01_final}
+TAG=${1:-r02_final}
 mkdir -p $OUT
 cd $REPO
 python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench_c3.json 2> $OUT/bench_c3.err
@@ -17,10 +17,11 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_write.log 2>&1
 # SQ / GRBM pass: MFMA-pipe busy cycles and the wave-cycle split (active / issue-stalled / parked) of the hot kernels
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o sq -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_sq.log 2>&1
-# BASELINE config c5's per-GPU step (ANPMRShapeNet3D): informational line + kernel stats
+# BASELINE config c5's per-GPU step (ANPMRShapeNet3D, bench.py --workload c5): bench line, per-label kernel times, kernel stats
 cd $REPO
-python scripts/bench_c5.py 2> $OUT/bench_c5.err | tail -1 > $OUT/${TAG}_bench_c5.json
+python bench.py --workload c5 --steps 30 --warmup 5 > $OUT/${TAG}_bench_c5.json 2> $OUT/bench_c5.err
+MLHOT_BENCH_KERNELS=$OUT/${TAG}_kernels_c5.json python bench.py --workload c5 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o stats -- python3 $REPO/scripts/bench_c5.py > $OUT/stats_c5.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o stats -- python3 $REPO/bench.py --workload c5 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/stats_c5.log 2>&1
 find $OUT -name "*.csv" | head -20
 ls -la $OUT

@@ -210,6 +210,13 @@ __device__ __forceinline__ float conv1a_pixel_fast(const Conv1Lane& cl, const Im
   return __builtin_fmaf(v, off >= 0 ? 1.f : 0.f, (ks == 2 && rowok) ? cl.k9 : 0.f);
 }
 
+__device__ __forceinline__ void conv1a_fetch_fast(Conv1A& ca, const Conv1Lane& cl, const ImgSrc& x, int tile, int wave) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) ca.a[j][ks] = conv1a_pixel_fast(cl, x, tile, j, ks, wave >> 2);
+}
+
 // conv1's ReLU sign bits, as the forward's accumulator layout yields them (one v_cmp per accumulator register, no
 // shuffling): record [img][a1 row][column group cg of 16] = 16 dwords; dword 4 r + 2 h + g, bit 16 e + c  <->  channel
 // 16 h + c of column 16 cg + 4 (2 g + e) + r.  (v_cmp of register r of channel half h is a 64-bit lane mask whose bit
@@ -217,9 +224,6 @@ __device__ __forceinline__ float conv1a_pixel_fast(const Conv1Lane& cl, const Im
 // one 16-byte store of wave-uniform values from every lane - no exec masking, no cross-lane assembly (v_writelane needs
 // inline asm, and any inline asm makes hipcc reserve a third of this kernel's 168 registers for AGPRs).  One junk
 // record behind the last image takes the row above the image.
-#ifndef C12_PRIO
-#define C12_PRIO 24
-#endif
 constexpr int M1_REC = 16;
 __device__ __forceinline__ size_t m1_record(int img, int iy1, int cg, int n_img) {
   return iy1 >= 0 ? (((size_t)img * 64 + iy1) * 4 + cg) * M1_REC : (size_t)n_img * 4096;
@@ -352,11 +356,10 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     float bnw = bn;
 #pragma unroll
     for (int ks = 0; ks < 72; ++ks) {
-#if C12_PRIO
       // rotate the issue priority among the three waves of a SIMD (w, w + 4, w + 8): left at equal priority the oldest wave
       // wins the matrix pipe, finishes its band ~25 % early and idles at the barrier while the youngest runs the tail alone
-      if (ks % C12_PRIO == 0) set_wave_prio((phase + ks / C12_PRIO) % 3);
-#endif
+      // (three turns per band measured best: 153 / 155 / 152 / 151 us for none / every 4 / 8 / 24 k-steps)
+      if (ks % 24 == 0) set_wave_prio((phase + ks / 24) % 3);
       acc0 = mfma4(xa0[ks % RD], wr[ks], acc0);
       acc1 = mfma4(xa1[ks % RD], wr[ks], acc1);
       if (ks + RD < 72) { xa0[ks % RD] = aread(ks + RD, 0); xa1[ks % RD] = aread(ks + RD, 2); }
@@ -442,7 +445,9 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
     }
   };
   int tile = blockIdx.x;
-  if (tile < ntiles) { if (cact) conv1a_fetch(ca, x, tile, wave, lr, lq); cells_fetch(tile); }
+  Conv1Lane cl;
+  conv1lane_init(cl, wave, lr, lq);
+  if (tile < ntiles) { if (cact) conv1a_fetch_fast(ca, cl, x, tile, wave); cells_fetch(tile); }
   int aoff[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -467,8 +472,10 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
         dyt[((2 * pyl + (q >> 1)) * 32 + 2 * px + (q & 1)) * DS + co] = (cam[j] == (unsigned)q) ? g : 0.f;
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) { if (cact) conv1a_fetch(ca, x, tile + gridDim.x, wave, lr, lq); cells_fetch(tile + gridDim.x); }
+    if (tile + (int)gridDim.x < ntiles) { if (cact) conv1a_fetch_fast(ca, cl, x, tile + gridDim.x, wave); cells_fetch(tile + gridDim.x); }
 
+    // 16 k-steps of 9 MFMAs (an explicit operand ring and the forward's priority rotation were measured here: 152.1 us as is,
+    // 153.5 / 153.4 / 155.8 us with ring / rotation / both - this loop already issues one LDS read per three MFMAs)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int orow_l = s >> 3, oxb = s & 7;
