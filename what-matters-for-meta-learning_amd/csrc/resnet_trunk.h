@@ -259,21 +259,33 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
     }
     MLHOT_TRY(rw::stem_wgrad_dispatch(C, H, jobs, s, "trunk.bwd.stem.wgrad"));
   }
-  // fold the slabs: one launch per weight set (all its convolutions' weights and biases)
-  for (int w = 0; w < n_wset; ++w) {
-    rw::WsumSegs segs{};
-    if (next_row[w][0] > 0 && ws[w].dw[0]) rw::wsum_add(segs, sc.slab[w][0], ws[w].dw[0], ws[w].db[0], next_row[w][0], 3, 25 * lv.C);
-    for (int c = 1; c < NCONV; ++c) {
-      if (next_row[w][c] <= 0 || !ws[w].dw[c]) continue;
-      rw::wsum_add(segs, sc.slab[w][c], ws[w].dw[c], nullptr, next_row[w][c], (c % 3 == 0 && ws[w].skip_k == 1) ? 1 : 0);
-      if (ws[w].db[c]) rw::wsum_add(segs, sc.slab_b[w][c], ws[w].db[c], nullptr, next_row[w][c], 2);
-    }
+  // fold the slabs: every convolution's weight and bias gradient of every weight set in one launch (a second one only if the
+  // segment table overflows its kernel-argument block)
+  rw::WsumSegs segs{};
+  segs.base = static_cast<const float*>(scratch);
+  auto flush = [&]() -> int {
     if (segs.blocks > 0) {
       ProfScope pr("trunk.bwd.wsum", s);
       hipLaunchKernelGGL(rw::wsum_kernel, dim3(segs.blocks), dim3(256), 0, s, segs);
       MLHOT_TRY(check_launch("trunk.bwd.wsum"));
     }
+    segs.n = 0; segs.blocks = 0;
+    return MLHOT_OK;
+  };
+  auto add = [&](const float* slab, float* out, float* out_b, int nrows, int kind, int K) -> int {
+    if (segs.n >= rw::WSUM_MAX) MLHOT_TRY(flush());
+    if (!rw::wsum_add(segs, slab, out, out_b, nrows, kind, K)) { set_error("resnet trunk bwd: slab does not fit the fold table"); return MLHOT_ERR_ARG; }
+    return MLHOT_OK;
+  };
+  for (int w = 0; w < n_wset; ++w) {
+    if (next_row[w][0] > 0 && ws[w].dw[0]) MLHOT_TRY(add(sc.slab[w][0], ws[w].dw[0], ws[w].db[0], next_row[w][0], 3, 25 * lv.C));
+    for (int c = 1; c < NCONV; ++c) {
+      if (next_row[w][c] <= 0 || !ws[w].dw[c]) continue;
+      MLHOT_TRY(add(sc.slab[w][c], ws[w].dw[c], nullptr, next_row[w][c], (c % 3 == 0 && ws[w].skip_k == 1) ? 1 : 0, 0));
+      if (ws[w].db[c]) MLHOT_TRY(add(sc.slab_b[w][c], ws[w].db[c], nullptr, next_row[w][c], 2, 0));
+    }
   }
+  MLHOT_TRY(flush());
   return MLHOT_OK;
 }
 

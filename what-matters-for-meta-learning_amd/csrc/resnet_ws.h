@@ -703,8 +703,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
 //   kind 1: 1x1 weight  dW[co][ci]        from rows of SLAB1 floats
 //   kind 2: bias        db[co]            from rows of 64 floats (plain)
 //   kind 3: stem weight dW[co][K] (+ db)  from rows of 4 * NJ * 256 floats ([w][j][lane][r]: co = 16w + 4(lane>>4) + r, n = 16j + (lane&15))
-struct WsumSeg { const float* slab; float* out; float* out_b; int nrows, kind, K, first; };
-struct WsumSegs { WsumSeg s[32]; int n; int blocks; };
+// 32 bytes per segment so that every fold of a backward (3 weight sets x 31 tensors for BASELINE c5) fits ONE launch's 4 KB of
+// kernel arguments: the slab is an offset into the caller's scratch block.
+struct WsumSeg { float* out; float* out_b; unsigned slab_off; int first; unsigned short nrows; unsigned char kind, K; };
+constexpr int WSUM_MAX = 100;
+struct WsumSegs { WsumSeg s[WSUM_MAX]; const float* base; int n; int blocks; };
+static_assert(sizeof(WsumSegs) <= 4000, "kernel argument block");
 __global__ __launch_bounds__(256) void wsum_kernel(const WsumSegs segs) {
   // 256 threads = 64 float4 columns x 4 row lanes: lane g sums rows g, g + 4, ... (4 loads in flight), fixed-order fold through LDS
   __shared__ float4 sm[4][64];
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(256) void wsum_kernel(const WsumSegs segs) {
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
   auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
   if (in) {
-    const float* p = sg.slab + (size_t)e4 * 4;
+    const float* p = segs.base + sg.slab_off + (size_t)e4 * 4;
     int z = g;
     for (; z + 12 < sg.nrows; z += 16) {
       add(s0, *reinterpret_cast<const float4*>(p + (size_t)z * rowlen));
@@ -752,12 +756,15 @@ __global__ __launch_bounds__(256) void wsum_kernel(const WsumSegs segs) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) sg.out[((size_t)(16 * w + 4 * lq + r) * CH + 16 * q + lr) * nt + t] = v[r];
 }
-inline void wsum_add(WsumSegs& segs, const float* slab, float* out, float* out_b, int nrows, int kind, int K = 0) {
+inline bool wsum_add(WsumSegs& segs, const float* slab, float* out, float* out_b, int nrows, int kind, int K = 0) {
   const int nj = kind == 3 ? (K + 1 + 15) / 16 : 0;
   const int rowlen = kind == 0 ? SLAB3 : kind == 1 ? SLAB1 : kind == 2 ? 64 : 4 * nj * 256;
+  const size_t off = (size_t)(slab - segs.base);
+  if (segs.n >= WSUM_MAX || nrows > 65535 || K > 255 || slab < segs.base || off > 0xffffffffu) return false;
   WsumSeg& sg = segs.s[segs.n++];
-  sg = WsumSeg{slab, out, out_b, nrows, kind, K, segs.blocks};
+  sg = WsumSeg{out, out_b, (unsigned)off, segs.blocks, (unsigned short)nrows, (unsigned char)kind, (unsigned char)K};
   segs.blocks += (rowlen / 4 + 63) / 64;
+  return true;
 }
 
 // Position splits of one job: enough workgroups to fill the chip twice over all jobs, at least 2 bands per workgroup when there are many
