@@ -63,6 +63,15 @@ inline int conv_hin(const Levels& lv, int conv) {        // input size of conv i
 }
 inline int conv_stride(int conv) { return (conv - 1) % 3 == 1 ? 1 : 2; }
 
+// the band total a job's slab rows are planned against: the 1x1 skips of a step share a launch of their own (skip1_wgrad_kernel),
+// so they split ITS workgroups among themselves, not those of a launch that also serves the other passes
+inline int skip1_total(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk_wset* ws, int p, int conv, const int* bands, int total) {
+  if (conv % 3 != 0 || ws[ps[p].wset].skip_k != 1) return total;
+  int t = 0;
+  for (int i = 0; i < n_pass; ++i) if (ws[ps[i].wset].skip_k == 1) t += bands[i];
+  return t;
+}
+
 inline TrunkScratch trunk_carve(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk_wset* ws, int n_wset, const Levels& lv, bool backward,
                                 void* base, size_t cap) {
   Arena a(base, cap);
@@ -85,7 +94,7 @@ inline TrunkScratch trunk_carve(const mlhot_trunk_pass* ps, int n_pass, const ml
         total += bands[p];
       }
       for (int w = 0; w < n_wset; ++w) s.rows[w][c] = 0;
-      for (int p = 0; p < n_pass; ++p) s.rows[ps[p].wset][c] += c == 0 ? wg_rows(bands[p], total, 512) : wg_rows(bands[p], total);
+      for (int p = 0; p < n_pass; ++p) s.rows[ps[p].wset][c] += c == 0 ? wg_rows(bands[p], total, 512) : wg_rows(bands[p], skip1_total(ps, n_pass, ws, p, c, bands, total));
       for (int w = 0; w < n_wset; ++w) {
         const size_t rowlen = c == 0 ? (size_t)rw::stem_slab_row(lv.C) : ((c % 3 == 0 && ws[w].skip_k == 1) ? rw::SLAB1 : rw::SLAB3);
         s.slab[w][c] = a.take<float>(rowlen * (s.rows[w][c] > 0 ? s.rows[w][c] : 1));
@@ -201,11 +210,12 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
       const int w = ps[p].wset;
       if (conv % 3 == 0 && ((ws[w].skip_k == 1) != want_tap1)) continue;
       (void)tap1;
-      const int nz = wg_rows(bands[p], total);
+      const int nz = wg_rows(bands[p], skip1_total(ps, n_pass, ws, p, conv, bands, total));
       jobs.j[jobs.n++] = rw::WgJob{xs[p], dys[p], sc.slab[w][conv], sc.slab_b[w][conv], ps[p].n_img, next_row[w][conv], nz, 0};
       next_row[w][conv] += nz;
     }
   };
+  rw::Sk1Jobs sk1{};
   for (int b = 4; b >= 1; --b) {
     const int c1 = 3 * b - 2, c2 = c1 + 1, sk = c1 + 2;
     const float *xin[MLHOT_TRUNK_MAX_PASS], *mid[MLHOT_TRUNK_MAX_PASS], *g[MLHOT_TRUNK_MAX_PASS], *dm[MLHOT_TRUNK_MAX_PASS];
@@ -244,10 +254,18 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
       if (jobs.n + n_pass > rw::MAX_JOBS) { MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, "trunk.bwd.conv1.wgrad")); jobs.n = 0; }
       wg_jobs(sk, false, false, jobs, xin, g);
       MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, "trunk.bwd.conv1.wgrad"));
+      // 1x1 skips: collected over the blocks, one launch behind the loop (same slab rows as a per-block launch would use)
       wg_jobs(sk, true, true, jobs1, xin, g);
-      MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, true, jobs1, s, "trunk.bwd.skip1.wgrad"));
+      for (int i = 0; i < jobs1.n; ++i) {
+        const rw::WgJob& j = jobs1.j[i];
+        int lg = 0;
+        while ((2 << lg) < lv.L[b - 1]) ++lg;                                  // output map HO = L[b - 1] / 2 = 1 << lg
+        if (sk1.n >= rw::SK1_MAX) { set_error("resnet trunk bwd: too many 1x1 skip jobs"); return MLHOT_ERR_ARG; }
+        sk1.j[sk1.n++] = rw::Sk1Job{j.x, j.dy, j.slab, j.slab_b, j.n_img, lg, j.z0, j.nz, 0};      // a row beyond the last chunk is written as zeros
+      }
     }
   }
+  MLHOT_TRY(rw::skip1_wgrad_launch(sk1, s, "trunk.bwd.skip1.wgrad"));
   {   // stem weight gradient
     rw::StemWgJobs jobs{};
     int bands[MLHOT_TRUNK_MAX_PASS], total = 0;

@@ -767,6 +767,76 @@ inline bool wsum_add(WsumSegs& segs, const float* slab, float* out, float* out_b
   return true;
 }
 
+// ---- weight (+ bias) gradient of the plain ResNet block's 1x1 stride-2 skip convolution, every block of a step in ONE launch ----
+// dW[co][ci] = sum over (image, oy, ox) of dy[co][oy][ox] * x[ci][2 oy][2 ox]: 0.3 GFLOP in all for BASELINE c5's decoder pass, so the
+// four per-block launches of wgrad_kernel<G, true> (17 us each, latency bound) become one run-time-shaped kernel: a job per
+// (block, pass), positions flattened over (image, oy, ox) and cut into chunks of 64; a workgroup (4 waves = 4 output-channel
+// tiles, 4 input-channel tiles each) walks chunks z, z + nz, ...: both operands staged [channel][position] (row stride 66: the
+// 16 channels x 2 positions of a half-wave land on 32 banks), slab rows in the same MFMA-native order as wgrad_kernel<G, true>.
+struct Sk1Job {
+  const float* x; const float* dy;     // x [n_img][64][2 HO][2 HO], dy [n_img][64][HO][HO]
+  float* slab; float* slab_b;          // rows [z][SLAB1]; bias rows [z][64] (may be null)
+  int n_img, ho_log2, z0, nz, wg0;
+};
+constexpr int SK1_MAX = 4 * MAX_JOBS, SK1_PS = 66;      // 4 blocks x the passes of a step
+struct Sk1Jobs { Sk1Job j[SK1_MAX]; int n; };
+__global__ __launch_bounds__(256) void skip1_wgrad_kernel(const Sk1Jobs jobs) {
+  __shared__ float xs[CH * SK1_PS], ds[CH * SK1_PS];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const Sk1Job& jb = jobs.j[ji];
+  const int z = (int)blockIdx.x - jb.wg0;
+  const int lg = jb.ho_log2, HO = 1 << lg, HIN = 2 * HO, lpi = 2 * lg;          // positions per image = 1 << lpi
+  const int total = jb.n_img << lpi, nchunks = (total + 63) >> 6;
+  f32x4_t acc[4], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool bias = jb.slab_b != nullptr;
+#pragma unroll 1
+  for (int c = z; c < nchunks; c += jb.nz) {
+    float sx[16], sd[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int e = tid + j * 256, pos = e & 63, ch = e >> 6;
+      const int p = c * 64 + pos, img = p >> lpi, pin = p & ((1 << lpi) - 1), oy = pin >> lg, ox = pin & (HO - 1);
+      const bool ok = p < total;
+      sd[j] = ok ? jb.dy[(((size_t)img * CH + ch) << lpi) + pin] : 0.f;
+      sx[j] = ok ? jb.x[(((size_t)img * CH + ch) * HIN + 2 * oy) * HIN + 2 * ox] : 0.f;
+    }
+    __syncthreads();                   // the previous chunk's operands have been consumed
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int e = tid + j * 256, pos = e & 63, ch = e >> 6;
+      ds[ch * SK1_PS + pos] = sd[j]; xs[ch * SK1_PS + pos] = sx[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float a = ds[(16 * w + lr) * SK1_PS + 4 * ks + lq];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = mfma4(a, xs[(16 * q + lr) * SK1_PS + 4 * ks + lq], acc[q]);
+      if (bias) accb = mfma4(a, 1.f, accb);
+    }
+  }
+  float* row = jb.slab + (size_t)(jb.z0 + z) * SLAB1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(row + (((size_t)q * 4 + w) * 64 + lane) * 4) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+  if (bias && lr == 0)
+    *reinterpret_cast<float4*>(jb.slab_b + (size_t)(jb.z0 + z) * 64 + 16 * w + 4 * lq) = make_float4(accb[0], accb[1], accb[2], accb[3]);
+}
+inline int skip1_wgrad_launch(Sk1Jobs& jobs, hipStream_t s, const char* what) {
+  int wg = 0;
+  for (int i = 0; i < jobs.n; ++i) { jobs.j[i].wg0 = wg; wg += jobs.j[i].nz; }
+  if (wg <= 0) return MLHOT_OK;
+  {
+    ProfScope pr(what, s);
+    hipLaunchKernelGGL(skip1_wgrad_kernel, dim3(wg), dim3(256), 0, s, jobs);
+  }
+  return check_launch(what);
+}
+
 // Position splits of one job: enough workgroups to fill the chip twice over all jobs, at least 2 bands per workgroup when there are many
 template <class G>
 inline int wgrad_bands(int n_img) { return G::MULTI ? (n_img + G::NI - 1) / G::NI : n_img * G::BANDS_PER_IMG; }
