@@ -82,12 +82,11 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ x, i
 }
 
 // dx[M][Kin] (+)= (dy * act'(y))[M][N] w[N][Kin]: out^T tile C[kin][m]; grid (ceil(M / 32), ceil(Kin / 16))
-__global__ __launch_bounds__(256) void dgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ yv, int ldy, int act,
-                                                    const float* __restrict__ w, int ldw, float* __restrict__ dx, int lddx, int accumulate,
-                                                    int M, int Kin, int N) {
-  __shared__ float red[4 * 2 * 64 * 4];
+__device__ __forceinline__ void dgrad_body(const float* __restrict__ dy, int lddy, const float* __restrict__ yv, int ldy, int act,
+                                           const float* __restrict__ w, int ldw, float* __restrict__ dx, int lddx, int accumulate,
+                                           int M, int Kin, int N, float* red, int bx, int by) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lq = lane >> 4;
-  const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 16;
+  const int m0 = bx * 32, c0 = by * 16;
   const int ra = m0 + lr, rb = m0 + 16 + lr, col = c0 + lr;
   const size_t oa = (size_t)(ra < M ? ra : 0), ob = (size_t)(rb < M ? rb : 0);
   const float* wp = w + (col < Kin ? col : 0);
@@ -133,19 +132,25 @@ __global__ __launch_bounds__(256) void dgrad_kernel(const float* __restrict__ dy
   }
 }
 
+__global__ __launch_bounds__(256) void dgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ yv, int ldy, int act,
+                                                    const float* __restrict__ w, int ldw, float* __restrict__ dx, int lddx, int accumulate,
+                                                    int M, int Kin, int N) {
+  __shared__ float red[4 * 2 * 64 * 4];
+  dgrad_body(dy, lddy, yv, ldy, act, w, ldw, dx, lddx, accumulate, M, Kin, N, red, blockIdx.x, blockIdx.y);
+}
+
 // dw[N][K] = (dy * act'(y))^T x ; db[N] = column sums.  Workgroup: 16 output rows (n) x 64 columns (k); the reduction over the M
 // rows is split over the four waves (row groups of 4: g = wave, wave + 4, ...) and folded through LDS in a fixed order.
 // grid (ceil(N / 16), ceil(K / 64))
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ yv, int ldy, int act,
-                                                    const float* __restrict__ x, int ldx, float* __restrict__ dw, int lddw, float* __restrict__ db,
-                                                    int M, int K, int N) {
-  __shared__ float red[4 * 5 * 64 * 4];
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ dy, int lddy, const float* __restrict__ yv, int ldy, int act,
+                                           const float* __restrict__ x, int ldx, float* __restrict__ dw, int lddw, float* __restrict__ db,
+                                           int M, int K, int N, float* red, int bx, int by) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lq = lane >> 4;
-  const int n0 = blockIdx.x * 16, k0 = blockIdx.y * 64;
+  const int n0 = bx * 16, k0 = by * 64;
   const int n = n0 + lr;
   const bool nin = n < N;
   f32x4_t acc[5] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  const bool with_b = db != nullptr && blockIdx.y == 0;
+  const bool with_b = db != nullptr && by == 0;
   for (int mb = 4 * wv; mb < M; mb += 64) {           // four row groups (of 4 rows) per trip: all their loads in flight
     float g[4], yq[4], xv[4][4];
 #pragma unroll
@@ -192,6 +197,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy
   }
 }
 
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ yv, int ldy, int act,
+                                                    const float* __restrict__ x, int ldx, float* __restrict__ dw, int lddw, float* __restrict__ db,
+                                                    int M, int K, int N) {
+  __shared__ float red[4 * 5 * 64 * 4];
+  wgrad_body(dy, lddy, yv, ldy, act, x, ldx, dw, lddw, db, M, K, N, red, blockIdx.x, blockIdx.y);
+}
+
+// Both gradients of a layer in ONE launch (they share dy and are independent): blocks [0, nd) are the data gradient's
+// (gdx x gdy grid), the rest the weight gradient's.  These layers are launch / ramp bound (6-11 us per launch for < 0.1 GFLOP).
+struct BwdArgs {
+  const float* dy; const float* yv; const float* w; const float* x; float* dx; float* dw; float* db;
+  int lddy, ldy, act, ldx, lddx, accumulate, M, K, N, gdx, nd, gwx;
+};
+__global__ __launch_bounds__(256) void bwd_kernel(const BwdArgs a) {
+  __shared__ float red[4 * 5 * 64 * 4];
+  const int b = blockIdx.x;
+  if (b < a.nd) dgrad_body(a.dy, a.lddy, a.yv, a.ldy, a.act, a.w, a.K, a.dx, a.lddx, a.accumulate, a.M, a.K, a.N, red, b % a.gdx, b / a.gdx);
+  else wgrad_body(a.dy, a.lddy, a.yv, a.ldy, a.act, a.x, a.ldx, a.dw, a.K, a.db, a.M, a.K, a.N, red, (b - a.nd) % a.gwx, (b - a.nd) / a.gwx);
+}
+
 // float4 operand loads need 16-byte aligned rows
 inline bool aligned4(const void* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0; }
 constexpr int MAX_ROWS = 512;
@@ -213,6 +238,16 @@ inline int run_wgrad(const float* dy, int lddy, const float* y, int ldy, int act
                      hipStream_t s, const char* what) {
   ProfScope ps(what, s);
   hipLaunchKernelGGL(wgrad_kernel, dim3((N + 15) / 16, (K + 63) / 64), dim3(256), 0, s, dy, lddy, y, ldy, act, x, ldx, dw, K, db, M, K, N);
+  return check_launch(what);
+}
+
+inline int run_bwd(const float* dy, int lddy, const float* y, int ldy, int act, const float* w, const float* x, int ldx, float* dx, int lddx,
+                   int accumulate, float* dw, float* db, int M, int K, int N, hipStream_t s, const char* what) {
+  if (M <= 0) return MLHOT_OK;
+  BwdArgs a{dy, y, w, x, dx, dw, db, lddy, ldy, act, ldx, lddx, accumulate, M, K, N, (M + 31) / 32, 0, (N + 15) / 16};
+  a.nd = a.gdx * ((K + 15) / 16);
+  ProfScope ps(what, s);
+  hipLaunchKernelGGL(bwd_kernel, dim3(a.nd + a.gwx * ((K + 63) / 64)), dim3(256), 0, s, a);
   return check_launch(what);
 }
 

@@ -137,6 +137,11 @@ int mlhot_linear_bwd(const float* x, int ldx, const float* w, const float* y, in
   (void)scratch; (void)scratch_bytes;
   if (M < 0 || K <= 0 || N <= 0 || act < 0 || act > 2) { set_error("linear_bwd: bad argument"); return MLHOT_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
+#ifndef MLHOT_HOSTSIM
+  // few-row layers: both gradients in one launch (linear_skinny.h; the conditions are lin_dgrad's and lin_wgrad's)
+  if (dw && dx && M <= sk::MAX_ROWS && N % 4 == 0 && sk::aligned4(dy, lddy) && (act == ACT_NONE || sk::aligned4(y, ldy)))
+    return sk::run_bwd(dy, lddy, y, ldy, act, w, x, ldx, dx, lddx, accumulate, dw, db, M, K, N, s, "linear_bwd");
+#endif
   if (dw) MLHOT_TRY(lin_wgrad(dy, lddy, y, ldy, act, x, ldx, gb1(dw, db, N), M, K, N, s, "linear_bwd.w"));
   if (dx) MLHOT_TRY(lin_dgrad(dy, lddy, y, ldy, act, wb1(w, nullptr, N), dx, lddx, accumulate, M, K, N, s, "linear_bwd.x"));
   return MLHOT_OK;

@@ -43,6 +43,7 @@ class StagedEps:
         self._offsets, self._total, self._cursor = None, 0, 0
         self._host, self._dev, self._done, self._turn = None, None, None, 0
         self._worker, self._worker_err = None, None
+        self._thread, self._go, self._ready, self._job = None, None, None, 0
 
     @contextlib.contextmanager
     def recording(self):
@@ -90,16 +91,27 @@ class StagedEps:
         if self._offsets is None:
             self._plan()
         k = self._turn ^ 1
+        if self._thread is None:                   # one long-lived drawer: starting a thread per step costs ~0.1 ms of the step
+            self._go, self._ready = threading.Event(), threading.Event()
+            self._thread = threading.Thread(target=self._draw_loop, name="mlhot-eps-draw", daemon=True)
+            self._thread.start()
+        self._job = k
+        self._ready.clear()
+        self._worker = True
+        self._go.set()
 
-        def work():
+    def _draw_loop(self):
+        while True:
+            self._go.wait()
+            self._go.clear()
+            k = self._job
             try:
                 if self._done[k] is not None:
                     self._done[k].synchronize()    # the copy out of this pinned buffer two steps ago
                 self.draw_host(self._host[k])
             except BaseException as e:             # noqa: BLE001 - surfaced by the collecting stage()
                 self._worker_err = e
-        self._worker = threading.Thread(target=work, name="mlhot-eps-draw", daemon=True)
-        self._worker.start()
+            self._ready.set()
 
     def stage(self):
         """The next forward's eps on the device: draws them on the CPU generator (or collects the draws a prefetch() made
@@ -110,7 +122,7 @@ class StagedEps:
             self._plan()
         k = self._turn = self._turn ^ 1
         if self._worker is not None:
-            self._worker.join()
+            self._ready.wait()
             self._worker = None
             if self._worker_err is not None:
                 err, self._worker_err = self._worker_err, None
