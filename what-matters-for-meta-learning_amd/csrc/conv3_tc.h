@@ -21,6 +21,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 constexpr int CIN = 48, COUT = 64, KW = 432;
+#ifndef C3_RD
+#define C3_RD 4
+#endif
 
 // ---- forward ---------------------------------------------------------------------------------------
 // 512 threads: wave = (nt = wave & 3: output channels 16nt..+15) x (mg = wave >> 2: output rows 2mg, 2mg+1
@@ -94,21 +97,30 @@ __global__ __launch_bounds__(F_NT) void conv3_fwd_kernel(const float* __restrict
     const float* ab = patch2 + cur * F_PATCH + aoff;
     const int next = unit + (int)gridDim.x;
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // A operands through a register ring C3_RD k-steps deep (reads of k-step ks + C3_RD behind the MFMA of k-step ks): left alone
+    // hipcc reads each operand right in front of its MFMA and waits lgkmcnt(0) on it (conv_tc.h, forward, has the measurements)
+    auto aread = [&](int ks) { const int t = ks / 12, c = ks % 12; return ab[c * 4 * F_PS + (t / 3) * F_RS + t % 3]; };
+#if C3_RD > 0
+    float xa[C3_RD];
 #pragma unroll
-    for (int ks = 0; ks < 54; ks += 2) {
-      const int t0 = ks / 12, c0 = ks % 12, t1 = (ks + 1) / 12, c1 = (ks + 1) % 12;
-      acc0 = mfma4(ab[c0 * 4 * F_PS + (t0 / 3) * F_RS + t0 % 3], wr[ks], acc0);
-      acc1 = mfma4(ab[c1 * 4 * F_PS + (t1 / 3) * F_RS + t1 % 3], wr[ks + 1], acc1);
-    }
-    if (next < nunits) {                       // the other buffer was released by the barrier that ended the previous unit
-      stash(patch2 + (cur ^ 1) * F_PATCH);
-      if (next + (int)gridDim.x < nunits) fetch(next + gridDim.x);
-    }
+    for (int d = 0; d < C3_RD; ++d) xa[d] = aread(d);
+#endif
 #pragma unroll
-    for (int ks = 54; ks < 108; ks += 2) {
-      const int t0 = ks / 12, c0 = ks % 12, t1 = (ks + 1) / 12, c1 = (ks + 1) % 12;
-      acc0 = mfma4(ab[c0 * 4 * F_PS + (t0 / 3) * F_RS + t0 % 3], wr[ks], acc0);
-      acc1 = mfma4(ab[c1 * 4 * F_PS + (t1 / 3) * F_RS + t1 % 3], wr[ks + 1], acc1);
+    for (int ks = 0; ks < 108; ++ks) {
+      if (ks == 54 && next < nunits) {             // the other buffer was released by the barrier that ended the previous unit
+        stash(patch2 + (cur ^ 1) * F_PATCH);
+        if (next + (int)gridDim.x < nunits) fetch(next + gridDim.x);
+      }
+#if C3_RD > 0
+      const float x = xa[ks % C3_RD];
+      if (ks + C3_RD < 108) xa[ks % C3_RD] = aread(ks + C3_RD);
+#else
+      const float x = aread(ks);
+#endif
+      if (ks & 1) acc1 = mfma4(x, wr[ks], acc1); else acc0 = mfma4(x, wr[ks], acc0);
+#if C3_RD > 0
+      if (ks % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     // lane holds positions 4lq..4lq+3 of the tile = row (lq >> 1), columns 4(lq & 1)..+3 of channel co
     const int img = unit >> 1, hf = unit & 1;
