@@ -196,6 +196,7 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
     }
     __syncthreads();
     if (img + (int)gridDim.x < n_img) fetch(img + gridDim.x);
+    // (double-buffering the 11 operands of a k-step across k-steps measured equal here: 35.7 vs 35.4 us)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       float a[3][3], b[2];
@@ -305,26 +306,33 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
       stash(patch2 + (cur ^ 1) * D_PATCH);
       if (next + (int)gridDim.x < n_img) fetch(next + gridDim.x);
     }
+    // operand i of the image: M-tile mt = i / (16 T), tap t = (i / 16) % T, k-step ks = i % 16; a 4-deep register ring keeps the
+    // reads ahead of their MFMAs (see conv3_fwd_kernel)
+    auto aread = [&](int i) {
+      const int mt = i / (16 * T), t = (i / 16) % T, ks = i % 16, ty = t / NTX, tx = t % NTX;
+      const int doy = (PY && ty == 0) ? 1 : 0, dox = (PX && tx == 0) ? 1 : 0;
+      return ab[(2 * mt + doy) * D_RS + dox + ks * 4 * D_PS];
+    };
+    constexpr int RD = 4, NOP = 4 * 16 * T;
+    float xa[RD];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < RD; ++d) xa[d] = aread(d);
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ty = 0; ty < NTY; ++ty)
+    for (int i = 0; i < NOP; ++i) {
+      const int mt = i / (16 * T), t = (i / 16) % T, ks = i % 16;
+      const float x = xa[i % RD];
+      if (i + RD < NOP) xa[i % RD] = aread(i + RD);
+      if (ks & 1) acc1 = mfma4(x, wr[t][ks], acc1); else acc0 = mfma4(x, wr[t][ks], acc0);
+      if (i % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+      if (i % (16 * T) == 16 * T - 1) {
+        // lane holds positions 4lq..+3 of the tile: y' = 2mt + (lq >> 1), x' = 4(lq & 1) + r, channel ci
+        const int y = 2 * (2 * mt + (lq >> 1)) + PY;
+        float* o = dp2 + (((size_t)img * CIN + ci) * 16 + y) * 16 + 8 * (lq & 1) + PX;
 #pragma unroll
-        for (int tx = 0; tx < NTX; ++tx) {
-          const int doy = (PY && ty == 0) ? 1 : 0, dox = (PX && tx == 0) ? 1 : 0;
-          const float* at = ab + (2 * mt + doy) * D_RS + dox;
-#pragma unroll
-          for (int ks = 0; ks < 16; ks += 2) {
-            acc0 = mfma4(at[ks * 4 * D_PS], wr[ty * NTX + tx][ks], acc0);
-            acc1 = mfma4(at[(ks + 1) * 4 * D_PS], wr[ty * NTX + tx][ks + 1], acc1);
-          }
-        }
-      // lane holds positions 4lq..+3 of the tile: y' = 2mt + (lq >> 1), x' = 4(lq & 1) + r, channel ci
-      const int y = 2 * (2 * mt + (lq >> 1)) + PY;
-      float* o = dp2 + (((size_t)img * CIN + ci) * 16 + y) * 16 + 8 * (lq & 1) + PX;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[2 * r] = acc0[r] + acc1[r];
+        for (int r = 0; r < 4; ++r) o[2 * r] = acc0[r] + acc1[r];
+        acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
     }
     __syncthreads();
   }
