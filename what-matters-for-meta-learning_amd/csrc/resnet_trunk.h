@@ -148,12 +148,17 @@ inline int trunk_forward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tru
     const int c1 = 3 * b - 2, c2 = c1 + 1, sk = c1 + 2;
     // stage A: conv1 (+ReLU) and the skip convolution, both on the block input - ONE launch for every pass: a 3x3 skip is a
     // second job on the same input, a 1x1 skip rides in its conv1 job (centre-tap operand)
-    {
+    // On the 32x32 input the kernel variant with the fused 1x1 skip (16 more weight registers, a second epilogue) costs the
+    // passes that do not need it more than a launch: there the two kinds of pass go out separately (158 us in one launch,
+    // 49 + 97 us in two); from 16x16 down one launch is the faster way.
+    const bool split_kinds = lv.L[b - 1] >= 32;
+    for (int kind = 0; kind < (split_kinds ? 2 : 1); ++kind) {
       rw::FwdJobs jobs{};
       bool any1 = false;
       for (int p = 0; p < n_pass; ++p) {
         const mlhot_trunk_wset& w = ws[ps[p].wset];
         const float* x = ps[p].act[2 * b - 2];
+        if (split_kinds && (w.skip_k == 1) != (kind == 0)) continue;
         if (jobs.n + (w.skip_k == 1 ? 1 : 2) > rw::MAX_JOBS) {
           MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, any1, jobs, s, "trunk.conv1"));
           jobs.n = 0; any1 = false;
@@ -168,7 +173,7 @@ inline int trunk_forward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tru
           jobs.j[jobs.n++] = rw::FwdJob{x, sc.wimg[ps[p].wset][sk], w.b[sk], sc.idn[p], nullptr, nullptr, nullptr, nullptr, ps[p].n_img, rw::EPI_BIAS, 0, 0, 0};
         }
       }
-      MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, any1, jobs, s, "trunk.conv1"));
+      if (jobs.n) MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, any1, jobs, s, "trunk.conv1"));
     }
     // stage B: conv2 + skip + ReLU
     rw::FwdJobs jobs{};
@@ -245,7 +250,7 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
           jb2.j[jb2.n++] = rw::DgJob{dm[p], sc.wimg[w][c1], sc.G[p][b - 1], xin[p], nullptr, nullptr, ps[p].n_img, 1, 0, 0};
         }
       }
-      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], any1, ja, s, "trunk.bwd.conv1.dgrad"));
+      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], any1, ja, s, "trunk.bwd.conv1.dgrad"));      // (split by kind like the forward: no gain here)
       MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], false, jb2, s, "trunk.bwd.conv1.dgrad2"));
     }
     {   // conv1 and 3x3-skip weight gradients (same input, same geometry: one launch); 1x1 skips on their own
