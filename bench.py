@@ -72,22 +72,24 @@ def trunk_flops_per_step(T):
     """Algorithmic FLOPs (2 x MACs) one c5 step spends under every ResNet-trunk launch label: two Bayes-by-backprop encoder passes
     (context, target: 3x3 skip) and the decoder pass (1x1 skip) over 15 images per task each; L = output map sizes."""
     n, C, L = 15 * T, 3, [32, 16, 8, 4, 2]
-    f = {k: 0.0 for k in ("trunk.stem", "trunk.conv1", "trunk.conv2", "trunk.bwd.conv2.dgrad", "trunk.bwd.conv2.wgrad",
-                          "trunk.bwd.conv1.dgrad", "trunk.bwd.conv1.dgrad2", "trunk.bwd.conv1.wgrad", "trunk.bwd.skip1.wgrad", "trunk.bwd.stem.wgrad")}
+    f = {"trunk.stem": 0.0, "trunk.bwd.stem.wgrad": 0.0, "trunk.bwd.skip1.wgrad": 0.0}
     for skip_k in (3, 3, 1):                               # the three passes
         stem = 2.0 * n * L[0] ** 2 * 64 * 25 * C
         f["trunk.stem"] += stem
         f["trunk.bwd.stem.wgrad"] += stem
-        for b in range(1, 5):
+        for b in range(1, 5):                              # labels carry the block: one label = one kernel geometry
             c33 = 2.0 * n * L[b] ** 2 * 64 * 576           # one 3x3 64 -> 64 convolution on the block's output grid
             c11 = 2.0 * n * L[b] ** 2 * 64 * 64
-            f["trunk.conv1"] += c33 + (c33 if skip_k == 3 else c11)
-            f["trunk.conv2"] += c33
-            f["trunk.bwd.conv2.dgrad"] += c33
-            f["trunk.bwd.conv2.wgrad"] += c33
-            f["trunk.bwd.conv1.dgrad"] += c33 + (0.0 if skip_k == 3 else c11)    # first writers of dx: 3x3 skips; conv1 + fused 1x1 skip
-            f["trunk.bwd.conv1.dgrad2"] += c33 if skip_k == 3 else 0.0          # conv1 of the 3x3-skip blocks, added onto the skip's
-            f["trunk.bwd.conv1.wgrad"] += c33 + (c33 if skip_k == 3 else 0.0)
+
+            def add(name, v):
+                f[f"{name}.b{b}"] = f.get(f"{name}.b{b}", 0.0) + v
+            add("trunk.conv1", c33 + (c33 if skip_k == 3 else c11))
+            add("trunk.conv2", c33)
+            add("trunk.bwd.conv2.dgrad", c33)
+            add("trunk.bwd.conv2.wgrad", c33)
+            add("trunk.bwd.conv1.dgrad", c33 + (0.0 if skip_k == 3 else c11))    # first writers of dx: 3x3 skips; conv1 + fused 1x1 skip
+            add("trunk.bwd.conv1.dgrad2", c33 if skip_k == 3 else 0.0)          # conv1 of the 3x3-skip blocks, added onto the skip's
+            add("trunk.bwd.conv1.wgrad", c33 + (c33 if skip_k == 3 else 0.0))
             f["trunk.bwd.skip1.wgrad"] += c11 if skip_k == 1 else 0.0
     return f
 

@@ -132,6 +132,16 @@ inline int trunk_prep(const mlhot_trunk_wset* ws, int n_wset, const Levels& lv, 
   return check_launch("trunk.prep");
 }
 
+// launch labels per block (mlhot_prof_*): a label is one geometry, so its time over its algorithmic FLOPs is a kernel's rate
+#define MLHOT_TRUNK_LABELS(name) {name ".b0", name ".b1", name ".b2", name ".b3", name ".b4"}
+static const char* const LBL_CONV1[5] = MLHOT_TRUNK_LABELS("trunk.conv1");
+static const char* const LBL_CONV2[5] = MLHOT_TRUNK_LABELS("trunk.conv2");
+static const char* const LBL_C2_DGRAD[5] = MLHOT_TRUNK_LABELS("trunk.bwd.conv2.dgrad");
+static const char* const LBL_C2_WGRAD[5] = MLHOT_TRUNK_LABELS("trunk.bwd.conv2.wgrad");
+static const char* const LBL_C1_DGRAD[5] = MLHOT_TRUNK_LABELS("trunk.bwd.conv1.dgrad");
+static const char* const LBL_C1_DGRAD2[5] = MLHOT_TRUNK_LABELS("trunk.bwd.conv1.dgrad2");
+static const char* const LBL_C1_WGRAD[5] = MLHOT_TRUNK_LABELS("trunk.bwd.conv1.wgrad");
+
 inline int trunk_forward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk_wset* ws, int n_wset, int C, int H, void* scratch,
                          size_t scratch_bytes, hipStream_t s) {
   MLHOT_TRY(trunk_check(ps, n_pass, ws, n_wset, C, H));
@@ -160,7 +170,7 @@ inline int trunk_forward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tru
         const float* x = ps[p].act[2 * b - 2];
         if (split_kinds && (w.skip_k == 1) != (kind == 0)) continue;
         if (jobs.n + (w.skip_k == 1 ? 1 : 2) > rw::MAX_JOBS) {
-          MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, any1, jobs, s, "trunk.conv1"));
+          MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, any1, jobs, s, LBL_CONV1[b]));
           jobs.n = 0; any1 = false;
         }
         if (w.skip_k == 1) {
@@ -173,14 +183,14 @@ inline int trunk_forward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tru
           jobs.j[jobs.n++] = rw::FwdJob{x, sc.wimg[ps[p].wset][sk], w.b[sk], sc.idn[p], nullptr, nullptr, nullptr, nullptr, ps[p].n_img, rw::EPI_BIAS, 0, 0, 0};
         }
       }
-      if (jobs.n) MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, any1, jobs, s, "trunk.conv1"));
+      if (jobs.n) MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b - 1], 2, any1, jobs, s, LBL_CONV1[b]));
     }
     // stage B: conv2 + skip + ReLU
     rw::FwdJobs jobs{};
     for (int p = 0; p < n_pass; ++p)
       jobs.j[jobs.n++] = rw::FwdJob{ps[p].act[2 * b - 1], sc.wimg[ps[p].wset][c2], ws[ps[p].wset].b[c2], ps[p].act[2 * b], sc.idn[p], nullptr, nullptr, nullptr,
                                     ps[p].n_img, rw::EPI_BIAS_RES_RELU, 0, 0, 0};
-    MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b], 1, false, jobs, s, "trunk.conv2"));
+    MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b], 1, false, jobs, s, LBL_CONV2[b]));
   }
   return MLHOT_OK;
 }
@@ -229,12 +239,12 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
       rw::FwdJobs jobs{};
       for (int p = 0; p < n_pass; ++p)
         jobs.j[jobs.n++] = rw::FwdJob{g[p], sc.wimg[ps[p].wset][c2], nullptr, sc.DM[p], mid[p], nullptr, nullptr, nullptr, ps[p].n_img, rw::EPI_MASK, 1, 0, 0};
-      MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b], 1, false, jobs, s, "trunk.bwd.conv2.dgrad"));
+      MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b], 1, false, jobs, s, LBL_C2_DGRAD[b]));
     }
     {   // conv2 weight gradient
       rw::WgJobs jobs{};
       wg_jobs(c2, false, false, jobs, mid, g);
-      MLHOT_TRY(rw::wgrad_dispatch(lv.L[b], 1, false, jobs, s, "trunk.bwd.conv2.wgrad"));
+      MLHOT_TRY(rw::wgrad_dispatch(lv.L[b], 1, false, jobs, s, LBL_C2_WGRAD[b]));
     }
     // data gradient into the block input (not needed for images: block 1's input is the stem output, whose gradient feeds the stem's wgrad)
     {
@@ -250,15 +260,15 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
           jb2.j[jb2.n++] = rw::DgJob{dm[p], sc.wimg[w][c1], sc.G[p][b - 1], xin[p], nullptr, nullptr, ps[p].n_img, 1, 0, 0};
         }
       }
-      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], any1, ja, s, "trunk.bwd.conv1.dgrad"));      // (split by kind like the forward: no gain here)
-      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], false, jb2, s, "trunk.bwd.conv1.dgrad2"));
+      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], any1, ja, s, LBL_C1_DGRAD[b]));      // (split by kind like the forward: no gain here)
+      MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], false, jb2, s, LBL_C1_DGRAD2[b]));
     }
     {   // conv1 and 3x3-skip weight gradients (same input, same geometry: one launch); 1x1 skips on their own
       rw::WgJobs jobs{}, jobs1{};
       wg_jobs(c1, false, false, jobs, xin, dm);
-      if (jobs.n + n_pass > rw::MAX_JOBS) { MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, "trunk.bwd.conv1.wgrad")); jobs.n = 0; }
+      if (jobs.n + n_pass > rw::MAX_JOBS) { MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, LBL_C1_WGRAD[b])); jobs.n = 0; }
       wg_jobs(sk, false, false, jobs, xin, g);
-      MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, "trunk.bwd.conv1.wgrad"));
+      MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, LBL_C1_WGRAD[b]));
       // 1x1 skips: collected over the blocks, one launch behind the loop (same slab rows as a per-block launch would use)
       wg_jobs(sk, true, true, jobs1, xin, g);
       for (int i = 0; i < jobs1.n; ++i) {
