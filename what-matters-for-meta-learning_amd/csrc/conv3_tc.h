@@ -234,13 +234,18 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
 #pragma unroll
       for (int cig = 0; cig < 3; ++cig)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = acc[kx][cig][c][r] + lds[((job * 18 + (kx * 3 + cig) * 2 + c) * 4 + r) * 64 + lane];
-            const int ci = 16 * cig + 4 * lq + r, co = 16 * (2 * np + c) + lr;
-            sw[((size_t)co * CIN + ci) * 9 + 3 * tg + kx] = v;
-          }
+        for (int c = 0; c < 2; ++c) {
+          // accumulator order [tile = job * 18 + (kx * 3 + cig) * 2 + c][lane][r]: one coalesced 16-byte store per tile and lane
+          // (as 4-byte scatters into [co][ci][tap] order these 72 stores per lane were a sixth of the kernel); the final fold
+          // un-permutes (c2::SumParts kind 2)
+          const int tile = job * 18 + (kx * 3 + cig) * 2 + c;
+          float4 v;
+          v.x = acc[kx][cig][c][0] + lds[(tile * 4 + 0) * 64 + lane];
+          v.y = acc[kx][cig][c][1] + lds[(tile * 4 + 1) * 64 + lane];
+          v.z = acc[kx][cig][c][2] + lds[(tile * 4 + 2) * 64 + lane];
+          v.w = acc[kx][cig][c][3] + lds[(tile * 4 + 3) * 64 + lane];
+          *reinterpret_cast<float4*>(sw + ((size_t)tile * 64 + lane) * 4) = v;
+        }
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {                   // 16 consecutive threads share an output channel

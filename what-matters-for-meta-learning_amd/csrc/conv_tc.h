@@ -80,8 +80,11 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
 
 // Up to 4 independent slab sums in ONE launch (the backward's deferred weight-gradient folds: conv3, conv2, conv1, the tail's
 // per-task slabs): segment i owns blocks [first[i], first[i+1]) and is summed exactly as sum_parts_kernel would.
-struct SumParts { const float* slab; float* out; int nparts, len, stride; };
-struct SumPartsMulti { SumParts seg[4]; int first[5]; int n; };
+// kind 1: the slab holds conv2's weight gradient in the order the weight-gradient kernel's accumulators have it
+// ([wave group mg][i][j][lane][r], coalesced float4 stores there); the fold writes element (mg, i, j, lane, r) to
+// dW2[co = 16 j + lane % 16][ci = 16 (mt % 2) + 4 (lane / 16) + r][tap = mt / 2], mt = 3 mg + i.  kind 2: the same for conv3.
+struct SumParts { const float* slab; float* out; int nparts, len, stride, kind; };
+struct SumPartsMulti { SumParts seg[8]; int first[9]; int n; };
 inline int sum_parts_blocks(int len) { return (len + 63) / 64; }
 __global__ __launch_bounds__(256) void sum_parts_multi_kernel(const SumPartsMulti mp) {
   __shared__ float4 sm[16][16];
@@ -110,7 +113,20 @@ __global__ __launch_bounds__(256) void sum_parts_multi_kernel(const SumPartsMult
     float4 t = sm[0][cx];
 #pragma unroll
     for (int k = 1; k < 16; ++k) add(t, sm[k][cx]);
-    *reinterpret_cast<float4*>(sp.out + e) = t;
+    if (sp.kind == 1) {
+      const int lane = (e >> 2) & 63, tile = e >> 8, j = tile % 3, mt = tile / 3;      // tile = (3 mg + i) * 3 + j
+      float* o = sp.out + ((size_t)(16 * j + (lane & 15)) * CIN + 16 * (mt & 1) + 4 * (lane >> 4)) * 9 + (mt >> 1);
+      o[0] = t.x; o[9] = t.y; o[18] = t.z; o[27] = t.w;
+    } else if (sp.kind == 2) {
+      // conv3's weight gradient in ITS kernel's accumulator order (conv3_tc.h): tile = job * 18 + (kx * 3 + cig) * 2 + c,
+      // job = (tg = job % 3: tap row, np = job / 3: output-channel tile pair)
+      const int lane = (e >> 2) & 63, tile = e >> 8, job = tile / 18, rem = tile % 18, kx = rem / 6, cig = (rem >> 1) % 3, c = rem & 1;
+      const int co = 16 * (2 * (job / 3) + c) + (lane & 15), ci = 16 * cig + 4 * (lane >> 4);
+      float* o = sp.out + ((size_t)co * 48 + ci) * 9 + 3 * (job % 3) + kx;
+      o[0] = t.x; o[9] = t.y; o[18] = t.z; o[27] = t.w;
+    } else {
+      *reinterpret_cast<float4*>(sp.out + e) = t;
+    }
   }
 }
 
@@ -509,13 +525,17 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int mt = 3 * mg + i, tap = mt >> 1;
+      (void)mt; (void)tap;
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ci = 16 * (mt & 1) + 4 * lq + r, co = 16 * j + lr;
-          sw[((size_t)co * CIN + ci) * 9 + tap] = acc[i][j][r] + lds[((mg * 9 + i * 3 + j) * 4 + r) * 64 + lane];
-        }
+      for (int j = 0; j < 3; ++j) {
+        // accumulator order, one coalesced 16-byte store per tile and lane; the final fold un-permutes (SumParts kind 1)
+        float4 v;
+        v.x = acc[i][j][0] + lds[((mg * 9 + i * 3 + j) * 4 + 0) * 64 + lane];
+        v.y = acc[i][j][1] + lds[((mg * 9 + i * 3 + j) * 4 + 1) * 64 + lane];
+        v.z = acc[i][j][2] + lds[((mg * 9 + i * 3 + j) * 4 + 2) * 64 + lane];
+        v.w = acc[i][j][3] + lds[((mg * 9 + i * 3 + j) * 4 + 3) * 64 + lane];
+        *reinterpret_cast<float4*>(sw + ((size_t)((3 * mg + i) * 3 + j) * 64 + lane) * 4) = v;
+      }
     }
   }
 #pragma unroll

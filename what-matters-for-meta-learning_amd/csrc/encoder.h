@@ -160,8 +160,8 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
 #ifndef MLHOT_HOSTSIM
   // deferred slab sums of the weight-stationary path: ONE launch at the very end (4 kernels fewer on the step's critical path)
   c2::SumPartsMulti mp{};
-  auto pend = [&](const float* slab, float* out, int nparts, int len, int stride) {
-    mp.seg[mp.n] = c2::SumParts{slab, out, nparts, len, stride};
+  auto pend = [&](const float* slab, float* out, int nparts, int len, int stride, int kind = 0) {
+    mp.seg[mp.n] = c2::SumParts{slab, out, nparts, len, stride, kind};
     mp.first[mp.n + 1] = mp.first[mp.n] + c2::sum_parts_blocks(len);
     ++mp.n;
   };
@@ -219,14 +219,9 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
       hipLaunchKernelGGL(c3::conv3_wgrad_kernel, dim3(grid), dim3(c3::W_NT), 0, s, sv.p2, sc.dy3, slab_w, slab_b, n);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv3.wgrad"));
-    if (g.b3 == g.w3 + L3 && (reinterpret_cast<uintptr_t>(g.w3) & 15) == 0) {
-      pend(slab_w, g.w3, grid, R3, R3);
-    } else {
-      ProfScope ps("slab_reduce", s);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(L3 / 64), dim3(256), 0, s, slab_w, grid, L3, g.w3, R3);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 64, g.b3, R3);
-    }
-    MLHOT_TRY(check_launch("enc.bwd.conv3.wgrad.reduce"));
+    // weights in accumulator order (coalesced stores in the kernel), un-permuted by the fold
+    pend(slab_w, g.w3, grid, L3, R3, 2);
+    pend(slab_b, g.b3, grid, 64, R3);
     {
       ProfScope ps("enc.bwd.conv3.dgrad", s);
       hipLaunchKernelGGL(c3::conv3_dgrad_kernel, dim3(grid), dim3(c3::D_NT), 0, s, p.w3, sc.dy3, sc.dp2, n);
@@ -259,14 +254,9 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
       hipLaunchKernelGGL(c2::conv12_wgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, xs, p.w1, p.b1, sc.dp2, sv.p2, sv.am2, slab_w, slab_b, n, g_opt.dbg);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv12.wgrad"));
-    if (g.b2 == g.w2 + L2 && (reinterpret_cast<uintptr_t>(g.w2) & 15) == 0) {
-      pend(slab_w, g.w2, grid, R2, R2);
-    } else {
-      ProfScope ps("slab_reduce", s);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(L2 / 64), dim3(256), 0, s, slab_w, grid, L2, g.w2, R2);
-      hipLaunchKernelGGL(c2::sum_parts_kernel, dim3(1), dim3(256), 0, s, slab_b, grid, 48, g.b2, R2);
-    }
-    MLHOT_TRY(check_launch("enc.bwd.conv2.wgrad.reduce"));
+    // the weights sit in the slab in accumulator order (coalesced stores in the kernel); the fold un-permutes them
+    pend(slab_w, g.w2, grid, L2, R2, 1);
+    pend(slab_b, g.b2, grid, 48, R2);
     {
       ProfScope ps("enc.bwd.conv12.dgrad", s);
       hipLaunchKernelGGL(c2::conv12_dgrad_kernel, dim3(grid), dim3(c2::NT2), 0, s, xs, sv.m1, sc.dp2, sv.p2, sv.am2, p.w2, slab_1, n);
