@@ -265,12 +265,14 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
 // registers (16 per tap), A = dY[co][y' + doy][x' + dox] from the LDS patch [co][9][16] (row 8 / column 8
 // are the zero halo; plane stride 168 = 8 mod 32: lq = 1 lands on banks 8..15 / 24..31).
 constexpr int D_RS = 16, D_PS = 168, D_PATCH = COUT * D_PS;
+constexpr int D_OS = 260;              // plane stride of the output tile [ci][256]: float4-aligned, 2-way at worst on the 4-byte writes
 constexpr int D_NT = 768;
 
 template <int PY, int PX>
 __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const float* __restrict__ dy3, float* __restrict__ dp2,
                                             float* patch2, int n_img, int nt, int tid, int lane) {
   constexpr int NTY = PY ? 2 : 1, NTX = PX ? 2 : 1, T = NTY * NTX;
+  float* outt = patch2 + 2 * D_PATCH;
   const int lr = lane & 15, lq = lane >> 4;
   const int ci = 16 * nt + lr;
   float wr[T][16];
@@ -331,13 +333,21 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
       if (ks & 1) acc1 = mfma4(x, wr[t][ks], acc1); else acc0 = mfma4(x, wr[t][ks], acc0);
       if (i % 2 == 1) __builtin_amdgcn_sched_barrier(0);
       if (i % (16 * T) == 16 * T - 1) {
-        // lane holds positions 4lq..+3 of the tile: y' = 2mt + (lq >> 1), x' = 4(lq & 1) + r, channel ci
+        // lane holds positions 4lq..+3 of the tile: y' = 2mt + (lq >> 1), x' = 4(lq & 1) + r, channel ci.  The four parity
+        // classes interleave in x and y, so straight to global every store instruction is 64 four-byte writes to 64 cache
+        // lines; the image's gradient is assembled in LDS ([ci][16][16], plane stride D_OS) and leaves as coalesced float4.
         const int y = 2 * (2 * mt + (lq >> 1)) + PY;
-        float* o = dp2 + (((size_t)img * CIN + ci) * 16 + y) * 16 + 8 * (lq & 1) + PX;
+        float* o = outt + ci * D_OS + y * 16 + 8 * (lq & 1) + PX;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[2 * r] = acc0[r] + acc1[r];
         acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                  // 48 x 256 floats = 3072 float4, 4 per thread
+      const int e = tid + j * D_NT, c = e >> 6, q4 = e & 63;
+      *reinterpret_cast<float4*>(dp2 + ((size_t)img * CIN + c) * 256 + 4 * q4) = *reinterpret_cast<const float4*>(outt + c * D_OS + 4 * q4);
     }
     __syncthreads();
   }
@@ -345,7 +355,7 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
 
 __global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dy3,
                                                            float* __restrict__ dp2, int n_img) {
-  __shared__ float patch2[2 * D_PATCH];
+  __shared__ float patch2[2 * D_PATCH + CIN * D_OS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 2 * D_PATCH; i += D_NT) patch2[i] = 0.f;      // halo row 8 / columns 8.. stay zero
   __syncthreads();
