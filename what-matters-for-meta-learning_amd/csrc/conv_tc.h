@@ -43,6 +43,20 @@ __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// conv2's [48][288] weight matrix -> LDS rows of 289 words with coalesced float4 loads.  The kernels' register-resident slices
+// are stride-9 / stride-288 gathers of it: read straight from global every wave load touches 16+ cache lines for 256 useful
+// bytes (72 such loads per lane and 12 waves behind one texture addresser: ~4 us before the forward's first MFMA).
+constexpr int W2_LD = CIN * 9 + 1;
+template <int NTHREADS>
+__device__ __forceinline__ void conv2w_stage(float* stage, const float* __restrict__ w, int tid) {
+  for (int i = tid; i < COUT * CIN * 9 / 4; i += NTHREADS) {
+    const float4 v = *reinterpret_cast<const float4*>(w + 4 * i);
+    const int r = (4 * i) / (CIN * 9), c = 4 * i - r * (CIN * 9);        // 288 % 4 == 0: a float4 stays inside its row
+    float* d = stage + r * W2_LD + c;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+}
+
 __device__ __forceinline__ void patch_zero_pad(float* patch, int tid) {
   for (int i = tid; i < CIN * ROWS; i += NT) patch[(i / ROWS) * PS + (i % ROWS) * RS] = 0.f;
 }
@@ -309,10 +323,13 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   const int n = nt * 16 + lr;
   const int phase = __builtin_amdgcn_readfirstlane(wave >> 2);
 
+  conv2w_stage<NT>(patch2, w, tid);
+  __syncthreads();
   float wr[72];
 #pragma unroll
-  for (int ks = 0; ks < 72; ++ks) wr[ks] = w[((size_t)n * CIN + (ks & 7) * 4 + lq) * 9 + (ks >> 3)];
+  for (int ks = 0; ks < 72; ++ks) wr[ks] = patch2[n * W2_LD + ((ks & 7) * 4 + lq) * 9 + (ks >> 3)];
   const float bn = bias[n];
+  __syncthreads();
   Conv1W cw;
   conv1w_load(cw, w1, b1, lr, lq);
   Conv1Lane cl;
@@ -622,6 +639,7 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
   const int lr = lane & 15, lq = lane >> 4;
   const int ci = 16 * nt + lr;
 
+  // (staged through LDS like the forward's, these loads measured 1 us slower: along ci the gather is a 36-byte stride, ~5 lines per load)
   float wr[9][12];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
