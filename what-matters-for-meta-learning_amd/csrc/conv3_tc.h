@@ -282,8 +282,11 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
     for (int tx = 0; tx < NTX; ++tx) {
       const int ky = PY ? (ty == 0 ? 0 : 2) : 1, kx = PX ? (tx == 0 ? 0 : 2) : 1;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) wr[ty * NTX + tx][ks] = w[((size_t)(4 * ks + lq) * CIN + ci) * 9 + ky * 3 + kx];
+      for (int ks = 0; ks < 16; ++ks) wr[ty * NTX + tx][ks] = patch2[(4 * ks + lq) * F_WLD + ci * 9 + ky * 3 + kx];     // staged by the kernel
     }
+  __syncthreads();                                                   // every wave has its weights: the staging area becomes the patch
+  for (int i = tid; i < 2 * D_PATCH; i += D_NT) patch2[i] = 0.f;      // halo row 8 / columns 8.. stay zero
+  __syncthreads();
   float4 sd[2];
   auto fetch = [&](int img) {
 #pragma unroll
@@ -356,8 +359,16 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
 __global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dy3,
                                                            float* __restrict__ dp2, int n_img) {
   __shared__ float patch2[2 * D_PATCH + CIN * D_OS];
+  static_assert(2 * D_PATCH + CIN * D_OS >= COUT * F_WLD, "weight staging area");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < 2 * D_PATCH; i += D_NT) patch2[i] = 0.f;      // halo row 8 / columns 8.. stay zero
+  // the [64][432] weight matrix through LDS with coalesced float4 loads (rows of 433 words); the waves' register slices are
+  // stride-9 / stride-432 gathers of it - straight from global ~20 cache lines per load instruction, 16-64 of them per lane
+  for (int i = tid; i < COUT * KW / 4; i += D_NT) {
+    const float4 v = *reinterpret_cast<const float4*>(w + 4 * i);
+    const int r = (4 * i) / KW, c = (4 * i) - r * KW;
+    float* d = patch2 + r * F_WLD + c;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
   __syncthreads();
   // per image a class costs 64 MFMAs per tap and tile: 256 / 128 / 128 / 64.  Waves w, w + 4, w + 8 share a SIMD:
   // SIMDs 0..2 get {256, 128, 64} (classes 11, 01, 00 of tile w), SIMD 3 gets the three 128s of class 10.
