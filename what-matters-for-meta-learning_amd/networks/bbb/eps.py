@@ -44,11 +44,12 @@ class StagedEps:
         self._host, self._dev, self._done, self._turn = None, None, None, 0
         self._worker, self._worker_err = None, None
         self._thread, self._go, self._ready, self._job = None, None, None, 0
+        self._runs = None
 
     @contextlib.contextmanager
     def recording(self):
         global _recorder
-        self.shapes, self._offsets = [], None
+        self.shapes, self._offsets, self._runs = [], None, None
         _recorder = self
         try:
             yield self
@@ -75,12 +76,37 @@ class StagedEps:
         self._dev = torch.empty(n, device=self.device)
         self._done = [torch.cuda.Event() if pin else None for _ in range(2)]
 
-    def draw_host(self, out):
-        """The recorded sequence of draws, in order, into the flat host tensor `out` (the numbers the lazy route would see)."""
-        for s, o in zip(self.shapes, self._offsets):
-            n = int(torch.Size(s).numel())
-            out[o:o + n].view(s).normal_(0, 1)
+    def draw_host(self, out, generator=None):
+        """The recorded sequence of draws, in order, into the flat host tensor `out` (the numbers the lazy route would see).
+        Neighbouring tensors whose sizes are multiples of 16 are drawn with ONE `normal_()` over their common slice: ATen fills a
+        float tensor with uniforms in order and turns them into normals 16 at a time, so the concatenation of such tensors gets
+        exactly the numbers the separate calls would (checked once per plan against the separate calls, `_plan_runs`); 52 calls
+        per step become 2, ~10 % of the draw time."""
+        if self._runs is None:
+            self._plan_runs()
+        for lo, hi in self._runs:
+            out[lo:hi].normal_(0, 1, generator=generator)
         return out
+
+    def _plan_runs(self):
+        sizes = [int(torch.Size(s).numel()) for s in self.shapes]
+        single = [(o, o + n) for o, n in zip(self._offsets, sizes)]
+        merged = []
+        for (lo, hi), n in zip(single, sizes):
+            if merged and merged[-1][1] == lo and n % 16 == 0 and (merged[-1][1] - merged[-1][0]) % 16 == 0:
+                merged[-1] = (merged[-1][0], hi)
+            else:
+                merged.append((lo, hi))
+        self._runs = single
+        if len(merged) < len(single):
+            g = torch.Generator()
+            g.manual_seed(0x5eed)
+            state = g.get_state()
+            ref = self.draw_host(torch.zeros(self._total), g)
+            g.set_state(state)
+            self._runs = merged
+            if not torch.equal(ref, self.draw_host(torch.zeros(self._total), g)):
+                self._runs = single                 # this torch build fills differently: keep one call per tensor
 
     def prefetch(self):
         """Start drawing the NEXT stage()'s eps on a worker thread (into the pinned buffer that stage() will ship)."""
