@@ -645,8 +645,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
     float4 sd[G::DCNT];
 #pragma unroll
     for (int j = 0; j < G::DCNT; ++j) {
-      // item e: 4 consecutive band positions p4 .. p4 + 3 of output channel co (they lie in one image plane: PI % 4 == 0)
-      const int e = tid + j * 256, p4 = 4 * (e % (G::BPOS / 4)), co = e / (G::BPOS / 4);
+      // item e: 4 consecutive band positions p4 .. p4 + 3 of output channel co (they lie in one image plane: PI % 4 == 0).
+      // The lanes of a wave take 64 different channels of ONE position quad: transposed into [pos][co] (row stride DS) their
+      // stores then hit 64 different banks.  With the positions along the lanes (coalesced 16-byte loads) the stores of a wave
+      // landed on 32 / gcd-limited few banks - 4 DS is a multiple of 4, of 32 for DS = 80: every store 32-way serialised, and
+      // the LDS pipe is shared with the other workgroup's operand reads; the loads now touch 64 lines of 16 bytes each, which the
+      // texture path absorbs in the background.
+      const int e = tid + j * 256, co = e & 63, p4 = 4 * (e >> 6);
       const int il = G::MULTI ? p4 / G::PI : 0, pin = G::MULTI ? p4 % G::PI : oy0 * G::WO + p4;
       sd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (img0 + il < jb.n_img) sd[j] = *reinterpret_cast<const float4*>(jb.dy + ((size_t)(img0 + il) * CH + co) * G::PI + pin);
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
     }
 #pragma unroll
     for (int j = 0; j < G::DCNT; ++j) {
-      const int e = tid + j * 256, p4 = 4 * (e % (G::BPOS / 4)), co = e / (G::BPOS / 4);
+      const int e = tid + j * 256, co = e & 63, p4 = 4 * (e >> 6);
       float* d = dyt + p4 * G::DS + co;
       d[0] = sd[j].x; d[G::DS] = sd[j].y; d[2 * G::DS] = sd[j].z; d[3 * G::DS] = sd[j].w;
     }
