@@ -560,6 +560,15 @@ struct GeoW {
     return true;
   }
   static_assert(conflict_free(), "LDS layout has bank conflicts");
+  // operand offsets split into a per-lane base and a compile-time part: position pb(ks, lq) = pb(ks, 0) + lq * Q never crosses
+  // a patch row differently from pb(0, lq), so posoff(pb(ks, lq)) = posoff(pb(ks, 0)) + [posoff(pb(0, lq)) - posoff(pb(0, 0))]
+  static constexpr bool separable() {
+    for (int ks = 0; ks < NKS_B; ++ks)
+      for (int q = 0; q < 4; ++q)
+        if (posoff(pb(ks, q)) - posoff(pb(ks, 0)) != posoff(pb(0, q)) - posoff(pb(0, 0)) || pb(ks, q) != pb(ks, 0) + q * Q) return false;
+    return true;
+  }
+  static_assert(separable(), "k-step offsets are not lane base + constant");
 };
 typedef GeoW<64, 2, 8, 65, 585, 585, 66> W64s2;
 typedef GeoW<32, 1, 16, 34, 204, 205, 65> W32s1;
@@ -594,17 +603,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
   const int rel = (int)blockIdx.x - jb.wg0, q = rel & 3, z = rel >> 2;
   constexpr int NT = TAP1 ? 1 : 9;
 
-  // per-lane operand offsets of every k-step of a band
-  int aoff[G::NKS_B], boff[G::NKS_B];
+  // per-lane operand bases; the k-step parts are compile-time immediates (GeoW::separable): as two 32-entry per-lane arrays they
+  // held 64 registers for the whole kernel
+  int lpa = 0, lpb = 0;
 #pragma unroll
-  for (int ks = 0; ks < G::NKS_B; ++ks) {
-    int pa = 0, pbv = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (lq == k) { pa = G::pb(ks, k) * G::DS; pbv = G::posoff(G::pb(ks, k)); }
-    aoff[ks] = pa + 16 * w + lr;
-    boff[ks] = TAP1 ? (aoff[ks] - (16 * w + lr)) / G::DS + lr * (G::BPOS + 1) : pbv + lr * G::PS;      // TAP1: compact [ci][position] tile
-  }
+  for (int k = 0; k < 4; ++k)
+    if (lq == k) { lpa = k * G::Q * G::DS; lpb = G::posoff(G::pb(0, k)) - G::posoff(G::pb(0, 0)); }
+  const int abase = lpa + 16 * w + lr;
+  const int bbase = TAP1 ? lq * G::Q + lr * (G::BPOS + 1) : lpb + lr * G::PS;      // TAP1: compact [ci][position] tile
   f32x4_t acc[NT], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -612,14 +618,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
 
   const int nbands = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
   typedef float stage_t __attribute__((ext_vector_type(G::SEGW)));
-#pragma unroll 1
-  for (int band = z; band < nbands; band += jb.nz) {
+  // the band's global loads are issued one band ahead: they are in flight under the previous band's MFMAs instead of in front of
+  // this band's barrier (exposed, a workgroup spent about as long waiting for HBM as computing, and so did its CU partner)
+  stage_t st[TAP1 ? 1 : G::CNT];
+  float s1[TAP1 ? 8 : 1];
+  float4 sd[G::DCNT];
+  auto fetch = [&](int band) __attribute__((always_inline)) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
     const int oy0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
     // ---- stage: x slice (channels 16q .. 16q + 15) and the transposed dy tile ----
     // TAP1 (1x1 stride-2 convolution) only ever reads x[ci][2 oy][2 ox]: a compact [16 ci][128 positions] gather, 8 loads per thread
-    stage_t st[TAP1 ? 1 : G::CNT];
-    float s1[TAP1 ? 8 : 1];
     if (TAP1) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -642,7 +650,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
         st[j] = v;
       }
     }
-    float4 sd[G::DCNT];
 #pragma unroll
     for (int j = 0; j < G::DCNT; ++j) {
       // item e: 4 consecutive band positions p4 .. p4 + 3 of output channel co (they lie in one image plane: PI % 4 == 0).
@@ -656,6 +663,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
       sd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (img0 + il < jb.n_img) sd[j] = *reinterpret_cast<const float4*>(jb.dy + ((size_t)(img0 + il) * CH + co) * G::PI + pin);
     }
+  };
+  if (z < nbands) fetch(z);
+#pragma unroll 1
+  for (int band = z; band < nbands; band += jb.nz) {
     __syncthreads();                   // the previous band's operands have been consumed
     if (TAP1) {
 #pragma unroll
@@ -679,11 +690,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
       d[0] = sd[j].x; d[G::DS] = sd[j].y; d[2 * G::DS] = sd[j].z; d[3 * G::DS] = sd[j].w;
     }
     __syncthreads();
+    if (band + jb.nz < nbands) fetch(band + jb.nz);
 
 #pragma unroll
     for (int ks = 0; ks < G::NKS_B; ++ks) {
-      const float a = dyt[aoff[ks]];
-      const float* bp = xs + boff[ks];
+      const float a = dyt[abase + G::pb(ks, 0) * G::DS];
+      const float* bp = xs + bbase + (TAP1 ? G::pb(ks, 0) : G::posoff(G::pb(ks, 0)));
       if (TAP1) {
         acc[0] = mfma4(a, bp[0], acc[0]);
       } else {
