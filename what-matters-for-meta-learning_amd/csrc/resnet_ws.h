@@ -1038,8 +1038,8 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgJobs job
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {           // 64 co x 128 positions = 2048 float4
-        const int e = tid + j * 256, p4 = 4 * (e % 32), co = e / 32;
+      for (int j = 0; j < 8; ++j) {           // 64 co x 128 positions = 2048 float4; channels along the lanes (see wgrad_kernel: conflict-free transposition)
+        const int e = tid + j * 256, co = e & 63, p4 = 4 * (e >> 6);
         sd[j] = *reinterpret_cast<const float4*>(jb.dy + ((size_t)img * CH + co) * G::PI + oy0 * G::WO + half * HALF + p4);
       }
       __syncthreads();
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgJobs job
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int e = tid + j * 256, p4 = 4 * (e % 32), co = e / 32;
+        const int e = tid + j * 256, co = e & 63, p4 = 4 * (e >> 6);
         float* d = dyt + p4 * DS + co;
         d[0] = sd[j].x; d[DS] = sd[j].y; d[2 * DS] = sd[j].z; d[3 * DS] = sd[j].w;
       }
