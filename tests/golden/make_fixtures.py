@@ -102,6 +102,10 @@ MODEL_CASES = {
     # ragged / edge cases (Nc != Nq, Nc = 0, T = 1, other aggregators, Pascal ANP)
     "s_anp_shapenet1d_ragged": ("ANPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=2, input_dim=3, output_dim=2,
                                                        agg_mode="attention", dim_r=64), 3, 5),
+    # mid-size: enough images for the band / unit loops of every kernel, few enough decisions (9.6 M) that no ReLU / pool tie
+    # routes differently on the GPU - the test asserts flips == 0, so the reference's own gradients are compared directly
+    "s_anp_shapenet1d_t2_full": ("ANPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=2, input_dim=3, output_dim=2,
+                                                        agg_mode="attention", dim_r=64), 15, 15),
     "s_anp_shapenet1d_t1": ("ANPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=1, input_dim=3, output_dim=2,
                                                    agg_mode="attention", dim_r=64), 25, 30),
     "s_anp_shapenet1d_nc0": ("ANPShapeNet1D", dict(task="shapenet_1d", tasks_per_batch=2, input_dim=3, output_dim=2,

@@ -132,10 +132,12 @@ def test_staged_eps_reproduces_the_lazy_draws():
 
 
 def test_committed_bench_line_honours_the_contract():
-    """profiles/r01_final_bench_c3.json is a bench.py line from the MI355X box: the driver's contract fields, the roofline and
-    cpu_baseline objects, metric / unit as BASELINE.json names them."""
+    """The newest profiles/r*_final_bench_c3.json is a bench.py line from the MI355X box: the driver's contract fields, the
+    roofline and cpu_baseline objects, metric / unit as BASELINE.json names them."""
+    import glob
     import json
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench_c3.json")))
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_final_bench_c3.json")))[-1]
+    line = json.load(open(newest))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
