@@ -22,7 +22,7 @@ namespace mlhot {
 
 // Run-time switches (mlhot_set_option): which implementation of a hot-path row runs.  The
 // generic igemm problems are always available as the A/B reference of the specialised kernels.
-struct Options { int conv2_tc; int tail_fused; int materialize_a1; int dbg; };
+struct Options { int conv2_tc; int tail_fused; int materialize_a1; int dbg; int tail_spec; };
 extern Options g_opt;
 constexpr int C2_GRID = 256;   // one persistent workgroup per CU
 

@@ -12,6 +12,7 @@
 #pragma once
 #include "encoder.h"
 #include "tail_fused.h"
+#include "tail_spec.h"
 #include "tail_cnp.h"
 #include "linear_skinny.h"
 #include "favor2.h"
@@ -195,12 +196,18 @@ inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   FavorDims f{d.T, MLHOT_HEADS, d.Nq, d.Nc, d.dim_w, d.m_feat};
   FavorWs w = favor_carve(f, b.favor, b.favor_bytes);
   if (!w.ok || !sc.d_merged) { set_error("tail_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
+  // the kernels specialised for the shipped dimensions (csrc/tail_spec.h) where they apply; the option is a bit mask over the
+  // phases (1 / 2 / 4: forward A / B / C, 8 / 16 / 32: backward C / B / A; default 63 = all; per-phase A/B experiments)
+  const int spec = ts::applies(td) ? g_opt.tail_spec : 0;
   tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, w.pc, w.max_k, w.arg_k, b.wot};
-  MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
+  if (spec & 1) MLHOT_TRY(tail_launch(ts::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, ts::phaseA_lds_bytes(), a, s, "tail.A"));
+  else MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
   tf::PhaseBArgs bb{td, tp, b.dec_in, b.rs, b.qh, b.vh, b.kh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged, sc.d_merged, b.wot};   // sc.d_merged: forward scratch for the heads' _W shares
-  MLHOT_TRY(tail_launch(tf::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_lds_bytes(td), bb, s, "tail.B"));
+  if (spec & 2) MLHOT_TRY(tail_launch(ts::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 512, ts::phaseB_lds_bytes(), bb, s, "tail.B"));
+  else MLHOT_TRY(tail_launch(tf::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_lds_bytes(td), bb, s, "tail.B"));
   tf::PhaseCArgs c{td, tp, sc.d_merged, b.rr, b.dec_in, b.d1, b.d2, mu};
-  MLHOT_TRY(tail_launch(tf::phaseC_fwd_kernel, d.T, 512, tf::phaseC_lds_bytes(td), c, s, "tail.C"));
+  if (spec & 4) MLHOT_TRY(tail_launch(ts::phaseC_fwd_kernel, d.T, 512, ts::phaseC_lds_bytes(), c, s, "tail.C"));
+  else MLHOT_TRY(tail_launch(tf::phaseC_fwd_kernel, d.T, 512, tf::phaseC_lds_bytes(td), c, s, "tail.C"));
   return MLHOT_OK;
 }
 
@@ -280,14 +287,17 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   if (!w.ok || !sc.tail_slab) { set_error("tail_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
   float* part_k = w.rsum_k;   // [T*H]
   tf::PhaseCBwdArgs c{td, tp, sl, dmu, mu, b.d2, b.d1, b.dec_in, b.rr, sc.d_dec_in, sc.d_rr, sc.tail_slab};
-  MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
+  const int spec = ts::applies(td) ? g_opt.tail_spec : 0;
+  if (spec & 8) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel, d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
+  else MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
   // sc.dqh / dkh / dvh double as the heads' input-gradient shares [T*H][N][dw] (same sizes)
   tf::PhaseBBwdArgs bb{td, tp, sl, b.qh, b.kh, b.vh, w.pc, w.qf, w.kf, w.S, w.D, b.merged, sc.d_rr, w.arg_q,
                        b.dec_in, b.cat_in, b.rs, b.wot, sc.dqh, sc.dkh, sc.dvh, part_k, sc.tail_slab};
   MLHOT_TRY(tail_launch(tf::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_bwd_lds_bytes(td), bb, s, "tail.bwd.B"));
   tf::PhaseABwdArgs a{td, tp, sl, ctx_y, b.cat_in, b.h[0], b.h[1], sc.dqh, sc.dkh, sc.dvh, w.pc, part_k, w.gpos,
                       sc.d_dec_in, sc.d_cat_in, sc.tail_slab};
-  MLHOT_TRY(tail_launch(tf::phaseA_bwd_kernel, d.T, 512, tf::phaseA_bwd_lds_bytes(td), a, s, "tail.bwd.A"));
+  if (spec & 32) MLHOT_TRY(tail_launch(ts::phaseA_bwd_kernel, d.T, 512, ts::phaseA_bwd_lds_bytes(), a, s, "tail.bwd.A"));
+  else MLHOT_TRY(tail_launch(tf::phaseA_bwd_kernel, d.T, 512, tf::phaseA_bwd_lds_bytes(td), a, s, "tail.bwd.A"));
   // per-task slabs -> parameter gradients
   tf::SlabReduce r{};
   int ns = 0, maxlen = 0;

@@ -1,0 +1,980 @@
+// The fused ANP tail (tail_fused.h) specialised for the dimensions every shipped vanilla-ANP config uses
+// (cfg/train/ANP_*1D.yaml: dim_w = dim_r = dim_z = 64, n_hidden_units_r = [100, 100], decoder hidden 100, hence
+// m = 266 random features), label / output widths 1..4 at run time.  Same six phases, same argument structs, same saved
+// buffers and slab layout as tail_fused.h - a step may mix the two flavours phase by phase (mlhot_set_option("tail_spec", 0)
+// keeps the generic kernels as the A/B reference) - but organised around what the stage timestamps of the generic kernels
+// showed (scripts/tail_ts.py): a layer of a per-task chain cost ~3.5 us of which ~2 us was ONE exposed L2 round trip for its
+// weights and ~0.5 us making run-time shapes wave-uniform.  Here
+//   * every weight fragment a wave will ever need in the kernel is requested at kernel entry, into registers, together with
+//     the activations (the weights do not depend on them): 60-120 VGPRs per lane, ONE round trip per kernel instead of one
+//     per layer;
+//   * every shape is a compile-time constant: tiles per wave, K-split and fold pattern are fixed, the k-loops unroll into
+//     ds_read_b128 + 4 MFMAs per 16 k with two accumulator chains (a dependent v_mfma_f32_16x16x4_f32 chain issues every 40
+//     cycles, two chains every 32);
+//   * ReLU's backward rides in the data-gradient epilogue and the row sums ride in the tiles that have the data anyway, so a
+//     layer is one barrier (two when its K range is split over idle waves).
+#pragma once
+#include "tail_fused.h"
+
+#ifndef MLHOT_HOSTSIM
+namespace mlhot {
+namespace ts {
+using namespace tf;
+
+constexpr int DW = 64, DZ = 64, H0 = 100, H1 = 100, DH = 100, M = 266;
+constexpr int LDC = DW + DW / 4, LDD = DW + DZ, HD = H * DW;
+constexpr int NWV = 8;                                    // waves per workgroup (512 threads)
+__host__ __device__ constexpr int pad16(int w) { return (w + 15) / 16 * 16; }
+__host__ __device__ constexpr int lds_ld(int w) { return pad16(w) + 4; }
+
+inline bool applies(const TailDims& d) {
+  return d.dw == DW && d.dz == DZ && d.h0 == H0 && d.h1 == H1 && d.dec_h == DH && d.m == M && d.label_dim >= 1 && d.label_dim <= 4 &&
+         d.y_dim >= 1 && d.y_dim <= 4 && d.Nc >= 1 && d.Nc <= 16 && d.Nq >= 1 && d.Nq <= 16;
+}
+
+// ---- Y[16 x N] = act(X[16 x K] W^T + b): weight fragments in registers ------------------------------------------------
+// Work items = (16-column tile of N) x (chunk of the k blocks); item w belongs to wave w.  With fewer tiles than waves the k
+// range is split (NT * NCH <= 8) and folded through LDS in a fixed order.  X lives in LDS with zero padding up to
+// pad16(K) columns, so out-of-range weight addresses are only clamped to something finite.
+// K, N compile time except KR / NR: the run-time extent (<= K / <= N) for the two layers whose width is the label / output size.
+template <int K, int N>
+struct Lin {
+  static constexpr int KB = (K + 15) / 16, NT = (N + 15) / 16;
+  static constexpr int NCH0 = NT >= 5 ? 1 : NT >= 3 ? 2 : NT == 2 ? 4 : 8;
+  static constexpr int NCH = NCH0 < KB ? NCH0 : KB;
+  static constexpr int PER = (KB + NCH - 1) / NCH;
+  f32x4_t b[PER];
+  float bias;
+
+  __device__ __forceinline__ static bool active(int wave) { return wave < NT * NCH; }
+
+  // kr / nr: run-time K / N of this call (= K / N for the fixed layers)
+  __device__ __forceinline__ void load(const float* __restrict__ W, const float* __restrict__ B, int wave, int lane, int kr = K, int nr = N) {
+    bias = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) b[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (!active(wave)) return;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int tile = wave % NT, chunk = wave / NT;
+    const int n = tile * 16 + lr, nc = n < nr ? n : nr - 1;
+    bias = B[nc];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int kb = chunk * PER + i;
+      if constexpr (K % 4 == 0) {
+        int k0 = kb * 16 + 4 * lq;
+        k0 = k0 <= K - 4 ? k0 : K - 4;
+        b[i] = *reinterpret_cast<const f32x4_t*>(W + nc * K + k0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = kb * 16 + 4 * lq + e;
+          b[i][e] = W[nc * kr + (k < kr ? k : kr - 1)];
+        }
+      }
+    }
+  }
+
+  // this wave's partial tile: rows 4 lq + r, column tile * 16 + lr
+  __device__ __forceinline__ f32x4_t mma(lcptr x, int ldx, int wave, int lane) const {
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    if (active(wave)) {
+      const int lr = lane & 15, lq = lane >> 4;
+      const int chunk = wave / NT;
+      lcptr xr = x + lr * ldx + 4 * lq;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int kb = chunk * PER + i;
+        if (kb < KB) {
+          const f32x4_t a = *reinterpret_cast<lc4ptr>(xr + kb * 16);
+          if (i & 1) {
+            a1 = mfma4(a[0], b[i][0], a1); a1 = mfma4(a[1], b[i][1], a1); a1 = mfma4(a[2], b[i][2], a1); a1 = mfma4(a[3], b[i][3], a1);
+          } else {
+            a0 = mfma4(a[0], b[i][0], a0); a0 = mfma4(a[1], b[i][1], a0); a0 = mfma4(a[2], b[i][2], a0); a0 = mfma4(a[3], b[i][3], a0);
+          }
+        }
+      }
+    }
+    return a0 + a1;
+  }
+
+  // fold the k chunks (fixed order), bias, activation, stores.  Call from ALL waves (one barrier inside when NCH > 1).
+  // ys: LDS tile (row stride ldy) or nullptr; yg: global rows (< nrows, row stride ldg) or nullptr.
+  __device__ __forceinline__ void finish(f32x4_t acc, int act, lptr red, lptr ys, int ldy, float* __restrict__ yg, int ldg, int nrows,
+                                         int wave, int lane, int nr = N) const {
+    const int lr = lane & 15, lq = lane >> 4;
+    const int tile = wave % NT, chunk = wave / NT;
+    if constexpr (NCH > 1) {
+      if (active(wave) && chunk > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+      }
+      __syncthreads();
+      if (active(wave) && chunk == 0) {
+#pragma unroll
+        for (int c = 1; c < NCH; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] += red[((wave + c * NT) * 4 + r) * 64 + lane];
+      }
+    }
+    if (active(wave) && chunk == 0) {
+      const int n = tile * 16 + lr;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[r] + bias;
+      if (act == ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (act == ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+      }
+      if (n < nr) {
+        if (ys != nullptr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ys[(4 * lq + r) * ldy + n] = v[r];
+        }
+        if (yg != nullptr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * lq + r < nrows) yg[(4 * lq + r) * ldg + n] = v[r];
+        }
+      }
+    }
+  }
+};
+
+// one 16 x 64 activation tile (rows < nrows of a [rows][ldg] global matrix, 64 columns from column c0) as one float4 per
+// thread of the first 256: issue (registers) / stash (LDS, row stride ld)
+struct Tile64 {
+  f32x4_t v;
+  __device__ __forceinline__ void fetch(const float* __restrict__ src, int ldg, int nrows, int tid) {
+    const int row = (tid >> 4) & 15, c4 = tid & 15;
+    v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (tid < 256 && row < nrows) v = *reinterpret_cast<const f32x4_t*>(src + (size_t)row * ldg + 4 * c4);
+  }
+  __device__ __forceinline__ void stash(lptr dst, int ld, int tid) const {
+    const int row = (tid >> 4) & 15, c4 = tid & 15;
+    if (tid < 256) *reinterpret_cast<MLHOT_LDS f32x4_t*>(dst + row * ld + 4 * c4) = v;
+  }
+};
+
+__device__ __forceinline__ void lds_zero4(lptr p, int nfloats, int tid) {      // nfloats % 4 == 0, p 16-byte aligned
+  const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < nfloats / 4; i += NWV * 64) reinterpret_cast<MLHOT_LDS f32x4_t*>(p)[i] = z;
+}
+
+// ==================================================================================================
+// phase A forward (see tail_fused.h): blocks [0, T) walk transform_y + EncoderFC of one task, blocks [T, T + T*H) make the
+// key projection of one (task, head) and its share of the batch-global key stabiliser.
+// ==================================================================================================
+constexpr int A_LCAT = lds_ld(LDC), A_LH = lds_ld(H0), A_LY = 20, A_LX = lds_ld(DW);
+constexpr int A_CHAIN_FLOATS = 16 * (A_LCAT + 2 * A_LH + A_LY) + NWV * 256;
+constexpr int A_KEY_FLOATS = 32 * A_LX + 16;
+__host__ inline size_t phaseA_lds_bytes() { return sizeof(float) * (A_CHAIN_FLOATS > A_KEY_FLOATS ? A_CHAIN_FLOATS : A_KEY_FLOATS); }
+
+__device__ __forceinline__ void keyhead_block(const PhaseAArgs& a, lptr L0, int th, int tid) {
+  const TailDims& d = a.d;
+  const int t = th / H, h = th - t * H, lane = tid & 63, wave = uni(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  lptr s_x = L0;                       // [16][A_LX] x_ctx
+  lptr s_k = s_x + 16 * A_LX;          // [16][A_LX] kh
+  lptr s_red = s_k + 16 * A_LX;        // [8] max, [8] packed position
+  // ---- every global read of the block, up front
+  Tile64 xt;
+  xt.fetch(a.cat_in + (size_t)t * d.Nc * LDC, LDC, d.Nc, tid);
+  const float* wk = a.p.wk_w[0]; const float* bk = a.p.wk_b[0];
+#pragma unroll
+  for (int i = 1; i < H; ++i)
+    if (h == i) { wk = a.p.wk_w[i]; bk = a.p.wk_b[i]; }
+  f32x4_t wkf[4]; float kbias = 0.f;
+  if (wave < 4) {
+    kbias = bk[wave * 16 + lr];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) wkf[kb] = *reinterpret_cast<const f32x4_t*>(wk + (wave * 16 + lr) * DW + kb * 16 + 4 * lq);
+  }
+  constexpr int NTILE = (M + 15) / 16;             // 17 feature tiles: waves take tiles wave, wave + 8, wave + 16
+  f32x4_t pf[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int jt = wave + 8 * i;
+    if (jt < NTILE) {
+      const int j = jt * 16 + lr, jc = j < M ? j : M - 1;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) pf[i][kb] = *reinterpret_cast<const f32x4_t*>(a.p.proj + (size_t)jc * DW + kb * 16 + 4 * lq);
+    }
+  }
+  // head-major copy of _W's weight for phase B (forward and backward): wot[h][j][e] = Wo[j][e*H + h]; the T blocks of a head
+  // copy 1/T of its [dw][dw] block each
+  {
+    const int per = (DW * DW + d.T - 1) / d.T, lo = t * per, hi = lo + per < DW * DW ? lo + per : DW * DW;
+    for (int i = lo + tid; i < hi; i += NWV * 64) {
+      const int j = i / DW, e = i - j * DW;
+      a.wot[(size_t)h * DW * DW + i] = a.p.wo_w[(size_t)j * HD + e * H + h];
+    }
+  }
+  lds_zero4(L0, 32 * A_LX, tid);
+  __syncthreads();
+  xt.stash(s_x, A_LX, tid);
+  __syncthreads();
+  if (wave < 4) {                                   // kh tile of wave: 16 columns
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const f32x4_t x = *reinterpret_cast<lc4ptr>(s_x + lr * A_LX + kb * 16 + 4 * lq);
+      if (kb & 1) { a1 = mfma4(x[0], wkf[kb][0], a1); a1 = mfma4(x[1], wkf[kb][1], a1); a1 = mfma4(x[2], wkf[kb][2], a1); a1 = mfma4(x[3], wkf[kb][3], a1); }
+      else { a0 = mfma4(x[0], wkf[kb][0], a0); a0 = mfma4(x[1], wkf[kb][1], a0); a0 = mfma4(x[2], wkf[kb][2], a0); a0 = mfma4(x[3], wkf[kb][3], a0); }
+    }
+    const int n = wave * 16 + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * lq + r;
+      if (row < d.Nc) {                 // rows >= Nc stay zero: they must not enter the max below
+        const float v = a0[r] + a1[r] + kbias;
+        s_k[row * A_LX + n] = v;
+        a.kh[(size_t)(t * d.Nc + row) * HD + h * DW + n] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const float c = powf((float)DW, -0.25f);
+  float best = -INFINITY; int bcode = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int jt = wave + 8 * i;
+    if (jt < NTILE) {
+      const int j = jt * 16 + lr;
+      f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const f32x4_t x = *reinterpret_cast<lc4ptr>(s_k + lr * A_LX + kb * 16 + 4 * lq);
+        const f32x4_t b = pf[i][kb] * c;
+        if (kb & 1) { a1 = mfma4(x[0], b[0], a1); a1 = mfma4(x[1], b[1], a1); a1 = mfma4(x[2], b[2], a1); a1 = mfma4(x[3], b[3], a1); }
+        else { a0 = mfma4(x[0], b[0], a0); a0 = mfma4(x[1], b[1], a0); a0 = mfma4(x[2], b[2], a0); a0 = mfma4(x[3], b[3], a0); }
+      }
+      if (j < M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * lq + r;
+          if (row < d.Nc) {
+            const float v = a0[r] + a1[r];
+            const int code = ((t * d.Nc + row) * H + h) * 4096 + j;      // row index of the [T*Nc*H, m] view, column
+            if (kmax_better(v, code, best, bcode)) { best = v; bcode = code; }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int oc = __shfl_xor(bcode, off, 64);
+    if (kmax_better(ov, oc, best, bcode)) { best = ov; bcode = oc; }
+  }
+  MLHOT_LDS int* s_redi = reinterpret_cast<MLHOT_LDS int*>(s_red + 8);
+  if (lane == 0) { s_red[wave] = best; s_redi[wave] = bcode; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < NWV; ++w)
+      if (kmax_better(s_red[w], s_redi[w], best, bcode)) { best = s_red[w]; bcode = s_redi[w]; }
+    a.tmax[th] = best; a.targ[th] = bcode;
+  }
+}
+
+__global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lptr L0 = (lptr)lds;
+  const TailDims& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  if ((int)blockIdx.x >= d.T) { keyhead_block(a, L0, blockIdx.x - d.T, tid); return; }
+  const int t = blockIdx.x;
+  lptr s_cat = L0;                     // [16][A_LCAT]  [x_ctx | transform_y(ctx_y)]
+  lptr s_h0 = s_cat + 16 * A_LCAT;
+  lptr s_h1 = s_h0 + 16 * A_LH;
+  lptr s_y = s_h1 + 16 * A_LH;         // [16][A_LY] labels
+  lptr s_red = s_y + 16 * A_LY;        // [8 waves][256] K-split partials
+  // ---- every global read of the block, up front
+  Tile64 xt;
+  xt.fetch(a.cat_in + (size_t)t * d.Nc * LDC, LDC, d.Nc, tid);
+  float yv = 0.f;
+  if (tid < d.Nc * d.label_dim) yv = a.ctx_y[(size_t)t * d.Nc * d.label_dim + tid];
+  Lin<4, DW / 4> l_ty;  Lin<LDC, H0> l_e0;  Lin<H0, H1> l_e1;  Lin<H1, DW> l_e2;
+  // transform_y: K = label_dim (1..4, run time) rides in a K = 4 layer through the scalar path
+  if (wave == 0) {
+    const int lr = lane & 15, lq = lane >> 4;
+    l_ty.bias = a.p.ty_b[lr];
+    l_ty.b[0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (lq == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) l_ty.b[0][e] = a.p.ty_w[lr * d.label_dim + (e < d.label_dim ? e : d.label_dim - 1)];
+    }
+  }
+  l_e0.load(a.p.er_w[0], a.p.er_b[0], wave, lane);
+  l_e1.load(a.p.er_w[1], a.p.er_b[1], wave, lane);
+  l_e2.load(a.p.er_w[2], a.p.er_b[2], wave, lane);
+  // pc = c * P for the later phases: each task writes its slice
+  {
+    const float c = powf((float)DW, -0.25f);
+    constexpr int n = M * DW;
+    const int per = ((n / 4 + d.T - 1) / d.T) * 4, lo = t * per, hi = lo + per < n ? lo + per : n;
+    for (int i = lo + 4 * tid; i < hi; i += 4 * NWV * 64) {
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(a.p.proj + i);
+      *reinterpret_cast<f32x4_t*>(a.pc + i) = v * c;
+    }
+  }
+  lds_zero4(L0, 16 * (A_LCAT + 2 * A_LH + A_LY), tid);
+  __syncthreads();
+  xt.stash(s_cat, A_LCAT, tid);
+  if (tid < d.Nc * d.label_dim) s_y[(tid / d.label_dim) * A_LY + tid % d.label_dim] = yv;
+  __syncthreads();
+  float* g_cat = a.cat_in + (size_t)t * d.Nc * LDC;
+  // transform_y -> cat[:, dw:]   (padding columns of s_y are zero, so the clamped weight columns contribute nothing)
+  if (wave == 0) {
+    const int lr = lane & 15, lq = lane >> 4;
+    const f32x4_t x = *reinterpret_cast<lc4ptr>(s_y + lr * A_LY + 4 * lq);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    acc = mfma4(x[0], l_ty.b[0][0], acc); acc = mfma4(x[1], l_ty.b[0][1], acc); acc = mfma4(x[2], l_ty.b[0][2], acc); acc = mfma4(x[3], l_ty.b[0][3], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * lq + r;
+      const float v = acc[r] + l_ty.bias;
+      s_cat[row * A_LCAT + DW + lr] = v;
+      if (row < d.Nc) g_cat[row * LDC + DW + lr] = v;
+    }
+  }
+  __syncthreads();
+  l_e0.finish(l_e0.mma(s_cat, A_LCAT, wave, lane), ACT_RELU, s_red, s_h0, A_LH, a.h0 + (size_t)t * d.Nc * H0, H0, d.Nc, wave, lane);
+  __syncthreads();
+  l_e1.finish(l_e1.mma(s_h0, A_LH, wave, lane), ACT_RELU, s_red, s_h1, A_LH, a.h1 + (size_t)t * d.Nc * H1, H1, d.Nc, wave, lane);
+  __syncthreads();
+  l_e2.finish(l_e2.mma(s_h1, A_LH, wave, lane), ACT_NONE, s_red, nullptr, 0, a.rs + (size_t)t * d.Nc * DW, DW, d.Nc, wave, lane);
+}
+
+// ==================================================================================================
+// phase B forward, one workgroup per (task, head): this head's query / value projections, FAVOR+ in the S-form, the head's
+// share of _W(merged).  Same outputs as tf::phaseB_fwd_kernel.
+// ==================================================================================================
+constexpr int B_LX = lds_ld(DW), B_LF = lds_ld(M);
+constexpr int B_FLOATS = 16 * (5 * B_LX + 2 * B_LF) + 8 * 16 * 17 + 16 * 17 + 64 + 16;
+__host__ inline size_t phaseB_lds_bytes() { return sizeof(float) * B_FLOATS; }
+
+__global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lptr L0 = (lptr)lds;
+  const TailDims& d = a.d;
+  const int t = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  lptr s_q = L0;                      // [16][B_LX]
+  lptr s_k = s_q + 16 * B_LX;
+  lptr s_v = s_k + 16 * B_LX;
+  lptr s_xq = s_v + 16 * B_LX;        // x_qry, later this head's attention output
+  lptr s_rs = s_xq + 16 * B_LX;
+  lptr s_qf = s_rs + 16 * B_LX;       // [16][B_LF]  dd -> E
+  lptr s_kf = s_qf + 16 * B_LF;
+  lptr s_Sp = s_kf + 16 * B_LF;       // [8 waves][16][17] partial S
+  lptr s_S = s_Sp + 8 * 16 * 17;      // [16][17] S
+  lptr s_st = s_S + 16 * 17;          // diag_q[16], diag_k[16], max_q[16], D[16]; [64]: the batch-global key maximum
+  // ---- every global read of the block, up front
+  Tile64 xq, xr, xk;
+  xq.fetch(a.dec_in + (size_t)t * d.Nq * LDD, LDD, d.Nq, tid);
+  xr.fetch(a.rs + (size_t)t * d.Nc * DW, DW, d.Nc, tid);
+  xk.fetch(a.kh + (size_t)t * d.Nc * HD + h * DW, HD, d.Nc, tid);
+  float gm = -INFINITY; int gcode = 0x7fffffff;
+  if (wave == 0) {
+    for (int i = lane; i < d.T * H; i += 64) {
+      const float v = a.tmax[i]; const int cd = a.targ[i];
+      if (kmax_better(v, cd, gm, gcode)) { gm = v; gcode = cd; }
+    }
+  }
+  const float *wq = a.p.wq_w[0], *bq = a.p.wq_b[0], *wv = a.p.wv_w[0], *bv = a.p.wv_b[0];
+#pragma unroll
+  for (int i = 1; i < H; ++i)
+    if (h == i) { wq = a.p.wq_w[i]; bq = a.p.wq_b[i]; wv = a.p.wv_w[i]; bv = a.p.wv_b[i]; }
+  const bool isv = wave >= 4;                       // waves 0-3: query tiles, 4-7: value tiles
+  const int pn = (wave & 3) * 16 + lr;
+  f32x4_t wpf[4], wof[4];
+  const float pbias = (isv ? bv : bq)[pn];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) wpf[kb] = *reinterpret_cast<const f32x4_t*>((isv ? wv : wq) + pn * DW + kb * 16 + 4 * lq);
+  if (wave < 4) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) wof[kb] = *reinterpret_cast<const f32x4_t*>(a.wot + (size_t)h * DW * DW + (16 * wave + lr) * DW + kb * 16 + 4 * lq);
+  }
+  constexpr int NTILE = (M + 15) / 16;
+  f32x4_t pf[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int jt = wave + 8 * i;
+    if (jt < NTILE) {
+      const int j = jt * 16 + lr, jc = j < M ? j : M - 1;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) pf[i][kb] = *reinterpret_cast<const f32x4_t*>(a.pc + (size_t)jc * DW + kb * 16 + 4 * lq);
+    }
+  }
+  lds_zero4(L0, B_FLOATS, tid);
+  __syncthreads();
+  xq.stash(s_xq, B_LX, tid);
+  xr.stash(s_rs, B_LX, tid);
+  xk.stash(s_k, B_LX, tid);
+  // batch-global key stabiliser (identical in every workgroup): largest share, first position on ties
+  if (wave == 0) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(gm, off, 64);
+      const int oc = __shfl_xor(gcode, off, 64);
+      if (kmax_better(ov, oc, gm, gcode)) { gm = ov; gcode = oc; }
+    }
+    if (lane == 0) {
+      s_st[64] = gm;
+      if (blockIdx.x == 0) { a.gmax[0] = gm; a.gpos[0] = gcode >> 12; a.gpos[1] = gcode & 4095; }
+    }
+  }
+  __syncthreads();
+  gm = s_st[64];
+  // this head's query and value projections: qh = W_q,h(x_qry), vh = W_v,h(rs)
+  {
+    lcptr xs = isv ? s_rs : s_xq;
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const f32x4_t x = *reinterpret_cast<lc4ptr>(xs + lr * B_LX + kb * 16 + 4 * lq);
+      if (kb & 1) { a1 = mfma4(x[0], wpf[kb][0], a1); a1 = mfma4(x[1], wpf[kb][1], a1); a1 = mfma4(x[2], wpf[kb][2], a1); a1 = mfma4(x[3], wpf[kb][3], a1); }
+      else { a0 = mfma4(x[0], wpf[kb][0], a0); a0 = mfma4(x[1], wpf[kb][1], a0); a0 = mfma4(x[2], wpf[kb][2], a0); a0 = mfma4(x[3], wpf[kb][3], a0); }
+    }
+    lptr ys = isv ? s_v : s_q;
+    float* yg = isv ? a.vh : a.qh;
+    const int nrows = isv ? d.Nc : d.Nq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * lq + r;
+      if (row < nrows) {
+        const float v = a0[r] + a1[r] + pbias;
+        ys[row * B_LX + pn] = v;
+        yg[(size_t)(t * nrows + row) * HD + h * DW + pn] = v;
+      }
+    }
+  }
+  __syncthreads();
+  // dd tiles: q and k against pc (shared B operand, two independent accumulator chains)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int jt = wave + 8 * i;
+    if (jt < NTILE) {
+      const int j = jt * 16 + lr;
+      f32x4_t accq = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const f32x4_t xqv = *reinterpret_cast<lc4ptr>(s_q + lr * B_LX + kb * 16 + 4 * lq);
+        const f32x4_t xkv = *reinterpret_cast<lc4ptr>(s_k + lr * B_LX + kb * 16 + 4 * lq);
+        const f32x4_t b = pf[i][kb];
+        accq = mfma4(xqv[0], b[0], accq); acck = mfma4(xkv[0], b[0], acck);
+        accq = mfma4(xqv[1], b[1], accq); acck = mfma4(xkv[1], b[1], acck);
+        accq = mfma4(xqv[2], b[2], accq); acck = mfma4(xkv[2], b[2], acck);
+        accq = mfma4(xqv[3], b[3], accq); acck = mfma4(xkv[3], b[3], acck);
+      }
+      if (j < M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s_qf[(4 * lq + r) * B_LF + j] = accq[r]; s_kf[(4 * lq + r) * B_LF + j] = acck[r]; }
+      }
+    }
+  }
+  // diag = c^2/2 |x|^2 : 32 rows (16 q + 16 k), 16 threads per row
+  {
+    const float half_c2 = 0.5f / sqrtf((float)DW);
+    const int row = tid >> 4, part = tid & 15;
+    lcptr xrow = (row < 16 ? s_q + row * B_LX : s_k + (row - 16) * B_LX);
+    const f32x4_t x = *reinterpret_cast<lc4ptr>(xrow + 4 * part);
+    float s = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+    if (part == 0) s_st[row] = s * half_c2;
+  }
+  __syncthreads();
+  // query row max / first arg-max: 16 rows x 32 threads
+  {
+    const int row = tid >> 5, part = tid & 31;
+    float best = -INFINITY; int arg = 0x7fffffff;
+    for (int j = part; j < M; j += 32) { const float v = s_qf[row * B_LF + j]; if (v > best) { best = v; arg = j; } }
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const float ov = __shfl_xor(best, off, 64); const int oa = __shfl_xor(arg, off, 64);
+      if (ov > best || (ov == best && oa < arg)) { best = ov; arg = oa; }
+    }
+    if (part == 0) {
+      s_st[32 + row] = best;
+      if (row < d.Nq) a.arg_q[(t * d.Nq + row) * H + h] = arg;
+    }
+  }
+  __syncthreads();
+  // E features in place (padding columns j >= m stay exactly 0), valid rows saved for the backward right away
+  const float ratio = 1.0f / sqrtf((float)M), re = ratio * 1e-4f;
+  for (int row = wave; row < 16; row += NWV) {
+    const float sq = s_st[row] + s_st[32 + row], sk = s_st[16 + row] + gm;
+    float* gq = a.qf + ((size_t)(t * d.Nq + row) * H + h) * M;
+    float* gk = a.kf + ((size_t)(t * d.Nc + row) * H + h) * M;
+    for (int j = lane; j < M; j += 64) {
+      const float eq = ratio * expf(s_qf[row * B_LF + j] - sq), ek = ratio * expf(s_kf[row * B_LF + j] - sk);
+      s_qf[row * B_LF + j] = eq;
+      s_kf[row * B_LF + j] = ek;
+      if (row < d.Nq) gq[j] = eq;
+      if (row < d.Nc) gk[j] = ek;
+    }
+  }
+  __syncthreads();
+  // S = (Eq + re)(Ek + re)^T : M = 16 q rows, N = 16 k rows, K = m split over the 8 waves
+  {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = wave * 4; j0 < M; j0 += 32) {
+      const int j = j0 + lq;
+      const bool vj = j < M;
+      const float av = vj ? s_qf[lr * B_LF + j] + re : 0.f;
+      const float bvv = vj ? s_kf[lr * B_LF + j] + re : 0.f;
+      acc = mfma4(av, bvv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_Sp[(wave * 16 + 4 * lq + r) * 17 + lr] = acc[r];
+  }
+  __syncthreads();
+  if (tid < 256) {                                  // fold the partials; D = row sums (16 consecutive lanes hold a row)
+    const int n = tid >> 4, np = tid & 15;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) s += s_Sp[(16 * w + n) * 17 + np];
+    if (n >= d.Nq || np >= d.Nc) s = 0.f;
+    s_S[n * 17 + np] = s;
+    if (n < d.Nq && np < d.Nc) a.S[(((size_t)t * H + h) * d.Nq + n) * d.Nc + np] = s;
+    float dsum = s;
+    dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64); dsum += __shfl_xor(dsum, 4, 64); dsum += __shfl_xor(dsum, 8, 64);
+    if (np == 0) {
+      s_st[48 + n] = dsum;
+      if (n < d.Nq) a.D[((size_t)t * H + h) * d.Nq + n] = dsum;
+    }
+  }
+  __syncthreads();
+  // out[n][e] = sum_n' S[n][n'] v[n'][e] / D[n]: one e tile per wave 0-3, K = 16 k rows
+  if (wave < 4) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int np = 4 * s4 + lq;
+      acc = mfma4(s_S[lr * 17 + np], s_v[np * B_LX + wave * 16 + lr], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 4 * lq + r, e = wave * 16 + lr;
+      const float o = n < d.Nq ? acc[r] / s_st[48 + n] : 0.f;
+      if (n < d.Nq) a.merged[(size_t)(t * d.Nq + n) * HD + e * H + h] = o;
+      s_xq[n * B_LX + e] = o;                          // x_qry is no longer needed: the tile now holds this head's output
+    }
+  }
+  __syncthreads();
+  // share of rr = _W(merged): rrp[n][j] = sum_e out[n][e] Wo[j][e*H + h], Wo_h from the head-major copy
+  if (wave < 4) {
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const f32x4_t x = *reinterpret_cast<lc4ptr>(s_xq + lr * B_LX + kb * 16 + 4 * lq);
+      if (kb & 1) { a1 = mfma4(x[0], wof[kb][0], a1); a1 = mfma4(x[1], wof[kb][1], a1); a1 = mfma4(x[2], wof[kb][2], a1); a1 = mfma4(x[3], wof[kb][3], a1); }
+      else { a0 = mfma4(x[0], wof[kb][0], a0); a0 = mfma4(x[1], wof[kb][1], a0); a0 = mfma4(x[2], wof[kb][2], a0); a0 = mfma4(x[3], wof[kb][3], a0); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 4 * lq + r;
+      if (n < d.Nq) a.rrp[((size_t)(t * H + h) * d.Nq + n) * DW + 16 * wave + lr] = a0[r] + a1[r];
+    }
+  }
+}
+
+// ==================================================================================================
+// phase C forward, one workgroup per task: rr = _W(merged) (bias + the 8 heads' shares); z = r_to_z(rr) -> dec_in[:, dw:];
+// d1, d2 = decoder hidden; mu = act(decoder out).
+// ==================================================================================================
+constexpr int C_LR = lds_ld(DW), C_LD = lds_ld(LDD), C_LH = lds_ld(DH);
+constexpr int C_FLOATS = 16 * (C_LR + C_LD + 2 * C_LH) + NWV * 256;
+__host__ inline size_t phaseC_lds_bytes() { return sizeof(float) * C_FLOATS; }
+
+__global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lptr L0 = (lptr)lds;
+  const TailDims& d = a.d;
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  lptr s_rr = L0;                  // [16][C_LR]
+  lptr s_dec = s_rr + 16 * C_LR;   // [16][C_LD]  [x_qry | z]
+  lptr s_d1 = s_dec + 16 * C_LD;
+  lptr s_d2 = s_d1 + 16 * C_LH;
+  lptr s_red = s_d2 + 16 * C_LH;   // [8 waves][256] K-split partials
+  // ---- every global read of the block, up front
+  Tile64 xq;
+  xq.fetch(a.dec_in + (size_t)t * d.Nq * LDD, LDD, d.Nq, tid);
+  // rr = _W(merged) = bias + the 8 heads' shares (fixed order): thread = (row tid / 32, columns 2 (tid % 32) .. + 1)
+  float2 rv[H]; float2 rb = make_float2(0.f, 0.f);
+  const int rrow = tid >> 5, rcol = 2 * (tid & 31);
+  if (rrow < d.Nq) {
+    rb = *reinterpret_cast<const float2*>(a.p.wo_b + rcol);
+#pragma unroll
+    for (int h = 0; h < H; ++h) rv[h] = *reinterpret_cast<const float2*>(a.rrp + ((size_t)(t * H + h) * d.Nq + rrow) * DW + rcol);
+  }
+  Lin<DW, DZ> l_z;  Lin<LDD, DH> l_d0;  Lin<DH, DH> l_d1;  Lin<DH, 4> l_d2;
+  l_z.load(a.p.r2z_w, a.p.r2z_b, wave, lane);
+  l_d0.load(a.p.dec_w[0], a.p.dec_b[0], wave, lane);
+  l_d1.load(a.p.dec_w[1], a.p.dec_b[1], wave, lane);
+  l_d2.load(a.p.dec_w[2], a.p.dec_b[2], wave, lane, DH, d.y_dim);
+  lds_zero4(L0, 16 * (C_LR + C_LD + 2 * C_LH), tid);
+  __syncthreads();
+  xq.stash(s_dec, C_LD, tid);
+  if (rrow < d.Nq) {
+    float2 sum = rb;
+#pragma unroll
+    for (int h = 0; h < H; ++h) { sum.x += rv[h].x; sum.y += rv[h].y; }
+    s_rr[rrow * C_LR + rcol] = sum.x; s_rr[rrow * C_LR + rcol + 1] = sum.y;
+    *reinterpret_cast<float2*>(a.rr + ((size_t)t * d.Nq + rrow) * DW + rcol) = sum;
+  }
+  __syncthreads();
+  float* g_dec = a.dec_in + (size_t)t * d.Nq * LDD;
+  l_z.finish(l_z.mma(s_rr, C_LR, wave, lane), ACT_NONE, s_red, s_dec + DW, C_LD, g_dec + DW, LDD, d.Nq, wave, lane);
+  __syncthreads();
+  l_d0.finish(l_d0.mma(s_dec, C_LD, wave, lane), ACT_RELU, s_red, s_d1, C_LH, a.d1 + (size_t)t * d.Nq * DH, DH, d.Nq, wave, lane);
+  __syncthreads();
+  l_d1.finish(l_d1.mma(s_d1, C_LH, wave, lane), ACT_RELU, s_red, s_d2, C_LH, a.d2 + (size_t)t * d.Nq * DH, DH, d.Nq, wave, lane);
+  __syncthreads();
+  l_d2.finish(l_d2.mma(s_d2, C_LH, wave, lane), d.out_act, s_red, nullptr, 0, a.mu + (size_t)t * d.Nq * d.y_dim, d.y_dim, d.Nq, wave, lane, d.y_dim);
+}
+
+// ==================================================================================================
+// backward building blocks
+// ==================================================================================================
+
+// dX[16 x KIN] = dY[16 x NOUT] W[NOUT x KIN], W fragments in registers (4 dwords per 16 rows of W, coalesced along KIN).
+// Items = (16-column tile of KIN) x (chunk of the j blocks), item w on wave w; dY in LDS with zero padding up to
+// pad16(NOUT) columns.  finish(): fold, optional ReLU mask from the saved activation tile (same layout as the result),
+// zero padding columns up to pad16(KIN) in the LDS result, rows < nrows to global.
+template <int NOUT, int KIN>
+struct Dg {
+  static constexpr int JB = (NOUT + 15) / 16, NI = (KIN + 15) / 16;
+  static constexpr int NCH0 = NI >= 5 ? 1 : NI >= 3 ? 2 : NI == 2 ? 4 : 8;
+  static constexpr int NCH = NCH0 < JB ? NCH0 : JB;
+  static constexpr int PER = (JB + NCH - 1) / NCH;
+  float b[PER][4];
+
+  __device__ __forceinline__ static bool active(int wave) { return wave < NI * NCH; }
+
+  __device__ __forceinline__ void load(const float* __restrict__ W, int wave, int lane, int nout = NOUT) {
+#pragma unroll
+    for (int p = 0; p < PER; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[p][e] = 0.f;
+    if (!active(wave)) return;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int tile = wave % NI, chunk = wave / NI;
+    const int i = tile * 16 + lr, ic = i < KIN ? i : KIN - 1;
+#pragma unroll
+    for (int p = 0; p < PER; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = (chunk * PER + p) * 16 + 4 * lq + e;
+        b[p][e] = W[(j < nout ? j : nout - 1) * KIN + ic];
+      }
+  }
+
+  __device__ __forceinline__ f32x4_t mma(lcptr dys, int ldy, int wave, int lane) const {
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    if (active(wave)) {
+      const int lr = lane & 15, lq = lane >> 4;
+      const int chunk = wave / NI;
+      lcptr yr = dys + lr * ldy + 4 * lq;
+#pragma unroll
+      for (int p = 0; p < PER; ++p) {
+        const int jb = chunk * PER + p;
+        if (jb < JB) {
+          const f32x4_t a = *reinterpret_cast<lc4ptr>(yr + jb * 16);
+          if (p & 1) { a1 = mfma4(a[0], b[p][0], a1); a1 = mfma4(a[1], b[p][1], a1); a1 = mfma4(a[2], b[p][2], a1); a1 = mfma4(a[3], b[p][3], a1); }
+          else { a0 = mfma4(a[0], b[p][0], a0); a0 = mfma4(a[1], b[p][1], a0); a0 = mfma4(a[2], b[p][2], a0); a0 = mfma4(a[3], b[p][3], a0); }
+        }
+      }
+    }
+    return a0 + a1;
+  }
+
+  // Call from ALL waves (one barrier inside when NCH > 1).
+  __device__ __forceinline__ void finish(f32x4_t acc, lptr red, lcptr relu_of, int ldm, lptr dxs, int ldxs, float* __restrict__ dxg, int ldg,
+                                         int nrows, int wave, int lane) const {
+    const int lr = lane & 15, lq = lane >> 4;
+    const int tile = wave % NI, chunk = wave / NI;
+    if constexpr (NCH > 1) {
+      if (active(wave) && chunk > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+      }
+      __syncthreads();
+      if (active(wave) && chunk == 0) {
+#pragma unroll
+        for (int c = 1; c < NCH; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] += red[((wave + c * NI) * 4 + r) * 64 + lane];
+      }
+    }
+    if (active(wave) && chunk == 0) {
+      const int i = tile * 16 + lr;
+      const bool vi = i < KIN;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = vi ? acc[r] : 0.f;
+        if (relu_of != nullptr) v = relu_of[(4 * lq + r) * ldm + i] > 0.f ? v : 0.f;
+        if (dxs != nullptr) dxs[(4 * lq + r) * ldxs + i] = v;
+        if (dxg != nullptr && vi && 4 * lq + r < nrows) dxg[(4 * lq + r) * ldg + i] = v;
+      }
+    }
+  }
+};
+
+// dW[NOUT x KIN] = dY^T X over the 16 rows (padded rows of dY are zero), db = column sums of dY; both to the task's slab.
+// Output tiles (16 j x 16 i) round-robin over the waves, 4 MFMAs each, operands straight from LDS.
+template <int NOUT, int KIN>
+__device__ __forceinline__ void wgrad16(lcptr dys, int ldy, lcptr xs, int ldx, float* __restrict__ dw, float* __restrict__ db,
+                                        int wave, int lane, int tid, int nout = NOUT, int kin = KIN) {
+  constexpr int NJ = (NOUT + 15) / 16, NI = (KIN + 15) / 16, TRIPS = (NJ * NI + NWV - 1) / NWV;
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int tr = 0; tr < TRIPS; ++tr) {
+    const int it = wave + NWV * tr;
+    if (it < NJ * NI) {
+      const int jt = it / NI, j0 = jt * 16, i0 = (it - jt * NI) * 16;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int row = 4 * s4 + lq;
+        acc = mfma4(dys[row * ldy + j0 + lr], xs[row * ldx + i0 + lr], acc);
+      }
+      const int i = i0 + lr;
+      if (i < kin) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = j0 + 4 * lq + r;
+          if (j < nout) dw[j * kin + i] = acc[r];
+        }
+      }
+    }
+  }
+  if (db != nullptr && tid < nout) {
+    float sum = 0.f;
+#pragma unroll
+    for (int row = 0; row < 16; ++row) sum += dys[row * ldy + tid];
+    db[tid] = sum;
+  }
+}
+
+// rows < nrows of a [rows][W] global matrix (row stride ldg, W % 4 == 0, W <= 128) -> registers -> LDS tile [16][ld] with
+// zeros in the rows >= nrows and in the padding columns up to pad16(W): one float4 per thread
+template <int W>
+struct TileW {
+  static constexpr int C4 = pad16(W) / 4;            // float4 per row incl. padding
+  f32x4_t v;
+  __device__ __forceinline__ void fetch(const float* __restrict__ src, int ldg, int nrows, int tid) {
+    const int row = tid / C4, c4 = tid - row * C4;
+    v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (row < nrows && 4 * c4 < W) v = *reinterpret_cast<const f32x4_t*>(src + (size_t)row * ldg + 4 * c4);
+  }
+  __device__ __forceinline__ void stash(lptr dst, int ld, int tid) const {
+    const int row = tid / C4, c4 = tid - row * C4;
+    if (row < 16) *reinterpret_cast<MLHOT_LDS f32x4_t*>(dst + row * ld + 4 * c4) = v;
+  }
+};
+
+// ==================================================================================================
+// phase C backward, one workgroup per task: decoder0, r_to_z backward and _W's bias gradient (see tf::phaseC_bwd_kernel).
+// The data gradient of layer k+1 and the weight gradient of layer k run between the same two barriers.
+// ==================================================================================================
+constexpr int CB_LY = 20;
+constexpr int CB_FLOATS = 16 * (CB_LY + 4 * C_LH + 2 * C_LD + 2 * C_LR) + NWV * 256;
+__host__ inline size_t phaseC_bwd_lds_bytes() { return sizeof(float) * CB_FLOATS; }
+
+__global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lptr L0 = (lptr)lds;
+  const TailDims& d = a.d;
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  lptr s_g = L0;                   // [16][CB_LY]   dmu * act'(mu)
+  lptr s_d2 = s_g + 16 * CB_LY;     // saved activations
+  lptr s_d1 = s_d2 + 16 * C_LH;
+  lptr s_dec = s_d1 + 16 * C_LH;
+  lptr s_rr = s_dec + 16 * C_LD;
+  lptr s_dd2 = s_rr + 16 * C_LR;    // gradients
+  lptr s_dd1 = s_dd2 + 16 * C_LH;
+  lptr s_ddec = s_dd1 + 16 * C_LH;
+  lptr s_drr = s_ddec + 16 * C_LD;
+  lptr s_red = s_drr + 16 * C_LR;   // [8 waves][256] partial tiles
+  const size_t rq = (size_t)t * d.Nq;
+  // ---- every global read of the block, up front
+  float gv = 0.f;
+  if (tid < 256) {
+    const int r = tid >> 4, c = tid & 15;
+    if (r < d.Nq && c < d.y_dim) gv = a.dmu[(rq + r) * d.y_dim + c] * act_grad_from_out(d.out_act, a.mu[(rq + r) * d.y_dim + c]);
+  }
+  TileW<DH> td2, td1; TileW<LDD> tdec; TileW<DW> trr;
+  td2.fetch(a.d2 + rq * DH, DH, d.Nq, tid);
+  td1.fetch(a.d1 + rq * DH, DH, d.Nq, tid);
+  tdec.fetch(a.dec_in + rq * LDD, LDD, d.Nq, tid);
+  trr.fetch(a.rr + rq * DW, DW, d.Nq, tid);
+  Dg<4, DH> g2;  Dg<DH, DH> g1;  Dg<DH, LDD> g0;  Dg<DZ, DW> gz;
+  g2.load(a.p.dec_w[2], wave, lane, d.y_dim);
+  g1.load(a.p.dec_w[1], wave, lane);
+  g0.load(a.p.dec_w[0], wave, lane);
+  gz.load(a.p.r2z_w, wave, lane);
+  if (tid < 256) s_g[(tid >> 4) * CB_LY + (tid & 15)] = gv;
+  td2.stash(s_d2, C_LH, tid); td1.stash(s_d1, C_LH, tid); tdec.stash(s_dec, C_LD, tid); trr.stash(s_rr, C_LR, tid);
+  __syncthreads();
+  float* sl = a.slab + (size_t)t * a.sl.total;
+  // decoder0.4: d d2
+  g2.finish(g2.mma(s_g, CB_LY, wave, lane), s_red, s_d2, C_LH, s_dd2, C_LH, nullptr, 0, 0, wave, lane);
+  __syncthreads();
+  // decoder0.2: d d1  |  decoder0.4 weight gradient
+  g1.finish(g1.mma(s_dd2, C_LH, wave, lane), s_red, s_d1, C_LH, s_dd1, C_LH, nullptr, 0, 0, wave, lane);
+  wgrad16<4, DH>(s_g, CB_LY, s_d2, C_LH, sl + a.sl.dec_w[2], sl + a.sl.dec_b[2], wave, lane, tid, d.y_dim, DH);
+  __syncthreads();
+  // decoder0.0: input gradient = [d x_qry | dz]  |  decoder0.2 weight gradient
+  g0.finish(g0.mma(s_dd1, C_LH, wave, lane), s_red, nullptr, 0, s_ddec, C_LD, a.d_dec_in + rq * LDD, LDD, d.Nq, wave, lane);
+  wgrad16<DH, DH>(s_dd2, C_LH, s_d1, C_LH, sl + a.sl.dec_w[1], sl + a.sl.dec_b[1], wave, lane, tid);
+  __syncthreads();
+  // r_to_z (dz = s_ddec[:, dw:]): d rr  |  decoder0.0 weight gradient
+  gz.finish(gz.mma(s_ddec + DW, C_LD, wave, lane), s_red, nullptr, 0, s_drr, C_LR, a.d_rr + rq * DW, DW, d.Nq, wave, lane);
+  wgrad16<DH, LDD>(s_dd1, C_LH, s_dec, C_LD, sl + a.sl.dec_w[0], sl + a.sl.dec_b[0], wave, lane, tid);
+  __syncthreads();
+  wgrad16<DZ, DW>(s_ddec + DW, C_LD, s_rr, C_LR, sl + a.sl.r2z_w, sl + a.sl.r2z_b, wave, lane, tid);
+  // _W: only its bias gradient here (column sums of d rr); weight and input gradient run per head in phase B
+  if (tid >= 256 && tid < 256 + DW) {
+    float sum = 0.f;
+#pragma unroll
+    for (int row = 0; row < 16; ++row) sum += s_drr[row * C_LR + tid - 256];
+    sl[a.sl.wo_b + tid - 256] = sum;
+  }
+}
+
+// ==================================================================================================
+// phase A backward, one workgroup per task (see tf::phaseA_bwd_kernel): sums the 8 heads' input-gradient shares from
+// phase B, applies the batch-global key arg-max correction, EncoderFC backward, transform_y weight gradient.
+// ==================================================================================================
+constexpr int AB_FLOATS = 16 * (2 * A_LCAT + 4 * A_LH + 2 * A_LX + A_LY) + NWV * 256 + 64 + 16;
+__host__ inline size_t phaseA_bwd_lds_bytes() { return sizeof(float) * AB_FLOATS; }
+
+__global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lptr L0 = (lptr)lds;
+  const TailDims& d = a.d;
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  lptr s_cat = L0;                  // saved activations
+  lptr s_h0 = s_cat + 16 * A_LCAT;
+  lptr s_h1 = s_h0 + 16 * A_LH;
+  lptr s_y = s_h1 + 16 * A_LH;
+  lptr s_drs = s_y + 16 * A_LY;     // gradients
+  lptr s_dxc = s_drs + 16 * A_LX;
+  lptr s_dh1 = s_dxc + 16 * A_LX;
+  lptr s_dh0 = s_dh1 + 16 * A_LH;
+  lptr s_dcat = s_dh0 + 16 * A_LH;
+  lptr s_red = s_dcat + 16 * A_LCAT; // [8 waves][256] partial tiles
+  lptr s_fix = s_red + NWV * 256;    // [64] correction vector, [16] wave partials of the key row-sum total
+  const size_t rc = (size_t)t * d.Nc, rq = (size_t)t * d.Nq;
+  // ---- every global read of the block, up front
+  TileW<LDC> tcat; TileW<H0> th0, th1;
+  tcat.fetch(a.cat_in + rc * LDC, LDC, d.Nc, tid);
+  th0.fetch(a.h0 + rc * H0, H0, d.Nc, tid);
+  th1.fetch(a.h1 + rc * H1, H1, d.Nc, tid);
+  float yv = 0.f;
+  if (tid < 256) {
+    const int r = tid >> 4, c = tid & 15;
+    if (r < d.Nc && c < d.label_dim) yv = a.ctx_y[(rc + r) * d.label_dim + c];
+  }
+  // the heads' shares (fixed order): d rs, the K-projection share of d x_ctx, the attention share of d x_qry;
+  // thread = (row tid / 32, columns 2 (tid % 32) .. + 1)
+  const int srow = tid >> 5, scol = 2 * (tid & 31);
+  float2 v1[H], v2[H], v3[H], dq0 = make_float2(0.f, 0.f);
+  if (srow < d.Nc) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      v1[h] = *reinterpret_cast<const float2*>(a.prs + ((size_t)(t * H + h) * d.Nc + srow) * DW + scol);
+      v2[h] = *reinterpret_cast<const float2*>(a.pxc + ((size_t)(t * H + h) * d.Nc + srow) * DW + scol);
+    }
+  }
+  if (srow < d.Nq) {
+    dq0 = *reinterpret_cast<const float2*>(a.d_dec_in + (rq + srow) * LDD + scol);
+#pragma unroll
+    for (int h = 0; h < H; ++h) v3[h] = *reinterpret_cast<const float2*>(a.pxq + ((size_t)(t * H + h) * d.Nq + srow) * DW + scol);
+  }
+  float pv = 0.f;
+  for (int i = tid; i < d.T * H; i += NWV * 64) pv += a.part_k[i];
+  const int grow = a.gpos[0], gcol = a.gpos[1];
+  Dg<DW, H1> g2;  Dg<H1, H0> g1;  Dg<H0, LDC> g0;
+  g2.load(a.p.er_w[2], wave, lane);
+  g1.load(a.p.er_w[1], wave, lane);
+  g0.load(a.p.er_w[0], wave, lane);
+  // ---- stash
+  tcat.stash(s_cat, A_LCAT, tid); th0.stash(s_h0, A_LH, tid); th1.stash(s_h1, A_LH, tid);
+  if (tid < 256) s_y[(tid >> 4) * A_LY + (tid & 15)] = yv;
+  {
+    float2 s1 = make_float2(0.f, 0.f), s2 = make_float2(0.f, 0.f);
+    if (srow < d.Nc) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) { s1.x += v1[h].x; s1.y += v1[h].y; s2.x += v2[h].x; s2.y += v2[h].y; }
+    }
+    s_drs[srow * A_LX + scol] = s1.x; s_drs[srow * A_LX + scol + 1] = s1.y;
+    s_dxc[srow * A_LX + scol] = s2.x; s_dxc[srow * A_LX + scol + 1] = s2.y;
+    if (srow < d.Nq) {
+      float2 s3 = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int h = 0; h < H; ++h) { s3.x += v3[h].x; s3.y += v3[h].y; }
+      *reinterpret_cast<float2*>(a.d_dec_in + (rq + srow) * LDD + scol) = make_float2(dq0.x + s3.x, dq0.y + s3.y);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) pv += __shfl_xor(pv, off, 64);
+  if (lane == 0) s_fix[64 + wave] = pv;
+  __syncthreads();
+  float* sl = a.slab + (size_t)t * a.sl.total;
+  // The batch-global key arg-max (see tf::phaseA_bwd_kernel): a rank-1 fix-up in the ONE task that holds it
+  const bool fix = grow / (d.Nc * H) == t;
+  if (fix) {                                         // block-uniform
+    const int fn = (grow / H) % d.Nc, fh = grow % H;
+    if (tid < DW) {
+      float total = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) total += s_fix[64 + w];
+      s_fix[tid] = -total * a.pc[(size_t)gcol * DW + tid];
+    }
+    __syncthreads();
+    const float* wk = a.p.wk_w[0];
+#pragma unroll
+    for (int i = 1; i < H; ++i)
+      if (fh == i) wk = a.p.wk_w[i];
+    float* gw = sl + a.sl.wk_w + fh * DW * DW;
+    for (int i = tid; i < DW * DW; i += NWV * 64) {
+      const int e = i / DW, c = i - e * DW;
+      gw[i] += s_fix[e] * s_cat[fn * A_LCAT + c];
+    }
+    if (tid < DW) {
+      sl[a.sl.wk_b + fh * DW + tid] += s_fix[tid];
+      float acc = 0.f;
+      for (int e = 0; e < DW; ++e) acc += s_fix[e] * wk[(size_t)e * DW + tid];
+      s_dxc[fn * A_LX + tid] += acc;
+    }
+    __syncthreads();
+  }
+  // EncoderFC, last layer first: d h1
+  g2.finish(g2.mma(s_drs, A_LX, wave, lane), s_red, s_h1, A_LH, s_dh1, A_LH, nullptr, 0, 0, wave, lane);
+  __syncthreads();
+  g1.finish(g1.mma(s_dh1, A_LH, wave, lane), s_red, s_h0, A_LH, s_dh0, A_LH, nullptr, 0, 0, wave, lane);
+  wgrad16<DW, H1>(s_drs, A_LX, s_h1, A_LH, sl + a.sl.er_w[2], sl + a.sl.er_b[2], wave, lane, tid);
+  __syncthreads();
+  g0.finish(g0.mma(s_dh0, A_LH, wave, lane), s_red, nullptr, 0, s_dcat, A_LCAT, nullptr, 0, 0, wave, lane);
+  wgrad16<H1, H0>(s_dh1, A_LH, s_h0, A_LH, sl + a.sl.er_w[1], sl + a.sl.er_b[1], wave, lane, tid);
+  __syncthreads();
+  // d_cat_in = EncoderFC input gradient (+ K-projection share on the x_ctx columns)
+  for (int i = tid; i < d.Nc * LDC; i += NWV * 64) {
+    const int r = i / LDC, c = i - r * LDC;
+    a.d_cat_in[(rc + r) * LDC + c] = s_dcat[r * A_LCAT + c] + (c < DW ? s_dxc[r * A_LX + c] : 0.f);
+  }
+  wgrad16<H0, LDC>(s_dh0, A_LH, s_cat, A_LCAT, sl + a.sl.er_w[0], sl + a.sl.er_b[0], wave, lane, tid);
+  // transform_y: dW = d_cat[:, dw:]^T ctx_y, db
+  wgrad16<DW / 4, 4>(s_dcat + DW, A_LCAT, s_y, A_LY, sl + a.sl.ty_w, sl + a.sl.ty_b, wave, lane, tid, DW / 4, d.label_dim);
+}
+
+}  // namespace ts
+}  // namespace mlhot
+#endif  // !MLHOT_HOSTSIM

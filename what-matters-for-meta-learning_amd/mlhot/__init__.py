@@ -2,7 +2,8 @@
 
 `lib()` returns the ctypes binding of csrc/libmlhot.so.  There is no fallback: if the
 HIP library is missing, or a tensor is not on a HIP device, the call raises.
-MLHOT_LIB=<path> selects another build of the same library (e.g. the -DMLHOT_TS instrumented one).
+MLHOT_LIB=<path> selects another build of the same library (e.g. the -DMLHOT_TS instrumented one);
+MLHOT_OPTS="name=value,..." applies mlhot_set_option() calls right after loading (kernel A/B runs of bench.py).
 """
 import os
 import threading
@@ -19,5 +20,9 @@ def lib():
     if _lib is None:
         with _lock:
             if _lib is None:
-                _lib = MlhotLib(os.environ.get("MLHOT_LIB") or PRODUCT_SO)
+                loaded = MlhotLib(os.environ.get("MLHOT_LIB") or PRODUCT_SO)
+                for item in filter(None, os.environ.get("MLHOT_OPTS", "").split(",")):
+                    name, _, value = item.partition("=")
+                    loaded.set_option(name.strip(), int(value))
+                _lib = loaded
     return _lib
