@@ -295,6 +295,61 @@ def test_mid_size_case_takes_the_reference_gradient_branch(gpulib):
     assert _run_case(gpulib, "s_anp_shapenet1d_t2_full") == 0
 
 
+@pytest.mark.parametrize("T,Nc,Nq", [(3, 7, 9), (2, 15, 15), (1, 16, 16)])
+def test_tail_with_sharp_attention_vs_oracle(gpulib, tail_impl, T, Nc, Nq):
+    """At the seeded initial weights the encoder features of all images are almost identical (spread 0.008 around a common
+    mean), FAVOR+'s attention is uniform and the query / key gradients are rounding residue (1e-8 of the model's largest
+    gradient): the fixtures cannot see an error in the dq / dk path of the tail kernels.  Here the encoder's last layer is
+    re-centred and scaled (features = 0.5 / spread * (features - mean)) so that the attention weights differ from key to key
+    and those gradients are first-class (>= 1e-5 of the largest): mu, loss and every gradient at 1e-4 against the fp64 oracle
+    under the kernels' routing, the W_q / W_k ones at 2e-4 of their OWN scale, no floor.  (Found by the trajectory test: a
+    wrong per-row normaliser in the specialised backward, invisible at 1e-4 with the usual floor.)"""
+    import types
+    from mlhot import ops
+    from mlhot.synth import get_batch
+    from networks.ANPShapeNet1D import ANPShapeNet1D
+    from trainer.losses import LossFunc
+    cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[128, 128, 1], tasks_per_batch=T, input_dim=3,
+                                output_dim=2, agg_mode="attention", img_agg="", dim_w=64, n_hidden_units_r=[100, 100], dim_r=64,
+                                dim_z=64, task="shapenet_1d")
+    model = ANPShapeNet1D(cfg).to(DEV)
+    cx, qx, cy, qy = get_batch("shapenet_1d", T, Nc, Nq, seed=77)
+    with torch.no_grad():
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        f = O.vanilla_encoder(torch.cat([cx.reshape(-1, 1, 128, 128), qx.reshape(-1, 1, 128, 128)]), sd)
+        scale = 0.5 / f.std(dim=0).mean().item()
+        model.encoder_w0[8].weight.mul_(scale)
+        model.encoder_w0[8].bias.copy_(((sd["encoder_w0.8.bias"] - f.mean(dim=0)) * scale).to(DEV))
+    ops.saved_taps = []
+    try:
+        mu = model(cx.to(DEV), cy.to(DEV), qx.to(DEV))[0]
+    finally:
+        taps, ops.saved_taps = ops.saved_taps, None
+    LossFunc("mse", "shapenet_1d").calc_loss(mu, None, qy.to(DEV)).backward()
+    routes = _vanilla_routes(gpulib, taps, T, Nc, Nq, "attention")
+    r64 = {k: (tuple(t.double() if t.is_floating_point() else t for t in v) if isinstance(v, tuple) else [t.double() for t in v])
+           for k, v in routes.items()}
+    p = {k: v.detach().cpu().double().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+    mu_o = O.vanilla_np_forward(p, cx.double(), cy.double(), qx.double(), "attention", tanh=True, routes=r64)
+    O.calc_loss("shapenet_1d", mu_o, qy.double()).backward()
+    assert U.rel_err(mu, mu_o) <= U.RTOL
+    gmax = max(p[k].grad.abs().max().item() for k, _ in model.named_parameters())
+    qk = [p[k].grad.abs().max().item() / gmax for k, _ in model.named_parameters() if k.startswith("_W_q") or k.startswith("_W_k")]
+    assert min(qk) > 1e-6, f"attention not sharp enough for this test: query / key gradients at {min(qk):.1e} of the largest"
+    worst, worst_qk = (0.0, None), (0.0, None)
+    for k, prm in model.named_parameters():
+        if k.startswith("_W_q") or k.startswith("_W_k"):
+            e = U.rel_err(prm.grad, p[k].grad)
+            worst_qk = max(worst_qk, (e, k))
+            assert e <= 2e-4, f"{k}: {e:.2e} of its own scale"
+        else:
+            e = U.rel_err(prm.grad, p[k].grad, floor=U.GRAD_FLOOR * gmax)
+            worst = max(worst, (e, k))
+            assert e <= U.RTOL, f"{k}: {e:.2e}"
+    print(f"sharp attention T={T} {Nc}+{Nq}: query / key gradients at {min(qk):.1e} .. {max(qk):.1e} of the largest, worst error "
+          f"{worst_qk[0]:.2e} of their own scale ({worst_qk[1]}); others {worst[0]:.2e} ({worst[1]})")
+
+
 @pytest.mark.parametrize("name", U.model_case_names("c"))
 def test_model_baseline_configs_vs_reference(gpulib, tail_impl, name):
     """BASELINE.json configs[0..2] at their full sizes (T=4 5+5; T=16 15+15 CNP / ANP): every gradient at 1e-4."""

@@ -293,7 +293,8 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   // sc.dqh / dkh / dvh double as the heads' input-gradient shares [T*H][N][dw] (same sizes)
   tf::PhaseBBwdArgs bb{td, tp, sl, b.qh, b.kh, b.vh, w.pc, w.qf, w.kf, w.S, w.D, b.merged, sc.d_rr, w.arg_q,
                        b.dec_in, b.cat_in, b.rs, b.wot, sc.dqh, sc.dkh, sc.dvh, part_k, sc.tail_slab};
-  MLHOT_TRY(tail_launch(tf::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_bwd_lds_bytes(td), bb, s, "tail.bwd.B"));
+  if (spec & 16) MLHOT_TRY(tail_launch(ts::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, ts::phaseB_bwd_lds_bytes(), bb, s, "tail.bwd.B"));
+  else MLHOT_TRY(tail_launch(tf::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_bwd_lds_bytes(td), bb, s, "tail.bwd.B"));
   tf::PhaseABwdArgs a{td, tp, sl, ctx_y, b.cat_in, b.h[0], b.h[1], sc.dqh, sc.dkh, sc.dvh, w.pc, part_k, w.gpos,
                       sc.d_dec_in, sc.d_cat_in, sc.tail_slab};
   if (spec & 32) MLHOT_TRY(tail_launch(ts::phaseA_bwd_kernel, d.T, 512, ts::phaseA_bwd_lds_bytes(), a, s, "tail.bwd.A"));

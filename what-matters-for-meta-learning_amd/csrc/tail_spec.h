@@ -975,6 +975,298 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   wgrad16<DW / 4, 4>(s_dcat + DW, A_LCAT, s_y, A_LY, sl + a.sl.ty_w, sl + a.sl.ty_b, wave, lane, tid, DW / 4, d.label_dim);
 }
 
+// ==================================================================================================
+// phase B backward, one workgroup per (task, head): FAVOR+ backward (S-form) and this head's W_q / W_k / W_v / _W backward
+// (see tf::phaseB_bwd_kernel: same inputs, same outputs).  Differences: every weight fragment (the head's slice of _W, the
+// projection matrix for the feature-map gradient, the three projection weights) is in registers before the first barrier;
+// dS and dV run side by side; the row sums of G come out of the G tiles' accumulators instead of a pass of their own.
+// ==================================================================================================
+constexpr int BB_FLOATS = 16 * (12 * B_LX + 4 * B_LF) + 2 * 16 * 17 + 64 + NWV * 32 + 2 * NWV * 256;
+__host__ inline size_t phaseB_bwd_lds_bytes() { return sizeof(float) * BB_FLOATS; }
+
+__global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  lptr L0 = (lptr)lds;
+  const TailDims& d = a.d;
+  const int t = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  lptr s_q = L0;                    // [16][B_LX]
+  lptr s_k = s_q + 16 * B_LX;
+  lptr s_v = s_k + 16 * B_LX;
+  lptr s_do = s_v + 16 * B_LX;       // dO
+  lptr s_xq = s_do + 16 * B_LX;      // projection inputs ...
+  lptr s_xc = s_xq + 16 * B_LX;
+  lptr s_rs = s_xc + 16 * B_LX;
+  lptr s_dq = s_rs + 16 * B_LX;      // ... and head-space gradients
+  lptr s_dk = s_dq + 16 * B_LX;
+  lptr s_dv = s_dk + 16 * B_LX;
+  lptr s_o = s_dv + 16 * B_LX;       // this head's attention output O (from merged) and d rr of the task (from phase C)
+  lptr s_drr = s_o + 16 * B_LX;
+  lptr s_qf = s_drr + 16 * B_LX;     // [16][B_LF] E features
+  lptr s_kf = s_qf + 16 * B_LF;
+  lptr s_gq = s_kf + 16 * B_LF;      // G, then d(dd)
+  lptr s_gk = s_gq + 16 * B_LF;
+  lptr s_S = s_gk + 16 * B_LF;       // [16][17]  S / D
+  lptr s_dS = s_S + 16 * 17;         // [16][17]
+  lptr s_st = s_dS + 16 * 17;        // wv[16], D[16], rsum_q[16], rsum_k[16]
+  lptr s_part = s_st + 64;           // [8 waves][32] partial row sums of G
+  lptr s_red = s_part + NWV * 32;    // 2 x [8 waves][256] partial tiles
+  const size_t rq = (size_t)t * d.Nq, rc = (size_t)t * d.Nc;
+  // ---- every global read of the block, up front
+  Tile64 tq, tk, tv, txq, txc, trs, tdrr;
+  tq.fetch(a.qh + rq * HD + h * DW, HD, d.Nq, tid);
+  tk.fetch(a.kh + rc * HD + h * DW, HD, d.Nc, tid);
+  tv.fetch(a.vh + rc * HD + h * DW, HD, d.Nc, tid);
+  txq.fetch(a.dec_in + rq * LDD, LDD, d.Nq, tid);
+  txc.fetch(a.cat_in + rc * LDC, LDC, d.Nc, tid);
+  trs.fetch(a.rs + rc * DW, DW, d.Nc, tid);
+  tdrr.fetch(a.d_rr + rq * DW, DW, d.Nq, tid);
+  float ov[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {                       // O[n][e] = merged[(t,n)][e*H + h]
+    const int idx = tid + 512 * k, n = idx >> 6, e = idx & 63;
+    ov[k] = n < d.Nq ? a.merged[(rq + n) * HD + e * H + h] : 0.f;
+  }
+  constexpr int F2 = M / 2;                           // 133 float2 per feature row
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t fq[5], fk[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int idx = tid + 512 * k, row = idx / F2, c2 = idx - row * F2;
+    fq[k] = f32x2_t{0.f, 0.f}; fk[k] = f32x2_t{0.f, 0.f};
+    if (row < d.Nq) fq[k] = *reinterpret_cast<const f32x2_t*>(a.qf + ((rq + row) * H + h) * M + 2 * c2);
+    if (row < d.Nc) fk[k] = *reinterpret_cast<const f32x2_t*>(a.kf + ((rc + row) * H + h) * M + 2 * c2);
+  }
+  float sdv = 0.f, dval = 1.f; int argq = 0;
+  if (tid < 256) {
+    const int n = tid >> 4, np = tid & 15;
+    if (n < d.Nq) dval = a.D[((size_t)t * H + h) * d.Nq + n];
+    if (n < d.Nq && np < d.Nc) sdv = a.S[(((size_t)t * H + h) * d.Nq + n) * d.Nc + np];
+  }
+  if (tid < d.Nq) argq = a.arg_q[(t * d.Nq + tid) * H + h];
+  const float *wq = a.p.wq_w[0], *wk = a.p.wk_w[0], *wv = a.p.wv_w[0];
+#pragma unroll
+  for (int i = 1; i < H; ++i)
+    if (h == i) { wq = a.p.wq_w[i]; wk = a.p.wk_w[i]; wv = a.p.wv_w[i]; }
+  Dg<DW, DW> g_o;                                     // dO = d rr . Wo_h
+  g_o.load(a.wot + (size_t)h * DW * DW, wave, lane);
+  Dg<M, DW> g_p;                                      // dx = d(dd) . pc   (shared by the query and the key rows)
+  g_p.load(a.pc, wave, lane);
+  // input-gradient shares P = dY W_h: items (projection pj, 16-column tile): wave w takes item w, waves 0-3 also item 8 + w
+  float wsh[2][4][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int item = wave + 8 * u;
+    if (item < 12) {
+      const int pj = item >> 2, i0 = (item & 3) * 16;
+      const float* wsel = (pj == 0 ? wq : pj == 1 ? wk : wv) + i0 + lr;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wsh[u][jb][e] = wsel[(jb * 16 + 4 * lq + e) * DW];
+    }
+  }
+  // ---- stash
+  tq.stash(s_q, B_LX, tid); tk.stash(s_k, B_LX, tid); tv.stash(s_v, B_LX, tid);
+  txq.stash(s_xq, B_LX, tid); txc.stash(s_xc, B_LX, tid); trs.stash(s_rs, B_LX, tid); tdrr.stash(s_drr, B_LX, tid);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) { const int idx = tid + 512 * k; s_o[(idx >> 6) * B_LX + (idx & 63)] = ov[k]; }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int idx = tid + 512 * k, row = idx / F2, c2 = idx - row * F2;
+    if (row < 16) {
+      *reinterpret_cast<MLHOT_LDS f32x2_t*>(s_qf + row * B_LF + 2 * c2) = fq[k];
+      *reinterpret_cast<MLHOT_LDS f32x2_t*>(s_kf + row * B_LF + 2 * c2) = fk[k];
+    }
+  }
+  if (tid < 256) s_S[(tid >> 4) * 17 + (tid & 15)] = sdv / dval;          // S / D (zero outside the valid block)
+  if (tid < 256 && (tid & 15) == 0) s_st[16 + (tid >> 4)] = dval;
+  __syncthreads();
+  // _W's input gradient for this head: dO[n][e] = sum_j d rr[n][j] Wo[j][e*H + h]; rows >= Nq of d rr are zero
+  g_o.finish(g_o.mma(s_drr, B_LX, wave, lane), s_red, nullptr, 0, s_do, B_LX, nullptr, 0, 0, wave, lane);
+  __syncthreads();
+  // wv[n] = dO[n] . O[n]  (16 threads per row)
+  if (tid < 256) {
+    const int n = tid >> 4, part = tid & 15;
+    const f32x4_t x = *reinterpret_cast<lc4ptr>(s_do + n * B_LX + 4 * part), y = *reinterpret_cast<lc4ptr>(s_o + n * B_LX + 4 * part);
+    float sum = x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64);
+    if (part == 0) s_st[n] = sum;
+  }
+  // dV[n'][e] = sum_n (S/D)[n][n'] dO[n][e]  (waves 4-7, one e tile each)
+  if (wave >= 4) {
+    const int et = wave - 4;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int n = 4 * s4 + lq;
+      acc = mfma4(s_S[n * 17 + lr], s_do[n * B_LX + et * 16 + lr], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int np = 4 * lq + r;
+      s_dv[np * B_LX + et * 16 + lr] = np < d.Nc ? acc[r] : 0.f;
+    }
+  }
+  __syncthreads();
+  // dS[n][n'] = (dO[n] . v[n'] - wv[n]) / D[n]   (wave 0), valid entries only
+  if (wave == 0) {
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e0 = 0; e0 < DW; e0 += 8) {
+      a0 = mfma4(s_do[lr * B_LX + e0 + lq], s_v[lr * B_LX + e0 + lq], a0);
+      a1 = mfma4(s_do[lr * B_LX + e0 + 4 + lq], s_v[lr * B_LX + e0 + 4 + lq], a1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 4 * lq + r, np = lr;
+      s_dS[n * 17 + np] = (n < d.Nq && np < d.Nc) ? (a0[r] + a1[r] - s_st[n]) / s_st[16 + n] : 0.f;
+    }
+  }
+  __syncthreads();
+  // G = dF (.) E with dQ' = dS (Ek + re), dK' = dS^T (Eq + re): 2 x 17 feature tiles over the waves; the row sums of G
+  // ride along (this lane: rows 4 lq + r of its tiles' column)
+  const float ratio = 1.0f / sqrtf((float)M), re = ratio * 1e-4f;
+  constexpr int NTILE = (M + 15) / 16;
+  {
+    float rsq[4] = {0.f, 0.f, 0.f, 0.f}, rsk[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tr = 0; tr < 5; ++tr) {
+      const int it = wave + 8 * tr;
+      if (it < 2 * NTILE) {
+        const bool isk = it >= NTILE;
+        const int jt = isk ? it - NTILE : it;
+        const int j = jt * 16 + lr;
+        const bool vj = j < M;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int o = 4 * s4 + lq;                    // summed row index (n' for queries, n for keys)
+          const float av = isk ? s_dS[o * 17 + lr] : s_dS[lr * 17 + o];
+          const float bvv = vj ? (isk ? s_qf[o * B_LF + j] : s_kf[o * B_LF + j]) + re : 0.f;
+          acc = mfma4(av, bvv, acc);
+        }
+        lptr g = isk ? s_gk : s_gq;
+        lcptr f = isk ? s_kf : s_qf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * lq + r;
+          const float gv = vj ? acc[r] * f[row * B_LF + j] : 0.f;
+          g[row * B_LF + j] = gv;                       // padding columns 266..271 become exact zeros
+          if (isk) rsk[r] += gv; else rsq[r] += gv;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) { rsq[r] += __shfl_xor(rsq[r], off, 64); rsk[r] += __shfl_xor(rsk[r], off, 64); }
+      if (lr == 0) { s_part[wave * 32 + 4 * lq + r] = rsq[r]; s_part[wave * 32 + 16 + 4 * lq + r] = rsk[r]; }
+    }
+  }
+  __syncthreads();
+  // row sums (32 rows: 16 query + 16 key), then d(dd): queries subtract the row sum at the arg-max
+  if (tid < 32) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) sum += s_part[w * 32 + tid];
+    s_st[32 + tid] = sum;
+    if (tid < d.Nq) s_gq[tid * B_LF + argq] -= sum;
+    float ks = (tid >= 16 && tid - 16 < d.Nc) ? sum : 0.f;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) ks += __shfl_xor(ks, off, 64);
+    if (tid == 0) a.part_k[t * H + h] = ks;
+  }
+  __syncthreads();
+  // dx[row][e] = sum_j d(dd)[row][j] pc[j][e] - rsum[row] c^2 x[row][e], query and key rows on the same pc fragments;
+  // the two halves of the j range are folded through LDS
+  {
+    f32x4_t aq = g_p.mma(s_gq, B_LF, wave, lane), ak = g_p.mma(s_gk, B_LF, wave, lane);
+    constexpr int NI = Dg<M, DW>::NI;                   // 4 tiles x 2 chunks
+    const int tile = wave % NI, chunk = wave / NI;
+    if (chunk > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s_red[(wave * 4 + r) * 64 + lane] = aq[r]; s_red[NWV * 256 + (wave * 4 + r) * 64 + lane] = ak[r]; }
+    }
+    __syncthreads();
+    if (chunk == 0) {
+      const float c2 = 1.0f / sqrtf((float)DW);
+      const int e = tile * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * lq + r;
+        const float vq = aq[r] + s_red[((wave + NI) * 4 + r) * 64 + lane], vk = ak[r] + s_red[NWV * 256 + ((wave + NI) * 4 + r) * 64 + lane];
+        s_dq[row * B_LX + e] = row < d.Nq ? vq - s_st[32 + row] * c2 * s_q[row * B_LX + e] : 0.f;
+        s_dk[row * B_LX + e] = row < d.Nc ? vk - s_st[48 + row] * c2 * s_k[row * B_LX + e] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- this head's W_q / W_k / W_v backward and _W's weight gradient -----------------------------------
+  {
+    float* sl = a.slab + (size_t)t * a.sl.total;
+    constexpr int nt = DW / 16, ww = DW * DW;
+    // input-gradient shares first (their weights have been in registers since the prologue)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int item = wave + 8 * u;
+      if (item < 12) {
+        const int pj = item >> 2, i0 = (item & 3) * 16;
+        lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
+        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          const f32x4_t x = *reinterpret_cast<lc4ptr>(dy + lr * B_LX + jb * 16 + 4 * lq);
+          if (jb & 1) { a1 = mfma4(x[0], wsh[u][jb][0], a1); a1 = mfma4(x[1], wsh[u][jb][1], a1); a1 = mfma4(x[2], wsh[u][jb][2], a1); a1 = mfma4(x[3], wsh[u][jb][3], a1); }
+          else { a0 = mfma4(x[0], wsh[u][jb][0], a0); a0 = mfma4(x[1], wsh[u][jb][1], a0); a0 = mfma4(x[2], wsh[u][jb][2], a0); a0 = mfma4(x[3], wsh[u][jb][3], a0); }
+        }
+        float* dst = pj == 0 ? a.pxq : pj == 1 ? a.pxc : a.prs;
+        const int nrows = pj == 0 ? d.Nq : d.Nc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * lq + r;
+          if (row < nrows) dst[((size_t)(t * H + h) * nrows + row) * DW + i0 + lr] = a0[r] + a1[r];
+        }
+      }
+    }
+    // weight gradients dW[n][i] = sum_row dY[row][n] X[row][i]: 3 nt^2 tiles of 4 MFMAs over the waves
+#pragma unroll
+    for (int tr = 0; tr < 3 * nt * nt / NWV; ++tr) {
+      const int it = wave + NWV * tr;
+      const int pj = it / (nt * nt), rem = it - pj * nt * nt, j0 = (rem / nt) * 16, i0 = (rem % nt) * 16;
+      lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
+      lcptr x = pj == 0 ? s_xq : pj == 1 ? s_xc : s_rs;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(dy[(4 * s4 + lq) * B_LX + j0 + lr], x[(4 * s4 + lq) * B_LX + i0 + lr], acc);
+      float* dst = sl + (pj == 0 ? a.sl.wq_w : pj == 1 ? a.sl.wk_w : a.sl.wv_w) + h * ww;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(j0 + 4 * lq + r) * DW + i0 + lr] = acc[r];
+    }
+    // _W's weight gradient for this head's columns: dWo[j][e*H + h] = sum_n d rr[n][j] O[n][e]
+#pragma unroll
+    for (int tr = 0; tr < nt * nt / NWV; ++tr) {
+      const int it = wave + NWV * tr;
+      const int j0 = (it / nt) * 16, e0 = (it % nt) * 16;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(s_drr[(4 * s4 + lq) * B_LX + j0 + lr], s_o[(4 * s4 + lq) * B_LX + e0 + lr], acc);
+      float* dst = sl + a.sl.wo_w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(size_t)(j0 + 4 * lq + r) * HD + (e0 + lr) * H + h] = acc[r];
+    }
+    // bias gradients: column sums
+    if (tid < 3 * DW) {
+      const int pj = tid / DW, n = tid - pj * DW;
+      lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
+      float sum = 0.f;
+#pragma unroll
+      for (int row = 0; row < 16; ++row) sum += dy[row * B_LX + n];
+      sl[(pj == 0 ? a.sl.wq_b : pj == 1 ? a.sl.wk_b : a.sl.wv_b) + h * DW + n] = sum;
+    }
+  }
+}
+
 }  // namespace ts
 }  // namespace mlhot
 #endif  // !MLHOT_HOSTSIM
