@@ -39,13 +39,16 @@ for it in range(N + 3):
         acc = v if acc is None else acc + v
     ts[199] = 0
 v = (acc / N).tolist()
-for base, name in ((0, "A.fwd"), (32, "B.fwd"), (64, "C.fwd"), (96, "C.bwd"), (128, "B.bwd"), (160, "A.bwd")):
-    seg = [(i, v[base + i]) for i in range(32) if v[base + i] > 0]
+for base, name in ((0, "A.fwd"), (16, "A.fwd.keyhead"), (32, "B.fwd"), (64, "C.fwd"), (96, "C.bwd"), (128, "B.bwd"), (160, "A.bwd")):
+    seg = [(i, v[base + i]) for i in range(16 if base < 32 else 32) if v[base + i] > 0]
     if len(seg) < 2:
         continue
     print(name, "total %.1f us:" % ((seg[-1][1] - seg[0][1]) / 100.0),
           " ".join("%d:%.1f" % (i, (t - seg[k - 1][1]) / 100.0) for k, (i, t) in enumerate(seg) if k))
 
+blk = [(v[220 + i] - v[200 + i]) / 100.0 for i in range(16) if v[220 + i] > 0]
+if blk:
+    print("A.bwd per block (us):", " ".join("%.1f" % x for x in blk))
 print("layer-function calls of workgroup 0 (cycles between stamps: entry | setup | k-loop | fold | epilogue | exit)")
 for c, row in enumerate(calls):
     if row[0] and row[5]:

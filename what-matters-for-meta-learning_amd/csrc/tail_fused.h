@@ -33,12 +33,14 @@ constexpr int H = 8;
 #ifdef MLHOT_TS
 __device__ long long* g_ts_dev = nullptr;
 #define MLHOT_TSTAMP(i) do { if (g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0) g_ts_dev[i] = wall_clock64(); } while (0)
+#define MLHOT_TSTAMP_AT(i, blk) do { if (g_ts_dev && (int)blockIdx.x == (blk) && threadIdx.x == 0) g_ts_dev[i] = wall_clock64(); } while (0)
 // inside a layer function: cycle stamps of call number g_ts_dev[199] (slots 200 + 8 * call + i)
 #define MLHOT_TSCALL_BEGIN() long long* tsc_ = nullptr; do { if (g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0) { \
     const long long c_ = g_ts_dev[199]; g_ts_dev[199] = c_ + 1; if (c_ < 36) tsc_ = g_ts_dev + 200 + 8 * c_; } } while (0)
 #define MLHOT_TSC(i) do { if (tsc_) tsc_[i] = clock64(); } while (0)
 #else
 #define MLHOT_TSTAMP(i) do {} while (0)
+#define MLHOT_TSTAMP_AT(i, blk) do {} while (0)
 #define MLHOT_TSCALL_BEGIN() do {} while (0)
 #define MLHOT_TSC(i) do {} while (0)
 #endif

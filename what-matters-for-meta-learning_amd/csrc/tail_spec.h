@@ -129,16 +129,14 @@ struct Lin {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
       }
-      if (n < nr) {
-        if (ys != nullptr) {
+      if (ys != nullptr) {                            // the tile's padding columns (n >= nr) become exact zeros: the next layer's k padding
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ys[(4 * lq + r) * ldy + n] = v[r];
-        }
-        if (yg != nullptr) {
+        for (int r = 0; r < 4; ++r) ys[(4 * lq + r) * ldy + n] = n < nr ? v[r] : 0.f;
+      }
+      if (yg != nullptr && n < nr) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (4 * lq + r < nrows) yg[(4 * lq + r) * ldg + n] = v[r];
-        }
+        for (int r = 0; r < 4; ++r)
+          if (4 * lq + r < nrows) yg[(4 * lq + r) * ldg + n] = v[r];
       }
     }
   }
@@ -180,6 +178,7 @@ __device__ __forceinline__ void keyhead_block(const PhaseAArgs& a, lptr L0, int 
   lptr s_x = L0;                       // [16][A_LX] x_ctx
   lptr s_k = s_x + 16 * A_LX;          // [16][A_LX] kh
   lptr s_red = s_k + 16 * A_LX;        // [8] max, [8] packed position
+  MLHOT_TSTAMP_AT(16, d.T);
   // ---- every global read of the block, up front
   Tile64 xt;
   xt.fetch(a.cat_in + (size_t)t * d.Nc * LDC, LDC, d.Nc, tid);
@@ -213,10 +212,9 @@ __device__ __forceinline__ void keyhead_block(const PhaseAArgs& a, lptr L0, int 
       a.wot[(size_t)h * DW * DW + i] = a.p.wo_w[(size_t)j * HD + e * H + h];
     }
   }
-  lds_zero4(L0, 32 * A_LX, tid);
+  xt.stash(s_x, A_LX, tid);                        // all 16 rows (zeros beyond Nc): nothing else of the tiles is ever read
   __syncthreads();
-  xt.stash(s_x, A_LX, tid);
-  __syncthreads();
+  MLHOT_TSTAMP_AT(17, d.T);
   if (wave < 4) {                                   // kh tile of wave: 16 columns
     f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -229,14 +227,13 @@ __device__ __forceinline__ void keyhead_block(const PhaseAArgs& a, lptr L0, int 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * lq + r;
-      if (row < d.Nc) {                 // rows >= Nc stay zero: they must not enter the max below
-        const float v = a0[r] + a1[r] + kbias;
-        s_k[row * A_LX + n] = v;
-        a.kh[(size_t)(t * d.Nc + row) * HD + h * DW + n] = v;
-      }
+      const float v = a0[r] + a1[r] + kbias;
+      s_k[row * A_LX + n] = row < d.Nc ? v : 0.f;       // rows >= Nc are zero: they must not enter the max below
+      if (row < d.Nc) a.kh[(size_t)(t * d.Nc + row) * HD + h * DW + n] = v;
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP_AT(18, d.T);
   const float c = powf((float)DW, -0.25f);
   float best = -INFINITY; int bcode = 0x7fffffff;
 #pragma unroll
@@ -279,6 +276,7 @@ __device__ __forceinline__ void keyhead_block(const PhaseAArgs& a, lptr L0, int 
       if (kmax_better(s_red[w], s_redi[w], best, bcode)) { best = s_red[w]; bcode = s_redi[w]; }
     a.tmax[th] = best; a.targ[th] = bcode;
   }
+  MLHOT_TSTAMP_AT(19, d.T);
 }
 
 __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
@@ -289,6 +287,7 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   if ((int)blockIdx.x >= d.T) { keyhead_block(a, L0, blockIdx.x - d.T, tid); return; }
   const int t = blockIdx.x;
   lptr s_cat = L0;                     // [16][A_LCAT]  [x_ctx | transform_y(ctx_y)]
+  MLHOT_TSTAMP(0);
   lptr s_h0 = s_cat + 16 * A_LCAT;
   lptr s_h1 = s_h0 + 16 * A_LH;
   lptr s_y = s_h1 + 16 * A_LH;         // [16][A_LY] labels
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   Tile64 xt;
   xt.fetch(a.cat_in + (size_t)t * d.Nc * LDC, LDC, d.Nc, tid);
   float yv = 0.f;
-  if (tid < d.Nc * d.label_dim) yv = a.ctx_y[(size_t)t * d.Nc * d.label_dim + tid];
+  if (tid < 256 && (tid >> 4) < d.Nc && (tid & 15) < d.label_dim) yv = a.ctx_y[((size_t)t * d.Nc + (tid >> 4)) * d.label_dim + (tid & 15)];
   Lin<4, DW / 4> l_ty;  Lin<LDC, H0> l_e0;  Lin<H0, H1> l_e1;  Lin<H1, DW> l_e2;
   // transform_y: K = label_dim (1..4, run time) rides in a K = 4 layer through the scalar path
   if (wave == 0) {
@@ -322,11 +321,13 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
       *reinterpret_cast<f32x4_t*>(a.pc + i) = v * c;
     }
   }
-  lds_zero4(L0, 16 * (A_LCAT + 2 * A_LH + A_LY), tid);
-  __syncthreads();
+  MLHOT_TSTAMP(1);
+  // no LDS zeroing: every tile is written in full (x rows via Tile64, labels as a 16 x 16 block, layer outputs incl. their
+  // zero padding columns by Lin::finish) before it is read
   xt.stash(s_cat, A_LCAT, tid);
-  if (tid < d.Nc * d.label_dim) s_y[(tid / d.label_dim) * A_LY + tid % d.label_dim] = yv;
+  if (tid < 256) s_y[(tid >> 4) * A_LY + (tid & 15)] = yv;
   __syncthreads();
+  MLHOT_TSTAMP(2);
   float* g_cat = a.cat_in + (size_t)t * d.Nc * LDC;
   // transform_y -> cat[:, dw:]   (padding columns of s_y are zero, so the clamped weight columns contribute nothing)
   if (wave == 0) {
@@ -343,11 +344,15 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(3);
   l_e0.finish(l_e0.mma(s_cat, A_LCAT, wave, lane), ACT_RELU, s_red, s_h0, A_LH, a.h0 + (size_t)t * d.Nc * H0, H0, d.Nc, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(4);
   l_e1.finish(l_e1.mma(s_h0, A_LH, wave, lane), ACT_RELU, s_red, s_h1, A_LH, a.h1 + (size_t)t * d.Nc * H1, H1, d.Nc, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(5);
   l_e2.finish(l_e2.mma(s_h1, A_LH, wave, lane), ACT_NONE, s_red, nullptr, 0, a.rs + (size_t)t * d.Nc * DW, DW, d.Nc, wave, lane);
+  MLHOT_TSTAMP(6);
 }
 
 // ==================================================================================================
@@ -374,6 +379,7 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
   lptr s_Sp = s_kf + 16 * B_LF;       // [8 waves][16][17] partial S
   lptr s_S = s_Sp + 8 * 16 * 17;      // [16][17] S
   lptr s_st = s_S + 16 * 17;          // diag_q[16], diag_k[16], max_q[16], D[16]; [64]: the batch-global key maximum
+  MLHOT_TSTAMP(32);
   // ---- every global read of the block, up front
   Tile64 xq, xr, xk;
   xq.fetch(a.dec_in + (size_t)t * d.Nq * LDD, LDD, d.Nq, tid);
@@ -411,8 +417,7 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
       for (int kb = 0; kb < 4; ++kb) pf[i][kb] = *reinterpret_cast<const f32x4_t*>(a.pc + (size_t)jc * DW + kb * 16 + 4 * lq);
     }
   }
-  lds_zero4(L0, B_FLOATS, tid);
-  __syncthreads();
+  MLHOT_TSTAMP(33);
   xq.stash(s_xq, B_LX, tid);
   xr.stash(s_rs, B_LX, tid);
   xk.stash(s_k, B_LX, tid);
@@ -431,6 +436,7 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
   }
   __syncthreads();
   gm = s_st[64];
+  MLHOT_TSTAMP(34);
   // this head's query and value projections: qh = W_q,h(x_qry), vh = W_v,h(rs)
   {
     lcptr xs = isv ? s_rs : s_xq;
@@ -447,14 +453,13 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * lq + r;
-      if (row < nrows) {
-        const float v = a0[r] + a1[r] + pbias;
-        ys[row * B_LX + pn] = v;
-        yg[(size_t)(t * nrows + row) * HD + h * DW + pn] = v;
-      }
+      const float v = a0[r] + a1[r] + pbias;
+      ys[row * B_LX + pn] = row < nrows ? v : 0.f;      // rows beyond the shots are zeros (no LDS zeroing in this kernel)
+      if (row < nrows) yg[(size_t)(t * nrows + row) * HD + h * DW + pn] = v;
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(35);
   // dd tiles: q and k against pc (shared B operand, two independent accumulator chains)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -489,7 +494,9 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
     if (part == 0) s_st[row] = s * half_c2;
   }
   __syncthreads();
-  // query row max / first arg-max: 16 rows x 32 threads
+  MLHOT_TSTAMP(36);
+  // query row max / first arg-max: 16 rows x 32 threads (tried: the maximum riding in the dd tiles' epilogue - the 32 cross-lane
+  // steps per wave cost more than this pass and its barrier: 14.8 -> 16.6 us)
   {
     const int row = tid >> 5, part = tid & 31;
     float best = -INFINITY; int arg = 0x7fffffff;
@@ -505,6 +512,7 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(37);
   // E features in place (padding columns j >= m stay exactly 0), valid rows saved for the backward right away
   const float ratio = 1.0f / sqrtf((float)M), re = ratio * 1e-4f;
   for (int row = wave; row < 16; row += NWV) {
@@ -520,6 +528,7 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(38);
   // S = (Eq + re)(Ek + re)^T : M = 16 q rows, N = 16 k rows, K = m split over the 8 waves
   {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -534,6 +543,7 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
     for (int r = 0; r < 4; ++r) s_Sp[(wave * 16 + 4 * lq + r) * 17 + lr] = acc[r];
   }
   __syncthreads();
+  MLHOT_TSTAMP(39);
   if (tid < 256) {                                  // fold the partials; D = row sums (16 consecutive lanes hold a row)
     const int n = tid >> 4, np = tid & 15;
     float s = 0.f;
@@ -550,6 +560,7 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(40);
   // out[n][e] = sum_n' S[n][n'] v[n'][e] / D[n]: one e tile per wave 0-3, K = 16 k rows
   if (wave < 4) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -567,6 +578,7 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(41);
   // share of rr = _W(merged): rrp[n][j] = sum_e out[n][e] Wo[j][e*H + h], Wo_h from the head-major copy
   if (wave < 4) {
     f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -582,6 +594,7 @@ __global__ __launch_bounds__(512) void phaseB_fwd_kernel(const PhaseBArgs a) {
       if (n < d.Nq) a.rrp[((size_t)(t * H + h) * d.Nq + n) * DW + 16 * wave + lr] = a0[r] + a1[r];
     }
   }
+  MLHOT_TSTAMP(42);
 }
 
 // ==================================================================================================
@@ -602,6 +615,7 @@ __global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
   lptr s_d1 = s_dec + 16 * C_LD;
   lptr s_d2 = s_d1 + 16 * C_LH;
   lptr s_red = s_d2 + 16 * C_LH;   // [8 waves][256] K-split partials
+  MLHOT_TSTAMP(64);
   // ---- every global read of the block, up front
   Tile64 xq;
   xq.fetch(a.dec_in + (size_t)t * d.Nq * LDD, LDD, d.Nq, tid);
@@ -618,25 +632,32 @@ __global__ __launch_bounds__(512) void phaseC_fwd_kernel(const PhaseCArgs a) {
   l_d0.load(a.p.dec_w[0], a.p.dec_b[0], wave, lane);
   l_d1.load(a.p.dec_w[1], a.p.dec_b[1], wave, lane);
   l_d2.load(a.p.dec_w[2], a.p.dec_b[2], wave, lane, DH, d.y_dim);
-  lds_zero4(L0, 16 * (C_LR + C_LD + 2 * C_LH), tid);
-  __syncthreads();
+  MLHOT_TSTAMP(65);
   xq.stash(s_dec, C_LD, tid);
-  if (rrow < d.Nq) {
-    float2 sum = rb;
+  {
+    float2 sum = make_float2(0.f, 0.f);                // rows >= Nq: zeros (every tile is written in full, no LDS zeroing)
+    if (rrow < d.Nq) {
+      sum = rb;
 #pragma unroll
-    for (int h = 0; h < H; ++h) { sum.x += rv[h].x; sum.y += rv[h].y; }
+      for (int h = 0; h < H; ++h) { sum.x += rv[h].x; sum.y += rv[h].y; }
+      *reinterpret_cast<float2*>(a.rr + ((size_t)t * d.Nq + rrow) * DW + rcol) = sum;
+    }
     s_rr[rrow * C_LR + rcol] = sum.x; s_rr[rrow * C_LR + rcol + 1] = sum.y;
-    *reinterpret_cast<float2*>(a.rr + ((size_t)t * d.Nq + rrow) * DW + rcol) = sum;
   }
   __syncthreads();
+  MLHOT_TSTAMP(66);
   float* g_dec = a.dec_in + (size_t)t * d.Nq * LDD;
   l_z.finish(l_z.mma(s_rr, C_LR, wave, lane), ACT_NONE, s_red, s_dec + DW, C_LD, g_dec + DW, LDD, d.Nq, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(67);
   l_d0.finish(l_d0.mma(s_dec, C_LD, wave, lane), ACT_RELU, s_red, s_d1, C_LH, a.d1 + (size_t)t * d.Nq * DH, DH, d.Nq, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(68);
   l_d1.finish(l_d1.mma(s_d1, C_LH, wave, lane), ACT_RELU, s_red, s_d2, C_LH, a.d2 + (size_t)t * d.Nq * DH, DH, d.Nq, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(69);
   l_d2.finish(l_d2.mma(s_d2, C_LH, wave, lane), d.out_act, s_red, nullptr, 0, a.mu + (size_t)t * d.Nq * d.y_dim, d.y_dim, d.Nq, wave, lane, d.y_dim);
+  MLHOT_TSTAMP(70);
 }
 
 // ==================================================================================================
@@ -805,6 +826,7 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   const size_t rq = (size_t)t * d.Nq;
   // ---- every global read of the block, up front
   float gv = 0.f;
+  MLHOT_TSTAMP(96);
   if (tid < 256) {
     const int r = tid >> 4, c = tid & 15;
     if (r < d.Nq && c < d.y_dim) gv = a.dmu[(rq + r) * d.y_dim + c] * act_grad_from_out(d.out_act, a.mu[(rq + r) * d.y_dim + c]);
@@ -822,22 +844,27 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   if (tid < 256) s_g[(tid >> 4) * CB_LY + (tid & 15)] = gv;
   td2.stash(s_d2, C_LH, tid); td1.stash(s_d1, C_LH, tid); tdec.stash(s_dec, C_LD, tid); trr.stash(s_rr, C_LR, tid);
   __syncthreads();
+  MLHOT_TSTAMP(97);
   float* sl = a.slab + (size_t)t * a.sl.total;
   // decoder0.4: d d2
   g2.finish(g2.mma(s_g, CB_LY, wave, lane), s_red, s_d2, C_LH, s_dd2, C_LH, nullptr, 0, 0, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(98);
   // decoder0.2: d d1  |  decoder0.4 weight gradient
   g1.finish(g1.mma(s_dd2, C_LH, wave, lane), s_red, s_d1, C_LH, s_dd1, C_LH, nullptr, 0, 0, wave, lane);
   wgrad16<4, DH>(s_g, CB_LY, s_d2, C_LH, sl + a.sl.dec_w[2], sl + a.sl.dec_b[2], wave, lane, tid, d.y_dim, DH);
   __syncthreads();
+  MLHOT_TSTAMP(99);
   // decoder0.0: input gradient = [d x_qry | dz]  |  decoder0.2 weight gradient
   g0.finish(g0.mma(s_dd1, C_LH, wave, lane), s_red, nullptr, 0, s_ddec, C_LD, a.d_dec_in + rq * LDD, LDD, d.Nq, wave, lane);
   wgrad16<DH, DH>(s_dd2, C_LH, s_d1, C_LH, sl + a.sl.dec_w[1], sl + a.sl.dec_b[1], wave, lane, tid);
   __syncthreads();
+  MLHOT_TSTAMP(100);
   // r_to_z (dz = s_ddec[:, dw:]): d rr  |  decoder0.0 weight gradient
   gz.finish(gz.mma(s_ddec + DW, C_LD, wave, lane), s_red, nullptr, 0, s_drr, C_LR, a.d_rr + rq * DW, DW, d.Nq, wave, lane);
   wgrad16<DH, LDD>(s_dd1, C_LH, s_dec, C_LD, sl + a.sl.dec_w[0], sl + a.sl.dec_b[0], wave, lane, tid);
   __syncthreads();
+  MLHOT_TSTAMP(101);
   wgrad16<DZ, DW>(s_ddec + DW, C_LD, s_rr, C_LR, sl + a.sl.r2z_w, sl + a.sl.r2z_b, wave, lane, tid);
   // _W: only its bias gradient here (column sums of d rr); weight and input gradient run per head in phase B
   if (tid >= 256 && tid < 256 + DW) {
@@ -846,6 +873,7 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
     for (int row = 0; row < 16; ++row) sum += s_drr[row * C_LR + tid - 256];
     sl[a.sl.wo_b + tid - 256] = sum;
   }
+  MLHOT_TSTAMP(102);
 }
 
 // ==================================================================================================
@@ -872,8 +900,13 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   lptr s_red = s_dcat + 16 * A_LCAT; // [8 waves][256] partial tiles
   lptr s_fix = s_red + NWV * 256;    // [64] correction vector, [16] wave partials of the key row-sum total
   const size_t rc = (size_t)t * d.Nc, rq = (size_t)t * d.Nq;
-  // ---- every global read of the block, up front
+  // ---- every global read of the block, up front (the arg-max position first: the fix-up's loads depend on it)
+  const int grow = a.gpos[0], gcol = a.gpos[1];
   TileW<LDC> tcat; TileW<H0> th0, th1;
+  MLHOT_TSTAMP(160);
+#ifdef MLHOT_TS
+  if (g_ts_dev && threadIdx.x == 0 && blockIdx.x < 16) g_ts_dev[200 + blockIdx.x] = wall_clock64();
+#endif
   tcat.fetch(a.cat_in + rc * LDC, LDC, d.Nc, tid);
   th0.fetch(a.h0 + rc * H0, H0, d.Nc, tid);
   th1.fetch(a.h1 + rc * H1, H1, d.Nc, tid);
@@ -900,11 +933,29 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   }
   float pv = 0.f;
   for (int i = tid; i < d.T * H; i += NWV * 64) pv += a.part_k[i];
-  const int grow = a.gpos[0], gcol = a.gpos[1];
   Dg<DW, H1> g2;  Dg<H1, H0> g1;  Dg<H0, LDC> g0;
   g2.load(a.p.er_w[2], wave, lane);
   g1.load(a.p.er_w[1], wave, lane);
   g0.load(a.p.er_w[0], wave, lane);
+  // The batch-global key arg-max (see tf::phaseA_bwd_kernel): a rank-1 fix-up in the ONE task that holds it.  Its operands
+  // (the [dw][dw] slab block it updates, W_k of that head, the projection row) are requested here with everything else.
+  float* sl = a.slab + (size_t)t * a.sl.total;
+  const bool fix = grow / (d.Nc * H) == t;           // block-uniform
+  const int fn = (grow / H) % d.Nc, fh = grow % H;
+  float gwv[8], wkv[8], pcv = 0.f, bkv = 0.f;
+  if (fix) {
+    const float* wk = a.p.wk_w[0];
+#pragma unroll
+    for (int i = 1; i < H; ++i)
+      if (fh == i) wk = a.p.wk_w[i];
+    const float* gw = sl + a.sl.wk_w + fh * DW * DW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      gwv[k] = gw[tid + NWV * 64 * k];
+      wkv[k] = wk[(8 * (tid >> 6) + k) * DW + (tid & 63)];      // thread (part = tid / 64, column tid % 64): rows 8 part .. + 7
+    }
+    if (tid < DW) { pcv = a.pc[(size_t)gcol * DW + tid]; bkv = sl[a.sl.wk_b + fh * DW + tid]; }
+  }
   // ---- stash
   tcat.stash(s_cat, A_LCAT, tid); th0.stash(s_h0, A_LH, tid); th1.stash(s_h1, A_LH, tid);
   if (tid < 256) s_y[(tid >> 4) * A_LY + (tid & 15)] = yv;
@@ -927,44 +978,49 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   for (int off = 32; off > 0; off >>= 1) pv += __shfl_xor(pv, off, 64);
   if (lane == 0) s_fix[64 + wave] = pv;
   __syncthreads();
-  float* sl = a.slab + (size_t)t * a.sl.total;
-  // The batch-global key arg-max (see tf::phaseA_bwd_kernel): a rank-1 fix-up in the ONE task that holds it
-  const bool fix = grow / (d.Nc * H) == t;
-  if (fix) {                                         // block-uniform
-    const int fn = (grow / H) % d.Nc, fh = grow % H;
+  MLHOT_TSTAMP(161);
+  // the fix-up: delta = -total * pc[col]; dW_k,fh += delta (x) x_ctx[fn], db_k,fh += delta, d x_ctx[fn] += delta . W_k,fh
+  if (fix) {
     if (tid < DW) {
       float total = 0.f;
 #pragma unroll
       for (int w = 0; w < NWV; ++w) total += s_fix[64 + w];
-      s_fix[tid] = -total * a.pc[(size_t)gcol * DW + tid];
+      const float dl = -total * pcv;
+      s_fix[tid] = dl;
+      sl[a.sl.wk_b + fh * DW + tid] = bkv + dl;
     }
     __syncthreads();
-    const float* wk = a.p.wk_w[0];
-#pragma unroll
-    for (int i = 1; i < H; ++i)
-      if (fh == i) wk = a.p.wk_w[i];
     float* gw = sl + a.sl.wk_w + fh * DW * DW;
-    for (int i = tid; i < DW * DW; i += NWV * 64) {
-      const int e = i / DW, c = i - e * DW;
-      gw[i] += s_fix[e] * s_cat[fn * A_LCAT + c];
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + NWV * 64 * k, e = i >> 6, c = i & 63;
+      gw[i] = gwv[k] + s_fix[e] * s_cat[fn * A_LCAT + c];
+      part += s_fix[8 * (tid >> 6) + k] * wkv[k];
     }
+    s_red[tid] = part;
+    __syncthreads();
     if (tid < DW) {
-      sl[a.sl.wk_b + fh * DW + tid] += s_fix[tid];
       float acc = 0.f;
-      for (int e = 0; e < DW; ++e) acc += s_fix[e] * wk[(size_t)e * DW + tid];
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) acc += s_red[w * 64 + tid];
       s_dxc[fn * A_LX + tid] += acc;
     }
     __syncthreads();
   }
+  MLHOT_TSTAMP(162);
   // EncoderFC, last layer first: d h1
   g2.finish(g2.mma(s_drs, A_LX, wave, lane), s_red, s_h1, A_LH, s_dh1, A_LH, nullptr, 0, 0, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(163);
   g1.finish(g1.mma(s_dh1, A_LH, wave, lane), s_red, s_h0, A_LH, s_dh0, A_LH, nullptr, 0, 0, wave, lane);
   wgrad16<DW, H1>(s_drs, A_LX, s_h1, A_LH, sl + a.sl.er_w[2], sl + a.sl.er_b[2], wave, lane, tid);
   __syncthreads();
+  MLHOT_TSTAMP(164);
   g0.finish(g0.mma(s_dh0, A_LH, wave, lane), s_red, nullptr, 0, s_dcat, A_LCAT, nullptr, 0, 0, wave, lane);
   wgrad16<H1, H0>(s_dh1, A_LH, s_h0, A_LH, sl + a.sl.er_w[1], sl + a.sl.er_b[1], wave, lane, tid);
   __syncthreads();
+  MLHOT_TSTAMP(165);
   // d_cat_in = EncoderFC input gradient (+ K-projection share on the x_ctx columns)
   for (int i = tid; i < d.Nc * LDC; i += NWV * 64) {
     const int r = i / LDC, c = i - r * LDC;
@@ -973,6 +1029,10 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   wgrad16<H0, LDC>(s_dh0, A_LH, s_cat, A_LCAT, sl + a.sl.er_w[0], sl + a.sl.er_b[0], wave, lane, tid);
   // transform_y: dW = d_cat[:, dw:]^T ctx_y, db
   wgrad16<DW / 4, 4>(s_dcat + DW, A_LCAT, s_y, A_LY, sl + a.sl.ty_w, sl + a.sl.ty_b, wave, lane, tid, DW / 4, d.label_dim);
+  MLHOT_TSTAMP(166);
+#ifdef MLHOT_TS
+  if (g_ts_dev && threadIdx.x == 0 && blockIdx.x < 16) g_ts_dev[220 + blockIdx.x] = wall_clock64();
+#endif
 }
 
 // ==================================================================================================
@@ -1014,6 +1074,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   const size_t rq = (size_t)t * d.Nq, rc = (size_t)t * d.Nc;
   // ---- every global read of the block, up front
   Tile64 tq, tk, tv, txq, txc, trs, tdrr;
+  MLHOT_TSTAMP(128);
   tq.fetch(a.qh + rq * HD + h * DW, HD, d.Nq, tid);
   tk.fetch(a.kh + rc * HD + h * DW, HD, d.Nc, tid);
   tv.fetch(a.vh + rc * HD + h * DW, HD, d.Nc, tid);
@@ -1082,9 +1143,11 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   if (tid < 256) s_S[(tid >> 4) * 17 + (tid & 15)] = sdv / dval;          // S / D (zero outside the valid block)
   if (tid < 256 && (tid & 15) == 0) s_st[16 + (tid >> 4)] = dval;
   __syncthreads();
+  MLHOT_TSTAMP(129);
   // _W's input gradient for this head: dO[n][e] = sum_j d rr[n][j] Wo[j][e*H + h]; rows >= Nq of d rr are zero
   g_o.finish(g_o.mma(s_drr, B_LX, wave, lane), s_red, nullptr, 0, s_do, B_LX, nullptr, 0, 0, wave, lane);
   __syncthreads();
+  MLHOT_TSTAMP(130);
   // wv[n] = dO[n] . O[n]  (16 threads per row)
   if (tid < 256) {
     const int n = tid >> 4, part = tid & 15;
@@ -1109,6 +1172,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(131);
   // dS[n][n'] = (dO[n] . v[n'] - wv[n]) / D[n]   (wave 0), valid entries only
   if (wave == 0) {
     f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -1124,6 +1188,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(132);
   // G = dF (.) E with dQ' = dS (Ek + re), dK' = dS^T (Eq + re): 2 x 17 feature tiles over the waves; the row sums of G
   // ride along (this lane: rows 4 lq + r of its tiles' column)
   const float ratio = 1.0f / sqrtf((float)M), re = ratio * 1e-4f;
@@ -1165,6 +1230,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(133);
   // row sums (32 rows: 16 query + 16 key), then d(dd): queries subtract the row sum at the arg-max
   if (tid < 32) {
     float sum = 0.f;
@@ -1178,6 +1244,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     if (tid == 0) a.part_k[t * H + h] = ks;
   }
   __syncthreads();
+  MLHOT_TSTAMP(134);
   // dx[row][e] = sum_j d(dd)[row][j] pc[j][e] - rsum[row] c^2 x[row][e], query and key rows on the same pc fragments;
   // the two halves of the j range are folded through LDS
   {
@@ -1202,6 +1269,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     }
   }
   __syncthreads();
+  MLHOT_TSTAMP(135);
   // ---- this head's W_q / W_k / W_v backward and _W's weight gradient -----------------------------------
   {
     float* sl = a.slab + (size_t)t * a.sl.total;
@@ -1265,6 +1333,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
       sl[(pj == 0 ? a.sl.wq_b : pj == 1 ? a.sl.wk_b : a.sl.wv_b) + h * DW + n] = sum;
     }
   }
+  MLHOT_TSTAMP(136);
 }
 
 }  // namespace ts
