@@ -136,10 +136,11 @@ def host_cpu():
     return phys or os.cpu_count() or 1, model
 
 
-def cpu_baseline(w, steps=5):
+def cpu_baseline(w, steps=5, warmups=2):
     """The CPU oracle (torch-CPU fp32 restatement of the reference forward, autograd backward; kind "port") on the same synthetic
-    batch, at 1 / 8 / 32 / all physical cores: a bounded sample per thread count (SURVEY §8d asks for median of 10 after 3
-    warm-ups; the default bench run has to finish within minutes).  `value` is the best of them, `cores` its thread count."""
+    batch, at 1 / 8 / 32 / all physical cores: the SAME bounded sample at every thread count - median of `steps` (5) timed steps
+    after `warmups` (2) untimed ones, ~30 s of CPU work in all (SURVEY §8d's median of 10 after 3 would be ~60 s; the default
+    bench run has to finish within minutes).  `value` is the best thread count's figure, `cores` that count."""
     import importlib
     from oracle import ref_cpu as O
     cfg = make_cfg(w, torch.device("cpu"))
@@ -169,8 +170,9 @@ def cpu_baseline(w, steps=5):
     try:
         for nthr in sorted({1, 8, 32, cores} & set(range(1, cores + 1))):
             torch.set_num_threads(nthr)
-            one()
-            times = sorted(one() for _ in range(steps if nthr in (cores, 8) else 2))
+            for _ in range(warmups):
+                one()
+            times = sorted(one() for _ in range(steps))
             by_threads[nthr] = times[len(times) // 2]
     finally:
         torch.set_num_threads(prev)
@@ -178,8 +180,8 @@ def cpu_baseline(w, steps=5):
     return {"value": w["T"] / by_threads[best], "unit": "meta-tasks/s", "cores": best, "kind": "port", "cpu_model": cpu_model,
             "physical_cores": cores, "single_thread_value": w["T"] / by_threads[1],
             "tasks_per_s_by_threads": {str(k): round(w["T"] / v, 2) for k, v in by_threads.items()},
-            "sample": f"fwd+bwd steps of the same {w['T']}-task 15+15 batch, torch threads in {sorted(by_threads)} (1 warm-up each, median of "
-                      f"{steps} steps at 8 and {cores} threads, of 2 at the others); value = the best thread count ({best}): "
+            "sample": f"fwd+bwd steps of the same {w['T']}-task 15+15 batch, torch threads in {sorted(by_threads)}: at EVERY count {warmups} "
+                      f"warm-ups, then the median of {steps} timed steps; value = the best thread count ({best}): "
                       f"{by_threads[best] * 1e3:.0f} ms/step; all {cores} physical cores: {by_threads[cores] * 1e3:.0f} ms/step"}
 
 
@@ -537,15 +539,20 @@ def main():
     model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(make_cfg(w, device)).to(device)
     loss_fn = LossFunc("mse", w["task"])
     cx, qx, cy, qy = make_batch(w, 1234 + rank, device)
-    bucket = mdist.GradBucket(model.parameters())
+    # the trainer's own setting (trainer/model_trainer.py): collectives on a communication stream, and - for the models that
+    # name them - the gradients that are complete early in the backward as a bucket of their own
+    bucket = mdist.GradBucket(model.parameters(), side_stream=True,
+                              early=model.early_grad_parameters() if hasattr(model, "early_grad_parameters") else None)
     beta = w.get("beta", 0.0)
 
-    def fwd_bwd():
+    def fwd_bwd(arm=False):
         model.zero_grad(set_to_none=True)
         mu, var, kl = model(cx, cy, qx)
         loss = loss_fn.calc_loss(mu, var, qy)
         if c5:
             loss = loss + beta * kl          # identical on every rank (same weights, kl does not depend on the batch): averaged, never summed
+        if arm:
+            bucket.arm()                     # eager steps only: the early bucket's all-reduce is issued from inside backward()
         loss.backward()
         return loss.detach()
 
@@ -565,9 +572,9 @@ def main():
         if eps is not None:
             eps.stage()
             with eps.active():
-                loss = fwd_bwd()
+                loss = fwd_bwd(arm=True)
         else:
-            loss = fwd_bwd()
+            loss = fwd_bwd(arm=True)
         bucket.sync(defer_scale=True)        # the 1/world average rides in the optimizer's gradient scale (FlatAdam.step(grad_scale=...))
         return loss
 

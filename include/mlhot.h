@@ -14,6 +14,13 @@
  *     on `stream` in order, so calls are hipGraph-capturable and re-entrant across streams;
  *   - workspaces are caller-provided; the *_bytes() helpers size them.
  *   - `stream` is a hipStream_t passed as void*.
+ *
+ * Threading (the reference's callers are ONE Python thread on the default stream).  The compute entries keep no
+ * state between calls - everything lives in the caller's buffers - so concurrent calls from several host threads on different
+ * streams and buffers are safe, and mlhot_last_error() is per thread.  The two DIAGNOSTIC facilities are process-global and are
+ * not part of that guarantee: mlhot_set_option() flips implementation switches read by every later call of every thread (set
+ * them before the first compute call, or from the one thread that issues the calls - the A/B tests do the latter), and the
+ * mlhot_prof_begin/end() recorder may be driven by one thread at a time while no other thread is inside the library.
  */
 #ifndef MLHOT_H
 #define MLHOT_H
@@ -34,11 +41,12 @@ enum { MLHOT_LOSS_AZIMUTH = 0, MLHOT_LOSS_MSE = 1, MLHOT_LOSS_QUATERNION = 2, ML
 int mlhot_version(void);
 const char* mlhot_last_error(void);
 
-/* Implementation switches for A/B tests: "conv2_tc" = 1 (default) runs the weight-stationary
- * conv2 kernels (csrc/conv_tc.h), 0 the generic implicit-GEMM problems; "tail_fused" = 1
- * (default) runs the fused per-task tail kernels (csrc/tail_fused.h) where they apply;
- * "materialize_a1" = 1 additionally stores the conv1 output (debug / tests; the fused conv1+conv2
- * kernels never need it).                                                                       */
+/* Implementation switches for A/B tests (process-global, see Threading above): "conv2_tc" = 1 (default) runs the
+ * weight-stationary conv2 kernels (csrc/conv_tc.h), 0 the generic implicit-GEMM problems; "tail_fused" = 1 (default) runs the
+ * fused per-task tail kernels where they apply, "tail_spec" = bit mask of the six tail phases that use the kernels specialised
+ * for the shipped dimensions (csrc/tail_spec.h; default 63 = all, 0 = the run-time-shaped csrc/tail_fused.h); "favor2" = 1
+ * (default) the two-launch FAVOR+ kernels, 0 the operator chain; "materialize_a1" = 1 additionally stores the conv1 output
+ * (debug / tests; the fused conv1+conv2 kernels never need it).                                                          */
 int mlhot_set_option(const char* name, int value);
 
 /* ---- bench-only: per-launch HIP-event timing ------------------------------------------------

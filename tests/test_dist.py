@@ -210,3 +210,75 @@ def test_bench_timing_protocol_on_eight_ranks():
             assert p.exitcode == 0
         vals = [out[r] for r in range(8)]
         assert max(vals) - min(vals) < 1e-9 and vals[0] >= 5 * 0.004
+
+
+# ---- the early bucket: its all-reduce leaves from inside backward(), before the late gradients exist -----------------------------
+def _early_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "what-matters-for-meta-learning_amd"), root]
+    from mlhot import dist as mdist
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    mdist.init_from_env("gloo")
+    torch.manual_seed(0)
+    late = torch.nn.Linear(8, 8)            # first layer of the forward = LAST gradient of the backward (the image trunks' role)
+    head = torch.nn.Sequential(torch.nn.Linear(8, 6), torch.nn.Tanh(), torch.nn.Linear(6, 3))
+    params = list(late.parameters()) + list(head.parameters())
+    log = []
+
+    class Logged(mdist.GradBucket):
+        def _issue(self, flat, asynchronous=False):
+            log.append(("issue", flat.numel(), asynchronous))
+            super()._issue(flat, asynchronous)
+
+    late.weight.register_post_accumulate_grad_hook(lambda p: log.append(("late gradient ready",)))
+    x = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + rank))
+    results = {}
+    for mode in ("one bucket", "early bucket"):
+        for p in params:
+            p.grad = None
+        del log[:]
+        bucket = Logged(params, early=list(head.parameters()) if mode == "early bucket" else None)
+        loss = head(torch.relu(late(x))).pow(2).mean()
+        bucket.arm()
+        loss.backward()
+        bucket.sync()
+        results[mode] = ([p.grad.clone() for p in params], list(log), list(bucket.issue_log))
+    n_head, n_late = sum(p.numel() for p in head.parameters()), sum(p.numel() for p in late.parameters())
+    # one bucket: a single collective after the backward
+    assert results["one bucket"][1] == [("late gradient ready",), ("issue", n_head + n_late, False)]
+    assert results["one bucket"][2] == [("all", n_head + n_late)]
+    # early bucket: its collective is issued (asynchronously) BEFORE the late gradient exists, the rest goes after the backward
+    assert results["early bucket"][1] == [("issue", n_head, True), ("late gradient ready",), ("issue", n_late, False)]
+    assert results["early bucket"][2] == [("early", n_head), ("rest", n_late)]
+    same = all(torch.equal(a, b) for a, b in zip(results["one bucket"][0], results["early bucket"][0]))
+    # and both are the mean over the ranks of the per-rank gradients
+    ref = []
+    for r in range(world):
+        xr = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + r))
+        for p in params:
+            p.grad = None
+        head(torch.relu(late(xr))).pow(2).mean().backward()
+        ref.append([p.grad.clone() for p in params])
+    mean = [sum(g) / world for g in zip(*ref)]
+    out[rank] = (same, max(float((a - b).abs().max()) for a, b in zip(results["early bucket"][0], mean)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_bucket_is_issued_inside_backward_and_equals_the_single_bucket():
+    """GradBucket(early=...): DESIGN.md §6 says the gradients that are complete early in the backward are all-reduced under the
+    rest of it - here the issue order is recorded on two gloo ranks (early collective, THEN the late layer's gradient becomes
+    ready, THEN the rest), and the result is bit-identical to the single-bucket path and equal to the mean over the ranks."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_early_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        assert len(out) == 2 and all(v[0] for v in out.values()) and max(v[1] for v in out.values()) <= 1e-7, dict(out)

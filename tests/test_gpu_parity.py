@@ -1420,6 +1420,72 @@ def test_bench_two_rank_control_flow_on_one_gpu(gpulib):
     assert abs(out["value"] - 32 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
 
 
+def _bucket_cuda_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "what-matters-for-meta-learning_amd"), root]
+    import torch.distributed as dist
+    from mlhot import dist as mdist
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    mdist.init_from_env("gloo")                     # two ranks sharing the box's one GPU: gloo carries the device tensors
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    late = torch.nn.Linear(256, 256).to(dev)
+    head = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.Tanh(), torch.nn.Linear(512, 64)).to(dev)
+    params = list(late.parameters()) + list(head.parameters())
+    x = torch.randn(64, 256, generator=torch.Generator().manual_seed(10 + rank)).to(dev)
+    res = {}
+    for name, kw, split in (("plain", dict(), False), ("side stream", dict(side_stream=True), False),
+                            ("side stream, issue / finish", dict(side_stream=True), True),
+                            ("early bucket on the side stream", dict(side_stream=True, early=list(head.parameters())), True)):
+        for p in params:
+            p.grad = None
+        bucket = mdist.GradBucket(params, **kw)
+        loss = head(torch.relu(late(x))).pow(2).mean()
+        bucket.arm()
+        loss.backward()
+        if split:
+            scale = bucket.sync(defer_scale=True, wait=False)
+            busy = torch.ones(1 << 20, device=dev).mul_(2.0).sum()       # compute-stream work that does not read the gradients
+            bucket.finish()
+            assert scale == 0.5 and float(busy) == 2.0 * (1 << 20)
+            grads = [p.grad * scale for p in params]
+        else:
+            assert bucket.sync() == 1.0
+            grads = [p.grad.clone() for p in params]
+        torch.cuda.synchronize()
+        res[name] = ([g.cpu() for g in grads], list(bucket.issue_log))
+    ok = all(torch.equal(a, b) for name in res for a, b in zip(res["plain"][0], res[name][0]))
+    out[rank] = (ok, res["early bucket on the side stream"][1], res["side stream"][1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_side_stream_and_early_bucket_on_cuda(gpulib):
+    """mlhot.dist.GradBucket on DEVICE tensors (two gloo ranks sharing this box's one GPU): the plain collective, the one on the
+    communication stream (sync, and issue -> unrelated compute -> finish) and the early bucket issued from inside backward() all
+    leave bit-identical averaged gradients; the early variant really issues two collectives."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_bucket_cuda_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        assert len(out) == 2
+        for ok, early_log, side_log in out.values():
+            assert ok
+            assert [k for k, _ in early_log] == ["early", "rest"] and [k for k, _ in side_log] == ["all"]
+
+
 def test_cpu_tensors_are_refused(gpulib):
     from mlhot.binding import MlhotError
     from mlhot.ops import LinearFunction

@@ -56,6 +56,13 @@ class ResNetNP(nn.Module):
             self.attn = FastAttention(dim_heads=256, causal=False)
             self.n_heads = self.N_HEADS
 
+    def early_grad_parameters(self):
+        """Parameters whose gradients are complete before the image trunks' backward starts (that backward - ONE C call over
+        the context / target / decoder passes - is the last node of the autograd graph): the MLPs, the attention and the decoder
+        head, i.e. everything outside `img_encoder` and `decoder.resnet`.  mlhot.dist.GradBucket(early=...) all-reduces them
+        from inside the backward, under the trunks' ~1 ms."""
+        return [p for k, p in self.named_parameters() if not (k.startswith("img_encoder.") or k.startswith("decoder.resnet."))]
+
     # the 8 per-head AttnLinear layers run as ONE linear over the stacked weights; rows come out
     # token-major / head-minor, which is the layout the FAVOR+ kernels take
     def _heads(self, x, mods):

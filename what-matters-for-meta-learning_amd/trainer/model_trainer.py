@@ -29,7 +29,10 @@ class ModelTrainer(BaseTrainer):
     def __init__(self, model, loss, optimizer, config, data):
         super().__init__(model=model, loss=loss, optimizer=optimizer, config=config)
         self.data = data
-        self.bucket = GradBucket(model.parameters(), side_stream=torch.device(config.device).type == "cuda")
+        # side stream: the RCCL kernels never sit in the compute queue; early bucket: models that know which gradients are complete
+        # before the backward ends (ResNet family: everything but the image trunks) all-reduce them under the rest of the backward
+        early = model.early_grad_parameters() if hasattr(model, "early_grad_parameters") else None
+        self.bucket = GradBucket(model.parameters(), side_stream=torch.device(config.device).type == "cuda", early=early)
         self.ingest, self._staged = None, None
         self._prefetch = False          # set per iteration by train(): may the NEXT training batch be drawn right away?
         self.rank0 = dist_rank() == 0   # files / logs / TensorBoard are rank 0's business (every rank holds the same weights)
@@ -150,11 +153,14 @@ class ModelTrainer(BaseTrainer):
     def _sync_and_step(self):
         """Gradient all-reduce + optimizer step of a multi-rank iteration; the 1/world average rides in the optimizer's
         gradient scale when it has one (mlhot.optim.FlatAdam), instead of a separate pass over the bucket."""
-        fused = hasattr(self.optimizer, "capturable")               # FlatAdam.step(grad_scale=...)
-        scale = self.bucket.sync(defer_scale=fused)
+        from mlhot.optim import FlatAdam
+        fused = isinstance(self.optimizer, FlatAdam)                # its step(grad_scale=...) folds the average into the update
         if fused:
+            scale = self.bucket.sync(defer_scale=True, wait=False)  # issued on the communication stream ...
+            self.bucket.finish()                                    # ... joined right before the first reader of the gradients
             self.optimizer.step(grad_scale=scale)
         else:
+            self.bucket.sync()
             self.optimizer.step()
 
     def _train_iter(self, it):
@@ -183,6 +189,7 @@ class ModelTrainer(BaseTrainer):
         losses = losses + kl * self.config.beta
         if contrastive:
             losses = losses + contra_loss * self.config.contrastive_rate
+        self.bucket.arm()                                         # world > 1: the early bucket's all-reduce goes out from inside backward()
         losses.backward()
         self._sync_and_step()
         value = losses.item()                                     # the iteration's only host sync
