@@ -56,6 +56,17 @@ int mlhot_set_option(const char* name, int value);
 int mlhot_prof_begin(int max_records);
 int mlhot_prof_end(const char** labels, float* ms, int cap);
 
+/* ---- B1 (eps stream): torch's CPU normal_() random stream continued on the device -------------------
+ * replaces the host-side `torch.empty(size).normal_(0, 1)` + `.to(device)` of bbb/BBBConv.py:86-95 and BBBLinear.py:79-88 for callers
+ * that hand the generator over (what-matters-for-meta-learning_amd/mlhot/rng.py): MT19937 (ATen/core/MT19937RNGEngine.h), 24-bit
+ * float uniforms, ATen's 16-wide Box-Muller normal_fill.  engine: uint32[626] = state[624], left, next - the engine's fields,
+ * advanced in place exactly as `total_outputs` calls would.  segs: nseg records of 4 int64 {dst offset in out, size (>= 16), stream
+ * offset of its first output, index of its first group of 16} in call order; a size that is not a multiple of 16 consumes
+ * size + 16 outputs and owns size / 16 + 1 groups.  uniform_ws: total_outputs floats of scratch.  Uniforms and engine state are
+ * bit-identical to torch's, the normals equal up to the last ulps of logf / sincosf.                                        */
+int mlhot_mt19937_normal(uint32_t* engine, float* uniform_ws, float* out, const int64_t* segs, int nseg, int64_t total_outputs,
+                         int64_t total_groups, void* stream);
+
 /* ---- E1: vanilla image encoder `encoder_w0` -------------------------------------------
  * replaces nn.Sequential(conv3x3s2+ReLU, conv3x3s2+ReLU, MaxPool2d(2), conv3x3s2+ReLU,
  * Flatten, Linear(4096,dim_w))   (networks/ANPShapeNet1D.py:46-56, CNPShapeNet1D.py:46-56,

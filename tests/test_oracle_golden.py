@@ -283,3 +283,55 @@ def test_oracle_routed_mr_and_bbb_models_equal_plain_under_their_own_routing():
     assert U.rel_err(out[1][0], out[0][0]) <= TIGHT
     for k, g in out[0][1].items():
         assert U.rel_err(out[1][1][k], g) <= TIGHT, k
+
+
+# ---- torch's CPU normal_() random stream (oracle/mt_normal.py: the checker of mlhot_mt19937_normal) ---------------------------
+def _ulps(a, b):
+    ai, bi = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ai, bi = np.where(ai < 0, -(ai & 0x7fffffff), ai), np.where(bi < 0, -(bi & 0x7fffffff), bi)
+    return np.abs(ai - bi)
+
+
+@pytest.mark.parametrize("seed", [0, 99, 2578])
+def test_mt_normal_restatement_against_torch(seed):
+    """The restated MT19937 engine + 24-bit uniforms + 16-wide Box-Muller against torch itself: uniforms and the generator state
+    after a normal_() call bit for bit (also from a mid-block position and for sizes that are not multiples of 16, which consume
+    16 extra outputs), normals within 6 ulp (numpy's log / sin / cos against ATen's Sleef)."""
+    from oracle import mt_normal as MT
+    torch.manual_seed(seed)
+    torch.rand(11)                                       # leave the block boundary
+    s0 = torch.get_rng_state()
+    st, left, nxt = MT.unpack_state(s0)
+    for size in (16, 33, 64, 100, 4800, 36864, 300007):
+        torch.set_rng_state(s0)
+        u = torch.empty(size).uniform_(0, 1).numpy()
+        raw, _, _, _ = MT.raw_outputs(st.copy(), left, nxt, size)
+        assert np.array_equal(MT.uniforms(raw), u), size
+        torch.set_rng_state(s0)
+        ref = torch.empty(size).normal_(0, 1).numpy()
+        st_t, left_t, nxt_t = MT.unpack_state(torch.get_rng_state())
+        x, st1, left1, nxt1 = MT.normal_(size, st.copy(), left, nxt)
+        assert np.array_equal(st1, st_t) and (left1, nxt1) == (left_t, nxt_t), size
+        assert _ulps(x, ref).max() <= 6, (size, _ulps(x, ref).max())
+    torch.set_rng_state(s0)
+
+
+def test_rng_state_pack_round_trip():
+    """mlhot.rng's view of torch.get_rng_state() (the product's hand-over / hand-back of the CPU generator): unpack -> pack leaves
+    the generator exactly where it was, and an engine advanced by the restatement continues like torch's own."""
+    from mlhot import rng as R
+    from oracle import mt_normal as MT
+    torch.manual_seed(7)
+    torch.rand(3)
+    s0 = torch.get_rng_state()
+    eng = R._unpack(s0)
+    torch.set_rng_state(R._pack(s0, eng))
+    a = torch.rand(9)
+    torch.set_rng_state(s0)
+    assert torch.equal(a, torch.rand(9))
+    torch.set_rng_state(s0)
+    ref = torch.empty(1000).normal_()
+    after = torch.rand(5)
+    x, st, left, nxt = MT.normal_(1000, eng[:624].copy(), int(eng[624]), int(eng[625]))
+    torch.set_rng_state(R._pack(s0, np.concatenate([st, np.array([left, nxt], dtype=np.uint32)])))
+    assert torch.equal(torch.rand(5), after) and _ulps(x, ref.numpy()).max() <= 6

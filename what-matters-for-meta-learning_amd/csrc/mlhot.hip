@@ -14,6 +14,7 @@
 #include "conv_rt.h"
 #include "ingest.h"
 #include "bbb_multi.h"
+#include "mt_normal.h"
 #include "resnet_trunk.h"
 #include "../../include/mlhot.h"
 
@@ -239,6 +240,33 @@ int mlhot_bbb_sample_multi_fwd(const mlhot_bbb_item* items, int n_items, float* 
 int mlhot_bbb_sample_multi_bwd(const mlhot_bbb_item* items, int n_items, const float* dkl, void* stream) {
   if (!items || !dkl) { set_error("bbb_sample_multi_bwd: bad argument"); return MLHOT_ERR_ARG; }
   return bbb_sample_multi_bwd(items, n_items, dkl, (hipStream_t)stream);
+}
+
+// ---- torch's CPU normal_() stream on the device (csrc/mt_normal.h) ----------------------------------------------------
+int mlhot_mt19937_normal(uint32_t* engine, float* uniform_ws, float* out, const int64_t* segs, int nseg, int64_t total_outputs,
+                         int64_t total_groups, void* stream) {
+  if (!engine || !uniform_ws || !out || !segs || nseg <= 0 || total_outputs <= 0 || total_groups <= 0) {
+    set_error("mt19937_normal: bad argument");
+    return MLHOT_ERR_ARG;
+  }
+#ifndef MLHOT_HOSTSIM
+  static_assert(sizeof(mt::Seg) == 4 * sizeof(int64_t), "segment record = 4 x int64");
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope ps("eps.mt19937", s);
+    hipLaunchKernelGGL(mt::mt_fill_kernel, dim3(1), dim3(256), 0, s, engine, uniform_ws, (long long)total_outputs);
+  }
+  MLHOT_TRY(check_launch("mt19937_normal (fill)"));
+  {
+    ProfScope ps("eps.box_muller", s);
+    const long long pairs = (long long)total_groups * 8;
+    hipLaunchKernelGGL(mt::mt_box_muller_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, uniform_ws, out,
+                       reinterpret_cast<const mt::Seg*>(segs), nseg, (long long)total_groups);
+  }
+  return check_launch("mt19937_normal (transform)");
+#else
+  (void)stream; set_error("mt19937_normal: GPU build only"); return MLHOT_ERR_ARG;
+#endif
 }
 
 // ---- whole ResNet trunks (weight-stationary kernels, csrc/resnet_ws.h / resnet_trunk.h) --------------------------------

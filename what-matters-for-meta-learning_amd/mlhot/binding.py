@@ -409,6 +409,17 @@ class MlhotLib:
         self._rc(self.c.mlhot_bbb_sample_multi_bwd(items, len(mus), _ptr(dkl), _stream(mus[0])), "mlhot_bbb_sample_multi_bwd")
         return dmus, drhos
 
+    # ---- torch's CPU normal_() stream on the device ---------------------------------------------
+    def mt19937_normal(self, engine, uniform_ws, out, segs, nseg, total_outputs, total_groups):
+        """engine: int32 [626] device tensor (state, left, next), advanced in place; segs: int64 [nseg, 4] device tensor."""
+        if not (engine.is_cuda and uniform_ws.is_cuda and out.is_cuda and segs.is_cuda):
+            raise MlhotError("mlhot_mt19937_normal: device tensors only")
+        if engine.dtype != torch.int32 or engine.numel() != 626 or segs.dtype != torch.int64 or out.dtype != torch.float32:
+            raise MlhotError("mlhot_mt19937_normal: engine int32[626], segs int64[nseg, 4], out float32")
+        self.c.mlhot_mt19937_normal.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
+        self._rc(self.c.mlhot_mt19937_normal(_ptr(engine), _ptr(uniform_ws), _ptr(out), _ptr(segs), nseg, total_outputs, total_groups,
+                                             _stream(out)), "mlhot_mt19937_normal")
+
     # ---- whole ResNet trunks -------------------------------------------------------------------
     @staticmethod
     def trunk_supported(C_, H):
