@@ -507,6 +507,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-extras", action="store_true", help="skip the fwd-only / +Adam timing legs")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing experiments (results become WRONG; never a bench line)")
+    ap.add_argument("--eps", choices=("host", "device"), default="host",
+                    help="c5: where the Bayes-by-backprop eps stream is produced - the torch CPU generator (the reference's route, bit-exact; "
+                         "default) or the same MT19937 stream continued on the GPU (mlhot_mt19937_normal)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="mlhot_set_option switches for A/B runs, e.g. c12_split=0")
     args = ap.parse_args()
     w = dict(WORKLOADS[args.workload], key=args.workload)
@@ -563,7 +566,7 @@ def main():
     if c5:
         from networks.bbb.eps import StagedEps
         torch.manual_seed(1234)
-        eps = StagedEps(device)
+        eps = StagedEps(device, source=args.eps)
         with eps.recording():
             fwd_bwd()
         torch.cuda.synchronize()
@@ -605,7 +608,8 @@ def main():
             def run():
                 if eps is not None:
                     eps.stage()              # collect the prefetched draws (or draw now) + one pinned H2D copy
-                    eps.prefetch()           # next step's draws, on a host thread, while this step runs
+                    if eps.source == "host":
+                        eps.prefetch()       # next step's draws, on a host thread, while this step runs (the device source looks ahead by itself)
                 graph.replay()
                 bucket.sync(defer_scale=True)
                 return static_loss
@@ -699,12 +703,24 @@ def main():
                "roofline": roof}
         if args.opt:
             out["options"] = args.opt
-        if eps is not None:
+        if eps is not None and eps.source == "host":
             d0 = time.perf_counter()
             eps.stage()
-            out["eps"] = {"floats_per_step": eps._total, "host_draw_ms_per_step": 1e3 * (time.perf_counter() - d0),
+            out["eps"] = {"source": "host", "floats_per_step": eps._total, "host_draw_ms_per_step": 1e3 * (time.perf_counter() - d0),
                           "note": "drawn on the torch CPU generator in the reference's order (bit-identical samples), on a host thread while "
                                   "the previous step runs; a step costs max(GPU time, draw time)"}
+        elif eps is not None:
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(eps._dn_stream):
+                e0.record()
+                eps._dn.draw(out=eps._dn_buf)
+                e1.record()
+            torch.cuda.synchronize()
+            out["eps"] = {"source": "device", "floats_per_step": eps._total, "device_draw_ms_per_step": e0.elapsed_time(e1),
+                          "note": "the torch CPU generator's MT19937 stream continued on the GPU (mlhot_mt19937_normal: identical uniforms, "
+                                  "normals within 4 ulp of torch's), one step ahead on a side stream; not the bit-exact default"}
+            eps.release()
         if extras:
             out["extras"] = extras
         if not args.no_cpu_baseline and world == 1:

@@ -847,6 +847,48 @@ def test_device_normal_continues_the_cpu_generator(gpulib, seed):
     print(f"device normal_ stream, seed {seed}: {2 * sum(sizes)} draws, worst difference {worst} ulp; generator state handed back bit-exact")
 
 
+def test_staged_eps_device_source_vs_host_source(gpulib):
+    """StagedEps(source="device"): ANPMRShapeNet3D steps fed from the device-side continuation of the CPU generator against the
+    same steps fed by the host draws: eps within 6 ulp, mu / kl / every gradient within 1e-5 (the 1e-4 parity bar of the model
+    against the reference therefore holds with either source), over three consecutive steps (the look-ahead draw, the double
+    buffer); release() leaves the CPU generator exactly where the host-only run leaves it."""
+    from networks.bbb.eps import StagedEps
+    from trainer.losses import LossFunc
+    fx, meta = U.load_case("r_anpmr_shapenet3d")
+    cx, qx, cy, qy = (t.to(DEV) for t in U.resnet_case_inputs(meta, fx))
+    results = {}
+    for source in ("host", "device"):
+        model = U.build_model(meta, DEV, fx=fx).to(DEV)
+        torch.manual_seed(99)
+        eps = StagedEps(DEV, source=source)
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            mu, var, kl = model(cx, cy, qx)
+            (LossFunc("mse", "shapenet_3d").calc_loss(mu, var, qy) + 1e-7 * kl).backward()
+            return mu.detach().clone(), kl.detach().clone()
+        with eps.recording():
+            step()                                         # lazy draws: consumes one step of the stream in both runs
+        outs = []
+        for _ in range(3):
+            eps.stage()
+            with eps.active():
+                mu, kl = step()
+            outs.append((eps._dev.clone(), mu, kl, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+        if source == "device":
+            eps.release()
+        torch.cuda.synchronize()
+        results[source] = (outs, torch.rand(4))
+    assert torch.equal(results["host"][1], results["device"][1])          # the CPU generator continues identically
+    for (eh, muh, klh, gh), (ed, mud, kld, gd) in zip(results["host"][0], results["device"][0]):
+        assert _ulps(ed.cpu().numpy(), eh.cpu().numpy()).max() <= 6
+        assert U.rel_err(mud, muh) <= 1e-5 and abs(kld.item() - klh.item()) <= 1e-6 * abs(klh.item())
+        for k in gh:
+            assert U.rel_err(gd[k], gh[k], floor=1e-3 * float(gh[k].abs().max()) + 1e-12) <= 1e-3, k
+    # and the first host-fed step is the reference's own (the fixture): the device-fed one within the parity bar
+    assert U.rel_err(results["device"][0][0][1], results["host"][0][0][1]) <= U.RTOL
+
+
 def test_flat_adam_matches_torch_adam(gpulib):
     """mlhot.optim.FlatAdam (parameters re-pointed into ONE flat buffer laid out like the library's
     flat gradient buffer; one mlhot_adam_step launch) against torch.optim.Adam on an identically seeded model, 3 steps."""

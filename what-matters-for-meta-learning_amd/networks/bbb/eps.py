@@ -16,6 +16,13 @@ buffer - which is what makes a Bayes-by-backprop training step capturable in a h
 order, so the numbers are exactly those of the lazy route) into the alternate pinned buffer while step k runs on the GPU; the
 next `stage()` only waits for that thread and starts the copy.  A step then costs max(GPU time, draw time), not their sum.
 Nothing else may use the torch CPU generator between prefetch() and the stage() that collects it.
+
+`StagedEps(device, source="device")` lifts the host out of the loop altogether: the CPU generator's MT19937 engine is handed to
+the device (mlhot.rng.DeviceNormal -> mlhot_mt19937_normal) and every stage() receives the SAME random stream from there -
+identical uniforms, normals equal to torch's up to <= 4 ulp of logf / sincosf (so a model output moves by ~1e-7, far inside the
+1e-4 parity bar, but it is not bit-identical: the host route stays the default).  Step k+1's numbers are produced on a side
+stream while step k runs (one CU for ~0.3 ms); stage() is then an event wait and one 3.5 MB device copy.  release() hands the
+engine back: the CPU generator continues exactly where a host-only run would be.
 """
 import contextlib
 import threading
@@ -37,8 +44,12 @@ def draw(size, device):
 
 
 class StagedEps:
-    def __init__(self, device):
+    def __init__(self, device, source="host"):
+        if source not in ("host", "device"):
+            raise ValueError("StagedEps: source is 'host' (torch CPU generator, bit-exact) or 'device' (the same stream on the GPU)")
         self.device = torch.device(device)
+        self.source = source
+        self._dn, self._dn_buf, self._dn_stream, self._dn_ready, self._dn_free = None, None, None, None, None
         self.shapes = []
         self._offsets, self._total, self._cursor = None, 0, 0
         self._host, self._dev, self._done, self._turn = None, None, None, 0
@@ -139,6 +150,47 @@ class StagedEps:
                 self._worker_err = e
             self._ready.set()
 
+    # ---- source = "device" ------------------------------------------------------------------------------------------
+    def _device_issue(self):
+        """Produce the NEXT stage()'s numbers on the side stream (behind the copy that emptied the buffer)."""
+        with torch.cuda.stream(self._dn_stream):
+            if self._dn_free is not None:
+                self._dn_stream.wait_event(self._dn_free)
+            self._dn_before = self._dn._engine.clone()      # the engine as of the numbers handed out so far (release())
+            self._dn.draw(out=self._dn_buf)
+            self._dn_ready = self._dn_stream.record_event()
+
+    def _device_stage(self):
+        if self._dn is None:
+            from mlhot.rng import DeviceNormal
+            sizes = [int(torch.Size(s).numel()) for s in self.shapes]
+            self._dn = DeviceNormal(self.device, sizes)
+            if self._dn.offsets != self._offsets or self._dn.total != self._total:
+                raise RuntimeError("StagedEps: device and host plans disagree")
+            with torch.cuda.device(self.device):
+                self._dn_stream = torch.cuda.Stream(self.device)
+                self._dn_buf = torch.empty(self._total, device=self.device)
+            self._dn.take_over()                       # from here on the device owns the CPU generator's stream
+            self._dn_stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._device_issue()
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self._dn_ready)
+        self._dev.copy_(self._dn_buf)
+        self._dn_free = cur.record_event()
+        self._device_issue()                           # step k+1's numbers, under step k
+        self._cursor = 0
+
+    def release(self):
+        """source = "device": hand the engine back to the torch CPU generator: it continues exactly where a host-only run would be
+        after the stage() calls made so far (the one look-ahead draw that is already on the device is given up - the engine is
+        handed back as it was before it)."""
+        if self._dn is None:
+            return
+        self._dn_stream.synchronize()
+        self._dn._engine = self._dn_before
+        self._dn.hand_back()
+        self._dn = None
+
     def stage(self):
         """The next forward's eps on the device: draws them on the CPU generator (or collects the draws a prefetch() made
         meanwhile) and starts the copy (current stream)."""
@@ -146,6 +198,8 @@ class StagedEps:
             raise RuntimeError("StagedEps.stage(): nothing recorded; run one step under recording() first")
         if self._offsets is None:
             self._plan()
+        if self.source == "device":
+            return self._device_stage()
         k = self._turn = self._turn ^ 1
         if self._worker is not None:
             self._ready.wait()
