@@ -316,6 +316,46 @@ def measure_variable_nc(w, device, loss_fn, model, batch, iters):
             "note": "context size ~ U{3..15} per step (the reference's training draw), 15 targets, one hipGraph per size"}
 
 
+def measure_variable_nc_3d(w, device, loss_fn, model, eps, fwd_bwd_on, iters):
+    """c5: the reference's ShapeNet3D TRAINING draw (dataset/shapenet_3d.py:110, 200-204): context size ~ U{1..15} per batch,
+    the REST of the object's 30 views are the targets (Nq = 30 - Nc, up to 29).  One captured hipGraph per context size,
+    replayed in a seeded random order with the eps staged per step like the headline loop."""
+    import numpy as np
+    from mlhot import synth
+    cx, qx, cy, qy = synth.get_batch_3d(w["T"], 15, 15, seed=4321, device=device, task_aug=True)
+    pool_x, pool_y = torch.cat([cx, qx], dim=1), torch.cat([cy, qy], dim=1)          # 30 views per task
+    graphs, keep = {}, []
+    for nc in range(1, 16):
+        b = (pool_x[:, :nc].contiguous(), pool_x[:, nc:].contiguous(), pool_y[:, :nc].contiguous(), pool_y[:, nc:].contiguous())
+        keep.append(b)                                   # a graph's inputs have to outlive its capture
+
+        def step(b=b):
+            eps.rewind()
+            fwd_bwd_on(*b)
+        eps.stage()
+        with eps.active():
+            graphs[nc] = _capture(step)
+    order = np.random.RandomState(0).randint(1, 16, size=2 * iters)
+
+    def run(seq):
+        for nc in seq:
+            eps.stage()
+            if eps.source == "host":
+                eps.prefetch()
+            graphs[int(nc)].replay()
+    run(order[:6])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(order)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / len(order)
+    if eps._worker is not None:
+        eps.stage()
+    return {"ms_per_step": ms, "tasks_per_s": 1e3 * w["T"] / ms, "mean_context": float(order.mean()), "steps": int(len(order)),
+            "note": "context size ~ U{1..15} per step, targets = the other 30 - Nc views (the reference's ShapeNet3D training draw), "
+                    "one hipGraph per size"}
+
+
 def measure_train_loop(w, device, loss_fn, iters):
     """A whole TRAINING iteration from host batch to updated weights, two ways (informational; `value` is the resident fwd+bwd step):
       reference-style loop: fp32 host batch `.to(device)`, eager zero_grad / forward / loss / backward on the HIP kernels,
@@ -548,10 +588,11 @@ def main():
                               early=model.early_grad_parameters() if hasattr(model, "early_grad_parameters") else None)
     beta = w.get("beta", 0.0)
 
-    def fwd_bwd(arm=False):
+    def fwd_bwd(arm=False, batch=None):
+        bx, by, tx, ty = batch if batch is not None else (cx, cy, qx, qy)
         model.zero_grad(set_to_none=True)
-        mu, var, kl = model(cx, cy, qx)
-        loss = loss_fn.calc_loss(mu, var, qy)
+        mu, var, kl = model(bx, by, tx)
+        loss = loss_fn.calc_loss(mu, var, ty)
         if c5:
             loss = loss + beta * kl          # identical on every rank (same weights, kl does not depend on the batch): averaged, never summed
         if arm:
@@ -684,6 +725,13 @@ def main():
     extras = None
     if world == 1 and not args.no_extras and not args.no_graph and not c5:
         extras = measure_extras(w, device, loss_fn, (cx, qx, cy, qy), max(10, args.steps // 2))
+    if world == 1 and not args.no_extras and not args.no_graph and c5:
+        try:
+            extras = {"variable_context": measure_variable_nc_3d(w, device, loss_fn, model, eps,
+                                                                 lambda a, b_, c_, d_: fwd_bwd(batch=(a, c_, b_, d_)), max(10, args.steps // 2)),
+                      "note": "informational, not the headline metric"}
+        except Exception as e:  # noqa: BLE001 - extras must never break the bench line
+            extras = {"error": f"{type(e).__name__}: {e}"}
     if world > 1:
         dist.barrier()
 

@@ -458,14 +458,16 @@ def test_anpmr_shapenet3d_vs_reference(gpulib):
     assert abs(loss.item() - float(fx["loss"])) <= U.RTOL * max(1.0, abs(float(fx["loss"])))
 
 
-def test_c5_full_size_forward_backward_vs_oracle(gpulib):
+@pytest.mark.parametrize("Nc,Nq", [(15, 15), (7, 23)])
+def test_c5_full_size_forward_backward_vs_oracle(gpulib, Nc, Nq):
     """BASELINE config c5 at its per-GPU size (ANPMRShapeNet3D, 8 tasks x (15 + 15) 3x64x64 images: 240 + 120 encoder images,
     FAVOR+ at d = 256 / m = 1419 over 15 x 15 shots): mu, kl, the quaternion loss AND every gradient of loss + 1e-7*kl at 1e-4
     against the CPU oracle (evaluated in fp64, see _anpmr3d_routed_check) under the same seeded eps draws and the kernels' ReLU
-    routing (360 images x ~1e5 decisions each)."""
+    routing (360 images x ~1e5 decisions each).  (7, 23): one batch of the reference's TRAINING draw - context size ~ U{1..15},
+    the other 30 - Nc views of the object are the targets (dataset/shapenet_3d.py:110, 200-204)."""
     import types
     from networks.ANPMRShapeNet3D import ANPMRShapeNet3D
-    T, Nc, Nq = 8, 15, 15
+    T = 8
     cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[64, 64, 4], tasks_per_batch=T, input_dim=4, output_dim=4,
                                 agg_mode="attention", img_agg="reshape", task="shapenet_3d", temperature=0.07)
     model = ANPMRShapeNet3D(cfg).to(DEV)

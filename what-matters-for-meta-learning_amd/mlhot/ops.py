@@ -105,6 +105,31 @@ class LinearFunction(torch.autograd.Function):
         return (dx.view(ctx.shp) if dx is not None else None), dw, (db if ctx.has_b else None), None
 
 
+class StackedLinearFunction(torch.autograd.Function):
+    """y = x [W_0; W_1; ...]^T + [b_0; b_1; ...] for the per-head Linear layers of the attention (networks/ANP.py:75-93 runs
+    them one by one and stacks the outputs): ONE linear over the stacked weight.  `stack_w` / `stack_b` are the buffers the
+    heads' parameters are views of (networks/_resnet_np.py::HeadStack), so nothing is concatenated per step; the backward's
+    dW / db are handed to the heads as views of one gradient tensor."""
+
+    @staticmethod
+    def forward(ctx, x, stack_w, stack_b, n_heads, *head_params):
+        _need_gpu(x, stack_w, stack_b)
+        shp = x.shape
+        x2 = _c(x.reshape(-1, shp[-1]).float())
+        y = lib().linear_fwd(x2, stack_w, stack_b, "none")
+        ctx.shp, ctx.n_heads = shp, n_heads
+        ctx.save_for_backward(x2, stack_w, y)
+        return y.view(*shp[:-1], stack_w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        dx, dw, db = lib().linear_bwd(x2, w, y, _c(dy.reshape(-1, w.shape[0])), "none", need_dx=ctx.needs_input_grad[0])
+        h = ctx.n_heads
+        return ((dx.view(ctx.shp) if dx is not None else None), None, None, None,
+                *dw.view(h, w.shape[0] // h, w.shape[1]).unbind(0), *db.view(h, -1).unbind(0))
+
+
 class AggFunction(torch.autograd.Function):
     """mean / max / baco over dim 1 of rs[T,Nc,R]: mlhot_agg_fwd / _bwd.
     For baco, `rs` is mu and `lv` the pre-softplus variance logits; returns (r, sigma_z)."""

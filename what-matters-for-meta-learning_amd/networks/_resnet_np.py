@@ -7,9 +7,45 @@ operators (run-time-shaped convolutions, linears, shot-axis aggregators, FAVOR+ 
 import torch
 from torch import nn
 
-from mlhot.ops import AggFunction, FavorFunction, LinearFunction
+from mlhot.ops import AggFunction, FavorFunction, LinearFunction, StackedLinearFunction
 from networks.fast_attention import FastAttention
 from networks.models import AttnLinear, ImageEncoder, NPDecoder, _mlp3, run_trunks
+
+
+class HeadStack:
+    """The weights / biases of the N per-head AttnLinear layers as views of ONE [N*h, h] / [N*h] buffer, so that the heads run as
+    one linear without a torch.cat per forward (3 stacks x (weight + bias) = 6 concatenations of 6 MB per step, and as many
+    gradient splits in the backward).  The modules keep their own Parameters and state_dict keys (the reference's layout:
+    `_W_k.3.linear.weight`); only their storage is shared.  `.to(device)` / `load_state_dict(assign=True)` give every
+    parameter a storage of its own again - tensors() notices (data pointers) and re-stacks."""
+
+    def __init__(self, mods):
+        self.mods, self.w, self.b = list(mods), None, None
+
+    def _aliased(self):
+        if self.w is None:
+            return False
+        h = self.mods[0].linear.weight.shape[0]
+        for i, m in enumerate(self.mods):
+            wt, bs = m.linear.weight, m.linear.bias
+            if (wt.device != self.w.device or wt.data_ptr() != self.w.data_ptr() + 4 * i * h * wt.shape[1] or not wt.is_contiguous()
+                    or bs.data_ptr() != self.b.data_ptr() + 4 * i * h):
+                return False
+        return True
+
+    def tensors(self):
+        if not self._aliased():
+            ws, bs = [m.linear.weight for m in self.mods], [m.linear.bias for m in self.mods]
+            h = ws[0].shape[0]
+            with torch.no_grad():
+                self.w, self.b = torch.cat([t.detach() for t in ws], dim=0), torch.cat([t.detach() for t in bs], dim=0)
+                for i, (wt, bt) in enumerate(zip(ws, bs)):
+                    wt.data = self.w[i * h:(i + 1) * h]
+                    bt.data = self.b[i * h:(i + 1) * h]
+        return self.w, self.b
+
+    def params(self):
+        return [m.linear.weight for m in self.mods] + [m.linear.bias for m in self.mods]
 
 
 class ResNetNP(nn.Module):
@@ -66,10 +102,13 @@ class ResNetNP(nn.Module):
     # the 8 per-head AttnLinear layers run as ONE linear over the stacked weights; rows come out
     # token-major / head-minor, which is the layout the FAVOR+ kernels take
     def _heads(self, x, mods):
-        w = torch.cat([m.linear.weight for m in mods], dim=0)
-        b = torch.cat([m.linear.bias for m in mods], dim=0)
+        stacks = self.__dict__.setdefault("_head_stacks", {})
+        st = stacks.get(id(mods))
+        if st is None:
+            st = stacks[id(mods)] = HeadStack(mods)
+        w, b = st.tensors()
         T, N, _ = x.shape
-        return LinearFunction.apply(x, w, b, "none").view(T, N, self.N_HEADS, -1)
+        return StackedLinearFunction.apply(x, w, b, self.N_HEADS, *st.params()).view(T, N, self.N_HEADS, -1)
 
     def _multihead_attention(self, k, v, q):
         merged = FavorFunction.apply(self._heads(q, self._W_q), self._heads(k, self._W_k), self._heads(v, self._W_v),

@@ -82,8 +82,8 @@ def trunk_weights(conv1, resnet):
 
 def run_trunks(jobs):
     """Every ResNet-trunk pass of a model step in one call per direction (mlhot.ops.ResNetTrunkFunction).
-    jobs: [(images [n, C, H, W], weights = list of 26 tensors, skip kernel 1 | 3, tap_log or None)]; passes whose `weights` are
-    the same list object share one weight set (their gradients come out summed).  Returns the output maps [n, 64, H/32, W/32].
+    jobs: [(images [n, C, H, W], weights = list of 26 tensors, skip kernel 1 | 3, tap_log or None)]; passes whose `weights` hold
+    the same tensor objects share one weight set (their gradients come out summed).  Returns the output maps [n, 64, H/32, W/32].
     Image sizes without weight-stationary kernels (anything but 3x64x64 / 1x128x128) return None: the caller composes the
     run-time-shaped convolution operators instead."""
     C, H, W = jobs[0][0].shape[1:]
@@ -95,7 +95,7 @@ def run_trunks(jobs):
         if ii is None:
             imgs.append(img)
             ii = len(imgs) - 1
-        wi = next((k for k, (ws, _) in enumerate(wsets) if ws is weights), None)
+        wi = next((k for k, (ws, _) in enumerate(wsets) if len(ws) == len(weights) and all(a is b for a, b in zip(ws, weights))), None)
         if wi is None:
             wsets.append((weights, skip_k))
             wi = len(wsets) - 1
@@ -128,10 +128,11 @@ class ImageEncoder(nn.Module):
         return self.tap_log[-1]
 
     def trunk_job(self, img):
-        """This encoder's pass over `img` as a run_trunks job; the weight list is cached so that two passes share one set."""
-        if getattr(self, "_tw", None) is None:
-            self._tw = trunk_weights(self.conv1, self.resnet)
-        return (img, self._tw, 1, self.tap_log)
+        """This encoder's pass over `img` as a run_trunks job.  The weight list is rebuilt on every call (26 attribute reads): a
+        cached list would keep feeding the kernels the OLD tensors after a parameter is re-bound (load_state_dict(assign=True),
+        parametrisations, `m.conv1.weight = nn.Parameter(...)`); two passes of one step share a weight set because run_trunks
+        compares the tensors themselves."""
+        return (img, trunk_weights(self.conv1, self.resnet), 1, self.tap_log)
 
     def features(self, fmap):
         """img_agg + reshape of a trunk output map [n, 64, h, w] -> [T, N, F]  (models.py:105-115)."""
@@ -161,9 +162,7 @@ class NPDecoder(nn.Module):
         self.tap_log = None
 
     def trunk_job(self, imgs):
-        if getattr(self, "_tw", None) is None:
-            self._tw = trunk_weights(self.conv1, self.resnet)
-        return (imgs, self._tw, 1, self.tap_log)
+        return (imgs, trunk_weights(self.conv1, self.resnet), 1, self.tap_log)      # rebuilt per call, see ImageEncoder.trunk_job
 
     def forward(self, test_images, sample_features, log_variance=None, fmap=None):
         """`fmap`: this decoder's trunk output over the target images when the caller already ran it together with the
