@@ -36,6 +36,10 @@ WORKLOADS = {   # BASELINE.json configs[1] / configs[2] (the headline metric) an
                fwd_gflop_per_task=3.92,
                name="ANPMRShapeNet3D (Bayes-by-backprop ResNet encoder) 64x64x3 15+15-shot + task augmentation of the labels, 8 tasks/GPU "
                     "(the per-GPU share of BASELINE configs[4]: 64 tasks over 8 GPUs)"),
+    # SURVEY §8f rank 4 (not a BASELINE config; kernel-time evidence for the 128 x 128 x 1 trunk geometries): cfg/train/ANP_Distractor.yaml
+    "distractor": dict(kind="resnet_dis", method="ANPDistractor", agg_mode="attention", T=20, image="128x128x1", task="distractor",
+                       fwd_gflop_per_task=11.1,
+                       name="ANPDistractor (ResNet encoder + decoder, 1x1 skips) 128x128x1 15+15-shot, 20 tasks/GPU (cfg/train/ANP_Distractor.yaml)"),
 }
 NC, NQ = 15, 15
 T_LOCAL = 16                    # vanilla workloads; WORKLOADS[...]["T"] is authoritative
@@ -68,12 +72,13 @@ def alg_flops(label, n_img):
     return table.get(label)
 
 
-def trunk_flops_per_step(T):
-    """Algorithmic FLOPs (2 x MACs) one c5 step spends under every ResNet-trunk launch label: two Bayes-by-backprop encoder passes
-    (context, target: 3x3 skip) and the decoder pass (1x1 skip) over 15 images per task each; L = output map sizes."""
-    n, C, L = 15 * T, 3, [32, 16, 8, 4, 2]
+def trunk_flops_per_step(T, kind="resnet3d"):
+    """Algorithmic FLOPs (2 x MACs) one step spends under every ResNet-trunk launch label.  c5: two Bayes-by-backprop encoder
+    passes (context, target: 3x3 skip) and the decoder pass (1x1 skip) over 15 3x64x64 images per task each; distractor: three
+    1x1-skip passes over 1x128x128 images.  L = output map sizes."""
+    n, C, L = (15 * T, 3, [32, 16, 8, 4, 2]) if kind == "resnet3d" else (15 * T, 1, [64, 32, 16, 8, 4])
     f = {"trunk.stem": 0.0, "trunk.bwd.stem.wgrad": 0.0, "trunk.bwd.skip1.wgrad": 0.0}
-    for skip_k in (3, 3, 1):                               # the three passes
+    for skip_k in ((3, 3, 1) if kind == "resnet3d" else (1, 1, 1)):      # the three passes
         stem = 2.0 * n * L[0] ** 2 * 64 * 25 * C
         f["trunk.stem"] += stem
         f["trunk.bwd.stem.wgrad"] += stem
@@ -98,6 +103,9 @@ def make_cfg(w, device):
     if w["kind"] == "resnet3d":
         return types.SimpleNamespace(device=device, seed=2578, img_size=[64, 64, 4], tasks_per_batch=w["T"], input_dim=4, output_dim=4,
                                      agg_mode="attention", img_agg="reshape", task="shapenet_3d", temperature=0.07, method=w["method"])
+    if w["kind"] == "resnet_dis":
+        return types.SimpleNamespace(device=device, seed=2578, img_size=[128, 128, 1], tasks_per_batch=w["T"], input_dim=2, output_dim=2,
+                                     agg_mode="attention", img_agg="max", dim_w=16, task="distractor", temperature=0.07, method=w["method"])
     return types.SimpleNamespace(device=device, seed=2578, img_size=[128, 128, 1], tasks_per_batch=w["T"], input_dim=3,
                                  output_dim=2, agg_mode=w["agg_mode"], img_agg="", dim_w=64, n_hidden_units_r=[100, 100],
                                  dim_r=w["dim_r"], dim_z=64, task="shapenet_1d", method=w["method"])
@@ -107,6 +115,11 @@ def make_batch(w, seed, device="cpu"):
     from mlhot import synth
     if w["kind"] == "resnet3d":
         return synth.get_batch_3d(w["T"], NC, NQ, seed=seed, device=device, task_aug=True)
+    if w["kind"] == "resnet_dis":                          # images in [0, 1), labels = object positions in [0, 1)^2 (dataset/shapenet_distractor.py)
+        g = torch.Generator().manual_seed(seed)
+        xs, xq = torch.rand(w["T"], NC, 1, 128, 128, generator=g), torch.rand(w["T"], NQ, 1, 128, 128, generator=g)
+        ys, yq = torch.rand(w["T"], NC, 2, generator=g), torch.rand(w["T"], NQ, 2, generator=g)
+        return tuple(t.to(device) for t in (xs, xq, ys, yq))
     return synth.get_batch("shapenet_1d", w["T"], NC, NQ, seed=seed, device=device)
 
 
@@ -159,6 +172,8 @@ def cpu_baseline(w, steps=5, warmups=2):
             torch.manual_seed(99)
             mu, kl = O.anpmr3d_forward(p, cx, cy, qx)
             (O.calc_loss("shapenet_3d", mu, qy) + w["beta"] * kl).backward()
+        elif w["kind"] == "resnet_dis":
+            O.calc_loss("distractor", O.resnet_np_forward(p, cx, cy, qx, "attention", "max"), qy).backward()
         else:
             mu = O.vanilla_np_forward(p, cx, cy, qx, w["agg_mode"], tanh=True)
             O.calc_loss("shapenet_1d", mu, qy).backward()
@@ -483,7 +498,7 @@ def forward_roofline(w, fwd_ms):
     t = fwd_ms * 1e-3
     flops = w["fwd_gflop_per_task"] * 1e9 * w["T"]
     img_bytes = {"128x128x1": 65536, "64x64x3": 49152}[w["image"]]
-    n_dec = NQ if w["kind"] == "resnet3d" else 0                      # the decoder ResNet re-reads the target images
+    n_dec = NQ if w["kind"] != "vanilla" else 0                      # the decoder ResNet re-reads the target images
     compulsory = w["T"] * (NC + NQ + n_dec) * img_bytes + {"c3": 1.96e6, "c2": 1.45e6, "c5": 17.2e6}.get(w.get("key", ""), 0.0)
     measured = None
     try:
@@ -685,7 +700,7 @@ def main():
         kernels = {k: {"launches_per_step": v[0] / args.prof_steps, "avg_us": 1e3 * v[1] / v[0],
                        "us_per_step": 1e3 * v[1] / args.prof_steps} for k, v in agg.items()}
         # algorithmic FLOPs of ALL launches of a label in one step (vanilla: one launch per label)
-        per_step = trunk_flops_per_step(T) if c5 else {k: alg_flops(k, n_img) * kernels[k]["launches_per_step"] for k in agg if alg_flops(k, n_img)}
+        per_step = trunk_flops_per_step(T, w["kind"]) if w["kind"] != "vanilla" else {k: alg_flops(k, n_img) * kernels[k]["launches_per_step"] for k in agg if alg_flops(k, n_img)}
         per_step = {k: v for k, v in per_step.items() if k in agg and v}
         if per_step:
             dom = max(per_step, key=lambda k: agg[k][1])
@@ -723,7 +738,7 @@ def main():
         roof["forward"] = fwd
     # ---- informational extras (SURVEY §8d "also report fwd-only and +Adam"), rank 0, single-GPU runs only -----------
     extras = None
-    if world == 1 and not args.no_extras and not args.no_graph and not c5:
+    if world == 1 and not args.no_extras and not args.no_graph and w["kind"] == "vanilla":
         extras = measure_extras(w, device, loss_fn, (cx, qx, cy, qy), max(10, args.steps // 2))
     if world == 1 and not args.no_extras and not args.no_graph and c5:
         try:
@@ -736,8 +751,9 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        out = {"metric": "meta-tasks/sec (fwd+bwd), ANP ShapeNet1D 15+15-shot 16-task batch" if not c5 else
-                         "meta-tasks/sec (fwd+bwd), ANPMR ShapeNet3D 15+15-shot, 8 tasks per GPU",
+        out = {"metric": "meta-tasks/sec (fwd+bwd), ANPMR ShapeNet3D 15+15-shot, 8 tasks per GPU" if c5 else
+                         "meta-tasks/sec (fwd+bwd), ANP Distractor 15+15-shot, 20 tasks per GPU" if w["kind"] == "resnet_dis" else
+                         "meta-tasks/sec (fwd+bwd), ANP ShapeNet1D 15+15-shot 16-task batch",
                "value": world * T * args.steps / elapsed, "unit": "meta-tasks/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

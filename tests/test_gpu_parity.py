@@ -659,7 +659,11 @@ def _trunk_dict(ws):
 
 
 @pytest.mark.parametrize("C,H,skip_k,ns,share", [(3, 64, 3, (5,), False), (3, 64, 1, (7, 3), True), (3, 64, 3, (33, 2, 9), False),
-                                                 (1, 128, 1, (3,), False), (1, 128, 1, (2, 5), True), (3, 64, 1, (120,), False)])
+                                                 (1, 128, 1, (3,), False), (1, 128, 1, (2, 5), True), (3, 64, 1, (120,), False),
+                                                 # production-sized image counts for the 1 x 128 x 128 (Distractor) geometries: thousands
+                                                 # of bands per launch, so the band loops (band += workgroups), the multi-band
+                                                 # weight-gradient slab rows and the stem / 1x1-skip row splitting all run
+                                                 (1, 128, 1, (96, 40), True), (1, 128, 3, (70,), False)])
 def test_resnet_trunk_fwd_bwd_vs_torch(gpulib, C, H, skip_k, ns, share):
     """mlhot_trunk_fwd / _bwd: several passes in one call (ragged image counts that end in partial bands; passes that share a
     weight set; the 1x1 and the 3x3 skip convolution; both supported image geometries) against torch's conv2d + autograd on the CPU.
