@@ -56,6 +56,16 @@ int mlhot_set_option(const char* name, int value);
 int mlhot_prof_begin(int max_records);
 int mlhot_prof_end(const char** labels, float* ms, int cap);
 
+/* ---- NT-Xent, the functional-contrastive term of the FCL* models ------------------
+ * replaces trainer/losses.py:82-99 (LossFunc.contrastive_loss / contrastive_loss_ANP -> pytorch_metric_learning.losses.NTXentLoss
+ * (temperature = t), an un-vendored dependency: algorithm restated in oracle/ref_cpu.py::nt_xent, value parity unpinned).  z: [N, d]
+ * embeddings (N <= 512, d <= 256, d % 16 == 0); the labels are always arange blocks, label(i) = (i / div) % mod
+ * (contrastive_loss: div = 1, mod = T, N = 2T; contrastive_loss_ANP: div = Nq, mod = T, N = T Nq).  ws: mlhot_nt_xent_ws_floats(N)
+ * floats kept between forward and backward.  loss / dloss: device scalars; dz: [N, d].                                          */
+size_t mlhot_nt_xent_ws_floats(int N);
+int mlhot_nt_xent_fwd(const float* z, int N, int d, int div, int mod, float t, float* ws, float* loss, void* stream);
+int mlhot_nt_xent_bwd(const float* z, int N, int d, int div, int mod, float t, const float* ws, const float* dloss, float* dz, void* stream);
+
 /* ---- B1 (eps stream): torch's CPU normal_() random stream continued on the device -------------------
  * replaces the host-side `torch.empty(size).normal_(0, 1)` + `.to(device)` of bbb/BBBConv.py:86-95 and BBBLinear.py:79-88 for callers
  * that hand the generator over (what-matters-for-meta-learning_amd/mlhot/rng.py): MT19937 (ATen/core/MT19937RNGEngine.h), 24-bit

@@ -895,6 +895,58 @@ def test_staged_eps_device_source_vs_host_source(gpulib):
     assert U.rel_err(results["device"][0][0][1], results["host"][0][0][1]) <= U.RTOL
 
 
+@pytest.mark.parametrize("N,d,div,mod", [(32, 64, 1, 16), (6, 256, 1, 3), (120, 256, 15, 8), (300, 256, 15, 20), (45, 64, 5, 9),
+                                         (7, 16, 7, 1), (10, 32, 1, 10), (512, 128, 16, 32)])
+def test_nt_xent_kernel_vs_definition(gpulib, N, d, div, mod):
+    """mlhot_nt_xent_fwd / _bwd (trainer/losses.py:82-99): value against the pair-by-pair definition in python floats / float64
+    (the published NTXentLoss algorithm; the package itself is absent, so this is what pins the term) at 1e-6, gradient against
+    float64 autograd of the same definition at 1e-4.  Shapes: both label structures (pairs: label = row % T; blocks: label =
+    row // Nq), row counts that are not multiples of 16, a single group (no negatives: loss and gradient are exactly 0), all
+    groups of size one (no positives: 0), the largest supported size."""
+    import math
+    from trainer.losses import nt_xent
+    t = 0.07
+    g = torch.Generator().manual_seed(N * 1000 + d)
+    z = torch.randn(N, d, generator=g) * (1.0 + torch.rand(N, 1, generator=g))
+    labels = [(i // div) % mod for i in range(N)]
+    zd = z.double().requires_grad_()
+    zn = zd / zd.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    sim = zn @ zn.t() / t
+    terms = []
+    for a in range(N):
+        neg = [k for k in range(N) if labels[k] != labels[a]]
+        if not neg:
+            continue
+        for p_ in range(N):
+            if p_ == a or labels[p_] != labels[a]:
+                continue
+            m = max(sim[a, p_].item(), sim[a, neg].max().item())
+            num = torch.exp(sim[a, p_] - m)
+            terms.append(-torch.log(num / (torch.exp(sim[a, neg] - m).sum() + num) + torch.finfo(torch.float32).tiny))
+    zg = z.to(DEV).requires_grad_()
+    loss = nt_xent(zg, div, mod, t)
+    loss.backward()
+    if not terms:
+        assert loss.item() == 0.0 and float(zg.grad.abs().max()) == 0.0
+        return
+    want = torch.stack(terms).mean()
+    want.backward()
+    assert abs(loss.item() - want.item()) <= 1e-6 * max(1.0, abs(want.item())), (loss.item(), want.item())
+    assert U.rel_err(zg.grad, zd.grad) <= U.RTOL
+    if N <= 32:                                    # python floats, term by term
+        s = sim.detach()
+        tot, cnt = 0.0, 0
+        for a in range(N):
+            neg = [k for k in range(N) if labels[k] != labels[a]]
+            for p_ in range(N):
+                if neg and p_ != a and labels[p_] == labels[a]:
+                    m = max([s[a, p_].item()] + [s[a, k].item() for k in neg])
+                    num = math.exp(s[a, p_].item() - m)
+                    tot += -math.log(num / (sum(math.exp(s[a, k].item() - m) for k in neg) + num))
+                    cnt += 1
+        assert abs(loss.item() - tot / cnt) <= 1e-6 * max(1.0, tot / cnt)
+
+
 def test_flat_adam_matches_torch_adam(gpulib):
     """mlhot.optim.FlatAdam (parameters re-pointed into ONE flat buffer laid out like the library's
     flat gradient buffer; one mlhot_adam_step launch) against torch.optim.Adam on an identically seeded model, 3 steps."""

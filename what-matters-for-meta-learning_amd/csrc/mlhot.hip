@@ -15,6 +15,7 @@
 #include "ingest.h"
 #include "bbb_multi.h"
 #include "mt_normal.h"
+#include "nt_xent.h"
 #include "resnet_trunk.h"
 #include "../../include/mlhot.h"
 
@@ -240,6 +241,60 @@ int mlhot_bbb_sample_multi_fwd(const mlhot_bbb_item* items, int n_items, float* 
 int mlhot_bbb_sample_multi_bwd(const mlhot_bbb_item* items, int n_items, const float* dkl, void* stream) {
   if (!items || !dkl) { set_error("bbb_sample_multi_bwd: bad argument"); return MLHOT_ERR_ARG; }
   return bbb_sample_multi_bwd(items, n_items, dkl, (hipStream_t)stream);
+}
+
+// ---- NT-Xent (csrc/nt_xent.h) -------------------------------------------------------------------------------------------
+size_t mlhot_nt_xent_ws_floats(int N) {
+  const size_t n16 = (size_t)((N + 15) & ~15);
+  return 4 * n16 + n16 / 16 + 16;
+}
+static int ntx_args(const float* z, int N, int d, int div, int mod, float t, float* ws, ntx::Args& a) {
+  if (!z || !ws || N < 1 || N > ntx::MAXN || d < 16 || d > ntx::MAXD || d % 16 || div < 1 || mod < 1 || !(t > 0.f)) {
+    set_error("nt_xent: needs 1 <= N <= %d rows, d <= %d with d %% 16 == 0, div, mod >= 1, t > 0", ntx::MAXN, ntx::MAXD);
+    return MLHOT_ERR_ARG;
+  }
+  const int n16 = (N + 15) & ~15;
+  a = ntx::Args{z, N, d, div, mod, 1.0f / t, ws, ws + n16, ws + 2 * n16, ws + 3 * n16, ws + 4 * n16};
+  return MLHOT_OK;
+}
+int mlhot_nt_xent_fwd(const float* z, int N, int d, int div, int mod, float t, float* ws, float* loss, void* stream) {
+  ntx::Args a;
+  MLHOT_TRY(ntx_args(z, N, d, div, mod, t, ws, a));
+  if (!loss) { set_error("nt_xent_fwd: null loss"); return MLHOT_ERR_ARG; }
+#ifndef MLHOT_HOSTSIM
+  hipStream_t s = (hipStream_t)stream;
+  const long long pairs = ntx::pair_count(N, div, mod);
+  const int nblk = (N + 15) / 16;
+  {
+    ProfScope ps("ntxent.fwd", s);
+    hipLaunchKernelGGL(ntx::ntx_fwd_kernel, dim3(nblk), dim3(256), ntx::lds_bytes(N, d), s, a);
+  }
+  MLHOT_TRY(check_launch("nt_xent_fwd"));
+  {
+    ProfScope ps("ntxent.finish", s);
+    hipLaunchKernelGGL(ntx::ntx_finish_kernel, dim3(1), dim3(64), 0, s, a.partial, nblk, pairs > 0 ? 1.0f / (float)pairs : 0.f, loss);
+  }
+  return check_launch("nt_xent_fwd (finish)");
+#else
+  (void)stream; set_error("nt_xent: GPU build only"); return MLHOT_ERR_ARG;
+#endif
+}
+int mlhot_nt_xent_bwd(const float* z, int N, int d, int div, int mod, float t, const float* ws, const float* dloss, float* dz, void* stream) {
+  ntx::Args a;
+  MLHOT_TRY(ntx_args(z, N, d, div, mod, t, const_cast<float*>(ws), a));
+  if (!dloss || !dz) { set_error("nt_xent_bwd: null argument"); return MLHOT_ERR_ARG; }
+#ifndef MLHOT_HOSTSIM
+  hipStream_t s = (hipStream_t)stream;
+  const long long pairs = ntx::pair_count(N, div, mod);
+  ntx::BwdArgs b{a, dloss, pairs > 0 ? 1.0f / (float)pairs : 0.f, dz};
+  {
+    ProfScope ps("ntxent.bwd", s);
+    hipLaunchKernelGGL(ntx::ntx_bwd_kernel, dim3((N + 15) / 16), dim3(256), ntx::lds_bytes(N, d), s, b);
+  }
+  return check_launch("nt_xent_bwd");
+#else
+  (void)stream; set_error("nt_xent: GPU build only"); return MLHOT_ERR_ARG;
+#endif
 }
 
 // ---- torch's CPU normal_() stream on the device (csrc/mt_normal.h) ----------------------------------------------------

@@ -409,6 +409,30 @@ class MlhotLib:
         self._rc(self.c.mlhot_bbb_sample_multi_bwd(items, len(mus), _ptr(dkl), _stream(mus[0])), "mlhot_bbb_sample_multi_bwd")
         return dmus, drhos
 
+    # ---- NT-Xent -----------------------------------------------------------------------------------
+    def nt_xent_fwd(self, z, div, mod, t):
+        """z [N, d] -> (loss scalar tensor, ws kept for the backward)."""
+        _chk(z)
+        if not z.is_cuda:
+            raise MlhotError("mlhot_nt_xent_fwd: device tensors only")
+        N, d = z.shape
+        self.c.mlhot_nt_xent_ws_floats.restype = C.c_size_t
+        self.c.mlhot_nt_xent_ws_floats.argtypes = [C.c_int]
+        ws = torch.empty(self.c.mlhot_nt_xent_ws_floats(N), device=z.device)
+        loss = torch.empty((), device=z.device)
+        self.c.mlhot_nt_xent_fwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._rc(self.c.mlhot_nt_xent_fwd(_ptr(z), N, d, div, mod, t, _ptr(ws), _ptr(loss), _stream(z)), "mlhot_nt_xent_fwd")
+        return loss, ws
+
+    def nt_xent_bwd(self, z, div, mod, t, ws, dloss):
+        _chk(z, ws, dloss)
+        N, d = z.shape
+        dz = torch.empty_like(z)
+        self.c.mlhot_nt_xent_bwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]
+        self._rc(self.c.mlhot_nt_xent_bwd(_ptr(z), N, d, div, mod, t, _ptr(ws), _ptr(dloss), _ptr(dz), _stream(z)), "mlhot_nt_xent_bwd")
+        return dz
+
     # ---- torch's CPU normal_() stream on the device ---------------------------------------------
     def mt19937_normal(self, engine, uniform_ws, out, segs, nseg, total_outputs, total_groups):
         """engine: int32 [626] device tensor (state, left, next), advanced in place; segs: int64 [nseg, 4] device tensor."""

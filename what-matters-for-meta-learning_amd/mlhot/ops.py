@@ -130,6 +130,26 @@ class StackedLinearFunction(torch.autograd.Function):
                 *dw.view(h, w.shape[0] // h, w.shape[1]).unbind(0), *db.view(h, -1).unbind(0))
 
 
+class NTXentFunction(torch.autograd.Function):
+    """NT-Xent of [N, d] embeddings whose labels are arange blocks, label(i) = (i // div) % mod: mlhot_nt_xent_fwd / _bwd
+    (trainer/losses.py:82-99).  No host-side index tensors, no host -> device copies, capturable."""
+
+    @staticmethod
+    def forward(ctx, z, div, mod, t):
+        _need_gpu(z)
+        z2 = _c(z.float())
+        loss, ws = lib().nt_xent_fwd(z2, div, mod, float(t))
+        ctx.meta = (div, mod, float(t))
+        ctx.save_for_backward(z2, ws)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        z2, ws = ctx.saved_tensors
+        div, mod, t = ctx.meta
+        return lib().nt_xent_bwd(z2, div, mod, t, ws, _c(dloss.float())), None, None, None
+
+
 class AggFunction(torch.autograd.Function):
     """mean / max / baco over dim 1 of rs[T,Nc,R]: mlhot_agg_fwd / _bwd.
     For baco, `rs` is mu and `lv` the pre-softplus variance logits; returns (r, sigma_z)."""

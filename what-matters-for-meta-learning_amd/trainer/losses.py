@@ -4,37 +4,24 @@ kernels (forward reduction + backward seed in one launch each).
 The functional-contrastive term (losses.py:82-99) is NT-Xent from the un-vendored dependency `pytorch_metric_learning`
 (listed without a version in the reference's requirements.txt:12; `NTXentLoss(temperature=t)` with its defaults: cosine
 similarity, every same-label pair a positive, every different-label pair a negative of its anchor, mean over the positive
-pairs).  `nt_xent` below restates that published algorithm on device tensors with torch operators - a few [2T x 2T] /
-[T*Nq x T*Nq] matrices, plumbing-sized work next to the encoders; autograd supplies its backward.
+pairs).  Its labels are always arange blocks, so the term runs as mlhot_nt_xent_fwd / _bwd (csrc/nt_xent.h: similarity on the
+matrix core, per-anchor log-sum-exp, hand-derived backward; 2 + 1 launches, nothing built on the host, capturable); embeddings
+outside the kernels' limits (N > 512 rows or d > 256 / d % 16 != 0) raise - there is no torch fallback on the product path.
 """
-import numpy as np
 import torch
-import torch.nn.functional as F
 
-from mlhot.ops import LossFunction
+from mlhot.binding import MlhotError
+from mlhot.ops import LossFunction, NTXentFunction
 
 
-def nt_xent(z, labels, t=0.07):
-    """NTXentLoss(temperature=t)(z, labels) of pytorch_metric_learning: for every positive pair (a, p)
-    -log( exp(s_ap / t) / (exp(s_ap / t) + sum over negatives n of a of exp(s_an / t)) ), cosine similarities s, the row
-    maximum subtracted before the exponentials, `finfo.tiny` added inside the log, averaged over the positive pairs.
-    `labels`: host integers (the reference builds them with torch.arange on the CPU), so the pair lists cost no device sync."""
-    lab = np.asarray(labels.cpu() if torch.is_tensor(labels) else labels).reshape(-1)
-    same = lab[:, None] == lab[None, :]
-    a1, p = np.nonzero(same & ~np.eye(len(lab), dtype=bool))
-    if len(a1) == 0 or same.all():
-        return z.sum() * 0.0
-    dev = z.device
-    a1_t, p_t = torch.from_numpy(a1).to(dev), torch.from_numpy(p).to(dev)
-    neg_mask = torch.from_numpy(~same[a1]).to(dev)                       # [P, N]: the negatives of each positive pair's anchor
-    zn = F.normalize(z, p=2, dim=1)
-    sim = zn @ zn.t()
-    pos = sim[a1_t, p_t].unsqueeze(1) / t
-    neg = (sim / t)[a1_t].masked_fill(~neg_mask, torch.finfo(z.dtype).min)
-    max_val = torch.max(pos, neg.max(dim=1, keepdim=True)[0]).detach()
-    num = torch.exp(pos - max_val).squeeze(1)
-    den = torch.exp(neg - max_val).sum(dim=1) + num
-    return (-torch.log(num / den + torch.finfo(z.dtype).tiny)).mean()
+def nt_xent(z, div, mod, t=0.07):
+    """NTXentLoss(temperature=t)(z, labels) of pytorch_metric_learning for labels(i) = (i // div) % mod: for every positive pair
+    (a, p)  -log( exp(s_ap / t) / (exp(s_ap / t) + sum over negatives n of a of exp(s_an / t)) ), cosine similarities s, the
+    maximum subtracted before the exponentials, `finfo.tiny` added inside the log, averaged over the positive pairs."""
+    N, d = z.shape
+    if N > 512 or d > 256 or d % 16:
+        raise MlhotError(f"nt_xent: [{N}, {d}] embeddings are outside the kernel's limits (N <= 512, d <= 256, d % 16 == 0)")
+    return NTXentFunction.apply(z, int(div), int(mod), float(t))
 
 
 class LossFunc:
@@ -70,13 +57,13 @@ class LossFunc:
 
     @staticmethod
     def contrastive_loss(z_1, z_2, t=0.07):
-        """Context-set vs target-set task embeddings [T, dim_z] each: embedding i of either set carries label i (losses.py:83-88)."""
-        z = torch.cat((z_1, z_2), dim=0)
-        labels = np.concatenate((np.arange(z_1.shape[0]), np.arange(z_2.shape[0])))
-        return nt_xent(z, labels, t)
+        """Context-set vs target-set task embeddings [T, dim_z] each: embedding i of either set carries label i (losses.py:83-88),
+        i.e. labels = [0..T-1, 0..T-1] = row % T."""
+        if z_1.shape[0] != z_2.shape[0]:
+            raise ValueError("contrastive_loss: both embedding sets hold one row per task")
+        return nt_xent(torch.cat((z_1, z_2), dim=0), 1, z_1.shape[0], t)
 
     @staticmethod
     def contrastive_loss_ANP(z, t=0.07):
-        """Per-target attention outputs [T, Nq, d]: the Nq embeddings of task i carry label i (losses.py:91-99)."""
-        labels = np.repeat(np.arange(z.shape[0]), z.shape[1])
-        return nt_xent(z.reshape(-1, z.shape[-1]), labels, t)
+        """Per-target attention outputs [T, Nq, d]: the Nq embeddings of task i carry label i (losses.py:91-99) = row // Nq."""
+        return nt_xent(z.reshape(-1, z.shape[-1]), z.shape[1], z.shape[0], t)
