@@ -691,6 +691,10 @@ def main():
             step()
         torch.cuda.synchronize()
         recs = L.prof_end()
+        if os.environ.get("MLHOT_BENCH_SEQ") and rank == 0:      # launch labels of ONE step, in launch order (scripts/pmc_by_label.py
+            per = len(recs) // args.prof_steps                   # folds a rocprofv3 --pmc dispatch list of eager steps onto them)
+            with open(os.environ["MLHOT_BENCH_SEQ"], "w") as f:
+                json.dump([lb for lb, _ in recs[:per]], f)
         agg = {}
         for label, ms in recs:
             a = agg.setdefault(label, [0, 0.0])
@@ -707,13 +711,14 @@ def main():
             sec_per_step = agg[dom][1] / args.prof_steps * 1e-3
             ach = per_step[dom] / sec_per_step / 1e12
             traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    tr = json.load(f)
-                if tr.get("_workload", "c3") == w["key"]:
-                    traffic = tr.get(dom, {}).get("hbm_bytes")
-            except (OSError, ValueError):
-                pass
+            for name in ("pmc_traffic.json", f"pmc_traffic_{w['key']}.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        tr = json.load(f)
+                    if tr.get("_workload", "c3") == w["key"] and tr.get(dom, {}).get("hbm_bytes"):
+                        traffic = tr[dom]["hbm_bytes"] / max(tr[dom].get("launches_per_step", 1), 1) if "launches_per_step" in tr[dom] else tr[dom]["hbm_bytes"]
+                except (OSError, ValueError):
+                    pass
             lps = kernels[dom]["launches_per_step"]
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_us": kernels[dom]["avg_us"],

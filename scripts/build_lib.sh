@@ -3,7 +3,7 @@
 # kernels whose mangled name contains $KFILTER (registers, spills, scratch).
 cd "$(dirname "$0")/../what-matters-for-meta-learning_amd/csrc" || exit 1
 out=${1:-libmlhot.so}; shift
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-comment -Wno-division-by-zero -Wno-pass-failed -Rpass-analysis=kernel-resource-usage "$@" mlhot.hip -o "$out" 2> /tmp/build_lib.log
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-comment -Wno-division-by-zero -Wno-pass-failed -mllvm -pragma-unroll-threshold=40000 -Rpass-analysis=kernel-resource-usage "$@" mlhot.hip -o "$out" 2> /tmp/build_lib.log
 rc=$?
 grep -E "error" -A6 /tmp/build_lib.log | head -40
 if [ -n "$KFILTER" ]; then

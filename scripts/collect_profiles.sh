@@ -5,7 +5,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 mkdir -p $OUT
 cd $REPO
 python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench_c3.json 2> $OUT/bench_c3.err
@@ -23,5 +23,16 @@ python bench.py --workload c5 --steps 30 --warmup 5 > $OUT/${TAG}_bench_c5.json 
 MLHOT_BENCH_KERNELS=$OUT/${TAG}_kernels_c5.json python bench.py --workload c5 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o stats -- python3 $REPO/bench.py --workload c5 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/stats_c5.log 2>&1
+# c5 counters per launch label (scripts/pmc_by_label.py folds the dispatch list onto the label sequence of one step)
+cd $REPO
+MLHOT_BENCH_SEQ=$OUT/seq_c5.json python bench.py --workload c5 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 2 > /dev/null 2>&1
+cd /tmp
+C5="python3 $REPO/bench.py --workload c5 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_c5 -o fetch -- $C5 > $OUT/pmc_fetch_c5.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_c5 -o write -- $C5 > $OUT/pmc_write_c5.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq_c5 -o sq -- $C5 > $OUT/pmc_sq_c5.log 2>&1
+cd $REPO
+python3 scripts/pmc_by_label.py $OUT/seq_c5.json $OUT/${TAG}_pmc_traffic_c5.json c5 $(find $OUT/pmc_fetch_c5 -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write_c5 -name "*counter_collection.csv" | head -1)
+python3 scripts/pmc_by_label.py $OUT/seq_c5.json $OUT/${TAG}_pmc_sq_c5.json c5 $(find $OUT/pmc_sq_c5 -name "*counter_collection.csv" | head -1)
 find $OUT -name "*.csv" | head -20
 ls -la $OUT

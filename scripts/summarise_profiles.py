@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 
 KERNEL_LABEL = {            # kernel-name fragment -> bench.py label
     "conv12_fwd_pool_kernel": "enc.conv12", "conv12_wgrad_kernel": "enc.bwd.conv12.wgrad", "conv12_dgrad_kernel": "enc.bwd.conv12.dgrad",
@@ -25,10 +25,13 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-for name in (f"{tag}_bench_c3.json", f"{tag}_bench_c2.json", f"{tag}_kernels_c3.json", f"{tag}_bench_c5.json", f"{tag}_kernels_c5.json"):
+for name in (f"{tag}_bench_c3.json", f"{tag}_bench_c2.json", f"{tag}_kernels_c3.json", f"{tag}_bench_c5.json", f"{tag}_kernels_c5.json",
+             f"{tag}_pmc_traffic_c5.json", f"{tag}_pmc_sq_c5.json"):
     p = os.path.join(SRC, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(DST, name))
+if os.path.exists(os.path.join(SRC, f"{tag}_pmc_traffic_c5.json")):
+    shutil.copy(os.path.join(SRC, f"{tag}_pmc_traffic_c5.json"), os.path.join(DST, "pmc_traffic_c5.json"))      # what bench.py --workload c5 reads
 stats = find("stats/**/*kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(DST, f"{tag}_kernel_stats.csv"))

@@ -1537,23 +1537,26 @@ def test_trainer_contrastive_model(gpulib, tmp_path, monkeypatch):
     assert all(torch.isfinite(v).all() for v in model.state_dict().values())
 
 
-def test_bench_two_rank_control_flow_on_one_gpu(gpulib):
-    """bench.py's N > 1 path (per-rank task shards, hipGraph step, flat gradient all-reduce outside the graph, max-over-ranks timing,
-    one JSON line from rank 0) driven by two gloo ranks sharing this box's only GPU - the RCCL launch itself needs an N-GPU node."""
+@pytest.mark.parametrize("workload,tasks", [("c3", 16), ("c5", 8)])
+def test_bench_two_rank_control_flow_on_one_gpu(gpulib, workload, tasks):
+    """bench.py's N > 1 path (per-rank task shards, hipGraph step, gradient all-reduce outside the graph - for c5 the same eps on
+    every rank and the side-stream bucket - max-over-ranks timing, one JSON line from rank 0) driven by two gloo ranks sharing this
+    box's only GPU - the RCCL launch itself needs an N-GPU node."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MLHOT_DIST_BACKEND="gloo", MLHOT_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+           "--master-port", "29533" if workload == "c3" else "29534", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "2", "--workload", workload]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak" and out["hipgraph"] is True
-    assert out["config"]["global_tasks"] == 32 and out["cpu_baseline"] is None
-    assert abs(out["value"] - 32 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
+    assert out["config"]["global_tasks"] == 2 * tasks and out["cpu_baseline"] is None
+    assert abs(out["value"] - 2 * tasks * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
 
 
 def _bucket_cuda_worker(rank, world, port, out):

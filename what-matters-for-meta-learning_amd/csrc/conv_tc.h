@@ -240,6 +240,22 @@ __device__ __forceinline__ float conv1a_pixel_fast(const Conv1Lane& cl, const Im
   return __builtin_fmaf(v, off >= 0 ? 1.f : 0.f, (ks == 2 && rowok) ? cl.k9 : 0.f);
 }
 
+// The same request cut in two for the forward's slot schedule: the load (2 VALU: offset, clamp) and - several k-steps later,
+// when the value has had time to arrive - the blend.  As ONE function hipcc put the blend's v_fma right behind the load with an
+// s_waitcnt vmcnt(0) in between: every one of the 9 pixel requests of a band stalled its wave for an L1 / L2 round trip inside
+// the MFMA loop (the k-steps are fenced for the scheduler, so the consumer could not sink by itself).
+__device__ __forceinline__ float conv1a_pixel_load(const Conv1Lane& cl, const ImgSrc& x, int tile, int j, int ks) {
+  const char* xi = reinterpret_cast<const char*>(x.img(tile >> 3));
+  const int off = cl.d[ks] + 4 * (768 * j + 2048 * (tile & 7));
+  return *reinterpret_cast<const float*>(xi + max(off, 0));
+}
+__device__ __forceinline__ float conv1a_pixel_blend(float v, const Conv1Lane& cl, int tile, int j, int ks, int row0) {
+  const int band = tile & 7;
+  const int off = cl.d[ks] + 4 * (768 * j + 2048 * band);
+  const bool rowok = band > 0 || row0 + 3 * j > 0;              // wave-uniform: the patch row is inside the image
+  return __builtin_fmaf(v, off >= 0 ? 1.f : 0.f, (ks == 2 && rowok) ? cl.k9 : 0.f);
+}
+
 __device__ __forceinline__ void conv1a_fetch_fast(Conv1A& ca, const Conv1Lane& cl, const ImgSrc& x, int tile, int wave) {
 #pragma unroll
   for (int j = 0; j < 3; ++j)
@@ -372,8 +388,8 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // 72 k-steps of 2 MFMAs.  Their A operands run through a register ring RD k-steps deep (left alone, hipcc reads each
     // pair right before its MFMAs and waits lgkmcnt(0) on it: conv2 loop in isolation 131 -> 142 TF, scripts/micro/conv2_loop).
-    // conv1 tile j of the next band rides along in fixed slots: pixels requested at k-steps 22j .. 22j+2, its 6 MFMAs one per
-    // k-step from 22j+8, ReLU / patch store / sign bits one accumulator register per k-step from 22j+15.  Every k-step is fenced for the scheduler, so each wave's VALU / LDS work sits in the shadow of its own MFMAs
+    // conv1 tile j of the next band rides along in fixed slots: pixels requested at k-steps 22j .. 22j+2, blended with their masks at
+    // 22j+5 .. 22j+7 (conv1a_pixel_load / _blend), its 6 MFMAs one per k-step from 22j+8, ReLU / patch store / sign bits one accumulator register per k-step from 22j+15.  Every k-step is fenced for the scheduler, so each wave's VALU / LDS work sits in the shadow of its own MFMAs
     // and no wave ever leaves the matrix pipe for a long stretch.
     constexpr int RD = 4;          // 6 measured 2 us slower
     // two base pointers (channel groups 0-3 | 4-7) keep every operand offset inside ds_read's 16-bit immediate
@@ -399,7 +415,8 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
       const int j = ks / 22, s = ks - 22 * j;          // j = 3 for ks >= 66: no slot
       if (j < 3) {
         const int tt = wave + 12 * j;
-        if (s < 3) ct.a[s] = conv1a_pixel_fast(cl, x, next, j, s, wave >> 2);
+        if (s < 3) ct.a[s] = conv1a_pixel_load(cl, x, next, j, s);                           // raw pixel: in flight for 5 k-steps
+        else if (s >= 5 && s < 8) ct.a[s - 5] = conv1a_pixel_blend(ct.a[s - 5], cl, next, j, s - 5, wave >> 2);
         else if (s >= 8 && s < 14) c1t_mfma(ct, cw, s - 8);
         else if (s >= 15 && s < 19) c1t_post<true>(ct, s - 15, c1t_dst(nb, tt, lr, lq), c1t_rec(m1, next, tt, n_img));
       }

@@ -111,8 +111,13 @@ inline int trunk_check(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk
   if (!trunk_supported(C, H)) { set_error("resnet trunk: no kernels for %d-channel %dx%d images", C, H, H); return MLHOT_ERR_UNSUPPORTED; }
   for (int p = 0; p < n_pass; ++p)
     if (ps[p].n_img < 1 || ps[p].wset < 0 || ps[p].wset >= n_wset || !ps[p].img) { set_error("resnet trunk: bad pass %d", p); return MLHOT_ERR_ARG; }
-  for (int w = 0; w < n_wset; ++w)
+  for (int w = 0; w < n_wset; ++w) {
     if (ws[w].skip_k != 1 && ws[w].skip_k != 3) { set_error("resnet trunk: skip kernel must be 1 or 3"); return MLHOT_ERR_ARG; }
+    bool used = false;
+    for (int p = 0; p < n_pass; ++p) used = used || ps[p].wset == w;
+    // a weight set without a pass would get no slab rows: its gradients would never be written (the caller would read whatever was in the buffers)
+    if (!used) { set_error("resnet trunk: weight set %d is not used by any pass", w); return MLHOT_ERR_ARG; }
+  }
   return MLHOT_OK;
 }
 

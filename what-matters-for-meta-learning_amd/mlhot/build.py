@@ -40,8 +40,11 @@ def build_product(force=False, verbose=False):
                     return PRODUCT_SO      # GPU box without a toolchain: use the prebuilt file that travelled
                 raise RuntimeError("mlhot: hipcc not found and no prebuilt libmlhot.so")
             tmp = f"{PRODUCT_SO}.{os.getpid()}.tmp"
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-comment",
-                   os.path.join(CSRC, "mlhot.hip"), "-o", tmp]
+            # -pragma-unroll-threshold: hipcc prices a `#pragma unroll` loop BEFORE it knows the induction variable, so the slot
+            # schedule of the conv12 forward (72 k-steps, every slot's slice counted 72 times) sits right at LLVM's default limit
+            # of 16 K; over it the loop is silently left rolled and the register arrays go to scratch
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-comment", "-mllvm",
+                   "-pragma-unroll-threshold=40000", os.path.join(CSRC, "mlhot.hip"), "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             try:

@@ -144,8 +144,10 @@ class StagedEps:
             k = self._job
             try:
                 if self._done[k] is not None:
-                    self._done[k].synchronize()    # the copy out of this pinned buffer two steps ago
+                    with torch.cuda.device(self.device):
+                        self._done[k].synchronize()    # the copy out of this pinned buffer two steps ago
                 self.draw_host(self._host[k])
+                self._state_after = torch.get_rng_state()      # stage() checks that nobody else drew in the meantime
             except BaseException as e:             # noqa: BLE001 - surfaced by the collecting stage()
                 self._worker_err = e
             self._ready.set()
@@ -207,6 +209,10 @@ class StagedEps:
             if self._worker_err is not None:
                 err, self._worker_err = self._worker_err, None
                 raise err
+            if not torch.equal(self._state_after, torch.get_rng_state()):
+                raise RuntimeError("StagedEps: the torch CPU generator was used between prefetch() and stage() (a loader, an init, CPU "
+                                   "dropout ...): the eps draw order of the reference is broken - draw without prefetch(), or keep other "
+                                   "consumers off the default generator while a prefetch is pending")
         else:
             if self._done[k] is not None:
                 self._done[k].synchronize()        # the copy out of this pinned buffer two steps ago
