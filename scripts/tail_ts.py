@@ -46,6 +46,10 @@ for base, name in ((0, "A.fwd"), (16, "A.fwd.keyhead"), (32, "B.fwd"), (64, "C.f
     print(name, "total %.1f us:" % ((seg[-1][1] - seg[0][1]) / 100.0),
           " ".join("%d:%.1f" % (i, (t - seg[k - 1][1]) / 100.0) for k, (i, t) in enumerate(seg) if k))
 
+rwts = ts.cpu()[300:321].tolist()
+if rwts[0]:
+    print("trunk conv3x3 (16x16 stride-1, workgroup 0) cycles from kernel entry: prologue done %d; per band [stage start, staged, MFMAs done, stored]:" % (rwts[1] - rwts[0]),
+          [[rwts[2 + 4 * k + i] - rwts[0] for i in range(4)] for k in range(4) if rwts[2 + 4 * k]], "exit", rwts[20] - rwts[0])
 blk = [(v[220 + i] - v[200 + i]) / 100.0 for i in range(16) if v[220 + i] > 0]
 if blk:
     print("A.bwd per block (us):", " ".join("%.1f" % x for x in blk))

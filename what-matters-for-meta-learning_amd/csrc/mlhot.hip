@@ -31,6 +31,7 @@ void set_error(const char* fmt, ...) {
 Options g_opt = {1, 1, 0, 0, 63};
 int g_favor2 = 1;
 
+
 #ifndef MLHOT_HOSTSIM
 // ---- per-launch event profiler -------------------------------------------------------------------
 bool g_prof_on = false;

@@ -23,6 +23,12 @@
 
 #ifndef MLHOT_HOSTSIM
 namespace mlhot {
+#ifdef MLHOT_TS
+namespace tf { extern __device__ long long* g_ts_dev; }
+#define RW_TS(slot) do { if (tf::g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0 && G::HIN == 16 && G::S == 1) tf::g_ts_dev[300 + (slot)] = clock64(); } while (0)
+#else
+#define RW_TS(slot) do {} while (0)
+#endif
 namespace rw {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -34,6 +40,16 @@ constexpr int WIMG = 4 * NKS * 64;     // floats of one lane-native 3x3 weight i
 constexpr int WIMG1 = 4 * 16 * 64;     // ... of a 1x1 weight image
 constexpr int MAX_JOBS = 6;
 constexpr int WG_SLOTS = 512;          // two 256-thread workgroups per CU
+#ifndef C3_RING
+#define C3_RING 2
+#endif
+// Measured and dropped (round 3, c5, one gpurun call each; the option switches are gone again):
+//   * fewer workgroups for launches with few bands (>= 2 / 3 / 4 / 6 bands each, to amortise the 147 KB weight image and the patch
+//     zeroing of every workgroup): strictly slower (c5 trunk sum 1413 -> 1525 / 1615 / 1839 / 2218 us) - the bands are latency-
+//     bound (staging 3.5-5 k cycles, 19.6 k of MFMAs, 21 k of epilogue under load) and more resident workgroups hide more of it;
+//   * starting the CU's second workgroup (LDS base != 0, or block index >= 256) 4-16 k cycles late so that one stages while the
+//     other computes: neutral to +3 % - the band timeline (scripts/dev/trunk_ts.py on a -DMLHOT_TS build) shows workgroup 0's
+//     MFMA phase already running at the full single-wave rate (34 cycles per MFMA), i.e. the two are out of phase by themselves.
 
 // ---- geometry of one 3x3, pad 1 convolution on square HIN x HIN maps -------------------------------------------
 // BPOS output positions per band; an M-tile = 16 positions = TR x TC block of the output map (or several whole images when an
@@ -190,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
   const FwdJob& jb = jobs.j[ji];
   const int co = 16 * nt + lr;
 
+  RW_TS(0);
   float wr[NKS];
   {
     const float* wp = jb.wimg + (size_t)nt * NKS * 64 + lane;
@@ -225,11 +242,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
   }
 
   const int nbands = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
+  RW_TS(1);
+  int ts_k = 0;
 #pragma unroll 1
   for (int band = (int)blockIdx.x - jb.wg0; band < nbands; band += jb.nwg) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
     const int oy0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
+    RW_TS(2 + 4 * ts_k);
     stage_patch<G>(patch, jb.x, img0, oy0, jb.n_img, tid);
+    RW_TS(3 + 4 * ts_k);
 
     // ---- 144 k-steps x NACC tiles ----
     f32x4_t acc[G::NACC], acc1[SKIP1 ? G::NACC : 1];
@@ -239,62 +260,101 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
 #pragma unroll
       for (int t = 0; t < G::NACC; ++t) acc1[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
+    // A operands through a register ring RD k-steps deep: the reads of k-step ks + RD are issued behind the MFMAs of k-step ks.
+    // Left to itself hipcc reads each operand right in front of its MFMA and waits lgkmcnt(0) on it - with 144 weight registers
+    // there is no room for anything else, and the SKIP1 instantiations funnelled EVERY operand through one register
+    // (`ds_read_b32 v16; s_waitcnt lgkmcnt(0); v_mfma ... v16` 576 times per band: the LDS round trip in front of every MFMA).
+    constexpr int RD = C3_RING;
+    auto aread = [&](int ks, int t) {
+      const int tap = ks / 16, cg = ks % 16;
+      return patch[aoff[t] + cg * 4 * G::PS + (tap / 3) * G::RS + tap % 3];
+    };
+    float xa[RD][G::NACC];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int d = 0; d < RD; ++d)
 #pragma unroll
-      for (int cg = 0; cg < 16; ++cg) {
-        const int off = cg * 4 * G::PS + (tap / 3) * G::RS + tap % 3;
-        float a[G::NACC];
+      for (int t = 0; t < G::NACC; ++t) xa[d][t] = aread(d, t);
 #pragma unroll
-        for (int t = 0; t < G::NACC; ++t) a[t] = patch[aoff[t] + off];
+    for (int ks = 0; ks < NKS; ++ks) {
+      float a[G::NACC];
 #pragma unroll
-        for (int t = 0; t < G::NACC; ++t) acc[t] = mfma4(a[t], wr[tap * 16 + cg], acc[t]);
-        if (SKIP1 && tap == 4 && has1) {
+      for (int t = 0; t < G::NACC; ++t) a[t] = xa[ks % RD][t];
 #pragma unroll
-          for (int t = 0; t < G::NACC; ++t) acc1[t] = mfma4(a[t], w1[cg], acc1[t]);
-        }
-        // unfenced, hipcc hoists the LDS operand reads of the whole band to the top and spills
-        if (cg % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < G::NACC; ++t) acc[t] = mfma4(a[t], wr[ks], acc[t]);
+      if (SKIP1 && ks / 16 == 4 && has1) {
+#pragma unroll
+        for (int t = 0; t < G::NACC; ++t) acc1[t] = mfma4(a[t], w1[ks % 16], acc1[t]);
       }
+      if (ks + RD < NKS) {
+#pragma unroll
+        for (int t = 0; t < G::NACC; ++t) xa[ks % RD][t] = aread(ks + RD, t);
+      }
+      __builtin_amdgcn_sched_barrier(0);       // pins the order; unfenced, hipcc hoists the reads of the whole band to the top and spills
     }
 
+    RW_TS(4 + 4 * ts_k);
     // ---- epilogue: lane holds rows 4lq..4lq+3 of every tile for channel co ----
+    // The four rows are contiguous in the NCHW plane in runs of VW (a tile row has TC >= 2 columns; 2x2 maps: a whole plane).
+    // Two passes: first every tile's output offset and - for the residual / mask epilogues - its `aux` load, ALL of them in
+    // flight together; then the arithmetic and the stores.  (One pass, tile by tile, hipcc waited for each tile's aux load
+    // before it issued the next: the band timeline of the 16x16 conv2 showed 23 k cycles of epilogue behind 19.6 k of MFMAs.)
+    constexpr int VW = G::PI < 16 ? 4 : (G::TC >= 4 ? 4 : 2);
+    constexpr int NV = 4 / VW;
+    typedef float vw_t __attribute__((ext_vector_type(VW)));
+    const bool need_aux = jb.epi == EPI_BIAS_RES_RELU || jb.epi == EPI_MASK;
+    size_t offs[G::NACC][NV];
+    bool live[G::NACC][NV];
+    vw_t ax[G::NACC][NV];
 #pragma unroll
     for (int t = 0; t < G::NACC; ++t) {
-      // the four rows are contiguous in the NCHW plane in runs of VW (a tile row has TC >= 2 columns; 2x2 maps: a whole plane)
-      constexpr int VW = G::PI < 16 ? 4 : (G::TC >= 4 ? 4 : 2);
 #pragma unroll
-      for (int v = 0; v < 4; v += VW) {
+      for (int vi = 0; vi < NV; ++vi) {
+        const int v = vi * VW;
         int il = 0, oy = 0, ox = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (lq == q) { il = G::tile_il(t, 4 * q + v); oy = G::tile_oy(t, 4 * q + v); ox = G::tile_ox(t, 4 * q + v); }
         const int img = img0 + il;
-        if (img >= jb.n_img) continue;
-        const size_t o = (((size_t)img * CH + co) * G::HO + oy0 + oy) * G::WO + ox;
-        float r[VW];
+        live[t][vi] = img < jb.n_img;
+        offs[t][vi] = (((size_t)(live[t][vi] ? img : 0) * CH + co) * G::HO + oy0 + oy) * G::WO + ox;
+#pragma unroll
+        for (int q = 0; q < VW; ++q) ax[t][vi][q] = 0.f;
+        if (need_aux && live[t][vi]) ax[t][vi] = *reinterpret_cast<const vw_t*>(jb.aux + offs[t][vi]);
+      }
+    }
+    RW_TS(16 + (ts_k > 0));
+#pragma unroll
+    for (int t = 0; t < G::NACC; ++t) {
+      if (t == 1) RW_TS(18 + (ts_k > 0));
+#pragma unroll
+      for (int vi = 0; vi < NV; ++vi) {
+        if (!live[t][vi]) continue;
+        const int v = vi * VW;
+        const size_t o = offs[t][vi];
+        vw_t r;
 #pragma unroll
         for (int q = 0; q < VW; ++q) r[q] = acc[t][v + q] + bn;
-        if (jb.epi == EPI_BIAS_RES_RELU || jb.epi == EPI_MASK) {
-          float ax[VW];
-          if (VW == 4) { const float4 u = *reinterpret_cast<const float4*>(jb.aux + o); ax[0] = u.x; ax[1] = u.y; ax[VW - 2] = u.z; ax[VW - 1] = u.w; }
-          else { const float2 u = *reinterpret_cast<const float2*>(jb.aux + o); ax[0] = u.x; ax[1] = u.y; }
+        if (need_aux) {
 #pragma unroll
-          for (int q = 0; q < VW; ++q) r[q] = jb.epi == EPI_MASK ? (ax[q] > 0.f ? r[q] : 0.f) : r[q] + ax[q];
+          for (int q = 0; q < VW; ++q) r[q] = jb.epi == EPI_MASK ? (ax[t][vi][q] > 0.f ? r[q] : 0.f) : r[q] + ax[t][vi][q];
         }
         if (jb.epi == EPI_BIAS_RELU || jb.epi == EPI_BIAS_RES_RELU) {
 #pragma unroll
           for (int q = 0; q < VW; ++q) r[q] = fmaxf(r[q], 0.f);
         }
-        if (VW == 4) *reinterpret_cast<float4*>(jb.y + o) = make_float4(r[0], r[1], r[VW - 2], r[VW - 1]);
-        else *reinterpret_cast<float2*>(jb.y + o) = make_float2(r[0], r[1]);
+        *reinterpret_cast<vw_t*>(jb.y + o) = r;
         if (has1) {
-          if (VW == 4) *reinterpret_cast<float4*>(jb.y1 + o) = make_float4(acc1[t][v] + bn1, acc1[t][v + 1] + bn1, acc1[t][v + VW - 2] + bn1, acc1[t][v + VW - 1] + bn1);
-          else *reinterpret_cast<float2*>(jb.y1 + o) = make_float2(acc1[t][v] + bn1, acc1[t][v + 1] + bn1);
+          vw_t r1;
+#pragma unroll
+          for (int q = 0; q < VW; ++q) r1[q] = acc1[t][v + q] + bn1;
+          *reinterpret_cast<vw_t*>(jb.y1 + o) = r1;
         }
       }
     }
+    RW_TS(5 + 4 * ts_k);
+    ts_k = ts_k < 3 ? ts_k + 1 : 3;
   }
+  RW_TS(20);
 }
 
 // Workgroup shares of the jobs of one launch: proportional to their band counts, at least one each, WG_SLOTS in all at most.
