@@ -24,8 +24,12 @@
 #ifndef MLHOT_HOSTSIM
 namespace mlhot {
 #ifdef MLHOT_TS
+#ifndef RW_TS_HIN
+#define RW_TS_HIN 16          // which conv3x3 geometry carries the band-timeline stamps (scripts/dev/trunk_ts.py)
+#define RW_TS_S 1
+#endif
 namespace tf { extern __device__ long long* g_ts_dev; }
-#define RW_TS(slot) do { if (tf::g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0 && G::HIN == 16 && G::S == 1) tf::g_ts_dev[300 + (slot)] = clock64(); } while (0)
+#define RW_TS(slot) do { if (tf::g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0 && G::HIN == RW_TS_HIN && G::S == RW_TS_S) tf::g_ts_dev[300 + (slot)] = clock64(); } while (0)
 #else
 #define RW_TS(slot) do {} while (0)
 #endif
