@@ -469,6 +469,22 @@ def measure_extras(w, device, loss_fn, batch, iters):
 
         out = {"fwd_only_ms": _time_graph(fwd, iters), "step_with_flat_adam_ms": _time_graph(step_adam, iters),
                "note": "hipGraph replays; informational, not the headline metric"}
+        # opt-in arithmetic, never the headline: conv2's forward on the bf16 matrix pipe over hi / mid / lo split fp32 operands
+        # (csrc/conv_split.h; the option is read when the graph is captured)
+        from mlhot import lib
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+
+        lib().set_option("conv2_split", 1)
+        try:
+            out["split_precision_conv2"] = {
+                "fwd_only_ms": _time_graph(fwd, iters), "step_ms": _time_graph(step, iters),
+                "arithmetic": "conv2 forward: v_mfma_f32_16x16x32_bf16 over 3-piece bf16 splits of fp32 operands, 6 of 9 piece "
+                              "products, fp32 accumulation; everything else fp32 as in `value`"}
+        finally:
+            lib().set_option("conv2_split", 0)
         # PCIe-inclusive view (the reference hands over HOST batches, model_trainer.py:63-70): pinned host -> device copy of
         # one batch's images + labels, NOT overlapped with compute; `value` above never includes it
         host = [t.detach().cpu().pin_memory() for t in (cx, qx, cy, qy)]

@@ -46,7 +46,9 @@ const char* mlhot_last_error(void);
  * fused per-task tail kernels where they apply, "tail_spec" = bit mask of the six tail phases that use the kernels specialised
  * for the shipped dimensions (csrc/tail_spec.h; default 63 = all, 0 = the run-time-shaped csrc/tail_fused.h); "favor2" = 1
  * (default) the two-launch FAVOR+ kernels, 0 the operator chain; "materialize_a1" = 1 additionally stores the conv1 output
- * (debug / tests; the fused conv1+conv2 kernels never need it).                                                          */
+ * (debug / tests; the fused conv1+conv2 kernels never need it); "conv2_split" = 1 (default 0) runs the vanilla encoder's conv1 +
+ * conv2 + pool forward with conv2 on the bf16 matrix pipe over exact hi / mid / lo splits of the fp32 operands (csrc/conv_split.h:
+ * same outputs' layout, same parity tolerances, 1.5 x the fp32 kernel; the benchmark's headline stays on the fp32 kernels).      */
 int mlhot_set_option(const char* name, int value);
 
 /* ---- bench-only: per-launch HIP-event timing ------------------------------------------------

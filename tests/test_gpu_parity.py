@@ -113,13 +113,16 @@ def _enc_params(seed=0):
     return {"encoder_w0." + k: torch.randn(*s, generator=g) * a for k, s, a in shapes}
 
 
-@pytest.fixture(params=[1, 0], ids=["conv2_tc", "conv2_igemm"])
+@pytest.fixture(params=[(1, 0), (0, 0), (1, 1)], ids=["conv2_tc", "conv2_igemm", "conv2_split"])
 def conv2_impl(gpulib, request):
-    """Both implementations of the conv2 rows: the weight-stationary kernels (csrc/conv_tc.h) and
-    the generic implicit-GEMM problems."""
-    gpulib.set_option("conv2_tc", request.param)
+    """The implementations of the conv2 rows: the weight-stationary fp32 kernels (csrc/conv_tc.h), the generic implicit-GEMM
+    problems, and the opt-in forward with conv2 on the bf16 pipe over hi / mid / lo split operands (csrc/conv_split.h: held to
+    the SAME tolerances as the fp32 kernels - the split is exact, the six kept piece products are as exact as an fp32 MFMA)."""
+    gpulib.set_option("conv2_tc", request.param[0])
+    gpulib.set_option("conv2_split", request.param[1])
     yield request.param
     gpulib.set_option("conv2_tc", 1)
+    gpulib.set_option("conv2_split", 0)
 
 
 @pytest.mark.parametrize("n0,n1", [(1, 0), (3, 2), (8, 9), (40, 0)])
@@ -141,7 +144,8 @@ def test_encoder_fwd_bwd_vs_oracle(gpulib, conv2_impl, n0, n1):
         assert U.rel_err(got, ref.grad) <= U.RTOL, k
 
 
-def test_encoder_full_size_gradients_with_pinned_routing(gpulib):
+@pytest.mark.parametrize("split", [0, 1], ids=["fp32", "split"])
+def test_encoder_full_size_gradients_with_pinned_routing(gpulib, split):
     """480 images (the c2/c3 batch).  ReLU / max-pool routing is discontinuous, so gradients are
     compared with the oracle evaluated under the KERNEL's routing decisions (see
     oracle.ref_cpu.vanilla_encoder_routed); the decisions themselves must match the oracle's except
@@ -154,10 +158,12 @@ def test_encoder_full_size_gradients_with_pinned_routing(gpulib):
     plist = [t.to(DEV) for t in p.values()]
     xd = x.to(DEV)
     gpulib.set_option("materialize_a1", 1)      # the fused conv1+conv2 kernels never store a1; keep it for this check
+    gpulib.set_option("conv2_split", split)
     try:
         f0, _, saved = gpulib.enc_vanilla_fwd(xd, None, plist, 64)
     finally:
         gpulib.set_option("materialize_a1", 0)
+        gpulib.set_option("conv2_split", 0)
     grads = gpulib.enc_vanilla_bwd(xd, None, plist, 64, df.to(DEV), torch.empty(0, 64, device=DEV), saved)
     a1, p2, am2, a3 = (t.cpu() for t in gpulib.enc_saved_views(saved, n))
     pr = {k: v.clone().requires_grad_() for k, v in p.items()}
@@ -354,6 +360,16 @@ def test_tail_with_sharp_attention_vs_oracle(gpulib, tail_impl, T, Nc, Nq):
 def test_model_baseline_configs_vs_reference(gpulib, tail_impl, name):
     """BASELINE.json configs[0..2] at their full sizes (T=4 5+5; T=16 15+15 CNP / ANP): every gradient at 1e-4."""
     _run_case(gpulib, name)
+
+
+@pytest.mark.parametrize("name", U.model_case_names("c"))
+def test_model_baseline_configs_with_split_precision_conv2(gpulib, name):
+    """The same cases, same tolerances, with the opt-in split-precision conv2 forward (csrc/conv_split.h) in the path."""
+    gpulib.set_option("conv2_split", 1)
+    try:
+        _run_case(gpulib, name)
+    finally:
+        gpulib.set_option("conv2_split", 0)
 
 
 @pytest.mark.parametrize("name", [n for n in U.resnet_case_names() if n != "r_anpmr_shapenet3d"])   # that one: test_anpmr_shapenet3d_vs_reference

@@ -14,6 +14,7 @@
 #include "problems.h"
 #include "favor.h"   // MLHOT_TRY
 #include "conv_tc.h"
+#include "conv_split.h"
 #include "conv3_tc.h"
 #include "enc_linear.h"
 #include "../../include/mlhot.h"
@@ -22,7 +23,7 @@ namespace mlhot {
 
 // Run-time switches (mlhot_set_option): which implementation of a hot-path row runs.  The
 // generic igemm problems are always available as the A/B reference of the specialised kernels.
-struct Options { int conv2_tc; int tail_fused; int materialize_a1; int dbg; int tail_spec; };
+struct Options { int conv2_tc; int tail_fused; int materialize_a1; int dbg; int tail_spec; int conv2_split; };
 extern Options g_opt;
 constexpr int C2_GRID = 256;   // one persistent workgroup per CU
 
@@ -99,7 +100,13 @@ inline int enc_forward(const float* img0, int n0, const float* img1, int n1, con
     // conv1 + conv2 + pool in one kernel: a1 is recomputed band by band in LDS and never stored
     if (g_opt.materialize_a1) MLHOT_TRY(run_foreach(Conv1Fwd<Src2>{x, p.w1, p.b1, sv.a1}, (size_t)n * 4096, s, "enc.conv1.debug"));
     const int grid = n * 8 < C2_GRID ? n * 8 : C2_GRID;
-    {
+    if (g_opt.conv2_split) {
+      // conv2 on the bf16 pipe with hi / mid / lo split operands (conv_split.h): same outputs' layout, opt-in
+      const int grid2 = n * 16 < C2_GRID ? n * 16 : C2_GRID;
+      ProfScope ps("enc.conv12.split", s);
+      hipLaunchKernelGGL(c2s::conv12_fwd_split_kernel, dim3(grid2), dim3(c2s::NT), 0, s, c2::ImgSrc{img0, n0, img1}, p.w1, p.b1,
+                         p.w2, p.b2, sv.p2, sv.am2, sv.m1, n);
+    } else {
       ProfScope ps("enc.conv12", s);
       hipLaunchKernelGGL(c2::conv12_fwd_pool_kernel, dim3(grid), dim3(c2::NT), 0, s, c2::ImgSrc{img0, n0, img1}, p.w1, p.b1,
                          p.w2, p.b2, sv.p2, sv.am2, sv.m1, n, g_opt.dbg);

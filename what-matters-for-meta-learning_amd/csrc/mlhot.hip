@@ -28,7 +28,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-Options g_opt = {1, 1, 0, 0, 63};
+Options g_opt = {1, 1, 0, 0, 63, 0};
 int g_favor2 = 1;
 
 
@@ -61,6 +61,7 @@ const char* mlhot_last_error(void) { return g_err; }
 // ---- run-time options -------------------------------------------------------------------------
 int mlhot_set_option(const char* name, int value) {
   if (!strcmp(name, "conv2_tc")) { g_opt.conv2_tc = value; return MLHOT_OK; }
+  if (!strcmp(name, "conv2_split")) { g_opt.conv2_split = value; return MLHOT_OK; }
   if (!strcmp(name, "tail_fused")) { g_opt.tail_fused = value; return MLHOT_OK; }
   if (!strcmp(name, "tail_spec")) { g_opt.tail_spec = value; return MLHOT_OK; }     // fused tail: bit mask of the phases that run the kernels specialised for the shipped dimensions (csrc/tail_spec.h; default 63 = all six) instead of the run-time-shaped ones
   if (!strcmp(name, "materialize_a1")) { g_opt.materialize_a1 = value; return MLHOT_OK; }

@@ -8,7 +8,7 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 PRODUCT_SO = os.path.join(CSRC, "libmlhot.so")
 SOURCES = ["mlhot.hip"]
 HEADERS = ["common.h", "foreach.h", "igemm.h", "problems.h", "ops_direct.h", "favor.h", "encoder.h", "np_vanilla.h",
-           "conv_tc.h", "conv3_tc.h", "enc_linear.h", "tail_fused.h", "tail_spec.h", "tail_cnp.h", "conv_rt.h", "ingest.h", "bbb_multi.h", "mt_normal.h", "nt_xent.h", "resnet_ws.h", "resnet_trunk.h", "linear_skinny.h", "favor2.h", os.path.join("..", "..", "include", "mlhot.h")]
+           "conv_tc.h", "conv_split.h", "conv3_tc.h", "enc_linear.h", "tail_fused.h", "tail_spec.h", "tail_cnp.h", "conv_rt.h", "ingest.h", "bbb_multi.h", "mt_normal.h", "nt_xent.h", "resnet_ws.h", "resnet_trunk.h", "linear_skinny.h", "favor2.h", os.path.join("..", "..", "include", "mlhot.h")]
 
 
 def _stale(out, deps):
