@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_split_kernel(const ImgSrc x, co
   const int row0 = wave >> 2;                  // patch rows of the wave's tiles: row0 and (w < 8) row0 + 3
 
   const int ntiles = n_img * 16;
-  int tile = blockIdx.x;
+  int tile = c2::first_tile<16>(blockIdx.x, gridDim.x);
   const int row1 = wave < 8 ? row0 + 3 : row0;
   float px[2][3], pn[2][3];                   // pixels of the band whose a1 this iteration computes | of the one after
   if (tile < ntiles) {

@@ -163,6 +163,20 @@ __device__ __forceinline__ void set_wave_prio(int pr) {
   else __builtin_amdgcn_s_setprio(2);
 }
 
+// First band of workgroup g in the persistent conv12 kernels; a workgroup then walks tile += gridDim.x.  Tile = image * BPI + band
+// (BPI bands per image).  With the full grid of 256 (one workgroup per CU, dispatched round-robin over the 8 XCDs: XCD = g % 8)
+// the plain start tile = g sends band b of EVERY image to XCD b % 8, so the rows two bands share (the halo image rows, the halo
+// pooled row of the data gradient, the other 3/4 of every 128-byte line of the byte-sized arg-max map) are fetched from HBM once
+// per XCD that touches them: 157 MB for an algorithmic 92 MB in the data gradient (profiles/r03_final_pmc_traffic.json).  Here
+// the 256 / BPI images of one sweep are dealt to the XCDs whole - all bands of an image run on the CUs of ONE XCD in the same
+// sweep and meet in its L2; 256 tiles per sweep either way, so the walk itself is unchanged.
+template <int BPI>
+__device__ __forceinline__ int first_tile(int g, int grid) {
+  if (grid != 256) return g;
+  const int x = g & 7, h = g >> 3;                         // XCD, slot on it (0..31)
+  return (8 * (h / BPI) + x) * BPI + h % BPI;              // image 8 (h / BPI) + x of the sweep, band h % BPI
+}
+
 struct ImgSrc {           // two-segment image batch (context | target), [n][1][128][128]
   const float* p0; int n0; const float* p1;
   __device__ __forceinline__ const float* img(int i) const { return i < n0 ? p0 + (size_t)i * 16384 : p1 + (size_t)(i - n0) * 16384; }
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   patch_zero_pad(patch2, tid);
   patch_zero_pad(patch2 + PATCH_FLOATS, tid);
   const int ntiles = n_img * 8;
-  int tile = blockIdx.x;
+  int tile = first_tile<8>(blockIdx.x, gridDim.x);
 #ifdef MLHOT_TS
   long long ts_c0 = clock64(), ts_w0 = wall_clock64();
 #endif
@@ -460,6 +474,13 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
 }
 
 // ---- weight + bias gradient of conv2 with the a1 patch recomputed from the image ------------------
+// Pooled cell e (< 1536 = 48 co x 2 pooled rows x 16 px) of a band -> (px, pooled row, co), two per thread.  A 32-lane half of
+// a wave is 8 px x 4 co: its four un-pooled stores into the dY tile ([pos][co], row stride DS = 50, a pooled px = 2 positions
+// = 100 = 4 mod 32 words apart) land on 8 x 4 = 32 different banks.  (px fastest over 16, then the row, then co - the order
+// of the global reads - put 4 lanes on every bank it touched: 2/3 of this kernel's bank-conflict cycles.)
+__device__ __forceinline__ int wg_px(int e) { return (e & 7) + ((e >> 2) & 8); }
+__device__ __forceinline__ int wg_pyl(int e) { return (e >> 6) & 1; }
+__device__ __forceinline__ int wg_co(int e) { return ((e >> 3) & 3) + 4 * (e >> 7); }
 __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const float* __restrict__ dp2, const float* __restrict__ p2,
                                                           const uint8_t* __restrict__ amax, float* __restrict__ slab_w,
@@ -489,12 +510,12 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
     const int img = t >> 3, band = t & 7;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int e = tid + j * NT, px = e & 15, pyl = (e >> 4) & 1, co = e >> 5;
+      const int e = tid + j * NT, px = wg_px(e), pyl = wg_pyl(e), co = wg_co(e);
       const size_t o = (((size_t)img * COUT + co) * 16 + 2 * band + pyl) * 16 + px;
       cdp[j] = dp2[o]; cp[j] = p2[o]; cam[j] = amax[o];
     }
   };
-  int tile = blockIdx.x;
+  int tile = first_tile<8>(blockIdx.x, gridDim.x);
   Conv1Lane cl;
   conv1lane_init(cl, wave, lr, lq);
   if (tile < ntiles) { if (cact) conv1a_fetch_fast(ca, cl, x, tile, wave); cells_fetch(tile); }
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int e = tid + j * NT, px = e & 15, pyl = (e >> 4) & 1, co = e >> 5;
+      const int e = tid + j * NT, px = wg_px(e), pyl = wg_pyl(e), co = wg_co(e);
       const float g = cp[j] > 0.f ? cdp[j] : 0.f;
       bsum[j] += g;
 #pragma unroll
@@ -572,13 +593,19 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
       }
     }
   }
+  // bias gradient: a channel's 32 cells sit in 16 lanes (bits 0-2, 5) of two waves (the pooled row); fixed-order fold
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     float v = bsum[j];
+    v += __shfl_xor(v, 32, 64);
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((lane & 31) == 0) slab_b[(size_t)blockIdx.x * (COUT * CIN * 9 + COUT) + ((tid + j * NT) >> 5)] = v;
+    for (int off = 4; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int e = tid + j * NT;
+    if ((lane & 39) == 0) lds[wg_pyl(e) * COUT + wg_co(e)] = v;
   }
+  __syncthreads();
+  if (tid < COUT) slab_b[(size_t)blockIdx.x * (COUT * CIN * 9 + COUT) + tid] = lds[tid] + lds[COUT + tid];
 }
 
 // ---- data gradient of conv2 + conv1 ReLU mask + conv1 weight/bias gradient ------------------------
@@ -720,7 +747,7 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
       }
     }
   };
-  int tile = blockIdx.x;
+  int tile = first_tile<8>(blockIdx.x, gridDim.x);
   __syncthreads();
   if (tile < ntiles) { cells_fetch(tile); cells_store(lds, lds + DYP_FLOATS); }
   if (tile + (int)gridDim.x < ntiles) cells_fetch(tile + gridDim.x);
