@@ -69,6 +69,14 @@ if raw[0][0]:
     for w, r in enumerate(raw):
         print("  wave %2d" % w, [x - t0 for x in r])
 
+# the same for the conv12 data-gradient kernel (8 waves)
+raw = ts.cpu()[448:496].view(8, 6).tolist()
+if raw[0][0]:
+    t0 = min(r[0] for r in raw)
+    print("conv12 dgrad per-wave band timeline [start, row 0 done, next band staged, row 1 done, barrier passed] (cycles):")
+    for w, r in enumerate(raw):
+        print("  wave %2d" % w, [x - t0 for x in r[:5]])
+
 # effective clock under back-to-back hipGraph replay (what bench.py times)
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())

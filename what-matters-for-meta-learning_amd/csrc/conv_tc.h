@@ -622,54 +622,84 @@ constexpr int NT2 = 512;
 constexpr int SRS = 132, STRIP_FLOATS = 17 * SRS;     // image strip rows 16b-1 .. 16b+15, col c <-> ix = c - 1
 constexpr int D12_BUF = DYP_FLOATS + STRIP_FLOATS;
 
-template <int PY>
-__device__ __forceinline__ void dgrad12_row(const float* dyp, const float* strip, const float (&wr)[9][12],
-                                            const unsigned* __restrict__ mrow, f32x4_t& z, int toff, int yl, int ci, int lr, int lq) {
-  const int yp = yl >> 1;
-  // xh stays a real loop and every 12-MFMA group is fenced for the scheduler: fully unrolled and
-  // unfenced, hipcc hoists all ~150 LDS operand reads of a row to the top (408 registers).
-#pragma unroll 1
-  for (int xh = 0; xh < 2; ++xh) {
-    // conv1 ReLU bits of the 8 positions this lane will hold (x0 .. x0+7, x0 = 32xh + 8lq): column group 2xh + lq/2,
-    // dwords 4 r' + 2 (ci / 16) + lq % 2 of its record, bit 16 e + ci % 16 for column offset 8 (lq % 2) + 4 e + r'
-    const unsigned* mrec = mrow + (2 * xh + (lq >> 1)) * M1_REC + 2 * (ci >> 4) + (lq & 1);
-    uint4 mb;
-    mb.x = mrec[0]; mb.y = mrec[4]; mb.z = mrec[8]; mb.w = mrec[12];
-    f32x4_t e = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
-    const float* base = dyp + lq * DPS + yp * DRS + 16 * xh + lr;
-    constexpr int NTY = PY ? 2 : 1;
+// One "row half" = 8 consecutive x of one a1 row and channel per lane (two 16 x 16 parity tiles, accumulators e | d), then the
+// conv1 weight-gradient MFMAs that consume them.  A wave's stream used to run half by half - operand reads, 36 / 72 conv MFMAs,
+// wait for the accumulators, 16 selects, 8 tap reads, 8 MFMAs - and a wave alone on its SIMD filled only 55-60 % of the matrix
+// pipe (stamps with the partner wave parked), the pair 70 %.  Now a half hands its accumulators on as PENDING: the masks and the
+// 8 weight-gradient MFMAs of half h run between the MFMA steps of half h + 1, whose chains they do not touch; only the last half
+// of a band is flushed on its own, in front of the band barrier.
+struct D12Pend {
+  f32x4_t e, d;      // d a1 before the ReLU mask: x = x0 + 2 r (e) and x0 + 2 r + 1 (d)
+  uint4 mb;          // conv1 ReLU bits of those positions
+  int tpoff;         // strip offset of the half's image taps (floats)
+};
+struct D12Lane { int ci, lr, lq, toff; float tmask, tconst; };      // tap column lr: image tap | ones (bias) | zero
+
+// mask register r of a pending half and feed both accumulators to the matrix core: Z += g^T T.
+// MFMA r of parity px has A = g[row 4lq+r][ci] (this lane's register) and needs
+// B[k = lq][n = tap lr] = T[position x' = 16xh + 4lq + r][tap] = strip[(2yl+ky)][2x + kx], x = 2x' + px.
+__device__ __forceinline__ void d12_pend_step(const D12Pend& p, int r, float t0, float t1, const D12Lane& ln, f32x4_t& z, f32x4_t& z2) {
+  const unsigned bit = (1u << (ln.ci & 15)) << (r >= 2 ? 16 : 0);
+  const unsigned me = (r & 1) ? p.mb.z : p.mb.x, md = (r & 1) ? p.mb.w : p.mb.y;
+  const float ge = (me & bit) ? p.e[r] : 0.f, gd = (md & bit) ? p.d[r] : 0.f;
+  z = mfma4(ge, __builtin_fmaf(t0, ln.tmask, ln.tconst), z);
+  z2 = mfma4(gd, __builtin_fmaf(t1, ln.tmask, ln.tconst), z2);
+}
+// (the taps are read unconditionally - tap columns lr > 8 have toff = 0 - and blended arithmetically: written as the select
+// `lr < 9 ? tp[..] : c`, hipcc wraps EACH read in an exec-masked branch with an s_waitcnt lgkmcnt(0) of its own - eight serial
+// LDS round trips, ~1 k cycles per half, during which the wave issues nothing)
+__device__ __forceinline__ void d12_pend_taps(const float* strip, const D12Pend& p, float (&t0)[4], float (&t1)[4]) {
+  const float* tp = strip + p.tpoff;
 #pragma unroll
-    for (int ty = 0; ty < NTY; ++ty) {
-      const int ky = PY ? (ty == 0 ? 0 : 2) : 1, doy = (PY && ty == 0) ? 1 : 0;
+  for (int r = 0; r < 4; ++r) { t0[r] = tp[4 * r]; t1[r] = tp[4 * r + 2]; }
+}
+__device__ __forceinline__ void d12_flush(const float* strip, const D12Pend& p, const D12Lane& ln, f32x4_t& z, f32x4_t& z2) {
+  float t0[4], t1[4];
+  d12_pend_taps(strip, p, t0, t1);
 #pragma unroll
-      for (int ks = 0; ks < 12; ++ks) e = mfma4(base[ks * 4 * DPS + doy * DRS], wr[ky * 3 + 1][ks], e);          // px = 0: kx = 1
-      __builtin_amdgcn_sched_barrier(0);
+  for (int r = 0; r < 4; ++r) d12_pend_step(p, r, t0[r], t1[r], ln, z, z2);
+}
+
+template <int PY, bool HAS_PREV>
+__device__ __forceinline__ void dgrad12_half(const float* dyp, const float* strip, const float (&wr)[9][12], const unsigned* __restrict__ mrow,
+                                             f32x4_t& z, f32x4_t& z2, int yl, int xh, const D12Lane& ln, const D12Pend& prev, D12Pend& out) {
+  const int lr = ln.lr, lq = ln.lq, yp = yl >> 1;
+  // conv1 ReLU bits of the 8 positions this lane will hold (x0 .. x0+7, x0 = 32xh + 8lq): column group 2xh + lq/2,
+  // dwords 4 r' + 2 (ci / 16) + lq % 2 of its record, bit 16 e + ci % 16 for column offset 8 (lq % 2) + 4 e + r'
+  const unsigned* mrec = mrow + (2 * xh + (lq >> 1)) * M1_REC + 2 * (ln.ci >> 4) + (lq & 1);
+  uint4 mb;
+  mb.x = mrec[0]; mb.y = mrec[4]; mb.z = mrec[8]; mb.w = mrec[12];
+  float t0[4], t1[4];
+  if (HAS_PREV) d12_pend_taps(strip, prev, t0, t1);
+  f32x4_t e = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+  const float* base = dyp + lq * DPS + yp * DRS + 16 * xh + lr;
+  // Step st = (tap row ty, k-step ks): TWO operand words (dY at the column and at its right neighbour, one ds_read2_b32) feed
+  // THREE MFMAs - px = 1 / kx = 0 on the neighbour, px = 0 / kx = 1 and px = 1 / kx = 2 on the column itself - issued d, e, d:
+  // the two accumulators alternate, so no MFMA waits out the 40-cycle latency of the one before it.  The operands run two steps
+  // ahead in a ring; every step is fenced for the scheduler (unfenced, hipcc hoists all reads of a half to its top - 408
+  // registers - or sinks each one to its use, behind an s_waitcnt lgkmcnt(0)).
+  constexpr int NS = PY ? 24 : 12, RING = 3;
+  float a0[RING], a1[RING];
+  auto opnd = [&](int st, int slot) {
+    const int ty = st / 12, ks = st % 12, doy = (PY && ty == 0) ? 1 : 0;
+    a0[slot] = base[ks * 4 * DPS + doy * DRS];
+    a1[slot] = base[ks * 4 * DPS + doy * DRS + 1];
+  };
 #pragma unroll
-      for (int tx = 0; tx < 2; ++tx) {
-        const int kx = tx == 0 ? 0 : 2, dox = tx == 0 ? 1 : 0;
+  for (int st = 0; st < RING - 1; ++st) opnd(st, st);
 #pragma unroll
-        for (int ks = 0; ks < 12; ++ks) d = mfma4(base[ks * 4 * DPS + doy * DRS + dox], wr[ky * 3 + kx][ks], d);   // px = 1
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // lane: channel ci, positions x = x0 + 2r + px.  Mask, then Z += g^T T on the matrix core:
-    // MFMA r of parity px has A = g[row 4lq+r][ci] (this lane's register) and needs
-    // B[k = lq][n = tap lr] = T[position x' = 16xh + 4lq + r][tap] = strip[(2yl+ky)][2x + kx], x = 2x' + px.
-    const unsigned lo = 1u << (ci & 15), hi = lo << 16;
-    e[0] = (mb.x & lo) ? e[0] : 0.f; d[0] = (mb.y & lo) ? d[0] : 0.f;
-    e[1] = (mb.z & lo) ? e[1] : 0.f; d[1] = (mb.w & lo) ? d[1] : 0.f;
-    e[2] = (mb.x & hi) ? e[2] : 0.f; d[2] = (mb.y & hi) ? d[2] : 0.f;
-    e[3] = (mb.z & hi) ? e[3] : 0.f; d[3] = (mb.w & hi) ? d[3] : 0.f;
-    const float* tp = strip + (2 * yl) * SRS + toff + 4 * (16 * xh + 4 * lq);      // + 4r + 2px below
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float t0 = lr < 9 ? tp[4 * r] : (lr == 9 ? 1.f : 0.f);
-      const float t1 = lr < 9 ? tp[4 * r + 2] : (lr == 9 ? 1.f : 0.f);
-      z = mfma4(e[r], t0, z);
-      z = mfma4(d[r], t1, z);
-    }
+  for (int st = 0; st < NS; ++st) {
+    if (st + RING - 1 < NS) opnd(st + RING - 1, (st + RING - 1) % RING);
+    __builtin_amdgcn_sched_barrier(0);
+    const int ty = st / 12, ks = st % 12, ky = PY ? (ty == 0 ? 0 : 2) : 1, sl = st % RING;
+    d = mfma4(a1[sl], wr[ky * 3 + 0][ks], d);
+    e = mfma4(a0[sl], wr[ky * 3 + 1][ks], e);
+    d = mfma4(a0[sl], wr[ky * 3 + 2][ks], d);
+    if (HAS_PREV && st >= 2 && st < 6) d12_pend_step(prev, st - 2, t0[st - 2], t1[st - 2], ln, z, z2);
     __builtin_amdgcn_sched_barrier(0);
   }
+  out.e = e; out.d = d; out.mb = mb;
+  out.tpoff = (2 * yl) * SRS + ln.toff + 4 * (16 * xh + 4 * lq);      // + 4r + 2px
 }
 
 __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const unsigned* __restrict__ m1,
@@ -691,7 +721,8 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
     for (int ks = 0; ks < 12; ++ks) wr[tap][ks] = w[((size_t)(4 * ks + lq) * CIN + ci) * 9 + tap];
   // this lane's tap (as B-operand column lr of the conv1 weight gradient): strip offset ky*SRS + kx
   const int toff = lr < 9 ? (lr / 3) * SRS + lr % 3 : 0;
-  f32x4_t z = {0.f, 0.f, 0.f, 0.f};          // Z[ci = 16nt + 4lq + r][tap lr], summed over this wave's positions
+  const D12Lane ln{ci, lr, lq, toff, lr < 9 ? 1.f : 0.f, lr == 9 ? 1.f : 0.f};
+  f32x4_t z = {0.f, 0.f, 0.f, 0.f}, z2 = z;  // Z[ci = 16nt + 4lq + r][tap lr], summed over this wave's positions (even | odd x: two chains)
 
   for (int bsel = 0; bsel < 2; ++bsel) {
     float* dypb = lds + bsel * D12_BUF;
@@ -758,19 +789,36 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
     const float* strip = dyp + DYP_FLOATS;
     const int img = tile >> 3, band = tile & 7;
     const unsigned* mrow = m1 + ((size_t)img * 64 + 8 * band + 2 * pg) * 64;
-    dgrad12_row<0>(dyp, strip, wr, mrow, z, toff, 2 * pg, ci, lr, lq);
-    // stage the next band into the idle buffers between the two rows; prefetch the one after it
+#ifdef MLHOT_TS
+    const bool tsb = tf::g_ts_dev && blockIdx.x == 0 && lane == 0 && (tile - first_tile<8>(0, gridDim.x)) / (int)gridDim.x == 6;   // 7th band of workgroup 0
+#define D12_STAMP(i) do { if (tsb) tf::g_ts_dev[448 + wave * 6 + (i)] = clock64(); } while (0)
+#else
+#define D12_STAMP(i) do { } while (0)
+#endif
+    D12_STAMP(0);
+    D12Pend pa, pb;
+    dgrad12_half<0, false>(dyp, strip, wr, mrow, z, z2, 2 * pg, 0, ln, pb, pa);
+    dgrad12_half<0, true>(dyp, strip, wr, mrow, z, z2, 2 * pg, 1, ln, pa, pb);
+    D12_STAMP(1);
+    // stage the next band into the idle buffers between the two rows; prefetch the one after it.  (The two waves of a SIMD
+    // staging at different points of the band - one here, one in the middle of the second row - measured 1 % better and was
+    // dropped for the pending-half pipeline; s_setprio 1 for the younger half of the waves: neutral.)
     const int next = tile + (int)gridDim.x;
     if (next < ntiles) {
       cells_store(lds + (cur ^ 1) * D12_BUF, lds + (cur ^ 1) * D12_BUF + DYP_FLOATS);
       if (next + (int)gridDim.x < ntiles) cells_fetch(next + gridDim.x);
     }
-    dgrad12_row<1>(dyp, strip, wr, mrow + 64, z, toff, 2 * pg + 1, ci, lr, lq);
+    D12_STAMP(2);
+    dgrad12_half<1, true>(dyp, strip, wr, mrow + 64, z, z2, 2 * pg + 1, 0, ln, pb, pa);
+    dgrad12_half<1, true>(dyp, strip, wr, mrow + 64, z, z2, 2 * pg + 1, 1, ln, pa, pb);
+    d12_flush(strip, pb, ln, z, z2);
+    D12_STAMP(3);
     __syncthreads();
+    D12_STAMP(4);
   }
   // conv1 gradient partials: fold the 4 row-group waves of each channel half, write [block][ci][16 tap columns]
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * lq + r) * 16 + lr] = z[r];
+  for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * lq + r) * 16 + lr] = z[r] + z2[r];
   __syncthreads();
   if (tid < 512) {
     const int c = tid >> 4, q = tid & 15, ntc = c >> 4, cl = c & 15;     // channel c, tap column q
