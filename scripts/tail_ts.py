@@ -77,6 +77,10 @@ if raw[0][0]:
     for w, r in enumerate(raw):
         print("  wave %2d" % w, [x - t0 for x in r[:5]])
 
+pro = ts.cpu()[502:507].tolist()
+if pro[0]:
+    print("prologues of workgroup 0 (cycles from kernel entry to the band loop): conv12 fwd %d, conv12 dgrad %d (its band loop: %d)" % (pro[1] - pro[0], pro[3] - pro[2], pro[4] - pro[3]))
+
 # effective clock under back-to-back hipGraph replay (what bench.py times)
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())

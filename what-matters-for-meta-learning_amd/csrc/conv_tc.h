@@ -352,6 +352,9 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   const int lr = lane & 15, lq = lane >> 4;
   const int n = nt * 16 + lr;
   const int phase = __builtin_amdgcn_readfirstlane(wave >> 2);
+#ifdef MLHOT_TS
+  if (tf::g_ts_dev && blockIdx.x == 0 && tid == 0) tf::g_ts_dev[502] = clock64();
+#endif
 
   conv2w_stage<NT>(patch2, w, tid);
   __syncthreads();
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   int tile = first_tile<8>(blockIdx.x, gridDim.x);
 #ifdef MLHOT_TS
   long long ts_c0 = clock64(), ts_w0 = wall_clock64();
+  if (tf::g_ts_dev && blockIdx.x == 0 && tid == 0) tf::g_ts_dev[503] = ts_c0;
 #endif
   if (tile < ntiles) {
     Conv1A ca;
@@ -713,6 +717,9 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
   const int lr = lane & 15, lq = lane >> 4;
   const int ci = 16 * nt + lr;
 
+#ifdef MLHOT_TS
+  if (tf::g_ts_dev && blockIdx.x == 0 && tid == 0) tf::g_ts_dev[504] = clock64();
+#endif
   // (staged through LDS like the forward's, these loads measured 1 us slower: along ci the gather is a 36-byte stride, ~5 lines per load)
   float wr[9][12];
 #pragma unroll
@@ -783,6 +790,9 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
   if (tile < ntiles) { cells_fetch(tile); cells_store(lds, lds + DYP_FLOATS); }
   if (tile + (int)gridDim.x < ntiles) cells_fetch(tile + gridDim.x);
   __syncthreads();
+#ifdef MLHOT_TS
+  if (tf::g_ts_dev && blockIdx.x == 0 && tid == 0) tf::g_ts_dev[505] = clock64();
+#endif
   int cur = 0;
   for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
     const float* dyp = lds + cur * D12_BUF;
@@ -816,6 +826,9 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
     __syncthreads();
     D12_STAMP(4);
   }
+#ifdef MLHOT_TS
+  if (tf::g_ts_dev && blockIdx.x == 0 && tid == 0) tf::g_ts_dev[506] = clock64();
+#endif
   // conv1 gradient partials: fold the 4 row-group waves of each channel half, write [block][ci][16 tap columns]
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * lq + r) * 16 + lr] = z[r] + z2[r];
