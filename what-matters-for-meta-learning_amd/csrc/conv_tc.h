@@ -637,15 +637,18 @@ struct D12Pend {
   uint4 mb;          // conv1 ReLU bits of those positions
   int tpoff;         // strip offset of the half's image taps (floats)
 };
-struct D12Lane { int ci, lr, lq, toff; float tmask, tconst; };      // tap column lr: image tap | ones (bias) | zero
+struct D12Lane { int ci, lr, lq, toff; float tmask, tconst; unsigned pos_lo, pos_hi; };      // tap column lr: image tap | ones (bias) | zero
 
 // mask register r of a pending half and feed both accumulators to the matrix core: Z += g^T T.
 // MFMA r of parity px has A = g[row 4lq+r][ci] (this lane's register) and needs
 // B[k = lq][n = tap lr] = T[position x' = 16xh + 4lq + r][tap] = strip[(2yl+ky)][2x + kx], x = 2x' + px.
 __device__ __forceinline__ void d12_pend_step(const D12Pend& p, int r, float t0, float t1, const D12Lane& ln, f32x4_t& z, f32x4_t& z2) {
-  const unsigned bit = (1u << (ln.ci & 15)) << (r >= 2 ? 16 : 0);
+  // bit (ci % 16) + 16 (r / 2) of the record dword, sign-extended to a 0 / ~0 word, ANDed onto the accumulator: v_bfe_i32 + v_and
+  // (and / compare / select is one vector instruction more per value, 32 per band: 145.2 -> 142.1 us)
+  const unsigned pos = r >= 2 ? ln.pos_hi : ln.pos_lo;
   const unsigned me = (r & 1) ? p.mb.z : p.mb.x, md = (r & 1) ? p.mb.w : p.mb.y;
-  const float ge = (me & bit) ? p.e[r] : 0.f, gd = (md & bit) ? p.d[r] : 0.f;
+  const float ge = __uint_as_float(__float_as_uint(p.e[r]) & (unsigned)__builtin_amdgcn_sbfe((int)me, pos, 1u));
+  const float gd = __uint_as_float(__float_as_uint(p.d[r]) & (unsigned)__builtin_amdgcn_sbfe((int)md, pos, 1u));
   z = mfma4(ge, __builtin_fmaf(t0, ln.tmask, ln.tconst), z);
   z2 = mfma4(gd, __builtin_fmaf(t1, ln.tmask, ln.tconst), z2);
 }
@@ -675,7 +678,8 @@ __device__ __forceinline__ void dgrad12_half(const float* dyp, const float* stri
   mb.x = mrec[0]; mb.y = mrec[4]; mb.z = mrec[8]; mb.w = mrec[12];
   float t0[4], t1[4];
   if (HAS_PREV) d12_pend_taps(strip, prev, t0, t1);
-  f32x4_t e = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t& e = out.e; f32x4_t& d = out.d;          // accumulate where the next half will look for them
+  e = f32x4_t{0.f, 0.f, 0.f, 0.f}; d = e;
   const float* base = dyp + lq * DPS + yp * DRS + 16 * xh + lr;
   // Step st = (tap row ty, k-step ks): TWO operand words (dY at the column and at its right neighbour, one ds_read2_b32) feed
   // THREE MFMAs - px = 1 / kx = 0 on the neighbour, px = 0 / kx = 1 and px = 1 / kx = 2 on the column itself - issued d, e, d:
@@ -702,7 +706,7 @@ __device__ __forceinline__ void dgrad12_half(const float* dyp, const float* stri
     if (HAS_PREV && st >= 2 && st < 6) d12_pend_step(prev, st - 2, t0[st - 2], t1[st - 2], ln, z, z2);
     __builtin_amdgcn_sched_barrier(0);
   }
-  out.e = e; out.d = d; out.mb = mb;
+  out.mb = mb;
   out.tpoff = (2 * yl) * SRS + ln.toff + 4 * (16 * xh + 4 * lq);      // + 4r + 2px
 }
 
@@ -728,7 +732,7 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
     for (int ks = 0; ks < 12; ++ks) wr[tap][ks] = w[((size_t)(4 * ks + lq) * CIN + ci) * 9 + tap];
   // this lane's tap (as B-operand column lr of the conv1 weight gradient): strip offset ky*SRS + kx
   const int toff = lr < 9 ? (lr / 3) * SRS + lr % 3 : 0;
-  const D12Lane ln{ci, lr, lq, toff, lr < 9 ? 1.f : 0.f, lr == 9 ? 1.f : 0.f};
+  const D12Lane ln{ci, lr, lq, toff, lr < 9 ? 1.f : 0.f, lr == 9 ? 1.f : 0.f, (unsigned)(ci & 15), (unsigned)(ci & 15) + 16u};
   f32x4_t z = {0.f, 0.f, 0.f, 0.f}, z2 = z;  // Z[ci = 16nt + 4lq + r][tap lr], summed over this wave's positions (even | odd x: two chains)
 
   for (int bsel = 0; bsel < 2; ++bsel) {
@@ -740,6 +744,10 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
   const int ntiles = n_img * 8;
   float cdp[5], cp[5]; unsigned cam[5];
   float4 sv[2];
+  // (Measured and dropped: cells dealt so that a thread's five requests differ by wave-uniform constants only - no division by
+  // 48 / modulo / 64-bit address per cell, ~60 vector instructions per band less - with plain loads +0.5 %, with raw buffer
+  // loads (scalar base + 32-bit lane offset, out-of-range lanes read 0, no branches, 16 registers less) +2 %: a buffer_load
+  // costs more issue time beside fp32 MFMAs than the address arithmetic it saves.)
   auto cells_fetch = [&](int t) {       // 48 co x 3 pooled rows x 16 px = 2304 cells, <= 5 per thread
     const int img = t >> 3, band = t & 7;
 #pragma unroll
