@@ -474,6 +474,9 @@ __global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[c][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // (An operand ring - the reads of step or group g + 1 in front of the MFMAs of g, fenced - as in conv3x3_kernel and
+    // wgrad_kernel made THIS kernel 8-13 % slower (78 -> 87 / 89 us on block 1): hipcc's own placement inside the 4-step fences
+    // below already overlaps the reads of one tile with the MFMAs of the other.)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int py = c >> 1, px = c & 1;
@@ -756,18 +759,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
     __syncthreads();
     if (band + jb.nz < nbands) fetch(band + jb.nz);
 
+    // operands of k-step ks + 1 (one dY word, nine / one x words) are read before the MFMAs of k-step ks, every step fenced:
+    // left alone, hipcc reads a step's ten operands right in front of its MFMAs and waits lgkmcnt(0) on them
+    {
+      float ar[2], br[2][NT];
+      auto rd = [&](int ks, int slot) {
+        ar[slot] = dyt[abase + G::pb(ks, 0) * G::DS];
+        const float* bp = xs + bbase + (TAP1 ? G::pb(ks, 0) : G::posoff(G::pb(ks, 0)));
 #pragma unroll
-    for (int ks = 0; ks < G::NKS_B; ++ks) {
-      const float a = dyt[abase + G::pb(ks, 0) * G::DS];
-      const float* bp = xs + bbase + (TAP1 ? G::pb(ks, 0) : G::posoff(G::pb(ks, 0)));
-      if (TAP1) {
-        acc[0] = mfma4(a, bp[0], acc[0]);
-      } else {
+        for (int t = 0; t < NT; ++t) br[slot][t] = TAP1 ? bp[0] : bp[(t / 3) * G::RS + t % 3];
+      };
+      rd(0, 0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = mfma4(a, bp[(t / 3) * G::RS + t % 3], acc[t]);
+      for (int ks = 0; ks < G::NKS_B; ++ks) {
+        if (ks + 1 < G::NKS_B) rd(ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float a = ar[ks & 1];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma4(a, br[ks & 1][t], acc[t]);
+        if (q == 0) accb = mfma4(a, 1.f, accb);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (q == 0) accb = mfma4(a, 1.f, accb);
-      if (ks % 2 == 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
   // ---- slab row z0 + z, MFMA-native: [q][w][tap][lane][4] ----
