@@ -305,6 +305,12 @@ __device__ __forceinline__ void c1t_mfma(Conv1Tile& t, const Conv1W& cw, int i) 
 // 0 of a band rewrites the record the band above writes, with the same bits)
 template <bool MASK>
 __device__ __forceinline__ void c1t_post(Conv1Tile& t, int r, float* d, unsigned* __restrict__ mrec) {
+  if (!MASK) {      // no sign bits wanted: ReLU in ONE instruction, v_max_i32 on the bit pattern (a negative float is a negative
+    // integer); compare + select is two, and fmaxf / v_med3_f32 come out as two as well (a canonicalising v_max in front)
+    d[r] = __int_as_float(max(__float_as_int(t.c0[r]), 0));
+    d[16 * PS + r] = __int_as_float(max(__float_as_int(t.c1[r]), 0));
+    return;
+  }
   const bool p0 = t.c0[r] > 0.f, p1 = t.c1[r] > 0.f;
   d[r] = p0 ? t.c0[r] : 0.f;
   d[16 * PS + r] = p1 ? t.c1[r] : 0.f;
