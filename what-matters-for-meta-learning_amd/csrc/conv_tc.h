@@ -353,7 +353,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
                                                              float* __restrict__ p2, uint8_t* __restrict__ amax,
                                                              unsigned* __restrict__ m1, int n_img, int dbg) {
   __shared__ float patch2[2 * PATCH_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: SGPR arithmetic and scalar branches for everything derived from it
   const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
   const int lr = lane & 15, lq = lane >> 4;
   const int n = nt * 16 + lr;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
   __shared__ float lds[PATCH_FLOATS + DYT_FLOATS];
   float* patch = lds;
   float* dyt = lds + PATCH_FLOATS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: SGPR arithmetic and scalar branches for everything derived from it
   const int mg = wave % 6, ph = wave / 6;
   const int lr = lane & 15, lq = lane >> 4;
   const bool cact = !(dbg & 1);
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
                                                            float* __restrict__ slab1, int n_img) {
   __shared__ float lds[2 * D12_BUF + 8 * 16 * 16];
   float* red = lds + 2 * D12_BUF;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: SGPR arithmetic and scalar branches for everything derived from it
   const int nt = wave & 1, pg = wave >> 1;
   const int lr = lane & 15, lq = lane >> 4;
   const int ci = 16 * nt + lr;
