@@ -39,7 +39,7 @@ constexpr int F_LDS = 2 * F_PATCH > COUT * F_WLD ? 2 * F_PATCH : COUT * F_WLD;
 __global__ __launch_bounds__(F_NT) void conv3_fwd_kernel(const float* __restrict__ p2, const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ a3, int n_img) {
   __shared__ float patch2[F_LDS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = wave & 3, mg = wave >> 2;
   const int lr = lane & 15, lq = lane >> 4;
   const int co = nt * 16 + lr;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
   __shared__ float lds[W_LDS];
   float* patch = lds;
   float* dyt = lds + W_PATCH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int job = wave % 6, ph = wave / 6, tg = job % 3, np = job / 3;
   const int lr = lane & 15, lq = lane >> 4;
 
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restri
                                                            float* __restrict__ dp2, int n_img) {
   __shared__ float patch2[2 * D_PATCH + CIN * D_OS];
   static_assert(2 * D_PATCH + CIN * D_OS >= COUT * F_WLD, "weight staging area");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // the [64][432] weight matrix through LDS with coalesced float4 loads (rows of 433 words); the waves' register slices are
   // stride-9 / stride-432 gathers of it - straight from global ~20 cache lines per load instruction, 16-64 of them per lane
   for (int i = tid; i < COUT * KW / 4; i += D_NT) {

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(NTH) void enc_linear_bwd_kernel(const Rows2 dfeat, 
   __shared__ float lds[LDS_FLOATS];
   float* s_dy = lds;                  // [RCH][DYS]
   float* s_a3 = lds + RCH * DYS;      // [RCH][AS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   const int i0 = blockIdx.x * 16;
   const int jt = wave & 3, rh = wave >> 2;            // weight-gradient tile (16 outputs j) and row half of the chunk

@@ -74,7 +74,7 @@ __device__ __forceinline__ const float* block_row(const Args& a, int t, int h, i
 template <int RT>
 __global__ __launch_bounds__(256) void f1_kernel(const Args a) {
   __shared__ float sm_v[256]; __shared__ int sm_r[256], sm_j[256];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int th = blockIdx.x, t = th / a.f.H, h = th % a.f.H, chunk = blockIdx.y;
   const int d = a.f.d, m = a.f.m, Nq = a.f.Nq, R = Nq + a.f.Nc, mp = a.w.mp;
   const int f0 = chunk * FCH + wv * 64;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void f1_kernel(const Args a) {
 __global__ __launch_bounds__(256) void f2_kernel(const Args a) {
   __shared__ float s_mx[MAXN], s_diag[2 * MAXN], s_S[MAXN * (MAXN + 1)], s_D[MAXN], red[4 * 4 * 64 * 4];
   __shared__ float s_g; __shared__ float sm_v[256]; __shared__ int sm_r[256], sm_j[256];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int th = blockIdx.x, t = th / a.f.H, h = th % a.f.H;
   const int d = a.f.d, m = a.f.m, Nq = a.f.Nq, Nc = a.f.Nc, H = a.f.H, mp = a.w.mp;
   // query row maxima from the partials
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void f2_kernel(const Args a) {
 // tau = 4 split + wave, + 16, ... of G_q / G_k and leaves its partial row sums.
 __global__ __launch_bounds__(256) void b1_kernel(const Args a) {
   __shared__ float s_S[MAXN * (MAXN + 1)], s_dS[MAXN * (MAXN + 1)], s_D[MAXN], s_w[MAXN], s_rq[4][MAXN], s_rk[4][MAXN], red[4 * 4 * 64 * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int th = blockIdx.x, t = th / a.f.H, h = th % a.f.H, sp = blockIdx.y;
   const int d = a.f.d, m = a.f.m, Nq = a.f.Nq, Nc = a.f.Nc, H = a.f.H, mp = a.w.mp;
   const int tq = (Nq + 15) / 16, tk = (Nc + 15) / 16;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void b2_kernel(const Args a) {
   __shared__ float s_gt;
   __shared__ float sm[256];
   __shared__ float red[4 * RT * 64 * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int th = blockIdx.x, t = th / a.f.H, h = th % a.f.H;
   const int d = a.f.d, m = a.f.m, Nq = a.f.Nq, Nc = a.f.Nc, H = a.f.H, mp = a.w.mp, R = Nq + Nc;
   const int e0 = blockIdx.y * 16;

@@ -46,7 +46,7 @@ __device__ __forceinline__ bool fold4(f32x4_t (&acc)[2], float* red, int tid) {
 __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw, const float* __restrict__ b,
                                                   float* __restrict__ y, int ldy, int M, int K, int N, int act) {
   __shared__ float red[4 * 2 * 64 * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 16;
   const int ra = m0 + lr, rb = m0 + 16 + lr, rn = n0 + lr;
   const float* xa = x + (size_t)(ra < M ? ra : 0) * ldx + 4 * lq;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ x, i
 __device__ __forceinline__ void dgrad_body(const float* __restrict__ dy, int lddy, const float* __restrict__ yv, int ldy, int act,
                                            const float* __restrict__ w, int ldw, float* __restrict__ dx, int lddx, int accumulate,
                                            int M, int Kin, int N, float* red, int bx, int by) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int m0 = bx * 32, c0 = by * 16;
   const int ra = m0 + lr, rb = m0 + 16 + lr, col = c0 + lr;
   const size_t oa = (size_t)(ra < M ? ra : 0), ob = (size_t)(rb < M ? rb : 0);
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void dgrad_kernel(const float* __restrict__ dy
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ dy, int lddy, const float* __restrict__ yv, int ldy, int act,
                                            const float* __restrict__ x, int ldx, float* __restrict__ dw, int lddw, float* __restrict__ db,
                                            int M, int K, int N, float* red, int bx, int by) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int n0 = bx * 16, k0 = by * 64;
   const int n = n0 + lr;
   const bool nin = n < N;

@@ -203,7 +203,7 @@ __device__ __forceinline__ void stage_patch(float* patch, const float* __restric
 template <class G, bool SKIP1>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
   __shared__ float patch[G::PATCH];
-  const int tid = threadIdx.x, lane = tid & 63, nt = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, nt = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
     constexpr int NV = 4 / VW;
     typedef float vw_t __attribute__((ext_vector_type(VW)));
     const bool need_aux = jb.epi == EPI_BIAS_RES_RELU || jb.epi == EPI_MASK;
-    size_t offs[G::NACC][NV];
+    unsigned offs[G::NACC][NV];      // element offsets into y / aux / y1 (maps stay far below 2^32 elements; 64-bit offsets cost a register more each - the kernel sits at the 256-register limit)
     bool live[G::NACC][NV];
     vw_t ax[G::NACC][NV];
 #pragma unroll
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
           if (lq == q) { il = G::tile_il(t, 4 * q + v); oy = G::tile_oy(t, 4 * q + v); ox = G::tile_ox(t, 4 * q + v); }
         const int img = img0 + il;
         live[t][vi] = img < jb.n_img;
-        offs[t][vi] = (((size_t)(live[t][vi] ? img : 0) * CH + co) * G::HO + oy0 + oy) * G::WO + ox;
+        offs[t][vi] = (((unsigned)(live[t][vi] ? img : 0) * CH + co) * G::HO + oy0 + oy) * G::WO + ox;
 #pragma unroll
         for (int q = 0; q < VW; ++q) ax[t][vi][q] = 0.f;
         if (need_aux && live[t][vi]) ax[t][vi] = *reinterpret_cast<const vw_t*>(jb.aux + offs[t][vi]);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
       for (int vi = 0; vi < NV; ++vi) {
         if (!live[t][vi]) continue;
         const int v = vi * VW;
-        const size_t o = offs[t][vi];
+        const unsigned o = offs[t][vi];
         vw_t r;
 #pragma unroll
         for (int q = 0; q < VW; ++q) r[q] = acc[t][v + q] + bn;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
   static_assert(G::KIND == 1 && (G::TC >= 4 || G::PI < 16), "epilogue needs 4 consecutive grid columns per lane (or whole 2x2 maps)");
   __shared__ float patch[G::PATCH * (SKIP1 ? 2 : 1)];
   float* patch1 = patch + G::PATCH;
-  const int tid = threadIdx.x, lane = tid & 63, nt = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, nt = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
   __shared__ float lds[G::LDS];
   float* xs = lds;
   float* dyt = lds + G::XS;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
@@ -875,7 +875,7 @@ constexpr int SK1_MAX = 4 * MAX_JOBS, SK1_PS = 66;      // 4 blocks x the passes
 struct Sk1Jobs { Sk1Job j[SK1_MAX]; int n; };
 __global__ __launch_bounds__(256) void skip1_wgrad_kernel(const Sk1Jobs jobs) {
   __shared__ float xs[CH * SK1_PS], ds[CH * SK1_PS];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
   const Sk1Job& jb = jobs.j[ji];
@@ -981,7 +981,7 @@ template <int C, int HIN>
 __global__ __launch_bounds__(256, 2) void stem_kernel(const StemJobs jobs) {
   typedef StemGeo<C, HIN> G;
   __shared__ float patch[G::PATCH];
-  const int tid = threadIdx.x, lane = tid & 63, nt = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, nt = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const StemWgJobs job
   __shared__ float lds[G::PATCH + HALF * DS];       // dy is staged in two halves of 128 positions (two workgroups per CU)
   float* patch = lds;
   float* dyt = lds + G::PATCH;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
