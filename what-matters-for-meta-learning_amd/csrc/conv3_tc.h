@@ -60,7 +60,9 @@ __global__ __launch_bounds__(F_NT) void conv3_fwd_kernel(const float* __restrict
   const float bn = bias[co];
   __syncthreads();
 
-  for (int i = tid; i < 2 * F_PATCH; i += F_NT) patch2[i] = 0.f;       // halo column 0 stays zero for good
+  // halo column 0 of every patch row stays zero for good; nothing else of the two patches is ever read unwritten (columns 1..16
+  // come from stash - zeros for the row above the image - and 17..23 / the plane's pad word are never read): 864 words, not 20.8 k
+  for (int i = tid; i < 2 * CIN * 9; i += F_NT) patch2[(i / (CIN * 9)) * F_PATCH + ((i / 9) % CIN) * F_PS + (i % 9) * F_RS] = 0.f;
   const int nunits = n_img * 2;
   // staging: 48 x 9 rows x 4 float4 = 1728 float4 per unit, up to 4 per thread
   float4 st[4];
