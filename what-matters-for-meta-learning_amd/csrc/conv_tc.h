@@ -36,8 +36,12 @@ constexpr int RS = 65, ROWS = 9, PS = ROWS * RS;          // 585
 constexpr int PATCH_FLOATS = CIN * PS;                     // 18720 floats = 74,880 B
 // dY tile for wgrad: [pos 128][cout], row stride 50 (8 positions apart = 16 banks apart)
 constexpr int DS = 50, DYT_FLOATS = 128 * DS;
-// dY patch for dgrad: [co 48][row 5][col 33] (col 32 / row 4 = halo), plane stride 176
-constexpr int DRS = 33, DPS = 176, DYP_FLOATS = COUT * DPS;
+// dY patch for dgrad: [row 5][col 33][co 48 + 2] (col 32 / row 4 = halo): the channel is the innermost index, so the twelve
+// k-steps of a tap (co = 4 ks + lq) and the right-hand neighbour column sit within 100 words of ONE lane base - immediate
+// offsets of a ds_read2_b32, no address arithmetic per step (as [co][row][col] planes of 176 words every step cost a v_add_u32 on
+// the port the fp32 MFMAs issue through: 63 per band and wave).  Position stride 50 = 18 mod 32: the 16 columns of a 32-lane
+// half land on the 16 even banks, lq = 1 on the odd ones.
+constexpr int DRS = 33, DCS = 50, DYP_FLOATS = 5 * DRS * DCS;
 
 __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -638,6 +642,12 @@ constexpr int D12_BUF = DYP_FLOATS + STRIP_FLOATS;
 // pipe (stamps with the partner wave parked), the pair 70 %.  Now a half hands its accumulators on as PENDING: the masks and the
 // 8 weight-gradient MFMAs of half h run between the MFMA steps of half h + 1, whose chains they do not touch; only the last half
 // of a band is flushed on its own, in front of the band barrier.
+// pooled cell e (< 2304 = 48 co x 3 pooled rows x 16 px) of a band: a 32-lane half is 8 px x 4 co, whose un-pooled stores into
+// the [position][co] patch (a pooled px = 2 positions = 100 = 4 mod 32 words apart) land on 32 different banks
+__device__ __forceinline__ int d12_px(int e) { return (e & 7) + ((e >> 2) & 8); }
+__device__ __forceinline__ int d12_pyl(int e) { return (e >> 6) % 3; }
+__device__ __forceinline__ int d12_co(int e) { return ((e >> 3) & 3) + 4 * ((e >> 6) / 3); }
+
 struct D12Pend {
   f32x4_t e, d;      // d a1 before the ReLU mask: x = x0 + 2 r (e) and x0 + 2 r + 1 (d)
   uint4 mb;          // conv1 ReLU bits of those positions
@@ -686,7 +696,7 @@ __device__ __forceinline__ void dgrad12_half(const float* dyp, const float* stri
   if (HAS_PREV) d12_pend_taps(strip, prev, t0, t1);
   f32x4_t& e = out.e; f32x4_t& d = out.d;          // accumulate where the next half will look for them
   e = f32x4_t{0.f, 0.f, 0.f, 0.f}; d = e;
-  const float* base = dyp + lq * DPS + yp * DRS + 16 * xh + lr;
+  const float* base = dyp + (yp * DRS + 16 * xh + lr) * DCS + lq;
   // Step st = (tap row ty, k-step ks): TWO operand words (dY at the column and at its right neighbour, one ds_read2_b32) feed
   // THREE MFMAs - px = 1 / kx = 0 on the neighbour, px = 0 / kx = 1 and px = 1 / kx = 2 on the column itself - issued d, e, d:
   // the two accumulators alternate, so no MFMA waits out the 40-cycle latency of the one before it.  The operands run two steps
@@ -696,8 +706,8 @@ __device__ __forceinline__ void dgrad12_half(const float* dyp, const float* stri
   float a0[RING], a1[RING];
   auto opnd = [&](int st, int slot) {
     const int ty = st / 12, ks = st % 12, doy = (PY && ty == 0) ? 1 : 0;
-    a0[slot] = base[ks * 4 * DPS + doy * DRS];
-    a1[slot] = base[ks * 4 * DPS + doy * DRS + 1];
+    a0[slot] = base[doy * DRS * DCS + 4 * ks];
+    a1[slot] = base[doy * DRS * DCS + 4 * ks + DCS];
   };
 #pragma unroll
   for (int st = 0; st < RING - 1; ++st) opnd(st, st);
@@ -744,7 +754,7 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
   for (int bsel = 0; bsel < 2; ++bsel) {
     float* dypb = lds + bsel * D12_BUF;
     float* stripb = dypb + DYP_FLOATS;
-    for (int i = tid; i < COUT * 5; i += NT2) dypb[(i / 5) * DPS + (i % 5) * DRS + 32] = 0.f;   // halo column
+    for (int i = tid; i < 5 * DCS; i += NT2) dypb[((i / DCS) * DRS + 32) * DCS + i % DCS] = 0.f;   // halo column
     for (int i = tid; i < 17; i += NT2) stripb[i * SRS] = 0.f;                                   // ix = -1 column
   }
   const int ntiles = n_img * 8;
@@ -758,7 +768,7 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
     const int img = t >> 3, band = t & 7;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const int e = tid + j * NT2, px = e & 15, pyl = (e >> 4) % 3, co = e / 48;
+      const int e = tid + j * NT2, px = d12_px(e), pyl = d12_pyl(e), co = d12_co(e);
       const int py = 2 * band + pyl;
       cdp[j] = 0.f; cp[j] = 0.f; cam[j] = 0;
       if (e < 2304 && py < 16) {
@@ -778,15 +788,15 @@ __global__ __launch_bounds__(NT2) void conv12_dgrad_kernel(const ImgSrc x, const
   auto cells_store = [&](float* dypb, float* stripb) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const int e = tid + j * NT2, px = e & 15, pyl = (e >> 4) % 3, co = e / 48;
+      const int e = tid + j * NT2, px = d12_px(e), pyl = d12_pyl(e), co = d12_co(e);
       if (e < 2304) {
         const float g = cp[j] > 0.f ? cdp[j] : 0.f;
-        float* d = dypb + co * DPS + (2 * pyl) * DRS + 2 * px;
+        float* d = dypb + ((2 * pyl) * DRS + 2 * px) * DCS + co;
         d[0] = cam[j] == 0u ? g : 0.f;
-        d[1] = cam[j] == 1u ? g : 0.f;
+        d[DCS] = cam[j] == 1u ? g : 0.f;
         if (pyl < 2) {
-          d[DRS] = cam[j] == 2u ? g : 0.f;
-          d[DRS + 1] = cam[j] == 3u ? g : 0.f;
+          d[DRS * DCS] = cam[j] == 2u ? g : 0.f;
+          d[DRS * DCS + DCS] = cam[j] == 3u ? g : 0.f;
         }
       }
     }
