@@ -323,6 +323,34 @@ __device__ __forceinline__ void c1t_post(Conv1Tile& t, int r, float* d, unsigned
     *reinterpret_cast<uint4*>(mrec + 4 * r) = make_uint4((unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32));
   }
 }
+// ---- the FORWARD's patch: [row 9][col 65][ci 32 + 2], the channel innermost ---------------------------------------------------
+// (the weight-gradient kernel keeps the [ci][row][col] planes above: its A operand runs over ci along the lanes.)  The forward's A
+// operand of k-step (tap, ci) is a1[ci][row + ky][2 x + kx]: with the channel innermost, every operand of a band sits at
+// lane base + a compile-time byte offset below 64 KB - ds_read's immediate - where the [ci] planes of 585 words needed a fresh
+// VGPR base per k-step (hipcc paired the two rows' reads into ds_read2_b32, 8-bit offsets: 40 v_add_u32 per band and wave on the
+// port the fp32 MFMAs issue through).  One ds_read_b64 brings the operands of TWO consecutive k-steps (ci = 8 m + 2 lq + {0, 1}:
+// the weights' registers are ordered to match).  Position stride 34 words: the 16 lanes of a tile sit 68 = 4 (mod 64) words apart
+// and lq adds 2, so a 32-lane half of a ds_read_b64 covers all 64 banks once; conv1's stores (lane = channel, 4 lq columns
+// = 136 = 8 mod 32 words apart) stay 2-way, which costs a ds_write_b32 nothing.
+constexpr int CS = 34, CROW = RS * CS, CPATCH = ROWS * CROW;       // 19,890 floats = 79,560 B; two of them: 159,120 B
+static_assert(2 * CPATCH * 4 <= 160 * 1024, "LDS");
+__device__ __forceinline__ float* c1t_dst_cl(float* patch, int t, int lr, int lq) {
+  return patch + ((t >> 2) * RS + 1 + 16 * (t & 3) + 4 * lq) * CS + lr;
+}
+template <bool MASK>
+__device__ __forceinline__ void c1t_post_cl(Conv1Tile& t, int r, float* d, unsigned* __restrict__ mrec) {
+  const bool p0 = t.c0[r] > 0.f, p1 = t.c1[r] > 0.f;
+  d[r * CS] = p0 ? t.c0[r] : 0.f;
+  d[r * CS + 16] = p1 ? t.c1[r] : 0.f;
+  if (MASK) {
+    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(p0), b1 = __builtin_amdgcn_ballot_w64(p1);
+    *reinterpret_cast<uint4*>(mrec + 4 * r) = make_uint4((unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32));
+  }
+}
+__device__ __forceinline__ void patch_zero_pad_cl(float* patch, int tid) {      // column 0 (ix = -1) of every row
+  for (int i = tid; i < ROWS * CS; i += NT) patch[(i / CS) * CROW + i % CS] = 0.f;
+}
+
 __device__ __forceinline__ float* c1t_dst(float* patch, int t, int lr, int lq) {
   return patch + lr * PS + (t >> 2) * RS + 1 + 16 * (t & 3) + 4 * lq;
 }
@@ -330,7 +358,7 @@ __device__ __forceinline__ unsigned* c1t_rec(unsigned* __restrict__ m1, int tile
   return m1 + m1_record(tile >> 3, 8 * (tile & 7) - 1 + (tt >> 2), tt & 3, n_img);
 }
 // M-tile j of this wave, start to end (prologue of the forward; the weight-gradient kernel)
-template <bool MASK>
+template <bool MASK, bool CL = false>       // CL: into the forward's channel-innermost patch
 __device__ __forceinline__ void conv1_tile(const Conv1A& ca, const Conv1W& cw, int j, float* patch, int tile, int wave, int lane,
                                            unsigned* __restrict__ m1, int n_img) {
   const int lr = lane & 15, lq = lane >> 4, tt = wave + 12 * j;
@@ -339,10 +367,12 @@ __device__ __forceinline__ void conv1_tile(const Conv1A& ca, const Conv1W& cw, i
   for (int ks = 0; ks < 3; ++ks) t.a[ks] = ca.a[j][ks];
 #pragma unroll
   for (int i = 0; i < 6; ++i) c1t_mfma(t, cw, i);
-  float* d = c1t_dst(patch, tt, lr, lq);
+  float* d = CL ? c1t_dst_cl(patch, tt, lr, lq) : c1t_dst(patch, tt, lr, lq);
   unsigned* mrec = MASK ? c1t_rec(m1, tile, tt, n_img) : nullptr;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) c1t_post<MASK>(t, r, d, mrec);
+  for (int r = 0; r < 4; ++r) {
+    if (CL) c1t_post_cl<MASK>(t, r, d, mrec); else c1t_post<MASK>(t, r, d, mrec);
+  }
 }
 
 // cache line li (< 76, clamped) of the 19-row image strip under band `tile`: rows 16 band - 3 .. 16 band + 15, 4 lines per row
@@ -356,7 +386,8 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ p2, uint8_t* __restrict__ amax,
                                                              unsigned* __restrict__ m1, int n_img, int dbg) {
-  __shared__ float patch2[2 * PATCH_FLOATS];
+  __shared__ __attribute__((aligned(16))) float patch2[2 * CPATCH];
+  static_assert(COUT * W2_LD <= 2 * CPATCH, "weight staging area");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: SGPR arithmetic and scalar branches for everything derived from it
   const int nt = wave % 3, pg = wave / 3, rp = pg >> 1, ch = pg & 1;
   const int lr = lane & 15, lq = lane >> 4;
@@ -370,7 +401,7 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   __syncthreads();
   float wr[72];
 #pragma unroll
-  for (int ks = 0; ks < 72; ++ks) wr[ks] = patch2[n * W2_LD + ((ks & 7) * 4 + lq) * 9 + (ks >> 3)];
+  for (int ks = 0; ks < 72; ++ks) wr[ks] = patch2[n * W2_LD + (8 * ((ks & 7) >> 1) + 2 * lq + (ks & 1)) * 9 + (ks >> 3)];      // k-step ks = (tap, pair m, j): ci = 8 m + 2 lq + j
   const float bn = bias[n];
   __syncthreads();
   Conv1W cw;
@@ -378,8 +409,8 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   Conv1Lane cl;
   conv1lane_init(cl, wave, lr, lq);
 
-  patch_zero_pad(patch2, tid);
-  patch_zero_pad(patch2 + PATCH_FLOATS, tid);
+  patch_zero_pad_cl(patch2, tid);
+  patch_zero_pad_cl(patch2 + CPATCH, tid);
   const int ntiles = n_img * 8;
   int tile = first_tile<8>(blockIdx.x, gridDim.x);
 #ifdef MLHOT_TS
@@ -390,10 +421,10 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     Conv1A ca;
     conv1a_fetch(ca, x, tile, wave, lr, lq);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) conv1_tile<true>(ca, cw, j, patch2, tile, wave, lane, m1, n_img);
+    for (int j = 0; j < 3; ++j) conv1_tile<true, true>(ca, cw, j, patch2, tile, wave, lane, m1, n_img);
   }
   __syncthreads();
-  const int aoff = lq * PS + (4 * rp) * RS + 2 * (16 * ch + lr);
+  const int aoff = ((4 * rp) * RS + 2 * (16 * ch + lr)) * CS + 2 * lq;
   int cur = 0;
   // The pixels of a conv1 tile are asked for ~1.5 k cycles before its MFMAs: enough for an L1 / L2 hit, not for HBM (the
   // 8 bands of an image run on 8 workgroups at the same time, so the first touch of a strip is a miss for all of them:
@@ -402,8 +433,8 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
   float warm = 0.f;
   if (wave < 2 && tile + (int)gridDim.x < ntiles) warm = strip_line(x, tile + (int)gridDim.x, tid);
   for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
-    const float* ab = patch2 + cur * PATCH_FLOATS + aoff;
-    float* nb = patch2 + (cur ^ 1) * PATCH_FLOATS;
+    const float* ab = patch2 + cur * CPATCH + aoff;
+    float* nb = patch2 + (cur ^ 1) * CPATCH;
     // the next band's a1 slice (3 M-tiles per wave) is produced under this band's MFMAs.  The workgroup's last band
     // produces its own slice once more instead of branching around the slices (same values to the same sign-bit
     // records, an LDS buffer nobody reads): the band body stays one straight line.
@@ -419,16 +450,17 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
     // conv1 tile j of the next band rides along in fixed slots: pixels requested at k-steps 22j .. 22j+2, blended with their masks at
     // 22j+5 .. 22j+7 (conv1a_pixel_load / _blend), its 6 MFMAs one per k-step from 22j+8, ReLU / patch store / sign bits one accumulator register per k-step from 22j+15.  Every k-step is fenced for the scheduler, so each wave's VALU / LDS work sits in the shadow of its own MFMAs
     // and no wave ever leaves the matrix pipe for a long stretch.
-    constexpr int RD = 4;          // 6 measured 2 us slower
-    // two base pointers (channel groups 0-3 | 4-7) keep every operand offset inside ds_read's 16-bit immediate
-    const float* ab4 = ab + 16 * PS;
-    auto aread = [&](int ks, int row2) {
-      const int tap = ks >> 3, ky = tap / 3, kx = tap % 3, cg = ks & 7;
-      return (cg < 4 ? ab : ab4)[(cg & 3) * 4 * PS + (ky + row2) * RS + kx];
+    // operand pair p = (tap, m) = k-steps 2 p and 2 p + 1, for the tile's two conv2 rows (patch rows ky and ky + 2): one
+    // ds_read_b64 each, offset = a compile-time constant; a ring RDP pairs (= 2 RDP k-steps) deep
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    constexpr int RDP = 2;
+    auto aread = [&](int p, int row2) {
+      const int tap = p >> 2, ky = tap / 3, kx = tap % 3, m = p & 3;
+      return *reinterpret_cast<const f32x2_t*>(ab + (ky + row2) * CROW + kx * CS + 8 * m);
     };
-    float xa0[RD], xa1[RD];
+    f32x2_t xa0[RDP], xa1[RDP];
 #pragma unroll
-    for (int d = 0; d < RD; ++d) { xa0[d] = aread(d, 0); xa1[d] = aread(d, 2); }
+    for (int d = 0; d < RDP; ++d) { xa0[d] = aread(d, 0); xa1[d] = aread(d, 2); }
     Conv1Tile ct;
     float bnw = bn;
 #pragma unroll
@@ -437,16 +469,16 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
       // wins the matrix pipe, finishes its band ~25 % early and idles at the barrier while the youngest runs the tail alone
       // (three turns per band measured best: 153 / 155 / 152 / 151 us for none / every 4 / 8 / 24 k-steps)
       if (ks % 24 == 0) set_wave_prio((phase + ks / 24) % 3);
-      acc0 = mfma4(xa0[ks % RD], wr[ks], acc0);
-      acc1 = mfma4(xa1[ks % RD], wr[ks], acc1);
-      if (ks + RD < 72) { xa0[ks % RD] = aread(ks + RD, 0); xa1[ks % RD] = aread(ks + RD, 2); }
+      acc0 = mfma4(xa0[(ks >> 1) % RDP][ks & 1], wr[ks], acc0);
+      acc1 = mfma4(xa1[(ks >> 1) % RDP][ks & 1], wr[ks], acc1);
+      if ((ks & 1) && (ks >> 1) + RDP < 36) { xa0[(ks >> 1) % RDP] = aread((ks >> 1) + RDP, 0); xa1[(ks >> 1) % RDP] = aread((ks >> 1) + RDP, 2); }
       const int j = ks / 22, s = ks - 22 * j;          // j = 3 for ks >= 66: no slot
       if (j < 3) {
         const int tt = wave + 12 * j;
         if (s < 3) ct.a[s] = conv1a_pixel_load(cl, x, next, j, s);                           // raw pixel: in flight for 5 k-steps
         else if (s >= 5 && s < 8) ct.a[s - 5] = conv1a_pixel_blend(ct.a[s - 5], cl, next, j, s - 5, wave >> 2);
         else if (s >= 8 && s < 14) c1t_mfma(ct, cw, s - 8);
-        else if (s >= 15 && s < 19) c1t_post<true>(ct, s - 15, c1t_dst(nb, tt, lr, lq), c1t_rec(m1, next, tt, n_img));
+        else if (s >= 15 && s < 19) c1t_post_cl<true>(ct, s - 15, c1t_dst_cl(nb, tt, lr, lq), c1t_rec(m1, next, tt, n_img));
       }
       // the warmed line has to be consumed somewhere or the load is dead code: it rides into the epilogue's bias as + 0 * pixel,
       // at the k-step where the wait for it costs nothing (inline asm would do, but see m1_record's note on AGPRs)
