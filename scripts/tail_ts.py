@@ -77,6 +77,10 @@ if raw[0][0]:
     for w, r in enumerate(raw):
         print("  wave %2d" % w, [x - t0 for x in r[:5]])
 
+c3t = ts.cpu()[340:353].tolist()
+if c3t[0]:
+    print("conv3 fwd, workgroup 0 (cycles from entry): weights in registers %d, first unit staged %d, units [MFMAs + store done, barrier passed]:" % (c3t[1] - c3t[0], c3t[2] - c3t[0]),
+          [[c3t[3 + 2 * k] - c3t[0], c3t[4 + 2 * k] - c3t[0]] for k in range(4) if c3t[3 + 2 * k]], "exit", c3t[12] - c3t[0])
 pro = ts.cpu()[502:507].tolist()
 if pro[0]:
     print("prologues of workgroup 0 (cycles from kernel entry to the band loop): conv12 fwd %d, conv12 dgrad %d (its band loop: %d)" % (pro[1] - pro[0], pro[3] - pro[2], pro[4] - pro[3]))

@@ -53,11 +53,23 @@ __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) {
 constexpr int W2_LD = CIN * 9 + 1;
 template <int NTHREADS>
 __device__ __forceinline__ void conv2w_stage(float* stage, const float* __restrict__ w, int tid) {
-  for (int i = tid; i < COUT * CIN * 9 / 4; i += NTHREADS) {
-    const float4 v = *reinterpret_cast<const float4*>(w + 4 * i);
-    const int r = (4 * i) / (CIN * 9), c = 4 * i - r * (CIN * 9);        // 288 % 4 == 0: a float4 stays inside its row
-    float* d = stage + r * W2_LD + c;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  // ALL of a thread's loads first, then the stores: as one load -> store loop (run-time trip count, not unrolled) every iteration
+  // waited out an L2 round trip - the same loop over conv3's 110 KB was 9 k of that kernel's 54 k cycles
+  constexpr int N4 = COUT * CIN * 9 / 4, CNT = (N4 + NTHREADS - 1) / NTHREADS;
+  float4 v[CNT];
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int i = tid + j * NTHREADS;
+    v[j] = i < N4 ? *reinterpret_cast<const float4*>(w + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int i = tid + j * NTHREADS;
+    if (i < N4) {
+      const int r = (4 * i) / (CIN * 9), c = 4 * i - r * (CIN * 9);        // 288 % 4 == 0: a float4 stays inside its row
+      float* d = stage + r * W2_LD + c;
+      d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+    }
   }
 }
 
