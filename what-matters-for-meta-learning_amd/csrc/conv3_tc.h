@@ -332,7 +332,7 @@ constexpr int D_NT = 768;
 
 template <int PY, int PX>
 __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const float* __restrict__ dy3, float* __restrict__ dp2,
-                                            float* patch2, int n_img, int nt, int tid, int lane) {
+                                            float* patch2, int n_img, int nt, int tid, int lane, float4 (&sd)[2]) {
   constexpr int NTY = PY ? 2 : 1, NTX = PX ? 2 : 1, T = NTY * NTX;
   float* outt = patch2 + 2 * D_PATCH;
   const int lr = lane & 15, lq = lane >> 4;
@@ -349,7 +349,6 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
   __syncthreads();                                                   // every wave has its weights: the staging area becomes the patch
   for (int i = tid; i < 2 * D_PATCH; i += D_NT) patch2[i] = 0.f;      // halo row 8 / columns 8.. stay zero
   __syncthreads();
-  float4 sd[2];
   auto fetch = [&](int img) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -366,7 +365,7 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
     }
   };
   int img = blockIdx.x;
-  if (img < n_img) { fetch(img); stash(patch2); }
+  if (img < n_img) stash(patch2);                    // fetched by the kernel, under the weight staging
   if (img + (int)gridDim.x < n_img) fetch(img + gridDim.x);
   __syncthreads();
   const int aoff = lq * D_PS + (lr >> 3) * D_RS + (lr & 7);
@@ -425,15 +424,22 @@ __global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // the [64][432] weight matrix through LDS with coalesced float4 loads (rows of 433 words); the waves' register slices are
   // stride-9 / stride-432 gathers of it - straight from global ~20 cache lines per load instruction, 16-64 of them per lane
+  float4 sd[2];                                      // the first image's dY: its HBM round trip runs under the weight staging
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + j * D_NT;
+    sd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < 1024 && (int)blockIdx.x < n_img) sd[j] = *reinterpret_cast<const float4*>(dy3 + (size_t)blockIdx.x * 4096 + 4 * e);
+  }
   conv3w_stage<D_NT>(patch2, w, tid);
   __syncthreads();
   // per image a class costs 64 MFMAs per tap and tile: 256 / 128 / 128 / 64.  Waves w, w + 4, w + 8 share a SIMD:
   // SIMDs 0..2 get {256, 128, 64} (classes 11, 01, 00 of tile w), SIMD 3 gets the three 128s of class 10.
   const int s = wave & 3, g = wave >> 2;
-  if (s == 3) dgrad_class<1, 0>(w, dy3, dp2, patch2, n_img, g, tid, lane);
-  else if (g == 0) dgrad_class<1, 1>(w, dy3, dp2, patch2, n_img, s, tid, lane);
-  else if (g == 1) dgrad_class<0, 1>(w, dy3, dp2, patch2, n_img, s, tid, lane);
-  else dgrad_class<0, 0>(w, dy3, dp2, patch2, n_img, s, tid, lane);
+  if (s == 3) dgrad_class<1, 0>(w, dy3, dp2, patch2, n_img, g, tid, lane, sd);
+  else if (g == 0) dgrad_class<1, 1>(w, dy3, dp2, patch2, n_img, s, tid, lane, sd);
+  else if (g == 1) dgrad_class<0, 1>(w, dy3, dp2, patch2, n_img, s, tid, lane, sd);
+  else dgrad_class<0, 0>(w, dy3, dp2, patch2, n_img, s, tid, lane, sd);
 }
 
 }  // namespace c3
