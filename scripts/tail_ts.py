@@ -77,6 +77,12 @@ if raw[0][0]:
     for w, r in enumerate(raw):
         print("  wave %2d" % w, [x - t0 for x in r[:5]])
 
+raw = ts.cpu()[360:420].view(12, 5).tolist()
+if raw[0][0]:
+    t0 = min(r[0] for r in raw)
+    print("conv12 wgrad per-wave band timeline [previous band's MFMAs done, barrier passed, conv1 + dY staged, barrier passed, MFMAs done] (cycles):")
+    for w, r in enumerate(raw):
+        print("  wave %2d" % w, [x - t0 for x in r])
 c3t = ts.cpu()[340:353].tolist()
 if c3t[0]:
     print("conv3 fwd, workgroup 0 (cycles from entry): weights in registers %d, first unit staged %d, units [MFMAs + store done, barrier passed]:" % (c3t[1] - c3t[0], c3t[2] - c3t[0]),

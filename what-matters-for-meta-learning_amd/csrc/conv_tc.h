@@ -586,7 +586,15 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
   const int boff = (8 * lq) * DS + lr;
 
   for (; tile < ntiles; tile += gridDim.x) {
+#ifdef MLHOT_TS
+    const bool tsb = tf::g_ts_dev && blockIdx.x == 0 && lane == 0 && (tile - first_tile<8>(0, gridDim.x)) / (int)gridDim.x == 6;
+#define WG_STAMP(i) do { if (tsb) tf::g_ts_dev[360 + wave * 5 + (i)] = clock64(); } while (0)
+#else
+#define WG_STAMP(i) do { } while (0)
+#endif
+    WG_STAMP(0);
     __syncthreads();
+    WG_STAMP(1);
     if (cact) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) conv1_tile<false>(ca, cw, j, patch, tile, wave, lane, nullptr, n_img);
@@ -600,7 +608,9 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
       for (int q = 0; q < 4; ++q)
         dyt[((2 * pyl + (q >> 1)) * 32 + 2 * px + (q & 1)) * DS + co] = (cam[j] == (unsigned)q) ? g : 0.f;
     }
+    WG_STAMP(2);
     __syncthreads();
+    WG_STAMP(3);
     if (tile + (int)gridDim.x < ntiles) { if (cact) conv1a_fetch_fast(ca, cl, x, tile + gridDim.x, wave); cells_fetch(tile + gridDim.x); }
 
     // 16 k-steps of 9 MFMAs (an explicit operand ring and the forward's priority rotation were measured here: 152.1 us as is,
@@ -620,6 +630,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
     }
+    WG_STAMP(4);
   }
 
   // fold the two position halves through LDS (the patch is free now): one slab per workgroup
@@ -665,6 +676,13 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_kernel(const ImgSrc x, const 
   __syncthreads();
   if (tid < COUT) slab_b[(size_t)blockIdx.x * (COUT * CIN * 9 + COUT) + tid] = lds[tid] + lds[COUT + tid];
 }
+
+// (Measured and removed: the same kernel pipelined - units of HALF a band (2 conv2 rows, 5 a1 rows, one pooled dY row), patch + dY
+// tile double buffered in 109 KB, the next unit's conv1 tiles and dY cell produced in slots between this unit's MFMAs, one barrier
+// per unit.  Stamps of the kernel above had shown 4.1 k of a band's 20.5 k cycles in the staging phase with the matrix pipe all
+// but idle.  Result: 136.3 -> 141.0 us.  The staging phase is not idle time that MFMAs could fill: its conv1 MFMAs, selects,
+// LDS stores and loads issue through the same port as the main MFMAs (the issue-bound model of DESIGN.md section 4), so moving
+// them under the MFMAs moves nothing - and half bands recompute the halo row twice and pay twice the barriers.)
 
 // ---- data gradient of conv2 + conv1 ReLU mask + conv1 weight/bias gradient ------------------------
 // 512 threads (8 waves, 2 per SIMD): wave w owns input channels 16*(w&1)..+15 and the band's a1 rows
