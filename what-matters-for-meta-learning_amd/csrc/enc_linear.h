@@ -40,25 +40,29 @@ __global__ __launch_bounds__(NTH) void enc_linear_bwd_kernel(const Rows2 dfeat, 
   for (int ks = 0; ks < 16; ++ks) wr[ks] = wl[(size_t)(4 * ks + lq) * KIN + i0 + lr];
   f32x4_t wacc = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
+  // the chunk's operands: dY (float4 along the 64 columns: 8 per thread) and the a3 slice (2 per thread), rows >= nr zeroed.  The
+  // loads of chunk c + 1 are issued before the MFMAs of chunk c (they used to follow them: an HBM round trip per chunk in the open)
+  float4 vy[8], va[2];
+  auto fetch = [&](int r0) {
+    const int nr = n - r0 < RCH ? n - r0 : RCH;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * NTH, row = e >> 4, c4 = e & 15;
+      vy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < RCH * 16 && row < nr) vy[u] = *reinterpret_cast<const float4*>(dfeat.row(r0 + row) + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * NTH, row = e >> 2, c4 = e & 3;
+      va[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < RCH * 4 && row < nr) va[u] = *reinterpret_cast<const float4*>(a3 + (size_t)(r0 + row) * KIN + i0 + 4 * c4);
+    }
+  };
+  if (n > 0) fetch(0);
   for (int r0 = 0; r0 < n; r0 += RCH) {
     const int nr = n - r0 < RCH ? n - r0 : RCH;
     __syncthreads();
-    // stage dY (float4 along the 64 columns: 8 per thread) and the a3 slice (2 per thread): all 10 loads are issued
-    // before the first LDS store; rows >= nr are zeroed
     {
-      float4 vy[8], va[2];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = tid + u * NTH, row = e >> 4, c4 = e & 15;
-        vy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < RCH * 16 && row < nr) vy[u] = *reinterpret_cast<const float4*>(dfeat.row(r0 + row) + 4 * c4);
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = tid + u * NTH, row = e >> 2, c4 = e & 3;
-        va[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < RCH * 4 && row < nr) va[u] = *reinterpret_cast<const float4*>(a3 + (size_t)(r0 + row) * KIN + i0 + 4 * c4);
-      }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int e = tid + u * NTH, row = e >> 4, c4 = e & 15;
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(NTH) void enc_linear_bwd_kernel(const Rows2 dfeat, 
       }
     }
     __syncthreads();
+    if (r0 + RCH < n) fetch(r0 + RCH);
     // weight gradient: dW[j][i] += sum_row dY[row][j] a3[row][i]; A lane (m = j, k = row), B lane (k = row, n = i)
     {
       const float* ap = s_dy + (rh * (RCH / 2) + lq) * DYS + 16 * jt + lr;
@@ -81,8 +86,17 @@ __global__ __launch_bounds__(NTH) void enc_linear_bwd_kernel(const Rows2 dfeat, 
 #pragma unroll 6
       for (int ks = 0; ks < RCH / 8; ++ks) wacc = mfma4(ap[4 * ks * DYS], bp[4 * ks * AS], wacc);
     }
-    if (blockIdx.x == 0 && tid < DW) {               // bias gradient: column sums of dY (one workgroup is enough)
-      for (int row = 0; row < nr; ++row) bsum += s_dy[row * DYS + tid];
+    if (blockIdx.x == 0) {
+      // bias gradient: column sums of dY (one workgroup is enough) - over ALL eight waves, rows part, part + 8, ...: as one
+      // wave walking the chunk row by row (a rolled loop: LDS read, wait, add - 480 times for the 480-image batch) workgroup 0
+      // finished ~10 us after the other 255 and set the kernel's duration
+      const int col = tid & 63, part = tid >> 6;
+      float s0 = 0.f, s1 = 0.f;
+      for (int row = part; row < nr; row += 16) {
+        s0 += s_dy[row * DYS + col];
+        if (row + 8 < nr) s1 += s_dy[(row + 8) * DYS + col];
+      }
+      bsum += s0 + s1;
     }
     // data gradient: 16-row tiles over the waves; A lane (m = row, k = j), B = wr; masked by a3 > 0
     for (int mt = wave; mt * 16 < nr; mt += 8) {
@@ -111,7 +125,17 @@ __global__ __launch_bounds__(NTH) void enc_linear_bwd_kernel(const Rows2 dfeat, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) dwl[(size_t)(16 * jt + 4 * lq + r) * KIN + i0 + lr] = wacc[r] + lds[(jt * 4 + r) * 64 + lane];
   }
-  if (blockIdx.x == 0 && tid < DW) dbl[tid] = bsum;
+  if (blockIdx.x == 0) {                             // fold the eight waves' partial column sums in a fixed order
+    __syncthreads();
+    lds[tid] = bsum;
+    __syncthreads();
+    if (tid < DW) {
+      float v = lds[tid];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v += lds[k * 64 + tid];
+      dbl[tid] = v;
+    }
+  }
 }
 
 }  // namespace el
