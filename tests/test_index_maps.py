@@ -1,0 +1,99 @@
+"""Index arithmetic of the persistent conv kernels, restated in numpy (no GPU): the XCD-aware band walk and the LDS bank maps of
+the channel-innermost patches (csrc/conv_tc.h `first_tile`, `DCS`, `CS`; csrc/conv3_tc.h `F_CS`).  The kernels carry the same
+facts as comments / static_asserts; these tests pin the numbers the comments quote."""
+import numpy as np
+import pytest
+
+
+def first_tile(g, grid, bpi):
+    """csrc/conv_tc.h first_tile<BPI>: first band of workgroup g; a workgroup then walks tile += grid."""
+    if grid != 256:
+        return g
+    x, h = g & 7, g >> 3
+    return (8 * (h // bpi) + x) * bpi + h % bpi
+
+
+@pytest.mark.parametrize("bpi", [8, 16])
+def test_band_walk_is_a_bijection_and_keeps_an_image_on_one_xcd(bpi):
+    starts = np.array([first_tile(g, 256, bpi) for g in range(256)])
+    assert sorted(starts.tolist()) == list(range(256))                 # one sweep covers 256 consecutive tiles exactly once
+    for n_img in (32, 40, 480):
+        seen = {}
+        for g in range(256):
+            t = first_tile(g, 256, bpi)
+            while t < n_img * bpi:
+                assert t not in seen
+                seen[t] = g
+                t += 256
+        assert len(seen) == n_img * bpi                                # every band of every image is some workgroup's
+        for img in range(n_img):
+            xcds = {seen[img * bpi + b] & 7 for b in range(bpi)}       # workgroup g runs on XCD g % 8 (round-robin dispatch)
+            assert len(xcds) == 1
+    for grid in (8, 24, 255):                                          # small batches: the plain walk
+        assert [first_tile(g, grid, bpi) for g in range(grid)] == list(range(grid))
+
+
+def _groups_b128():
+    """lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS table)"""
+    base = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    return [[lane + 32 * half for lane in g] for half in (0, 1) for g in base]
+
+
+def test_dgrad_dy_patch_reads_are_conflict_free():
+    # conv12 data gradient, [row][col][co 48 + 2]: lane (lr = column, lq = co % 4) reads word (col * 50 + lq); a ds_read2_b32 is
+    # two b32 reads, each serviced in two 32-lane halves over 32 banks
+    dcs = 50
+    for half in (0, 1):
+        banks = [((lane & 15) * dcs + (lane >> 4)) % 32 for lane in range(32 * half, 32 * half + 32)]
+        assert len(set(banks)) == 32
+    # the pooled cells' un-pooled stores: a 32-lane half = 8 px x 4 co, a pooled px = 2 positions = 100 words
+    banks = [((2 * (lane & 7)) * dcs + ((lane >> 3) & 3)) % 32 for lane in range(32)]
+    assert len(set(banks)) == 32
+
+
+def test_forward_patch_b64_reads_cover_the_64_banks_once():
+    # conv12 forward, [row][col][ci 32 + 2]: lane (lr, lq) reads the two words at (2 lr) * 34 + 2 lq (stride-2 convolution)
+    cs = 34
+    for half in (0, 1):
+        words = []
+        for lane in range(32 * half, 32 * half + 32):
+            w = 2 * (lane & 15) * cs + 2 * (lane >> 4)
+            words += [w % 64, (w + 1) % 64]
+        assert len(set(words)) == 64
+    assert 2 * 9 * 65 * cs * 4 <= 160 * 1024                           # two patches fit the CU's LDS
+
+
+def test_conv3_forward_patch_b128_reads_are_conflict_free():
+    # conv3 forward, [row 9][col 24][ci 48 + 4]: lane (lr = (oy & 1) * 8 + ox, lq) reads 4 words at the position's base + 4 lq
+    rs, cs = 24, 52
+    for grp in _groups_b128():
+        words = []
+        for lane in grp:
+            lr, lq = lane & 15, lane >> 4
+            w = ((2 * (lr >> 3)) * rs + 2 * (lr & 7)) * cs + 4 * lq
+            words += [(w + q) % 64 for q in range(4)]
+        assert len(set(words)) == 64
+    # staging item e = (column quad e % 4, channel (e / 4) % 8, row, channel / 8): a 32-lane half's transposing stores are 2-way
+    for half in (0, 1):
+        banks = {}
+        for lane in range(32 * half, 32 * half + 32):
+            c4, q = lane & 3, lane >> 2
+            r, ci = (q >> 3) % 9, 8 * (q // 72) + (q & 7)
+            banks.setdefault(((r * rs + 1 + 4 * c4) * cs + ci) % 32, []).append(lane)
+        assert max(len(v) for v in banks.values()) <= 2
+    # ... and the items cover the unit's 48 x 9 x 4 float4 exactly once
+    items = set()
+    for e in range(1728):
+        c4, q = e & 3, e >> 2
+        items.add((8 * (q // 72) + (q & 7), (q >> 3) % 9, c4))
+    assert len(items) == 1728 and max(i[0] for i in items) == 47
+
+
+def test_forward_k_step_order_matches_the_weight_registers():
+    # conv12 forward: k-step ks = (tap, pair m, j) takes ci = 8 m + 2 lq + j; over the 8 k-steps of a tap and the 4 lane groups
+    # every input channel appears exactly once.  conv3 forward: ks = 12 tap + 4 g + j takes ci = 16 g + 4 lq + j (48 channels).
+    for tap in range(9):
+        ci = sorted(8 * ((ks & 7) >> 1) + 2 * lq + (ks & 1) for ks in range(8 * tap, 8 * tap + 8) for lq in range(4))
+        assert ci == list(range(32))
+        ci3 = sorted(16 * ((ks % 12) >> 2) + 4 * lq + (ks & 3) for ks in range(12 * tap, 12 * tap + 12) for lq in range(4))
+        assert ci3 == list(range(48))
