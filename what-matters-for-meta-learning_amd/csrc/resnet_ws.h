@@ -167,6 +167,46 @@ __device__ __forceinline__ void stage_patch(float* patch, const float* __restric
   typedef float stage_t __attribute__((ext_vector_type(G::SEGW)));
   constexpr int CH_ITEMS = 10;
   __syncthreads();
+  if constexpr (G::SEG >= 4) {
+    // Maps of 16 x 16 and up: thread = (row segment seg, channel cil of a group of 256 / SEG); its items run over (channel group,
+    // image, patch row) - compile-time steps, so the requests and stores of a thread differ by wave-uniform / immediate offsets
+    // only and whether a row exists is a scalar test.  (Dealt as item e = tid + 256 j every item cost two divisions by run-time-
+    // irregular constants and a 64-bit address: ~15 vector instructions, 18 times per band in the 32 x 32 stride-2 geometry - on the
+    // port the fp32 MFMAs issue through.)
+    constexpr int TCI = 256 / G::SEG, NCH = CH / TCI, NROW = G::NI * G::PR, CNT2 = NCH * NROW;
+    static_assert(TCI <= CH && CH % TCI == 0, "thread map");
+    const int seg = tid & (G::SEG - 1), cil = tid / G::SEG;
+    const float* gl = x + (size_t)cil * (G::HIN * G::HIN) + 4 * seg;                 // lane part of the address
+    float* dl = patch + cil * G::PS + G::COL0 + 4 * seg;
+#pragma unroll
+    for (int j0 = 0; j0 < CNT2; j0 += CH_ITEMS) {
+      stage_t st[CH_ITEMS];
+#pragma unroll
+      for (int jj = 0; jj < CH_ITEMS; ++jj) {
+        const int j = j0 + jj;
+        if (j >= CNT2) break;
+        const int ch = j / NROW, il = (j % NROW) / G::PR, pr = j % G::PR;
+        const int iy = G::S * oy0 + G::ROW0 + pr;                                     // wave-uniform
+        stage_t v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = 0.f;
+        if (iy >= 0 && iy < G::HIN && img0 + il < n_img)
+          v = *reinterpret_cast<const stage_t*>(gl + ((size_t)(img0 + il) * CH + ch * TCI) * (G::HIN * G::HIN) + iy * G::HIN);
+        st[jj] = v;
+      }
+#pragma unroll
+      for (int jj = 0; jj < CH_ITEMS; ++jj) {
+        const int j = j0 + jj;
+        if (j >= CNT2) break;
+        const int ch = j / NROW, il = (j % NROW) / G::PR, pr = j % G::PR;
+        float* d = dl + ch * TCI * G::PS + il * G::ISZ + pr * G::RS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = st[jj][q];
+      }
+    }
+    __syncthreads();
+    return;
+  }
 #pragma unroll
   for (int j0 = 0; j0 < G::CNT; j0 += CH_ITEMS) {
     stage_t st[CH_ITEMS];
