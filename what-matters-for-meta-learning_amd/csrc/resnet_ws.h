@@ -727,7 +727,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
   typedef float stage_t __attribute__((ext_vector_type(G::SEGW)));
   // the band's global loads are issued one band ahead: they are in flight under the previous band's MFMAs instead of in front of
   // this band's barrier (exposed, a workgroup spent about as long waiting for HBM as computing, and so did its CU partner)
-  stage_t st[TAP1 ? 1 : G::CNT];
+  // regular staging map (one image per band, maps of 16 x 16 and up): 256 threads = SEG row segments x 16 channels x RP row phases
+  constexpr bool REG_MAP = !TAP1 && !G::MULTI && G::SEG >= 4 && G::SEG <= 16;
+  constexpr int RM_RP = REG_MAP ? 256 / (G::SEG * 16) : 1, RM_RPP = REG_MAP ? (G::PR + RM_RP - 1) / RM_RP : 1;
+  const int rm_seg = tid & (G::SEG - 1), rm_ci = (tid / G::SEG) & 15, rm_row0 = (tid / (G::SEG * 16)) * RM_RPP;
+  stage_t st[TAP1 ? 1 : (REG_MAP ? RM_RPP : G::CNT)];
   float s1[TAP1 ? 8 : 1];
   float4 sd[G::DCNT];
   auto fetch = [&](int band) __attribute__((always_inline)) {
@@ -742,6 +746,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
         const int il = G::MULTI ? p / G::PI : 0, pin = G::MULTI ? p % G::PI : p;
         const int oy = oy0 + pin / G::WO, ox = pin % G::WO;
         s1[j] = img0 + il < jb.n_img ? jb.x[(((size_t)(img0 + il) * CH + 16 * q + ci) * G::HIN + 2 * oy) * G::HIN + 2 * ox] : 0.f;
+      }
+    } else if constexpr (REG_MAP) {
+      // thread = (row segment, channel of the slice, row phase): its items are consecutive patch rows - one lane base, steps of
+      // one map row (see stage_patch: the item = tid + 256 j deal cost two irregular divisions and a 64-bit address per item)
+      const float* gl = jb.x + ((size_t)img0 * CH + 16 * q + rm_ci) * (G::HIN * G::HIN) + 4 * rm_seg;
+#pragma unroll
+      for (int j = 0; j < RM_RPP; ++j) {
+        const int pr = rm_row0 + j, iy = G::S * oy0 - 1 + pr;
+        stage_t v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = 0.f;
+        if (pr < G::PR && iy >= 0 && iy < G::HIN) v = *reinterpret_cast<const stage_t*>(gl + iy * G::HIN);
+        st[j] = v;
       }
     } else {
 #pragma unroll
@@ -778,6 +795,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
     if (TAP1) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const int e = tid + j * 256; xs[(e / G::BPOS) * (G::BPOS + 1) + e % G::BPOS] = s1[j]; }
+    } else if constexpr (REG_MAP) {
+      float* dl = xs + rm_ci * G::PS + rm_row0 * G::RS + 1 + 4 * rm_seg;
+#pragma unroll
+      for (int j = 0; j < RM_RPP; ++j) {
+        if (rm_row0 + j < G::PR) {
+          float* d = dl + j * G::RS;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[k] = st[j][k];
+        }
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < G::CNT; ++j) {
