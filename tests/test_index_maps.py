@@ -73,20 +73,20 @@ def test_conv3_forward_patch_b128_reads_are_conflict_free():
             w = ((2 * (lr >> 3)) * rs + 2 * (lr & 7)) * cs + 4 * lq
             words += [(w + q) % 64 for q in range(4)]
         assert len(set(words)) == 64
-    # staging item e = (column quad e % 4, channel (e / 4) % 8, row, channel / 8): a 32-lane half's transposing stores are 2-way
-    for half in (0, 1):
+    # staging thread = (column quad tid % 4, channel 8 (tid / 32 % 8) + tid / 4 % 8, row phase tid / 256), items = rows 5 phase + j:
+    # a 32-lane half holds 4 quads x 8 channels of one row - its transposing stores are 2-way at worst
+    for half in range(16):
         banks = {}
-        for lane in range(32 * half, 32 * half + 32):
-            c4, q = lane & 3, lane >> 2
-            r, ci = (q >> 3) % 9, 8 * (q // 72) + (q & 7)
-            banks.setdefault(((r * rs + 1 + 4 * c4) * cs + ci) % 32, []).append(lane)
+        for tid in range(32 * half, 32 * half + 32):
+            c4, ci, r = tid & 3, 8 * ((tid >> 5) & 7) + ((tid >> 2) & 7), 5 * (tid >> 8)
+            banks.setdefault(((r * rs + 1 + 4 * c4) * cs + ci) % 32, []).append(tid)
         assert max(len(v) for v in banks.values()) <= 2
     # ... and the items cover the unit's 48 x 9 x 4 float4 exactly once
-    items = set()
-    for e in range(1728):
-        c4, q = e & 3, e >> 2
-        items.add((8 * (q // 72) + (q & 7), (q >> 3) % 9, c4))
-    assert len(items) == 1728 and max(i[0] for i in items) == 47
+    items = []
+    for tid in range(512):
+        c4, ci, r0 = tid & 3, 8 * ((tid >> 5) & 7) + ((tid >> 2) & 7), 5 * (tid >> 8)
+        items += [(ci, r0 + j, c4) for j in range(5) if ci < 48 and r0 + j < 9]
+    assert len(items) == 1728 and len(set(items)) == 1728
 
 
 def test_forward_k_step_order_matches_the_weight_registers():

@@ -96,33 +96,31 @@ __global__ __launch_bounds__(F_NT) void conv3_fwd_kernel(const float* __restrict
   C3_TS(0);
 
   const int nunits = n_img * 2;
-  // staging: 48 x 9 rows x 4 float4 = 1728 float4 per unit, up to 4 per thread.  Item e = (column quad c4 = e % 4, channel
-  // ci % 8 = (e / 4) % 8, then the row, then ci / 8): a 32-lane half holds 4 quads x 8 channels of ONE row - its transposing
-  // stores (a quad = 4 positions = 208 = 16 mod 32 words, a channel 1 word) are 2-way at worst.  (Row-major items - a channel's 9
-  // rows are 576 contiguous bytes - put 8 rows, 24 x 52 = 0 mod 32 words apart, into every half: 16-way stores, the kernel 2.4 us
-  // slower than with [ci] planes.)  The loads still use every 64-byte line they touch.
-  auto item = [](int e, int& ci, int& r, int& c4) { c4 = e & 3; const int q = e >> 2; r = (q >> 3) % 9; ci = 8 * (q / 72) + (q & 7); };
-  float4 st[4];
+  // staging: 48 ci x 9 rows x 4 column quads of float4 per unit.  Thread = (quad c4 = tid % 4, channel ci = 8 (tid / 32 % 8) +
+  // tid / 4 % 8, row phase tid / 256): its five items are consecutive rows 5 phase + j - one lane base and compile-time steps for
+  // the requests and the transposing stores alike (threads with tid / 32 % 8 >= 6 idle: 48 = 6 x 8 channels).  A 32-lane half
+  // holds 4 quads x 8 channels of ONE row: its stores (a quad = 4 positions = 208 = 16 mod 32 words, a channel 1 word) are 2-way
+  // at worst.  (Row-major items - a channel's 9 rows are 576 contiguous bytes - put 8 rows, 24 x 52 = 0 mod 32 words apart, into
+  // every half: 16-way stores, the kernel 2.4 us slower; items dealt as e = tid + 512 j cost two divisions per item and use.)
+  const int s_c4 = tid & 3, s_ci = 8 * ((tid >> 5) & 7) + ((tid >> 2) & 7), s_r0 = 5 * (tid >> 8);
+  const bool s_on = s_ci < CIN;
+  float4 st[5];
   auto fetch = [&](int u) {
     const int img = u >> 1, hf = u & 1;
+    const float* gl = p2 + (((size_t)img * CIN + (s_on ? s_ci : 0)) * 16 + 8 * hf - 1 + s_r0) * 16 + 4 * s_c4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = tid + j * F_NT;
-      int ci, r, c4;
-      item(e, ci, r, c4);
-      const int iy = 8 * hf - 1 + r;
+    for (int j = 0; j < 5; ++j) {
+      const int r = s_r0 + j, iy = 8 * hf - 1 + r;
       st[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < 1728 && iy >= 0) st[j] = *reinterpret_cast<const float4*>(p2 + (((size_t)img * CIN + ci) * 16 + iy) * 16 + 4 * c4);
+      if (s_on && r < 9 && iy >= 0) st[j] = *reinterpret_cast<const float4*>(gl + 16 * j);
     }
   };
   auto stash = [&](float* buf) {
+    float* dl = buf + (s_r0 * F_RS + 1 + 4 * s_c4) * F_CS + s_ci;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = tid + j * F_NT;
-      if (e < 1728) {
-        int ci, r, c4;
-        item(e, ci, r, c4);
-        float* d = buf + (r * F_RS + 1 + 4 * c4) * F_CS + ci;
+    for (int j = 0; j < 5; ++j) {
+      if (s_on && s_r0 + j < 9) {
+        float* d = dl + j * F_ROW;
         d[0] = st[j].x; d[F_CS] = st[j].y; d[2 * F_CS] = st[j].z; d[3 * F_CS] = st[j].w;
       }
     }
