@@ -66,9 +66,17 @@ inline int conv_stride(int conv) { return (conv - 1) % 3 == 1 ? 1 : 2; }
 // the band total a job's slab rows are planned against: the 1x1 skips of a step share a launch of their own (skip1_wgrad_kernel),
 // so they split ITS workgroups among themselves, not those of a launch that also serves the other passes
 inline int skip1_total(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk_wset* ws, int p, int conv, const int* bands, int total) {
-  if (conv % 3 != 0 || ws[ps[p].wset].skip_k != 1) return total;
-  int t = 0;
-  for (int i = 0; i < n_pass; ++i) if (ws[ps[i].wset].skip_k == 1) t += bands[i];
+  if (conv % 3 == 2) return total;                                   // conv2: a launch of its own over all passes
+  if (conv % 3 == 0 && ws[ps[p].wset].skip_k == 1) {
+    int t = 0;
+    for (int i = 0; i < n_pass; ++i) if (ws[ps[i].wset].skip_k == 1) t += bands[i];
+    return t;
+  }
+  // conv1 of every pass and the 3x3 skips (same input, same geometry) share ONE launch: its ~512 workgroups are split over all
+  // of those jobs.  (Planned per convolution, ShapeNet3D's block-1 launch came to 840 workgroups for 512 resident slots: a second
+  // round 64 % full, 143 us where one round needs ~95 - per-workgroup start / end stamps, scripts/dev/trunk_wgrad_ts.py.)
+  int t = total;
+  for (int i = 0; i < n_pass; ++i) if (ws[ps[i].wset].skip_k != 1) t += bands[i];
   return t;
 }
 

@@ -788,10 +788,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
       if (img0 + il < jb.n_img) sd[j] = *reinterpret_cast<const float4*>(jb.dy + ((size_t)(img0 + il) * CH + co) * G::PI + pin);
     }
   };
+#ifdef MLHOT_TS
+#define WG_TS(slot) do { if (tf::g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0 && !TAP1 && G::HIN == 32 && G::S == 2 && (slot) < 26) tf::g_ts_dev[420 + (slot)] = clock64(); } while (0)
+  int ts_b = 0;
+  if (tf::g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0 && !TAP1 && G::HIN == 32 && G::S == 2) { tf::g_ts_dev[446] = nbands; tf::g_ts_dev[447] = jb.nz; }
+#else
+#define WG_TS(slot) do { } while (0)
+#endif
+  WG_TS(0);
+#ifdef MLHOT_TS
+  if (tf::g_ts_dev && threadIdx.x == 0 && !TAP1 && G::HIN == 32 && G::S == 2 && blockIdx.x < 1024) tf::g_ts_dev[1024 + 2 * blockIdx.x] = wall_clock64();
+#endif
   if (z < nbands) fetch(z);
 #pragma unroll 1
   for (int band = z; band < nbands; band += jb.nz) {
+    WG_TS(1 + 4 * ts_b);
     __syncthreads();                   // the previous band's operands have been consumed
+    WG_TS(2 + 4 * ts_b);
     if (TAP1) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const int e = tid + j * 256; xs[(e / G::BPOS) * (G::BPOS + 1) + e % G::BPOS] = s1[j]; }
@@ -824,6 +837,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
       d[0] = sd[j].x; d[G::DS] = sd[j].y; d[2 * G::DS] = sd[j].z; d[3 * G::DS] = sd[j].w;
     }
     __syncthreads();
+    WG_TS(3 + 4 * ts_b);
     if (band + jb.nz < nbands) fetch(band + jb.nz);
 
     // operands of k-step ks + 1 (one dY word, nine / one x words) are read before the MFMAs of k-step ks, every step fenced:
@@ -848,7 +862,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#ifdef MLHOT_TS
+    WG_TS(4 + 4 * ts_b); ++ts_b;
+#endif
   }
+  WG_TS(24);
   // ---- slab row z0 + z, MFMA-native: [q][w][tap][lane][4] ----
   float* row = jb.slab + (size_t)(jb.z0 + z) * (TAP1 ? SLAB1 : SLAB3);
 #pragma unroll
@@ -856,6 +874,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
     *reinterpret_cast<float4*>(row + ((((size_t)q * 4 + w) * NT + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
   if (q == 0 && jb.slab_b && lr == 0)
     *reinterpret_cast<float4*>(jb.slab_b + (size_t)(jb.z0 + z) * 64 + 16 * w + 4 * lq) = make_float4(accb[0], accb[1], accb[2], accb[3]);
+  WG_TS(25);
+#ifdef MLHOT_TS
+  if (tf::g_ts_dev && threadIdx.x == 0 && !TAP1 && G::HIN == 32 && G::S == 2 && blockIdx.x < 1024) tf::g_ts_dev[1025 + 2 * blockIdx.x] = wall_clock64();
+#endif
 }
 
 // out = sum over slab rows, un-permuted from MFMA-native order to the parameter's own layout.
