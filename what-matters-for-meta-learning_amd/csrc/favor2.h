@@ -22,6 +22,7 @@ __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return _
 constexpr int FCH = 256;          // features per F1 workgroup (4 waves x 4 tiles of 16)
 constexpr int MAXN = 32;          // shots per side
 constexpr int NSP = 4;            // B1 workgroups per (task, head): each takes a quarter of the feature tiles
+constexpr int NPMAX = 32;         // partial row maxima per query row (4 per F1 feature chunk): m <= 2048
 
 struct Ws {     // carved from the caller's workspace; the forward fills it, the backward reuses it
   float *eq, *ek;                 // dd, then E = ratio exp(...) in place: [rows_q][mp], [rows_k][mp]
@@ -53,7 +54,7 @@ inline Ws carve(const FavorDims& f, void* ws, size_t bytes, size_t* need = nullp
   if (need) *need = a.off + 256;
   return w;
 }
-inline bool applies(const FavorDims& f) { return f.Nq <= MAXN && f.Nc <= MAXN && f.d % 16 == 0 && f.d <= 256 && f.m >= 16; }
+inline bool applies(const FavorDims& f) { return f.Nq <= MAXN && f.Nc <= MAXN && f.d % 16 == 0 && f.d <= 256 && f.m >= 16 && f.m <= FCH * NPMAX / 4; }
 
 struct Args {
   FavorDims f; Ws w;
@@ -169,11 +170,18 @@ __global__ __launch_bounds__(256) void f2_kernel(const Args a) {
   // query row maxima from the partials
   if (tid < Nq) {
     const size_t grow = (size_t)(t * Nq + tid) * H + h;
-    float best = -INFINITY; int bj = 0x7fffffff;
-    for (int p = 0; p < a.w.npart; ++p) {
-      const float vv = a.w.pm_v[grow * a.w.npart + p]; const int j = a.w.pm_i[grow * a.w.npart + p];
-      if (vv > best || (vv == best && j < bj)) { best = vv; bj = j; }
+    // all partials requested before the first compare (as a loop with a run-time trip count the 24 value / index pairs were 24
+    // serial L2 round trips: ~10 us of this kernel's 48)
+    float pv[NPMAX]; int pj[NPMAX];
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p) {
+      pv[p] = -INFINITY; pj[p] = 0x7fffffff;
+      if (p < a.w.npart) { pv[p] = a.w.pm_v[grow * a.w.npart + p]; pj[p] = a.w.pm_i[grow * a.w.npart + p]; }
     }
+    float best = -INFINITY; int bj = 0x7fffffff;
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p)
+      if (pv[p] > best || (pv[p] == best && pj[p] < bj)) { best = pv[p]; bj = pj[p]; }
     s_mx[tid] = best; a.w.mx_q[grow] = best; a.w.arg_q[grow] = bj;
   }
   // batch-global key maximum from the per-workgroup maxima
@@ -220,25 +228,43 @@ __global__ __launch_bounds__(256) void f2_kernel(const Args a) {
   }
   f32x4_t acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
   const int tq = (Nq + 15) / 16, tk = (Nc + 15) / 16;
-  auto feat = [&](float* row, int j, float sub, float4& f) {        // dd -> E (stored back), returns F = E + ratio eps (0 beyond m)
+  auto ldd = [&](float* row, int j) { return (row != nullptr && j < mp) ? *reinterpret_cast<const float4*>(row + j) : make_float4(0.f, 0.f, 0.f, 0.f); };
+  auto feat = [&](float* row, int j, float sub, const float4 dd, float4& f) {        // dd -> E (stored back), returns F = E + ratio eps (0 beyond m)
     f = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row == nullptr) return;
-    const float4 dd = *reinterpret_cast<const float4*>(row + j);
     float4 e;
     e.x = j < m ? a.ratio * expf(dd.x - sub) : 0.f; e.y = j + 1 < m ? a.ratio * expf(dd.y - sub) : 0.f;
     e.z = j + 2 < m ? a.ratio * expf(dd.z - sub) : 0.f; e.w = j + 3 < m ? a.ratio * expf(dd.w - sub) : 0.f;
     *reinterpret_cast<float4*>(row + j) = e;
     f = make_float4(j < m ? e.x + a.re : 0.f, j + 1 < m ? e.y + a.re : 0.f, j + 2 < m ? e.z + a.re : 0.f, j + 3 < m ? e.w + a.re : 0.f);
   };
-  for (int jb = 16 * wv; jb < mp; jb += 128) {       // two 16-feature chunks per trip
+  // two 16-feature chunks per trip; the dd of trip + 1 are requested before the exponentials of this trip (un-pipelined, each of the
+  // 11 trips waited out an HBM round trip)
+  float4 dq[2][2], dk[2][2];
+  auto fetch = [&](int jb) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = jb + 64 * u + 4 * lq;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { dq[u][i] = ldd(qrow[i], j); dk[u][i] = ldd(krow[i], j); }
+    }
+  };
+  fetch(16 * wv);
+  for (int jb = 16 * wv; jb < mp; jb += 128) {
+    float4 cq[2][2], ck[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { cq[u][i] = dq[u][i]; ck[u][i] = dk[u][i]; }
+    if (jb + 128 < mp) fetch(jb + 128);
     float4 fa[2][2], fb[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int j = jb + 64 * u + 4 * lq;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        feat(j < mp ? qrow[i] : nullptr, j, qsub[i], fa[u][i]);
-        feat(j < mp ? krow[i] : nullptr, j, ksub[i], fb[u][i]);
+        feat(j < mp ? qrow[i] : nullptr, j, qsub[i], cq[u][i], fa[u][i]);
+        feat(j < mp ? krow[i] : nullptr, j, ksub[i], ck[u][i], fb[u][i]);
       }
     }
 #pragma unroll
@@ -285,10 +311,15 @@ __global__ __launch_bounds__(256) void f2_kernel(const Args a) {
     float o[16];
 #pragma unroll
     for (int n = 0; n < 16; ++n) o[n] = 0.f;
-    for (int np = 0; np < Nc; ++np) {
-      const float vv = a.v[((size_t)(t * Nc + np) * H + h) * d + e];
+    float vcol[MAXN];                                  // the value column, all rows requested together (it was a serial loop of loads)
 #pragma unroll
-      for (int n = 0; n < 16; ++n) o[n] = fmaf(s_S[(16 * half + n) * (MAXN + 1) + np], vv, o[n]);
+    for (int np = 0; np < MAXN; ++np) vcol[np] = np < Nc ? a.v[((size_t)(t * Nc + np) * H + h) * d + e] : 0.f;
+#pragma unroll
+    for (int np = 0; np < MAXN; ++np) {
+      if (np < Nc) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) o[n] = fmaf(s_S[(16 * half + n) * (MAXN + 1) + np], vcol[np], o[n]);
+      }
     }
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
