@@ -495,8 +495,13 @@ __global__ __launch_bounds__(256) void b2_kernel(const Args a) {
   const int e0 = blockIdx.y * 16;
   // sum of G over every key row of the batch (the global stabiliser's gradient)
   {
-    float s = 0.f;
-    for (int i = tid; i < a.f.T * Nc * H * NSP; i += 256) s += a.w.rs_k[i];
+    // (four independent partial sums: as one rolled loop its 15 trips were 15 serial L2 round trips in every one of the workgroups)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int nrs = a.f.T * Nc * H * NSP;
+    int i = tid;
+    for (; i + 768 < nrs; i += 1024) { s0 += a.w.rs_k[i]; s1 += a.w.rs_k[i + 256]; s2 += a.w.rs_k[i + 512]; s3 += a.w.rs_k[i + 768]; }
+    for (; i < nrs; i += 256) s0 += a.w.rs_k[i];
+    const float s = (s0 + s1) + (s2 + s3);
     sm[tid] = s;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) { if (tid < k) sm[tid] += sm[tid + k]; __syncthreads(); }
