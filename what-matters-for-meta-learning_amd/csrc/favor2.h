@@ -483,16 +483,19 @@ __global__ __launch_bounds__(256) void b1_kernel(const Args a) {
 
 // ---- B2 ---------------------------------------------------------------------------------------------------------
 // dx[row][e] = c sum_j ddd[row][j] P[j][e] - rsum[row] c^2 x[row][e],  ddd = G - stabiliser corrections (rank-1 fix-ups in the epilogue).
-// grid (task x head, d / 16): a workgroup owns 16 channels e for the block's rows; its four waves split the m features.
+// grid (task x head, d / 64): a workgroup owns 64 channels e (four N-tiles) for the block's rows; its four waves split the m
+// features.  (With 16-channel slices every block's G rows - 171 KB - were re-read by 16 workgroups: 175 MB through L2 per launch for
+// 11 MB of gradients, and the kernel ran at L2 bandwidth.)
+constexpr int B2_NT = 4;
 template <int RT>
 __global__ __launch_bounds__(256) void b2_kernel(const Args a) {
   __shared__ float s_gt;
   __shared__ float sm[256];
-  __shared__ float red[4 * RT * 64 * 4];
+  __shared__ float red[4 * RT * B2_NT * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int th = blockIdx.x, t = th / a.f.H, h = th % a.f.H;
   const int d = a.f.d, m = a.f.m, Nq = a.f.Nq, Nc = a.f.Nc, H = a.f.H, mp = a.w.mp, R = Nq + Nc;
-  const int e0 = blockIdx.y * 16;
+  const int e0 = blockIdx.y * 16 * B2_NT;
   // sum of G over every key row of the batch (the global stabiliser's gradient)
   {
     // (four independent partial sums: as one rolled loop its 15 trips were 15 serial L2 round trips in every one of the workgroups)
@@ -513,58 +516,68 @@ __global__ __launch_bounds__(256) void b2_kernel(const Args a) {
     const int r = 16 * i + lr;
     grow[i] = r < Nq ? a.w.gq + ((size_t)(t * Nq + r) * H + h) * mp : (r < R ? a.w.gk + ((size_t)(t * Nc + r - Nq) * H + h) * mp : nullptr);
   }
-  f32x4_t acc[RT];
+  f32x4_t acc[RT][B2_NT];
 #pragma unroll
-  for (int i = 0; i < RT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int n = 0; n < B2_NT; ++n) acc[i][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const float* pcol = a.proj + e0 + lr;
-  constexpr int UF = RT <= 2 ? 4 : 2;
+  constexpr int UF = 2;
   for (int jb = 16 * wv; jb < mp; jb += 64 * UF) {
-    float4 g[UF][RT]; float p[UF][4];
+    float4 g[UF][RT]; float p[UF][4][B2_NT];
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
       const int j = jb + 64 * u + 4 * lq;
 #pragma unroll
       for (int i = 0; i < RT; ++i) g[u][i] = (grow[i] && j < mp) ? *reinterpret_cast<const float4*>(grow[i] + j) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) p[u][k] = (j + k < m && e0 + lr < d) ? pcol[(size_t)(j + k) * d] : 0.f;        // B[k = j (lq)][n = e (lr)]
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int n = 0; n < B2_NT; ++n) p[u][k][n] = (j + k < m && e0 + 16 * n + lr < d) ? pcol[(size_t)(j + k) * d + 16 * n] : 0.f;        // B[k = j (lq)][n = e (lr)]
     }
 #pragma unroll
     for (int u = 0; u < UF; ++u)
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        acc[i] = mfma4(g[u][i].x, p[u][0], acc[i]); acc[i] = mfma4(g[u][i].y, p[u][1], acc[i]);
-        acc[i] = mfma4(g[u][i].z, p[u][2], acc[i]); acc[i] = mfma4(g[u][i].w, p[u][3], acc[i]);
-      }
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int n = 0; n < B2_NT; ++n) {
+          acc[i][n] = mfma4(g[u][i].x, p[u][0][n], acc[i][n]); acc[i][n] = mfma4(g[u][i].y, p[u][1][n], acc[i][n]);
+          acc[i][n] = mfma4(g[u][i].z, p[u][2][n], acc[i][n]); acc[i][n] = mfma4(g[u][i].w, p[u][3][n], acc[i][n]);
+        }
   }
 #pragma unroll
-  for (int i = 0; i < RT; ++i) *reinterpret_cast<f32x4_t*>(red + ((wv * RT + i) * 64 + lane) * 4) = acc[i];
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int n = 0; n < B2_NT; ++n) *reinterpret_cast<f32x4_t*>(red + (((wv * RT + i) * B2_NT + n) * 64 + lane) * 4) = acc[i][n];
   __syncthreads();
-  if (wv >= RT) return;
-  const int i = wv;                                // wave i folds and finishes row tile i
-  f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const f32x4_t vv = *reinterpret_cast<const f32x4_t*>(red + ((k * RT + i) * 64 + lane) * 4);
-    sacc[0] += vv[0]; sacc[1] += vv[1]; sacc[2] += vv[2]; sacc[3] += vv[3];
-  }
-  const int e = e0 + lr;
-  if (e >= d) return;
   const int gr = a.w.gpos[0], gj = a.w.gpos[1];
+  // tile (i, n) is folded and finished by wave (i * B2_NT + n) % 4, in a fixed order
+  for (int tile = wv; tile < RT * B2_NT; tile += 4) {
+    const int i = tile / B2_NT, n = tile % B2_NT;
+    f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = 16 * i + 4 * lq + r;
-    if (row >= R) continue;
-    float vv = sacc[r];
-    if (row < Nq) {
-      const size_t g = (size_t)(t * Nq + row) * H + h;
-      const float rs = (a.w.rs_q[g * NSP] + a.w.rs_q[g * NSP + 1]) + (a.w.rs_q[g * NSP + 2] + a.w.rs_q[g * NSP + 3]);
-      vv -= rs * a.proj[(size_t)a.w.arg_q[g] * d + e];              // - [j == argmax] rowsum
-      a.dq[g * d + e] = a.c * vv - rs * a.c * a.c * a.q[g * d + e];
-    } else {
-      const size_t g = (size_t)(t * Nc + row - Nq) * H + h;
-      const float rs = (a.w.rs_k[g * NSP] + a.w.rs_k[g * NSP + 1]) + (a.w.rs_k[g * NSP + 2] + a.w.rs_k[g * NSP + 3]);
-      if ((int)g == gr) vv -= s_gt * a.proj[(size_t)gj * d + e];    // - [this is THE global arg-max element] total
-      a.dk[g * d + e] = a.c * vv - rs * a.c * a.c * a.k[g * d + e];
+    for (int k = 0; k < 4; ++k) {
+      const f32x4_t vv = *reinterpret_cast<const f32x4_t*>(red + (((k * RT + i) * B2_NT + n) * 64 + lane) * 4);
+      sacc[0] += vv[0]; sacc[1] += vv[1]; sacc[2] += vv[2]; sacc[3] += vv[3];
+    }
+    const int e = e0 + 16 * n + lr;
+    if (e >= d) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * i + 4 * lq + r;
+      if (row >= R) continue;
+      float vv = sacc[r];
+      if (row < Nq) {
+        const size_t g = (size_t)(t * Nq + row) * H + h;
+        const float rs = (a.w.rs_q[g * NSP] + a.w.rs_q[g * NSP + 1]) + (a.w.rs_q[g * NSP + 2] + a.w.rs_q[g * NSP + 3]);
+        vv -= rs * a.proj[(size_t)a.w.arg_q[g] * d + e];              // - [j == argmax] rowsum
+        a.dq[g * d + e] = a.c * vv - rs * a.c * a.c * a.q[g * d + e];
+      } else {
+        const size_t g = (size_t)(t * Nc + row - Nq) * H + h;
+        const float rs = (a.w.rs_k[g * NSP] + a.w.rs_k[g * NSP + 1]) + (a.w.rs_k[g * NSP + 2] + a.w.rs_k[g * NSP + 3]);
+        if ((int)g == gr) vv -= s_gt * a.proj[(size_t)gj * d + e];    // - [this is THE global arg-max element] total
+        a.dk[g * d + e] = a.c * vv - rs * a.c * a.c * a.k[g * d + e];
+      }
     }
   }
 }
@@ -608,8 +621,8 @@ inline int backward(const FavorDims& f, const float* q, const float* k, const fl
   MLHOT_TRY(check_launch("favor.b1"));
   {
     ProfScope ps("favor.b2", s);
-    if (R <= 32) hipLaunchKernelGGL((b2_kernel<2>), dim3(th, (f.d + 15) / 16), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((b2_kernel<4>), dim3(th, (f.d + 15) / 16), dim3(256), 0, s, a);
+    if (R <= 32) hipLaunchKernelGGL((b2_kernel<2>), dim3(th, (f.d + 16 * B2_NT - 1) / (16 * B2_NT)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((b2_kernel<4>), dim3(th, (f.d + 16 * B2_NT - 1) / (16 * B2_NT)), dim3(256), 0, s, a);
   }
   return check_launch("favor.b2");
 }
