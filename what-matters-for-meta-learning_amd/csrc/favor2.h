@@ -15,11 +15,16 @@
 
 #ifndef MLHOT_HOSTSIM
 namespace mlhot {
+#ifdef MLHOT_TS
+namespace tf { extern __device__ long long* g_ts_dev; }
+#endif
 namespace fv {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-constexpr int FCH = 256;          // features per F1 workgroup (4 waves x 4 tiles of 16)
+constexpr int F1_TPW = 3;         // 16-feature tiles per F1 wave
+constexpr int FCH = 4 * 16 * F1_TPW;   // features per F1 workgroup (4 waves x 3 tiles of 16 = 192: m = 1419 -> 8 chunks x 64 (task, head) blocks =
+                                       // 512 workgroups, two per CU; with 256 features it was 384 - half the CUs carried two, and the kernel ran at their pace)
 constexpr int MAXN = 32;          // shots per side
 constexpr int NSP = 4;            // B1 workgroups per (task, head): each takes a quarter of the feature tiles
 constexpr int NPMAX = 32;         // partial row maxima per query row (4 per F1 feature chunk): m <= 2048
@@ -78,21 +83,28 @@ __global__ __launch_bounds__(256) void f1_kernel(const Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int th = blockIdx.x, t = th / a.f.H, h = th % a.f.H, chunk = blockIdx.y;
   const int d = a.f.d, m = a.f.m, Nq = a.f.Nq, R = Nq + a.f.Nc, mp = a.w.mp;
-  const int f0 = chunk * FCH + wv * 64;
+  const int f0 = chunk * FCH + wv * (16 * F1_TPW);
+#ifdef MLHOT_TS
+  const int ts_wg = blockIdx.y * gridDim.x + blockIdx.x;
+#define F1_TS(k) do { if (tf::g_ts_dev && tid == 0 && ts_wg < 512) tf::g_ts_dev[1024 + 4 * ts_wg + (k)] = wall_clock64(); } while (0)
+#else
+#define F1_TS(k) do { } while (0)
+#endif
+  F1_TS(0);
   const float* xr[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) xr[i] = block_row(a, t, h, 16 * i + lr);
-  const float* pr[4];
+  const float* pr[F1_TPW];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { const int fj = f0 + 16 * j + lr; pr[j] = fj < m ? a.proj + (size_t)fj * d + 4 * lq : nullptr; }
-  f32x4_t acc[RT][4];
+  for (int j = 0; j < F1_TPW; ++j) { const int fj = f0 + 16 * j + lr; pr[j] = fj < m ? a.proj + (size_t)fj * d + 4 * lq : nullptr; }
+  f32x4_t acc[RT][F1_TPW];
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < F1_TPW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   constexpr int UF = RT <= 2 ? 4 : 2;           // 16-deep chunks per trip: all their operand loads are in flight together
   for (int c0 = 0; c0 < d; c0 += 16 * UF) {
-    float4 av[UF][RT], bv[UF][4];
+    float4 av[UF][RT], bv[UF][F1_TPW];
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
       const int k0 = c0 + 16 * u;
@@ -103,19 +115,20 @@ __global__ __launch_bounds__(256) void f1_kernel(const Args a) {
         av[u][i].x *= a.c; av[u][i].y *= a.c; av[u][i].z *= a.c; av[u][i].w *= a.c;       // data_normalizer * data, then the product
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[u][j] = (kin && pr[j]) ? *reinterpret_cast<const float4*>(pr[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < F1_TPW; ++j) bv[u][j] = (kin && pr[j]) ? *reinterpret_cast<const float4*>(pr[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < UF; ++u)
 #pragma unroll
       for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < F1_TPW; ++j) {
           acc[i][j] = mfma4(av[u][i].x, bv[u][j].x, acc[i][j]); acc[i][j] = mfma4(av[u][i].y, bv[u][j].y, acc[i][j]);
           acc[i][j] = mfma4(av[u][i].z, bv[u][j].z, acc[i][j]); acc[i][j] = mfma4(av[u][i].w, bv[u][j].w, acc[i][j]);
         }
   }
-  // store dd; partial maxima per row over this wave's 64 features (first position wins ties)
+  F1_TS(1);
+  // store dd; partial maxima per row over this wave's 48 features (first position wins ties)
   float kbest = -INFINITY; int kbr = 0x7fffffff, kbj = 0x7fffffff;
 #pragma unroll
   for (int i = 0; i < RT; ++i)
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(256) void f1_kernel(const Args a) {
       float* drow = nullptr;
       if (valid) drow = isq ? a.w.eq + ((size_t)(t * Nq + row) * a.f.H + h) * mp : a.w.ek + ((size_t)(t * a.f.Nc + row - Nq) * a.f.H + h) * mp;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < F1_TPW; ++j) {
         const int fj = f0 + 16 * j + lr;
         const float vv = acc[i][j][r];
         if (valid && fj < mp) drow[fj] = fj < m ? vv : 0.f;
@@ -148,6 +161,7 @@ __global__ __launch_bounds__(256) void f1_kernel(const Args a) {
         }
       }
     }
+  F1_TS(2);
   sm_v[tid] = kbest; sm_r[tid] = kbr; sm_j[tid] = kbj;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -158,6 +172,7 @@ __global__ __launch_bounds__(256) void f1_kernel(const Args a) {
     __syncthreads();
   }
   if (tid == 0) { const int o = th * a.w.nch + chunk; a.w.wg_v[o] = sm_v[0]; a.w.wg_row[o] = sm_r[0]; a.w.wg_j[o] = sm_j[0]; }
+  F1_TS(3);
 }
 
 // ---- F2 ---------------------------------------------------------------------------------------------------------
