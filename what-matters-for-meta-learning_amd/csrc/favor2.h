@@ -176,9 +176,12 @@ __global__ __launch_bounds__(256) void f1_kernel(const Args a) {
 }
 
 // ---- F2 ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void f2_kernel(const Args a) {
-  __shared__ float s_mx[MAXN], s_diag[2 * MAXN], s_S[MAXN * (MAXN + 1)], s_D[MAXN], red[4 * 4 * 64 * 4];
-  __shared__ float s_g; __shared__ float sm_v[256]; __shared__ int sm_r[256], sm_j[256];
+// 1024 threads: ONE workgroup per (task, head) - 64 of them on 256 CUs - so the block's 30 x 1424 exponentials and their dd / E
+// traffic are spread over 16 waves instead of 4 (the grid cannot grow: S = F_q F_k^T needs every feature of the block).
+constexpr int F2_NT = 1024, F2_NW = F2_NT / 64;
+__global__ __launch_bounds__(F2_NT) void f2_kernel(const Args a) {
+  __shared__ float s_mx[MAXN], s_diag[2 * MAXN], s_S[MAXN * (MAXN + 1)], s_D[MAXN], red[F2_NW * 4 * 64 * 4];
+  __shared__ float s_g; __shared__ float sm_v[F2_NT]; __shared__ int sm_r[F2_NT], sm_j[F2_NT];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int th = blockIdx.x, t = th / a.f.H, h = th % a.f.H;
   const int d = a.f.d, m = a.f.m, Nq = a.f.Nq, Nc = a.f.Nc, H = a.f.H, mp = a.w.mp;
@@ -202,13 +205,13 @@ __global__ __launch_bounds__(256) void f2_kernel(const Args a) {
   // batch-global key maximum from the per-workgroup maxima
   {
     float best = -INFINITY; int br = 0x7fffffff, bj = 0x7fffffff;
-    for (int i = tid; i < a.f.T * H * a.w.nch; i += 256) {
+    for (int i = tid; i < a.f.T * H * a.w.nch; i += F2_NT) {
       const float vv = a.w.wg_v[i]; const int r = a.w.wg_row[i], j = a.w.wg_j[i];
       if (vv > best || (vv == best && (r < br || (r == br && j < bj)))) { best = vv; br = r; bj = j; }
     }
     sm_v[tid] = best; sm_r[tid] = br; sm_j[tid] = bj;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = F2_NT / 2; s > 0; s >>= 1) {
       if (tid < s) {
         const float ov = sm_v[tid + s]; const int orow = sm_r[tid + s], oj = sm_j[tid + s];
         if (ov > sm_v[tid] || (ov == sm_v[tid] && (orow < sm_r[tid] || (orow == sm_r[tid] && oj < sm_j[tid])))) { sm_v[tid] = ov; sm_r[tid] = orow; sm_j[tid] = oj; }
@@ -217,11 +220,11 @@ __global__ __launch_bounds__(256) void f2_kernel(const Args a) {
     }
     if (tid == 0) { s_g = sm_v[0]; if (th == 0) { a.w.gmax[0] = sm_v[0]; a.w.gpos[0] = sm_r[0]; a.w.gpos[1] = sm_j[0]; } }
   }
-  // diag = 0.5 c^2 |x|^2 of the block's rows: 4 threads per row
+  // diag = 0.5 c^2 |x|^2 of the block's rows: 4 threads per row (the first 256 threads)
   {
     const int r = tid >> 2, part = tid & 3;
     float s = 0.f;
-    const float* xp = block_row(a, t, h, r);
+    const float* xp = r < 2 * MAXN ? block_row(a, t, h, r) : nullptr;
     if (xp) {
 #pragma unroll 4
       for (int e = 4 * part; e < d; e += 16) { const float4 u = *reinterpret_cast<const float4*>(xp + e); s += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w); }
@@ -259,23 +262,23 @@ __global__ __launch_bounds__(256) void f2_kernel(const Args a) {
   auto fetch = [&](int jb) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = jb + 64 * u + 4 * lq;
+      const int j = jb + 16 * F2_NW * u + 4 * lq;
 #pragma unroll
       for (int i = 0; i < 2; ++i) { dq[u][i] = ldd(qrow[i], j); dk[u][i] = ldd(krow[i], j); }
     }
   };
   fetch(16 * wv);
-  for (int jb = 16 * wv; jb < mp; jb += 128) {
+  for (int jb = 16 * wv; jb < mp; jb += 32 * F2_NW) {
     float4 cq[2][2], ck[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int i = 0; i < 2; ++i) { cq[u][i] = dq[u][i]; ck[u][i] = dk[u][i]; }
-    if (jb + 128 < mp) fetch(jb + 128);
+    if (jb + 32 * F2_NW < mp) fetch(jb + 32 * F2_NW);
     float4 fa[2][2], fb[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = jb + 64 * u + 4 * lq;
+      const int j = jb + 16 * F2_NW * u + 4 * lq;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         feat(j < mp ? qrow[i] : nullptr, j, qsub[i], cq[u][i], fa[u][i]);
@@ -293,17 +296,17 @@ __global__ __launch_bounds__(256) void f2_kernel(const Args a) {
           acc[i][jj] = mfma4(fa[u][i].z, fb[u][jj].z, acc[i][jj]); acc[i][jj] = mfma4(fa[u][i].w, fb[u][jj].w, acc[i][jj]);
         }
   }
-  // fold the four waves: S[n][n'] (C layout: n = 16 i + 4 lq + r, n' = 16 jj + lr)
+  // fold the sixteen waves: S[n][n'] (C layout: n = 16 i + 4 lq + r, n' = 16 jj + lr)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) *reinterpret_cast<f32x4_t*>(red + (((wv * 2 + i) * 2 + jj) * 64 + lane) * 4) = acc[i][jj];
   __syncthreads();
-  {
-    const int i = wv >> 1, jj = wv & 1;            // wave wv folds tile (i, jj)
+  if (wv < 4) {
+    const int i = wv >> 1, jj = wv & 1;            // wave wv folds tile (i, jj), in a fixed order
     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < F2_NW; ++k) {
       const f32x4_t vv = *reinterpret_cast<const f32x4_t*>(red + (((k * 2 + i) * 2 + jj) * 64 + lane) * 4);
       s[0] += vv[0]; s[1] += vv[1]; s[2] += vv[2]; s[3] += vv[3];
     }
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void f2_kernel(const Args a) {
   }
   __syncthreads();
   // out[t][n][e H + h] = sum_n' S[n][n'] v[(t, n', h)][e] / D[n]: thread = (e, n-half)
-  for (int idx = tid; idx < d * 2; idx += 256) {
+  for (int idx = tid; idx < d * 2; idx += F2_NT) {
     const int e = idx % d, half = idx / d;
     float o[16];
 #pragma unroll
@@ -618,7 +621,7 @@ inline int forward(const FavorDims& f, const float* q, const float* k, const flo
   MLHOT_TRY(check_launch("favor.f1"));
   {
     ProfScope ps("favor.f2", s);
-    hipLaunchKernelGGL(f2_kernel, dim3(th), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(f2_kernel, dim3(th), dim3(F2_NT), 0, s, a);
   }
   return check_launch("favor.f2");
 }
