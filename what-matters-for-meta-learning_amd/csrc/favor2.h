@@ -26,7 +26,11 @@ constexpr int F1_TPW = 3;         // 16-feature tiles per F1 wave
 constexpr int FCH = 4 * 16 * F1_TPW;   // features per F1 workgroup (4 waves x 3 tiles of 16 = 192: m = 1419 -> 8 chunks x 64 (task, head) blocks =
                                        // 512 workgroups, two per CU; with 256 features it was 384 - half the CUs carried two, and the kernel ran at their pace)
 constexpr int MAXN = 32;          // shots per side
-constexpr int NSP = 4;            // B1 workgroups per (task, head): each takes a quarter of the feature tiles
+constexpr int NSP = 8;            // B1 workgroups per (task, head): each takes an eighth of the feature tiles (512 workgroups, two per CU)
+__device__ __forceinline__ float sum_splits(const float* p) {      // the NSP partial row sums of one row, in a fixed order
+  return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+}
+static_assert(NSP == 8, "sum_splits");
 constexpr int NPMAX = 32;         // partial row maxima per query row (4 per F1 feature chunk): m <= 2048
 
 struct Ws {     // carved from the caller's workspace; the forward fills it, the backward reuses it
@@ -587,12 +591,12 @@ __global__ __launch_bounds__(256) void b2_kernel(const Args a) {
       float vv = sacc[r];
       if (row < Nq) {
         const size_t g = (size_t)(t * Nq + row) * H + h;
-        const float rs = (a.w.rs_q[g * NSP] + a.w.rs_q[g * NSP + 1]) + (a.w.rs_q[g * NSP + 2] + a.w.rs_q[g * NSP + 3]);
+        const float rs = sum_splits(a.w.rs_q + g * NSP);
         vv -= rs * a.proj[(size_t)a.w.arg_q[g] * d + e];              // - [j == argmax] rowsum
         a.dq[g * d + e] = a.c * vv - rs * a.c * a.c * a.q[g * d + e];
       } else {
         const size_t g = (size_t)(t * Nc + row - Nq) * H + h;
-        const float rs = (a.w.rs_k[g * NSP] + a.w.rs_k[g * NSP + 1]) + (a.w.rs_k[g * NSP + 2] + a.w.rs_k[g * NSP + 3]);
+        const float rs = sum_splits(a.w.rs_k + g * NSP);
         if ((int)g == gr) vv -= s_gt * a.proj[(size_t)gj * d + e];    // - [this is THE global arg-max element] total
         a.dk[g * d + e] = a.c * vv - rs * a.c * a.c * a.k[g * d + e];
       }
