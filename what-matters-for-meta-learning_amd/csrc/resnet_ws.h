@@ -110,7 +110,8 @@ typedef Geo<32, 1, 64, 16, 34, 136, 144> G32s1;
 typedef Geo<32, 2, 64, 16, 33, 297, 297> G32s2;
 typedef Geo<16, 1, 64, 16, 18, 108, 112> G16s1;
 typedef Geo<16, 2, 64, 2, 18, 306, 307> G16s2;
-typedef Geo<8, 1, 64, 2, 10, 100, 112> G8s1;
+typedef Geo<8, 1, 32, 4, 12, 72, 80> G8s1;       // half-image bands: 240-image launches have 720 of them - three per CU, where 360 whole-image
+                                                 // bands left 104 CUs with two and the rest with one (scripts/lds_layout_search.py search(8, 1, bpos_list=(32,)))
 typedef Geo<8, 2, 32, 4, 12, 108, 217> G8s2;
 typedef Geo<4, 1, 64, 4, 8, 48, 196> G4s1;
 typedef Geo<4, 2, 16, 2, 6, 40, 161> G4s2;
