@@ -109,7 +109,7 @@ typedef Geo<64, 2, 32, 16, 65, 195, 195> G64s2;
 typedef Geo<32, 1, 64, 16, 34, 136, 144> G32s1;
 typedef Geo<32, 2, 64, 16, 33, 297, 297> G32s2;
 typedef Geo<16, 1, 64, 16, 18, 108, 112> G16s1;
-typedef Geo<16, 2, 64, 2, 18, 306, 307> G16s2;
+typedef Geo<16, 2, 32, 4, 20, 180, 181> G16s2;    // half-image bands, as G8s1 (8 x 8 output maps: 360 whole-image bands balance badly over 256 CUs)
 typedef Geo<8, 1, 32, 4, 12, 72, 80> G8s1;       // half-image bands: 240-image launches have 720 of them - three per CU, where 360 whole-image
                                                  // bands left 104 CUs with two and the rest with one (scripts/lds_layout_search.py search(8, 1, bpos_list=(32,)))
 typedef Geo<8, 2, 32, 4, 12, 108, 217> G8s2;
