@@ -142,6 +142,25 @@ int mlhot_favor_bwd(const float* q, const float* k, const float* v, const float*
                     int T, int H, int Nq, int Nc, int d, int m, const float* out, const float* dout,
                     float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- strict sharded parity of the key stabiliser -------------------------
+ * fast_attention.py:96-97 takes torch.max over the keys of the WHOLE batch.  When a caller shards the meta-batch over
+ * ranks, each rank's launch sequence can be run in two halves around the caller's own collectives on `xchg`
+ * (device memory, 4 floats, caller-owned):
+ *   forward  stage 0: everything up to the rank-local key maximum           -> xchg[0] = that maximum
+ *            (caller: xchg[0] = MAX over ranks; xchg[1] = 1 on the lowest rank whose maximum equals it, else 0)
+ *            stage 1: the rest of the forward, with xchg[0] as the stabiliser
+ *   backward stage 0: everything up to the rank-local sum of dL/d(stabiliser) -> xchg[2] = that sum
+ *            (caller: xchg[2] = SUM over ranks)
+ *            stage 1: the rest; the rank with xchg[1] = 1 routes the batch-wide sum to its arg-max key, the others to none
+ * The same saved / scratch / ws buffers must be passed to both stages; a world of one (xchg[1] = 1, xchg untouched) reproduces
+ * the unstaged call.  No communication library is linked: the collective is the caller's (mlhot/dist.py: StabiliserExchange).  */
+int mlhot_favor_fwd_staged(const float* q, const float* k, const float* v, const float* proj,
+                           int T, int H, int Nq, int Nc, int d, int m, float* out,
+                           void* ws, size_t ws_bytes, int stage, float* xchg, void* stream);
+int mlhot_favor_bwd_staged(const float* q, const float* k, const float* v, const float* proj,
+                           int T, int H, int Nq, int Nc, int d, int m, const float* out, const float* dout,
+                           float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, int stage, float* xchg, void* stream);
+
 /* ---- L1: losses --------------------------------------------------------------------------
  * LossFunc.calc_loss (trainer/losses.py:32-80).  mu[rows,y_dim], gt[rows,gt_dim];
  * loss / dloss are device scalars.                                                            */
@@ -307,6 +326,15 @@ int mlhot_np_vanilla_bwd(const mlhot_np_dims* d, const mlhot_np_params* p,
                          const float* ctx_x, const float* ctx_y, const float* qry_x,
                          const float* mu, const float* dmu, const mlhot_np_grads* g,
                          const void* saved, void* scratch, size_t scratch_bytes, void* stream);
+/* Staged variants (see "strict sharded parity" above).  Built on the fused attention tail's launch boundaries: attention
+ * aggregation with Nc, Nq <= 16 (every shipped ANP configuration); MLHOT_ERR_UNSUPPORTED otherwise. */
+int mlhot_np_vanilla_fwd_staged(const mlhot_np_dims* d, const mlhot_np_params* p,
+                                const float* ctx_x, const float* ctx_y, const float* qry_x, float* mu,
+                                void* saved, void* scratch, size_t scratch_bytes, int stage, float* xchg, void* stream);
+int mlhot_np_vanilla_bwd_staged(const mlhot_np_dims* d, const mlhot_np_params* p,
+                                const float* ctx_x, const float* ctx_y, const float* qry_x,
+                                const float* mu, const float* dmu, const mlhot_np_grads* g,
+                                const void* saved, void* scratch, size_t scratch_bytes, int stage, float* xchg, void* stream);
 
 #ifdef __cplusplus
 }

@@ -282,3 +282,52 @@ def test_early_bucket_is_issued_inside_backward_and_equals_the_single_bucket():
             p.join(300)
             assert p.exitcode == 0
         assert len(out) == 2 and all(v[0] for v in out.values()) and max(v[1] for v in out.values()) <= 1e-7, dict(out)
+
+
+def _stab_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "what-matters-for-meta-learning_amd"), root]
+    from mlhot import dist as mdist
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    mdist.init_from_env("gloo")
+    ex = mdist.StabiliserExchange()
+    res = []
+    # (rank-local key maxima, rank-local stabiliser-gradient sums) -> every rank: the batch maximum, ONE owner, the batch sum
+    for maxima, sums in (([1.5, 3.0], [2.0, -0.5]), ([3.0, 3.0], [0.25, 0.5]), ([-2.0, -7.0], [1.0, 1.0])):
+        x = torch.tensor([maxima[rank], 7.0, sums[rank], 0.0])        # x[1] holds garbage on entry
+        ex.forward(x)
+        ex.backward(x)
+        res.append(x.tolist())
+    out[rank] = (res, list(ex.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stabiliser_exchange_on_two_ranks():
+    """mlhot.dist.StabiliserExchange (the collective between the staged halves of the attention passes, include/mlhot.h "strict
+    sharded parity"): the batch maximum reaches every rank, exactly one rank owns the arg-max (the lowest on ties), the
+    stabiliser's gradient is summed."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_stab_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        (r0, c0), (r1, c1) = out[0], out[1]
+    assert c0 == c1 == ["fwd", "bwd"] * 3
+    assert r0 == [[3.0, 0.0, 1.5, 0.0], [3.0, 1.0, 0.75, 0.0], [-2.0, 1.0, 2.0, 0.0]]
+    assert r1 == [[3.0, 1.0, 1.5, 0.0], [3.0, 0.0, 0.75, 0.0], [-2.0, 0.0, 2.0, 0.0]]
+
+
+def test_stabiliser_exchange_without_a_process_group_owns_the_maximum():
+    from mlhot import dist as mdist
+    x = torch.tensor([0.5, 0.0, -3.0, 0.0])
+    ex = mdist.StabiliserExchange()
+    ex.forward(x)
+    ex.backward(x)
+    assert x.tolist() == [0.5, 1.0, -3.0, 0.0]

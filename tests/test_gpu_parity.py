@@ -1641,6 +1641,106 @@ def test_grad_bucket_side_stream_and_early_bucket_on_cuda(gpulib):
             assert [k for k, _ in early_log] == ["early", "rest"] and [k for k, _ in side_log] == ["all"]
 
 
+def _strict_worker(rank, world, port, name, opts, out):
+    import copy
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "what-matters-for-meta-learning_amd"), root]
+    import torch.distributed as dist
+    import mlhot
+    from mlhot import dist as mdist, ops
+    from trainer.losses import LossFunc
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    mdist.init_from_env("gloo")                     # two ranks sharing the box's one GPU: gloo carries the device scalars
+    torch.cuda.set_device(0)
+    for k, v in opts.items():
+        mlhot.lib().set_option(k, v)
+    fx, meta = U.load_case(name)
+    full = U.build_model(meta, DEV, fx=fx).to(DEV)
+    T = meta["cfg"]["tasks_per_batch"]
+    smeta = copy.deepcopy(meta)
+    smeta["cfg"]["tasks_per_batch"] = T // world
+    shard = getattr(importlib.import_module("networks." + meta["method"]), meta["method"])(U.case_config(smeta, DEV)).to(DEV)
+    shard.load_state_dict(full.state_dict())
+    cx, qx, cy, qy = U.resnet_case_inputs(meta, fx) if name.startswith("r_") else U.case_inputs(meta)
+    lossf = LossFunc("mse", meta["cfg"]["task"])
+
+    def run(model, sl, exchange):
+        ops.set_stabiliser_exchange(exchange)
+        try:
+            for p in model.parameters():
+                p.grad = None
+            mu, var, _ = model(cx[sl].to(DEV), cy[sl].to(DEV), qx[sl].to(DEV))
+            loss = lossf.calc_loss(mu, var, qy[sl].to(DEV))
+            loss.backward()
+        finally:
+            ops.set_stabiliser_exchange(None)
+        return mu.detach().clone(), loss.detach().clone()
+
+    sl = mdist.task_slice(T, rank, world)
+    mu_full, loss_full = run(full, slice(0, T), None)
+    gfull = {k: p.grad.clone() for k, p in full.named_parameters() if p.grad is not None}
+    floor = U.GRAD_FLOOR * max(float(g.abs().max()) for g in gfull.values())
+    res = {}
+    for mode, ex in (("rank-local", None), ("strict", mdist.StabiliserExchange())):
+        mu, loss = run(shard, sl, ex)
+        mdist.GradBucket(shard.parameters()).sync()
+        lsum = loss.clone()
+        dist.all_reduce(lsum)
+        res[mode] = dict(mu_equal=bool(torch.equal(mu, mu_full[sl])), mu_err=U.rel_err(mu, mu_full[sl]),
+                         loss_err=abs(float(lsum) / world - float(loss_full)) / max(1.0, abs(float(loss_full))),
+                         grad_err=max(U.rel_err(p.grad, gfull[k], floor=floor) for k, p in shard.named_parameters() if k in gfull),
+                         calls=list(ex.calls) if ex else [])
+    # a world of one through the staged entry points reproduces the unstaged pass bit for bit (x[1] = 1: this rank owns the maximum)
+    class Alone(mdist.StabiliserExchange):
+        def _world(self):
+            return 1
+    mu1, _ = run(full, slice(0, T), Alone())
+    res["alone"] = bool(torch.equal(mu1, mu_full)) and all(torch.equal(p.grad, gfull[k]) for k, p in full.named_parameters() if k in gfull)
+    torch.cuda.synchronize()
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,opts", [("s_anp_shapenet1d_t2_full", {}), ("s_anp_shapenet1d_ragged", {}), ("s_anp_shapenet1d_ragged", {"tail_spec": 0}),
+                                       ("r_anp_shapenet3d", {}), ("r_anp_shapenet3d", {"favor2": 0})],
+                         ids=["anp1d_15+15", "anp1d_ragged", "anp1d_ragged_generic_tail", "resnet_anp_favor2", "resnet_anp_favor_chain"])
+def test_strict_sharded_parity_on_two_ranks(gpulib, name, opts):
+    """config.strict_sharded_parity (fast_attention.py:96-97): two gloo ranks share this box's GPU, each owns one
+    of the batch's two tasks.  Through the staged entry points (mlhot_np_vanilla_*_staged for the vanilla ANP's fused tail,
+    mlhot_favor_*_staged for the ResNet family - both FAVOR+ implementations) + mlhot.dist.StabiliserExchange the shard's outputs are
+    BIT-IDENTICAL to the same tasks' rows of the un-sharded batch and the averaged gradients equal the un-sharded gradients to
+    float rounding; with the rank-local stabiliser (the default) the rank that does not hold the batch maximum differs."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_strict_worker, args=(r, 2, port, name, opts, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        res = {r: dict(out[r]) for r in range(2)}
+    print(f"{name} {opts}: " + "; ".join(
+        f"rank {r} {m}: mu {'==' if res[r][m]['mu_equal'] else '%.1e' % res[r][m]['mu_err']} loss {res[r][m]['loss_err']:.1e} "
+        f"grad {res[r][m]['grad_err']:.1e}" for r in range(2) for m in ("rank-local", "strict")))
+    for r in range(2):
+        assert res[r]["alone"]
+        st = res[r]["strict"]
+        assert st["mu_equal"] and st["loss_err"] <= 1e-6 and st["grad_err"] <= 2e-6, (r, st)
+        assert st["calls"] == ["fwd", "bwd"]
+    # the default: exactly one rank (the one without the batch's largest key) computes with another stabiliser
+    assert sorted(res[r]["rank-local"]["mu_equal"] for r in range(2)) == [False, True]
+    assert max(res[r]["rank-local"]["mu_err"] for r in range(2)) <= 1e-4        # ... a small effect, as SURVEY 8e(i) says
+
+
 def test_cpu_tensors_are_refused(gpulib):
     from mlhot.binding import MlhotError
     from mlhot.ops import LinearFunction

@@ -5,6 +5,7 @@ import os
 import types
 
 import numpy as np
+import pytest
 import torch
 
 from mlhot import synth
@@ -153,3 +154,24 @@ def test_grad_bucket_deferred_scale_and_overridable_collective():
         scale = b.sync(defer_scale=defer)
         assert scale == (0.5 if defer else 1.0)
         assert torch.equal(lin.weight.grad * scale, torch.ones(2, 3)) and torch.equal(lin.bias.grad * scale, torch.full((2,), 3.0))
+
+
+def test_strict_sharded_parity_option_installs_the_exchange_and_refuses_graph_steps(tmp_path):
+    """config.strict_sharded_parity: ModelTrainer installs mlhot.dist.StabiliserExchange as the attention passes' exchange
+    (mlhot.ops.set_stabiliser_exchange); together with config.graph_steps it is refused (the collective sits between two C calls)."""
+    from mlhot import ops
+    from mlhot.dist import StabiliserExchange
+    from trainer.model_trainer import ModelTrainer
+    model = TinyModel()
+    mk = lambda **kw: ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=torch.optim.SGD(model.parameters(), lr=1e-2),
+                                   config=_cfg(tmp_path, **kw), data=CountingData())
+    try:
+        assert ops._stab_exchange is None
+        mk()
+        assert ops._stab_exchange is None
+        mk(strict_sharded_parity=True)
+        assert isinstance(ops._stab_exchange, StabiliserExchange)
+        with pytest.raises(ValueError):
+            mk(strict_sharded_parity=True, graph_steps=True)
+    finally:
+        ops.set_stabiliser_exchange(None)

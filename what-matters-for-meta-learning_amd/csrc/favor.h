@@ -14,6 +14,7 @@
 // out[t][n][e*H + h] (ANPShapeNet1D.py:113-114).
 #pragma once
 #include "common.h"
+#include "stab_xchg.h"
 #include "foreach.h"
 #include "igemm.h"
 #include "problems.h"
@@ -215,11 +216,12 @@ struct SumRed {
 #define MLHOT_TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 inline int favor_forward(const FavorDims& f, const float* q, const float* k, const float* v, const float* proj,
-                         float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+                         float* out, void* ws, size_t ws_bytes, hipStream_t s, const Stage& st = Stage{}) {
   FavorWs w = favor_carve(f, ws, ws_bytes);
   if (!w.ok) { set_error("favor_fwd: workspace too small"); return MLHOT_ERR_WORKSPACE; }
   const float c = powf((float)f.d, -0.25f), ratio = 1.0f / sqrtf((float)f.m), eps = 1e-4f;
   const size_t rq = f.rows_q(), rk = f.rows_k();
+  if (st.first()) {
   MLHOT_TRY(run_foreach(ScaleCopy{proj, w.pc, c}, (size_t)f.m * f.d, s, "favor.scale_proj"));
   WBlocks pb{}; pb.w[0] = w.pc; pb.b[0] = nullptr; pb.rows = f.m;
   LinearFwd lq{(int)rq, f.m, f.d, q, f.d, pb, w.qf, f.m, ACT_NONE};
@@ -231,6 +233,12 @@ inline int favor_forward(const FavorDims& f, const float* q, const float* k, con
   MLHOT_TRY(run_reduce_seg(FavorRowMax{w.qf, f.m, w.max_q, w.arg_q}, (int)rq, f.m, s, "favor.rowmax_q"));
   MLHOT_TRY(run_reduce_seg(FavorRowMax{w.kf, f.m, w.max_k, w.arg_k}, (int)rk, f.m, s, "favor.rowmax_k"));
   MLHOT_TRY(run_reduce1(FavorGlobalMax{w.max_k, w.arg_k, w.gmax, w.gpos}, (int)rk, s, "favor.gmax"));
+  }
+#ifndef MLHOT_HOSTSIM
+  // strict sharded parity (stab_xchg.h): the rank's maximum goes out, the batch's comes back (and the position with it)
+  if (st.stage == 0) return sx::max_publish(w.gmax, 1, st.x, s);
+  if (st.stage == 1) MLHOT_TRY(sx::max_apply(w.gmax, w.gpos, 1, st.x, s));
+#endif
   MLHOT_TRY(run_foreach(FavorFeat{w.qf, w.diag_q, w.max_q, nullptr, f.m, ratio}, rq * f.m, s, "favor.feat_q"));
   MLHOT_TRY(run_foreach(FavorFeat{w.kf, w.diag_k, nullptr, w.gmax, f.m, ratio}, rk * f.m, s, "favor.feat_k"));
   MLHOT_TRY(run_reduce_seg(FavorS{f, w.qf, w.kf, ratio * eps, w.S}, f.T * f.H * f.Nq * f.Nc, f.m, s, "favor.S"));
@@ -240,11 +248,13 @@ inline int favor_forward(const FavorDims& f, const float* q, const float* k, con
 }
 
 inline int favor_backward(const FavorDims& f, const float* q, const float* k, const float* v, const float* out,
-                          const float* dout, float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, hipStream_t s) {
+                          const float* dout, float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, hipStream_t s,
+                          const Stage& st = Stage{}) {
   FavorWs w = favor_carve(f, ws, ws_bytes);
   if (!w.ok) { set_error("favor_bwd: workspace too small"); return MLHOT_ERR_WORKSPACE; }
   const float c = powf((float)f.d, -0.25f), ratio = 1.0f / sqrtf((float)f.m), eps = 1e-4f;
   const size_t rq = f.rows_q(), rk = f.rows_k(), thn = (size_t)f.T * f.H * f.Nq;
+  if (st.first()) {
   MLHOT_TRY(run_reduce_seg(FavorBwdW{f, out, dout, w.wv}, (int)thn, f.d, s, "favor.bwd.w"));
   MLHOT_TRY(run_reduce_seg(FavorBwdDS{f, dout, v, w.wv, w.D, w.dS}, (int)(thn * f.Nc), f.d, s, "favor.bwd.dS"));
   MLHOT_TRY(run_foreach(FavorBwdDV{f, w.S, w.D, dout, dv}, rk * f.d, s, "favor.bwd.dv"));
@@ -253,6 +263,11 @@ inline int favor_backward(const FavorDims& f, const float* q, const float* k, co
   MLHOT_TRY(run_reduce_seg(RowSum{w.Gq, f.m, w.rsum_q}, (int)rq, f.m, s, "favor.bwd.rsum_q"));
   MLHOT_TRY(run_reduce_seg(RowSum{w.Gk, f.m, w.rsum_k}, (int)rk, f.m, s, "favor.bwd.rsum_k"));
   MLHOT_TRY(run_reduce1(SumRed{w.rsum_k, w.gtotal}, (int)rk, s, "favor.bwd.gtotal"));
+  }
+#ifndef MLHOT_HOSTSIM
+  if (st.stage == 0) return sx::sum_publish(w.gtotal, 1, st.x, s);
+  if (st.stage == 1) MLHOT_TRY(sx::sum_apply(w.gtotal, 1, st.x, w.gtotal, 1, s));
+#endif
   FavorDx xq{(int)rq, f.d, f.m, w.Gq, w.rsum_q, w.arg_q, nullptr, nullptr, w.pc, q, c * c, dq};
   FavorDx xk{(int)rk, f.d, f.m, w.Gk, w.rsum_k, nullptr, w.gpos, w.gtotal, w.pc, k, c * c, dk};
   MLHOT_TRY(run_igemm_auto(xq, s, "favor.bwd.dq"));

@@ -42,6 +42,7 @@ struct Ws {     // carved from the caller's workspace; the forward fills it, the
   float *diag;                    // [rows_q + rows_k] (block order: a block's query rows, then its key rows)
   float *S, *D;                   // [T H][Nq][Nc], [T H][Nq]
   float *gq, *gk, *rs_q, *rs_k;   // backward: G; per-row sums of G, one partial per B1 split: [rows][NSP]
+  float* gt_fix;                  // staged backward only (stab_xchg.h): the other ranks' share of the stabiliser gradient
   int mp, nch, npart;
   bool ok;
 };
@@ -59,6 +60,7 @@ inline Ws carve(const FavorDims& f, void* ws, size_t bytes, size_t* need = nullp
   w.S = a.take<float>(th * f.Nq * f.Nc); w.D = a.take<float>(th * f.Nq);
   w.gq = a.take<float>(rq * w.mp); w.gk = a.take<float>(rk * w.mp);
   w.rs_q = a.take<float>(rq * NSP); w.rs_k = a.take<float>(rk * NSP);
+  w.gt_fix = a.take<float>(4);
   w.ok = a.ok;
   if (need) *need = a.off + 256;
   return w;
@@ -71,6 +73,7 @@ struct Args {
   float* out; const float* dout;
   float *dq, *dk, *dv;
   float c, ratio, re;            // d^-1/4, m^-1/2, ratio * 1e-4
+  const float* gt_fix;           // null unless the backward is staged
 };
 
 // row r of block (t, h): r < Nq -> query row, else key row; returns nullptr past the block
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(256) void b2_kernel(const Args a) {
     sm[tid] = s;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) { if (tid < k) sm[tid] += sm[tid + k]; __syncthreads(); }
-    if (tid == 0) s_gt = sm[0];
+    if (tid == 0) s_gt = sm[0] + (a.gt_fix ? a.gt_fix[0] : 0.f);
   }
   const float* grow[RT];
 #pragma unroll
@@ -611,18 +614,21 @@ inline Args make_args(const FavorDims& f, const Ws& w, const float* q, const flo
   return a;
 }
 inline int forward(const FavorDims& f, const float* q, const float* k, const float* v, const float* proj, float* out, void* ws, size_t ws_bytes,
-                   hipStream_t s) {
+                   hipStream_t s, const Stage& st = Stage{}) {
   const Ws w = carve(f, ws, ws_bytes);
   if (!w.ok) { set_error("favor_fwd: workspace too small"); return MLHOT_ERR_WORKSPACE; }
   Args a = make_args(f, w, q, k, v, proj);
   a.out = out;
   const int th = f.T * f.H, R = f.Nq + f.Nc;
-  {
+  if (st.first()) {
     ProfScope ps("favor.f1", s);
     if (R <= 32) hipLaunchKernelGGL((f1_kernel<2>), dim3(th, w.nch), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((f1_kernel<4>), dim3(th, w.nch), dim3(256), 0, s, a);
   }
   MLHOT_TRY(check_launch("favor.f1"));
+  // strict sharded parity (stab_xchg.h): F2 folds the per-workgroup candidates (wg_v, wg_row, wg_j) into the batch maximum
+  if (st.stage == 0) return sx::max_publish(w.wg_v, th * w.nch, st.x, s);
+  if (st.stage == 1) MLHOT_TRY(sx::max_apply(w.wg_v, w.wg_row, th * w.nch, st.x, s));
   {
     ProfScope ps("favor.f2", s);
     hipLaunchKernelGGL(f2_kernel, dim3(th), dim3(F2_NT), 0, s, a);
@@ -630,17 +636,21 @@ inline int forward(const FavorDims& f, const float* q, const float* k, const flo
   return check_launch("favor.f2");
 }
 inline int backward(const FavorDims& f, const float* q, const float* k, const float* v, const float* proj, const float* out, const float* dout,
-                    float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, hipStream_t s) {
+                    float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, hipStream_t s, const Stage& st = Stage{}) {
   const Ws w = carve(f, ws, ws_bytes);
   if (!w.ok) { set_error("favor_bwd: workspace too small"); return MLHOT_ERR_WORKSPACE; }
   Args a = make_args(f, w, q, k, v, proj);
   a.out = const_cast<float*>(out); a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv;
   const int th = f.T * f.H, R = f.Nq + f.Nc;
-  {
+  if (st.first()) {
     ProfScope ps("favor.b1", s);
     hipLaunchKernelGGL(b1_kernel, dim3(th, NSP), dim3(256), 0, s, a);
   }
   MLHOT_TRY(check_launch("favor.b1"));
+  // strict sharded parity: B2 folds rs_k into the stabiliser's gradient; the other ranks' share arrives through gt_fix
+  const int nrs = f.T * f.Nc * f.H * NSP;
+  if (st.stage == 0) return sx::sum_publish(w.rs_k, nrs, st.x, s);
+  if (st.stage == 1) { MLHOT_TRY(sx::sum_apply(w.rs_k, nrs, st.x, w.gt_fix, 0, s)); a.gt_fix = w.gt_fix; }
   {
     ProfScope ps("favor.b2", s);
     if (R <= 32) hipLaunchKernelGGL((b2_kernel<2>), dim3(th, (f.d + 16 * B2_NT - 1) / (16 * B2_NT)), dim3(256), 0, s, a);
@@ -672,17 +682,18 @@ inline size_t favor_ws_need(const FavorDims& f) {
   return a > b ? a : b;
 }
 inline int favor_fwd_any(const FavorDims& f, const float* q, const float* k, const float* v, const float* proj, float* out, void* ws,
-                         size_t ws_bytes, hipStream_t s) {
+                         size_t ws_bytes, hipStream_t s, const Stage& st = Stage{}) {
 #ifndef MLHOT_HOSTSIM
-  if (favor2_on(f)) return fv::forward(f, q, k, v, proj, out, ws, ws_bytes, s);
+  if (favor2_on(f)) return fv::forward(f, q, k, v, proj, out, ws, ws_bytes, s, st);
 #endif
-  return favor_forward(f, q, k, v, proj, out, ws, ws_bytes, s);
+  return favor_forward(f, q, k, v, proj, out, ws, ws_bytes, s, st);
 }
 inline int favor_bwd_any(const FavorDims& f, const float* q, const float* k, const float* v, const float* proj, const float* out,
-                         const float* dout, float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, hipStream_t s) {
+                         const float* dout, float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, hipStream_t s,
+                         const Stage& st = Stage{}) {
 #ifndef MLHOT_HOSTSIM
-  if (favor2_on(f)) return fv::backward(f, q, k, v, proj, out, dout, dq, dk, dv, ws, ws_bytes, s);
+  if (favor2_on(f)) return fv::backward(f, q, k, v, proj, out, dout, dq, dk, dv, ws, ws_bytes, s, st);
 #endif
-  return favor_backward(f, q, k, v, out, dout, dq, dk, dv, ws, ws_bytes, s);
+  return favor_backward(f, q, k, v, out, dout, dq, dk, dv, ws, ws_bytes, s, st);
 }
 }  // namespace mlhot

@@ -179,6 +179,30 @@ int mlhot_favor_bwd(const float* q, const float* k, const float* v, const float*
   if (T <= 0 || H <= 0 || Nq <= 0 || Nc <= 0 || d <= 0 || m <= 0) { set_error("favor_bwd: bad argument"); return MLHOT_ERR_ARG; }
   return favor_bwd_any(FavorDims{T, H, Nq, Nc, d, m}, q, k, v, proj, out, dout, dq, dk, dv, ws, ws_bytes, (hipStream_t)stream);
 }
+// Staged passes (strict sharded parity of the key stabiliser, csrc/stab_xchg.h): stage 0 runs up to the rank-local scalar and
+// publishes it in xchg, stage 1 takes the batch-wide scalar from xchg and runs the rest.
+static int staged_args(int stage, float* xchg, const char* what) {
+  if ((stage != 0 && stage != 1) || !xchg) { set_error("%s: stage must be 0 or 1 and xchg a device block of 4 floats", what); return MLHOT_ERR_ARG; }
+#ifdef MLHOT_HOSTSIM
+  set_error("%s: GPU build only", what);
+  return MLHOT_ERR_UNSUPPORTED;
+#else
+  return MLHOT_OK;
+#endif
+}
+int mlhot_favor_fwd_staged(const float* q, const float* k, const float* v, const float* proj, int T, int H, int Nq, int Nc,
+                           int d, int m, float* out, void* ws, size_t ws_bytes, int stage, float* xchg, void* stream) {
+  if (T <= 0 || H <= 0 || Nq <= 0 || Nc <= 0 || d <= 0 || m <= 0) { set_error("favor_fwd_staged: bad argument"); return MLHOT_ERR_ARG; }
+  MLHOT_TRY(staged_args(stage, xchg, "favor_fwd_staged"));
+  return favor_fwd_any(FavorDims{T, H, Nq, Nc, d, m}, q, k, v, proj, out, ws, ws_bytes, (hipStream_t)stream, Stage{stage, xchg});
+}
+int mlhot_favor_bwd_staged(const float* q, const float* k, const float* v, const float* proj, int T, int H, int Nq, int Nc,
+                           int d, int m, const float* out, const float* dout, float* dq, float* dk, float* dv, void* ws,
+                           size_t ws_bytes, int stage, float* xchg, void* stream) {
+  if (T <= 0 || H <= 0 || Nq <= 0 || Nc <= 0 || d <= 0 || m <= 0) { set_error("favor_bwd_staged: bad argument"); return MLHOT_ERR_ARG; }
+  MLHOT_TRY(staged_args(stage, xchg, "favor_bwd_staged"));
+  return favor_bwd_any(FavorDims{T, H, Nq, Nc, d, m}, q, k, v, proj, out, dout, dq, dk, dv, ws, ws_bytes, (hipStream_t)stream, Stage{stage, xchg});
+}
 
 // ---- losses -----------------------------------------------------------------------------------
 int mlhot_loss_fwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim, float* loss, void* stream) {
@@ -430,6 +454,20 @@ int mlhot_np_vanilla_bwd(const mlhot_np_dims* d, const mlhot_np_params* p, const
                          void* scratch, size_t scratch_bytes, void* stream) {
   if (!d || !p || !g) { set_error("np_vanilla_bwd: null dims/params/grads"); return MLHOT_ERR_ARG; }
   return np_backward(*d, *p, ctx_x, ctx_y, qry_x, mu, dmu, *g, saved, scratch, scratch_bytes, (hipStream_t)stream);
+}
+int mlhot_np_vanilla_fwd_staged(const mlhot_np_dims* d, const mlhot_np_params* p, const float* ctx_x, const float* ctx_y,
+                                const float* qry_x, float* mu, void* saved, void* scratch, size_t scratch_bytes, int stage, float* xchg,
+                                void* stream) {
+  if (!d || !p) { set_error("np_vanilla_fwd_staged: null dims/params"); return MLHOT_ERR_ARG; }
+  MLHOT_TRY(staged_args(stage, xchg, "np_vanilla_fwd_staged"));
+  return np_forward(*d, *p, ctx_x, ctx_y, qry_x, mu, saved, scratch, scratch_bytes, (hipStream_t)stream, Stage{stage, xchg});
+}
+int mlhot_np_vanilla_bwd_staged(const mlhot_np_dims* d, const mlhot_np_params* p, const float* ctx_x, const float* ctx_y,
+                                const float* qry_x, const float* mu, const float* dmu, const mlhot_np_grads* g, const void* saved,
+                                void* scratch, size_t scratch_bytes, int stage, float* xchg, void* stream) {
+  if (!d || !p || !g) { set_error("np_vanilla_bwd_staged: null dims/params/grads"); return MLHOT_ERR_ARG; }
+  MLHOT_TRY(staged_args(stage, xchg, "np_vanilla_bwd_staged"));
+  return np_backward(*d, *p, ctx_x, ctx_y, qry_x, mu, dmu, *g, saved, scratch, scratch_bytes, (hipStream_t)stream, Stage{stage, xchg});
 }
 
 }  // extern "C"

@@ -190,7 +190,7 @@ inline int tail_launch(K kernel, int grid, int block, size_t lds, const A& args,
 }
 
 inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, float* mu,
-                              const NpBuf& b, const NpScratch& sc, hipStream_t s) {
+                              const NpBuf& b, const NpScratch& sc, hipStream_t s, const Stage& st = Stage{}) {
   const tf::TailDims td = tail_dims(d);
   const tf::TailParams tp = tail_params(p);
   FavorDims f{d.T, MLHOT_HEADS, d.Nq, d.Nc, d.dim_w, d.m_feat};
@@ -200,8 +200,13 @@ inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   // phases (1 / 2 / 4: forward A / B / C, 8 / 16 / 32: backward C / B / A; default 63 = all; per-phase A/B experiments)
   const int spec = ts::applies(td) ? g_opt.tail_spec : 0;
   tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, w.pc, w.max_k, w.arg_k, b.wot};
-  if (spec & 1) MLHOT_TRY(tail_launch(ts::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, ts::phaseA_lds_bytes(), a, s, "tail.A"));
-  else MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
+  if (st.first()) {
+    if (spec & 1) MLHOT_TRY(tail_launch(ts::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, ts::phaseA_lds_bytes(), a, s, "tail.A"));
+    else MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
+  }
+  // strict sharded parity (stab_xchg.h): phase B folds the (task, head) shares (max_k, arg_k) into the batch-global key stabiliser
+  if (st.stage == 0) return sx::max_publish(w.max_k, d.T * MLHOT_HEADS, st.x, s);
+  if (st.stage == 1) MLHOT_TRY(sx::max_apply(w.max_k, w.arg_k, d.T * MLHOT_HEADS, st.x, s));
   tf::PhaseBArgs bb{td, tp, b.dec_in, b.rs, b.qh, b.vh, b.kh, w.pc, w.max_k, w.arg_k, w.qf, w.kf, w.S, w.D, w.gmax, w.arg_q, w.gpos, b.merged, sc.d_merged, b.wot};   // sc.d_merged: forward scratch for the heads' _W shares
   if (spec & 2) MLHOT_TRY(tail_launch(ts::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 512, ts::phaseB_lds_bytes(), bb, s, "tail.B"));
   else MLHOT_TRY(tail_launch(tf::phaseB_fwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_lds_bytes(td), bb, s, "tail.B"));
@@ -278,7 +283,7 @@ inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
 
 inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu,
                                const float* dmu, const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s,
-                               PendingSum* later) {
+                               PendingSum* later, const Stage& st = Stage{}) {
   const tf::TailDims td = tail_dims(d);
   const tf::TailParams tp = tail_params(p);
   const tf::TailSlab sl = tf::tail_slab_layout(td);
@@ -288,13 +293,20 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   float* part_k = w.rsum_k;   // [T*H]
   tf::PhaseCBwdArgs c{td, tp, sl, dmu, mu, b.d2, b.d1, b.dec_in, b.rr, sc.d_dec_in, sc.d_rr, sc.tail_slab};
   const int spec = ts::applies(td) ? g_opt.tail_spec : 0;
-  if (spec & 8) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel, d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
-  else MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
+  if (st.first()) {
+    if (spec & 8) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel, d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
+    else MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
+  }
   // sc.dqh / dkh / dvh double as the heads' input-gradient shares [T*H][N][dw] (same sizes)
   tf::PhaseBBwdArgs bb{td, tp, sl, b.qh, b.kh, b.vh, w.pc, w.qf, w.kf, w.S, w.D, b.merged, sc.d_rr, w.arg_q,
                        b.dec_in, b.cat_in, b.rs, b.wot, sc.dqh, sc.dkh, sc.dvh, part_k, sc.tail_slab};
-  if (spec & 16) MLHOT_TRY(tail_launch(ts::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, ts::phaseB_bwd_lds_bytes(), bb, s, "tail.bwd.B"));
-  else MLHOT_TRY(tail_launch(tf::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_bwd_lds_bytes(td), bb, s, "tail.bwd.B"));
+  if (st.first()) {
+    if (spec & 16) MLHOT_TRY(tail_launch(ts::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, ts::phaseB_bwd_lds_bytes(), bb, s, "tail.bwd.B"));
+    else MLHOT_TRY(tail_launch(tf::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_bwd_lds_bytes(td), bb, s, "tail.bwd.B"));
+  }
+  // strict sharded parity: phase A folds part_k into the stabiliser's gradient and routes it to the arg-max key's task
+  if (st.stage == 0) return sx::sum_publish(part_k, d.T * MLHOT_HEADS, st.x, s);
+  if (st.stage == 1) MLHOT_TRY(sx::sum_apply(part_k, d.T * MLHOT_HEADS, st.x, part_k, 1, s));
   tf::PhaseABwdArgs a{td, tp, sl, ctx_y, b.cat_in, b.h[0], b.h[1], sc.dqh, sc.dkh, sc.dvh, w.pc, part_k, w.gpos,
                       sc.d_dec_in, sc.d_cat_in, sc.tail_slab};
   if (spec & 32) MLHOT_TRY(tail_launch(ts::phaseA_bwd_kernel, d.T, 512, ts::phaseA_bwd_lds_bytes(), a, s, "tail.bwd.A"));
@@ -382,8 +394,10 @@ inline size_t np_grads_flat_layout(const mlhot_np_dims& d, mlhot_np_grads& o) {
 }
 
 inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_x, const float* ctx_y,
-                      const float* qry_x, float* mu, void* saved, void* scratch, size_t scratch_bytes, hipStream_t s) {
+                      const float* qry_x, float* mu, void* saved, void* scratch, size_t scratch_bytes, hipStream_t s,
+                      const Stage& st = Stage{}) {
   MLHOT_TRY(np_check_dims(d));
+  MLHOT_TRY(stage_check(st, "np_vanilla_fwd"));
   NpBuf b = np_saved_carve(d, saved, (size_t)-1 / 2);
   NpScratch sc = np_scratch_carve(d, scratch, scratch_bytes);
   if (!sc.ok) { set_error("np_vanilla_fwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
@@ -391,9 +405,18 @@ inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const fl
   const int ldc = dw + dw / 4, ldd = dw + d.dim_z;
 
   // E1 on [context | target] images in one pass; rows land in cat_in / dec_in
-  MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s));
 #ifndef MLHOT_HOSTSIM
-  if (tail_fused_applies(d)) return tail_forward_fused(d, p, ctx_y, mu, b, sc, s);
+  const bool fused = tail_fused_applies(d);
+#else
+  const bool fused = false;
+#endif
+  if (st.staged() && !fused) {      // the staged pass is built on the fused attention tail's launch boundaries
+    set_error("np_vanilla_fwd: staged passes need the fused attention tail (attention aggregation, Nc, Nq <= 16, option tail_fused)");
+    return MLHOT_ERR_UNSUPPORTED;
+  }
+  if (st.first()) MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s));
+#ifndef MLHOT_HOSTSIM
+  if (fused) return tail_forward_fused(d, p, ctx_y, mu, b, sc, s, st);
   if (cnp_fused_applies(d)) return cnp_forward_fused(d, p, ctx_y, mu, b, s);
 #endif
 
@@ -437,8 +460,9 @@ inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const fl
 
 inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_x, const float* ctx_y,
                        const float* qry_x, const float* mu, const float* dmu, const mlhot_np_grads& g,
-                       const void* saved, void* scratch, size_t scratch_bytes, hipStream_t s) {
+                       const void* saved, void* scratch, size_t scratch_bytes, hipStream_t s, const Stage& st = Stage{}) {
   MLHOT_TRY(np_check_dims(d));
+  MLHOT_TRY(stage_check(st, "np_vanilla_bwd"));
   NpBuf b = np_saved_carve(d, (void*)saved, (size_t)-1 / 2);
   NpScratch sc = np_scratch_carve(d, scratch, scratch_bytes);
   if (!sc.ok) { set_error("np_vanilla_bwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
@@ -447,10 +471,15 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
   const int out_act = d.out_tanh ? ACT_TANH : ACT_NONE;
 
 #ifndef MLHOT_HOSTSIM
+  if (st.staged() && !tail_fused_applies(d)) {
+    set_error("np_vanilla_bwd: staged passes need the fused attention tail (attention aggregation, Nc, Nq <= 16, option tail_fused)");
+    return MLHOT_ERR_UNSUPPORTED;
+  }
   if (tail_fused_applies(d) || cnp_fused_applies(d)) {
     PendingSum tail_sum{};       // the tail's per-task slabs: summed by the encoder backward's final reduce launch when contiguous
-    if (tail_fused_applies(d)) MLHOT_TRY(tail_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum));
+    if (tail_fused_applies(d)) MLHOT_TRY(tail_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum, st));
     else MLHOT_TRY(cnp_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum));
+    if (st.stage == 0) return MLHOT_OK;
     return enc_backward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{sc.d_cat_in, ldc, Rc, sc.d_dec_in, ldd}, b.enc, g.enc, sc.enc, sc.enc_bytes, s,
                         &tail_sum);
   }

@@ -150,6 +150,8 @@ class MlhotLib:
         c.mlhot_agg_bwd.argtypes = [i, P, P, P, P, P, P, i, i, i, P, P, P]
         c.mlhot_favor_fwd.argtypes = [P, P, P, P, i, i, i, i, i, i, P, P, z, P]
         c.mlhot_favor_bwd.argtypes = [P, P, P, P, i, i, i, i, i, i, P, P, P, P, P, P, z, P]
+        c.mlhot_favor_fwd_staged.argtypes = [P, P, P, P, i, i, i, i, i, i, P, P, z, i, P, P]
+        c.mlhot_favor_bwd_staged.argtypes = [P, P, P, P, i, i, i, i, i, i, P, P, P, P, P, P, z, i, P, P]
         c.mlhot_loss_fwd.argtypes = [i, P, P, i, i, i, P, P]
         c.mlhot_loss_bwd.argtypes = [i, P, P, i, i, i, P, P, P]
         c.mlhot_conv2d_bwd_scratch_bytes.restype = C.c_size_t
@@ -169,6 +171,8 @@ class MlhotLib:
         c.mlhot_spatial_mean_bwd.argtypes = [P, P, i, i, P]
         c.mlhot_np_vanilla_fwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, P, z, P]
         c.mlhot_np_vanilla_bwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, C.POINTER(NpGrads), P, P, z, P]
+        c.mlhot_np_vanilla_fwd_staged.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, P, z, i, P, P]
+        c.mlhot_np_vanilla_bwd_staged.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, C.POINTER(NpGrads), P, P, z, i, P, P]
         for which, st in ((0, NpDims), (1, NpParams), (2, NpGrads)):
             if c.mlhot_np_struct_bytes(which) != C.sizeof(st):
                 raise MlhotError(f"mlhot: ABI struct size mismatch for {st.__name__}")
@@ -592,7 +596,17 @@ class MlhotLib:
         return drs, dlv
 
     # ---- FAVOR+ --------------------------------------------------------------------------------
-    def favor_fwd(self, q, k, v, proj):
+    @staticmethod
+    def _staged(call, exchange, direction):
+        """Run `call(stage, xchg_ptr)` as the two staged halves around the caller's collective (include/mlhot.h, "strict sharded
+        parity"): exchange = (object with forward(x) / backward(x), x = 4 floats on the device)."""
+        ex, x = exchange
+        _chk(x)
+        call(0, _ptr(x))
+        (ex.forward if direction == "fwd" else ex.backward)(x)
+        call(1, _ptr(x))
+
+    def favor_fwd(self, q, k, v, proj, exchange=None):
         """q [T,Nq,H,d], k/v [T,Nc,H,d], proj [m,d] -> out [T,Nq,d*H] (merged order), ws"""
         _chk(q, k, v, proj)
         T, Nq, H, d = q.shape
@@ -600,15 +614,25 @@ class MlhotLib:
         out = torch.empty(T, Nq, d * H, device=q.device)
         wb = self.c.mlhot_favor_ws_bytes(T, H, Nq, Nc, d, m)
         ws = self._bytes(wb, q)
+        if exchange is not None:
+            self._staged(lambda st, xp: self._rc(self.c.mlhot_favor_fwd_staged(
+                _ptr(q), _ptr(k), _ptr(v), _ptr(proj), T, H, Nq, Nc, d, m, _ptr(out), _ptr(ws), wb, st, xp, _stream(q)),
+                "mlhot_favor_fwd_staged"), exchange, "fwd")
+            return out, ws
         self._rc(self.c.mlhot_favor_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(proj), T, H, Nq, Nc, d, m, _ptr(out), _ptr(ws), wb, _stream(q)),
                  "mlhot_favor_fwd")
         return out, ws
 
-    def favor_bwd(self, q, k, v, proj, out, dout, ws):
+    def favor_bwd(self, q, k, v, proj, out, dout, ws, exchange=None):
         _chk(dout)
         T, Nq, H, d = q.shape
         Nc, m = k.shape[1], proj.shape[0]
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        if exchange is not None:
+            self._staged(lambda st, xp: self._rc(self.c.mlhot_favor_bwd_staged(
+                _ptr(q), _ptr(k), _ptr(v), _ptr(proj), T, H, Nq, Nc, d, m, _ptr(out), _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv),
+                _ptr(ws), ws.numel(), st, xp, _stream(q)), "mlhot_favor_bwd_staged"), exchange, "bwd")
+            return dq, dk, dv
         self._rc(self.c.mlhot_favor_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(proj), T, H, Nq, Nc, d, m, _ptr(out), _ptr(dout),
                                         _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), ws.numel(), _stream(q)), "mlhot_favor_bwd")
         return dq, dk, dv
@@ -700,18 +724,23 @@ class MlhotLib:
             s.proj = proj.data_ptr()
         return s
 
-    def np_vanilla_fwd(self, dims, params, ctx_x, ctx_y, qry_x, proj=None):
+    def np_vanilla_fwd(self, dims, params, ctx_x, ctx_y, qry_x, proj=None, exchange=None):
         _chk(ctx_x, ctx_y, qry_x, proj, *params.values())
         mu = torch.empty(dims.T, dims.Nq, dims.y_dim, device=qry_x.device)
         saved = self._bytes(self.c.mlhot_np_saved_bytes(C.byref(dims)), qry_x)
         sb = self.c.mlhot_np_scratch_bytes(C.byref(dims))
         scratch = self._bytes(sb, qry_x)
         ps = self.np_struct(NpParams, dims, params, proj)
+        if exchange is not None:
+            self._staged(lambda st, xp: self._rc(self.c.mlhot_np_vanilla_fwd_staged(
+                C.byref(dims), C.byref(ps), _ptr(ctx_x), _ptr(ctx_y), _ptr(qry_x), _ptr(mu), _ptr(saved), _ptr(scratch), sb, st, xp,
+                _stream(qry_x)), "mlhot_np_vanilla_fwd_staged"), exchange, "fwd")
+            return mu, saved, scratch
         self._rc(self.c.mlhot_np_vanilla_fwd(C.byref(dims), C.byref(ps), _ptr(ctx_x), _ptr(ctx_y), _ptr(qry_x), _ptr(mu),
                                              _ptr(saved), _ptr(scratch), sb, _stream(qry_x)), "mlhot_np_vanilla_fwd")
         return mu, saved, scratch
 
-    def np_vanilla_bwd(self, dims, params, ctx_x, ctx_y, qry_x, mu, dmu, saved, scratch=None, proj=None):
+    def np_vanilla_bwd(self, dims, params, ctx_x, ctx_y, qry_x, mu, dmu, saved, scratch=None, proj=None, exchange=None):
         _chk(dmu, mu)
         # one flat gradient buffer in the library's preferred order; the per-parameter gradients are views of it
         offs = NpGrads()
@@ -727,6 +756,11 @@ class MlhotLib:
             scratch = self._bytes(sb, qry_x)
         ps = self.np_struct(NpParams, dims, params, proj)
         gs = self.np_struct(NpGrads, dims, grads)
+        if exchange is not None:
+            self._staged(lambda st, xp: self._rc(self.c.mlhot_np_vanilla_bwd_staged(
+                C.byref(dims), C.byref(ps), _ptr(ctx_x), _ptr(ctx_y), _ptr(qry_x), _ptr(mu), _ptr(dmu), C.byref(gs), _ptr(saved),
+                _ptr(scratch), sb, st, xp, _stream(qry_x)), "mlhot_np_vanilla_bwd_staged"), exchange, "bwd")
+            return grads
         self._rc(self.c.mlhot_np_vanilla_bwd(C.byref(dims), C.byref(ps), _ptr(ctx_x), _ptr(ctx_y), _ptr(qry_x), _ptr(mu), _ptr(dmu),
                                              C.byref(gs), _ptr(saved), _ptr(scratch), sb, _stream(qry_x)), "mlhot_np_vanilla_bwd")
         return grads

@@ -32,6 +32,53 @@ def task_slice(n_tasks, rank, world):
     return slice(rank * per, (rank + 1) * per)
 
 
+class StabiliserExchange:
+    """Strict sharded parity of the FAVOR+ key stabiliser (fast_attention.py:96-97: torch.max over the keys of the WHOLE batch).
+
+    With the meta-batch sharded over ranks every rank's FAVOR+ pass sees only its own tasks' keys.  The staged entry points of
+    include/mlhot.h stop where the rank-local scalar exists; this object is the collective in between, on the 4-float device
+    block `x` (csrc/stab_xchg.h):
+      forward(x):  x[0] <- MAX over ranks of x[0]; x[1] <- 1 on the lowest rank whose maximum equals it (it holds the arg-max key),
+                   0 elsewhere - ONE collective on `world` floats, the rest is element arithmetic on the device (no host sync)
+      backward(x): x[2] <- SUM over ranks of x[2] (the stabiliser's gradient; the owner routes it to its arg-max key).  The ranks'
+                   losses are means over their own tasks and GradBucket averages the gradients, so the owner's contribution is
+                   the plain sum: mean_r(sum_r' g_r' [r == owner]) = (1 / world) sum_r' g_r', the un-sharded gradient.
+    Install with mlhot.ops.set_stabiliser_exchange(StabiliserExchange()) (ModelTrainer does, for config.strict_sharded_parity);
+    without it each rank uses its own maximum (a <= 1e-6 effect on the loss)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.calls = []                 # "fwd" / "bwd", in issue order (tests)
+
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def forward(self, x):
+        self.calls.append("fwd")
+        world = self._world()
+        if world == 1:
+            x[1] = 1.0
+            return
+        rank = dist.get_rank(self.group)
+        # an all-gather spelled as a SUM all-reduce of a one-hot vector (exact: every other rank adds zeros; and the one form
+        # every backend takes for device tensors)
+        vals = torch.zeros(world, device=x.device, dtype=x.dtype)
+        vals[rank] = x[0]
+        dist.all_reduce(vals, op=dist.ReduceOp.SUM, group=self.group)
+        g = vals.max()
+        idx = torch.arange(world, device=x.device, dtype=torch.float32)
+        owner = torch.where(vals == g, idx, torch.full_like(idx, float(world))).min()
+        x[0] = g
+        x[1] = (owner == rank).to(x.dtype)
+
+    def backward(self, x):
+        self.calls.append("bwd")
+        if self._world() > 1:
+            s = x[2:3].clone()
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+            x[2:3] = s
+
+
 class GradBucket:
     """One flat fp32 bucket for every parameter that receives a gradient.
 

@@ -15,6 +15,17 @@ from .binding import MlhotError
 saved_taps = None
 
 
+# Strict sharded parity of the FAVOR+ key stabiliser (mlhot.dist.StabiliserExchange): when set, the attention passes run as two
+# staged calls around exchange.forward(x) / exchange.backward(x) on a 4-float device block (include/mlhot.h, "strict sharded parity").
+_stab_exchange = None
+
+
+def set_stabiliser_exchange(exchange):
+    """exchange: an object with forward(x) / backward(x) (x: 4 floats on the device), or None for the rank-local stabiliser."""
+    global _stab_exchange
+    _stab_exchange = exchange
+
+
 def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -35,7 +46,9 @@ class VanillaNPFunction(torch.autograd.Function):
         L = lib()
         ctx_x, ctx_y, qry_x = _c(ctx_x.float()), _c(ctx_y.float()), _c(qry_x.float())
         pd = {k: _c(p.detach()) for k, p in zip(keys, params)}
-        mu, saved, scratch = L.np_vanilla_fwd(dims, pd, ctx_x, ctx_y, qry_x, proj)
+        # the exchange only concerns the attention models with a context (the empty-context branch has no keys)
+        ctx.xchg = (_stab_exchange, torch.zeros(4, device=qry_x.device)) if _stab_exchange is not None and proj is not None and dims.Nc > 0 else None
+        mu, saved, scratch = L.np_vanilla_fwd(dims, pd, ctx_x, ctx_y, qry_x, proj, exchange=ctx.xchg)
         if saved_taps is not None:
             saved_taps.append(("np", dims, saved))
         ctx.dims, ctx.keys, ctx.proj = dims, keys, proj
@@ -47,7 +60,7 @@ class VanillaNPFunction(torch.autograd.Function):
     def backward(ctx, dmu):
         ctx_x, ctx_y, qry_x, mu, saved, *params = ctx.saved_tensors
         pd = dict(zip(ctx.keys, params))
-        grads = lib().np_vanilla_bwd(ctx.dims, pd, ctx_x, ctx_y, qry_x, mu, _c(dmu), saved, ctx.scratch, ctx.proj)
+        grads = lib().np_vanilla_bwd(ctx.dims, pd, ctx_x, ctx_y, qry_x, mu, _c(dmu), saved, ctx.scratch, ctx.proj, exchange=ctx.xchg)
         ctx.scratch = None
         used = used_param_keys(ctx.keys, ctx.dims.Nc)
         return (None, None, None, None, None, None) + tuple(grads[k] if k in used else None for k in ctx.keys)
@@ -178,14 +191,15 @@ class FavorFunction(torch.autograd.Function):
     def forward(ctx, q, k, v, proj):
         _need_gpu(q, k, v, proj)
         q, k, v, proj = _c(q), _c(k), _c(v), _c(proj)
-        out, ws = lib().favor_fwd(q, k, v, proj)
+        ctx.xchg = (_stab_exchange, torch.zeros(4, device=q.device)) if _stab_exchange is not None else None
+        out, ws = lib().favor_fwd(q, k, v, proj, exchange=ctx.xchg)
         ctx.save_for_backward(q, k, v, proj, out, ws)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, proj, out, ws = ctx.saved_tensors
-        dq, dk, dv = lib().favor_bwd(q, k, v, proj, out, _c(dout), ws)
+        dq, dk, dv = lib().favor_bwd(q, k, v, proj, out, _c(dout), ws, exchange=ctx.xchg)
         return dq, dk, dv, None
 
 

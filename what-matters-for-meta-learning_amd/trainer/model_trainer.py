@@ -14,6 +14,12 @@ iteration (autograd bookkeeping, ~20 launches, the optimizer) costs about twice 
 tens of microseconds.  One graph per batch shape (the context size is drawn per iteration, dataset/shapenet_1d.py:120); the
 first iteration of a shape runs eagerly and doubles as the warm-up, the second captures.  The loss is then fetched every
 `config.log_every` iterations only (default 1 = the reference's per-iteration log and finiteness check).
+
+`config.strict_sharded_parity = True` (off by default; attention models on more than one rank): the FAVOR+ key stabiliser is the
+maximum over the keys of the WHOLE meta-batch as in the reference's single-process batch (fast_attention.py:96-97), not of the
+rank's shard - one scalar all-gather in the forward and one scalar all-reduce in the backward
+(mlhot.dist.StabiliserExchange, include/mlhot.h "strict sharded parity").  Eager iterations only: the exchange runs between
+two C calls, so it cannot sit inside a replayed hipGraph.
 """
 import math
 import os
@@ -33,6 +39,12 @@ class ModelTrainer(BaseTrainer):
         # before the backward ends (ResNet family: everything but the image trunks) all-reduce them under the rest of the backward
         early = model.early_grad_parameters() if hasattr(model, "early_grad_parameters") else None
         self.bucket = GradBucket(model.parameters(), side_stream=torch.device(config.device).type == "cuda", early=early)
+        if getattr(config, "strict_sharded_parity", False):
+            if getattr(config, "graph_steps", False):
+                raise ValueError("config.strict_sharded_parity runs a collective between two C calls of the forward: not with config.graph_steps")
+            from mlhot import ops
+            from mlhot.dist import StabiliserExchange
+            ops.set_stabiliser_exchange(StabiliserExchange())
         self.ingest, self._staged = None, None
         self._prefetch = False          # set per iteration by train(): may the NEXT training batch be drawn right away?
         self.rank0 = dist_rank() == 0   # files / logs / TensorBoard are rank 0's business (every rank holds the same weights)
