@@ -83,8 +83,9 @@ if raw[0][0]:
     print("conv12 wgrad per-wave band timeline [previous band's MFMAs done, barrier passed, conv1 + dY staged, barrier passed, MFMAs done] (cycles):")
     for w, r in enumerate(raw):
         print("  wave %2d" % w, [x - t0 for x in r])
-c3t = ts.cpu()[340:353].tolist()
+c3t = ts.cpu()[340:356].tolist()
 if c3t[0]:
+    print("conv3 fwd prologue: weight loads landed %d, staged in LDS (barrier passed) %d" % (c3t[14] - c3t[0], c3t[13] - c3t[0]))
     print("conv3 fwd, workgroup 0 (cycles from entry): weights in registers %d, first unit staged %d, units [MFMAs + store done, barrier passed]:" % (c3t[1] - c3t[0], c3t[2] - c3t[0]),
           [[c3t[3 + 2 * k] - c3t[0], c3t[4 + 2 * k] - c3t[0]] for k in range(4) if c3t[3 + 2 * k]], "exit", c3t[12] - c3t[0])
 pro = ts.cpu()[502:507].tolist()

@@ -97,3 +97,34 @@ def test_forward_k_step_order_matches_the_weight_registers():
         assert ci == list(range(32))
         ci3 = sorted(16 * ((ks % 12) >> 2) + 4 * lq + (ks & 3) for ks in range(12 * tap, 12 * tap + 12) for lq in range(4))
         assert ci3 == list(range(48))
+
+
+def test_conv3_forward_weight_staging_is_tap_major_and_conflict_free():
+    # csrc/conv3_tc.h conv3w_stage_tap_major<512, 472, 52>: LDS word of W[co][ci][tap] = co * 472 + tap * 52 + ci; a lane (lr -> co,
+    # lq) gathers the four channels 16 g + 4 lq + j of k-steps (tap, g, j) with ONE ds_read_b128 (27 per lane for its 108 weights)
+    S, TS = 472, 52
+    for grp in _groups_b128():
+        words = []
+        for lane in grp:
+            lr, lq = lane & 15, lane >> 4
+            words += [(lr * S + 4 * lq + q) % 64 for q in range(4)]
+        assert len(set(words)) == 64
+    assert 64 * S * 4 <= 160 * 1024 and 9 * TS <= S and TS % 4 == 0 and S % 4 == 0       # fits, rows do not overlap, 16-byte reads
+    # staging items (co, ci) = tid + 512 j: every weight lands exactly once ...
+    seen = set()
+    for i in range(64 * 48):
+        co, ci = divmod(i, 48)
+        for t in range(9):
+            seen.add(co * S + t * TS + ci)
+    assert len(seen) == 64 * 432
+    # ... and the 32 lanes of a store (consecutive items, one tap) are at most 2-way on the 32 banks (the row seam: 472 = 24 mod 32)
+    worst = 0
+    for base in range(0, 64 * 48, 32):
+        banks = {}
+        for i in range(base, base + 32):
+            co, ci = divmod(i, 48)
+            banks[(co * S + ci) % 32] = banks.get((co * S + ci) % 32, 0) + 1
+        worst = max(worst, max(banks.values()))
+    assert worst <= 2
+    # the gather's k-step order: quad qd = 3 tap + g -> registers 4 qd + j = 12 tap + 4 g + j, the order the MFMA loop consumes
+    assert [(4 * qd + j) for qd in range(27) for j in range(4)] == [12 * (qd // 3) + 4 * (qd % 3) + j for qd in range(27) for j in range(4)]

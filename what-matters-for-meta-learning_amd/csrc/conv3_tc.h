@@ -46,6 +46,39 @@ __device__ __forceinline__ void conv3w_stage(float* stage, const float* __restri
     }
   }
 }
+// The forward's variant: rows re-ordered [co][tap][ci 48 + 4] (tap stride TS_ = 52, row stride S_ = 472 words) so that the four
+// weights of a lane's k-steps (tap, g, j = 0..3) - input channels 16 g + 4 lq + j - are ONE ds_read_b128: 27 gather reads per
+// lane instead of 108 ds_read_b32 that were 2-way conflicted (a row of 433 words put lr and lr + 4 of the other lq on one bank),
+// (tests/test_index_maps.py restates the bank counts).
+template <int NTHREADS, int S_, int TS_>
+__device__ __forceinline__ void conv3w_stage_tap_major(float* stage, const float* __restrict__ w, int tid) {
+  // item = (row co, input channel ci): its 9 taps are 9 consecutive words of the [64][48][9] matrix (36 bytes - dword loads, the
+  // lanes of a wave cover consecutive channels: whole cache lines), stored at ONE lane address + compile-time tap steps; the lanes'
+  // words are consecutive channels: no bank conflicts inside a row.  (As float4 items the four words of an item were four
+  // (ci, tap) pairs with a wrap in between: a compare, two selects and a multiply-add per store.)
+  constexpr int NI = 64 * 48, CNT = (NI + NTHREADS - 1) / NTHREADS;
+  float v[CNT][9];
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int i = tid + j * NTHREADS;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[j][t] = i < NI ? w[9 * i + t] : 0.f;
+  }
+#ifdef MLHOT_TS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  C3_TS(14);
+#endif
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int i = tid + j * NTHREADS;
+    if (i < NI) {
+      const int r = i / 48, ci = i - 48 * r;
+      float* d = stage + r * S_ + ci;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) d[t * TS_] = v[j][t];
+    }
+  }
+}
 __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 constexpr int CIN = 48, COUT = 64, KW = 432;
@@ -64,7 +97,7 @@ constexpr int CIN = 48, COUT = 64, KW = 432;
 // lanes of every ds_read_b128 group cover the 64 banks once (checked below).
 constexpr int F_RS = 24, F_CS = 52, F_ROW = F_RS * F_CS, F_PATCH = 9 * F_ROW;       // 11,232 floats = 44.9 KB per buffer
 constexpr int F_NT = 512;
-constexpr int F_WLD = KW + 1;                       // weight staging rows [co][433]: odd stride, conflict-free lane reads
+constexpr int F_WTS = 52, F_WLD = 472;              // weight staging [co][tap][ci 48 + 4], rows of 472 words (conv3w_stage_tap_major)
 constexpr int F_LDS = 2 * F_PATCH > COUT * F_WLD ? 2 * F_PATCH : COUT * F_WLD;
 constexpr bool f_b128_conflict_free() {
   // lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS): {0-3,12-15,20-27}, {4-11,16-19,28-31}, the same + 32
@@ -129,13 +162,19 @@ __global__ __launch_bounds__(F_NT) void conv3_fwd_kernel(const float* __restrict
   if (unit < nunits) fetch(unit);        // the first unit's HBM round trip runs under the weight staging
 
   // The register-resident weights are a stride-9 gather of the [64][432] matrix: read straight from global every
-  // wave load touches ~32 cache lines for 256 useful bytes.  Stage the matrix through LDS with coalesced float4 loads
-  // (rows padded to 433 words so the lanes of the gather hit different banks), then gather from LDS.
-  conv3w_stage<F_NT>(patch2, w, tid);
+  // wave load touches ~32 cache lines for 256 useful bytes.  Stage the matrix through LDS with coalesced loads, tap-major
+  // (conv3w_stage_tap_major), then gather 27 x ds_read_b128 per lane.  Stamps of workgroup 0, cycles from entry, with the
+  // [co][433] staging of conv3w_stage before: loads landed 6.0 k, stored + barrier 9.5 k (4-way conflicted ds_write_b32), gathered
+  // 13.3 k (108 ds_read_b32, 2-way), exit 52.2 k; now 6.8 k / 9.2 k / 10.4 k, exit 49.9 k.
+  conv3w_stage_tap_major<F_NT, F_WLD, F_WTS>(patch2, w, tid);
   __syncthreads();
+  C3_TS(13);
   float wr[108];           // k-step ks = (tap, g, j) = 12 tap + 4 g + j: ci = 16 g + 4 lq + j
 #pragma unroll
-  for (int ks = 0; ks < 108; ++ks) wr[ks] = patch2[co * F_WLD + (16 * ((ks % 12) >> 2) + 4 * lq + (ks & 3)) * 9 + ks / 12];
+  for (int qd = 0; qd < 27; ++qd) {      // quad (tap, g): one ds_read_b128
+    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(patch2 + co * F_WLD + (qd / 3) * F_WTS + 16 * (qd % 3) + 4 * lq);
+    wr[4 * qd] = v[0]; wr[4 * qd + 1] = v[1]; wr[4 * qd + 2] = v[2]; wr[4 * qd + 3] = v[3];
+  }
   const float bn = bias[co];
   __syncthreads();
   C3_TS(1);
@@ -327,6 +366,7 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
 constexpr int D_RS = 16, D_PS = 168, D_PATCH = COUT * D_PS;
 constexpr int D_OS = 260;              // plane stride of the output tile [ci][256]: float4-aligned, 2-way at worst on the 4-byte writes
 constexpr int D_NT = 768;
+constexpr int D_WLD = KW + 1;                       // weight staging rows [co][433] (conv3w_stage): odd stride, conflict-free lane reads
 
 template <int PY, int PX>
 __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const float* __restrict__ dy3, float* __restrict__ dp2,
@@ -342,7 +382,7 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
     for (int tx = 0; tx < NTX; ++tx) {
       const int ky = PY ? (ty == 0 ? 0 : 2) : 1, kx = PX ? (tx == 0 ? 0 : 2) : 1;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) wr[ty * NTX + tx][ks] = patch2[(4 * ks + lq) * F_WLD + ci * 9 + ky * 3 + kx];     // staged by the kernel
+      for (int ks = 0; ks < 16; ++ks) wr[ty * NTX + tx][ks] = patch2[(4 * ks + lq) * D_WLD + ci * 9 + ky * 3 + kx];     // staged by the kernel
     }
   __syncthreads();                                                   // every wave has its weights: the staging area becomes the patch
   for (int i = tid; i < 2 * D_PATCH; i += D_NT) patch2[i] = 0.f;      // halo row 8 / columns 8.. stay zero
@@ -418,7 +458,7 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
 __global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dy3,
                                                            float* __restrict__ dp2, int n_img) {
   __shared__ float patch2[2 * D_PATCH + CIN * D_OS];
-  static_assert(2 * D_PATCH + CIN * D_OS >= COUT * F_WLD, "weight staging area");
+  static_assert(2 * D_PATCH + CIN * D_OS >= COUT * D_WLD, "weight staging area");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // the [64][432] weight matrix through LDS with coalesced float4 loads (rows of 433 words); the waves' register slices are
   // stride-9 / stride-432 gathers of it - straight from global ~20 cache lines per load instruction, 16-64 of them per lane
