@@ -73,7 +73,7 @@ __device__ __forceinline__ void conv3w_stage_tap_major(float* stage, const float
     const int i = tid + j * NTHREADS;
     if (i < NI) {
       const int r = i / 48, ci = i - 48 * r;
-      float* d = stage + r * S_ + ci;
+      float* d = stage + r * S_ + ci;                // word of W[co][ci][tap] = co * S_ + tap * TS_ + ci
 #pragma unroll
       for (int t = 0; t < 9; ++t) d[t * TS_] = v[j][t];
     }
@@ -469,6 +469,8 @@ __global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restri
     sd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < 1024 && (int)blockIdx.x < n_img) sd[j] = *reinterpret_cast<const float4*>(dy3 + (size_t)blockIdx.x * 4096 + 4 * e);
   }
+  // ((co, ci) items as in the forward - conflict-free stores instead of 4-way - made this kernel 1.2 us SLOWER: 36 dword loads per
+  // thread whose lanes are 36 bytes apart cost the vector memory pipe more than the stores saved; it has no 108-read gather to win back)
   conv3w_stage<D_NT>(patch2, w, tid);
   __syncthreads();
   // per image a class costs 64 MFMAs per tap and tile: 256 / 128 / 128 / 64.  Waves w, w + 4, w + 8 share a SIMD:
