@@ -4,6 +4,9 @@
 Needs the instrumented build:  hipcc ... -DMLHOT_TS mlhot.hip -o csrc/libmlhot_ts.so, then
     MLHOT_LIB=.../libmlhot_ts.so python scripts/tail_ts.py
 Workgroup 0 / thread 0 of each instrumented kernel stores wall_clock64() (100 MHz) at stage boundaries.
+Reading the numbers: a stamp loads the buffer pointer and waits vmcnt(0) before it stores, i.e. it also waits for every global load
+the kernel has in flight at that point (e.g. the conv3 forward's "first unit staged" stamp sits right after the next unit's prefetch
+was issued and shows that round trip, ~2.6 k cycles, which the product build does not wait for).
 """
 import ctypes
 import importlib
@@ -83,9 +86,9 @@ if raw[0][0]:
     print("conv12 wgrad per-wave band timeline [previous band's MFMAs done, barrier passed, conv1 + dY staged, barrier passed, MFMAs done] (cycles):")
     for w, r in enumerate(raw):
         print("  wave %2d" % w, [x - t0 for x in r])
-c3t = ts.cpu()[340:356].tolist()
+c3t = ts.cpu()[340:358].tolist()
 if c3t[0]:
-    print("conv3 fwd prologue: weight loads landed %d, staged in LDS (barrier passed) %d" % (c3t[14] - c3t[0], c3t[13] - c3t[0]))
+    print("conv3 fwd prologue: weight loads landed %d, staged in LDS (barrier passed) %d; after the gather: halo zeroed %d, wave 0 stashed %d" % (c3t[14] - c3t[0], c3t[13] - c3t[0], c3t[15] - c3t[0], c3t[16] - c3t[0]))
     print("conv3 fwd, workgroup 0 (cycles from entry): weights in registers %d, first unit staged %d, units [MFMAs + store done, barrier passed]:" % (c3t[1] - c3t[0], c3t[2] - c3t[0]),
           [[c3t[3 + 2 * k] - c3t[0], c3t[4 + 2 * k] - c3t[0]] for k in range(4) if c3t[3 + 2 * k]], "exit", c3t[12] - c3t[0])
 pro = ts.cpu()[502:507].tolist()

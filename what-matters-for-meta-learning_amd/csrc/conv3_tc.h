@@ -183,7 +183,9 @@ __global__ __launch_bounds__(F_NT) void conv3_fwd_kernel(const float* __restrict
   // come from stash - zeros for the row above the image - and 17..23 / the four pad channels are never read)
   for (int i = tid; i < 2 * 9 * F_CS; i += F_NT) patch2[(i / (9 * F_CS)) * F_PATCH + ((i / F_CS) % 9) * F_ROW + i % F_CS] = 0.f;
   __syncthreads();
+  C3_TS(15);
   if (unit < nunits) stash(patch2);
+  C3_TS(16);
   if (unit + (int)gridDim.x < nunits) fetch(unit + gridDim.x);
   __syncthreads();
   const int aoff = ((2 * (2 * mg + (lr >> 3))) * F_RS + 2 * (lr & 7)) * F_CS + 4 * lq;
