@@ -10,7 +10,7 @@ k = json.load(open('gpurun_out/kx.json')); b = json.load(open('gpurun_out/bx.jso
 top = sorted(k.items(), key=lambda kv: -kv[1]['us_per_step'])[:6]
 flt = os.environ.get("KSHOW")
 if flt:
-    top = [kv for kv in sorted(k.items()) if flt in kv[0]]
+    top = [kv for kv in sorted(k.items()) if any(f in kv[0] for f in flt.split(","))]
 print(sys.argv[1], round(b['ms_per_step'], 4), ' '.join(f"{n}={v['us_per_step']:.1f}" for n, v in top))
 PY
 done

@@ -112,16 +112,19 @@ typedef Geo<16, 1, 64, 16, 18, 108, 112> G16s1;
 typedef Geo<16, 2, 32, 4, 20, 180, 181> G16s2;    // half-image bands, as G8s1 (8 x 8 output maps: 360 whole-image bands balance badly over 256 CUs)
 typedef Geo<8, 1, 32, 4, 12, 72, 80> G8s1;       // half-image bands: 240-image launches have 720 of them - three per CU, where 360 whole-image
                                                  // bands left 104 CUs with two and the rest with one (scripts/lds_layout_search.py search(8, 1, bpos_list=(32,)))
-typedef Geo<8, 2, 32, 4, 12, 108, 217> G8s2;
-typedef Geo<4, 1, 64, 4, 8, 48, 196> G4s1;
+// The 4 x 4 / 2 x 2 maps (blocks 3 and 4 of a 64 x 64 trunk): ONE M-tile (16 positions) or two per band.  With 64 / 32 positions a
+// 240-image launch was 60-120 bands on 256 CUs, each a serial chain of 288-576 MFMAs per wave behind its weight load: the 4 x 4
+// stride-1 convolution and data gradient 20.8 / 20.0 -> 14.4 / 14.0 us, the 2 x 2 ones 15.3 / 15.3 -> 12.0 / 10.9 (c5 labels).
+typedef Geo<8, 2, 16, 4, 12, 108, 109> G8s2;
+typedef Geo<4, 1, 32, 4, 8, 48, 100> G4s1;       // (16 positions = one image per band: no further gain)
 typedef Geo<4, 2, 16, 2, 6, 40, 161> G4s2;
-typedef Geo<2, 1, 32, 2, 4, 24, 194> G2s1;
+typedef Geo<2, 1, 16, 2, 4, 24, 98> G2s1;
 // stride-2 data gradient, by the size of the dy map
 typedef Geo<32, 1, 32, 16, 33, 66, 80, 1> D32;
 typedef Geo<16, 1, 32, 8, 24, 72, 80, 1> D16;
 typedef Geo<8, 1, 32, 4, 12, 60, 80, 1> D8;
-typedef Geo<4, 1, 32, 4, 8, 40, 84, 1> D4;
-typedef Geo<2, 1, 32, 2, 4, 24, 194, 1> D2;
+typedef Geo<4, 1, 16, 4, 8, 40, 44, 1> D4;       // one M-tile per band, as above: stride-2 data gradients of blocks 3 / 4 (two launches each)
+typedef Geo<2, 1, 16, 2, 4, 24, 98, 1> D2;       // 17.0 / 17.0 / 17.9 / 18.0 -> 15.5 / 12.8 / 12.4 / 12.6 us
 
 // ---- lane-native weight images ------------------------------------------------------------------------------------
 // F image (forward operand order)  : [nt][ks][lane] = W[16nt + lr][4(ks % 16) + lq][tap = ks / 16]
