@@ -29,3 +29,11 @@ w = (w - t0) / 100.0
 print("F1 workgroups %d: start us med/max %.1f %.1f | loop done med/max %.1f %.1f | dd stored med/max %.1f %.1f | exit med/max %.1f %.1f" % (
     len(w), np.median(w[:, 0]), w[:, 0].max(), np.median(w[:, 1]), w[:, 1].max(), np.median(w[:, 2]), w[:, 2].max(), np.median(w[:, 3]), w[:, 3].max()))
 print("per-workgroup durations: loop med %.1f, stores med %.1f, tree med %.1f" % (np.median(w[:, 1] - w[:, 0]), np.median(w[:, 2] - w[:, 1]), np.median(w[:, 3] - w[:, 2])))
+
+f2 = ts.cpu()[3200:3200 + 8 * 64].view(64, 8).numpy().astype(np.float64)
+f2 = f2[f2[:, 0] > 0]
+if len(f2):
+    f2 = (f2 - f2[:, 0].min()) / 100.0
+    d = np.diff(f2[:, :5], axis=1)
+    print("F2 workgroups %d: start med/max %.1f %.1f, exit med/max %.1f %.1f us | phases (median us): preamble %.1f, feature loop %.1f, fold + D %.1f, out %.1f" % (
+        len(f2), np.median(f2[:, 0]), f2[:, 0].max(), np.median(f2[:, 4]), f2[:, 4].max(), *np.median(d, axis=0)))

@@ -186,12 +186,18 @@ __global__ __launch_bounds__(256) void f1_kernel(const Args a) {
 // 1024 threads: ONE workgroup per (task, head) - 64 of them on 256 CUs - so the block's 30 x 1424 exponentials and their dd / E
 // traffic are spread over 16 waves instead of 4 (the grid cannot grow: S = F_q F_k^T needs every feature of the block).
 constexpr int F2_NT = 1024, F2_NW = F2_NT / 64;
+#ifdef MLHOT_TS
+#define F2_TS(k) do { if (tf::g_ts_dev && threadIdx.x == 0 && blockIdx.x < 64) tf::g_ts_dev[3200 + 8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define F2_TS(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(F2_NT) void f2_kernel(const Args a) {
   __shared__ float s_mx[MAXN], s_diag[2 * MAXN], s_S[MAXN * (MAXN + 1)], s_D[MAXN], red[F2_NW * 4 * 64 * 4];
   __shared__ float s_g; __shared__ float sm_v[F2_NT]; __shared__ int sm_r[F2_NT], sm_j[F2_NT];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int th = blockIdx.x, t = th / a.f.H, h = th % a.f.H;
   const int d = a.f.d, m = a.f.m, Nq = a.f.Nq, Nc = a.f.Nc, H = a.f.H, mp = a.w.mp;
+  F2_TS(0);
   // query row maxima from the partials
   if (tid < Nq) {
     const size_t grow = (size_t)(t * Nq + tid) * H + h;
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(F2_NT) void f2_kernel(const Args a) {
     if (xp && part == 0) { s_diag[r] = 0.5f * a.c * a.c * s; a.w.diag[(size_t)th * (Nq + Nc) + r] = s_diag[r]; }
   }
   __syncthreads();
+  F2_TS(1);
   // S = F_q F_k^T over the features: 16-feature chunks c = wv, wv + 4, ...
   const float gst = s_g;
   float* qrow[2]; float* krow[2]; float qsub[2], ksub[2];
@@ -303,6 +310,7 @@ __global__ __launch_bounds__(F2_NT) void f2_kernel(const Args a) {
           acc[i][jj] = mfma4(fa[u][i].z, fb[u][jj].z, acc[i][jj]); acc[i][jj] = mfma4(fa[u][i].w, fb[u][jj].w, acc[i][jj]);
         }
   }
+  F2_TS(2);
   // fold the sixteen waves: S[n][n'] (C layout: n = 16 i + 4 lq + r, n' = 16 jj + lr)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -330,6 +338,7 @@ __global__ __launch_bounds__(F2_NT) void f2_kernel(const Args a) {
     s_D[tid] = s; a.w.D[(size_t)th * Nq + tid] = s;
   }
   __syncthreads();
+  F2_TS(3);
   // out[t][n][e H + h] = sum_n' S[n][n'] v[(t, n', h)][e] / D[n]: thread = (e, n-half)
   for (int idx = tid; idx < d * 2; idx += F2_NT) {
     const int e = idx % d, half = idx / d;
@@ -352,6 +361,7 @@ __global__ __launch_bounds__(F2_NT) void f2_kernel(const Args a) {
       if (nn < Nq) a.out[(size_t)(t * Nq + nn) * ((size_t)d * H) + (size_t)e * H + h] = o[n] / s_D[nn];
     }
   }
+  F2_TS(4);
 }
 
 // ---- B1 ---------------------------------------------------------------------------------------------------------
