@@ -638,14 +638,14 @@ inline int dgrad2_dispatch(int HO, bool skip1, DgJobs& jobs, hipStream_t s, cons
 //   dW[co][ci][tap] = sum over positions  dy[co][pos] * x[ci][pos shifted by tap]:   M = co, N = (tap, ci), K = positions.
 // Workgroup (q, z): input-channel tile q (16 channels, so it stages only a quarter of the x patch) and position split z; wave w
 // = output-channel tile.  The nine accumulators of a wave (one per tap, 36 registers) live for the whole kernel; per k-step (4
-// positions) a wave reads ONE dy operand and nine x operands from LDS.  Bands of 128 positions; the x slice uses the forward's
+// positions) a wave reads ONE dy operand and nine x operands from LDS.  Bands of 128 (small maps: 64) positions; the x slice uses the forward's
 // patch geometry, dy is staged transposed ([pos][co], stride DS) - strides from scripts/lds_layout_search.py.  The k-step's four
 // positions are Q apart (pb = blk*4Q + lq*Q + j), which is what makes both gathers bank-conflict free.  Results go out in
 // MFMA-native order (one coalesced float4 per lane and tap) into slab row z; wsum_kernel folds the rows and un-permutes.
 // The bias gradient rides along in the q = 0 workgroups as a tenth accumulator against an all-ones operand.
-template <int HIN_, int S_, int Q_, int RS_, int ISZ_, int PS_, int DS_>
+template <int HIN_, int S_, int Q_, int RS_, int ISZ_, int PS_, int DS_, int BPOS_ = 128>
 struct GeoW {
-  static constexpr int HIN = HIN_, S = S_, Q = Q_, RS = RS_, ISZ = ISZ_, PS = PS_, DS = DS_, BPOS = 128, NKS_B = BPOS / 4;
+  static constexpr int HIN = HIN_, S = S_, Q = Q_, RS = RS_, ISZ = ISZ_, PS = PS_, DS = DS_, BPOS = BPOS_, NKS_B = BPOS / 4;
   static constexpr int HO = HIN / S, WO = HO, PI = HO * WO;
   static constexpr bool MULTI = PI < BPOS;
   static constexpr int NI = MULTI ? BPOS / PI : 1, RB = MULTI ? HO : BPOS / WO, PR = S * (RB - 1) + 3;
@@ -687,10 +687,12 @@ typedef GeoW<32, 2, 8, 33, 561, 561, 66> W32s2;
 typedef GeoW<16, 1, 1, 18, 180, 182, 80> W16s1;
 typedef GeoW<16, 2, 16, 20, 340, 681, 65> W16s2;
 typedef GeoW<8, 1, 1, 10, 100, 202, 80> W8s1;
-typedef GeoW<8, 2, 16, 9, 81, 650, 65> W8s2;
-typedef GeoW<4, 1, 1, 6, 36, 290, 80> W4s1;
-typedef GeoW<4, 2, 4, 5, 25, 802, 68> W4s2;
-typedef GeoW<2, 1, 4, 4, 16, 513, 68> W2s1;
+// 64-position bands on the 4 x 4 / 2 x 2 output maps (blocks 3 / 4 of a 64 x 64 trunk): a 240-image launch has 150 bands instead of 75,
+// so the planner reaches its 128 slab rows (512 workgroups, each half the chain) - 20.7 / 15.4 / 14.5 / 13.8 -> 19.4 / 13.7 / 13.5 / 12.4 us
+typedef GeoW<8, 2, 16, 9, 81, 326, 65, 64> W8s2;
+typedef GeoW<4, 1, 1, 6, 36, 146, 80, 64> W4s1;
+typedef GeoW<4, 2, 4, 5, 25, 402, 68, 64> W4s2;
+typedef GeoW<2, 1, 4, 4, 16, 257, 68, 64> W2s1;
 
 constexpr int SLAB3 = 4 * 4 * 9 * 64 * 4;      // floats of one slab row of a 3x3 weight gradient (= 64 * 576), MFMA-native order
 constexpr int SLAB1 = 4 * 4 * 64 * 4;          // ... of a 1x1 weight gradient
@@ -736,7 +738,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
   constexpr int RM_RP = REG_MAP ? 256 / (G::SEG * 16) : 1, RM_RPP = REG_MAP ? (G::PR + RM_RP - 1) / RM_RP : 1;
   const int rm_seg = tid & (G::SEG - 1), rm_ci = (tid / G::SEG) & 15, rm_row0 = (tid / (G::SEG * 16)) * RM_RPP;
   stage_t st[TAP1 ? 1 : (REG_MAP ? RM_RPP : G::CNT)];
-  float s1[TAP1 ? 8 : 1];
+  constexpr int S1N = 16 * G::BPOS / 256;      // TAP1: the compact [16 ci][BPOS positions] tile, items per thread
+  float s1[TAP1 ? S1N : 1];
   float4 sd[G::DCNT];
   auto fetch = [&](int band) __attribute__((always_inline)) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
     // TAP1 (1x1 stride-2 convolution) only ever reads x[ci][2 oy][2 ox]: a compact [16 ci][128 positions] gather, 8 loads per thread
     if (TAP1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < S1N; ++j) {
         const int e = tid + j * 256, p = e % G::BPOS, ci = e / G::BPOS;
         const int il = G::MULTI ? p / G::PI : 0, pin = G::MULTI ? p % G::PI : p;
         const int oy = oy0 + pin / G::WO, ox = pin % G::WO;
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
     WG_TS(2 + 4 * ts_b);
     if (TAP1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const int e = tid + j * 256; xs[(e / G::BPOS) * (G::BPOS + 1) + e % G::BPOS] = s1[j]; }
+      for (int j = 0; j < S1N; ++j) { const int e = tid + j * 256; xs[(e / G::BPOS) * (G::BPOS + 1) + e % G::BPOS] = s1[j]; }
     } else if constexpr (REG_MAP) {
       float* dl = xs + rm_ci * G::PS + rm_row0 * G::RS + 1 + 4 * rm_seg;
 #pragma unroll
