@@ -522,11 +522,15 @@ __global__ __launch_bounds__(256) void b1_kernel(const Args a) {
 // features.  (With 16-channel slices every block's G rows - 171 KB - were re-read by 16 workgroups: 175 MB through L2 per launch for
 // 11 MB of gradients, and the kernel ran at L2 bandwidth.)
 constexpr int B2_NT = 4;
+#ifndef B2_NW
+#define B2_NW 8                   // waves per workgroup: the m features are split over them (with 4 - one wave per SIMD, 704 MFMAs and 400 loads each - 35.0 us at c5's shape, with 8: 32.8)
+#endif
+constexpr int B2_TH = 64 * B2_NW;
 template <int RT>
-__global__ __launch_bounds__(256) void b2_kernel(const Args a) {
+__global__ __launch_bounds__(B2_TH) void b2_kernel(const Args a) {
   __shared__ float s_gt;
-  __shared__ float sm[256];
-  __shared__ float red[4 * RT * B2_NT * 64 * 4];
+  __shared__ float sm[B2_TH];
+  __shared__ float red[B2_NW * RT * B2_NT * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int th = blockIdx.x, t = th / a.f.H, h = th % a.f.H;
   const int d = a.f.d, m = a.f.m, Nq = a.f.Nq, Nc = a.f.Nc, H = a.f.H, mp = a.w.mp, R = Nq + Nc;
@@ -537,12 +541,12 @@ __global__ __launch_bounds__(256) void b2_kernel(const Args a) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const int nrs = a.f.T * Nc * H * NSP;
     int i = tid;
-    for (; i + 768 < nrs; i += 1024) { s0 += a.w.rs_k[i]; s1 += a.w.rs_k[i + 256]; s2 += a.w.rs_k[i + 512]; s3 += a.w.rs_k[i + 768]; }
-    for (; i < nrs; i += 256) s0 += a.w.rs_k[i];
+    for (; i + 3 * B2_TH < nrs; i += 4 * B2_TH) { s0 += a.w.rs_k[i]; s1 += a.w.rs_k[i + B2_TH]; s2 += a.w.rs_k[i + 2 * B2_TH]; s3 += a.w.rs_k[i + 3 * B2_TH]; }
+    for (; i < nrs; i += B2_TH) s0 += a.w.rs_k[i];
     const float s = (s0 + s1) + (s2 + s3);
     sm[tid] = s;
     __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) { if (tid < k) sm[tid] += sm[tid + k]; __syncthreads(); }
+    for (int k = B2_TH / 2; k > 0; k >>= 1) { if (tid < k) sm[tid] += sm[tid + k]; __syncthreads(); }
     if (tid == 0) s_gt = sm[0] + (a.gt_fix ? a.gt_fix[0] : 0.f);
   }
   const float* grow[RT];
@@ -558,11 +562,11 @@ __global__ __launch_bounds__(256) void b2_kernel(const Args a) {
     for (int n = 0; n < B2_NT; ++n) acc[i][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const float* pcol = a.proj + e0 + lr;
   constexpr int UF = 2;
-  for (int jb = 16 * wv; jb < mp; jb += 64 * UF) {
+  for (int jb = 16 * wv; jb < mp; jb += 16 * B2_NW * UF) {
     float4 g[UF][RT]; float p[UF][4][B2_NT];
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
-      const int j = jb + 64 * u + 4 * lq;
+      const int j = jb + 16 * B2_NW * u + 4 * lq;
 #pragma unroll
       for (int i = 0; i < RT; ++i) g[u][i] = (grow[i] && j < mp) ? *reinterpret_cast<const float4*>(grow[i] + j) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -586,12 +590,12 @@ __global__ __launch_bounds__(256) void b2_kernel(const Args a) {
     for (int n = 0; n < B2_NT; ++n) *reinterpret_cast<f32x4_t*>(red + (((wv * RT + i) * B2_NT + n) * 64 + lane) * 4) = acc[i][n];
   __syncthreads();
   const int gr = a.w.gpos[0], gj = a.w.gpos[1];
-  // tile (i, n) is folded and finished by wave (i * B2_NT + n) % 4, in a fixed order
-  for (int tile = wv; tile < RT * B2_NT; tile += 4) {
+  // tile (i, n) is folded and finished by wave (i * B2_NT + n) % B2_NW, in a fixed order
+  for (int tile = wv; tile < RT * B2_NT; tile += B2_NW) {
     const int i = tile / B2_NT, n = tile % B2_NT;
     f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < B2_NW; ++k) {
       const f32x4_t vv = *reinterpret_cast<const f32x4_t*>(red + (((k * RT + i) * B2_NT + n) * 64 + lane) * 4);
       sacc[0] += vv[0]; sacc[1] += vv[1]; sacc[2] += vv[2]; sacc[3] += vv[3];
     }
@@ -663,8 +667,8 @@ inline int backward(const FavorDims& f, const float* q, const float* k, const fl
   if (st.stage == 1) { MLHOT_TRY(sx::sum_apply(w.rs_k, nrs, st.x, w.gt_fix, 0, s)); a.gt_fix = w.gt_fix; }
   {
     ProfScope ps("favor.b2", s);
-    if (R <= 32) hipLaunchKernelGGL((b2_kernel<2>), dim3(th, (f.d + 16 * B2_NT - 1) / (16 * B2_NT)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((b2_kernel<4>), dim3(th, (f.d + 16 * B2_NT - 1) / (16 * B2_NT)), dim3(256), 0, s, a);
+    if (R <= 32) hipLaunchKernelGGL((b2_kernel<2>), dim3(th, (f.d + 16 * B2_NT - 1) / (16 * B2_NT)), dim3(B2_TH), 0, s, a);
+    else hipLaunchKernelGGL((b2_kernel<4>), dim3(th, (f.d + 16 * B2_NT - 1) / (16 * B2_NT)), dim3(B2_TH), 0, s, a);
   }
   return check_launch("favor.b2");
 }
