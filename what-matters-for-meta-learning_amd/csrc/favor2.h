@@ -193,7 +193,7 @@ constexpr int F2_NT = 1024, F2_NW = F2_NT / 64;
 #endif
 __global__ __launch_bounds__(F2_NT) void f2_kernel(const Args a) {
   __shared__ float s_mx[MAXN], s_diag[2 * MAXN], s_S[MAXN * (MAXN + 1)], s_D[MAXN], red[F2_NW * 4 * 64 * 4];
-  __shared__ float s_g; __shared__ float sm_v[F2_NT]; __shared__ int sm_r[F2_NT], sm_j[F2_NT];
+  __shared__ float s_g; __shared__ float sm_v[F2_NW]; __shared__ int sm_r[F2_NW], sm_j[F2_NW];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int th = blockIdx.x, t = th / a.f.H, h = th % a.f.H;
   const int d = a.f.d, m = a.f.m, Nq = a.f.Nq, Nc = a.f.Nc, H = a.f.H, mp = a.w.mp;
@@ -222,16 +222,24 @@ __global__ __launch_bounds__(F2_NT) void f2_kernel(const Args a) {
       const float vv = a.w.wg_v[i]; const int r = a.w.wg_row[i], j = a.w.wg_j[i];
       if (vv > best || (vv == best && (r < br || (r == br && j < bj)))) { best = vv; br = r; bj = j; }
     }
-    sm_v[tid] = best; sm_r[tid] = br; sm_j[tid] = bj;
-    __syncthreads();
-    for (int s = F2_NT / 2; s > 0; s >>= 1) {
-      if (tid < s) {
-        const float ov = sm_v[tid + s]; const int orow = sm_r[tid + s], oj = sm_j[tid + s];
-        if (ov > sm_v[tid] || (ov == sm_v[tid] && (orow < sm_r[tid] || (orow == sm_r[tid] && oj < sm_j[tid])))) { sm_v[tid] = ov; sm_r[tid] = orow; sm_j[tid] = oj; }
-      }
-      __syncthreads();
+    // lanes by shuffles, then the sixteen wave results (a ten-level tree through LDS was ten barriers of 1024 threads); the order
+    // (value, then row, then feature) is total, so the result does not depend on the shape of the tree
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off, 64); const int orow = __shfl_xor(br, off, 64), oj = __shfl_xor(bj, off, 64);
+      if (ov > best || (ov == best && (orow < br || (orow == br && oj < bj)))) { best = ov; br = orow; bj = oj; }
     }
-    if (tid == 0) { s_g = sm_v[0]; if (th == 0) { a.w.gmax[0] = sm_v[0]; a.w.gpos[0] = sm_r[0]; a.w.gpos[1] = sm_j[0]; } }
+    if (lane == 0) { sm_v[wv] = best; sm_r[wv] = br; sm_j[wv] = bj; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 1; k < F2_NW; ++k) {
+        const float ov = sm_v[k]; const int orow = sm_r[k], oj = sm_j[k];
+        if (ov > best || (ov == best && (orow < br || (orow == br && oj < bj)))) { best = ov; br = orow; bj = oj; }
+      }
+      s_g = best;
+      if (th == 0) { a.w.gmax[0] = best; a.w.gpos[0] = br; a.w.gpos[1] = bj; }
+    }
   }
   // diag = 0.5 c^2 |x|^2 of the block's rows: 4 threads per row (the first 256 threads)
   {
@@ -239,8 +247,12 @@ __global__ __launch_bounds__(F2_NT) void f2_kernel(const Args a) {
     float s = 0.f;
     const float* xp = r < 2 * MAXN ? block_row(a, t, h, r) : nullptr;
     if (xp) {
-#pragma unroll 4
-      for (int e = 4 * part; e < d; e += 16) { const float4 u = *reinterpret_cast<const float4*>(xp + e); s += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w); }
+      // d <= 256 (applies()): the row's 16 float4 of this thread requested together (unrolled by 4 it was four serial round trips)
+      float4 u[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const int e = 4 * part + 16 * k; u[k] = e < d ? *reinterpret_cast<const float4*>(xp + e) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += (u[k].x * u[k].x + u[k].y * u[k].y) + (u[k].z * u[k].z + u[k].w * u[k].w);
     }
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
     if (xp && part == 0) { s_diag[r] = 0.5f * a.c * a.c * s; a.w.diag[(size_t)th * (Nq + Nc) + r] = s_diag[r]; }
@@ -339,27 +351,32 @@ __global__ __launch_bounds__(F2_NT) void f2_kernel(const Args a) {
   }
   __syncthreads();
   F2_TS(3);
-  // out[t][n][e H + h] = sum_n' S[n][n'] v[(t, n', h)][e] / D[n]: thread = (e, n-half)
-  for (int idx = tid; idx < d * 2; idx += F2_NT) {
-    const int e = idx % d, half = idx / d;
-    float o[16];
+  // out[t][n][e H + h] = sum_n' S[n][n'] v[(t, n', h)][e] / D[n] on the matrix core: wave = a 16-channel tile of e (d / 16 <= 16
+  // tiles), A = S[n][n'] from LDS (lane: n = 16 i + lr, k = n' = 4 ks + lq), B = v[n'][e] (lane: k = n', column e = 16 wave + lr),
+  // K = 32 key slots (zero beyond Nc).  (As scalar code - thread = (e, n half), 15 loads, 240 FMAs against LDS broadcasts, 16
+  // stores - this phase was 7.6 of the kernel's 26 us.)
+  for (int et = wv; et * 16 < d; et += F2_NW) {
+    const int e = 16 * et + lr;
+    float bv[MAXN / 4];
 #pragma unroll
-    for (int n = 0; n < 16; ++n) o[n] = 0.f;
-    float vcol[MAXN];                                  // the value column, all rows requested together (it was a serial loop of loads)
+    for (int ks = 0; ks < MAXN / 4; ++ks) { const int np = 4 * ks + lq; bv[ks] = np < Nc ? a.v[((size_t)(t * Nc + np) * H + h) * d + e] : 0.f; }
+    f32x4_t o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int np = 0; np < MAXN; ++np) vcol[np] = np < Nc ? a.v[((size_t)(t * Nc + np) * H + h) * d + e] : 0.f;
+    for (int ks = 0; ks < MAXN / 4; ++ks) {
+      const int np = 4 * ks + lq;
 #pragma unroll
-    for (int np = 0; np < MAXN; ++np) {
-      if (np < Nc) {
-#pragma unroll
-        for (int n = 0; n < 16; ++n) o[n] = fmaf(s_S[(16 * half + n) * (MAXN + 1) + np], vcol[np], o[n]);
+      for (int i = 0; i < 2; ++i) {
+        const float av = (16 * i + lr < Nq && np < Nc) ? s_S[(16 * i + lr) * (MAXN + 1) + np] : 0.f;
+        o[i] = mfma4(av, bv[ks], o[i]);
       }
     }
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
-      const int nn = 16 * half + n;
-      if (nn < Nq) a.out[(size_t)(t * Nq + nn) * ((size_t)d * H) + (size_t)e * H + h] = o[n] / s_D[nn];
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = 16 * i + 4 * lq + r;
+        if (nn < Nq) a.out[(size_t)(t * Nq + nn) * ((size_t)d * H) + (size_t)e * H + h] = o[i][r] / s_D[nn];
+      }
   }
   F2_TS(4);
 }
