@@ -62,6 +62,10 @@ inline int conv_hin(const Levels& lv, int conv) {        // input size of conv i
   return r == 1 ? lv.L[b] : lv.L[b - 1];
 }
 inline int conv_stride(int conv) { return (conv - 1) % 3 == 1 ? 1 : 2; }
+// slab-row target of a 3x3 / 1x1 weight-gradient job: every row is 147 KB written by the kernel and read again by the fold.  The
+// 4 x 4 / 2 x 2 output maps get 64 rows (256 workgroups): measured 128 / 64 / 32 rows at c5's shape - weight gradient of block 3's
+// conv1 19.2 / 17.9 / 22.9 us, conv2 13.0 / 13.0 / 15.4, fold 34.3 / 33.9 / 32.9
+inline int wg_target(const Levels& lv, int conv) { return conv_hin(lv, conv) / conv_stride(conv) <= 4 ? 64 : 128; }
 
 // the band total a job's slab rows are planned against: the 1x1 skips of a step share a launch of their own (skip1_wgrad_kernel),
 // so they split ITS workgroups among themselves, not those of a launch that also serves the other passes
@@ -102,7 +106,7 @@ inline TrunkScratch trunk_carve(const mlhot_trunk_pass* ps, int n_pass, const ml
         total += bands[p];
       }
       for (int w = 0; w < n_wset; ++w) s.rows[w][c] = 0;
-      for (int p = 0; p < n_pass; ++p) s.rows[ps[p].wset][c] += c == 0 ? wg_rows(bands[p], total, 512) : wg_rows(bands[p], skip1_total(ps, n_pass, ws, p, c, bands, total));
+      for (int p = 0; p < n_pass; ++p) s.rows[ps[p].wset][c] += c == 0 ? wg_rows(bands[p], total, 512) : wg_rows(bands[p], skip1_total(ps, n_pass, ws, p, c, bands, total), wg_target(lv, c));
       for (int w = 0; w < n_wset; ++w) {
         const size_t rowlen = c == 0 ? (size_t)rw::stem_slab_row(lv.C) : ((c % 3 == 0 && ws[w].skip_k == 1) ? rw::SLAB1 : rw::SLAB3);
         s.slab[w][c] = a.take<float>(rowlen * (s.rows[w][c] > 0 ? s.rows[w][c] : 1));
@@ -238,7 +242,7 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
       const int w = ps[p].wset;
       if (conv % 3 == 0 && ((ws[w].skip_k == 1) != want_tap1)) continue;
       (void)tap1;
-      const int nz = wg_rows(bands[p], skip1_total(ps, n_pass, ws, p, conv, bands, total));
+      const int nz = wg_rows(bands[p], skip1_total(ps, n_pass, ws, p, conv, bands, total), wg_target(lv, conv));
       jobs.j[jobs.n++] = rw::WgJob{xs[p], dys[p], sc.slab[w][conv], sc.slab_b[w][conv], ps[p].n_img, next_row[w][conv], nz, 0};
       next_row[w][conv] += nz;
     }
