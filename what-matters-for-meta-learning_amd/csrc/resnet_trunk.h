@@ -144,7 +144,7 @@ inline int trunk_prep(const mlhot_trunk_wset* ws, int n_wset, const Levels& lv, 
   }
   {
     ProfScope ps("trunk.prep", s);
-    hipLaunchKernelGGL(rw::prep_kernel, dim3(16, items.n), dim3(256), 0, s, items);
+    hipLaunchKernelGGL(rw::prep_kernel, dim3(144, items.n), dim3(256), 0, s, items);      // 4 x 144 = the 576 wave items of a 3x3 image: one trip per wave (with 16 blocks a wave made nine load -> store trips, each a round trip: 10.6 us)
   }
   return check_launch("trunk.prep");
 }
