@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLHOT_ABI_VERSION 1
+#define MLHOT_ABI_VERSION 2
 
 enum { MLHOT_ACT_NONE = 0, MLHOT_ACT_RELU = 1, MLHOT_ACT_TANH = 2 };
 enum { MLHOT_AGG_MEAN = 0, MLHOT_AGG_MAX = 1, MLHOT_AGG_BACO = 2, MLHOT_AGG_ATTENTION = 3 };
@@ -61,7 +61,7 @@ int mlhot_prof_end(const char** labels, float* ms, int cap);
 /* ---- NT-Xent, the functional-contrastive term of the FCL* models ------------------
  * replaces trainer/losses.py:82-99 (LossFunc.contrastive_loss / contrastive_loss_ANP -> pytorch_metric_learning.losses.NTXentLoss
  * (temperature = t), an un-vendored dependency: algorithm restated in oracle/ref_cpu.py::nt_xent, value parity unpinned).  z: [N, d]
- * embeddings (N <= 512, d <= 256, d % 16 == 0); the labels are always arange blocks, label(i) = (i / div) % mod
+ * embeddings (N <= 2048, d <= 256, d % 16 == 0); the labels are always arange blocks, label(i) = (i / div) % mod
  * (contrastive_loss: div = 1, mod = T, N = 2T; contrastive_loss_ANP: div = Nq, mod = T, N = T Nq).  ws: mlhot_nt_xent_ws_floats(N)
  * floats kept between forward and backward.  loss / dloss: device scalars; dz: [N, d].                                          */
 size_t mlhot_nt_xent_ws_floats(int N);

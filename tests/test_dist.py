@@ -262,6 +262,29 @@ def _early_worker(rank, world, port, out):
         head(torch.relu(late(xr))).pow(2).mean().backward()
         ref.append([p.grad.clone() for p in params])
     mean = [sum(g) / world for g in zip(*ref)]
+    # An early list that names a module the forward never uses (transform_y, latent heads, FCL-only paths of a ResNetNP flavour):
+    # step 1 cannot count down - everything goes out in one late collective and the list is re-planned; step 2 fires early.
+    unused = torch.nn.Linear(3, 3)
+    bucket = Logged(params + list(unused.parameters()), early=list(head.parameters()) + list(unused.parameters()))
+    pruned = []
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        del log[:]
+        loss = head(torch.relu(late(x))).pow(2).mean()
+        bucket.arm()
+        loss.backward()
+        bucket.sync()
+        pruned.append((list(bucket.issue_log), max(float((p.grad - m).abs().max()) for p, m in zip(params, mean))))
+    assert pruned[0][0] == [("all", n_head + n_late)] and pruned[1][0] == [("early", n_head), ("rest", n_late)], pruned
+    assert len(bucket.early) == len(list(head.parameters())) and max(e for _, e in pruned) <= 1e-7
+    # sync(wait=False) without defer_scale is refused BEFORE anything is issued (no rank is left inside a collective)
+    del log[:]
+    try:
+        bucket.sync(wait=False)
+        raise AssertionError("sync(wait=False, defer_scale=False) must raise")
+    except ValueError:
+        assert log == []
     out[rank] = (same, max(float((a - b).abs().max()) for a, b in zip(results["early bucket"][0], mean)))
     dist.barrier()
     dist.destroy_process_group()

@@ -89,6 +89,34 @@ def test_favor_against_reference_vectors(gpulib, favor_impl):
             assert U.rel_err(gt.permute(0, 2, 1, 3), fx[f"{tag}/{n}"], floor=1e-12) <= U.RTOL, (tag, n)
 
 
+@pytest.mark.parametrize("staged", [False, True], ids=["plain", "staged_world1"])
+def test_favor_at_the_shipped_c5_shape_with_live_gradients(gpulib, favor_impl, staged):
+    """FAVOR+ at ANPMRShapeNet3D's own shape (T = 2, 8 heads, d = 256, m = 1419; 15 + 15 and the ragged 7 + 23)
+    against vectors the reference generated (tests/golden/make_fixtures.py::run_favor_c5_cases), with inputs whose features sit
+    ~50x above the +1e-4 floor so that dq / dk are 0.4-0.6 of dv's scale: out / dq / dk / dv each at 1e-4 of ITS OWN scale, no
+    floor, for favor2.h, favor.h's chain and - world of one - both through the staged entry points."""
+    from mlhot.dist import StabiliserExchange
+    fx = np.load(os.path.join(U.GOLDEN, "favor_c5.npz"))
+    meta = json.loads(str(fx["meta"]))
+    proj = torch.from_numpy(fx["proj"]).to(DEV)
+    for tag, mt in meta.items():
+        q, k, v, wout = (torch.from_numpy(fx[f"{tag}/{n}"]) for n in ("q", "k", "v", "wout"))
+        T, H, Nq, d = q.shape
+        assert (H, d, proj.shape[0]) == (8, 256, 1419)
+        qn, kn, vn = (t.permute(0, 2, 1, 3).contiguous().to(DEV) for t in (q, k, v))
+        ex = (StabiliserExchange(), torch.zeros(4, device=DEV)) if staged else None
+        out, ws = gpulib.favor_fwd(qn, kn, vn, proj, exchange=ex)
+        e = {"out": U.rel_err(out.view(T, Nq, d, H).permute(0, 3, 1, 2), fx[f"{tag}/out"])}
+        dout = wout.permute(0, 2, 3, 1).reshape(T, Nq, d * H).contiguous().to(DEV)
+        dq, dk, dv = gpulib.favor_bwd(qn, kn, vn, proj, out, dout, ws, exchange=ex)
+        for n, gt in (("dq", dq), ("dk", dk), ("dv", dv)):
+            e[n] = U.rel_err(gt.permute(0, 2, 1, 3), fx[f"{tag}/{n}"])
+        print(f"favor_c5 {tag} impl={favor_impl} staged={staged}: " + " ".join(f"{n}={x:.2e}" for n, x in e.items()))
+        assert max(e.values()) <= U.RTOL, (tag, e)
+        if staged:
+            assert list(ex[0].calls) == ["fwd", "bwd"]
+
+
 def test_losses_against_reference_vectors(gpulib):
     fx = np.load(os.path.join(U.GOLDEN, "losses.npz"))
     for kind, tag, key, task in (("azimuth", "az", "train", "shapenet_1d"), ("degree", "az", "test", "shapenet_1d"),
@@ -495,6 +523,107 @@ def test_c5_full_size_forward_backward_vs_oracle(gpulib, Nc, Nq):
     assert mu.shape == (T, Nq, 4)
     assert abs(kl_o.item() - 1383162.5) < 4.0      # SURVEY §8c known answer
     print(f"c5 per-GPU size: {flips} routing decisions on a tie")
+
+
+def _sharpen_resnet_attention(model, forward):
+    """Make the FAVOR+ attention of a ResNet-family ANP non-degenerate.  At the seeded weights the query /
+    key rows q = W_q x + b have norms of O(10): exp(dd - diag - max) underflows below the +1e-4 floor and the reference's own
+    W_q / W_k gradients are 0 .. 4e-4 of the largest.  One recording pass (`forward()` under no_grad) captures the encoder features
+    that enter the head projections; every head's projection is then re-centred and scaled,
+        W <- s W,  b <- -s W mean(x),   s = 0.25 / std(W (x - mean x)),
+    so that the rows have zero mean and 0.25 spread per component: dd has unit spread, diag ~ 0.5 (the regime favor_c5.npz pins
+    for the kernels in isolation).  Returns the measured spread of q / k before the change."""
+    seen = {}
+    heads0 = model._heads
+
+    def rec(x, mods):
+        seen[id(mods)] = x.detach().reshape(-1, x.shape[-1]).clone()
+        return heads0(x, mods)
+    model._heads = rec
+    try:
+        with torch.no_grad():
+            forward()
+    finally:
+        del model._heads
+    before = {}
+    with torch.no_grad():
+        for name, mods in (("q", model._W_q), ("k", model._W_k)):
+            x = seen[id(mods)]
+            xm = x.mean(dim=0)
+            for m in mods:
+                w = m.linear.weight
+                rows = (x - xm) @ w.t()
+                before[name] = float((x @ w.t() + m.linear.bias).std())
+                sc = 0.25 / float(rows.std())
+                m.linear.bias.copy_(-(w @ xm) * sc)
+                w.mul_(sc)
+    return before
+
+
+@pytest.mark.parametrize("method,Nc,Nq", [("ANPMRShapeNet3D", 15, 15), ("ANPMRShapeNet3D", 7, 23), ("ANP", 15, 15)])
+def test_resnet_anp_with_sharp_attention_vs_oracle(gpulib, favor_impl, method, Nc, Nq):
+    """The ResNet-family twin of test_tail_with_sharp_attention_vs_oracle, at c5's per-GPU size (8 tasks, 64x64x3, FAVOR+ at d = 256 /
+    m = 1419 - ANPMRShapeNet3D.py:160-183, fast_attention.py:74-99,151-156): with the head projections re-centred and scaled
+    (_sharpen_resnet_attention) the W_q / W_k gradients are first-class - asserted: the smallest of them > 1e-5 of the model's
+    largest gradient entry - and are held to 2e-4 of their OWN scale against the fp64 oracle under the same eps draws and the
+    kernels' ReLU routing; mu, loss and every other gradient at 1e-4 as in the other whole-model tests.  Both FAVOR+
+    implementations (favor2.h's two launches per direction, favor.h's chain)."""
+    import importlib
+    import types
+    from trainer.losses import LossFunc
+    T = 8
+    cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[64, 64, 4], tasks_per_batch=T, input_dim=4, output_dim=4,
+                                agg_mode="attention", img_agg="reshape" if method == "ANPMRShapeNet3D" else "max", task="shapenet_3d",
+                                temperature=0.07)
+    model = getattr(importlib.import_module("networks." + method), method)(cfg).to(DEV)
+    g = torch.Generator().manual_seed(4321)
+    cx, qx = torch.rand(T, Nc, 3, 64, 64, generator=g), torch.rand(T, Nq, 3, 64, 64, generator=g)
+    cy = F.normalize(torch.randn(T, Nc, 4, generator=g), dim=-1)
+    qy = F.normalize(torch.randn(T, Nq, 4, generator=g), dim=-1)
+    mr = method == "ANPMRShapeNet3D"
+
+    def forward():
+        torch.manual_seed(99)
+        return model(cx.to(DEV), cy.to(DEV), qx.to(DEV))
+    before = _sharpen_resnet_attention(model, forward)
+    model.img_encoder.tap_log, model.decoder.tap_log = [], []
+    mu, var, kl = forward()
+    loss = LossFunc("mse", "shapenet_3d").calc_loss(mu, var, qy.to(DEV))
+    (loss + 1e-7 * kl).backward()
+    routes = [[(t.detach().cpu() > 0).double() for t in taps] for taps in model.img_encoder.tap_log + model.decoder.tap_log]
+    model.img_encoder.tap_log, model.decoder.tap_log = None, None
+    p = {k: v.detach().cpu().double().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+    pres = []
+    torch.manual_seed(99)
+    if mr:
+        mu_o, kl_o = O.anpmr3d_forward(p, cx.double(), cy.double(), qx.double(), routes=routes, pres=pres)
+    else:
+        mu_o, kl_o = O.resnet_np_forward(p, cx.double(), cy.double(), qx.double(), "attention", cfg.img_agg, routes=routes, pres=pres), 0.0
+    loss_o = O.calc_loss("shapenet_3d", mu_o, qy.double())
+    (loss_o + 1e-7 * kl_o).backward()
+    flips = sum(U.relu_flips(m, v, "resnet") for masks, pre in zip(routes, pres) for m, v in zip(masks, pre))
+    assert flips <= max(1, FLIP_RATE * _count_decisions(routes))
+    assert U.rel_err(mu, mu_o) <= U.RTOL
+    assert abs(loss.item() - loss_o.item()) <= U.RTOL * max(1.0, abs(loss_o.item()))
+    named = [(k, prm) for k, prm in model.named_parameters() if p[k].grad is not None]
+    gmax = max(p[k].grad.abs().max().item() for k, _ in named)
+    qk = {k: p[k].grad.abs().max().item() / gmax for k, _ in named if k.startswith("_W_q") or k.startswith("_W_k")}
+    assert len(qk) == 32 and min(qk.values()) > 1e-5, \
+        f"attention not sharp enough: query / key gradients at {min(qk.values()):.1e} of the largest"
+    worst, worst_qk = (0.0, None), (0.0, None)
+    for k, prm in named:
+        assert prm.grad is not None, k
+        if k in qk:
+            e = U.rel_err(prm.grad, p[k].grad)                                  # its OWN scale, no floor
+            worst_qk = max(worst_qk, (e, k))
+            assert e <= 2e-4, f"{k}: {e:.2e} of its own scale"
+        else:
+            e = U.rel_err(prm.grad, p[k].grad, floor=U.GRAD_FLOOR * gmax)
+            worst = max(worst, (e, k))
+            assert e <= U.RTOL, f"{k}: {e:.2e}"
+    print(f"sharp resnet attention {method} {Nc}+{Nq} favor2={favor_impl}: q / k row spread {before['q']:.2f} / {before['k']:.2f} -> 0.25; "
+          f"W_q / W_k gradients at {min(qk.values()):.1e} .. {max(qk.values()):.1e} of the largest, worst error {worst_qk[0]:.2e} of their "
+          f"own scale ({worst_qk[1]}); others {worst[0]:.2e} ({worst[1]}); {flips} routing ties")
 
 
 @pytest.mark.parametrize("name", U.fcl_case_names())
@@ -1341,11 +1470,16 @@ def test_trainer_ingest_path_equals_host_path(gpulib, tmp_path, monkeypatch):
         assert torch.equal(finals[0][k], finals[1][k]), k
 
 
-@pytest.mark.parametrize("method,agg", [("ANPShapeNet1D", "attention"), ("CNPShapeNet1D", "max")])
-def test_evaluator_context_sweep_vs_oracle(gpulib, tmp_path, method, agg):
+@pytest.mark.parametrize("method,agg,max_ctx,nq", [("ANPShapeNet1D", "attention", 5, None), ("CNPShapeNet1D", "max", 5, None),
+                                                    ("ANPShapeNet1D", "attention", 25, 30), ("CNPShapeNet1D", "mean", 25, 30)],
+                         ids=["anp_1..5", "cnp_max_1..5", "anp_1..25_nq30", "cnp_mean_1..25_nq30"])
+def test_evaluator_context_sweep_vs_oracle(gpulib, tmp_path, method, agg, max_ctx, nq):
     """SURVEY §8f rank 3, the eval path (evaluator/model_evaluator.py:95-179): forward-only test-mode batches for every
-    context size 1..max_ctx_num (Nc = Nq = size), mean / std of the test loss per size against the CPU oracle on the same
-    draws; the ingest route and the host route must agree bit for bit."""
+    context size 1..max_ctx_num, mean / std of the test loss per size against the CPU oracle on the same draws; the ingest
+    route and the host route must agree bit for bit.  The `1..25_nq30` cases are the shipped evaluation sizes (max_ctx_num = 25 in
+    cfg/evaluation/*, 30 target views per task as dataset/shapenet_3d.py:201-202's eval mode): context sizes above 16 leave the
+    specialised tail for the generic one and FAVOR+ runs up to 25 + 30 shots THROUGH THE EVALUATOR; the oracle is evaluated at the
+    sizes {1, 5, 16, 17, 25} (both sides of the 16-shot boundary), the kernels at every size."""
     import importlib
     import types
     from evaluator.model_evaluator import ModelEvaluator
@@ -1353,8 +1487,14 @@ def test_evaluator_context_sweep_vs_oracle(gpulib, tmp_path, method, agg):
     from trainer.losses import LossFunc
 
     class HostData(synth.SyntheticData):
+        def get_batch_u8(self, source, tasks_per_batch, shot):
+            if nq is None:
+                return synth.SyntheticData.get_batch_u8(self, source, tasks_per_batch, shot)
+            rng = {"train": self.rng, "validation": self.val_rng, "test": self.test_rng}[source]
+            return synth.get_batch_u8(self.task, tasks_per_batch, shot, nq, seed=int(rng.randint(0, 2 ** 31 - 1)))
+
         def get_batch(self, source, tasks_per_batch, shot):
-            xs, xq, ys, yq = synth.SyntheticData.get_batch_u8(self, source, tasks_per_batch, shot)
+            xs, xq, ys, yq = self.get_batch_u8(source, tasks_per_batch, shot)
             return synth.host_convert(xs), synth.host_convert(xq), ys, yq
 
     results = {}
@@ -1362,26 +1502,27 @@ def test_evaluator_context_sweep_vs_oracle(gpulib, tmp_path, method, agg):
         cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[128, 128, 1], tasks_per_batch=2, input_dim=3,
                                     output_dim=2, agg_mode=agg, img_agg="", dim_w=64, n_hidden_units_r=[100, 100],
                                     dim_r=64 if agg == "attention" else 100, dim_z=64, task="shapenet_1d", iterations=0, val_iters=2,
-                                    max_ctx_num=5, contrastive=False, ingest_u8=use_ingest, logger=None,
+                                    max_ctx_num=max_ctx, contrastive=False, ingest_u8=use_ingest, logger=None,
                                     save_path=str(tmp_path / f"eval{int(use_ingest)}"))
         model = getattr(importlib.import_module("networks." + method), method)(cfg).to(cfg.device)
         ev = ModelEvaluator(model=model, loss=LossFunc("mse", "shapenet_1d"), config=cfg, data=HostData())
         assert (ev.ingest is not None) == use_ingest
         results[use_ingest] = ev.evaluate()
         table = np.loadtxt(tmp_path / f"eval{int(use_ingest)}" / "test_losses.txt")
-        assert table.shape == (5, 3) and list(table[:, 0]) == [1, 2, 3, 4, 5]
+        assert table.shape == (max_ctx, 3) and list(table[:, 0]) == list(range(1, max_ctx + 1))
         assert os.path.exists(tmp_path / f"eval{int(use_ingest)}" / "models" / "model.pt")
     assert results[True] == results[False]
     # the oracle on the same draws
     p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    data = HostData()
+    check = set(range(1, 6)) if max_ctx <= 5 else {1, 5, 16, 17, 25}
     for si, source in enumerate(("validation", "test")):
-        for ctx_num in range(1, 6):
+        for ctx_num in sorted(check):
+            data = HostData()
             getattr(data, "test_rng" if source == "test" else "val_rng").seed(42)
             vals = []
             for _ in range(2):
                 cx, qx, cy, qy = data.get_batch(source, 2, ctx_num)
-                assert cx.shape[1] == ctx_num and qx.shape[1] == ctx_num
+                assert cx.shape[1] == ctx_num and qx.shape[1] == (ctx_num if nq is None else nq)
                 mu = O.vanilla_np_forward(p, cx, cy, qx, agg, tanh=True)
                 vals.append(O.calc_loss("shapenet_1d", mu, qy, test=True).view(1))
             vals = torch.cat(vals)

@@ -112,6 +112,29 @@ def test_oracle_favor_matches_reference():
             assert U.rel_err(t.grad, fx[f"{tag}/{n}"], floor=1e-12) <= 1e-5, (tag, n)
 
 
+def test_oracle_favor_at_the_shipped_c5_shape_matches_reference():
+    """favor_c5.npz: d = 256, m = 1419, 8 heads, 15 + 15 and 7 + 23 shots, inputs scaled so that the features sit ~50x above the
+    +1e-4 floor (meta.kp_median_over_floor) and dq / dk are first-class (0.4-0.6 of dv's scale): fast_attention.py:74-99,151-156
+    as ANPMRShapeNet3D.py:160-183 calls it."""
+    fx = np.load(os.path.join(U.GOLDEN, "favor_c5.npz"))
+    meta = json.loads(str(fx["meta"]))
+    proj = torch.from_numpy(fx["proj"])
+    for tag, mt in meta.items():
+        assert U.sha(proj) == mt["proj_sha"] and mt["m"] == 1419 and mt["d"] == 256
+        assert mt["kp_median_over_floor"] > 20 and min(mt["dq_over_dv"], mt["dk_over_dv"]) > 0.1
+        q, k, v, wout = (torch.from_numpy(fx[f"{tag}/{n}"]).requires_grad_(n != "wout") for n in ("q", "k", "v", "wout"))
+        # exp() of a 256-term dot product: the oracle's einsum and the reference's differ in summation order (5e-6 of scale)
+        assert U.rel_err(O.favor_features(q, proj, True)[0, 0], fx[f"{tag}/qp00"]) <= 5e-6
+        assert U.rel_err(O.favor_features(k, proj, False)[0, 0], fx[f"{tag}/kp00"]) <= 5e-6
+        out = O.favor_attention(q, k, v, proj)
+        assert U.rel_err(out, fx[f"{tag}/out"]) <= 5e-6
+        (out * wout).sum().backward()
+        # the reference's own fp32 dq / dk sit 0.5-1e-5 from the float64 evaluation of the same formulas at this shape (the batch-
+        # global stabiliser's gradient is a 340 k-term sum), two fp32 orders up to 2.7e-5 apart: held to 5e-5 here
+        for n, t in (("dq", q), ("dk", k), ("dv", v)):
+            assert U.rel_err(t.grad, fx[f"{tag}/{n}"]) <= 5e-5, (tag, n)
+
+
 def test_oracle_losses_match_reference():
     fx = np.load(os.path.join(U.GOLDEN, "losses.npz"))
     for tag, task, key, test in (("az", "shapenet_1d", "train", False), ("az", "shapenet_1d", "test", True),

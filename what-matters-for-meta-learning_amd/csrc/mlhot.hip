@@ -291,11 +291,7 @@ int mlhot_nt_xent_fwd(const float* z, int N, int d, int div, int mod, float t, f
   hipStream_t s = (hipStream_t)stream;
   const long long pairs = ntx::pair_count(N, div, mod);
   const int nblk = (N + 15) / 16;
-  {
-    ProfScope ps("ntxent.fwd", s);
-    hipLaunchKernelGGL(ntx::ntx_fwd_kernel, dim3(nblk), dim3(256), ntx::lds_bytes(N, d), s, a);
-  }
-  MLHOT_TRY(check_launch("nt_xent_fwd"));
+  MLHOT_TRY(tail_launch(ntx::ntx_fwd_kernel, nblk, 256, ntx::lds_bytes(N, d), a, s, "ntxent.fwd"));
   {
     ProfScope ps("ntxent.finish", s);
     hipLaunchKernelGGL(ntx::ntx_finish_kernel, dim3(1), dim3(64), 0, s, a.partial, nblk, pairs > 0 ? 1.0f / (float)pairs : 0.f, loss);
@@ -313,11 +309,7 @@ int mlhot_nt_xent_bwd(const float* z, int N, int d, int div, int mod, float t, c
   hipStream_t s = (hipStream_t)stream;
   const long long pairs = ntx::pair_count(N, div, mod);
   ntx::BwdArgs b{a, dloss, pairs > 0 ? 1.0f / (float)pairs : 0.f, dz};
-  {
-    ProfScope ps("ntxent.bwd", s);
-    hipLaunchKernelGGL(ntx::ntx_bwd_kernel, dim3((N + 15) / 16), dim3(256), ntx::lds_bytes(N, d), s, b);
-  }
-  return check_launch("nt_xent_bwd");
+  return tail_launch(ntx::ntx_bwd_kernel, (N + 15) / 16, 256, ntx::lds_bytes(N, d), b, s, "ntxent.bwd");
 #else
   (void)stream; set_error("nt_xent: GPU build only"); return MLHOT_ERR_ARG;
 #endif

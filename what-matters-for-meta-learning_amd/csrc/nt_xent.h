@@ -8,7 +8,7 @@
 // label) contributes  -log( e^{s_ap - m} / (e^{s_ap - m} + sum_{n: label(n) != label(a)} e^{s_an - m}) + tiny ),
 // m = max(s_ap, max_n s_an) treated as a constant; mean over the pairs (anchors without negatives contribute nothing).
 //
-// Kernels (N <= 512, d <= 256, d % 16 == 0; one workgroup = 16 anchors):
+// Kernels (N <= 2048, d <= 256, d % 16 == 0; one workgroup = 16 anchors):
 //   forward : S[16][N] = anchors x all rows on the matrix core (both operands read as float4 along d; the row norms come out of
 //             the same loads), per anchor negmax / E = sum_neg e^{s - negmax} / the pairs' loss and W = sum_p q/(q+tiny) e^{negmax-m}/den;
 //             per-workgroup partial sums, a one-workgroup finish kernel divides by the pair count.
@@ -23,7 +23,7 @@
 namespace mlhot {
 namespace ntx {
 
-constexpr int MAXN = 512, MAXD = 256;
+constexpr int MAXN = 2048, MAXD = 256;     // 16 x (N + 4) similarity rows in LDS: 156 KB of the CU's 160 at the limits (FCLANP's own config reaches N = 580)
 struct Args {
   const float* z; int N, d, div, mod; float inv_t;
   float *rinv, *negmax, *E, *W;         // [N] each (saved for the backward)

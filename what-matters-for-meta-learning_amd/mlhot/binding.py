@@ -22,6 +22,9 @@ LOSS = {"azimuth": 0, "mse": 1, "quaternion": 2, "degree": 3, "distractor": 4}
 _f = C.c_void_p  # every device pointer travels as void*
 
 
+ABI_VERSION = 2     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients)
+
+
 class MlhotError(RuntimeError):
     pass
 
@@ -129,6 +132,9 @@ class MlhotLib:
         MlhotLib._last = self
         c = self.c
         c.mlhot_version.restype = C.c_int
+        if c.mlhot_version() != ABI_VERSION:       # before any other symbol is touched: an older prebuilt library lacks the newer ones
+            raise MlhotError(f"mlhot: libmlhot.so has ABI version {c.mlhot_version()}, this binding needs {ABI_VERSION} "
+                             f"(include/mlhot.h MLHOT_ABI_VERSION) - rebuild with mlhot.build.build_product(force=True)")
         c.mlhot_last_error.restype = C.c_char_p
         for fn in ("mlhot_enc_vanilla_saved_bytes", "mlhot_enc_vanilla_scratch_bytes", "mlhot_linear_bwd_scratch_bytes",
                    "mlhot_favor_ws_bytes", "mlhot_np_struct_bytes", "mlhot_np_saved_bytes", "mlhot_np_scratch_bytes",
@@ -176,8 +182,6 @@ class MlhotLib:
         for which, st in ((0, NpDims), (1, NpParams), (2, NpGrads)):
             if c.mlhot_np_struct_bytes(which) != C.sizeof(st):
                 raise MlhotError(f"mlhot: ABI struct size mismatch for {st.__name__}")
-        if c.mlhot_version() != 1:
-            raise MlhotError("mlhot: ABI version mismatch")
 
     # ------------------------------------------------------------------------------------------
     def _rc(self, rc, what):

@@ -7,8 +7,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 PRODUCT_SO = os.path.join(CSRC, "libmlhot.so")
 SOURCES = ["mlhot.hip"]
-HEADERS = ["common.h", "foreach.h", "igemm.h", "problems.h", "ops_direct.h", "favor.h", "encoder.h", "np_vanilla.h",
-           "conv_tc.h", "conv_split.h", "conv3_tc.h", "enc_linear.h", "tail_fused.h", "tail_spec.h", "tail_cnp.h", "conv_rt.h", "ingest.h", "bbb_multi.h", "mt_normal.h", "nt_xent.h", "resnet_ws.h", "resnet_trunk.h", "linear_skinny.h", "favor2.h", os.path.join("..", "..", "include", "mlhot.h")]
+
+
+def _headers():
+    """Every header next to the sources (globbed: a header added to csrc/ cannot be forgotten here) + the C ABI's."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "mlhot.h")]
 
 
 def _stale(out, deps):
@@ -19,7 +23,7 @@ def _stale(out, deps):
 
 
 def _deps():
-    return [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return [os.path.join(CSRC, f) for f in SOURCES] + _headers()
 
 
 def build_product(force=False, verbose=False):

@@ -6,6 +6,8 @@ one sum all-reduce of a single flat fp32 gradient bucket per step (RCCL over xGM
 box, gloo in the CPU tests); with equal shards mean_r(grad_r) equals the full-batch gradient
 because every loss is a mean over (task, target).
 """
+import collections
+import logging
 import os
 
 import torch
@@ -46,9 +48,14 @@ class StabiliserExchange:
     Install with mlhot.ops.set_stabiliser_exchange(StabiliserExchange()) (ModelTrainer does, for config.strict_sharded_parity);
     without it each rank uses its own maximum (a <= 1e-6 effect on the loss)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, dedicated_group=False):
+        """`dedicated_group`: create a process group of its own for the scalar exchanges (every rank must construct the object
+        at the same point).  ProcessGroupNCCL runs the collectives of one group on one internal stream, so on the default group
+        the backward's 4-byte exchange would queue behind an early gradient bucket of several MB that is still in flight."""
+        if dedicated_group and group is None and dist.is_initialized() and dist.get_world_size() > 1:
+            group = dist.new_group()
         self.group = group
-        self.calls = []                 # "fwd" / "bwd", in issue order (tests)
+        self.calls = collections.deque(maxlen=64)     # the most recent "fwd" / "bwd", in issue order (tests, diagnostics)
 
     def _world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -112,6 +119,7 @@ class GradBucket:
         self.early = [p for p in (early or []) if p.requires_grad]
         self._early_ids = {id(p) for p in self.early}
         self._hooks, self._armed, self._left, self._early_state = None, False, 0, None
+        self._warned_prune = False
         self.issue_log = []                  # ("early" | "rest" | "all", n_elements) per collective of the last step (tests, diagnostics)
 
     @staticmethod
@@ -149,7 +157,7 @@ class GradBucket:
             with torch.cuda.stream(self._comm):
                 self._all_reduce(flat)
             flat.record_stream(self._comm)
-            self._pending.append(self._comm.record_event())
+            self._pending.append((self._comm.record_event(), flat.device))
         elif asynchronous and type(self)._all_reduce is GradBucket._all_reduce and not flat.is_cuda:
             self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -159,8 +167,8 @@ class GradBucket:
         """Join every collective issued since the last wait(): the current stream (GPU) / the host (gloo) may read the buckets."""
         pending, self._pending = self._pending, []
         for h in pending:
-            if isinstance(h, torch.cuda.Event):
-                torch.cuda.current_stream().wait_event(h)
+            if isinstance(h, tuple):                          # (event of the communication stream, the bucket's device)
+                torch.cuda.current_stream(h[1]).wait_event(h[0])
             elif h is not None:
                 h.wait()
 
@@ -193,11 +201,32 @@ class GradBucket:
     def sync(self, defer_scale=False, wait=True):
         """Returns the factor the caller still has to apply to the gradients (1.0 unless defer_scale).  wait=False: the
         collectives are only issued (side stream / async handles); call wait() before the gradients are read."""
+        if not wait and not defer_scale:      # before anything is issued: a rank that raises must not leave the others inside a collective
+            raise ValueError("GradBucket.sync(wait=False) needs defer_scale=True (the average would read the bucket)")
         world = self.world_size()
         live = [p for p in self.params if p.grad is not None]
         if not self.issue_log or self.issue_log[0][0] != "early":
             self.issue_log = []
-        self._armed = False                                  # a backward that never reached every early parameter: reduce them below
+        if self._armed:
+            # The backward never reached every early parameter (modules a flavour / step does not use: transform_y, the latent
+            # heads, FCL-only paths): nothing went out early, everything is reduced below.  From the next step on the early
+            # bucket counts only parameters that DID receive a gradient - grad is None on every rank alike (class docstring), so
+            # the ranks prune identically - and the silent fallback is logged once.
+            self._armed = False
+            missing = [p for p in self.early if p.grad is None]
+            if missing and len(missing) < len(self.early):
+                if not self._warned_prune:
+                    self._warned_prune = True
+                    logging.getLogger("mlhot.dist").warning(
+                        "GradBucket: %d of %d early parameters received no gradient; the early bucket did not fire this step and "
+                        "is re-planned without them", len(missing), len(self.early))
+                gone = {id(p) for p in missing}
+                self.early = [p for p in self.early if id(p) not in gone]
+                self._early_ids = {id(p) for p in self.early}
+                if self._hooks is not None:
+                    for h in self._hooks:
+                        h.remove()
+                    self._hooks = None
         if world == 1 or not live:
             return 1.0
         scale = 1.0 / world
@@ -215,12 +244,8 @@ class GradBucket:
                 self.wait()
             if defer_scale:
                 return scale
-            if not wait:
-                raise ValueError("GradBucket.sync(wait=False) needs defer_scale=True (the average would read the bucket)")
             shared.mul_(scale)
             return 1.0
-        if not wait and not defer_scale:
-            raise ValueError("GradBucket.sync(wait=False) needs defer_scale=True (the average would read the bucket)")
         views = []
         if live:
             n = sum(p.grad.numel() for p in live)

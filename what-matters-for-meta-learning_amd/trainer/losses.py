@@ -6,7 +6,7 @@ The functional-contrastive term (losses.py:82-99) is NT-Xent from the un-vendore
 similarity, every same-label pair a positive, every different-label pair a negative of its anchor, mean over the positive
 pairs).  Its labels are always arange blocks, so the term runs as mlhot_nt_xent_fwd / _bwd (csrc/nt_xent.h: similarity on the
 matrix core, per-anchor log-sum-exp, hand-derived backward; 2 + 1 launches, nothing built on the host, capturable); embeddings
-outside the kernels' limits (N > 512 rows or d > 256 / d % 16 != 0) raise - there is no torch fallback on the product path.
+outside the kernels' limits (N > 2048 rows or d > 256 / d % 16 != 0) raise - there is no torch fallback on the product path.
 """
 import torch
 
@@ -19,8 +19,8 @@ def nt_xent(z, div, mod, t=0.07):
     (a, p)  -log( exp(s_ap / t) / (exp(s_ap / t) + sum over negatives n of a of exp(s_an / t)) ), cosine similarities s, the
     maximum subtracted before the exponentials, `finfo.tiny` added inside the log, averaged over the positive pairs."""
     N, d = z.shape
-    if N > 512 or d > 256 or d % 16:
-        raise MlhotError(f"nt_xent: [{N}, {d}] embeddings are outside the kernel's limits (N <= 512, d <= 256, d % 16 == 0)")
+    if N > 2048 or d > 256 or d % 16:
+        raise MlhotError(f"nt_xent: [{N}, {d}] embeddings are outside the kernel's limits (N <= 2048, d <= 256, d % 16 == 0)")
     return NTXentFunction.apply(z, int(div), int(mod), float(t))
 
 

@@ -44,7 +44,7 @@ class ModelTrainer(BaseTrainer):
                 raise ValueError("config.strict_sharded_parity runs a collective between two C calls of the forward: not with config.graph_steps")
             from mlhot import ops
             from mlhot.dist import StabiliserExchange
-            ops.set_stabiliser_exchange(StabiliserExchange())
+            ops.set_stabiliser_exchange(StabiliserExchange(dedicated_group=True))
         self.ingest, self._staged = None, None
         self._prefetch = False          # set per iteration by train(): may the NEXT training batch be drawn right away?
         self.rank0 = dist_rank() == 0   # files / logs / TensorBoard are rank 0's business (every rank holds the same weights)
