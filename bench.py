@@ -547,9 +547,11 @@ def timed_region(run, steps, warmup, world, device, sync=None, record=None):
     import torch.distributed as dist
     sync = sync or (lambda: None)
 
+    multi = world > 1 or (dist.is_available() and dist.is_initialized())     # a forced world of one (mlhot.dist.force_collectives) runs the protocol too
+
     def fence():
         sync()
-        if world > 1:
+        if multi:
             dist.barrier()
             sync()
 
@@ -567,7 +569,7 @@ def timed_region(run, steps, warmup, world, device, sync=None, record=None):
     t_enqueue = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -583,6 +585,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--strict", action="store_true",
+                    help="N > 1: FAVOR+'s key stabiliser is the maximum over the WHOLE meta-batch, as in the reference's single-process batch "
+                         "(fast_attention.py:96-97), through mlhot.dist.StabiliserExchange - two scalar collectives per attention pass between "
+                         "the staged C calls, so the step runs eagerly (implies --no-graph).  Default: each rank's own maximum "
+                         "(negligible for ANPShapeNet1D, up to 15 %% of a gradient's scale for the d = 256 models, DESIGN.md section 6d)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fwd-only / +Adam timing legs")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing experiments (results become WRONG; never a bench line)")
     ap.add_argument("--eps", choices=("host", "device"), default="host",
@@ -613,6 +620,16 @@ def main():
     for kv in args.opt:
         name, _, val = kv.partition("=")
         mlhot.lib().set_option(name, int(val))
+    stabiliser = "single process: the batch maximum"
+    if world > 1 or mdist.force_collectives():
+        stabiliser = "rank-local maximum (graph replay; --strict for the reference's batch-global form)"
+        if args.strict:
+            from mlhot import ops as mops
+            mops.set_stabiliser_exchange(mdist.StabiliserExchange(dedicated_group=True))
+            args.no_graph = True
+            stabiliser = "batch-global maximum over all ranks (StabiliserExchange, eager steps)"
+    if (world > 1 or mdist.force_collectives()) and rank == 0:
+        print(f"[bench] key stabiliser: {stabiliser}", file=sys.stderr)
     if world > 1 and rank == 0:
         print(f"[bench] {world} ranks over {dist.get_backend()} (RCCL when 'nccl'); rank 0 on {torch.cuda.get_device_name(device)}; "
               f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG', '-')}", file=sys.stderr)
@@ -775,7 +792,7 @@ def main():
                       "note": "informational, not the headline metric"}
         except Exception as e:  # noqa: BLE001 - extras must never break the bench line
             extras = {"error": f"{type(e).__name__}: {e}"}
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
 
     if rank == 0:
@@ -786,7 +803,7 @@ def main():
                "config": {"workload": w["name"], "tasks_per_gpu": T, "global_tasks": world * T,
                           "context_shots": NC, "target_shots": NQ, "image": w["image"],
                           "parallelism": f"task-sharded x{world}, one flat grad all-reduce" if world > 1 else "single GPU"},
-               "final_loss": final_loss, "hipgraph": graphed, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
+               "final_loss": final_loss, "hipgraph": graphed, "key_stabiliser": stabiliser, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
                "ms_per_step_event_median": step_ms[len(step_ms) // 2], "ms_per_step_event_min": step_ms[0],
                "timing": f"value = wall clock over {args.steps} steps between two barrier + synchronize fences (max over ranks); "
                          "event_median = median of per-step HIP-event durations on the replaying stream",
@@ -826,7 +843,7 @@ def main():
                 with open(os.environ["MLHOT_BENCH_KERNELS"], "w") as f:
                     json.dump({k: v for k, v in top}, f, indent=1)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -91,6 +91,21 @@ struct ProfScope { ProfScope(const char*, hipStream_t) {} };
 #endif
 
 #ifndef MLHOT_HOSTSIM
+// A helper stream of the library's own beside the caller's stream (defined in mlhot.hip).  fork(): the lane waits for
+// everything enqueued on `main` so far; join(): `main` waits for the lane.  Both are event record + stream wait, so inside a
+// hipGraph capture of `main` they become graph edges and the lane's launches parallel branches.  Used for work that is off the
+// step's critical path (the weight-gradient slab folds of the encoder backward run beside the kernels that follow their
+// producers).  One lane per caller stream (created on first use outside a capture; nullptr while `main` is capturing and no lane
+// exists yet, or when the "side_fold" option is 0 - the callers then run the work in line).
+struct SideLane {
+  hipStream_t main, side; hipEvent_t ev_fork, ev_join;
+  bool fork() { return hipEventRecord(ev_fork, main) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess; }
+  bool join() { return hipEventRecord(ev_join, side) == hipSuccess && hipStreamWaitEvent(main, ev_join, 0) == hipSuccess; }
+};
+SideLane* side_lane(hipStream_t main);
+#endif
+
+#ifndef MLHOT_HOSTSIM
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -172,19 +172,33 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     mp.first[mp.n + 1] = mp.first[mp.n] + c2::sum_parts_blocks(len);
     ++mp.n;
   };
-  auto flush = [&]() -> int {
+  auto flush_on = [&](hipStream_t st, const char* what) -> int {
     if (mp.n == 0) return MLHOT_OK;
     {
-      ProfScope ps("slab_reduce", s);
-      hipLaunchKernelGGL(c2::sum_parts_multi_kernel, dim3(mp.first[mp.n]), dim3(256), 0, s, mp);
+      ProfScope ps(what, st);
+      hipLaunchKernelGGL(c2::sum_parts_multi_kernel, dim3(mp.first[mp.n]), dim3(256), 0, st, mp);
     }
     mp.n = 0;
-    return check_launch("slab_reduce");
+    return check_launch(what);
   };
+  auto flush = [&]() -> int { return flush_on(s, "slab_reduce"); };
   const bool defer = g_opt.conv2_tc && n > 0;
+  // The folds do not sit on the step's critical path: with a side lane (common.h) each one is issued right behind its producer
+  // and runs BESIDE the kernels that follow (the tail's slabs under the Linear backward, conv3's 28 MB under conv3's data gradient
+  // and the conv12 weight gradient, conv2's 14 MB under the conv12 data gradient); the lane is joined at the end.  Fixed fold
+  // order either way (bitwise the same result).  Without a lane: ONE deferred launch at the very end, as before.
+  SideLane* lane = defer ? side_lane(s) : nullptr;
+  bool forked = false;
+  auto fold_aside = [&]() -> int {            // everything pended so far, on the lane, behind what `s` holds now
+    if (lane == nullptr) return MLHOT_OK;     // stays pended for the final flush
+    if (!lane->fork()) { set_error("enc_vanilla_bwd: side lane fork failed"); return MLHOT_ERR_LAUNCH; }
+    forked = true;
+    return flush_on(lane->side, "slab_reduce.side");
+  };
   if (extra != nullptr && extra->slab != nullptr) {
     pend(extra->slab, extra->out, extra->nparts, extra->len, extra->stride);
     if (!defer) MLHOT_TRY(flush());
+    else MLHOT_TRY(fold_aside());
   }
 #else
   (void)extra;
@@ -192,7 +206,13 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
   if (n <= 0) return MLHOT_OK;
   EncSaved sv = enc_saved_carve(n, (void*)saved, (size_t)-1 / 2);
   EncScratch sc = enc_scratch_carve(n, dim_w, scratch, scratch_bytes);
-  if (!sc.ok) { set_error("enc_vanilla_bwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes); return MLHOT_ERR_WORKSPACE; }
+  if (!sc.ok) {
+#ifndef MLHOT_HOSTSIM
+    if (forked) (void)lane->join();
+#endif
+    set_error("enc_vanilla_bwd: scratch too small (%zu < %zu)", scratch_bytes, sc.bytes);
+    return MLHOT_ERR_WORKSPACE;
+  }
   const Src2 x{img0, n0, img1, (size_t)128 * 128};
 
   // Linear(4096 -> dim_w): input gradient (masked by conv3's ReLU), weight + bias gradient
@@ -229,6 +249,7 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     // weights in accumulator order (coalesced stores in the kernel), un-permuted by the fold
     pend(slab_w, g.w3, grid, L3, R3, 2);
     pend(slab_b, g.b3, grid, 64, R3);
+    MLHOT_TRY(fold_aside());
     {
       ProfScope ps("enc.bwd.conv3.dgrad", s);
       hipLaunchKernelGGL(c3::conv3_dgrad_kernel, dim3(grid), dim3(c3::D_NT), 0, s, p.w3, sc.dy3, sc.dp2, n);
@@ -264,6 +285,7 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     // the weights sit in the slab in accumulator order (coalesced stores in the kernel); the fold un-permutes them
     pend(slab_w, g.w2, grid, L2, R2, 1);
     pend(slab_b, g.b2, grid, 48, R2);
+    MLHOT_TRY(fold_aside());
     {
       ProfScope ps("enc.bwd.conv12.dgrad", s);
       hipLaunchKernelGGL(c2::conv12_dgrad_kernel, dim3(grid), dim3(c2::NT2), 0, s, xs, sv.m1, sc.dp2, sv.p2, sv.am2, p.w2, slab_1, n);
@@ -276,7 +298,9 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
       hipLaunchKernelGGL(c2::conv1_grads_kernel, dim3(16), dim3(320), 0, s, slab_1, grid, g.w1, g.b1);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv1.grads"));
-    return flush();
+    MLHOT_TRY(flush());                        // conv1's 320 x grid slab (and everything, when there is no lane)
+    if (forked && !lane->join()) { set_error("enc_vanilla_bwd: side lane join failed"); return MLHOT_ERR_LAUNCH; }
+    return MLHOT_OK;
   } else
 #endif
   {

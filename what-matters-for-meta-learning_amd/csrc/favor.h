@@ -136,35 +136,23 @@ struct FavorOut {
 };
 
 // ---- backward -------------------------------------------------------------------------------
-// wv[t,h,n] = sum_e dO O
-struct FavorBwdW {          // one workgroup per (t, h, n), reduction over the d channels
-  typedef float T;
-  FavorDims f; const float* out; const float* dout; float* wv;
-  MLHOT_HD T identity() const { return 0.f; }
-  MLHOT_HD T load(int i, int e) const {
-    const int n = i % f.Nq, h = (i / f.Nq) % f.H, t = i / (f.Nq * f.H);
-    const size_t o = (size_t)(t * f.Nq + n) * ((size_t)f.d * f.H) + h + (size_t)e * f.H;
-    return dout[o] * out[o];
-  }
-  MLHOT_HD T combine(T a, T b) const { return a + b; }
-  MLHOT_HD void finish(int i, T a) const { wv[i] = a; }
-};
-// dS[t,h,n,n'] = (dO[t,h,n,:] . v[(t,n',h),:] - wv[t,h,n]) / D[t,h,n]
+// dS[t,h,n,n'] = dO[t,h,n,:] . (v[(t,n',h),:] - O[t,h,n,:]) / D[t,h,n]: the difference is formed per channel, BEFORE the sum - O[n] is
+// a convex combination of the value rows, and dO . v - dO . O as two rounded sums loses the digits they share (favor2.h, B1)
 struct FavorBwdDS {         // one workgroup per entry, reduction over the d channels
   typedef float T;
-  FavorDims f; const float* dout; const float* v; const float* wv; const float* D; float* dS;
+  FavorDims f; const float* dout; const float* v; const float* out; const float* D; float* dS;
   MLHOT_HD T identity() const { return 0.f; }
   MLHOT_HD T load(int i, int e) const {
     const int np = i % f.Nc, n = (i / f.Nc) % f.Nq, h = (i / (f.Nc * f.Nq)) % f.H, t = i / (f.Nc * f.Nq * f.H);
     const size_t ob = (size_t)(t * f.Nq + n) * ((size_t)f.d * f.H) + h;
     const float* vr = v + ((size_t)(t * f.Nc + np) * f.H + h) * f.d;
-    return dout[ob + (size_t)e * f.H] * vr[e];
+    return dout[ob + (size_t)e * f.H] * (vr[e] - out[ob + (size_t)e * f.H]);
   }
   MLHOT_HD T combine(T a, T b) const { return a + b; }
   MLHOT_HD void finish(int i, T a) const {
     const int n = (i / f.Nc) % f.Nq, h = (i / (f.Nc * f.Nq)) % f.H, t = i / (f.Nc * f.Nq * f.H);
     const size_t sd = (size_t)(t * f.H + h) * f.Nq + n;
-    dS[i] = (a - wv[sd]) / D[sd];
+    dS[i] = a / D[sd];
   }
 };
 // dv[(t,n',h)][e] = sum_n S[t,h,n,n'] dO[t,h,n,e] / D[t,h,n]
@@ -255,8 +243,7 @@ inline int favor_backward(const FavorDims& f, const float* q, const float* k, co
   const float c = powf((float)f.d, -0.25f), ratio = 1.0f / sqrtf((float)f.m), eps = 1e-4f;
   const size_t rq = f.rows_q(), rk = f.rows_k(), thn = (size_t)f.T * f.H * f.Nq;
   if (st.first()) {
-  MLHOT_TRY(run_reduce_seg(FavorBwdW{f, out, dout, w.wv}, (int)thn, f.d, s, "favor.bwd.w"));
-  MLHOT_TRY(run_reduce_seg(FavorBwdDS{f, dout, v, w.wv, w.D, w.dS}, (int)(thn * f.Nc), f.d, s, "favor.bwd.dS"));
+  MLHOT_TRY(run_reduce_seg(FavorBwdDS{f, dout, v, out, w.D, w.dS}, (int)(thn * f.Nc), f.d, s, "favor.bwd.dS"));
   MLHOT_TRY(run_foreach(FavorBwdDV{f, w.S, w.D, dout, dv}, rk * f.d, s, "favor.bwd.dv"));
   MLHOT_TRY(run_foreach(FavorBwdG{f, 1, w.dS, w.qf, w.kf, ratio * eps, w.Gq}, rq * f.m, s, "favor.bwd.Gq"));
   MLHOT_TRY(run_foreach(FavorBwdG{f, 0, w.dS, w.kf, w.qf, ratio * eps, w.Gk}, rk * f.m, s, "favor.bwd.Gk"));

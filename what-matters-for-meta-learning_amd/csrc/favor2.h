@@ -4,7 +4,7 @@
 //       straight from global memory in MFMA lane order; partial row maxima (+ first arg-max) and the workgroup's key maximum.
 //   F2  grid (task x head): row / batch-global stabilisers from the partials, E = ratio exp(dd - diag - stab) (kept for the
 //       backward), S = F_q F_k^T (K = m features split over the four waves), D = rowsum(S), out = S V / D in the merged order.
-//   B1  grid (task x head): w = <dO, O>, dS = (dO V^T - w) / D, dV, G_q = (dS F_k) . E_q, G_k = (dS^T F_q) . E_k and their row sums.
+//   B1  grid (task x head): w = <dO, O - c>, dS = (dO (V - c)^T - w) / D with c = the block's first value row, dV, G_q = (dS F_k) . E_q, G_k = (dS^T F_q) . E_k and their row sums.
 //   B2  grid (task x head, 64-wide slice of d): dx = c (G - stabiliser corrections) P - rowsum c^2 x for query and key rows.
 // Feature buffers use a row stride mp = m rounded up to 16 (float4 operand loads); features >= m are written as zeros.
 // v_mfma_f32_16x16x4_f32: A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15], C/D lane l reg r = C[4*(l>>4)+r][l&15]; a float4
@@ -393,19 +393,24 @@ __global__ __launch_bounds__(256) void b1_kernel(const Args a) {
   for (int i = tid; i < Nq * Nc; i += 256) s_S[(i / Nc) * (MAXN + 1) + i % Nc] = a.w.S[(size_t)th * Nq * Nc + i];
   if (tid < Nq) s_D[tid] = a.w.D[(size_t)th * Nq + tid];
   for (int i = tid; i < MAXN * (MAXN + 1); i += 256) s_dS[i] = 0.f;
-  // w[n] = sum_e dO[n][e] O[n][e]: 8 threads per row
+  // dS[n][n'] = dO[n] . (v[n'] - O[n]) / D[n].  O[n] is a convex combination of the block's value rows, so when those share a
+  // large common component (the task encoder's features do: |v| ~ 20 x the spread between keys) the two inner products dO . v and
+  // dO . O agree in their leading digits and their fp32 rounding dominates the difference.  Both are therefore taken relative to
+  // the block's first value row c = v[0]: dO . (v[n'] - c) and w[n] = dO . (O[n] - c) - the same dS, without the common mode.
+  const float* vc = a.v + ((size_t)(t * Nc) * H + h) * d;
+  // w[n] = sum_e dO[n][e] (O[n][e] - c[e]): 8 threads per row
   {
     const int n = tid >> 3, part = tid & 7;
     float s = 0.f;
     if (n < Nq) {
       const size_t ob = (size_t)(t * Nq + n) * ((size_t)d * H) + h;
 #pragma unroll 4
-      for (int e = part; e < d; e += 8) s += a.dout[ob + (size_t)e * H] * a.out[ob + (size_t)e * H];
+      for (int e = part; e < d; e += 8) s += a.dout[ob + (size_t)e * H] * (a.out[ob + (size_t)e * H] - vc[e]);
     }
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
     if (n < Nq && part == 0) s_w[n] = s;
   }
-  // T1[n][n'] = sum_e dO[n][e] v[n'][e] on the matrix core: k-steps (4 channels e) ks = wv, wv + 4, ...; 8 per trip in flight
+  // T1[n][n'] = sum_e dO[n][e] (v[n'][e] - c[e]) on the matrix core: k-steps (4 channels e) ks = wv, wv + 4, ...; 8 per trip in flight
   {
     f32x4_t acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
     const float* ap[2]; const float* bp[2];
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(256) void b1_kernel(const Args a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           av[u][i] = (ap[i] && e < d) ? ap[i][(size_t)e * H] : 0.f;
-          bv[u][i] = (bp[i] && e < d) ? bp[i][e] : 0.f;
+          bv[u][i] = (bp[i] && e < d) ? bp[i][e] - vc[e] : 0.f;
         }
       }
 #pragma unroll

@@ -1,6 +1,7 @@
 // libmlhot.so - C ABI (include/mlhot.h) over the gfx950 kernels.  Single translation unit:
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC mlhot.hip -o libmlhot.so
 #include <stdarg.h>
+#include <mutex>
 
 #include "common.h"
 #include "foreach.h"
@@ -33,6 +34,26 @@ int g_favor2 = 1;
 
 
 #ifndef MLHOT_HOSTSIM
+// ---- side lanes (common.h) ---------------------------------------------------------------------------
+int g_side_fold = 1;
+static std::mutex g_lane_mu;
+static SideLane g_lanes[8];
+static int g_nlanes = 0;
+SideLane* side_lane(hipStream_t main) {
+  if (!g_side_fold) return nullptr;
+  std::lock_guard<std::mutex> lk(g_lane_mu);
+  for (int i = 0; i < g_nlanes; ++i) if (g_lanes[i].main == main) return &g_lanes[i];
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(main, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;   // no object creation inside a capture
+  if (g_nlanes == 8) return nullptr;
+  SideLane l{};
+  l.main = main;
+  if (hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  g_lanes[g_nlanes] = l;
+  return &g_lanes[g_nlanes++];
+}
+
 // ---- per-launch event profiler -------------------------------------------------------------------
 bool g_prof_on = false;
 struct ProfRec { const char* what; hipEvent_t a, b; bool open; };
@@ -66,7 +87,10 @@ int mlhot_set_option(const char* name, int value) {
   if (!strcmp(name, "tail_spec")) { g_opt.tail_spec = value; return MLHOT_OK; }     // fused tail: bit mask of the phases that run the kernels specialised for the shipped dimensions (csrc/tail_spec.h; default 63 = all six) instead of the run-time-shaped ones
   if (!strcmp(name, "materialize_a1")) { g_opt.materialize_a1 = value; return MLHOT_OK; }
   if (!strcmp(name, "dbg")) { g_opt.dbg = value; return MLHOT_OK; }   // timing experiments only (results become wrong)
-  if (!strcmp(name, "favor2")) { g_favor2 = value; return MLHOT_OK; }  // FAVOR+: the two-launch kernels (csrc/favor2.h, default) or favor.h's chain
+  if (!strcmp(name, "favor2")) { g_favor2 = value; return MLHOT_OK; }
+#ifndef MLHOT_HOSTSIM
+  if (!strcmp(name, "side_fold")) { g_side_fold = value; return MLHOT_OK; }   // 1 (default): slab folds of the encoder backward on the library's helper stream (common.h SideLane)
+#endif  // FAVOR+: the two-launch kernels (csrc/favor2.h, default) or favor.h's chain
   set_error("mlhot_set_option: unknown option %s", name);
   return MLHOT_ERR_ARG;
 }

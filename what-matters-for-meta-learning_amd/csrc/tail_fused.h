@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     const int n = tid >> 4, part = tid & 15;
     float s = 0.f;
     if (n < d.Nq)
-      for (int e = part; e < d.dw; e += 16) s += s_do[n * Lx + e] * s_o[n * Lx + e];
+      for (int e = part; e < d.dw; e += 16) s += s_do[n * Lx + e] * (s_o[n * Lx + e] - s_v[e]);     // relative to c = v[0], see below
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
     if (part == 0) s_st[n] = s;
@@ -1233,10 +1233,12 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   }
   __syncthreads();
   MLHOT_TSTAMP(131);
-  // dS[n][n'] = (dO[n] . v[n'] - wv[n]) / D[n]   (wave 0), valid entries only
+  // dS[n][n'] = (dO[n] . (v[n'] - c) - wv[n]) / D[n], wv[n] = dO[n] . (O[n] - c), c = v[0]   (wave 0), valid entries only.  O[n] is
+  // a convex combination of the value rows: without the common centre the two inner products share their leading digits whenever
+  // the value rows have a large common component, and the difference is their fp32 rounding (favor2.h, B1)
   if (wave == 0) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int e0 = 0; e0 < d.dw; e0 += 4) acc = mfma4(s_do[lr * Lx + e0 + lq], s_v[lr * Lx + e0 + lq], acc);
+    for (int e0 = 0; e0 < d.dw; e0 += 4) acc = mfma4(s_do[lr * Lx + e0 + lq], s_v[lr * Lx + e0 + lq] - s_v[e0 + lq], acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = 4 * lq + r, np = lr;

@@ -1148,11 +1148,12 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   g_o.finish(g_o.mma(s_drr, B_LX, wave, lane), s_red, nullptr, 0, s_do, B_LX, nullptr, 0, 0, wave, lane);
   __syncthreads();
   MLHOT_TSTAMP(130);
-  // wv[n] = dO[n] . O[n]  (16 threads per row)
+  // wv[n] = dO[n] . (O[n] - c), c = v[0]: the common centre of the two inner products of dS below  (16 threads per row)
   if (tid < 256) {
     const int n = tid >> 4, part = tid & 15;
     const f32x4_t x = *reinterpret_cast<lc4ptr>(s_do + n * B_LX + 4 * part), y = *reinterpret_cast<lc4ptr>(s_o + n * B_LX + 4 * part);
-    float sum = x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    const f32x4_t cz = *reinterpret_cast<lc4ptr>(s_v + 4 * part);
+    float sum = x[0] * (y[0] - cz[0]) + x[1] * (y[1] - cz[1]) + x[2] * (y[2] - cz[2]) + x[3] * (y[3] - cz[3]);
     sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64);
     if (part == 0) s_st[n] = sum;
   }
@@ -1173,13 +1174,15 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   }
   __syncthreads();
   MLHOT_TSTAMP(131);
-  // dS[n][n'] = (dO[n] . v[n'] - wv[n]) / D[n]   (wave 0), valid entries only
+  // dS[n][n'] = (dO[n] . (v[n'] - c) - wv[n]) / D[n]   (wave 0), valid entries only.  O[n] is a convex combination of the value rows:
+  // taken against the common centre c = v[0] the two inner products no longer share the value rows' common component, whose fp32
+  // rounding would otherwise dominate their difference (favor2.h, B1; measured on trained-scale features: 5e-4 -> 1e-5 of dk)
   if (wave == 0) {
     f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e0 = 0; e0 < DW; e0 += 8) {
-      a0 = mfma4(s_do[lr * B_LX + e0 + lq], s_v[lr * B_LX + e0 + lq], a0);
-      a1 = mfma4(s_do[lr * B_LX + e0 + 4 + lq], s_v[lr * B_LX + e0 + 4 + lq], a1);
+      a0 = mfma4(s_do[lr * B_LX + e0 + lq], s_v[lr * B_LX + e0 + lq] - s_v[e0 + lq], a0);
+      a1 = mfma4(s_do[lr * B_LX + e0 + 4 + lq], s_v[lr * B_LX + e0 + 4 + lq] - s_v[e0 + 4 + lq], a1);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -14,15 +14,28 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives():
+    """MLHOT_FORCE_COLLECTIVES=1: a world of ONE still initialises the process group and runs every collective of the data path
+    (GradBucket's all-reduces incl. the early bucket and the communication stream, StabiliserExchange's exchanges) instead of
+    taking the world == 1 shortcuts.  A test hook: it lets a 1-GPU box drive backend "nccl" - i.e. load librccl and order its
+    kernels against the compute / communication streams - before an 8-GPU node ever does (tests/test_gpu_parity.py::
+    test_rccl_world_of_one_*); results are unchanged (a sum over one rank)."""
+    return os.environ.get("MLHOT_FORCE_COLLECTIVES") == "1"
+
+
 def init_from_env(backend=None):
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if backend == "nccl" and not os.environ.get("MLHOT_ONE_DEVICE"):
+            kw["device_id"] = torch.device("cuda", local)          # binds the communicator to this rank's GPU up front
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local, world
 
 
@@ -63,7 +76,7 @@ class StabiliserExchange:
     def forward(self, x):
         self.calls.append("fwd")
         world = self._world()
-        if world == 1:
+        if world == 1 and not (force_collectives() and dist.is_initialized()):
             x[1] = 1.0
             return
         rank = dist.get_rank(self.group)
@@ -80,7 +93,7 @@ class StabiliserExchange:
 
     def backward(self, x):
         self.calls.append("bwd")
-        if self._world() > 1:
+        if self._world() > 1 or (force_collectives() and dist.is_initialized()):
             s = x[2:3].clone()
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
             x[2:3] = s
@@ -141,6 +154,10 @@ class GradBucket:
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    def _single(self):
+        """A world of one without the force_collectives() test hook: nothing to exchange."""
+        return self.world_size() == 1 and not (force_collectives() and dist.is_initialized())
+
     # ---- the collective -------------------------------------------------------------------------------------------------
     def _all_reduce(self, flat):
         """SUM over the ranks, in place (the one exchange of the data path; tests override it to run without a process group)."""
@@ -176,7 +193,7 @@ class GradBucket:
     def arm(self):
         """Call before backward() of a step whose gradients sync() will reduce: the early bucket goes out from inside the backward."""
         self.issue_log = []
-        if not self.early or self.world_size() == 1:
+        if not self.early or self._single():
             return
         if self._hooks is None:
             self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.early]
@@ -227,7 +244,7 @@ class GradBucket:
                     for h in self._hooks:
                         h.remove()
                     self._hooks = None
-        if world == 1 or not live:
+        if self._single() or not live:
             return 1.0
         scale = 1.0 / world
         early, self._early_state = self._early_state, None
