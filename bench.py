@@ -47,6 +47,11 @@ METRIC = {   # BASELINE.json's headline metric string is c3's; every other workl
     "c5": "meta-tasks/sec (fwd+bwd), ANPMR ShapeNet3D 15+15-shot, 8 tasks per GPU",
     "distractor": "meta-tasks/sec (fwd+bwd), ANP Distractor 15+15-shot, 20 tasks per GPU",
 }
+# hipGraph capture mode: "global" (torch's default) makes ANY thread's event query / allocation during a capture an error - and
+# with a process group alive ProcessGroupNCCL's watchdog thread polls its work events all the time (seen on the GPU box: the
+# bench aborting inside the capture, rc -6, once in two runs at a forced world of one).  "thread_local" confines the check to the
+# capturing thread, which is the one that matters here.
+CAPTURE_MODE = "thread_local"
 NC, NQ = 15, 15
 T_LOCAL = 16                    # vanilla workloads; WORKLOADS[...]["T"] is authoritative
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = fp32 vector rate
@@ -216,7 +221,7 @@ def _time_graph(fn, iters):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
+    with torch.cuda.graph(graph, stream=side, capture_error_mode=CAPTURE_MODE):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
         fn()
     for _ in range(5):
         graph.replay()
@@ -237,7 +242,7 @@ def _capture(fn):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
+    with torch.cuda.graph(graph, stream=side, capture_error_mode=CAPTURE_MODE):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
         fn()
     return graph
 
@@ -431,7 +436,7 @@ def measure_train_loop(w, device, loss_fn, iters):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):
+    with torch.cuda.graph(graph, stream=side, capture_error_mode=CAPTURE_MODE):
         static_loss = it()
     ing.stage(*hb)
     n_rep = 4 * iters
@@ -642,6 +647,7 @@ def main():
     bucket = mdist.GradBucket(model.parameters(), side_stream=True,
                               early=model.early_grad_parameters() if hasattr(model, "early_grad_parameters") else None)
     beta = w.get("beta", 0.0)
+    seed = torch.ones((), device=device)     # d loss / d loss: torch.ones_like(loss) allocated once instead of per step
 
     def fwd_bwd(arm=False, batch=None):
         bx, by, tx, ty = batch if batch is not None else (cx, cy, qx, qy)
@@ -652,7 +658,7 @@ def main():
             loss = loss + beta * kl          # identical on every rank (same weights, kl does not depend on the batch): averaged, never summed
         if arm:
             bucket.arm()                     # eager steps only: the early bucket's all-reduce is issued from inside backward()
-        loss.backward()
+        loss.backward(gradient=seed)         # the constant 1.0 autograd would otherwise make with a fill kernel every step
         return loss.detach()
 
     # Bayes-by-backprop eps: the reference draws them on the torch CPU generator inside the forward (bbb/BBBConv.py:88).  Every rank
@@ -698,7 +704,7 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             model.zero_grad(set_to_none=True)
-            with (eps.active() if eps is not None else contextlib_null()), torch.cuda.graph(graph, stream=side):   # the warm-up's stream: the parameters' grad-accumulation nodes live there
+            with (eps.active() if eps is not None else contextlib_null()), torch.cuda.graph(graph, stream=side, capture_error_mode=CAPTURE_MODE):   # the warm-up's stream: the parameters' grad-accumulation nodes live there
                 static_loss = body()
 
             def run():

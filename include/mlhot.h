@@ -116,6 +116,42 @@ int mlhot_linear_bwd(const float* x, int ldx, const float* w, const float* y, in
                      int M, int K, int N, int act, float* dx, int lddx, int accumulate, float* dw, float* db,
                      void* scratch, size_t scratch_bytes, void* stream);
 
+/* ---- M1 / D2 as chains: up to 4 Linear(+ReLU / tanh) layers on few rows (M <= 512) in ONE launch --------------------------
+ * The ResNet-family models' task-side MLPs (networks/ANP.py:44-52 task_encoder + mu, models.py:139-145,182-184 fc_mu behind
+ * torch.cat([x, sample_features]); ANPMRShapeNet3D.py:135-139,204-216).  Layer k computes
+ *     y_k = act_k([side_k | y_{k-1}] w_k^T + b_k)   (side_first = 1)    or    act_k([y_{k-1} | side_k] w_k^T + b_k)   (side_first = 0)
+ * with y_{-1} = x0 and side_k an optional second input tensor of side_w columns (the reference's torch.cat, folded: the labels
+ * behind the context features, the decoder's image features in front of the sampled latent).  K = the layer's total input width
+ * (side_w + the previous layer's N; 4 <= K <= 512, K % 4 == 0, side_w % 4 == 0), N <= 256 (inner layers N % 4 == 0); every y_k is
+ * written to the caller's buffer (ldy >= N): the backward reads them.  All operand rows 16-byte aligned.                       */
+#define MLHOT_CHAIN_MAX_LAYERS 4
+typedef struct {
+  const float* w; const float* b;      /* [N][K], [N] or NULL */
+  int K, N, act;
+  const float* side; int side_w, side_ld, side_first;   /* side_w = 0: no side input */
+  float* y; int ldy;                   /* [M][ldy]: this layer's output */
+} mlhot_chain_layer;
+typedef struct {
+  float* dw; float* db;                /* [N][K], [N] or NULL: written */
+  float* g; int ldg;                   /* workspace [M][ldg], ldg >= N, ldg % 4 == 0: dy_k * act'(y_k) */
+  float* dside; int dside_ld, dside_accumulate;         /* gradient of the side columns, or NULL */
+} mlhot_chain_grads;
+int mlhot_mlp_chain_fwd(const float* x0, int ldx0, int M, const mlhot_chain_layer* layers, int n_layers, void* stream);
+/* dy[M][lddy]: gradient of the last layer's output; dx0 (NULL: not wanted) (+)= the gradient of x0's columns.  Two launches:
+ * the data-gradient walk (also fills every g) and ONE weight + bias gradient launch for all layers.                             */
+int mlhot_mlp_chain_bwd(const float* x0, int ldx0, int M, const mlhot_chain_layer* layers, const mlhot_chain_grads* grads,
+                        int n_layers, const float* dy, int lddy, float* dx0, int lddx0, int dx0_accumulate, void* stream);
+
+/* Up to 8 INDEPENDENT few-row Linear layers in one launch (the K / V / Q head stacks of the attention, ANP.py:80-93: one
+ * Linear(256 -> 8 x 256) each over the stacked head weights): forward y = act(x w^T + b); backward dx (+)= (dy act'(y)) w,
+ * dw = (dy act'(y))^T x, db.  M <= 512, K % 4 == 0, rows 16-byte aligned; the backward needs N % 4 == 0 and all of dy, dx, dw.  */
+typedef struct {
+  const float* x; int ldx; const float* w; const float* b; float* y; int ldy; int M, K, N, act;
+  const float* dy; int lddy; float* dx; int lddx, dx_accumulate; float* dw; float* db;      /* backward only */
+} mlhot_linear_job;
+int mlhot_linear_multi_fwd(const mlhot_linear_job* jobs, int n_jobs, void* stream);
+int mlhot_linear_multi_bwd(const mlhot_linear_job* jobs, int n_jobs, void* stream);
+
 /* ---- G1: per-task aggregation over the shot axis ------------------------------------------
  * mean / max / Bayesian ("baco") over dim 1 of rs[T,Nc,R]   (CNPShapeNet1D.py:78-126,
  * CondNeuralProcess.py:59-108).  baco: `rs` holds mu, `lv` the pre-softplus variance logits;
@@ -309,7 +345,7 @@ typedef struct mlhot_np_grads {
   float *wo_w, *wo_b;
 } mlhot_np_grads;
 
-size_t mlhot_np_struct_bytes(int which); /* 0 dims, 1 params, 2 grads: binding self-check */
+size_t mlhot_np_struct_bytes(int which); /* 0 dims, 1 params, 2 grads, 3 chain_layer, 4 chain_grads, 5 linear_job: binding self-check */
 size_t mlhot_np_saved_bytes(const mlhot_np_dims* d);
 size_t mlhot_np_scratch_bytes(const mlhot_np_dims* d);
 /* Recommended gradient layout: ONE flat fp32 buffer (what torch.optim / an all-reduce bucket want anyway,

@@ -1883,7 +1883,11 @@ def test_rccl_world_of_one_bench(gpulib, workload, extra):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--workload", workload,
            "--no-cpu-baseline", "--no-extras", "--prof-steps", "1"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
+    if r.returncode != 0:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", f"rccl_bench_{workload}{'_strict' if extra else ''}.stderr"), "w") as f:
+            f.write(r.stderr)
+    assert r.returncode == 0, r.stderr[:3000] + "\n...\n" + r.stderr[-1500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])

@@ -43,11 +43,10 @@ __device__ __forceinline__ bool fold4(f32x4_t (&acc)[2], float* red, int tid) {
 }
 
 // y[M][N] = act(x[M][K] w[N][K]^T + b): grid (ceil(M / 32), ceil(N / 16)), 256 threads
-__global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw, const float* __restrict__ b,
-                                                  float* __restrict__ y, int ldy, int M, int K, int N, int act) {
-  __shared__ float red[4 * 2 * 64 * 4];
+__device__ __forceinline__ void fwd_body(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw, const float* __restrict__ b,
+                                         float* __restrict__ y, int ldy, int M, int K, int N, int act, float* red, int bx, int by) {
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 16;
+  const int m0 = bx * 32, n0 = by * 16;
   const int ra = m0 + lr, rb = m0 + 16 + lr, rn = n0 + lr;
   const float* xa = x + (size_t)(ra < M ? ra : 0) * ldx + 4 * lq;
   const float* xb = x + (size_t)(rb < M ? rb : 0) * ldx + 4 * lq;
@@ -79,6 +78,11 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ x, i
     const int m = m0 + 16 * t + 4 * lq + r;
     if (m < M) y[(size_t)m * ldy + n] = act_apply(act, acc[0][r] + bn);
   }
+}
+__global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw, const float* __restrict__ b,
+                                                  float* __restrict__ y, int ldy, int M, int K, int N, int act) {
+  __shared__ float red[4 * 2 * 64 * 4];
+  fwd_body(x, ldx, w, ldw, b, y, ldy, M, K, N, act, red, blockIdx.x, blockIdx.y);
 }
 
 // dx[M][Kin] (+)= (dy * act'(y))[M][N] w[N][Kin]: out^T tile C[kin][m]; grid (ceil(M / 32), ceil(Kin / 16))

@@ -17,6 +17,7 @@
 #include "bbb_multi.h"
 #include "mt_normal.h"
 #include "nt_xent.h"
+#include "mlp_chain.h"
 #include "resnet_trunk.h"
 #include "../../include/mlhot.h"
 
@@ -35,7 +36,7 @@ int g_favor2 = 1;
 
 #ifndef MLHOT_HOSTSIM
 // ---- side lanes (common.h) ---------------------------------------------------------------------------
-int g_side_fold = 1;
+int g_side_fold = 0;   // measured on c3: the folds beside the persistent one-workgroup-per-CU kernels cost +65 us per step (a fold workgroup and a conv workgroup do not fit one CU together, so the conv kernel waits for the fold), DESIGN.md section 4 round 4
 static std::mutex g_lane_mu;
 static SideLane g_lanes[8];
 static int g_nlanes = 0;
@@ -89,7 +90,7 @@ int mlhot_set_option(const char* name, int value) {
   if (!strcmp(name, "dbg")) { g_opt.dbg = value; return MLHOT_OK; }   // timing experiments only (results become wrong)
   if (!strcmp(name, "favor2")) { g_favor2 = value; return MLHOT_OK; }
 #ifndef MLHOT_HOSTSIM
-  if (!strcmp(name, "side_fold")) { g_side_fold = value; return MLHOT_OK; }   // 1 (default): slab folds of the encoder backward on the library's helper stream (common.h SideLane)
+  if (!strcmp(name, "side_fold")) { g_side_fold = value; return MLHOT_OK; }   // 1 (default 0): slab folds of the encoder backward on the library's helper stream (common.h SideLane)
 #endif  // FAVOR+: the two-launch kernels (csrc/favor2.h, default) or favor.h's chain
   set_error("mlhot_set_option: unknown option %s", name);
   return MLHOT_ERR_ARG;
@@ -174,6 +175,38 @@ int mlhot_linear_bwd(const float* x, int ldx, const float* w, const float* y, in
   if (dw) MLHOT_TRY(lin_wgrad(dy, lddy, y, ldy, act, x, ldx, gb1(dw, db, N), M, K, N, s, "linear_bwd.w"));
   if (dx) MLHOT_TRY(lin_dgrad(dy, lddy, y, ldy, act, wb1(w, nullptr, N), dx, lddx, accumulate, M, K, N, s, "linear_bwd.x"));
   return MLHOT_OK;
+}
+
+// ---- chains of few-row linears, independent few-row linears in one launch (csrc/mlp_chain.h) ---------------------
+int mlhot_mlp_chain_fwd(const float* x0, int ldx0, int M, const mlhot_chain_layer* layers, int n_layers, void* stream) {
+#ifndef MLHOT_HOSTSIM
+  return mc::chain_forward(x0, ldx0, M, layers, n_layers, (hipStream_t)stream);
+#else
+  (void)x0; (void)ldx0; (void)M; (void)layers; (void)n_layers; (void)stream; set_error("mlp_chain: GPU build only"); return MLHOT_ERR_ARG;
+#endif
+}
+int mlhot_mlp_chain_bwd(const float* x0, int ldx0, int M, const mlhot_chain_layer* layers, const mlhot_chain_grads* grads, int n_layers,
+                        const float* dy, int lddy, float* dx0, int lddx0, int dx0_accumulate, void* stream) {
+#ifndef MLHOT_HOSTSIM
+  return mc::chain_backward(x0, ldx0, M, layers, grads, n_layers, dy, lddy, dx0, lddx0, dx0_accumulate, (hipStream_t)stream);
+#else
+  (void)x0; (void)ldx0; (void)M; (void)layers; (void)grads; (void)n_layers; (void)dy; (void)lddy; (void)dx0; (void)lddx0; (void)dx0_accumulate; (void)stream;
+  set_error("mlp_chain: GPU build only"); return MLHOT_ERR_ARG;
+#endif
+}
+int mlhot_linear_multi_fwd(const mlhot_linear_job* jobs, int n_jobs, void* stream) {
+#ifndef MLHOT_HOSTSIM
+  return mc::multi_forward(jobs, n_jobs, (hipStream_t)stream);
+#else
+  (void)jobs; (void)n_jobs; (void)stream; set_error("linear_multi: GPU build only"); return MLHOT_ERR_ARG;
+#endif
+}
+int mlhot_linear_multi_bwd(const mlhot_linear_job* jobs, int n_jobs, void* stream) {
+#ifndef MLHOT_HOSTSIM
+  return mc::multi_backward(jobs, n_jobs, (hipStream_t)stream);
+#else
+  (void)jobs; (void)n_jobs; (void)stream; set_error("linear_multi: GPU build only"); return MLHOT_ERR_ARG;
+#endif
 }
 
 // ---- aggregators ------------------------------------------------------------------------------
@@ -454,7 +487,8 @@ int mlhot_spatial_mean_bwd(const float* dy, float* dx, int planes, int HW, void*
 
 // ---- whole model ------------------------------------------------------------------------------
 size_t mlhot_np_struct_bytes(int which) {
-  return which == 0 ? sizeof(mlhot_np_dims) : which == 1 ? sizeof(mlhot_np_params) : sizeof(mlhot_np_grads);
+  return which == 0 ? sizeof(mlhot_np_dims) : which == 1 ? sizeof(mlhot_np_params) : which == 2 ? sizeof(mlhot_np_grads)
+       : which == 3 ? sizeof(mlhot_chain_layer) : which == 4 ? sizeof(mlhot_chain_grads) : sizeof(mlhot_linear_job);
 }
 size_t mlhot_np_saved_bytes(const mlhot_np_dims* d) { return d ? np_saved_carve(*d, nullptr, 0).bytes : 0; }
 size_t mlhot_np_scratch_bytes(const mlhot_np_dims* d) { return d ? np_scratch_carve(*d, nullptr, 0).bytes : 0; }

@@ -31,6 +31,10 @@ from mlhot.dist import GradBucket, rank as dist_rank
 from trainer.base_trainer import BaseTrainer
 
 
+# torch's default capture mode ("global") turns any OTHER thread's event query into a capture error; ProcessGroupNCCL's watchdog
+# thread polls its work events continuously, so with a process group alive a capture would abort at random (seen with bench.py).
+CAPTURE_MODE = "thread_local"
+
 class ModelTrainer(BaseTrainer):
     def __init__(self, model, loss, optimizer, config, data):
         super().__init__(model=model, loss=loss, optimizer=optimizer, config=config)
@@ -105,6 +109,13 @@ class ModelTrainer(BaseTrainer):
             self._staged = stage("train")
         return batch
 
+    def _seed(self, loss):
+        """d loss / d loss = 1, allocated once: autograd's implicit seed is a fill kernel per iteration."""
+        s = getattr(self, "_one", None)
+        if s is None or s.device != loss.device or s.dtype != loss.dtype:
+            s = self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        return s
+
     # ---- graph-replayed training iterations -------------------------------------------------------------------
     def _step_body(self, ctx_x, qry_x, ctx_y, qry_y, with_optimizer):
         self.optimizer.zero_grad()
@@ -116,7 +127,7 @@ class ModelTrainer(BaseTrainer):
         losses = self.loss.calc_loss(pr_mu, pr_var, qry_y) + kl * self.config.beta
         if contra_loss is not None:
             losses = losses + contra_loss * self.config.contrastive_rate
-        losses.backward()
+        losses.backward(gradient=self._seed(losses))
         if with_optimizer:
             self.optimizer.step()
         return losses.detach()
@@ -149,7 +160,7 @@ class ModelTrainer(BaseTrainer):
             if entry == "warm":                                      # second time: capture (nothing executes), then replay below
                 graph = torch.cuda.CUDAGraph()
                 self._side.wait_stream(cur)
-                with torch.cuda.graph(graph, stream=self._side):
+                with torch.cuda.graph(graph, stream=self._side, capture_error_mode=CAPTURE_MODE):
                     static_loss = self._step_body(*static, with_optimizer=single)
                 # the gradient tensors THIS graph writes (its private pool): a replay does not rebind p.grad, and another
                 # shape's graph or eager warm-up may have re-pointed it since
@@ -202,7 +213,7 @@ class ModelTrainer(BaseTrainer):
         if contrastive:
             losses = losses + contra_loss * self.config.contrastive_rate
         self.bucket.arm()                                         # world > 1: the early bucket's all-reduce goes out from inside backward()
-        losses.backward()
+        losses.backward(gradient=self._seed(losses))
         self._sync_and_step()
         value = losses.item()                                     # the iteration's only host sync
         if self.writer is not None and self.rank0:
