@@ -48,6 +48,103 @@ def test_linear_asymmetric_identity(gpulib):
     assert torch.equal(y.cpu(), w.t())
 
 
+def _chain_reference(x0, layers):
+    """torch autograd restatement of a chain: layers = [(w, b, act, side | None, side_first)]."""
+    h = x0
+    for w, b, act, side, side_first in layers:
+        if side is not None:
+            h = torch.cat([side, h] if side_first else [h, side], dim=-1)
+        h = F.linear(h, w, b)
+        h = torch.relu(h) if act == "relu" else torch.tanh(h) if act == "tanh" else h
+    return h
+
+
+@pytest.mark.parametrize("M", [120, 7, 240, 16])
+@pytest.mark.parametrize("case", ["task_encoder", "decoder_head", "one_layer", "tanh_no_bias"])
+def test_mlp_chain_fwd_bwd_vs_autograd(gpulib, M, case):
+    """csrc/mlp_chain.h: chains of few-row Linear layers in one launch (two for the backward) against torch autograd of the same
+    layers with the reference's torch.cat in front (ANP.py:113 cat([x_ctx, labels]) -> task_encoder; ANP.py:128 mu, models.py:182-184
+    cat([x, sample_features]) -> fc_mu): outputs, the input's, the sides' and every weight / bias gradient at 1e-4."""
+    from mlhot.ops import mlp_chain
+    g = torch.Generator().manual_seed(M + len(case))
+
+    def lin(n, k, bias=True):
+        return torch.randn(n, k, generator=g) * k ** -0.5, (torch.randn(n, generator=g) * 0.1 if bias else None)
+    if case == "task_encoder":
+        x0, side = torch.randn(M, 256, generator=g), torch.randn(M, 4, generator=g)
+        spec = [(*lin(256, 260), "relu", side, False), (*lin(256, 256), "relu", None, False), (*lin(256, 256), "relu", None, False)]
+    elif case == "decoder_head":
+        x0, side = torch.randn(M, 256, generator=g), torch.randn(M, 256, generator=g)
+        spec = [(*lin(256, 256), "none", None, False), (*lin(256, 512), "relu", side, True), (*lin(256, 256), "relu", None, False),
+                (*lin(4, 256), "none", None, False)]
+    elif case == "one_layer":
+        x0, side = torch.randn(M, 272, generator=g), None
+        spec = [(*lin(100, 272), "relu", None, False)]
+    else:
+        x0, side = torch.randn(M, 64, generator=g), torch.randn(M, 16, generator=g)
+        spec = [(*lin(128, 80, bias=False), "tanh", side, True), (*lin(2, 128), "tanh", None, False)]
+    leaves = []
+
+    def leaf(t, dev):
+        if t is None:
+            return None
+        t = t.clone().to(dev).requires_grad_()
+        leaves.append(t)
+        return t
+    res = {}
+    for dev in ("cpu", DEV):
+        del leaves[:]
+        x = leaf(x0, dev)
+        sd = leaf(side, dev)
+        layers = [(leaf(w, dev), leaf(b, dev), act, sd if sdx is not None else None, sf) for w, b, act, sdx, sf in spec]
+        y = _chain_reference(x, layers) if dev == "cpu" else mlp_chain(x, layers)
+        assert y is not None
+        wout = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+        (y * wout).sum().backward()
+        res[dev] = (y.detach().cpu(), [t.grad.detach().cpu() for t in leaves])
+    assert U.rel_err(res[DEV][0], res["cpu"][0]) <= U.RTOL
+    for i, (a, b) in enumerate(zip(res[DEV][1], res["cpu"][1])):
+        assert a.shape == b.shape and U.rel_err(a, b) <= U.RTOL, (case, M, i)
+
+
+def test_mlp_chain_refuses_shapes_outside_its_limits(gpulib):
+    from mlhot.ops import mlp_chain
+    x = torch.randn(600, 256, device=DEV)
+    w, b = torch.randn(256, 256, device=DEV), torch.randn(256, device=DEV)
+    assert mlp_chain(x, [(w, b, "relu", None, False)]) is None                      # > 512 rows: the caller runs the layers one by one
+    assert mlp_chain(x[:8], [(torch.randn(300, 256, device=DEV), None, "relu", None, False)]) is None    # > 256 outputs
+    assert mlp_chain(x[:8], [(w, b, "relu", None, False)] * 5) is None              # > 4 layers
+
+
+@pytest.mark.parametrize("rows", [(120, 120, 120), (56, 184, 56), (1, 30, 1)])
+def test_head_stacks_in_one_launch_vs_autograd(gpulib, rows):
+    """mlhot_linear_multi_fwd / _bwd: the query / key / value head stacks (8 x Linear(256, 256) each, ANP.py:80-93) as three
+    Linear(256 -> 2048) jobs of ONE launch per direction, against torch autograd of the 24 separate layers."""
+    from mlhot.ops import HeadStacksFunction
+    g = torch.Generator().manual_seed(sum(rows))
+    H, h = 8, 256
+    xs = [torch.randn(1, m, h, generator=g) for m in rows]
+    ws = [torch.randn(H * h, h, generator=g) * h ** -0.5 for _ in rows]
+    bs = [torch.randn(H * h, generator=g) * 0.1 for _ in rows]
+    douts = [torch.randn(1, m, H, h, generator=g) for m in rows]
+    # reference: per-head layers, stacked on a head axis
+    xr, wr, br = [[t.clone().requires_grad_() for t in ts] for ts in (xs, ws, bs)]
+    for x, w, b, do in zip(xr, wr, br, douts):
+        (F.linear(x, w, b).view(1, -1, H, h) * do).sum().backward()
+    xd = [t.clone().to(DEV).requires_grad_() for t in xs]
+    wd, bd = [t.to(DEV) for t in ws], [t.to(DEV) for t in bs]
+    heads = [[wd[i].view(H, h, h)[k].clone().requires_grad_() for k in range(H)] + [bd[i].view(H, h)[k].clone().requires_grad_() for k in range(H)]
+             for i in range(3)]
+    args = [t for i in range(3) for t in (xd[i], wd[i], bd[i])]
+    outs = HeadStacksFunction.apply(H, 3, *args, *[p for hp in heads for p in hp])
+    sum((o * do.to(DEV)).sum() for o, do in zip(outs, douts)).backward()
+    for i in range(3):
+        assert U.rel_err(outs[i], F.linear(xs[i], ws[i], bs[i]).view(1, -1, H, h)) <= U.RTOL
+        assert U.rel_err(xd[i].grad, xr[i].grad) <= U.RTOL
+        assert U.rel_err(torch.cat([p.grad for p in heads[i][:H]]), wr[i].grad) <= U.RTOL
+        assert U.rel_err(torch.cat([p.grad for p in heads[i][H:]]), br[i].grad) <= U.RTOL
+
+
 @pytest.mark.parametrize("mode", ["mean", "max", "baco"])
 @pytest.mark.parametrize("T,Nc,R", [(3, 7, 100), (16, 15, 64), (1, 1, 256), (2, 25, 100)])
 def test_agg_fwd_bwd(gpulib, mode, T, Nc, R):
@@ -534,17 +631,18 @@ def _sharpen_resnet_attention(model, forward):
     so that the rows have zero mean and 0.25 spread per component: dd has unit spread, diag ~ 0.5 (the regime favor_c5.npz pins
     for the kernels in isolation).  Returns the measured spread of q / k before the change."""
     seen = {}
-    heads0 = model._heads
+    mha0 = model._multihead_attention
 
-    def rec(x, mods):
-        seen[id(mods)] = x.detach().reshape(-1, x.shape[-1]).clone()
-        return heads0(x, mods)
-    model._heads = rec
+    def rec(k, v, q):
+        for x, mods in ((q, model._W_q), (k, model._W_k), (v, model._W_v)):
+            seen[id(mods)] = x.detach().reshape(-1, x.shape[-1]).clone()
+        return mha0(k, v, q)
+    model._multihead_attention = rec
     try:
         with torch.no_grad():
             forward()
     finally:
-        del model._heads
+        del model._multihead_attention
     before = {}
     with torch.no_grad():
         for name, mods in (("q", model._W_q), ("k", model._W_k)):

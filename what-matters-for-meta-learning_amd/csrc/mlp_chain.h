@@ -16,8 +16,15 @@
 //   * multi_wgrad_kernel / multi_fwd_kernel / multi_bwd_kernel: job tables over linear_skinny.h's bodies - the weight + bias
 //     gradients of all layers of a chain in one launch; the K / V / Q head stacks' forwards in one launch, their six gradient
 //     bodies in one launch.
-// A 16-row tile on one CU is bound by the fp32 matrix pipe of that CU: 1024 MFMAs per 256 x 256 layer = 3.4 us; a chain of
-// four layers is ~12 us against ~34 us as four launches.  v_mfma_f32_16x16x4_f32: A lane l = A[l&15][l>>4], B lane l =
+// MEASURED (MI355X, c5: 120 rows, round 4): the chain kernels are NOT faster than one launch per layer at 256-wide layers - 48 us
+// for the four-layer decoder head and 48 us for its data-gradient walk, against 4 x 7.7 us as four launches.  A workgroup that owns
+// 16 rows pulls every layer's whole weight matrix (256-512 KB) through ONE CU (~70 GB/s: 3.7-7.5 us per layer) and issues all of
+// the layer's 1024-2048 MFMAs on that CU's matrix pipe (3.4-6.8 us), one after the other; splitting the columns over several CUs
+// instead needs a cross-CU exchange of the activations per layer (release + flag + acquire: 4-5 us, MI355X_MICROARCH.md price
+// list "handoff-flag" / "splitk-seam") - the price of the launch boundary it would remove.  The models therefore keep one launch
+// per layer (MLHOT_MLP_CHAIN=1 switches the chains on for A/B runs); what stays in the default path is the job-table launches
+// (the three head stacks per direction).  The chains pay where the weights are small against the rows (not these models).
+// v_mfma_f32_16x16x4_f32: A lane l = A[l&15][l>>4], B lane l =
 // B[l>>4][l&15], C/D lane l reg r = C[4*(l>>4)+r][l&15].
 #pragma once
 #include "common.h"
@@ -50,13 +57,21 @@ struct Args {
 
 // rows m0 .. m0+15 of an [M][w] global tensor -> LDS columns [off, off + w) of a [16][LDX] buffer (zeros past M); w % 4 == 0
 __device__ __forceinline__ void stage_cols(float* buf, int off, const float* __restrict__ src, int ld, int w, int m0, int M, int tid) {
-  const int w4 = w >> 2;
-  for (int e = tid; e < 16 * w4; e += NT) {
-    const int r = e / w4, c = 4 * (e - r * w4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m0 + r < M) v = *reinterpret_cast<const float4*>(src + (size_t)(m0 + r) * ld + c);
-    float* d = buf + r * LDX + off + c;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;        // off may be 4-aligned only in words of a padded row: plain stores
+  const int w4 = w >> 2;                      // <= 128: at most 4 float4 per thread, all requested before the first LDS store
+  float4 v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + NT * j, r = e / w4, c = 4 * (e - r * w4);
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < 16 * w4 && m0 + r < M) v[j] = *reinterpret_cast<const float4*>(src + (size_t)(m0 + r) * ld + c);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + NT * j, r = e / w4, c = 4 * (e - r * w4);
+    if (e < 16 * w4) {
+      float* d = buf + r * LDX + off + c;
+      d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+    }
   }
 }
 
@@ -82,27 +97,35 @@ __global__ __launch_bounds__(NT) void chain_fwd_kernel(const Args a) {
     const bool has0 = t0 < ntile, has1 = t1 < ntile;
     if (has0) {
       const int n0r = 16 * t0 + lr, n1r = 16 * t1 + lr;
-      const float* w0 = l.w + (size_t)(n0r < N ? n0r : 0) * K + 4 * lq;
-      const float* w1 = l.w + (size_t)((has1 && n1r < N) ? n1r : 0) * K + 4 * lq;
+      // no per-lane load masks: rows past N and k past K are clamped to valid addresses - their products are discarded by the
+      // epilogue (n >= N) or multiplied by the zeroed A operand (k >= K)
+      const float* w0 = l.w + (size_t)(n0r < N ? n0r : N - 1) * K;
+      const float* w1 = l.w + (size_t)((has1 && n1r < N) ? n1r : N - 1) * K;
       const float* ap = in + lr * LDX + 4 * lq;
       f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      for (int kb = 0; kb < K; kb += 64) {                 // four 16-deep chunks per trip: 8 weight float4 in flight
-        float4 b0[4], b1[4];
-        f32x4_t av[4];
+      // a pass = 256 k: ALL its 32 weight float4 (128 VGPRs) are requested before the first MFMA - one L2 round trip per pass
+      // (as 64-k trips every trip waited out its own: 45 us for a four-layer chain)
+      for (int kb = 0; kb < K; kb += 256) {
+        float4 b0[16], b1[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 16; ++u) {
           const int k0 = kb + 16 * u;
-          const bool kin = k0 + 4 * lq < K;
-          b0[u] = sk::ld4(w0 + k0, kin && n0r < N);
-          b1[u] = sk::ld4(w1 + k0, kin && has1 && n1r < N);
-          av[u] = kin ? *reinterpret_cast<const f32x4_t*>(ap + k0) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+          if (k0 < K) {                                     // wave-uniform
+            const int kk = k0 + 4 * lq < K ? k0 + 4 * lq : K - 4;
+            b0[u] = *reinterpret_cast<const float4*>(w0 + kk);
+            b1[u] = *reinterpret_cast<const float4*>(w1 + kk);
+          }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          acc0 = mfma4(av[u][0], b0[u].x, acc0); acc1 = mfma4(av[u][0], b1[u].x, acc1);
-          acc0 = mfma4(av[u][1], b0[u].y, acc0); acc1 = mfma4(av[u][1], b1[u].y, acc1);
-          acc0 = mfma4(av[u][2], b0[u].z, acc0); acc1 = mfma4(av[u][2], b1[u].z, acc1);
-          acc0 = mfma4(av[u][3], b0[u].w, acc0); acc1 = mfma4(av[u][3], b1[u].w, acc1);
+        for (int u = 0; u < 16; ++u) {
+          const int k0 = kb + 16 * u;
+          if (k0 < K) {                                     // wave-uniform
+            const f32x4_t av = (k0 + 4 * lq < K) ? *reinterpret_cast<const f32x4_t*>(ap + k0) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            acc0 = mfma4(av[0], b0[u].x, acc0); acc1 = mfma4(av[0], b1[u].x, acc1);
+            acc0 = mfma4(av[1], b0[u].y, acc0); acc1 = mfma4(av[1], b1[u].y, acc1);
+            acc0 = mfma4(av[2], b0[u].z, acc0); acc1 = mfma4(av[2], b1[u].z, acc1);
+            acc0 = mfma4(av[3], b0[u].w, acc0); acc1 = mfma4(av[3], b1[u].w, acc1);
+          }
         }
       }
       const int poff = last ? 0 : a.L[k + 1].off_prev();
@@ -136,60 +159,94 @@ __global__ __launch_bounds__(NT) void chain_dgrad_kernel(const Args a) {
     const int K = l.K, N = l.N;
     // G_k = dY_k . act'(y_k): rows of this tile, all N columns; to LDS (zero past N up to a multiple of 16) and to global
     const int N16 = (N + 15) & ~15;
-    for (int e = tid; e < 16 * N16; e += NT) {
-      const int r = e / N16, c = e - r * N16;
-      float g = 0.f;
-      if (c < N && m0 + r < M) {
-        const float dyv = (k == a.n - 1) ? a.dy[(size_t)(m0 + r) * a.lddy + c] : dbuf[r * LDX + c];
-        g = l.act == ACT_NONE ? dyv : dyv * sk::dact(l.act, l.yin[(size_t)(m0 + r) * l.ldy + c]);
-        l.g[(size_t)(m0 + r) * l.ldg + c] = g;
+    {
+      float dyv[8], yv[8];                    // <= 8 elements per thread; every global load requested before the first store
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = tid + NT * j, r = e / N16, c = e - r * N16;
+        const bool ok = e < 16 * N16 && c < N && m0 + r < M;
+        dyv[j] = 0.f; yv[j] = 0.f;
+        if (ok) {
+          dyv[j] = (k == a.n - 1) ? a.dy[(size_t)(m0 + r) * a.lddy + c] : dbuf[r * LDX + c];
+          if (l.act != ACT_NONE) yv[j] = l.yin[(size_t)(m0 + r) * l.ldy + c];
+        }
       }
-      gbuf[r * LDG + c] = g;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = tid + NT * j, r = e / N16, c = e - r * N16;
+        if (e < 16 * N16) {
+          const bool ok = c < N && m0 + r < M;
+          const float g = !ok ? 0.f : (l.act == ACT_NONE ? dyv[j] : dyv[j] * sk::dact(l.act, yv[j]));
+          if (ok) l.g[(size_t)(m0 + r) * l.ldg + c] = g;
+          gbuf[r * LDG + c] = g;
+        }
+      }
     }
     __syncthreads();
     const bool want_prev = k > 0 || a.dx0 != nullptr, want_side = l.side_w > 0 && l.dside != nullptr;
     if (!want_prev && !want_side) break;
     // dX[16][K] = G[16][N] W[N][K]: column tiles of K over the waves; B[kk = n][col] = W[n][col] (dword loads, contiguous over lr)
     const int ktile = (K + 15) >> 4;
-    for (int ct = wv; ct < ktile; ct += 8) {
-      const int col = 16 * ct + lr;
-      const bool cin = col < K;
-      const float* wp = l.w + (cin ? col : 0);
-      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-      for (int nb = 0; nb < N16; nb += 32) {               // two 16-deep chunks per trip
-        float wq[2][4];
-        f32x4_t gv[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int n = nb + 16 * u + 4 * lq;
-          const bool nin = n < N16;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) wq[u][i] = (cin && n + i < N) ? wp[(size_t)(n + i) * K] : 0.f;
-          gv[u] = nin ? *reinterpret_cast<const f32x4_t*>(gbuf + lr * LDG + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int op = l.off_prev(), os = l.off_side(), pw = l.prev_w();
+    // dX element (row, col): previous-layer columns -> dbuf (or dx0 for layer 0), side columns -> the side's gradient
+    auto route = [&](int row, int col, float v) {
+      if (col >= op && col < op + pw) {
+        if (k > 0) dbuf[row * LDX + col - op] = v;
+        else if (a.dx0 != nullptr && m0 + row < M) {
+          float* d = a.dx0 + (size_t)(m0 + row) * a.lddx0 + col - op;
+          *d = a.dx0_acc ? *d + v : v;
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          acc = mfma4(gv[u][0], wq[u][0], acc); acc = mfma4(gv[u][1], wq[u][1], acc);
-          acc = mfma4(gv[u][2], wq[u][2], acc); acc = mfma4(gv[u][3], wq[u][3], acc);
-        }
+      } else if (want_side && m0 + row < M) {
+        float* d = l.dside + (size_t)(m0 + row) * l.dside_ld + col - os;
+        *d = l.dside_acc ? *d + v : v;
       }
-      if (cin) {
-        // C[row 4 lq + r][col lr]: previous-layer columns -> dbuf (or dx0 for layer 0), side columns -> the side's gradient
-        const int op = l.off_prev(), os = l.off_side();
-        const bool is_prev = col >= op && col < op + l.prev_w();
+    };
+    if (N & 15) {
+      // a narrow layer (the model's output: 1 .. 4 columns, or any N that is not a multiple of 16): N multiply-adds per element
+      for (int e = tid; e < 16 * K; e += NT) {
+        const int row = e / K, col = e - row * K;
+        float sacc = 0.f;
+        for (int n = 0; n < N; ++n) sacc = fmaf(gbuf[row * LDG + n], l.w[(size_t)n * K + col], sacc);
+        route(row, col, sacc);
+      }
+    } else {
+      // a pass = two column tiles per wave (cp + wv, cp + wv + 8); ALL their weight words (2 x 16 chunks x 4 dwords = 128 VGPRs) are
+      // requested before the first MFMA: one L2 round trip per pass (in 32-deep trips every trip waited out its own: 64 us per
+      // chain).  Addressing: ONE 32-bit lane offset per tile (row 4 lq, the tile's column; columns past K clamped - their results
+      // are never stored) on top of a wave-uniform row base per (chunk, i): 128 loads in flight on two address registers.
+      for (int cp = 0; cp < ktile; cp += 16) {
+        const int ct0 = cp + wv, ct1 = cp + wv + 8;
+        if (ct0 >= ktile) break;                              // wave-uniform; no barrier inside the pass loop
+        const int c0 = 16 * ct0 + lr, c1 = 16 * ct1 + lr;
+        const bool in0 = c0 < K, in1 = ct1 < ktile && c1 < K;
+        const unsigned lo0 = (unsigned)(4 * lq * K + (in0 ? c0 : K - 1)), lo1 = (unsigned)(4 * lq * K + (in1 ? c1 : K - 1));
+        float wq0[16][4], wq1[16][4];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (16 * u < N) {                                   // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float* sb = l.w + (size_t)(16 * u + i) * K;
+              wq0[u][i] = sb[lo0];
+              wq1[u][i] = sb[lo1];
+            }
+          }
+        }
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (16 * u < N) {                                   // wave-uniform
+            const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(gbuf + lr * LDG + 16 * u + 4 * lq);
+            acc0 = mfma4(gv[0], wq0[u][0], acc0); acc1 = mfma4(gv[0], wq1[u][0], acc1);
+            acc0 = mfma4(gv[1], wq0[u][1], acc0); acc1 = mfma4(gv[1], wq1[u][1], acc1);
+            acc0 = mfma4(gv[2], wq0[u][2], acc0); acc1 = mfma4(gv[2], wq1[u][2], acc1);
+            acc0 = mfma4(gv[3], wq0[u][3], acc0); acc1 = mfma4(gv[3], wq1[u][3], acc1);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 4 * lq + r;
-          if (is_prev) {
-            if (k > 0) dbuf[row * LDX + col - op] = acc[r];
-            else if (a.dx0 != nullptr && m0 + row < M) {
-              float* d = a.dx0 + (size_t)(m0 + row) * a.lddx0 + col - op;
-              *d = a.dx0_acc ? *d + acc[r] : acc[r];
-            }
-          } else if (want_side && m0 + row < M) {
-            float* d = l.dside + (size_t)(m0 + row) * l.dside_ld + col - os;
-            *d = l.dside_acc ? *d + acc[r] : acc[r];
-          }
+          if (in0) route(4 * lq + r, c0, acc0[r]);
+          if (in1) route(4 * lq + r, c1, acc1[r]);
         }
       }
     }

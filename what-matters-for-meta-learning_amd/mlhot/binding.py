@@ -107,8 +107,28 @@ class TrunkPass(C.Structure):        # struct mlhot_trunk_pass
     _fields_ = [("img", C.c_void_p), ("n_img", C.c_int), ("wset", C.c_int), ("act", C.c_void_p * 9), ("dfeat", C.c_void_p)]
 
 
+class ChainLayer(C.Structure):       # struct mlhot_chain_layer
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("K", C.c_int), ("N", C.c_int), ("act", C.c_int), ("side", C.c_void_p),
+                ("side_w", C.c_int), ("side_ld", C.c_int), ("side_first", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int)]
+
+
+class ChainGrads(C.Structure):       # struct mlhot_chain_grads
+    _fields_ = [("dw", C.c_void_p), ("db", C.c_void_p), ("g", C.c_void_p), ("ldg", C.c_int), ("dside", C.c_void_p),
+                ("dside_ld", C.c_int), ("dside_accumulate", C.c_int)]
+
+
+class LinearJob(C.Structure):        # struct mlhot_linear_job
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int),
+                ("M", C.c_int), ("K", C.c_int), ("N", C.c_int), ("act", C.c_int), ("dy", C.c_void_p), ("lddy", C.c_int),
+                ("dx", C.c_void_p), ("lddx", C.c_int), ("dx_accumulate", C.c_int), ("dw", C.c_void_p), ("db", C.c_void_p)]
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _addr(t):
+    return None if t is None else t.data_ptr()
 
 
 def _stream(t):
@@ -179,7 +199,11 @@ class MlhotLib:
         c.mlhot_np_vanilla_bwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, C.POINTER(NpGrads), P, P, z, P]
         c.mlhot_np_vanilla_fwd_staged.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, P, z, i, P, P]
         c.mlhot_np_vanilla_bwd_staged.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, C.POINTER(NpGrads), P, P, z, i, P, P]
-        for which, st in ((0, NpDims), (1, NpParams), (2, NpGrads)):
+        c.mlhot_mlp_chain_fwd.argtypes = [P, i, i, C.POINTER(ChainLayer), i, P]
+        c.mlhot_mlp_chain_bwd.argtypes = [P, i, i, C.POINTER(ChainLayer), C.POINTER(ChainGrads), i, P, i, P, i, i, P]
+        c.mlhot_linear_multi_fwd.argtypes = [C.POINTER(LinearJob), i, P]
+        c.mlhot_linear_multi_bwd.argtypes = [C.POINTER(LinearJob), i, P]
+        for which, st in ((0, NpDims), (1, NpParams), (2, NpGrads), (3, ChainLayer), (4, ChainGrads), (5, LinearJob)):
             if c.mlhot_np_struct_bytes(which) != C.sizeof(st):
                 raise MlhotError(f"mlhot: ABI struct size mismatch for {st.__name__}")
 
@@ -579,6 +603,86 @@ class MlhotLib:
         self._rc(self.c.mlhot_linear_bwd(_ptr(x), K, _ptr(w), _ptr(y), N, _ptr(dy), N, M, K, N, ACT[act], _ptr(dx), K, 0,
                                          _ptr(dw), _ptr(db), None, 0, _stream(x)), "mlhot_linear_bwd")
         return dx, dw, db
+
+    # ---- chains of few-row linears / independent few-row linears in one launch (csrc/mlp_chain.h) --------------
+    @staticmethod
+    def chain_ok(x0, layers):
+        """Shapes mlhot_mlp_chain_* take: <= 4 layers, <= 512 rows, input widths <= 512 (multiples of 4), outputs <= 256."""
+        M = x0.shape[0]
+        if not (1 <= len(layers) <= 4 and M <= 512 and x0.shape[1] % 4 == 0):
+            return False
+        prev = x0.shape[1]
+        for k, (w, b, act, side, side_first) in enumerate(layers):
+            sw = side.shape[1] if side is not None else 0
+            N, K = w.shape
+            if K != prev + sw or K > 512 or K % 4 or sw % 4 or N > 256 or (k + 1 < len(layers) and N % 4):
+                return False
+            prev = N
+        return True
+
+    def _chain_structs(self, x0, layers, ys):
+        L = (ChainLayer * len(layers))()
+        for k, (w, b, act, side, side_first) in enumerate(layers):
+            _chk(w, b, side)
+            N, K = w.shape
+            L[k] = ChainLayer(_addr(w), _addr(b), K, N, ACT[act], _addr(side), side.shape[1] if side is not None else 0,
+                              side.shape[1] if side is not None else 0, int(bool(side_first)), _addr(ys[k]), N)
+        return L
+
+    def mlp_chain_fwd(self, x0, layers):
+        """x0 [M, K0]; layers: [(w [N, K], b, act, side [M, side_w] | None, side_first)] -> list of the layers' outputs [M, N]."""
+        _chk(x0)
+        M = x0.shape[0]
+        ys = [torch.empty(M, w.shape[0], device=x0.device) for (w, *_rest) in layers]
+        L = self._chain_structs(x0, layers, ys)
+        self._rc(self.c.mlhot_mlp_chain_fwd(_ptr(x0), x0.shape[1], M, L, len(layers), _stream(x0)), "mlhot_mlp_chain_fwd")
+        return ys
+
+    def mlp_chain_bwd(self, x0, layers, ys, dy, need_dx0=True, need_dside=None):
+        """-> (dx0 | None, [(dw, db, dside | None)] per layer)."""
+        _chk(x0, dy)
+        M = x0.shape[0]
+        need_dside = need_dside or [False] * len(layers)
+        L = self._chain_structs(x0, layers, ys)
+        G = (ChainGrads * len(layers))()
+        outs, keep = [], []
+        for k, (w, b, act, side, side_first) in enumerate(layers):
+            dw, db = torch.empty_like(w), (torch.empty_like(b) if b is not None else None)
+            g = torch.empty(M, w.shape[0] + (-w.shape[0]) % 4, device=x0.device)
+            ds = torch.empty_like(side) if (side is not None and need_dside[k]) else None
+            G[k] = ChainGrads(_addr(dw), _addr(db), _addr(g), g.shape[1], _addr(ds), ds.shape[1] if ds is not None else 0, 0)
+            outs.append((dw, db, ds))
+            keep.append(g)
+        dx0 = torch.empty_like(x0) if need_dx0 else None
+        self._rc(self.c.mlhot_mlp_chain_bwd(_ptr(x0), x0.shape[1], M, L, G, len(layers), _ptr(dy), dy.shape[1], _ptr(dx0), x0.shape[1], 0,
+                                            _stream(x0)), "mlhot_mlp_chain_bwd")
+        return dx0, outs
+
+    def linear_multi_fwd(self, jobs):
+        """jobs: [(x [M, K], w [N, K], b, act)] - independent layers, one launch -> [y]."""
+        J = (LinearJob * len(jobs))()
+        ys = []
+        for k, (x, w, b, act) in enumerate(jobs):
+            _chk(x, w, b)
+            y = torch.empty(x.shape[0], w.shape[0], device=x.device)
+            J[k] = LinearJob(_addr(x), x.shape[1], _addr(w), _addr(b), _addr(y), w.shape[0], x.shape[0], x.shape[1], w.shape[0], ACT[act],
+                             None, 0, None, 0, 0, None, None)
+            ys.append(y)
+        self._rc(self.c.mlhot_linear_multi_fwd(J, len(jobs), _stream(jobs[0][0])), "mlhot_linear_multi_fwd")
+        return ys
+
+    def linear_multi_bwd(self, jobs):
+        """jobs: [(x, w, y, dy, act)] -> [(dx, dw, db)], all gradient bodies in one launch."""
+        J = (LinearJob * len(jobs))()
+        outs = []
+        for k, (x, w, y, dy, act) in enumerate(jobs):
+            _chk(x, w, y, dy)
+            dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty(w.shape[0], device=x.device)
+            J[k] = LinearJob(_addr(x), x.shape[1], _addr(w), None, _addr(y), w.shape[0], x.shape[0], x.shape[1], w.shape[0], ACT[act],
+                             _addr(dy), dy.shape[1], _addr(dx), x.shape[1], 0, _addr(dw), _addr(db))
+            outs.append((dx, dw, db))
+        self._rc(self.c.mlhot_linear_multi_bwd(J, len(jobs), _stream(jobs[0][0])), "mlhot_linear_multi_bwd")
+        return outs
 
     # ---- aggregators ---------------------------------------------------------------------------
     def agg_fwd(self, mode, rs, lv=None):

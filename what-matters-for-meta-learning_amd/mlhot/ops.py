@@ -143,6 +143,112 @@ class StackedLinearFunction(torch.autograd.Function):
                 *dw.view(h, w.shape[0] // h, w.shape[1]).unbind(0), *db.view(h, -1).unbind(0))
 
 
+class MlpChainFunction(torch.autograd.Function):
+    """Up to four Linear(+ReLU / tanh) layers on few rows in ONE launch (backward: two): mlhot_mlp_chain_fwd / _bwd
+    (csrc/mlp_chain.h).  Layer k's input is the previous layer's output, optionally concatenated with a second tensor
+    (`side`, before or behind it) - the reference's torch.cat([x, sample_features]) / cat([x_ctx, labels]) folded into the
+    kernel.  Call through mlp_chain()."""
+
+    @staticmethod
+    def forward(ctx, spec, x0, *tensors):
+        # spec: per layer (act, has_bias, has_side, side_first); tensors: per layer weight[, bias][, side]
+        _need_gpu(x0, *tensors)
+        shp = x0.shape
+        x2 = _c(x0.reshape(-1, shp[-1]).float())
+        layers, it, where = [], iter(range(len(tensors))), []
+        for act, has_b, has_side, side_first in spec:
+            iw = next(it)
+            ib = next(it) if has_b else None
+            isd = next(it) if has_side else None
+            side = tensors[isd] if isd is not None else None
+            layers.append((_c(tensors[iw].detach()), _c(tensors[ib].detach()) if ib is not None else None, act,
+                           _c(side.detach().reshape(-1, side.shape[-1]).float()) if side is not None else None, side_first))
+            where.append((iw, ib, isd))
+        ys = lib().mlp_chain_fwd(x2, layers)
+        ctx.spec, ctx.where, ctx.shp, ctx.n_t = spec, where, shp, len(tensors)
+        ctx.side_shapes = [tensors[isd].shape if isd is not None else None for _, _, isd in where]
+        flat = [x2]
+        for (w, b, _, side, _), y in zip(layers, ys):
+            flat += [w, y] + ([b] if b is not None else []) + ([side] if side is not None else [])
+        ctx.save_for_backward(*flat)
+        return ys[-1].view(*shp[:-1], ys[-1].shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved = list(ctx.saved_tensors)
+        x2, pos = saved[0], 1
+        layers, ys = [], []
+        for act, has_b, has_side, side_first in ctx.spec:
+            w, y = saved[pos], saved[pos + 1]
+            pos += 2
+            b = side = None
+            if has_b:
+                b, pos = saved[pos], pos + 1
+            if has_side:
+                side, pos = saved[pos], pos + 1
+            layers.append((w, b, act, side, side_first))
+            ys.append(y)
+        need_side = [isd is not None and ctx.needs_input_grad[2 + isd] for _, _, isd in ctx.where]
+        dx0, gl = lib().mlp_chain_bwd(x2, layers, ys, _c(dy.reshape(-1, dy.shape[-1]).float()), need_dx0=ctx.needs_input_grad[1],
+                                      need_dside=need_side)
+        grads = [None] * ctx.n_t
+        for (iw, ib, isd), (dw, db, ds), shp in zip(ctx.where, gl, ctx.side_shapes):
+            grads[iw] = dw
+            if ib is not None:
+                grads[ib] = db
+            if isd is not None and ds is not None:
+                grads[isd] = ds.view(shp)
+        return (None, dx0.view(ctx.shp) if dx0 is not None else None) + tuple(grads)
+
+
+def mlp_chain(x0, layers):
+    """layers: [(weight, bias | None, act, side | None, side_first)] -> the last layer's output, or None when the shapes are
+    outside the chain kernels' limits (the caller then runs the layers one by one)."""
+    rows = x0.reshape(-1, x0.shape[-1])
+    probe = [(w, b, act, side.reshape(-1, side.shape[-1]) if side is not None else None, sf) for w, b, act, side, sf in layers]
+    if not x0.is_cuda or not lib().chain_ok(rows, probe):
+        return None
+    spec, tensors = [], []
+    for w, b, act, side, side_first in layers:
+        spec.append((act, b is not None, side is not None, bool(side_first)))
+        tensors += [w] + ([b] if b is not None else []) + ([side] if side is not None else [])
+    return MlpChainFunction.apply(tuple(spec), x0, *tensors)
+
+
+class HeadStacksFunction(torch.autograd.Function):
+    """The per-head Linear stacks of SEVERAL attention inputs (query, key, value: ANP.py:80-93) in one launch per direction:
+    mlhot_linear_multi_fwd / _bwd over the stacked head weights (networks/_resnet_np.py::HeadStack).  Inputs: n stacks of
+    (x [T, N, h], stacked weight [H h, h], stacked bias [H h]) followed by every head's own Parameters (their gradients are views of
+    the stacks' gradient tensors).  Returns n tensors [T, N, H, h]."""
+
+    @staticmethod
+    def forward(ctx, n_heads, n_stacks, *args):
+        xs, ws, bs = args[0:3 * n_stacks:3], args[1:3 * n_stacks:3], args[2:3 * n_stacks:3]
+        _need_gpu(*xs, *ws, *bs)
+        x2 = [_c(x.reshape(-1, x.shape[-1]).float()) for x in xs]
+        ys = lib().linear_multi_fwd([(x, w, b, "none") for x, w, b in zip(x2, ws, bs)])
+        ctx.n_heads, ctx.n_stacks, ctx.shapes = n_heads, n_stacks, [x.shape for x in xs]
+        ctx.save_for_backward(*x2, *ws, *ys)
+        return tuple(y.view(*x.shape[:-1], n_heads, -1) for y, x in zip(ys, xs))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, h = ctx.n_stacks, ctx.n_heads
+        sv = ctx.saved_tensors
+        x2, ws, ys = sv[:n], sv[n:2 * n], sv[2 * n:]
+        outs = lib().linear_multi_bwd([(x, w, y, _c(dy.reshape(-1, w.shape[0]).float()), "none") for x, w, y, dy in zip(x2, ws, ys, dys)])
+        lead = []
+        heads_w, heads_b = [], []
+        for (dx, dw, db), shp, w in zip(outs, ctx.shapes, ws):
+            lead += [dx.view(shp), None, None]
+            heads_w.append(dw.view(h, w.shape[0] // h, w.shape[1]).unbind(0))
+            heads_b.append(db.view(h, -1).unbind(0))
+        per_stack = []
+        for hw, hb in zip(heads_w, heads_b):          # the order HeadStack.params() hands the Parameters over: weights, then biases
+            per_stack += list(hw) + list(hb)
+        return (None, None) + tuple(lead) + tuple(per_stack)
+
+
 class NTXentFunction(torch.autograd.Function):
     """NT-Xent of [N, d] embeddings whose labels are arange blocks, label(i) = (i // div) % mod: mlhot_nt_xent_fwd / _bwd
     (trainer/losses.py:82-99).  No host-side index tensors, no host -> device copies, capturable."""

@@ -132,9 +132,9 @@ class ANPMRShapeNet3D(ResNetNP):
                 x_ctx, _ = self.img_encoder(ctx_imgs)
                 x_tgt, kl = self.img_encoder(tgt_imgs)     # a second, independent weight sample
             x_ctx, x_tgt = self.pixel_agg(x_ctx), self.pixel_agg(x_tgt)
-            feats = _mlp3(torch.cat([x_ctx, label_train], dim=2), self.task_encoder, last_relu=True)
-            sample = LinearFunction.apply(self._multihead_attention(x_ctx, feats, x_tgt), self.mu.weight, self.mu.bias, "none")
-            out, var = self.decoder(batch_test_images, sample, fmap=fmap_dec)
+            feats = _mlp3(x_ctx, self.task_encoder, last_relu=True, side=label_train)      # cat([x_ctx, labels]), ANPMRShapeNet3D.py:204-205
+            # mu (ANPMRShapeNet3D.py:209) runs inside the decoder head's launch: mu -> cat([features, sample]) -> fc_mu as one chain
+            out, var = self.decoder(batch_test_images, self._multihead_attention(x_ctx, feats, x_tgt), fmap=fmap_dec, pre=self.mu)
             return out, var, kl
         sample = torch.zeros(self.task_num, self.test_num, 256, device=batch_test_images.device)
         out, var = self.decoder(batch_test_images, sample)

@@ -7,7 +7,7 @@ operators (run-time-shaped convolutions, linears, shot-axis aggregators, FAVOR+ 
 import torch
 from torch import nn
 
-from mlhot.ops import AggFunction, FavorFunction, LinearFunction, StackedLinearFunction
+from mlhot.ops import AggFunction, FavorFunction, HeadStacksFunction, LinearFunction, StackedLinearFunction
 from networks.fast_attention import FastAttention
 from networks.models import AttnLinear, ImageEncoder, NPDecoder, _mlp3, run_trunks
 
@@ -110,9 +110,26 @@ class ResNetNP(nn.Module):
         T, N, _ = x.shape
         return StackedLinearFunction.apply(x, w, b, self.N_HEADS, *st.params()).view(T, N, self.N_HEADS, -1)
 
+    def _stack(self, mods):
+        stacks = self.__dict__.setdefault("_head_stacks", {})
+        st = stacks.get(id(mods))
+        if st is None:
+            st = stacks[id(mods)] = HeadStack(mods)
+        return st
+
     def _multihead_attention(self, k, v, q):
-        merged = FavorFunction.apply(self._heads(q, self._W_q), self._heads(k, self._W_k), self._heads(v, self._W_v),
-                                     self.attn.projection_matrix)
+        if q.is_cuda and max(q.shape[0] * q.shape[1], k.shape[0] * k.shape[1]) <= 512 and q.shape[-1] % 4 == 0:
+            # the three head stacks in ONE launch per direction (few rows: mlhot_linear_multi_*)
+            sts = [self._stack(m) for m in (self._W_q, self._W_k, self._W_v)]
+            args, params = [], []
+            for x, st in zip((q, k, v), sts):
+                w, b = st.tensors()
+                args += [x, w, b]
+                params += st.params()
+            qh, kh, vh = HeadStacksFunction.apply(self.N_HEADS, 3, *args, *params)
+        else:
+            qh, kh, vh = self._heads(q, self._W_q), self._heads(k, self._W_k), self._heads(v, self._W_v)
+        merged = FavorFunction.apply(qh, kh, vh, self.attn.projection_matrix)
         return self._W(merged)
 
     def _aggregate(self, feats, quirk=False):
@@ -165,15 +182,20 @@ class ResNetNP(nn.Module):
             if self.TRANSFORM_Y:
                 label_train = LinearFunction.apply(label_train, self.transform_y.weight, self.transform_y.bias, "none")
             x_ctx = encode(ctx_imgs, "ctx")
-            feats = _mlp3(torch.cat([x_ctx, label_train], dim=2), self.task_encoder, last_relu=True)
+            feats = _mlp3(x_ctx, self.task_encoder, last_relu=True, side=label_train)      # cat([x_ctx, labels]), ANP.py:113
+            pre = None
             if self.ATTENTION:
                 x_tgt = encode(tgt_imgs, "tgt")
-                sample = LinearFunction.apply(self._multihead_attention(x_ctx, feats, x_tgt), self.mu.weight, self.mu.bias, "none")
+                sample = self._multihead_attention(x_ctx, feats, x_tgt)
+                if self.CONTRASTIVE and not test:                 # the contrastive term reads mu's output itself
+                    sample = LinearFunction.apply(sample, self.mu.weight, self.mu.bias, "none")
+                else:
+                    pre = self.mu                                 # mu runs inside the decoder head's launch (models._mlp3)
             else:
                 z_0 = self._aggregate(feats)
                 sample = z_0[:, None, :].expand(-1, self.test_num, -1)
         else:
-            sample = torch.zeros(self.task_num, self.test_num, 256, device=batch_test_images.device)
+            sample, pre = torch.zeros(self.task_num, self.test_num, 256, device=batch_test_images.device), None
         contra = 0
         if self.CONTRASTIVE and not test:
             if self.ATTENTION:
@@ -186,7 +208,7 @@ class ResNetNP(nn.Module):
                     label_test = LinearFunction.apply(label_test, self.transform_y.weight, self.transform_y.bias, "none")
                 z_q = self._aggregate(_mlp3(torch.cat([x_qry, label_test], dim=2), self.task_encoder, last_relu=True), quirk=True)
                 contra = LossFunc.contrastive_loss(z_0, z_q)
-        out, var = self.decoder(batch_test_images, sample, fmap=fm.get("dec"))
+        out, var = self.decoder(batch_test_images, sample, fmap=fm.get("dec"), pre=pre)
         if self.CONTRASTIVE:
             return out, var, 0, contra
         return out, var, 0

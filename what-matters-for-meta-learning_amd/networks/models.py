@@ -4,11 +4,13 @@ These classes are parameter containers with the reference's construction order (
 seeded model draws identical initial weights) and state_dict keys; their own forward()
 runs the mlhot HIP linear kernels, while the fused model path reads the parameters directly.
 """
+import os
+
 import torch
 from torch import nn
 
 from mlhot import lib
-from mlhot.ops import LinearFunction, MaxPool2Function, ResNetTrunkFunction
+from mlhot.ops import LinearFunction, MaxPool2Function, ResNetTrunkFunction, mlp_chain
 from networks.ResNet import BasicBlock, ResNet, run_conv
 
 
@@ -47,6 +49,9 @@ class AttnLinear(nn.Module):
         return LinearFunction.apply(x, self.linear.weight, self.linear.bias, "none")
 
 
+CHAINS_IN_MODELS = os.environ.get("MLHOT_MLP_CHAIN") == "1"
+
+
 def _aggregate_feature_map(x, aggregate):
     """img_agg of ImageEncoder / NPDecoder (models.py:105-113): [n,64,h,w] -> [n,F]."""
     if aggregate in ("max", "baco"):                    # AdaptiveMaxPool2d((2,2))
@@ -61,11 +66,29 @@ def _aggregate_feature_map(x, aggregate):
     return x.reshape(x.size(0), -1)
 
 
-def _mlp3(x, seq, last_relu):
-    """Sequential(Linear, ReLU, Linear, ReLU, Linear[, ReLU]) through the HIP linear kernels."""
+def _mlp3(x, seq, last_relu, side=None, side_first=False, pre=None):
+    """Sequential(Linear, ReLU, Linear, ReLU, Linear[, ReLU]) over [side | x] / [x | side] (the reference's torch.cat in front of the
+    first layer; `side` = None: just x), optionally behind a plain Linear `pre` applied to x first (the attention models' `mu`,
+    ANP.py:52,128): ONE launch per direction through the chain kernels (mlhot.ops.mlp_chain) when the shapes fit them, the HIP
+    linear kernels layer by layer otherwise.
+
+    Measured on MI355X (c5: 120 rows, 256-wide layers): the chain kernels LOSE to one launch per
+    layer at these shapes - a workgroup that owns 16 rows has to pull every layer's whole weight matrix (256 KB - 512 KB) through ONE
+    CU (~70 GB/s) and to issue all of the layer's MFMAs on that CU: 48 us for a four-layer chain against 4 x 7.7 us - so the models
+    use them only when MLHOT_MLP_CHAIN=1 (kept for A/B runs and for shapes with small weights); the default is one launch per layer."""
     lins = [m for m in seq if isinstance(m, nn.Linear)]
-    for i, lin in enumerate(lins):
-        act = "relu" if (i < len(lins) - 1 or last_relu) else "none"
+    acts = ["relu" if (i < len(lins) - 1 or last_relu) else "none" for i in range(len(lins))]
+    layers = [(pre.weight, pre.bias, "none", None, False)] if pre is not None else []
+    layers += [(lin.weight, lin.bias, act, side if i == 0 else None, side_first) for i, (lin, act) in enumerate(zip(lins, acts))]
+    if CHAINS_IN_MODELS:
+        y = mlp_chain(x, layers)
+        if y is not None:
+            return y
+    if pre is not None:
+        x = LinearFunction.apply(x, pre.weight, pre.bias, "none")
+    if side is not None:
+        x = torch.cat([side, x] if side_first else [x, side], dim=-1)
+    for lin, act in zip(lins, acts):
         x = LinearFunction.apply(x, lin.weight, lin.bias, act)
     return x
 
@@ -164,9 +187,10 @@ class NPDecoder(nn.Module):
     def trunk_job(self, imgs):
         return (imgs, trunk_weights(self.conv1, self.resnet), 1, self.tap_log)      # rebuilt per call, see ImageEncoder.trunk_job
 
-    def forward(self, test_images, sample_features, log_variance=None, fmap=None):
+    def forward(self, test_images, sample_features, log_variance=None, fmap=None, pre=None):
         """`fmap`: this decoder's trunk output over the target images when the caller already ran it together with the
-        encoder passes (run_trunks); computed here otherwise."""
+        encoder passes (run_trunks); computed here otherwise.  `pre`: a Linear still to be applied to `sample_features` (the
+        attention models' `mu`), so that it runs inside fc_mu's launch."""
         n_per_task = sample_features.size(1)
         if fmap is None:
             imgs = test_images.reshape(self.task_num * n_per_task, self.img_channels, self.img_size[0], self.img_size[1])
@@ -179,5 +203,5 @@ class NPDecoder(nn.Module):
                 maps = [self.resnet.trunk(run_conv(self.conv1, imgs, relu=True), taps)]
             fmap = maps[0]
         x = _aggregate_feature_map(fmap, self.aggregate).reshape(self.task_num, n_per_task, -1)
-        mu = _mlp3(torch.cat([x, sample_features], dim=-1), self.fc_mu, last_relu=False)
+        mu = _mlp3(sample_features, self.fc_mu, last_relu=False, side=x, side_first=True, pre=pre)      # cat([x, sample_features]), models.py:182
         return mu, None
