@@ -644,6 +644,8 @@ def main():
     cx, qx, cy, qy = make_batch(w, 1234 + rank, device)
     # the trainer's own setting (trainer/model_trainer.py): collectives on a communication stream, and - for the models that
     # name them - the gradients that are complete early in the backward as a bucket of their own
+    if (world > 1 or mdist.force_collectives()) and hasattr(model, "enable_flat_grads"):
+        model.enable_flat_grads()            # ResNet / BBB family: gradients in one flat buffer, all-reduced in place (mlhot/arena.py)
     bucket = mdist.GradBucket(model.parameters(), side_stream=True,
                               early=model.early_grad_parameters() if hasattr(model, "early_grad_parameters") else None)
     beta = w.get("beta", 0.0)

@@ -1890,6 +1890,79 @@ def test_grad_bucket_side_stream_and_early_bucket_on_cuda(gpulib):
             assert [k for k, _ in early_log] == ["early", "rest"] and [k for k, _ in side_log] == ["all"]
 
 
+@pytest.mark.parametrize("method", ["ANPMRShapeNet3D", "ANP", "CondNeuralProcess"])
+def test_flat_gradient_arena_for_the_resnet_family(gpulib, method):
+    """VERDICT r3 item 5 i (train.py:52-56: one optimizer over all parameters): with model.enable_flat_grads() every gradient of a
+    ResNet / Bayes-by-backprop model is a view of ONE flat buffer (mlhot/arena.py) - the trunk backward, the linears, the head
+    stacks and the Bayes-by-backprop sampling write their slots directly - bit-identical to the separately allocated gradients,
+    the early parameters in the buffer's first range; GradBucket then reduces both ranges in place (no _foreach_copy_)."""
+    import importlib
+    import types
+    from mlhot import binding, dist as mdist
+    from trainer.losses import LossFunc
+    T, Nc, Nq = 2, 5, 6
+    cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[64, 64, 4], tasks_per_batch=T, input_dim=4, output_dim=4,
+                                agg_mode="attention" if method != "CondNeuralProcess" else "max", img_agg="reshape" if method == "ANPMRShapeNet3D" else "max",
+                                task="shapenet_3d", temperature=0.07)
+    model = getattr(importlib.import_module("networks." + method), method)(cfg).to(DEV)
+    g = torch.Generator().manual_seed(7)
+    cx, qx = torch.rand(T, Nc, 3, 64, 64, generator=g).to(DEV), torch.rand(T, Nq, 3, 64, 64, generator=g).to(DEV)
+    cy = F.normalize(torch.randn(T, Nc, 4, generator=g), dim=-1).to(DEV)
+    qy = F.normalize(torch.randn(T, Nq, 4, generator=g), dim=-1).to(DEV)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(99)
+        mu, var, kl = model(cx, cy, qx)
+        (LossFunc("mse", "shapenet_3d").calc_loss(mu, var, qy) + 1e-7 * kl).backward()
+        return {k: p.grad for k, p in model.named_parameters()}
+    try:
+        plain = {k: (v.clone() if v is not None else None) for k, v in step().items()}
+        arena = model.enable_flat_grads()
+        step()                               # first step with the arena: the head stacks' storages may be re-laid, the layout follows
+        grads = step()
+        base = arena.flat.untyped_storage().data_ptr()
+        early = {id(p) for p in model.early_grad_parameters()}
+        for k, p in model.named_parameters():
+            if plain[k] is None:
+                assert grads[k] is None, k
+                continue
+            assert grads[k].untyped_storage().data_ptr() == base, f"{k}: gradient outside the flat buffer"
+            assert torch.equal(grads[k], plain[k]), k
+            assert (grads[k].storage_offset() < arena.first_numel) == (id(p) in early), k
+        # the bucket reduces both ranges in place: a world of one, collectives replaced by a recorder
+        copies = []
+        real = torch._foreach_copy_
+        log = []
+
+        class Rec(mdist.GradBucket):
+            def _single(self):
+                return False
+
+            def _all_reduce(self, flat):
+                log.append((flat.data_ptr(), flat.numel()))
+        bucket = Rec(model.parameters(), early=model.early_grad_parameters())
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(99)
+        mu, var, kl = model(cx, cy, qx)
+        loss = LossFunc("mse", "shapenet_3d").calc_loss(mu, var, qy) + 1e-7 * kl
+        bucket.arm()
+        torch._foreach_copy_ = lambda *a, **k: (copies.append(1), real(*a, **k))[1]
+        try:
+            loss.backward()
+            bucket.sync()
+        finally:
+            torch._foreach_copy_ = real
+        assert [k for k, _ in bucket.issue_log] == ["early", "rest"] and not copies
+        (p0, n0), (p1, n1) = log
+        assert p0 >= arena.flat.data_ptr() and p0 + 4 * n0 <= arena.flat.data_ptr() + 4 * arena.first_numel <= p1
+        for k, p in model.named_parameters():
+            if plain[k] is not None:
+                assert torch.equal(p.grad, plain[k]), k
+    finally:
+        binding.set_grad_arena(None)
+
+
 def _rccl_one_worker(port, out):
     """backend "nccl" (= RCCL on ROCm) at a world of ONE on the box's GPU, collectives forced (MLHOT_FORCE_COLLECTIVES)."""
     import sys

@@ -123,6 +123,25 @@ class LinearJob(C.Structure):        # struct mlhot_linear_job
                 ("dx", C.c_void_p), ("lddx", C.c_int), ("dx_accumulate", C.c_int), ("dw", C.c_void_p), ("db", C.c_void_p)]
 
 
+_GRAD_ARENA = None
+
+
+def set_grad_arena(arena):
+    """Install (or, with None, remove) the flat gradient buffer the weight / bias gradients of the following calls are written
+    into (mlhot/arena.py).  Process-global, like the parameters it mirrors: one model trains at a time."""
+    global _GRAD_ARENA
+    _GRAD_ARENA = arena
+
+
+def _grad_like(t):
+    """Storage for the gradient of `t`: its slot in the installed arena, or a fresh tensor."""
+    if _GRAD_ARENA is not None:
+        v = _GRAD_ARENA.slot(t)
+        if v is not None:
+            return v
+    return torch.empty_like(t)
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -398,7 +417,7 @@ class MlhotLib:
 
     def bbb_sample_bwd(self, mu, rho, eps, dw, dkl):
         _chk(dw, dkl)
-        dmu, drho = torch.empty_like(mu), torch.empty_like(mu)
+        dmu, drho = _grad_like(mu), _grad_like(rho)
         self._rc(self.c.mlhot_bbb_sample_bwd(_ptr(mu), _ptr(rho), _ptr(eps), _ptr(dw), _ptr(dkl), _ptr(dmu), _ptr(drho), mu.numel(), _stream(mu)),
                  "mlhot_bbb_sample_bwd")
         return dmu, drho
@@ -436,7 +455,7 @@ class MlhotLib:
 
     def bbb_sample_multi_bwd(self, mus, rhos, epss, dws, dkl, epss2=None, dws2=None):
         _chk(*[d for d in dws if d is not None], dkl, *[d for d in (dws2 or []) if d is not None])
-        dmus, drhos = [torch.empty_like(m) for m in mus], [torch.empty_like(m) for m in mus]
+        dmus, drhos = [_grad_like(m) for m in mus], [_grad_like(r) for r in rhos]
         items = self._bbb_items(mus, rhos, epss, dws=dws, dmus=dmus, drhos=drhos, epss2=epss2, dws2=dws2)
         self._rc(self.c.mlhot_bbb_sample_multi_bwd(items, len(mus), _ptr(dkl), _stream(mus[0])), "mlhot_bbb_sample_multi_bwd")
         return dmus, drhos
@@ -543,7 +562,7 @@ class MlhotLib:
         _chk(*dfeats)
         imgs = [p[0] for p in passes]
         C_, H = imgs[0].shape[1], imgs[0].shape[2]
-        grads = [[torch.empty_like(t) for t in ts] for ts, _ in wsets]
+        grads = [[_grad_like(t) for t in ts] for ts, _ in wsets]
         pa, wa = self._trunk_structs(passes, wsets, grads=grads, dfeats=dfeats)
         sb, scratch = self._trunk_scratch(pa, len(passes), wa, len(wsets), C_, H, 1, imgs[0])
         self.c.mlhot_trunk_bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -594,12 +613,13 @@ class MlhotLib:
         self._rc(self.c.mlhot_linear_fwd(_ptr(x), K, _ptr(w), _ptr(b), _ptr(y), N, M, K, N, ACT[act], _stream(x)), "mlhot_linear_fwd")
         return y
 
-    def linear_bwd(self, x, w, y, dy, act="none", need_dx=True):
+    def linear_bwd(self, x, w, y, dy, act="none", need_dx=True, b=None):
+        """`b`: the layer's bias tensor, only to find its gradient's slot in an installed arena."""
         _chk(x, w, y, dy)
         M, K = x.shape
         N = w.shape[0]
         dx = torch.empty_like(x) if need_dx else None
-        dw, db = torch.empty_like(w), torch.empty(N, device=x.device)
+        dw, db = _grad_like(w), (_grad_like(b) if b is not None else torch.empty(N, device=x.device))
         self._rc(self.c.mlhot_linear_bwd(_ptr(x), K, _ptr(w), _ptr(y), N, _ptr(dy), N, M, K, N, ACT[act], _ptr(dx), K, 0,
                                          _ptr(dw), _ptr(db), None, 0, _stream(x)), "mlhot_linear_bwd")
         return dx, dw, db
@@ -647,7 +667,7 @@ class MlhotLib:
         G = (ChainGrads * len(layers))()
         outs, keep = [], []
         for k, (w, b, act, side, side_first) in enumerate(layers):
-            dw, db = torch.empty_like(w), (torch.empty_like(b) if b is not None else None)
+            dw, db = _grad_like(w), (_grad_like(b) if b is not None else None)
             g = torch.empty(M, w.shape[0] + (-w.shape[0]) % 4, device=x0.device)
             ds = torch.empty_like(side) if (side is not None and need_dside[k]) else None
             G[k] = ChainGrads(_addr(dw), _addr(db), _addr(g), g.shape[1], _addr(ds), ds.shape[1] if ds is not None else 0, 0)
@@ -672,12 +692,13 @@ class MlhotLib:
         return ys
 
     def linear_multi_bwd(self, jobs):
-        """jobs: [(x, w, y, dy, act)] -> [(dx, dw, db)], all gradient bodies in one launch."""
+        """jobs: [(x, w, y, dy, act[, bias])] -> [(dx, dw, db)], all gradient bodies in one launch."""
         J = (LinearJob * len(jobs))()
         outs = []
-        for k, (x, w, y, dy, act) in enumerate(jobs):
+        for k, (x, w, y, dy, act, *bias) in enumerate(jobs):
             _chk(x, w, y, dy)
-            dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty(w.shape[0], device=x.device)
+            b = bias[0] if bias else None
+            dx, dw, db = torch.empty_like(x), _grad_like(w), (_grad_like(b) if b is not None else torch.empty(w.shape[0], device=x.device))
             J[k] = LinearJob(_addr(x), x.shape[1], _addr(w), None, _addr(y), w.shape[0], x.shape[0], x.shape[1], w.shape[0], ACT[act],
                              _addr(dy), dy.shape[1], _addr(dx), x.shape[1], 0, _addr(dw), _addr(db))
             outs.append((dx, dw, db))

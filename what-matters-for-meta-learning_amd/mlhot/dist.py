@@ -207,9 +207,14 @@ class GradBucket:
             self._armed = False
             live = [q for q in self.early if q.grad is not None]
             if live:
-                flat = torch.empty(sum(q.grad.numel() for q in live), dtype=torch.float32, device=live[0].grad.device)
-                views = list(flat.split([q.grad.numel() for q in live]))
-                torch._foreach_copy_(views, [q.grad.reshape(-1) for q in live])
+                flat, views = self._shared_flat(live), None      # a gradient arena (mlhot/arena.py): reduce the range in place
+                if flat is not None and flat.numel() > sum(q.grad.numel() for q in live) + 4 * len(live) + sum(
+                        q.numel() for q in self.early if q.grad is None):
+                    flat = None                                  # the range holds more than the early gradients (+ padding, unused ones): not theirs alone
+                if flat is None:
+                    flat = torch.empty(sum(q.grad.numel() for q in live), dtype=torch.float32, device=live[0].grad.device)
+                    views = list(flat.split([q.grad.numel() for q in live]))
+                    torch._foreach_copy_(views, [q.grad.reshape(-1) for q in live])
                 self.issue_log.append(("early", flat.numel()))
                 self._issue(flat, asynchronous=True)
                 self._early_state = (live, flat, views)
@@ -251,43 +256,44 @@ class GradBucket:
         if early is not None:
             done = {id(q) for q in early[0]}
             live = [p for p in live if id(p) not in done]
-        shared = self._shared_flat(live) if (live and early is None) else None
-        if shared is not None:
-            # the library already wrote every gradient into ONE flat buffer (mlhot_np_grads_flat_layout): reduce it in
-            # place, no pack / unpack.  Alignment padding and regions of unused parameters ride along harmlessly.
-            self.issue_log.append(("all", shared.numel()))
-            self._issue(shared)
-            if wait:
-                self.wait()
-            if defer_scale:
-                return scale
-            shared.mul_(scale)
-            return 1.0
-        views = []
+        rest_flat, rest_views = None, None
         if live:
-            n = sum(p.grad.numel() for p in live)
-            if self.flat is None or self.flat.numel() != n or self.flat.device != live[0].grad.device:
-                self.flat = torch.empty(n, dtype=torch.float32, device=live[0].grad.device)
-            views = list(self.flat.split([p.grad.numel() for p in live]))
-            torch._foreach_copy_(views, [p.grad.reshape(-1) for p in live])
-            self.issue_log.append(("rest" if early is not None else "all", n))
-            self._issue(self.flat, asynchronous=not wait)
-        self._unpack = (live, views, early)
+            # Gradients that are views of ONE flat buffer (the vanilla models' single backward call writes them so,
+            # mlhot_np_grads_flat_layout; the ResNet / BBB family through mlhot.arena.GradArena) are reduced in place: no pack /
+            # unpack.  Alignment padding and regions of unused parameters ride along harmlessly.
+            rest_flat = self._shared_flat(live)
+            if rest_flat is not None and early is not None:
+                # the early bucket has been (or is being) reduced already: an in-place range for the rest must not reach into it
+                # (it cannot when the arena was built with first=<the early parameters>; any other layout packs the rest)
+                a0, a1 = rest_flat.data_ptr(), rest_flat.data_ptr() + 4 * rest_flat.numel()
+                for q in early[0]:
+                    if q.grad.data_ptr() < a1 and q.grad.data_ptr() + 4 * q.grad.numel() > a0:
+                        rest_flat = None
+                        break
+            if rest_flat is None:
+                n = sum(p.grad.numel() for p in live)
+                if self.flat is None or self.flat.numel() != n or self.flat.device != live[0].grad.device:
+                    self.flat = torch.empty(n, dtype=torch.float32, device=live[0].grad.device)
+                rest_flat, rest_views = self.flat, list(self.flat.split([p.grad.numel() for p in live]))
+                torch._foreach_copy_(rest_views, [p.grad.reshape(-1) for p in live])
+            self.issue_log.append(("rest" if early is not None else "all", rest_flat.numel()))
+            self._issue(rest_flat, asynchronous=not wait)
+        self._unpack = (live, rest_flat, rest_views, early)
         if wait:
             self.wait()
         return self._finish(scale, defer_scale) if wait else scale
 
     def _finish(self, scale, defer_scale):
-        live, views, early = self._unpack
+        live, rest_flat, rest_views, early = self._unpack
         self._unpack = None
         if not defer_scale:
-            if live:
-                self.flat.mul_(scale)
+            if rest_flat is not None:
+                rest_flat.mul_(scale)
             if early is not None:
                 early[1].mul_(scale)
-        if live:
-            torch._foreach_copy_([p.grad.view(-1) for p in live], views)
-        if early is not None:
+        if rest_views is not None:
+            torch._foreach_copy_([p.grad.view(-1) for p in live], rest_views)
+        if early is not None and early[2] is not None:
             torch._foreach_copy_([q.grad.view(-1) for q in early[0]], early[2])
         return scale if defer_scale else 1.0
 

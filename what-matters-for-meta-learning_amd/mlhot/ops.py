@@ -108,13 +108,14 @@ class LinearFunction(torch.autograd.Function):
         x2 = _c(x.reshape(-1, shp[-1]).float())
         y = lib().linear_fwd(x2, _c(w.detach()), _c(b.detach()) if b is not None else None, act)
         ctx.act, ctx.shp, ctx.has_b = act, shp, b is not None
-        ctx.save_for_backward(x2, _c(w.detach()), y)
+        ctx.save_for_backward(x2, _c(w.detach()), y, *([b.detach()] if b is not None else []))
         return y.view(*shp[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, y = ctx.saved_tensors
-        dx, dw, db = lib().linear_bwd(x2, w, y, _c(dy.reshape(-1, w.shape[0])), ctx.act, need_dx=ctx.needs_input_grad[0])
+        x2, w, y, *bias = ctx.saved_tensors
+        dx, dw, db = lib().linear_bwd(x2, w, y, _c(dy.reshape(-1, w.shape[0])), ctx.act, need_dx=ctx.needs_input_grad[0],
+                                      b=bias[0] if bias else None)
         return (dx.view(ctx.shp) if dx is not None else None), dw, (db if ctx.has_b else None), None
 
 
@@ -131,13 +132,13 @@ class StackedLinearFunction(torch.autograd.Function):
         x2 = _c(x.reshape(-1, shp[-1]).float())
         y = lib().linear_fwd(x2, stack_w, stack_b, "none")
         ctx.shp, ctx.n_heads = shp, n_heads
-        ctx.save_for_backward(x2, stack_w, y)
+        ctx.save_for_backward(x2, stack_w, y, stack_b)
         return y.view(*shp[:-1], stack_w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, y = ctx.saved_tensors
-        dx, dw, db = lib().linear_bwd(x2, w, y, _c(dy.reshape(-1, w.shape[0])), "none", need_dx=ctx.needs_input_grad[0])
+        x2, w, y, b = ctx.saved_tensors
+        dx, dw, db = lib().linear_bwd(x2, w, y, _c(dy.reshape(-1, w.shape[0])), "none", need_dx=ctx.needs_input_grad[0], b=b)
         h = ctx.n_heads
         return ((dx.view(ctx.shp) if dx is not None else None), None, None, None,
                 *dw.view(h, w.shape[0] // h, w.shape[1]).unbind(0), *db.view(h, -1).unbind(0))
@@ -228,15 +229,16 @@ class HeadStacksFunction(torch.autograd.Function):
         x2 = [_c(x.reshape(-1, x.shape[-1]).float()) for x in xs]
         ys = lib().linear_multi_fwd([(x, w, b, "none") for x, w, b in zip(x2, ws, bs)])
         ctx.n_heads, ctx.n_stacks, ctx.shapes = n_heads, n_stacks, [x.shape for x in xs]
-        ctx.save_for_backward(*x2, *ws, *ys)
+        ctx.save_for_backward(*x2, *ws, *ys, *bs)
         return tuple(y.view(*x.shape[:-1], n_heads, -1) for y, x in zip(ys, xs))
 
     @staticmethod
     def backward(ctx, *dys):
         n, h = ctx.n_stacks, ctx.n_heads
         sv = ctx.saved_tensors
-        x2, ws, ys = sv[:n], sv[n:2 * n], sv[2 * n:]
-        outs = lib().linear_multi_bwd([(x, w, y, _c(dy.reshape(-1, w.shape[0]).float()), "none") for x, w, y, dy in zip(x2, ws, ys, dys)])
+        x2, ws, ys, bs = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:]
+        outs = lib().linear_multi_bwd([(x, w, y, _c(dy.reshape(-1, w.shape[0]).float()), "none", b)
+                                       for x, w, y, dy, b in zip(x2, ws, ys, dys, bs)])
         lead = []
         heads_w, heads_b = [], []
         for (dx, dw, db), shp, w in zip(outs, ctx.shapes, ws):

@@ -112,6 +112,7 @@ class ANPMRShapeNet3D(ResNetNP):
         return x.view(self.task_num, -1, x.size(1))
 
     def forward(self, batch_train_images, label_train, batch_test_images, test=False):
+        self._refresh_arena()
         self.test_num = batch_test_images.shape[1]
         self.ctx_num = batch_train_images.shape[1]
         C, H, W = self.img_channels, self.img_size[0], self.img_size[1]

@@ -99,6 +99,22 @@ class ResNetNP(nn.Module):
         from inside the backward, under the trunks' ~1 ms."""
         return [p for k, p in self.named_parameters() if not (k.startswith("img_encoder.") or k.startswith("decoder.resnet."))]
 
+    def enable_flat_grads(self, on=True):
+        """Every gradient of this model in ONE flat buffer (mlhot/arena.py): the kernels write weight / bias gradients straight
+        into their slots, mlhot.dist.GradBucket all-reduces the buffer in place (the early bucket = its first range) instead of
+        packing / unpacking <= 15 MB per step.  Process-global while on (one model trains at a time)."""
+        from mlhot import binding
+        from mlhot.arena import GradArena
+        arena = GradArena(self.parameters(), first=self.early_grad_parameters()) if on else None
+        self.__dict__["_arena"] = arena
+        binding.set_grad_arena(arena)
+        return arena
+
+    def _refresh_arena(self):
+        arena = self.__dict__.get("_arena")
+        if arena is not None:
+            arena.refresh()          # a no-op unless a parameter's storage changed (first step: the head stacks were just built)
+
     # the 8 per-head AttnLinear layers run as ONE linear over the stacked weights; rows come out
     # token-major / head-minor, which is the layout the FAVOR+ kernels take
     def _heads(self, x, mods):
@@ -148,6 +164,7 @@ class ResNetNP(nn.Module):
     def forward(self, batch_train_images, label_train, batch_test_images, *rest, test=False):
         """(ctx images, ctx labels, target images[, test]) -> (mu, var, 0); the FCL classes take the target labels as 4th
         positional argument and return (mu, var, 0, contrastive term) like the reference (FCLANP.py:108, FCLCNPDistractor.py:82)."""
+        self._refresh_arena()
         label_test = None
         if self.CONTRASTIVE:
             if not rest:

@@ -43,6 +43,8 @@ class ModelTrainer(BaseTrainer):
         # before the backward ends (ResNet family: everything but the image trunks) all-reduce them under the rest of the backward
         early = model.early_grad_parameters() if hasattr(model, "early_grad_parameters") else None
         self.bucket = GradBucket(model.parameters(), side_stream=torch.device(config.device).type == "cuda", early=early)
+        if not self.bucket._single() and hasattr(model, "enable_flat_grads") and torch.device(config.device).type == "cuda":
+            model.enable_flat_grads()      # more than one rank: the ResNet / BBB family's gradients in one flat buffer, reduced in place
         if getattr(config, "strict_sharded_parity", False):
             if getattr(config, "graph_steps", False):
                 raise ValueError("config.strict_sharded_parity runs a collective between two C calls of the forward: not with config.graph_steps")
