@@ -78,6 +78,13 @@ int mlhot_nt_xent_bwd(const float* z, int N, int d, int div, int mod, float t, c
  * bit-identical to torch's, the normals equal up to the last ulps of logf / sincosf.                                        */
 int mlhot_mt19937_normal(uint32_t* engine, float* uniform_ws, float* out, const int64_t* segs, int nseg, int64_t total_outputs,
                          int64_t total_groups, void* stream);
+/* The same draw from n_sub parallel sub-streams of stride_blocks 624-word blocks each (MT19937 jump-ahead; the polynomials
+ * polys[n_sub - 1][624] = t^(624 stride_blocks k) mod phi, k = 1 .. n_sub - 1, come from mlhot/mt_jump.py): identical uniforms, normals
+ * and final engine state.  Needs n_sub * stride_blocks >= the number of new blocks of the draw; jump_ws: mlhot_mt19937_jump_ws_words(n_sub)
+ * uint32 words of scratch.  ~0.1 ms for 0.9 M outputs where the one-workgroup form takes ~1 ms.                               */
+size_t mlhot_mt19937_jump_ws_words(int n_sub);
+int mlhot_mt19937_normal_par(uint32_t* engine, float* uniform_ws, float* out, const int64_t* segs, int nseg, int64_t total_outputs,
+                             int64_t total_groups, const uint32_t* polys, int n_sub, int stride_blocks, uint32_t* jump_ws, void* stream);
 
 /* ---- E1: vanilla image encoder `encoder_w0` -------------------------------------------
  * replaces nn.Sequential(conv3x3s2+ReLU, conv3x3s2+ReLU, MaxPool2d(2), conv3x3s2+ReLU,

@@ -1076,8 +1076,9 @@ def _ulps(a, b):
     return np.abs(ai - bi)
 
 
+@pytest.mark.parametrize("parallel", [64, 8, 1], ids=["jump_ahead_64_substreams", "jump_ahead_8_substreams", "one_workgroup"])
 @pytest.mark.parametrize("seed", [0, 99])
-def test_device_normal_continues_the_cpu_generator(gpulib, seed):
+def test_device_normal_continues_the_cpu_generator(gpulib, seed, parallel):
     """mlhot_mt19937_normal (mlhot.rng.DeviceNormal): the torch CPU generator's stream continued on the device.  Against the
     same `torch.empty(n).normal_()` calls on the CPU: 1.3 M draws across tensor sizes that are / are not multiples of 16 (16, 33,
     100, odd, the c5 model's conv shapes), from a mid-block engine position, two consecutive steps; every normal within 6 ulp of
@@ -1091,7 +1092,8 @@ def test_device_normal_continues_the_cpu_generator(gpulib, seed):
     ref = [[torch.empty(n).normal_(0, 1) for n in sizes] for _ in range(2)]
     after_ref = torch.rand(7)
     torch.set_rng_state(s0)
-    dn = DeviceNormal(DEV, sizes)
+    dn = DeviceNormal(DEV, sizes, sub_streams=parallel)   # K MT19937 sub-streams positioned by jump-ahead polynomials (mlhot/mt_jump.py)
+    assert (dn._polys is not None) == (parallel > 1)
     dn.take_over()
     worst = 0
     for step in range(2):

@@ -175,3 +175,30 @@ def test_strict_sharded_parity_option_installs_the_exchange_and_refuses_graph_st
             mk(strict_sharded_parity=True, graph_steps=True)
     finally:
         ops.set_stabiliser_exchange(None)
+
+
+def test_mt19937_jump_ahead_polynomials_against_brute_force():
+    """mlhot/mt_jump.py (host side of the parallel device eps stream): Berlekamp-Massey recovers MT19937's characteristic polynomial
+    (degree 19937, 135 terms), and the jump polynomials t^(624 S k) mod phi, applied to the raw output window as the device kernel
+    applies them, reproduce the block the generator holds S k regenerations later - against plain regeneration (oracle/mt_normal.py,
+    itself pinned to torch's generator)."""
+    import numpy as np
+    from mlhot import mt_jump as J
+    from oracle import mt_normal as MT
+    phi = J.char_poly()
+    assert phi.bit_length() - 1 == 19937 and bin(phi).count("1") == 135
+    S = 3
+    polys = J.jump_polys(S, 5)
+    rng = np.random.RandomState(3)
+    st = rng.randint(0, 2 ** 32, size=624, dtype=np.uint64).astype(np.uint32)
+    blocks = [st]
+    for _ in range(34):
+        blocks.append(MT.next_state(blocks[-1]))
+    window = np.concatenate(blocks[:34])[:J.DEG + J.N]
+    for k in range(1, 6):
+        got, want = J.apply_poly(polys[k - 1], window), blocks[S * k]
+        assert np.array_equal(got[1:], want[1:]) and (got[0] >> 31) == (want[0] >> 31), k
+    # the regeneration of a jumped block does not depend on the undefined low bits of its word 0
+    a = blocks[S * 2].copy()
+    a[0] ^= np.uint32(0x7fffffff)
+    assert np.array_equal(MT.next_state(a), blocks[S * 2 + 1])

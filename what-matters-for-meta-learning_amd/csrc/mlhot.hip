@@ -373,6 +373,51 @@ int mlhot_nt_xent_bwd(const float* z, int N, int d, int div, int mod, float t, c
 }
 
 // ---- torch's CPU normal_() stream on the device (csrc/mt_normal.h) ----------------------------------------------------
+size_t mlhot_mt19937_jump_ws_words(int n_sub) {
+  return n_sub < 1 ? 0 : (size_t)33 * 624 + 8 + (size_t)(n_sub - 1) * 8 * 624;
+}
+int mlhot_mt19937_normal_par(uint32_t* engine, float* uniform_ws, float* out, const int64_t* segs, int nseg, int64_t total_outputs,
+                             int64_t total_groups, const uint32_t* polys, int n_sub, int stride_blocks, uint32_t* jump_ws, void* stream) {
+  if (!engine || !uniform_ws || !out || !segs || nseg <= 0 || total_outputs <= 0 || total_groups <= 0 || !polys || n_sub < 2 || n_sub > 1024 ||
+      stride_blocks < 1 || !jump_ws) {
+    set_error("mt19937_normal_par: bad argument");
+    return MLHOT_ERR_ARG;
+  }
+  if ((int64_t)n_sub * stride_blocks * 624 < total_outputs) {      // every output of new blocks must belong to a sub-stream (conservative: ignores the current block's rest)
+    set_error("mt19937_normal_par: %d sub-streams of %d blocks do not cover %lld outputs", n_sub, stride_blocks, (long long)total_outputs);
+    return MLHOT_ERR_ARG;
+  }
+#ifndef MLHOT_HOSTSIM
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* x = jump_ws;
+  uint32_t* partial = jump_ws + (size_t)mt::JWIN + 8;      // 8 words behind the window: the engine's (left, next) as the draw found them
+  {
+    ProfScope ps("eps.mt19937.window", s);
+    hipLaunchKernelGGL(mt::mt_window_kernel, dim3(1), dim3(256), 0, s, engine, x);
+  }
+  MLHOT_TRY(check_launch("mt19937_normal_par (window)"));
+  {
+    ProfScope ps("eps.mt19937.jump", s);
+    hipLaunchKernelGGL(mt::mt_jump_kernel, dim3(n_sub - 1, mt::JPARTS), dim3(256), 0, s, x, polys, partial);
+  }
+  MLHOT_TRY(check_launch("mt19937_normal_par (jump)"));
+  {
+    ProfScope ps("eps.mt19937.chunks", s);
+    hipLaunchKernelGGL(mt::mt_chunk_kernel, dim3(n_sub), dim3(256), 0, s, engine, x, partial, uniform_ws, (long long)total_outputs, stride_blocks);
+  }
+  MLHOT_TRY(check_launch("mt19937_normal_par (chunks)"));
+  {
+    ProfScope ps("eps.box_muller", s);
+    const long long pairs = (long long)total_groups * 8;
+    hipLaunchKernelGGL(mt::mt_box_muller_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, uniform_ws, out,
+                       reinterpret_cast<const mt::Seg*>(segs), nseg, (long long)total_groups);
+  }
+  return check_launch("mt19937_normal_par (transform)");
+#else
+  (void)stream; set_error("mt19937_normal_par: GPU build only"); return MLHOT_ERR_ARG;
+#endif
+}
+
 int mlhot_mt19937_normal(uint32_t* engine, float* uniform_ws, float* out, const int64_t* segs, int nseg, int64_t total_outputs,
                          int64_t total_groups, void* stream) {
   if (!engine || !uniform_ws || !out || !segs || nseg <= 0 || total_outputs <= 0 || total_groups <= 0) {

@@ -66,6 +66,120 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(unsigned* __restrict__ eng
   if (tid == 0) { engine[N] = (unsigned)left; engine[N + 1] = (unsigned)next; }
 }
 
+// ---- the same stream from K sub-streams (jump-ahead; host side: mlhot/mt_jump.py) ----------------------------------------
+// The recurrence is linear over GF(2): with g^(k) = t^(624 S k) mod phi (phi: MT19937's characteristic polynomial, degree 19937)
+// the block the engine will hold S k regenerations from now is  B_{Sk}[n] = XOR over { i : g^(k)_i = 1 } of x[n + i],  x = the
+// raw words from the current block on (x[0..623] = the current block).  Three launches instead of one workgroup's ~1 ms:
+//   mt_window_kernel (1 workgroup): x[0 .. 33 * 624): the current block and its next 32 regenerations (19937 + 624 words needed);
+//   mt_jump_kernel   (K - 1 sub-streams x 8 parts): part p XORs the windows of the polynomial's bits [2496 p, 2496 p + 2496)
+//                    out of an LDS copy of x[2496 p .. 2496 p + 3120) - 624 x ~1250 word XORs per workgroup;
+//   mt_chunk_kernel  (K workgroups): sub-stream k folds its 8 partial blocks (k = 0: the engine's own block), regenerates its S
+//                    blocks, tempers and writes their uniforms at their stream positions; the workgroup that makes the LAST block
+//                    leaves (state, left, next) where the sequential stream would.
+// The low 31 bits of a jumped block's word 0 are not defined by the recurrence (they are not part of MT19937's state); the
+// regeneration reads only that word's top bit and a jumped block itself is never output - it was output by the sub-stream before.
+// Measured (c5, 896 k outputs per draw, MI355X): 64 sub-streams 0.99 -> 0.16-0.20 ms per draw (window 20 + jump 99 + chunks 21 + Box-
+// Muller 16 us), 8 sub-streams 0.26 ms.  BUT the draw of step k + 1 runs beside step k's kernels, and there the one-workgroup
+// form is the cheapest for the step: 1.520 ms per c5 step against 1.54 (4 sub-streams) / 1.58 (8) / 1.60 (64) - what counts is the
+// CU time taken from the trunk kernels, not the draw's latency.  mlhot.rng.DeviceNormal therefore keeps ONE workgroup by default
+// and uses the sub-streams on request (MLHOT_MT_SUBSTREAMS / sub_streams=): for steps shorter than the sequential draw.
+constexpr int DEG = 19937, JBLK = 33, JWIN = JBLK * N, JPARTS = 8, JPW = N / JPARTS, JSPAN = 32 * JPW + N;    // 20592 words; 78 words = 2496 bits per part; 3120
+static_assert(JWIN >= DEG + N && JPARTS * JPW == N && (JPARTS - 1) * 32 * JPW + JSPAN == JWIN, "jump window");
+
+__device__ __forceinline__ void mt_regen(unsigned*& cur, unsigned*& nxt, int tid) {      // one block regeneration; ends in a barrier
+  if (tid < N - M) nxt[tid] = cur[tid + M] ^ twist(cur[tid], cur[tid + 1]);
+  __syncthreads();
+  if (tid < N - M) nxt[tid + N - M] = nxt[tid] ^ twist(cur[tid + N - M], cur[tid + N - M + 1]);
+  __syncthreads();
+  if (tid < 2 * M - N - 1) nxt[tid + 2 * (N - M)] = nxt[tid + N - M] ^ twist(cur[tid + 2 * (N - M)], cur[tid + 2 * (N - M) + 1]);
+  if (tid == 255) nxt[N - 1] = nxt[M - 1] ^ twist(cur[N - 1], nxt[0]);
+  __syncthreads();
+  unsigned* t = cur; cur = nxt; nxt = t;
+}
+
+__global__ __launch_bounds__(256) void mt_window_kernel(const unsigned* __restrict__ engine, unsigned* __restrict__ x) {
+  __shared__ unsigned sa[N], sb[N];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N; i += 256) { sa[i] = engine[i]; x[i] = sa[i]; }
+  if (tid < 2) x[JWIN + tid] = engine[N + tid];       // (left, next) as they were: the chunk kernel's last workgroup rewrites the engine while others may still start
+  unsigned* cur = sa;
+  unsigned* nxt = sb;
+  __syncthreads();
+  for (int b = 1; b < JBLK; ++b) {
+    mt_regen(cur, nxt, tid);
+    for (int i = tid; i < N; i += 256) x[b * N + i] = cur[i];
+  }
+}
+
+// grid (K - 1, JPARTS): partial[(k - 1) * JPARTS + part][624]
+__global__ __launch_bounds__(256) void mt_jump_kernel(const unsigned* __restrict__ x, const unsigned* __restrict__ polys, unsigned* __restrict__ partial) {
+  __shared__ unsigned xs[JSPAN];
+  const int tid = threadIdx.x, k1 = blockIdx.x, part = blockIdx.y;
+  for (int i = tid; i < JSPAN; i += 256) xs[i] = x[part * 32 * JPW + i];
+  __syncthreads();
+  const unsigned* g = polys + (size_t)k1 * N + part * JPW;
+  const bool has2 = tid + 512 < N;
+  unsigned a0 = 0u, a1 = 0u, a2 = 0u;
+  // a loop over the SET bits (half the reads of a branch-free walk over all 32 positions, which measured 131 us against this
+  // loop's 91-99 us per workgroup: the LDS pipe, not the per-iteration round trip, is what both wait for)
+  for (int w = 0; w < JPW; ++w) {
+    unsigned gw = __builtin_amdgcn_readfirstlane(g[w]);          // the same word for every thread: the bit loop is scalar control flow
+    while (gw) {
+      const int i = 32 * w + __builtin_ctz(gw);
+      gw &= gw - 1;
+      a0 ^= xs[i + tid];
+      a1 ^= xs[i + tid + 256];
+      if (has2) a2 ^= xs[i + tid + 512];
+    }
+  }
+  unsigned* o = partial + ((size_t)k1 * JPARTS + part) * N;
+  o[tid] = a0; o[tid + 256] = a1;
+  if (has2) o[tid + 512] = a2;
+}
+
+// grid K: sub-stream k makes blocks k S + 1 .. (k + 1) S of the nb new blocks this draw needs (block j's words are outputs
+// r + 624 (j - 1) ..., r = the usable rest of the engine's current block, written by sub-stream 0)
+__global__ __launch_bounds__(256) void mt_chunk_kernel(unsigned* __restrict__ engine, const unsigned* __restrict__ x, const unsigned* __restrict__ partial,
+                                                       float* __restrict__ u, long long total, int S) {
+  __shared__ unsigned sa[N], sb[N];
+  const int tid = threadIdx.x, k = blockIdx.x;
+  const int left0 = (int)x[JWIN], next0 = (int)x[JWIN + 1];      // the window kernel's copy: `engine` is rewritten by the workgroup of the last block
+  const int r = left0 > 1 ? left0 - 1 : 0;                       // usable words of the current block (mt_fill_kernel's `take`)
+  const long long fresh = total - r;                             // outputs that come out of new blocks
+  const long long nb = fresh > 0 ? (fresh + N - 1) / N : 0;
+  for (int i = tid; i < N; i += 256) {
+    unsigned v;
+    if (k == 0) v = x[i];
+    else {
+      const unsigned* p = partial + (size_t)(k - 1) * JPARTS * N + i;
+      v = p[0] ^ p[N] ^ p[2 * N] ^ p[3 * N] ^ p[4 * N] ^ p[5 * N] ^ p[6 * N] ^ p[7 * N];
+    }
+    sa[i] = v;
+  }
+  unsigned* cur = sa;
+  unsigned* nxt = sb;
+  __syncthreads();
+  if (k == 0) {
+    const int take = total < (long long)r ? (int)total : r;
+    for (int i = tid; i < take; i += 256) u[i] = (float)(temper(cur[next0 + i]) & 0xffffffu) * (1.0f / 16777216.0f);
+    if (nb == 0 && tid == 0) { engine[N] = (unsigned)(left0 - take); engine[N + 1] = (unsigned)(next0 + take); }    // the draw ends inside the current block
+  }
+  for (int b = 1; b <= S; ++b) {
+    const long long j = (long long)k * S + b;                    // 1-based index of the new block
+    if (j > nb) break;                                           // uniform over the workgroup
+    mt_regen(cur, nxt, tid);
+    const long long pos = (long long)r + (j - 1) * N;
+    const long long room = total - pos;
+    const int take = room < (long long)N ? (int)room : N;
+    for (int i = tid; i < take; i += 256) u[pos + i] = (float)(temper(cur[i]) & 0xffffffu) * (1.0f / 16777216.0f);
+    if (j == nb) {                                               // the stream's last block: hand the engine on
+      __syncthreads();
+      for (int i = tid; i < N; i += 256) engine[i] = cur[i];
+      if (tid == 0) { engine[N] = (unsigned)(N + 1 - take); engine[N + 1] = (unsigned)take; }
+    }
+  }
+}
+
 // one thread per (group of 16, j < 8)
 __global__ __launch_bounds__(256) void mt_box_muller_kernel(const float* __restrict__ u, float* __restrict__ out, const Seg* __restrict__ segs,
                                                             int nseg, long long total_groups) {

@@ -495,6 +495,27 @@ class MlhotLib:
         self._rc(self.c.mlhot_mt19937_normal(_ptr(engine), _ptr(uniform_ws), _ptr(out), _ptr(segs), nseg, total_outputs, total_groups,
                                              _stream(out)), "mlhot_mt19937_normal")
 
+    def mt19937_normal_par(self, engine, uniform_ws, out, segs, nseg, total_outputs, total_groups, polys, n_sub, stride_blocks, jump_ws):
+        """The same draw from n_sub jump-ahead sub-streams (polys: int32 [n_sub - 1, 624] device tensor from mlhot.mt_jump)."""
+        if not (engine.is_cuda and uniform_ws.is_cuda and out.is_cuda and segs.is_cuda and polys.is_cuda and jump_ws.is_cuda):
+            raise MlhotError("mlhot_mt19937_normal_par: device tensors only")
+        if engine.dtype != torch.int32 or engine.numel() != 626 or segs.dtype != torch.int64 or out.dtype != torch.float32 or \
+                polys.dtype != torch.int32 or tuple(polys.shape) != (n_sub - 1, 624) or jump_ws.dtype != torch.int32:
+            raise MlhotError("mlhot_mt19937_normal_par: engine int32[626], segs int64[nseg, 4], out float32, polys int32[n_sub - 1, 624]")
+        self.c.mlhot_mt19937_jump_ws_words.restype = C.c_size_t
+        self.c.mlhot_mt19937_jump_ws_words.argtypes = [C.c_int]
+        if jump_ws.numel() < self.c.mlhot_mt19937_jump_ws_words(n_sub):
+            raise MlhotError("mlhot_mt19937_normal_par: jump workspace too small")
+        self.c.mlhot_mt19937_normal_par.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self._rc(self.c.mlhot_mt19937_normal_par(_ptr(engine), _ptr(uniform_ws), _ptr(out), _ptr(segs), nseg, total_outputs, total_groups,
+                                                 _ptr(polys), n_sub, stride_blocks, _ptr(jump_ws), _stream(out)), "mlhot_mt19937_normal_par")
+
+    def mt19937_jump_ws_words(self, n_sub):
+        self.c.mlhot_mt19937_jump_ws_words.restype = C.c_size_t
+        self.c.mlhot_mt19937_jump_ws_words.argtypes = [C.c_int]
+        return int(self.c.mlhot_mt19937_jump_ws_words(n_sub))
+
     # ---- whole ResNet trunks -------------------------------------------------------------------
     @staticmethod
     def trunk_supported(C_, H):

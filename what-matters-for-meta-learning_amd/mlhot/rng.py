@@ -12,6 +12,8 @@ Between take_over() and hand_back() the torch CPU generator must not be used: th
 the engine state are bit-identical to what the CPU calls would have produced; the normals agree up to the last ulps of the
 device's logf / sincosf against ATen's Sleef (tests: <= 8 ulp over 1 M draws).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -40,10 +42,18 @@ def _pack(rng_state, engine):
 
 
 class DeviceNormal:
-    def __init__(self, device, sizes):
+    """`sub_streams`: K >= 2 draws from K parallel MT19937 sub-streams positioned by jump-ahead polynomials (mlhot/mt_jump.py;
+    identical uniforms / normals / final state; ~1.6 s of host arithmetic per table, cached per process); 1 = ONE workgroup
+    walking the recurrence.  Default: MLHOT_MT_SUBSTREAMS or 1.  The draw of step k + 1 runs beside step k's kernels, so what it
+    costs the step is the CU time it takes from them, not its latency - measured on c5 (896 k outputs per draw): one workgroup
+    0.99 ms of draw, 1.520 ms per step; 4 / 8 / 64 sub-streams 0.42 / 0.26 / 0.16-0.20 ms of draw, 1.54 / 1.58 / 1.60 ms per step.
+    The sub-streams are for steps shorter than the sequential draw."""
+
+    def __init__(self, device, sizes, sub_streams=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("DeviceNormal needs a ROCm device (the CPU route is torch's own normal_())")
+        n_sub = int(os.environ.get("MLHOT_MT_SUBSTREAMS", "1")) if sub_streams is None else int(sub_streams)
         sizes = [int(n) for n in sizes]
         if not sizes or min(sizes) < 16:
             raise ValueError("every draw needs >= 16 elements (smaller tensors take torch's scalar double-precision path)")
@@ -59,6 +69,15 @@ class DeviceNormal:
         self._segs = torch.tensor(segs, dtype=torch.int64).to(self.device)
         self._uniform = torch.empty(src, device=self.device)
         self._engine = None
+        # jump-ahead plan: K sub-streams of `stride` blocks each cover the draw whatever the engine's position inside its block
+        self._polys = self._jump_ws = None
+        if n_sub >= 2 and src >= n_sub * _N * 4:
+            from . import mt_jump
+            self._n_sub = n_sub
+            self._stride = -(-(src // _N + 1) // self._n_sub)            # ceil((blocks + 1) / K)
+            polys = mt_jump.jump_polys(self._stride, self._n_sub - 1)      # ~3 s of host arithmetic, once per (stride) and process
+            self._polys = torch.from_numpy(polys.view(np.int32).copy()).to(self.device)
+            self._jump_ws = torch.empty(lib().mt19937_jump_ws_words(self._n_sub), dtype=torch.int32, device=self.device)
 
     def take_over(self, generator=None):
         """The (default) CPU generator's engine moves to the device."""
@@ -71,7 +90,11 @@ class DeviceNormal:
         if self._engine is None:
             raise RuntimeError("DeviceNormal.draw(): call take_over() first")
         out = out if out is not None else torch.empty(self.total, device=self.device)
-        lib().mt19937_normal(self._engine, self._uniform, out, self._segs, len(self.sizes), self.total_outputs, self.total_groups)
+        if self._polys is not None:
+            lib().mt19937_normal_par(self._engine, self._uniform, out, self._segs, len(self.sizes), self.total_outputs, self.total_groups,
+                                     self._polys, self._n_sub, self._stride, self._jump_ws)
+        else:
+            lib().mt19937_normal(self._engine, self._uniform, out, self._segs, len(self.sizes), self.total_outputs, self.total_groups)
         return out
 
     def views(self, flat, shapes):
