@@ -45,6 +45,8 @@ struct TrunkScratch {
   float* idn[MLHOT_TRUNK_MAX_PASS];               // forward: skip-path output of the current block
   float* G[MLHOT_TRUNK_MAX_PASS][5];              // backward: masked gradient wrt a0 / y_1..y_4
   float* DM[MLHOT_TRUNK_MAX_PASS];                // backward: masked gradient wrt mid_i of the current block
+  float* idn4[MLHOT_TRUNK_MAX_PASS];              // fused blocks 3-4, forward: block 4's skip-path output (idn = block 3's)
+  float* DM34[MLHOT_TRUNK_MAX_PASS][2];           // fused blocks 3-4, backward: masked gradients wrt mid_3, mid_4 (both outlive the fused launch)
   float* slab[MLHOT_TRUNK_MAX_WSET][NCONV]; float* slab_b[MLHOT_TRUNK_MAX_WSET][NCONV]; int rows[MLHOT_TRUNK_MAX_WSET][NCONV];
   bool ok; size_t bytes;
 };
@@ -93,9 +95,10 @@ inline TrunkScratch trunk_carve(const mlhot_trunk_pass* ps, int n_pass, const ml
     for (int c = 1; c < NCONV; ++c) s.wimg[w][c] = a.take<float>((c % 3 == 0 && ws[w].skip_k == 1) ? rw::WIMG1 : rw::WIMG);
   }
   for (int p = 0; p < n_pass; ++p) {
-    if (!backward) { s.idn[p] = a.take<float>(act_floats(lv, ps[p].n_img, 2)); continue; }
+    if (!backward) { s.idn[p] = a.take<float>(act_floats(lv, ps[p].n_img, 2)); s.idn4[p] = a.take<float>(act_floats(lv, ps[p].n_img, 8)); continue; }
     for (int l = 0; l < 5; ++l) s.G[p][l] = a.take<float>(act_floats(lv, ps[p].n_img, 2 * l));
     s.DM[p] = a.take<float>(act_floats(lv, ps[p].n_img, 1));
+    s.DM34[p][0] = a.take<float>(act_floats(lv, ps[p].n_img, 5)); s.DM34[p][1] = a.take<float>(act_floats(lv, ps[p].n_img, 7));
   }
   if (backward) {
     // slab rows per (weight set, conv): the sum over the passes that use the set
@@ -117,6 +120,10 @@ inline TrunkScratch trunk_carve(const mlhot_trunk_pass* ps, int n_pass, const ml
   s.ok = a.ok; s.bytes = a.off + 256;
   return s;
 }
+
+// Blocks 3 and 4 as one launch per direction (rw::tail34_*): 64 x 64 trunks (8 x 8 -> 4 x 4 -> 2 x 2 maps), "trunk_fuse34" option
+extern int g_trunk_fuse34;
+inline bool fuse34(const Levels& lv) { return g_trunk_fuse34 && lv.L[2] == 8; }
 
 inline int trunk_check(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk_wset* ws, int n_wset, int C, int H) {
   if (!ps || !ws || n_pass < 1 || n_pass > MLHOT_TRUNK_MAX_PASS || n_wset < 1 || n_wset > MLHOT_TRUNK_MAX_WSET) { set_error("resnet trunk: bad pass / weight-set count"); return MLHOT_ERR_ARG; }
@@ -171,7 +178,8 @@ inline int trunk_forward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tru
     for (int p = 0; p < n_pass; ++p) jobs.j[jobs.n++] = rw::StemJob{ps[p].img, sc.wimg[ps[p].wset][0], ws[ps[p].wset].b[0], ps[p].act[0], ps[p].n_img, 0, 0};
     MLHOT_TRY(rw::stem_dispatch(C, H, jobs, s, "trunk.stem"));
   }
-  for (int b = 1; b <= 4; ++b) {
+  const bool fused = fuse34(lv);
+  for (int b = 1; b <= (fused ? 2 : 4); ++b) {
     const int c1 = 3 * b - 2, c2 = c1 + 1, sk = c1 + 2;
     // stage A: conv1 (+ReLU) and the skip convolution, both on the block input - ONE launch for every pass: a 3x3 skip is a
     // second job on the same input, a 1x1 skip rides in its conv1 job (centre-tap operand)
@@ -208,6 +216,21 @@ inline int trunk_forward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tru
       jobs.j[jobs.n++] = rw::FwdJob{ps[p].act[2 * b - 1], sc.wimg[ps[p].wset][c2], ws[ps[p].wset].b[c2], ps[p].act[2 * b], sc.idn[p], nullptr, nullptr, nullptr,
                                     ps[p].n_img, rw::EPI_BIAS_RES_RELU, 0, 0, 0};
     MLHOT_TRY(rw::conv3x3_dispatch(lv.L[b], 1, false, jobs, s, LBL_CONV2[b]));
+  }
+  if (fused) {
+    rw::T34Jobs jobs{};
+    for (int p = 0; p < n_pass; ++p) {
+      const int wi = ps[p].wset;
+      const mlhot_trunk_wset& w = ws[wi];
+      rw::T34Pass& t = jobs.p[jobs.n++];
+      t = rw::T34Pass{};
+      t.x = ps[p].act[4]; t.mid3 = ps[p].act[5]; t.y3 = ps[p].act[6]; t.mid4 = ps[p].act[7]; t.y4 = ps[p].act[8];
+      t.idn3 = sc.idn[p]; t.idn4 = sc.idn4[p];
+      const int order[6] = {7, 8, 9, 10, 11, 12};        // c1_3, c2_3, sk_3, c1_4, c2_4, sk_4
+      for (int i = 0; i < 6; ++i) { t.wimg[i] = sc.wimg[wi][order[i]]; t.b[i] = w.b[order[i]]; }
+      t.n_img = ps[p].n_img; t.skip1 = w.skip_k == 1;
+    }
+    MLHOT_TRY(rw::tail34_launch(jobs, false, s, "trunk.fwd.b34"));
   }
   return MLHOT_OK;
 }
@@ -247,12 +270,31 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
       next_row[w][conv] += nz;
     }
   };
+  const bool fused = fuse34(lv);
+  if (fused) {      // every data gradient of blocks 4 and 3 in one launch; their weight gradients follow in the loop below
+    rw::T34Jobs jobs{};
+    for (int p = 0; p < n_pass; ++p) {
+      const int wi = ps[p].wset;
+      rw::T34Pass& t = jobs.p[jobs.n++];
+      t = rw::T34Pass{};
+      t.x = ps[p].act[4]; t.mid3 = ps[p].act[5]; t.y3 = ps[p].act[6]; t.mid4 = ps[p].act[7]; t.y4 = ps[p].act[8];
+      const int order[6] = {7, 8, 9, 10, 11, 12};
+      for (int i = 0; i < 6; ++i) t.wimg[i] = sc.wimg[wi][order[i]];
+      t.g4 = sc.G[p][4]; t.dm4 = sc.DM34[p][1]; t.g3 = sc.G[p][3]; t.dm3 = sc.DM34[p][0]; t.g2 = sc.G[p][2];
+      t.n_img = ps[p].n_img; t.skip1 = ws[wi].skip_k == 1;
+    }
+    MLHOT_TRY(rw::tail34_launch(jobs, true, s, "trunk.bwd.b34.dgrad"));
+  }
   rw::Sk1Jobs sk1{};
   for (int b = 4; b >= 1; --b) {
     const int c1 = 3 * b - 2, c2 = c1 + 1, sk = c1 + 2;
+    const bool in_fused = fused && b >= 3;
     const float *xin[MLHOT_TRUNK_MAX_PASS], *mid[MLHOT_TRUNK_MAX_PASS], *g[MLHOT_TRUNK_MAX_PASS], *dm[MLHOT_TRUNK_MAX_PASS];
-    for (int p = 0; p < n_pass; ++p) { xin[p] = ps[p].act[2 * b - 2]; mid[p] = ps[p].act[2 * b - 1]; g[p] = sc.G[p][b]; dm[p] = sc.DM[p]; }
-    {   // conv2 data gradient: d_mid = conv^T(g, W2) * (mid > 0)
+    for (int p = 0; p < n_pass; ++p) {
+      xin[p] = ps[p].act[2 * b - 2]; mid[p] = ps[p].act[2 * b - 1]; g[p] = sc.G[p][b];
+      dm[p] = in_fused ? sc.DM34[p][b - 3] : sc.DM[p];
+    }
+    if (!in_fused) {   // conv2 data gradient: d_mid = conv^T(g, W2) * (mid > 0)
       rw::FwdJobs jobs{};
       for (int p = 0; p < n_pass; ++p)
         jobs.j[jobs.n++] = rw::FwdJob{g[p], sc.wimg[ps[p].wset][c2], nullptr, sc.DM[p], mid[p], nullptr, nullptr, nullptr, ps[p].n_img, rw::EPI_MASK, 1, 0, 0};
@@ -264,7 +306,7 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
       MLHOT_TRY(rw::wgrad_dispatch(lv.L[b], 1, false, jobs, s, LBL_C2_WGRAD[b]));
     }
     // data gradient into the block input (not needed for images: block 1's input is the stem output, whose gradient feeds the stem's wgrad)
-    {
+    if (!in_fused) {
       // launch 1: every first writer of dx - the 3x3 skips' data gradients and the 1x1-skip blocks' fused conv1 + skip gradient;
       // launch 2: the 3x3-skip blocks' conv1 gradient, added onto launch 1's result and masked
       rw::DgJobs ja{}, jb2{};

@@ -160,6 +160,7 @@ struct FwdJob {
   const float* w1img; const float* b1; float* y1;     // fused 1x1 stride-2 convolution of the same input (SKIP1 kernels)
   int n_img, epi, flip;        // flip: use tap 8 - t (transposed convolution)
   int wg0, nwg;                // workgroups [wg0, wg0 + nwg) of the launch belong to this job
+  int img_lo;                  // images below this index are treated as absent (zeros in, nothing out): the fused small-map kernels own image ranges
 };
 struct FwdJobs { FwdJob j[MAX_JOBS]; int n; };
 
@@ -167,7 +168,7 @@ struct FwdJobs { FwdJob j[MAX_JOBS]; int n; };
 // Stage one band's patch: HBM -> registers -> LDS in chunks of <= 10 vector loads per thread (a barrier in front: every wave is
 // done reading the previous band; one behind: the patch is complete).  Rows outside the map and images beyond n_img become zeros.
 template <class G>
-__device__ __forceinline__ void stage_patch(float* patch, const float* __restrict__ x, int img0, int oy0, int n_img, int tid) {
+__device__ __forceinline__ void stage_patch(float* patch, const float* __restrict__ x, int img0, int oy0, int n_img, int tid, int img_lo = 0) {
   typedef float stage_t __attribute__((ext_vector_type(G::SEGW)));
   constexpr int CH_ITEMS = 10;
   __syncthreads();
@@ -194,7 +195,7 @@ __device__ __forceinline__ void stage_patch(float* patch, const float* __restric
         stage_t v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = 0.f;
-        if (iy >= 0 && iy < G::HIN && img0 + il < n_img)
+        if (iy >= 0 && iy < G::HIN && img0 + il < n_img && img0 + il >= img_lo)
           v = *reinterpret_cast<const stage_t*>(gl + ((size_t)(img0 + il) * CH + ch * TCI) * (G::HIN * G::HIN) + iy * G::HIN);
         st[jj] = v;
       }
@@ -224,7 +225,7 @@ __device__ __forceinline__ void stage_patch(float* patch, const float* __restric
       stage_t v;
 #pragma unroll
       for (int q = 0; q < G::SEGW; ++q) v[q] = 0.f;
-      if (e < G::ITEMS && iy >= 0 && iy < G::HIN && img0 + il < n_img)
+      if (e < G::ITEMS && iy >= 0 && iy < G::HIN && img0 + il < n_img && img0 + il >= img_lo)
         v = *reinterpret_cast<const stage_t*>(x + (((size_t)(img0 + il) * CH + ci) * G::HIN + iy) * G::HIN + G::SEGW * seg);
       st[jj] = v;
     }
@@ -244,14 +245,13 @@ __device__ __forceinline__ void stage_patch(float* patch, const float* __restric
   __syncthreads();
 }
 
+// The body of a forward-type launch: bands band0, band0 + band_step, ... < band_end of job `jb`, the patch in `patch` (G::PATCH floats
+// of LDS).  conv3x3_kernel runs it over its share of a job's bands; the fused small-map kernels (tail34_*) call it once per
+// convolution on the bands of the workgroup's own image group.
 template <class G, bool SKIP1>
-__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
-  __shared__ float patch[G::PATCH];
+__device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int band0, int band_end, int band_step) {
   const int tid = threadIdx.x, lane = tid & 63, nt = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
-  int ji = 0;
-  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
-  const FwdJob& jb = jobs.j[ji];
   const int co = 16 * nt + lr;
 
   RW_TS(0);
@@ -289,15 +289,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
     aoff[t] = lq * G::PS + o;
   }
 
-  const int nbands = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
+  const int nbands_all = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
+  const int nbands = band_end < nbands_all ? band_end : nbands_all;
   RW_TS(1);
   int ts_k = 0;
 #pragma unroll 1
-  for (int band = (int)blockIdx.x - jb.wg0; band < nbands; band += jb.nwg) {
+  for (int band = band0; band < nbands; band += band_step) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
     const int oy0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
     RW_TS(2 + 4 * ts_k);
-    stage_patch<G>(patch, jb.x, img0, oy0, jb.n_img, tid);
+    stage_patch<G>(patch, jb.x, img0, oy0, jb.n_img, tid, jb.img_lo);
     RW_TS(3 + 4 * ts_k);
 
     // ---- 144 k-steps x NACC tiles ----
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
         for (int q = 0; q < 4; ++q)
           if (lq == q) { il = G::tile_il(t, 4 * q + v); oy = G::tile_oy(t, 4 * q + v); ox = G::tile_ox(t, 4 * q + v); }
         const int img = img0 + il;
-        live[t][vi] = img < jb.n_img;
+        live[t][vi] = img < jb.n_img && img >= jb.img_lo;
         offs[t][vi] = (((unsigned)(live[t][vi] ? img : 0) * CH + co) * G::HO + oy0 + oy) * G::WO + ox;
 #pragma unroll
         for (int q = 0; q < VW; ++q) ax[t][vi][q] = 0.f;
@@ -403,6 +404,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
     ts_k = ts_k < 3 ? ts_k + 1 : 3;
   }
   RW_TS(20);
+}
+
+template <class G, bool SKIP1>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
+  __shared__ float patch[G::PATCH];
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const FwdJob& jb = jobs.j[ji];
+  conv3x3_body<G, SKIP1>(jb, patch, (int)blockIdx.x - jb.wg0, 1 << 30, jb.nwg);
 }
 
 // Workgroup shares of the jobs of one launch: proportional to their band counts, at least one each, WG_SLOTS in all at most.
@@ -466,19 +476,16 @@ struct DgJob {
   const float* xact;           // when set: dx *= (xact > 0)   (the ReLU that produced the convolution's input)
   const float* g1; const float* w1img;      // SKIP1: dy and D image of the 1x1 stride-2 convolution on the same input
   int n_img, accumulate, wg0, nwg;
+  int img_lo;                  // as FwdJob::img_lo
 };
 struct DgJobs { DgJob j[MAX_JOBS]; int n; };
 
 template <class G, bool SKIP1>
-__global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
+__device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch, int band0, int band_end, int band_step) {
   static_assert(G::KIND == 1 && (G::TC >= 4 || G::PI < 16), "epilogue needs 4 consecutive grid columns per lane (or whole 2x2 maps)");
-  __shared__ float patch[G::PATCH * (SKIP1 ? 2 : 1)];
   float* patch1 = patch + G::PATCH;
   const int tid = threadIdx.x, lane = tid & 63, nt = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
-  int ji = 0;
-  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
-  const DgJob& jb = jobs.j[ji];
   const int ci = 16 * nt + lr;
   constexpr int NT = G::NACC, HX = 2 * G::HO;
 
@@ -505,13 +512,14 @@ __global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
     for (int m = 0; m < 16; ++m) o = (lr == m) ? G::posoff(t, m) : o;
     aoff[t] = lq * G::PS + o;
   }
-  const int nbands = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
+  const int nbands_all = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
+  const int nbands = band_end < nbands_all ? band_end : nbands_all;
 #pragma unroll 1
-  for (int band = (int)blockIdx.x - jb.wg0; band < nbands; band += jb.nwg) {
+  for (int band = band0; band < nbands; band += band_step) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
     const int a0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
-    stage_patch<G>(patch, jb.dy, img0, a0, jb.n_img, tid);
-    if (has1) stage_patch<G>(patch1, jb.g1, img0, a0, jb.n_img, tid);
+    stage_patch<G>(patch, jb.dy, img0, a0, jb.n_img, tid, jb.img_lo);
+    if (has1) stage_patch<G>(patch1, jb.g1, img0, a0, jb.n_img, tid, jb.img_lo);
 
     f32x4_t acc[4][NT];
 #pragma unroll
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
       for (int q = 0; q < 4; ++q)
         if (lq == q) { il = G::tile_il(t, 4 * q); a = G::tile_oy(t, 4 * q); b = G::tile_ox(t, 4 * q); }
       const int img = img0 + il;
-      if (img >= jb.n_img) continue;
+      if (img >= jb.n_img || img < jb.img_lo) continue;
 #pragma unroll
       for (int py = 0; py < 2; ++py) {
         if (G::PI >= 16) {
@@ -600,6 +608,15 @@ __global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
   }
 }
 
+template <class G, bool SKIP1>
+__global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
+  __shared__ float patch[G::PATCH * (SKIP1 ? 2 : 1)];
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const DgJob& jb = jobs.j[ji];
+  dgrad2_body<G, SKIP1>(jb, patch, (int)blockIdx.x - jb.wg0, 1 << 30, jb.nwg);
+}
+
 template <class G>
 inline int plan_dg(DgJobs& jobs) {
   int nb[MAX_JOBS], total = 0, wg = 0;
@@ -632,6 +649,135 @@ inline int dgrad2_dispatch(int HO, bool skip1, DgJobs& jobs, hipStream_t s, cons
   MLHOT_RW_CASE(32, D32) MLHOT_RW_CASE(16, D16) MLHOT_RW_CASE(8, D8) MLHOT_RW_CASE(4, D4) MLHOT_RW_CASE(2, D2)
 #undef MLHOT_RW_CASE
   return MLHOT_ERR_UNSUPPORTED;
+}
+
+// ---- blocks 3 and 4 of a 64 x 64 trunk (8 x 8 -> 4 x 4 -> 2 x 2 maps) in ONE launch per direction ---------------------------
+// These two blocks are < 1 % of a trunk's FLOPs and were 14 of its launches (c5: 195 us of a 1.52 ms step): every launch a
+// weight-image load per workgroup, 144-288 dependent MFMAs per wave, an epilogue and a launch boundary - 9-24 us each.  A
+// workgroup of the fused kernels owns FOUR images of one pass (their 2 x 2 maps fill one M-tile) and runs the same convolution
+// bodies one after the other on those images' bands, each stage's output going through global memory (L2) to the next stage
+// of the SAME workgroup: no cross-workgroup dependency, only __syncthreads() between stages (workgroup-scope release / acquire:
+// the stores of a stage are visible to the CU's own later loads).  Unlike the few-row Linear chains (mlp_chain.h) nothing is
+// lost: every per-layer launch reloaded a 147 KB weight image per workgroup as well.
+//   forward  : conv1.b3 (+ 1x1 skip fused | 3x3 skip as a second body) -> conv2.b3 + skip + ReLU -> the same for block 4
+//   backward : conv2^T.b4 (masked) -> stride-2 data gradients of block 4 (skip / conv1, join + mask) -> the same for block 3; the
+//              masked gradients every stage leaves (DM4, G3, DM3, G2) are what the weight-gradient launches read afterwards.
+struct T34Pass {
+  const float* x;                       // y2 [n][64][8][8]: the output of block 2
+  float *mid3, *y3, *mid4, *y4;         // forward: saved activations (outputs); backward: read
+  float *idn3, *idn4;                   // forward scratch: skip-path outputs [n][64][4][4], [n][64][2][2]
+  const float* wimg[6];                 // c1_3, c2_3, sk_3, c1_4, c2_4, sk_4: F images (forward) / D images (backward); sk: the 1x1 image when skip1
+  const float* b[6];                    // forward: biases
+  float *g4, *dm4, *g3, *dm3, *g2;      // backward: masked gradients wrt y4 (input), mid4, y3, mid3, y2 (outputs)
+  int n_img, skip1, wg0, nwg;
+};
+struct T34Jobs { T34Pass p[MAX_JOBS]; int n; };
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+#ifndef T34_GI
+#define T34_GI 1
+#endif
+constexpr int GI = T34_GI;        // images per workgroup: 1, 2 or 4.  The 2 x 2 maps of FOUR images fill an M-tile, so with fewer the block-4
+                                  // stages (and with one image block 3's stride-1 stages, two images per band) run their band with the other
+                                  // images masked out (img_lo / n_img of the job): wasted matrix rows, but a dependent chain of 1008 / 1296 MFMAs per
+                                  // wave instead of 2160 - these launches are latency-bound (measured, c5: forward 63 us with 4 images per workgroup)
+static_assert(GI == 1 || GI == 2 || GI == 4, "image group");
+
+__global__ __launch_bounds__(256, 2) void tail34_fwd_kernel(const T34Jobs jobs) {
+  __shared__ float patch[cmax(cmax(G8s2::PATCH, G4s1::PATCH), cmax(G4s2::PATCH, G2s1::PATCH))];
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.p[ji + 1].wg0) ++ji;
+  const T34Pass& P = jobs.p[ji];
+  const int g = (int)blockIdx.x - P.wg0, i0 = GI * g;       // image group: images i0 .. i0 + GI - 1
+  const int hi = i0 + GI < P.n_img ? i0 + GI : P.n_img;
+  const bool s1 = P.skip1 != 0;
+  // block 3, stage A: 8 x 8 -> 4 x 4, one image per band
+  {
+    const FwdJob a{P.x, P.wimg[0], P.b[0], P.mid3, nullptr, s1 ? P.wimg[2] : nullptr, s1 ? P.b[2] : nullptr, s1 ? P.idn3 : nullptr, hi, EPI_BIAS_RELU, 0, 0, 0, i0};
+    if (s1) conv3x3_body<G8s2, true>(a, patch, i0, i0 + GI, 1);
+    else {
+      conv3x3_body<G8s2, false>(a, patch, i0, i0 + GI, 1);
+      __syncthreads();
+      const FwdJob k{P.x, P.wimg[2], P.b[2], P.idn3, nullptr, nullptr, nullptr, nullptr, hi, EPI_BIAS, 0, 0, 0, i0};
+      conv3x3_body<G8s2, false>(k, patch, i0, i0 + GI, 1);
+    }
+  }
+  __syncthreads();
+  {   // block 3, stage B: 4 x 4 stride 1, two images per band
+    const FwdJob c{P.mid3, P.wimg[1], P.b[1], P.y3, P.idn3, nullptr, nullptr, nullptr, hi, EPI_BIAS_RES_RELU, 0, 0, 0, i0};
+    conv3x3_body<G4s1, false>(c, patch, i0 / 2, (i0 + GI + 1) / 2, 1);
+  }
+  __syncthreads();
+  {   // block 4, stage A: 4 x 4 -> 2 x 2, four images per band
+    const FwdJob a{P.y3, P.wimg[3], P.b[3], P.mid4, nullptr, s1 ? P.wimg[5] : nullptr, s1 ? P.b[5] : nullptr, s1 ? P.idn4 : nullptr, hi, EPI_BIAS_RELU, 0, 0, 0, i0};
+    if (s1) conv3x3_body<G4s2, true>(a, patch, i0 / 4, i0 / 4 + 1, 1);
+    else {
+      conv3x3_body<G4s2, false>(a, patch, i0 / 4, i0 / 4 + 1, 1);
+      __syncthreads();
+      const FwdJob k{P.y3, P.wimg[5], P.b[5], P.idn4, nullptr, nullptr, nullptr, nullptr, hi, EPI_BIAS, 0, 0, 0, i0};
+      conv3x3_body<G4s2, false>(k, patch, i0 / 4, i0 / 4 + 1, 1);
+    }
+  }
+  __syncthreads();
+  {   // block 4, stage B: 2 x 2 stride 1
+    const FwdJob c{P.mid4, P.wimg[4], P.b[4], P.y4, P.idn4, nullptr, nullptr, nullptr, hi, EPI_BIAS_RES_RELU, 0, 0, 0, i0};
+    conv3x3_body<G2s1, false>(c, patch, i0 / 4, i0 / 4 + 1, 1);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void tail34_bwd_kernel(const T34Jobs jobs) {
+  __shared__ float patch[cmax(cmax(G2s1::PATCH, G4s1::PATCH), 2 * cmax(D2::PATCH, D4::PATCH))];
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.p[ji + 1].wg0) ++ji;
+  const T34Pass& P = jobs.p[ji];
+  const int g = (int)blockIdx.x - P.wg0, i0 = GI * g;
+  const int hi = i0 + GI < P.n_img ? i0 + GI : P.n_img;
+  const bool s1 = P.skip1 != 0;
+  {   // block 4: d mid4 = conv2^T(g4) . (mid4 > 0)
+    const FwdJob c{P.g4, P.wimg[4], nullptr, P.dm4, P.mid4, nullptr, nullptr, nullptr, hi, EPI_MASK, 1, 0, 0, i0};
+    conv3x3_body<G2s1, false>(c, patch, i0 / 4, i0 / 4 + 1, 1);
+  }
+  __syncthreads();
+  // block 4: gradient wrt y3 = (conv1^T(dm4) + skip^T(g4)) . (y3 > 0); dy maps 2 x 2, four images per band
+  if (s1) {
+    const DgJob a{P.dm4, P.wimg[3], P.g3, P.y3, P.g4, P.wimg[5], hi, 0, 0, 0, i0};
+    dgrad2_body<D2, true>(a, patch, i0 / 4, i0 / 4 + 1, 1);
+  } else {
+    const DgJob a{P.g4, P.wimg[5], P.g3, nullptr, nullptr, nullptr, hi, 0, 0, 0, i0};
+    dgrad2_body<D2, false>(a, patch, i0 / 4, i0 / 4 + 1, 1);
+    __syncthreads();
+    const DgJob b2{P.dm4, P.wimg[3], P.g3, P.y3, nullptr, nullptr, hi, 1, 0, 0, i0};
+    dgrad2_body<D2, false>(b2, patch, i0 / 4, i0 / 4 + 1, 1);
+  }
+  __syncthreads();
+  {   // block 3: d mid3 = conv2^T(g3) . (mid3 > 0); 4 x 4 maps, two images per band
+    const FwdJob c{P.g3, P.wimg[1], nullptr, P.dm3, P.mid3, nullptr, nullptr, nullptr, hi, EPI_MASK, 1, 0, 0, i0};
+    conv3x3_body<G4s1, false>(c, patch, i0 / 2, (i0 + GI + 1) / 2, 1);
+  }
+  __syncthreads();
+  // block 3: gradient wrt y2; dy maps 4 x 4, one image per band
+  if (s1) {
+    const DgJob a{P.dm3, P.wimg[0], P.g2, P.x, P.g3, P.wimg[2], hi, 0, 0, 0, i0};
+    dgrad2_body<D4, true>(a, patch, i0, i0 + GI, 1);
+  } else {
+    const DgJob a{P.g3, P.wimg[2], P.g2, nullptr, nullptr, nullptr, hi, 0, 0, 0, i0};
+    dgrad2_body<D4, false>(a, patch, i0, i0 + GI, 1);
+    __syncthreads();
+    const DgJob b2{P.dm3, P.wimg[0], P.g2, P.x, nullptr, nullptr, hi, 1, 0, 0, i0};
+    dgrad2_body<D4, false>(b2, patch, i0, i0 + GI, 1);
+  }
+}
+
+inline int tail34_launch(T34Jobs& jobs, bool backward, hipStream_t s, const char* what) {
+  int wg = 0;
+  for (int i = 0; i < jobs.n; ++i) { jobs.p[i].wg0 = wg; jobs.p[i].nwg = (jobs.p[i].n_img + GI - 1) / GI; wg += jobs.p[i].nwg; }
+  if (wg == 0) return MLHOT_OK;
+  {
+    ProfScope ps(what, s);
+    if (backward) hipLaunchKernelGGL(tail34_bwd_kernel, dim3(wg), dim3(256), 0, s, jobs);
+    else hipLaunchKernelGGL(tail34_fwd_kernel, dim3(wg), dim3(256), 0, s, jobs);
+  }
+  return check_launch(what);
 }
 
 // ---- weight gradient of a 3x3 (pad 1, stride 1 / 2) convolution ------------------------------------------------------
