@@ -155,6 +155,9 @@ int mlhot_mlp_chain_bwd(const float* x0, int ldx0, int M, const mlhot_chain_laye
 typedef struct {
   const float* x; int ldx; const float* w; const float* b; float* y; int ldy; int M, K, N, act;
   const float* dy; int lddy; float* dx; int lddx, dx_accumulate; float* dw; float* db;      /* backward only */
+  /* two-source input (the reference's torch.cat([x, x2], -1) in front of the layer, folded): the LAST K2 of the layer's K input
+   * columns come from x2 (NULL: all K from x; K2 % 4 == 0); dx2 receives their gradient (NULL: not wanted; dx may then be NULL too) */
+  const float* x2; int ldx2, K2; float* dx2; int lddx2;
 } mlhot_linear_job;
 int mlhot_linear_multi_fwd(const mlhot_linear_job* jobs, int n_jobs, void* stream);
 int mlhot_linear_multi_bwd(const mlhot_linear_job* jobs, int n_jobs, void* stream);

@@ -48,6 +48,40 @@ def test_linear_asymmetric_identity(gpulib):
     assert torch.equal(y.cpu(), w.t())
 
 
+@pytest.mark.parametrize("M,Ka,Kb,N,act", [(120, 256, 4, 256, "relu"), (120, 256, 256, 256, "relu"), (7, 256, 16, 256, "none"), (240, 64, 16, 100, "tanh")])
+@pytest.mark.parametrize("grads", [(True, False), (True, True), (False, True)], ids=["dxa", "dxa_dxb", "dxb"])
+def test_two_source_linear_vs_autograd(gpulib, M, Ka, Kb, N, act, grads):
+    """Linear2Function: act(cat([xa, xb], -1) W^T + b) with the concatenation folded into the few-row Linear kernels (the reference's
+    torch.cat([x_ctx, labels]) -> task_encoder[0], ANP.py:113; torch.cat([x, sample_features]) -> fc_mu[0], models.py:182): output,
+    both input gradients (each optional), dW and db against torch autograd of the concatenated form."""
+    from mlhot.ops import Linear2Function, linear2_ok
+    g = torch.Generator().manual_seed(M + Ka + Kb)
+    xa, xb = torch.randn(2, M // 2 if M % 2 == 0 else M, Ka, generator=g)[:1 if M % 2 else 2], None
+    xa = torch.randn(M, Ka, generator=g)
+    xb = torch.randn(M, Kb, generator=g)
+    w, b = torch.randn(N, Ka + Kb, generator=g) * (Ka + Kb) ** -0.5, torch.randn(N, generator=g) * 0.1
+    dy = torch.randn(M, N, generator=g)
+    ar, br, wr, bbr = xa.clone().requires_grad_(grads[0]), xb.clone().requires_grad_(grads[1]), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.linear(torch.cat([ar, br], -1), wr, bbr)
+    yr = torch.relu(yr) if act == "relu" else torch.tanh(yr) if act == "tanh" else yr
+    yr.backward(dy)
+    ad, bd = xa.clone().to(DEV).requires_grad_(grads[0]), xb.clone().to(DEV).requires_grad_(grads[1])
+    wd, bbd = w.clone().to(DEV).requires_grad_(), b.clone().to(DEV).requires_grad_()
+    assert linear2_ok(ad, bd, wd)
+    y = Linear2Function.apply(ad, bd, wd, bbd, act)
+    y.backward(dy.to(DEV))
+    assert U.rel_err(y, yr) <= U.RTOL
+    assert U.rel_err(wd.grad, wr.grad) <= U.RTOL and U.rel_err(bbd.grad, bbr.grad) <= U.RTOL
+    if grads[0]:
+        assert U.rel_err(ad.grad, ar.grad) <= U.RTOL
+    else:
+        assert ad.grad is None
+    if grads[1]:
+        assert U.rel_err(bd.grad, br.grad) <= U.RTOL
+    else:
+        assert bd.grad is None
+
+
 def _chain_reference(x0, layers):
     """torch autograd restatement of a chain: layers = [(w, b, act, side | None, side_first)]."""
     h = x0

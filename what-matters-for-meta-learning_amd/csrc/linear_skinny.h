@@ -43,13 +43,19 @@ __device__ __forceinline__ bool fold4(f32x4_t (&acc)[2], float* red, int tid) {
 }
 
 // y[M][N] = act(x[M][K] w[N][K]^T + b): grid (ceil(M / 32), ceil(N / 16)), 256 threads
+// Two-source input (the reference's torch.cat in front of a layer, folded): columns [0, K1) of the layer's input come from x,
+// columns [K1, K) from x2 (K1 % 4 == 0; x2 = nullptr / K1 >= K: one source).  The same for the data gradient's destination
+// (dx | dx2) and the weight gradient's operand.
 __device__ __forceinline__ void fwd_body(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw, const float* __restrict__ b,
-                                         float* __restrict__ y, int ldy, int M, int K, int N, int act, float* red, int bx, int by) {
+                                         float* __restrict__ y, int ldy, int M, int K, int N, int act, float* red, int bx, int by,
+                                         const float* __restrict__ x2 = nullptr, int ldx2 = 0, int K1 = 1 << 30) {
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int m0 = bx * 32, n0 = by * 16;
   const int ra = m0 + lr, rb = m0 + 16 + lr, rn = n0 + lr;
   const float* xa = x + (size_t)(ra < M ? ra : 0) * ldx + 4 * lq;
   const float* xb = x + (size_t)(rb < M ? rb : 0) * ldx + 4 * lq;
+  const float* xa2 = x2 ? x2 + (size_t)(ra < M ? ra : 0) * ldx2 + 4 * lq - K1 : xa;      // second source, indexed by the layer's k as well
+  const float* xb2 = x2 ? x2 + (size_t)(rb < M ? rb : 0) * ldx2 + 4 * lq - K1 : xb;
   const float* wp = w + (size_t)(rn < N ? rn : 0) * ldw + 4 * lq;
   f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   // four 16-deep k chunks per trip: 12 independent float4 loads are in flight before the first MFMA needs one
@@ -58,8 +64,8 @@ __device__ __forceinline__ void fwd_body(const float* __restrict__ x, int ldx, c
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int k0 = kb + 64 * u;
-      const bool kin = k0 + 4 * lq < K;
-      a0[u] = ld4(xa + k0, kin && ra < M); a1[u] = ld4(xb + k0, kin && rb < M); bv[u] = ld4(wp + k0, kin && rn < N);
+      const bool kin = k0 + 4 * lq < K, first = k0 + 4 * lq < K1;
+      a0[u] = ld4((first ? xa : xa2) + k0, kin && ra < M); a1[u] = ld4((first ? xb : xb2) + k0, kin && rb < M); bv[u] = ld4(wp + k0, kin && rn < N);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -88,7 +94,8 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ x, i
 // dx[M][Kin] (+)= (dy * act'(y))[M][N] w[N][Kin]: out^T tile C[kin][m]; grid (ceil(M / 32), ceil(Kin / 16))
 __device__ __forceinline__ void dgrad_body(const float* __restrict__ dy, int lddy, const float* __restrict__ yv, int ldy, int act,
                                            const float* __restrict__ w, int ldw, float* __restrict__ dx, int lddx, int accumulate,
-                                           int M, int Kin, int N, float* red, int bx, int by) {
+                                           int M, int Kin, int N, float* red, int bx, int by,
+                                           float* __restrict__ dx2 = nullptr, int lddx2 = 0, int K1 = 1 << 30) {
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int m0 = bx * 32, c0 = by * 16;
   const int ra = m0 + lr, rb = m0 + 16 + lr, col = c0 + lr;
@@ -124,15 +131,17 @@ __device__ __forceinline__ void dgrad_body(const float* __restrict__ dy, int ldd
   if (!fold4(acc, red, tid)) return;
   const int t = tid >> 6, m = m0 + 16 * t + lr, c = c0 + 4 * lq;        // C[row = kin 4 lq + r][col = m lr]
   if (m >= M || c >= Kin) return;
-  float* d = dx + (size_t)m * lddx + c;
-  if (c + 3 < Kin && ((reinterpret_cast<uintptr_t>(d) & 15) == 0)) {
+  if (c >= K1 && dx2 == nullptr) return;                                  // the second source's gradient is not wanted
+  float* d = c < K1 ? dx + (size_t)m * lddx + c : dx2 + (size_t)m * lddx2 + (c - K1);
+  if (c < K1 && dx == nullptr) return;
+  if (c + 3 < Kin && (c + 3 < K1 || c >= K1) && ((reinterpret_cast<uintptr_t>(d) & 15) == 0)) {
     float4 v = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
     if (accumulate) { const float4 u = *reinterpret_cast<const float4*>(d); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
     *reinterpret_cast<float4*>(d) = v;
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (c + r < Kin) d[r] = accumulate ? d[r] + acc[0][r] : acc[0][r];
+      if (c + r < Kin && ((c + r < K1) == (c < K1))) d[r] = accumulate ? d[r] + acc[0][r] : acc[0][r];      // K1 % 4 == 0: a group of 4 never straddles
   }
 }
 
@@ -148,7 +157,8 @@ __global__ __launch_bounds__(256) void dgrad_kernel(const float* __restrict__ dy
 // grid (ceil(N / 16), ceil(K / 64))
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ dy, int lddy, const float* __restrict__ yv, int ldy, int act,
                                            const float* __restrict__ x, int ldx, float* __restrict__ dw, int lddw, float* __restrict__ db,
-                                           int M, int K, int N, float* red, int bx, int by) {
+                                           int M, int K, int N, float* red, int bx, int by,
+                                           const float* __restrict__ x2 = nullptr, int ldx2 = 0, int K1 = 1 << 30) {
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int n0 = bx * 16, k0 = by * 64;
   const int n = n0 + lr;
@@ -164,8 +174,9 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ dy, int ldd
       g[u] = (min_ && nin) ? dy[(size_t)m * lddy + n] : 0.f;                   // A[row = n (lr)][k = m (lq)]
       yq[u] = (act != ACT_NONE && min_ && nin) ? yv[(size_t)m * ldy + n] : 0.f;
       const float* xr = x + (size_t)(min_ ? m : 0) * ldx + k0 + lr;             // B[k = m (lq)][col = k (lr)]
+      const float* xr2 = x2 ? x2 + (size_t)(min_ ? m : 0) * ldx2 + k0 + lr - K1 : xr;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xv[u][j] = (min_ && k0 + 16 * j + lr < K) ? xr[16 * j] : 0.f;
+      for (int j = 0; j < 4; ++j) xv[u][j] = (min_ && k0 + 16 * j + lr < K) ? (k0 + 16 * j + lr < K1 ? xr : xr2)[16 * j] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

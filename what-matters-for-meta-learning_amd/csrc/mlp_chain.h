@@ -267,9 +267,10 @@ __global__ __launch_bounds__(256) void multi_wgrad_kernel(const WJobs t) {
   sk::wgrad_body(j.dy, j.lddy, nullptr, 0, ACT_NONE, j.x, j.ldx, j.dw, j.lddw, j.db, j.M, j.K, j.N, red, b % j.gx, b / j.gx);
 }
 
-struct LJob {       // one Linear layer: forward, or both gradients
+struct LJob {       // one Linear layer: forward, or both gradients; x2 / dx2: the columns [K1, K) of a two-source input (torch.cat folded)
   const float* x; const float* w; const float* b; float* y; const float* dy; float* dx; float* dw; float* db;
-  int ldx, ldy, lddy, lddx, M, K, N, act, dx_acc, gdx, nd, gwx, first;
+  const float* x2; float* dx2;
+  int ldx, ldy, lddy, lddx, M, K, N, act, dx_acc, gdx, nd, gwx, first, ldx2, lddx2, K1;
 };
 struct LJobs { LJob j[MAXJ]; int n, total; };
 __global__ __launch_bounds__(256) void multi_fwd_kernel(const LJobs t) {
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void multi_fwd_kernel(const LJobs t) {
   while (ji + 1 < t.n && (int)blockIdx.x >= t.j[ji + 1].first) ++ji;
   const LJob& j = t.j[ji];
   const int b = (int)blockIdx.x - j.first;
-  sk::fwd_body(j.x, j.ldx, j.w, j.K, j.b, j.y, j.ldy, j.M, j.K, j.N, j.act, red, b % j.gdx, b / j.gdx);
+  sk::fwd_body(j.x, j.ldx, j.w, j.K, j.b, j.y, j.ldy, j.M, j.K, j.N, j.act, red, b % j.gdx, b / j.gdx, j.x2, j.ldx2, j.K1);
 }
 __global__ __launch_bounds__(256) void multi_bwd_kernel(const LJobs t) {
   __shared__ float red[4 * 5 * 64 * 4];
@@ -286,8 +287,8 @@ __global__ __launch_bounds__(256) void multi_bwd_kernel(const LJobs t) {
   while (ji + 1 < t.n && (int)blockIdx.x >= t.j[ji + 1].first) ++ji;
   const LJob& j = t.j[ji];
   const int b = (int)blockIdx.x - j.first;
-  if (b < j.nd) sk::dgrad_body(j.dy, j.lddy, j.y, j.ldy, j.act, j.w, j.K, j.dx, j.lddx, j.dx_acc, j.M, j.K, j.N, red, b % j.gdx, b / j.gdx);
-  else sk::wgrad_body(j.dy, j.lddy, j.y, j.ldy, j.act, j.x, j.ldx, j.dw, j.K, j.db, j.M, j.K, j.N, red, (b - j.nd) % j.gwx, (b - j.nd) / j.gwx);
+  if (b < j.nd) sk::dgrad_body(j.dy, j.lddy, j.y, j.ldy, j.act, j.w, j.K, j.dx, j.lddx, j.dx_acc, j.M, j.K, j.N, red, b % j.gdx, b / j.gdx, j.dx2, j.lddx2, j.K1);
+  else sk::wgrad_body(j.dy, j.lddy, j.y, j.ldy, j.act, j.x, j.ldx, j.dw, j.K, j.db, j.M, j.K, j.N, red, (b - j.nd) % j.gwx, (b - j.nd) / j.gwx, j.x2, j.ldx2, j.K1);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -378,7 +379,9 @@ inline int check_multi(const mlhot_linear_job* J, int n, bool bwd, const char* w
     const mlhot_linear_job& j = J[i];
     bool ok = j.x && j.w && j.y && j.M >= 0 && j.M <= sk::MAX_ROWS && j.K >= 4 && j.K % 4 == 0 && j.N >= 1 && j.act >= 0 && j.act <= 2 &&
               sk::aligned4(j.x, j.ldx) && a16(j.w);
-    if (bwd) ok = ok && j.dy && j.dx && j.dw && j.N % 4 == 0 && sk::aligned4(j.dy, j.lddy) && (j.act == ACT_NONE || sk::aligned4(j.y, j.ldy));
+    if (j.x2) ok = ok && j.K2 >= 4 && j.K2 % 4 == 0 && j.K2 < j.K && sk::aligned4(j.x2, j.ldx2);
+    if (bwd) ok = ok && j.dy && (j.dx || (j.x2 && j.dx2)) && j.dw && j.N % 4 == 0 && sk::aligned4(j.dy, j.lddy) && (j.act == ACT_NONE || sk::aligned4(j.y, j.ldy)) &&
+                  (!j.dx || sk::aligned4(j.dx, j.lddx)) && (!j.dx2 || sk::aligned4(j.dx2, j.lddx2));
     if (!ok) { set_error("%s: job %d: few-row Linear jobs need M <= %d, K %% 4 == 0, 16-byte aligned rows%s", what, i, sk::MAX_ROWS, bwd ? ", N % 4 == 0, dx and dw" : ""); return MLHOT_ERR_ARG; }
   }
   return MLHOT_OK;
@@ -388,7 +391,8 @@ inline void fill_jobs(LJobs& t, const mlhot_linear_job* J, int n, bool bwd) {
   for (int i = 0; i < n; ++i) {
     const mlhot_linear_job& s = J[i];
     LJob& j = t.j[t.n];
-    j = LJob{s.x, s.w, s.b, s.y, s.dy, s.dx, s.dw, s.db, s.ldx, s.ldy, s.lddy, s.lddx, s.M, s.K, s.N, s.act, s.dx_accumulate, (s.M + 31) / 32, 0, (s.N + 15) / 16, t.total};
+    j = LJob{s.x, s.w, s.b, s.y, s.dy, s.dx, s.dw, s.db, s.x2, s.dx2, s.ldx, s.ldy, s.lddy, s.lddx, s.M, s.K, s.N, s.act, s.dx_accumulate, (s.M + 31) / 32, 0,
+             (s.N + 15) / 16, t.total, s.ldx2, s.lddx2, s.x2 ? s.K - s.K2 : (1 << 30)};
     if (s.M == 0) continue;
     if (!bwd) t.total += j.gdx * ((s.N + 15) / 16);
     else { j.nd = j.gdx * ((s.K + 15) / 16); t.total += j.nd + j.gwx * ((s.K + 63) / 64); }

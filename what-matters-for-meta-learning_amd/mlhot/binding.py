@@ -120,7 +120,8 @@ class ChainGrads(C.Structure):       # struct mlhot_chain_grads
 class LinearJob(C.Structure):        # struct mlhot_linear_job
     _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int),
                 ("M", C.c_int), ("K", C.c_int), ("N", C.c_int), ("act", C.c_int), ("dy", C.c_void_p), ("lddy", C.c_int),
-                ("dx", C.c_void_p), ("lddx", C.c_int), ("dx_accumulate", C.c_int), ("dw", C.c_void_p), ("db", C.c_void_p)]
+                ("dx", C.c_void_p), ("lddx", C.c_int), ("dx_accumulate", C.c_int), ("dw", C.c_void_p), ("db", C.c_void_p),
+                ("x2", C.c_void_p), ("ldx2", C.c_int), ("K2", C.c_int), ("dx2", C.c_void_p), ("lddx2", C.c_int)]
 
 
 _GRAD_ARENA = None
@@ -700,29 +701,37 @@ class MlhotLib:
         return dx0, outs
 
     def linear_multi_fwd(self, jobs):
-        """jobs: [(x [M, K], w [N, K], b, act)] - independent layers, one launch -> [y]."""
+        """jobs: [(x [M, K1], w [N, K], b, act[, x2 [M, K - K1]])] - independent layers, one launch -> [y].  x2: the layer's input is
+        cat([x, x2], -1) (folded into the kernel)."""
         J = (LinearJob * len(jobs))()
         ys = []
-        for k, (x, w, b, act) in enumerate(jobs):
-            _chk(x, w, b)
+        for k, (x, w, b, act, *second) in enumerate(jobs):
+            x2 = second[0] if second else None
+            _chk(x, w, b, x2)
             y = torch.empty(x.shape[0], w.shape[0], device=x.device)
-            J[k] = LinearJob(_addr(x), x.shape[1], _addr(w), _addr(b), _addr(y), w.shape[0], x.shape[0], x.shape[1], w.shape[0], ACT[act],
-                             None, 0, None, 0, 0, None, None)
+            J[k] = LinearJob(_addr(x), x.shape[1], _addr(w), _addr(b), _addr(y), w.shape[0], x.shape[0], w.shape[1], w.shape[0], ACT[act],
+                             None, 0, None, 0, 0, None, None, _addr(x2), x2.shape[1] if x2 is not None else 0,
+                             x2.shape[1] if x2 is not None else 0, None, 0)
             ys.append(y)
         self._rc(self.c.mlhot_linear_multi_fwd(J, len(jobs), _stream(jobs[0][0])), "mlhot_linear_multi_fwd")
         return ys
 
     def linear_multi_bwd(self, jobs):
-        """jobs: [(x, w, y, dy, act[, bias])] -> [(dx, dw, db)], all gradient bodies in one launch."""
+        """jobs: [(x, w, y, dy, act[, bias[, x2, need_dx, need_dx2]])] -> [(dx, dw, db[, dx2])], all gradient bodies in one launch."""
         J = (LinearJob * len(jobs))()
         outs = []
-        for k, (x, w, y, dy, act, *bias) in enumerate(jobs):
-            _chk(x, w, y, dy)
-            b = bias[0] if bias else None
-            dx, dw, db = torch.empty_like(x), _grad_like(w), (_grad_like(b) if b is not None else torch.empty(w.shape[0], device=x.device))
-            J[k] = LinearJob(_addr(x), x.shape[1], _addr(w), None, _addr(y), w.shape[0], x.shape[0], x.shape[1], w.shape[0], ACT[act],
-                             _addr(dy), dy.shape[1], _addr(dx), x.shape[1], 0, _addr(dw), _addr(db))
-            outs.append((dx, dw, db))
+        for k, (x, w, y, dy, act, *rest) in enumerate(jobs):
+            b = rest[0] if rest else None
+            x2, need_dx, need_dx2 = (rest[1], rest[2], rest[3]) if len(rest) > 1 else (None, True, False)
+            _chk(x, w, y, dy, x2)
+            dx = torch.empty_like(x) if need_dx else None
+            dx2 = torch.empty_like(x2) if (x2 is not None and need_dx2) else None
+            dw, db = _grad_like(w), (_grad_like(b) if b is not None else torch.empty(w.shape[0], device=x.device))
+            J[k] = LinearJob(_addr(x), x.shape[1], _addr(w), None, _addr(y), w.shape[0], x.shape[0], w.shape[1], w.shape[0], ACT[act],
+                             _addr(dy), dy.shape[1], _addr(dx), x.shape[1], 0, _addr(dw), _addr(db),
+                             _addr(x2), x2.shape[1] if x2 is not None else 0, x2.shape[1] if x2 is not None else 0,
+                             _addr(dx2), x2.shape[1] if x2 is not None else 0)
+            outs.append((dx, dw, db) if x2 is None else (dx, dw, db, dx2))
         self._rc(self.c.mlhot_linear_multi_bwd(J, len(jobs), _stream(jobs[0][0])), "mlhot_linear_multi_bwd")
         return outs
 

@@ -144,6 +144,39 @@ class StackedLinearFunction(torch.autograd.Function):
                 *dw.view(h, w.shape[0] // h, w.shape[1]).unbind(0), *db.view(h, -1).unbind(0))
 
 
+class Linear2Function(torch.autograd.Function):
+    """y = act(cat([xa, xb], -1) W^T + b) on few rows without the concatenation: the two inputs are the two k ranges of ONE launch
+    (mlhot_linear_multi_* with a two-source job; the reference's torch.cat([x_ctx, labels]) -> Linear, ANP.py:113, and
+    torch.cat([x, sample_features]) -> fc_mu, models.py:182-184).  Backward: both input gradients, dW and db in one launch."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, w, b, act):
+        _need_gpu(xa, xb, w, b)
+        shp_a, shp_b = xa.shape, xb.shape
+        a2, b2 = _c(xa.reshape(-1, shp_a[-1]).float()), _c(xb.reshape(-1, shp_b[-1]).float())
+        wd, bd = _c(w.detach()), (_c(b.detach()) if b is not None else None)
+        (y,) = lib().linear_multi_fwd([(a2, wd, bd, act, b2)])
+        ctx.act, ctx.shp_a, ctx.shp_b, ctx.has_b = act, shp_a, shp_b, b is not None
+        ctx.save_for_backward(a2, b2, wd, y, *([bd] if bd is not None else []))
+        return y.view(*shp_a[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, b2, w, y, *bias = ctx.saved_tensors
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ((dxa, dw, db, dxb),) = lib().linear_multi_bwd([(a2, w, y, _c(dy.reshape(-1, w.shape[0]).float()), ctx.act, bias[0] if bias else None,
+                                                         b2, need_a, need_b)])
+        return (dxa.view(ctx.shp_a) if dxa is not None else None, dxb.view(ctx.shp_b) if dxb is not None else None, dw,
+                db if ctx.has_b else None, None)
+
+
+def linear2_ok(xa, xb, w):
+    """Shapes the two-source few-row Linear takes (else: torch.cat + LinearFunction)."""
+    rows = xa.numel() // xa.shape[-1]
+    return (xa.is_cuda and rows <= 512 and xa.shape[-1] % 4 == 0 and xb.shape[-1] % 4 == 0 and xb.shape[-1] >= 4 and w.shape[0] % 4 == 0
+            and xa.shape[-1] + xb.shape[-1] == w.shape[1])
+
+
 class MlpChainFunction(torch.autograd.Function):
     """Up to four Linear(+ReLU / tanh) layers on few rows in ONE launch (backward: two): mlhot_mlp_chain_fwd / _bwd
     (csrc/mlp_chain.h).  Layer k's input is the previous layer's output, optionally concatenated with a second tensor

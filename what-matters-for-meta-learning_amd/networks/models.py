@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from mlhot import lib
-from mlhot.ops import LinearFunction, MaxPool2Function, ResNetTrunkFunction, mlp_chain
+from mlhot.ops import Linear2Function, LinearFunction, MaxPool2Function, ResNetTrunkFunction, linear2_ok, mlp_chain
 from networks.ResNet import BasicBlock, ResNet, run_conv
 
 
@@ -86,9 +86,15 @@ def _mlp3(x, seq, last_relu, side=None, side_first=False, pre=None):
             return y
     if pre is not None:
         x = LinearFunction.apply(x, pre.weight, pre.bias, "none")
+    first = 0
     if side is not None:
-        x = torch.cat([side, x] if side_first else [x, side], dim=-1)
-    for lin, act in zip(lins, acts):
+        xa, xb = (side, x) if side_first else (x, side)
+        if xb.dim() == xa.dim() and xa.shape[:-1] == xb.shape[:-1] and linear2_ok(xa, xb, lins[0].weight):
+            # the concatenation folded into the first layer: its two inputs are the two k ranges of one launch
+            x, first = Linear2Function.apply(xa, xb, lins[0].weight, lins[0].bias, acts[0]), 1
+        else:
+            x = torch.cat([xa, xb], dim=-1)
+    for lin, act in zip(lins[first:], acts[first:]):
         x = LinearFunction.apply(x, lin.weight, lin.bias, act)
     return x
 
