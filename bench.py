@@ -103,8 +103,10 @@ def trunk_flops_per_step(T, kind="resnet3d"):
             add("trunk.conv2", c33)
             add("trunk.bwd.conv2.dgrad", c33)
             add("trunk.bwd.conv2.wgrad", c33)
-            add("trunk.bwd.conv1.dgrad", c33 + (0.0 if skip_k == 3 else c11))    # first writers of dx: 3x3 skips; conv1 + fused 1x1 skip
-            add("trunk.bwd.conv1.dgrad2", c33 if skip_k == 3 else 0.0)          # conv1 of the 3x3-skip blocks, added onto the skip's
+            # blocks 1-2 (blocks 3-4 of a 64 x 64 trunk are one fused launch, no label of their own): the 1x1-skip passes' conv1^T + fused
+            # skip under "dgrad"; the 3x3-skip passes' two sources (skip^T, conv1^T) in ONE launch under "dgrad2" (rw::dgrad2_dual_kernel)
+            add("trunk.bwd.conv1.dgrad", (c33 + c11) if skip_k == 1 else 0.0)
+            add("trunk.bwd.conv1.dgrad2", 2.0 * c33 if skip_k == 3 else 0.0)
             add("trunk.bwd.conv1.wgrad", c33 + (c33 if skip_k == 3 else 0.0))
             f["trunk.bwd.skip1.wgrad"] += c11 if skip_k == 1 else 0.0
     return f

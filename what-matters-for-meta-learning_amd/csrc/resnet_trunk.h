@@ -122,7 +122,7 @@ inline TrunkScratch trunk_carve(const mlhot_trunk_pass* ps, int n_pass, const ml
 }
 
 // Blocks 3 and 4 as one launch per direction (rw::tail34_*): 64 x 64 trunks (8 x 8 -> 4 x 4 -> 2 x 2 maps), "trunk_fuse34" option
-extern int g_trunk_fuse34;
+extern int g_trunk_fuse34, g_trunk_dual_dgrad;
 inline bool fuse34(const Levels& lv) { return g_trunk_fuse34 && lv.L[2] == 8; }
 
 inline int trunk_check(const mlhot_trunk_pass* ps, int n_pass, const mlhot_trunk_wset* ws, int n_wset, int C, int H) {
@@ -309,18 +309,23 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
     if (!in_fused) {
       // launch 1: every first writer of dx - the 3x3 skips' data gradients and the 1x1-skip blocks' fused conv1 + skip gradient;
       // launch 2: the 3x3-skip blocks' conv1 gradient, added onto launch 1's result and masked
-      rw::DgJobs ja{}, jb2{};
+      rw::DgJobs ja{}, jb2{}, jd{};
       bool any1 = false;
+      const bool dual = g_trunk_dual_dgrad && rw::dgrad2_dual_supported(lv.L[b]);
       for (int p = 0; p < n_pass; ++p) {
         const int w = ps[p].wset;
         if (ws[w].skip_k == 1) { any1 = true; ja.j[ja.n++] = rw::DgJob{dm[p], sc.wimg[w][c1], sc.G[p][b - 1], xin[p], g[p], sc.wimg[w][sk], ps[p].n_img, 0, 0, 0}; }
-        else {
+        else if (dual) {
+          // 3x3 skip: both sources (skip^T(g), conv1^T(dm)) in ONE launch, dx written once with its mask (rw::dgrad2_dual_kernel)
+          jd.j[jd.n++] = rw::DgJob{g[p], sc.wimg[w][sk], sc.G[p][b - 1], xin[p], dm[p], sc.wimg[w][c1], ps[p].n_img, 0, 0, 0};
+        } else {
           ja.j[ja.n++] = rw::DgJob{g[p], sc.wimg[w][sk], sc.G[p][b - 1], nullptr, nullptr, nullptr, ps[p].n_img, 0, 0, 0};
           jb2.j[jb2.n++] = rw::DgJob{dm[p], sc.wimg[w][c1], sc.G[p][b - 1], xin[p], nullptr, nullptr, ps[p].n_img, 1, 0, 0};
         }
       }
       MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], any1, ja, s, LBL_C1_DGRAD[b]));      // (split by kind like the forward: no gain here)
       MLHOT_TRY(rw::dgrad2_dispatch(lv.L[b], false, jb2, s, LBL_C1_DGRAD2[b]));
+      MLHOT_TRY(rw::dgrad2_dual_dispatch(lv.L[b], jd, s, LBL_C1_DGRAD2[b]));
     }
     {   // conv1 and 3x3-skip weight gradients (same input, same geometry: one launch); 1x1 skips on their own
       rw::WgJobs jobs{}, jobs1{};

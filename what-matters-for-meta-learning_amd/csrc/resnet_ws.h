@@ -480,18 +480,27 @@ struct DgJob {
 };
 struct DgJobs { DgJob j[MAX_JOBS]; int n; };
 
-template <class G, bool SKIP1>
-__device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch, int band0, int band_end, int band_step) {
+// DUAL (512 threads): the block input's gradient has TWO 3x3 stride-2 sources - the skip convolution's (dy, wimg) and conv1's (g1,
+// w1img) - that used to be two launches, the second adding onto the first one's dx (read - modify - write of the largest
+// gradient map: 262 MB of HBM traffic in c5's block 1, `frac_wait_any` 0.61).  Waves 0-3 run the first source, waves 4-7 the
+// second, each with its own weight registers and patch; the second half hands its accumulators over through LDS and the first
+// half writes dx once, masked.
+template <class G, bool SKIP1, bool DUAL = false>
+__device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, int band0, int band_end, int band_step) {
   static_assert(G::KIND == 1 && (G::TC >= 4 || G::PI < 16), "epilogue needs 4 consecutive grid columns per lane (or whole 2x2 maps)");
+  static_assert(!(SKIP1 && DUAL), "a pass has a 1x1 or a 3x3 skip");
+  const int half = DUAL ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+  float* patch = patch_all + (DUAL ? half * G::PATCH : 0);
   float* patch1 = patch + G::PATCH;
-  const int tid = threadIdx.x, lane = tid & 63, nt = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = DUAL ? ((int)threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, nt = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   const int ci = 16 * nt + lr;
   constexpr int NT = G::NACC, HX = 2 * G::HO;
+  const float* src_dy = (DUAL && half) ? jb.g1 : jb.dy;
 
   float wr[NKS];
   {
-    const float* wp = jb.wimg + (size_t)nt * NKS * 64 + lane;
+    const float* wp = ((DUAL && half) ? jb.w1img : jb.wimg) + (size_t)nt * NKS * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) wr[ks] = wp[ks * 64];
   }
@@ -518,7 +527,7 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch, int b
   for (int band = band0; band < nbands; band += band_step) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
     const int a0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
-    stage_patch<G>(patch, jb.dy, img0, a0, jb.n_img, tid, jb.img_lo);
+    stage_patch<G>(patch, src_dy, img0, a0, jb.n_img, tid, jb.img_lo);
     if (has1) stage_patch<G>(patch1, jb.g1, img0, a0, jb.n_img, tid, jb.img_lo);
 
     f32x4_t acc[4][NT];
@@ -562,7 +571,28 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch, int b
       }
     }
 
+    if (DUAL) {       // the second source's accumulators -> LDS -> added by the first half, which alone runs the epilogue
+      float* xw = patch_all + 2 * G::PATCH + (size_t)nt * (16 * NT) * 64 + lane;
+      if (half == 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xw[((c * NT + t) * 4 + r) * 64] = acc[c][t][r];
+      }
+      __syncthreads();
+      if (half == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[c][t][r] += xw[((c * NT + t) * 4 + r) * 64];
+      }
+    }
     // ---- epilogue: rows 4lq..4lq+3 of tile t = 4 consecutive grid columns (or a whole 2x2 grid) of channel ci ----
+    if (!DUAL || half == 0)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       int il = 0, a = 0, b = 0;
@@ -650,6 +680,45 @@ inline int dgrad2_dispatch(int HO, bool skip1, DgJobs& jobs, hipStream_t s, cons
 #undef MLHOT_RW_CASE
   return MLHOT_ERR_UNSUPPORTED;
 }
+
+template <class G>
+__global__ __launch_bounds__(512) void dgrad2_dual_kernel(const DgJobs jobs) {
+  __shared__ float patch[2 * G::PATCH + 4 * 16 * G::NACC * 64];      // two dy patches + the accumulator exchange
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const DgJob& jb = jobs.j[ji];
+  dgrad2_body<G, false, true>(jb, patch, (int)blockIdx.x - jb.wg0, 1 << 30, jb.nwg);
+}
+template <class G>
+inline int launch_dgrad2_dual(DgJobs& jobs, hipStream_t s, const char* what) {
+  int grid = plan_dg<G>(jobs);
+  if (grid <= 0) return MLHOT_OK;
+  if (grid > WG_SLOTS / 2) {            // one 512-thread workgroup per CU: plan against 256 slots
+    int nb[MAX_JOBS], total = 0, wg = 0;
+    for (int i = 0; i < jobs.n; ++i) { nb[i] = G::MULTI ? (jobs.j[i].n_img + G::NI - 1) / G::NI : jobs.j[i].n_img * G::BANDS_PER_IMG; total += nb[i]; }
+    for (int i = 0; i < jobs.n; ++i) {
+      int share = (int)((long)(WG_SLOTS / 2) * nb[i] / total);
+      if (share < 1) share = 1;
+      if (share > nb[i]) share = nb[i];
+      jobs.j[i].wg0 = wg; jobs.j[i].nwg = share; wg += share;
+    }
+    grid = wg;
+  }
+  {
+    ProfScope ps(what, s);
+    hipLaunchKernelGGL((dgrad2_dual_kernel<G>), dim3(grid), dim3(512), 0, s, jobs);
+  }
+  return check_launch(what);
+}
+// both 3x3 stride-2 sources of a block input's gradient in one launch (DgJob: dy / wimg = the skip's, g1 / w1img = conv1's)
+inline int dgrad2_dual_dispatch(int HO, DgJobs& jobs, hipStream_t s, const char* what) {
+  if (jobs.n <= 0) return MLHOT_OK;
+  if (HO == 16) return launch_dgrad2_dual<D16>(jobs, s, what);
+  if (HO == 8) return launch_dgrad2_dual<D8>(jobs, s, what);
+  if (HO == 32) return launch_dgrad2_dual<D32>(jobs, s, what);
+  return MLHOT_ERR_UNSUPPORTED;
+}
+inline bool dgrad2_dual_supported(int HO) { return HO == 8 || HO == 16 || HO == 32; }
 
 // ---- blocks 3 and 4 of a 64 x 64 trunk (8 x 8 -> 4 x 4 -> 2 x 2 maps) in ONE launch per direction ---------------------------
 // These two blocks are < 1 % of a trunk's FLOPs and were 14 of its launches (c5: 195 us of a 1.52 ms step): every launch a
