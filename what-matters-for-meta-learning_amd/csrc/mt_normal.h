@@ -79,10 +79,10 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(unsigned* __restrict__ eng
 // The low 31 bits of a jumped block's word 0 are not defined by the recurrence (they are not part of MT19937's state); the
 // regeneration reads only that word's top bit and a jumped block itself is never output - it was output by the sub-stream before.
 // Measured (c5, 896 k outputs per draw, MI355X): 64 sub-streams 0.99 -> 0.16-0.20 ms per draw (window 20 + jump 99 + chunks 21 + Box-
-// Muller 16 us), 8 sub-streams 0.26 ms.  BUT the draw of step k + 1 runs beside step k's kernels, and there the one-workgroup
-// form is the cheapest for the step: 1.520 ms per c5 step against 1.54 (4 sub-streams) / 1.58 (8) / 1.60 (64) - what counts is the
-// CU time taken from the trunk kernels, not the draw's latency.  mlhot.rng.DeviceNormal therefore keeps ONE workgroup by default
-// and uses the sub-streams on request (MLHOT_MT_SUBSTREAMS / sub_streams=): for steps shorter than the sequential draw.
+// Muller 16 us), 8 sub-streams 0.26 ms, 4 sub-streams 0.42 ms.  The draw of step k + 1 runs beside step k's kernels; the one-
+// workgroup form, 0.99 ms alone, stretches to ~1.45 ms there (its CU is shared with the trunk kernels) and was the floor of the c5
+// step: 1.527 ms per step with one workgroup, **1.474 ms with 2-4 sub-streams** (the default: 4), 1.52 with 8, 1.60 with 64 (their
+// 56 / 504 jump workgroups cost the trunk kernels more than the shorter draw returns).
 constexpr int DEG = 19937, JBLK = 33, JWIN = JBLK * N, JPARTS = 8, JPW = N / JPARTS, JSPAN = 32 * JPW + N;    // 20592 words; 78 words = 2496 bits per part; 3120
 static_assert(JWIN >= DEG + N && JPARTS * JPW == N && (JPARTS - 1) * 32 * JPW + JSPAN == JWIN, "jump window");
 

@@ -43,17 +43,19 @@ def _pack(rng_state, engine):
 
 class DeviceNormal:
     """`sub_streams`: K >= 2 draws from K parallel MT19937 sub-streams positioned by jump-ahead polynomials (mlhot/mt_jump.py;
-    identical uniforms / normals / final state; ~1.6 s of host arithmetic per table, cached per process); 1 = ONE workgroup
-    walking the recurrence.  Default: MLHOT_MT_SUBSTREAMS or 1.  The draw of step k + 1 runs beside step k's kernels, so what it
-    costs the step is the CU time it takes from them, not its latency - measured on c5 (896 k outputs per draw): one workgroup
-    0.99 ms of draw, 1.520 ms per step; 4 / 8 / 64 sub-streams 0.42 / 0.26 / 0.16-0.20 ms of draw, 1.54 / 1.58 / 1.60 ms per step.
-    The sub-streams are for steps shorter than the sequential draw."""
+    identical uniforms / normals / final state; ~0.5 s of host arithmetic per table, cached per process); 1 = ONE workgroup
+    walking the recurrence.  Default: MLHOT_MT_SUBSTREAMS or 4.  The draw of step k + 1 runs beside step k's kernels and has to be
+    finished when step k ends.  Measured on c5 (896 k outputs per draw, MI355X): ONE workgroup takes 0.99 ms alone but ~1.45 ms
+    beside a step that fills the chip (its CU is shared with the trunk kernels' workgroups) - as long as the step itself, i.e. the
+    draw is the step's floor: 1.527 ms per step; 2 / 3 / 4 sub-streams (0.4-0.6 ms of draw on 2-4 + 8-24 workgroups) 1.474 ms;
+    8 sub-streams 1.52 and 64 sub-streams 1.60 - their 56 / 504 jump workgroups take more from the trunk kernels than the shorter
+    draw gives back (rocprofv3 timelines: scripts/dev/step_timeline.py)."""
 
     def __init__(self, device, sizes, sub_streams=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("DeviceNormal needs a ROCm device (the CPU route is torch's own normal_())")
-        n_sub = int(os.environ.get("MLHOT_MT_SUBSTREAMS", "1")) if sub_streams is None else int(sub_streams)
+        n_sub = int(os.environ.get("MLHOT_MT_SUBSTREAMS", "4")) if sub_streams is None else int(sub_streams)
         sizes = [int(n) for n in sizes]
         if not sizes or min(sizes) < 16:
             raise ValueError("every draw needs >= 16 elements (smaller tensors take torch's scalar double-precision path)")
