@@ -286,6 +286,10 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
     MLHOT_TRY(rw::tail34_launch(jobs, true, s, "trunk.bwd.b34.dgrad"));
   }
   rw::Sk1Jobs sk1{};
+  rw::Wg34Jobs w34{};      // fused blocks 3-4: their 3x3 weight gradients as ONE launch when the job table holds them (conv1 + conv2 of every
+  int n_skip3 = 0;         // pass + the 3x3 skips, for both blocks: 16 jobs for c5's three passes); per-block launches otherwise
+  for (int p = 0; p < n_pass; ++p) n_skip3 += ws[ps[p].wset].skip_k == 3;
+  const bool w34_ok = fused && 2 * (2 * n_pass + n_skip3) <= rw::WG34_MAX;
   for (int b = 4; b >= 1; --b) {
     const int c1 = 3 * b - 2, c2 = c1 + 1, sk = c1 + 2;
     const bool in_fused = fused && b >= 3;
@@ -303,7 +307,8 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
     {   // conv2 weight gradient
       rw::WgJobs jobs{};
       wg_jobs(c2, false, false, jobs, mid, g);
-      MLHOT_TRY(rw::wgrad_dispatch(lv.L[b], 1, false, jobs, s, LBL_C2_WGRAD[b]));
+      if (in_fused && w34_ok) { for (int i = 0; i < jobs.n; ++i) { w34.j[w34.n] = jobs.j[i]; w34.geo[w34.n++] = b == 3 ? 1 : 3; } }      // one launch behind block 3 (rw::wgrad34_kernel)
+      else MLHOT_TRY(rw::wgrad_dispatch(lv.L[b], 1, false, jobs, s, LBL_C2_WGRAD[b]));
     }
     // data gradient into the block input (not needed for images: block 1's input is the stem output, whose gradient feeds the stem's wgrad)
     if (!in_fused) {
@@ -330,9 +335,17 @@ inline int trunk_backward(const mlhot_trunk_pass* ps, int n_pass, const mlhot_tr
     {   // conv1 and 3x3-skip weight gradients (same input, same geometry: one launch); 1x1 skips on their own
       rw::WgJobs jobs{}, jobs1{};
       wg_jobs(c1, false, false, jobs, xin, dm);
-      if (jobs.n + n_pass > rw::MAX_JOBS) { MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, LBL_C1_WGRAD[b])); jobs.n = 0; }
-      wg_jobs(sk, false, false, jobs, xin, g);
-      MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, LBL_C1_WGRAD[b]));
+      if (in_fused && w34_ok) {
+        for (int i = 0; i < jobs.n; ++i) { w34.j[w34.n] = jobs.j[i]; w34.geo[w34.n++] = b == 3 ? 0 : 2; }
+        jobs.n = 0;
+        wg_jobs(sk, false, false, jobs, xin, g);
+        for (int i = 0; i < jobs.n; ++i) { w34.j[w34.n] = jobs.j[i]; w34.geo[w34.n++] = b == 3 ? 0 : 2; }
+        if (b == 3) MLHOT_TRY(rw::wgrad34_launch(w34, s, "trunk.bwd.b34.wgrad"));
+      } else {
+        if (jobs.n + n_pass > rw::MAX_JOBS) { MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, LBL_C1_WGRAD[b])); jobs.n = 0; }
+        wg_jobs(sk, false, false, jobs, xin, g);
+        MLHOT_TRY(rw::wgrad_dispatch(lv.L[b - 1], 2, false, jobs, s, LBL_C1_WGRAD[b]));
+      }
       // 1x1 skips: collected over the blocks, one launch behind the loop (same slab rows as a per-block launch would use)
       wg_jobs(sk, true, true, jobs1, xin, g);
       for (int i = 0; i < jobs1.n; ++i) {

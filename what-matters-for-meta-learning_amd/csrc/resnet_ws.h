@@ -918,17 +918,14 @@ struct WgJob {
 };
 struct WgJobs { WgJob j[MAX_JOBS]; int n; };
 
+// body of one weight-gradient workgroup: `rel` = its index inside job `jb` (q = rel & 3: input-channel tile, z = rel >> 2: slab row)
 template <class G, bool TAP1>          // TAP1: only the centre tap (the 1x1 stride-2 skip convolution: x[ci][2oy][2ox])
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
-  __shared__ float lds[G::LDS];
+__device__ __forceinline__ void wgrad_body(const WgJob& jb, float* lds, int rel) {
   float* xs = lds;
   float* dyt = lds + G::XS;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
-  int ji = 0;
-  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
-  const WgJob& jb = jobs.j[ji];
-  const int rel = (int)blockIdx.x - jb.wg0, q = rel & 3, z = rel >> 2;
+  const int q = rel & 3, z = rel >> 2;
   constexpr int NT = TAP1 ? 1 : 9;
 
   // per-lane operand bases; the k-step parts are compile-time immediates (GeoW::separable): as two 32-entry per-lane arrays they
@@ -1100,6 +1097,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
 #ifdef MLHOT_TS
   if (tf::g_ts_dev && threadIdx.x == 0 && !TAP1 && G::HIN == 32 && G::S == 2 && blockIdx.x < 1024) tf::g_ts_dev[1025 + 2 * blockIdx.x] = wall_clock64();
 #endif
+}
+
+template <class G, bool TAP1>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgJobs jobs) {
+  __shared__ float lds[G::LDS];
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const WgJob& jb = jobs.j[ji];
+  wgrad_body<G, TAP1>(jb, lds, (int)blockIdx.x - jb.wg0);
+}
+
+// The 3x3 weight gradients of blocks 3 and 4 of a 64 x 64 trunk (conv1 / 3x3 skip / conv2 of both blocks, every pass: up to 16 jobs
+// of four geometries) in ONE launch: each was a launch of 10-15 us for a few hundred short workgroups (c5: 48 us in four launches).
+constexpr int WG34_MAX = 16;
+struct Wg34Jobs { WgJob j[WG34_MAX]; unsigned char geo[WG34_MAX]; int n; };      // geo: 0 = 8x8 s2, 1 = 4x4 s1, 2 = 4x4 s2, 3 = 2x2 s1
+__global__ __launch_bounds__(256, 2) void wgrad34_kernel(const Wg34Jobs jobs) {
+  __shared__ float lds[cmax(cmax(W8s2::LDS, W4s1::LDS), cmax(W4s2::LDS, W2s1::LDS))];
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
+  const WgJob& jb = jobs.j[ji];
+  const int rel = (int)blockIdx.x - jb.wg0;
+  switch (jobs.geo[ji]) {
+    case 0: wgrad_body<W8s2, false>(jb, lds, rel); break;
+    case 1: wgrad_body<W4s1, false>(jb, lds, rel); break;
+    case 2: wgrad_body<W4s2, false>(jb, lds, rel); break;
+    default: wgrad_body<W2s1, false>(jb, lds, rel); break;
+  }
+}
+inline int wgrad34_launch(Wg34Jobs& jobs, hipStream_t s, const char* what) {
+  int wg = 0;
+  for (int i = 0; i < jobs.n; ++i) { jobs.j[i].wg0 = wg; wg += 4 * jobs.j[i].nz; }
+  if (wg <= 0) return MLHOT_OK;
+  {
+    ProfScope ps(what, s);
+    hipLaunchKernelGGL(wgrad34_kernel, dim3(wg), dim3(256), 0, s, jobs);
+  }
+  return check_launch(what);
 }
 
 // out = sum over slab rows, un-permuted from MFMA-native order to the parameter's own layout.
