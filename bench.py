@@ -612,6 +612,7 @@ def main():
     import torch.distributed as dist
     import mlhot
     from mlhot import dist as mdist
+    from mlhot.ops import add_scaled
     from trainer.losses import LossFunc
     # MLHOT_DIST_BACKEND / MLHOT_ONE_DEVICE: test hooks (e.g. two gloo ranks sharing the only GPU of a 1-GPU box, to
     # exercise the N>1 control flow); the driver's launch uses neither (nccl = RCCL, one rank per GPU)
@@ -659,7 +660,7 @@ def main():
         mu, var, kl = model(bx, by, tx)
         loss = loss_fn.calc_loss(mu, var, ty)
         if c5:
-            loss = loss + beta * kl          # identical on every rank (same weights, kl does not depend on the batch): averaged, never summed
+            loss = add_scaled(loss, kl, beta)     # loss + kl * beta as the trainer writes it; identical on every rank (same weights, kl does not depend on the batch): averaged, never summed
         if arm:
             bucket.arm()                     # eager steps only: the early bucket's all-reduce is issued from inside backward()
         loss.backward(gradient=seed)         # the constant 1.0 autograd would otherwise make with a fill kernel every step

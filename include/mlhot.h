@@ -225,6 +225,9 @@ int mlhot_conv2d_fwd(const float* x, const float* w, const float* b, float* y, i
 int mlhot_conv2d_bwd(const float* x, const float* w, const float* y, const float* dy, int N, int Cin, int H, int W, int Cout, int k,
                      int stride, int pad, int relu, float* dx, float* dw, float* db, void* scratch, size_t scratch_bytes, void* stream);
 /* residual join y = relu(a + b) (ResNet.py:69-72); backward g = dy * (y > 0) is the gradient of both inputs */
+/* y[i] = a[i] + alpha * x[i] (a NULL: alpha * x[i]); product and sum rounded separately.  The trainer's `loss + kl * beta`
+ * (trainer/model_trainer.py:77-78) as one launch per direction instead of two elementwise torch operators.                   */
+int mlhot_axpy(const float* a, const float* x, float alpha, float* y, size_t n, void* stream);
 int mlhot_add_relu_fwd(const float* a, const float* b, float* y, size_t n, void* stream);
 int mlhot_add_relu_bwd(const float* y, const float* dy, float* g, size_t n, void* stream);
 /* 2x2 max-pool over `planes` maps of H x W (nn.AdaptiveMaxPool2d((2,2)) on 4x4 maps, models.py:107-110) */

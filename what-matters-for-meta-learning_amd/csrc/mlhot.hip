@@ -300,6 +300,10 @@ int mlhot_add_relu_fwd(const float* a, const float* b, float* y, size_t n, void*
 int mlhot_add_relu_bwd(const float* y, const float* dy, float* g, size_t n, void* stream) {
   return run_foreach(AddReluBwd{y, dy, g}, n, (hipStream_t)stream, "add_relu.bwd");
 }
+int mlhot_axpy(const float* a, const float* x, float alpha, float* y, size_t n, void* stream) {
+  if (!x || !y) { set_error("axpy: null argument"); return MLHOT_ERR_ARG; }
+  return run_foreach(Axpy{a, x, alpha, y}, n, (hipStream_t)stream, "axpy");
+}
 int mlhot_pool2_fwd(const float* x, float* y, uint8_t* amax, int planes, int H, int W, void* stream) {
   if (planes <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) { set_error("pool2_fwd: bad argument"); return MLHOT_ERR_ARG; }
   return run_foreach(Pool2Fwd{x, y, amax, H, W}, (size_t)planes * (H / 2) * (W / 2), (hipStream_t)stream, "pool2.fwd");

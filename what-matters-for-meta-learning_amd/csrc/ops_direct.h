@@ -65,6 +65,20 @@ struct Pool2Fwd {
 
 // residual join of a BasicBlock: y = relu(a + b)  (ResNet.py:69-72) and its backward g = dy * (y > 0)
 struct AddRelu { const float* a; const float* b; float* y; MLHOT_HD void operator()(size_t i) const { const float v = a[i] + b[i]; y[i] = v > 0.f ? v : 0.f; } };
+// y = a + alpha * x  (a may be null: y = alpha * x), product and sum rounded separately like the two torch operators they replace
+// (trainer/model_trainer.py:77-78: loss + kl * beta)
+struct Axpy {
+  const float* a; const float* x; float alpha; float* y;
+  MLHOT_HD void operator()(size_t i) const {
+#ifdef MLHOT_HOSTSIM
+    volatile float p = alpha * x[i];
+    y[i] = a ? a[i] + p : p;
+#else
+    const float p = __fmul_rn(alpha, x[i]);
+    y[i] = a ? __fadd_rn(a[i], p) : p;
+#endif
+  }
+};
 struct AddReluBwd { const float* y; const float* dy; float* g; MLHOT_HD void operator()(size_t i) const { g[i] = y[i] > 0.f ? dy[i] : 0.f; } };
 // max-pool backward: route dp to the window arg-max (dx must be pre-zeroed by construction: every element written)
 struct Pool2Bwd {

@@ -735,6 +735,14 @@ class MlhotLib:
         self._rc(self.c.mlhot_linear_multi_bwd(J, len(jobs), _stream(jobs[0][0])), "mlhot_linear_multi_bwd")
         return outs
 
+    def axpy(self, a, x, alpha):
+        """a + alpha * x (a None: alpha * x), elementwise, one launch."""
+        _chk(a, x)
+        y = torch.empty_like(x)
+        self.c.mlhot_axpy.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
+        self._rc(self.c.mlhot_axpy(_ptr(a), _ptr(x), float(alpha), _ptr(y), x.numel(), _stream(x)), "mlhot_axpy")
+        return y
+
     # ---- aggregators ---------------------------------------------------------------------------
     def agg_fwd(self, mode, rs, lv=None):
         _chk(rs, lv)

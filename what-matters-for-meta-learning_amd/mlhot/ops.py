@@ -177,6 +177,31 @@ def linear2_ok(xa, xb, w):
             and xa.shape[-1] + xb.shape[-1] == w.shape[1])
 
 
+class ScaledAddFunction(torch.autograd.Function):
+    """a + alpha * x for same-shaped fp32 device tensors (the trainer's `loss + kl * beta`, trainer/model_trainer.py:77-78): one launch
+    per direction instead of torch's mul + add (+ mul in the backward); the same two roundings."""
+
+    @staticmethod
+    def forward(ctx, a, x, alpha):
+        _need_gpu(a, x)
+        ctx.alpha = float(alpha)
+        return lib().axpy(_c(a.float()), _c(x.float()), ctx.alpha)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy.float())
+        return (dy if ctx.needs_input_grad[0] else None), (lib().axpy(None, dy, ctx.alpha) if ctx.needs_input_grad[1] else None), None
+
+
+def add_scaled(a, x, alpha):
+    """a + x * alpha the way the reference writes it; fused into one launch when both are fp32 device tensors of one shape."""
+    if torch.is_tensor(a) and torch.is_tensor(x) and a.is_cuda and x.is_cuda and a.shape == x.shape and a.dtype == x.dtype == torch.float32:
+        return ScaledAddFunction.apply(a, x, alpha)
+    if not torch.is_tensor(x) and x * alpha == 0:
+        return a                           # the models without a KL term return the int 0: loss + 0 is loss, no launch
+    return a + x * alpha
+
+
 class MlpChainFunction(torch.autograd.Function):
     """Up to four Linear(+ReLU / tanh) layers on few rows in ONE launch (backward: two): mlhot_mlp_chain_fwd / _bwd
     (csrc/mlp_chain.h).  Layer k's input is the previous layer's output, optionally concatenated with a second tensor

@@ -28,6 +28,7 @@ import sys
 import torch
 
 from mlhot.dist import GradBucket, rank as dist_rank
+from mlhot.ops import add_scaled
 from trainer.base_trainer import BaseTrainer
 
 
@@ -126,7 +127,7 @@ class ModelTrainer(BaseTrainer):
         else:
             pr_mu, pr_var, kl = self.model(ctx_x, ctx_y, qry_x)
             contra_loss = None
-        losses = self.loss.calc_loss(pr_mu, pr_var, qry_y) + kl * self.config.beta
+        losses = add_scaled(self.loss.calc_loss(pr_mu, pr_var, qry_y), kl, self.config.beta)
         if contra_loss is not None:
             losses = losses + contra_loss * self.config.contrastive_rate
         losses.backward(gradient=self._seed(losses))
@@ -210,8 +211,7 @@ class ModelTrainer(BaseTrainer):
             pr_mu, pr_var, kl, contra_loss = self.model(ctx_x, ctx_y, qry_x, qry_y)
         else:
             pr_mu, pr_var, kl = self.model(ctx_x, ctx_y, qry_x)
-        losses = self.loss.calc_loss(pr_mu, pr_var, qry_y)
-        losses = losses + kl * self.config.beta
+        losses = add_scaled(self.loss.calc_loss(pr_mu, pr_var, qry_y), kl, self.config.beta)      # loss + kl * beta (model_trainer.py:77-78), one launch
         if contrastive:
             losses = losses + contra_loss * self.config.contrastive_rate
         self.bucket.arm()                                         # world > 1: the early bucket's all-reduce goes out from inside backward()
