@@ -5,7 +5,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 mkdir -p $OUT
 cd $REPO
 python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench_c3.json 2> $OUT/bench_c3.err
@@ -20,9 +20,11 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 # BASELINE config c5's per-GPU step (ANPMRShapeNet3D, bench.py --workload c5): bench line, per-label kernel times, kernel stats
 cd $REPO
 python bench.py --workload c5 --steps 30 --warmup 5 > $OUT/${TAG}_bench_c5.json 2> $OUT/bench_c5.err
-MLHOT_BENCH_KERNELS=$OUT/${TAG}_kernels_c5.json python bench.py --workload c5 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+# the same step with the eps stream continued on the device (4 jump-ahead sub-streams): the mode the c5 kernel numbers are quoted in
+python bench.py --workload c5 --eps device --steps 40 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_c5_device_eps.json 2> $OUT/bench_c5d.err
+MLHOT_BENCH_KERNELS=$OUT/${TAG}_kernels_c5.json python bench.py --workload c5 --eps device --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o stats -- python3 $REPO/bench.py --workload c5 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/stats_c5.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o stats -- python3 $REPO/bench.py --workload c5 --eps device --steps 20 --warmup 5 --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/stats_c5.log 2>&1
 # c5 counters per launch label (scripts/pmc_by_label.py folds the dispatch list onto the label sequence of one step)
 cd $REPO
 MLHOT_BENCH_SEQ=$OUT/seq_c5.json python bench.py --workload c5 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 2 > /dev/null 2>&1

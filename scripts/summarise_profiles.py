@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
 
 KERNEL_LABEL = {            # kernel-name fragment -> bench.py label
     "conv12_fwd_pool_kernel": "enc.conv12", "conv12_wgrad_kernel": "enc.bwd.conv12.wgrad", "conv12_dgrad_kernel": "enc.bwd.conv12.dgrad",
@@ -25,7 +25,7 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-for name in (f"{tag}_bench_c3.json", f"{tag}_bench_c2.json", f"{tag}_kernels_c3.json", f"{tag}_bench_c5.json", f"{tag}_kernels_c5.json",
+for name in (f"{tag}_bench_c3.json", f"{tag}_bench_c2.json", f"{tag}_kernels_c3.json", f"{tag}_bench_c5.json", f"{tag}_bench_c5_device_eps.json", f"{tag}_kernels_c5.json",
              f"{tag}_pmc_traffic_c5.json", f"{tag}_pmc_sq_c5.json"):
     p = os.path.join(SRC, name)
     if os.path.exists(p) and os.path.getsize(p):
