@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLHOT_ABI_VERSION 2
+#define MLHOT_ABI_VERSION 3
 
 enum { MLHOT_ACT_NONE = 0, MLHOT_ACT_RELU = 1, MLHOT_ACT_TANH = 2 };
 enum { MLHOT_AGG_MEAN = 0, MLHOT_AGG_MAX = 1, MLHOT_AGG_BACO = 2, MLHOT_AGG_ATTENTION = 3 };
@@ -111,6 +111,18 @@ int mlhot_enc_vanilla_fwd(const float* img0, int n0, const float* img1, int n1, 
 int mlhot_enc_vanilla_bwd(const float* img0, int n0, const float* img1, int n1, const mlhot_enc_params* p, int dim_w,
                           const float* dfeat0, int ldd0, const float* dfeat1, int ldd1,
                           const void* saved, const mlhot_enc_grads* g, void* scratch, size_t scratch_bytes, void* stream);
+
+/* E1's first block on its own - conv1 (1 -> 32, 3x3 s2 p1) + ReLU + conv2 (32 -> 48, 3x3 s2 p1) + ReLU + 2x2 max-pool of n
+ * 128 x 128 images (networks/conv_embedding_model.py:18-31, the first five layers) - for tests and micro-benchmarks of the three
+ * kernels that carry 80 % of the vanilla models' FLOPs.  `saved` has the layout and size of mlhot_enc_vanilla_saved_bytes(n): the
+ * forward leaves p2 [n,48,16,16], the pool arg-max and conv1's ReLU sign bits there; the backward takes d p2 and returns the four
+ * parameter gradients.  Option "conv2_split" (bit 1 forward, 2 data gradient, 4 weight gradient) selects the split-bf16 kernels. */
+size_t mlhot_conv12_scratch_bytes(int n_img);
+int mlhot_conv12_fwd(const float* img, int n_img, const float* w1, const float* b1, const float* w2, const float* b2,
+                     void* saved, void* stream);
+int mlhot_conv12_bwd(const float* img, int n_img, const float* w1, const float* b1, const float* w2, const float* dp2,
+                     const void* saved, float* dw1, float* db1, float* dw2, float* db2, void* scratch, size_t scratch_bytes,
+                     void* stream);
 
 /* ---- M1 / D1 / A1 / A4: nn.Linear (+ReLU / tanh) ----------------------------------------
  * y[M,N] = act(x[M,K] w[N,K]^T + b)   (networks/models.py:27-60 EncoderFC, 195-203 AttnLinear;

@@ -272,11 +272,12 @@ def _enc_params(seed=0):
     return {"encoder_w0." + k: torch.randn(*s, generator=g) * a for k, s, a in shapes}
 
 
-@pytest.fixture(params=[(1, 0), (0, 0), (1, 1)], ids=["conv2_tc", "conv2_igemm", "conv2_split"])
+@pytest.fixture(params=[(1, 0), (0, 0), (1, 1), (1, 7)], ids=["conv2_tc", "conv2_igemm", "conv2_split", "conv2_split_all"])
 def conv2_impl(gpulib, request):
     """The implementations of the conv2 rows: the weight-stationary fp32 kernels (csrc/conv_tc.h), the generic implicit-GEMM
-    problems, and the opt-in forward with conv2 on the bf16 pipe over hi / mid / lo split operands (csrc/conv_split.h: held to
-    the SAME tolerances as the fp32 kernels - the split is exact, the six kept piece products are as exact as an fp32 MFMA)."""
+    problems, and the opt-in kernels with conv2 on the bf16 pipe over hi / mid / lo split operands (csrc/conv_split.h: held to
+    the SAME tolerances as the fp32 kernels - the split is exact, the six kept piece products are as exact as an fp32 MFMA):
+    the forward alone, or the forward and both gradients (option bits 1 | 2 | 4)."""
     gpulib.set_option("conv2_tc", request.param[0])
     gpulib.set_option("conv2_split", request.param[1])
     yield request.param

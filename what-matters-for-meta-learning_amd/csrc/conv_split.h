@@ -1,14 +1,18 @@
-// conv1 + conv2 + pool forward of the vanilla encoder with conv2 on the bf16 matrix pipe and SPLIT fp32 operands
-// (mlhot_set_option("conv2_split", 1); OFF by default: bench.py's `value` stays on the exact-fp32 kernels of conv_tc.h, this
-// variant is reported under `extras` with its arithmetic spelled out).
+// The vanilla encoder's conv1 + conv2 + pool block with conv2 on the bf16 matrix pipe and SPLIT fp32 operands: forward, data
+// gradient (+ conv1's weight gradient) and weight gradient (mlhot_set_option("conv2_split", 1); OFF by default: bench.py's
+// `value` stays on the exact-fp32 kernels of conv_tc.h, these variants are reported under `extras` with their arithmetic spelled out).
 //
-// Every fp32 operand is cut into three bf16 pieces by truncation, x = hi + mid + lo EXACTLY (3 x 8 mantissa bits: hi = x with the
-// low 16 bits cleared, mid = the same of x - hi, lo = x - hi - mid).  A product x w is then the sum of piece products, each exact in
-// fp32, accumulated in fp32 by v_mfma_f32_16x16x32_bf16; 6 of the 9 are kept (hh, hm, mh, hl, lh, mm: the dropped ones are below
-// 2^-24 of the product).  scripts/micro/split_bf16_error.py: against float64 this is as exact as the fp32 MFMA it replaces
-// (5.4e-7 of the largest output either way); scripts/micro/conv2_split_loop.hip: 2.2 x the fp32 inner loop.
+// Every fp32 operand is cut into three bf16 pieces, x = hi + mid + lo EXACTLY: hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid,
+// each conversion round-to-nearest-even (v_cvt_pk_bf16_f32: two values per instruction, already packed).  The residual after two
+// 8-bit pieces has at most 6 significant bits, so lo is exact.  A product x w is then the sum of piece products, each exact in fp32,
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16; 6 of the 9 are kept (hh, hm, mh, hl, lh, mm).  With nearest pieces |mid| <= 2^-9 |x|
+// and |lo| <= 2^-18 |x|, so the dropped ml + lm + ll are below 2^-26 |x w| - under the 2^-25 half-ulp a single fp32 rounding of the
+// product's sum costs - and of either sign (pieces cut by truncation, the round-3 form, dropped up to 2^-23, always towards zero).
+// The five small products of a K block are summed in an accumulator of their own and join the hh sum once, at the end.
+// tests/test_gpu_parity.py::test_split_precision_error_vs_fp32_mfma compares both arithmetics with float64 on adversarial operands;
+// scripts/micro/split_bf16_error.py is the CPU model; scripts/micro/conv2_split_loop.hip: 2.2 x the fp32 inner loop.
 //
-// Shape: one persistent 768-thread workgroup per CU, bands of TWO conv2 output rows (16 per image): the a1 patch of a band is
+// FORWARD.  One persistent 768-thread workgroup per CU, bands of TWO conv2 output rows (16 per image): the a1 patch of a band is
 // [5 rows][65 cols][3 pieces][32 ci] bf16 at 208 bytes per position (67.6 KB; two of them: the next band's conv1 is computed
 // under this band's MFMAs - conv1 itself stays on the fp32 pipe, K = 9 + bias padded to 12, as in conv_tc.h, and leaves the same
 // ReLU sign-bit records for the backward).  Wave = (16 output channels nt) x (row r2 of the band, column half ch): ONE 16 x 16
@@ -45,14 +49,17 @@ __device__ long long g_c2s_ts[12 * 16 + 4];
 
 __device__ __forceinline__ f32x4_t mfma_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
-// x = hi + mid + lo exactly; each piece has at most 8 significant bits, i.e. is a bf16 (returned as fp32 bit patterns whose low
-// 16 bits are zero)
-__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = __float_as_uint(x) & 0xffff0000u;
-  const float r1 = x - __uint_as_float(hi);
-  mid = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(mid);
-  lo = __float_as_uint(r2) & 0xffff0000u;
+// (v0, v1) -> three dwords of packed bf16 pairs (low half = v0's piece): v = hi + mid + lo exactly, nearest pieces (see the header)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float v0, float v1) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{v0, v1}, bf16x2_t));     // v_cvt_pk_bf16_f32
+}
+__device__ __forceinline__ void split3_pk(float v0, float v1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = pk_bf16(v0, v1);
+  const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xffff0000u);
+  mid = pk_bf16(r0, r1);
+  lo = pk_bf16(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
 }
 
 // A fragment of tap t (ky = t / 3, kx = t % 3), piece p, for the wave's 16 positions (pa: position (row 2 r2, column 2 (16 ch + lr)),
@@ -113,16 +120,12 @@ __global__ __launch_bounds__(NT) void conv12_fwd_split_kernel(const ImgSrc x, co
     const float* stage = reinterpret_cast<const float*>(lds) + co * c2::W2_LD;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      unsigned pc[3][8];
+      unsigned v[3][4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) split3(stage[(16 * (j & 1) + 4 * lq + (j >> 1)) * 9 + t], pc[0][j], pc[1][j], pc[2][j]);   // k' = 8 lq + j <-> ci
+      for (int i = 0; i < 4; ++i)     // k' = 8 lq + j <-> ci = 16 (j & 1) + 4 lq + (j >> 1), j = 2 i | 2 i + 1
+        split3_pk(stage[(4 * lq + i) * 9 + t], stage[(16 + 4 * lq + i) * 9 + t], v[0][i], v[1][i], v[2][i]);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        u32x4_t v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (pc[p][2 * i] >> 16) | pc[p][2 * i + 1];
-        wr[t][p] = __builtin_bit_cast(bf16x8_t, v);
-      }
+      for (int p = 0; p < 3; ++p) wr[t][p] = __builtin_bit_cast(bf16x8_t, u32x4_t{v[p][0], v[p][1], v[p][2], v[p][3]});
     }
   }
   const float bn = bias[co];
@@ -170,15 +173,8 @@ __global__ __launch_bounds__(NT) void conv12_fwd_split_kernel(const ImgSrc x, co
     for (int q = 0; q < 4; ++q) {
       const bool p0 = c0[q] > 0.f, p1 = c1[q] > 0.f;
       const float v0 = p0 ? c0[q] : 0.f, v1 = p1 ? c1[q] : 0.f;          // (fmaxf costs a canonicalising v_max on top)
-      // hi / mid / lo by truncation; v_perm_b32 packs the upper halves of the two channels, so only the subtrahends are masked
-      const float h0 = __uint_as_float(__float_as_uint(v0) & 0xffff0000u), h1 = __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
-      const float r0 = v0 - h0, r1 = v1 - h1;
-      const float m0 = __uint_as_float(__float_as_uint(r0) & 0xffff0000u), mm1 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-      const float l0 = r0 - m0, l1 = r1 - mm1;
       unsigned* dq = reinterpret_cast<unsigned*>(d + q * POSB);
-      dq[0] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(h0), 0x07060302u);
-      dq[16] = __builtin_amdgcn_perm(__float_as_uint(mm1), __float_as_uint(m0), 0x07060302u);
-      dq[32] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+      split3_pk(v0, v1, dq[0], dq[16], dq[32]);
       const unsigned long long b0 = __builtin_amdgcn_ballot_w64(p0), bb1 = __builtin_amdgcn_ballot_w64(p1);
       *reinterpret_cast<uint4*>(mrec + 4 * q) = make_uint4((unsigned)b0, (unsigned)(b0 >> 32), (unsigned)bb1, (unsigned)(bb1 >> 32));
     }
@@ -279,6 +275,261 @@ __global__ __launch_bounds__(NT) void conv12_fwd_split_kernel(const ImgSrc x, co
 #ifdef C2S_TS
   if (blockIdx.x == 0 && tid == 0) { g_c2s_ts[192] = clock64() - ts_c0; g_c2s_ts[193] = wall_clock64() - ts_w0; g_c2s_ts[194] = band_no + 1; }
 #endif
+}
+
+
+// ==================================================================================================================================
+// DATA GRADIENT of conv2 (+ conv1's ReLU mask + conv1's weight / bias gradient), the split twin of c2::conv12_dgrad_kernel: same
+// inputs, same slab out, same band walk (one image x 8 a1 rows per band, one persistent 512-thread workgroup per CU), same hand-over
+// of a finished row half to the conv1 weight-gradient MFMAs (c2::D12Pend; those stay on the fp32 pipe: K = positions, 8 per half).
+//
+// d a1[pos][ci] = sum over (tap, co) of dY[pos'(tap)][co] W2[co][ci][tap] runs over K = (tap, co) in blocks of 32 on
+// v_mfma_f32_16x16x32_bf16: A = the un-pooled dY (16 conv2 columns ox = 16 xh + lr of one row, 8 consecutive co per lane), B = the
+// wave's 16 input channels of W2 (pieces in registers).  The dY patch of a band is three piece planes [row 5][col 33][co 48] bf16,
+// DENSE - 96 bytes per position - so that a K run continues from position ox into ox + 1: for an odd a1 column x = 2 ox + 1 the
+// two taps of a tap row are kx = 2 at ox and kx = 0 at ox + 1, i.e. 96 consecutive co-slots = three K blocks whose fragments sit at
+// lane base + 0 / 64 / 128 bytes.  The even column's single tap kx = 1 (48 co = 1.5 blocks) reads the first two of the SAME
+// fragments against weights that are zero in the last two k-groups.  So a tap row costs 3 fragment reads x 3 pieces and 5 blocks x 6
+// piece products; an even a1 row has one tap row (ky = 1), an odd one two (ky = 2 on dY row (y - 1) / 2, ky = 0 on the row below).
+// Waves specialise by row parity - wave = (ci tile nt, parity PY, row group g): 60 / 120 weight registers, 30 / 60 MFMAs per half
+// - and the two waves of a SIMD (w, w + 4) have different parities, so every SIMD issues the same 360 MFMAs per band.
+// A 16-lane group of a ds_read_b128 covers the 64 banks once (position stride 24 dwords, k-group stride 4).
+// ==================================================================================================================================
+namespace dg {
+constexpr int NT2 = c2::NT2;
+constexpr int DCOLS = 33, DPOSB = 96, DROWB = DCOLS * DPOSB, DPLANEB = 5 * DROWB;       // 3,168 B per row, 15,840 B per piece plane
+constexpr int DYPB = 3 * DPLANEB;                                                          // 47,520 B
+constexpr int STRIPB = c2::STRIP_FLOATS * 4;                                               // 8,976 B
+constexpr int BUFB = DYPB + STRIPB;                                                        // 56,496 B per band buffer
+constexpr int LDS_BYTES = 2 * BUFB + 8 * 16 * 16 * 4;                                      // 121,184 B
+static_assert(LDS_BYTES <= 160 * 1024 && BUFB % 16 == 0 && DPLANEB % 16 == 0, "LDS");
+static_assert(COUT * c2::W2_LD * 4 <= 2 * BUFB, "weight staging area");
+
+__device__ __forceinline__ bf16x8_t dfrag(const unsigned char* base, int off) {
+  return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(base + off));
+}
+
+// the six piece products of one K block for the odd-column accumulators (d: hh | ds: the five small ones) and - for the first
+// two blocks of a tap row - the even-column ones (e | es) on the same fragments; the chains alternate
+template <bool WITH_E>
+__device__ __forceinline__ void block6(const bf16x8_t (&a)[3], const bf16x8_t (&wd)[3], const bf16x8_t (&we)[3],
+                                       f32x4_t& e, f32x4_t& es, f32x4_t& d, f32x4_t& ds) {
+  ds = mfma_bf16(a[2], wd[0], ds);
+  if (WITH_E) es = mfma_bf16(a[2], we[0], es);
+  ds = mfma_bf16(a[1], wd[0], ds);
+  if (WITH_E) es = mfma_bf16(a[1], we[0], es);
+  ds = mfma_bf16(a[1], wd[1], ds);
+  if (WITH_E) es = mfma_bf16(a[1], we[1], es);
+  d = mfma_bf16(a[0], wd[0], d);
+  if (WITH_E) e = mfma_bf16(a[0], we[0], e);
+  ds = mfma_bf16(a[0], wd[1], ds);
+  if (WITH_E) es = mfma_bf16(a[0], we[1], es);
+  ds = mfma_bf16(a[0], wd[2], ds);
+  if (WITH_E) es = mfma_bf16(a[0], we[2], es);
+}
+
+// One row half (a1 row yl of the band, columns 32 xh ..): NR = 1 + PY tap rows of 3 blocks.  wd[3 NR][piece], we[2 NR][piece].
+template <int PY, bool HAS_PREV>
+__device__ __forceinline__ void half(const unsigned char* dyp, const float* strip, const bf16x8_t (&wd)[3 * (1 + PY)][3],
+                                     const bf16x8_t (&we)[2 * (1 + PY)][3], const unsigned* __restrict__ mrow, f32x4_t& z, f32x4_t& z2,
+                                     int yl, int xh, const c2::D12Lane& ln, const c2::D12Pend& prev, c2::D12Pend& out) {
+  constexpr int NR = 1 + PY, NB = 3 * NR;
+  const int lq = ln.lq;
+  const unsigned* mrec = mrow + (2 * xh + (lq >> 1)) * c2::M1_REC + 2 * (ln.ci >> 4) + (lq & 1);
+  uint4 mb;
+  mb.x = mrec[0]; mb.y = mrec[4]; mb.z = mrec[8]; mb.w = mrec[12];
+  float t0[4], t1[4];
+  if (HAS_PREV) c2::d12_pend_taps(strip, prev, t0, t1);
+  // dY row of the first tap row: even a1 row y: ky = 1 at y / 2; odd: ky = 2 at (y - 1) / 2, then ky = 0 one row further down
+  const unsigned char* base = dyp + ((yl >> 1) * DCOLS + 16 * xh + ln.lr) * DPOSB + 16 * lq;
+  f32x4_t e = {0.f, 0.f, 0.f, 0.f}, es = e, d = e, ds = e;
+  bf16x8_t a[2][3];
+  auto fetch = [&](int b, int slot) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[slot][p] = dfrag(base, (b / 3) * DROWB + 64 * (b % 3) + p * DPLANEB);
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) fetch(b + 1, (b + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (b % 3 < 2) block6<true>(a[b & 1], wd[b], we[2 * (b / 3) + b % 3], e, es, d, ds);
+    else block6<false>(a[b & 1], wd[b], wd[b], e, es, d, ds);
+    if (HAS_PREV) {          // the previous half's masks + conv1 weight-gradient MFMAs, spread over this half's blocks
+      if (NB == 3) { c2::d12_pend_step(prev, b, t0[b], t1[b], ln, z, z2); if (b == 2) c2::d12_pend_step(prev, 3, t0[3], t1[3], ln, z, z2); }
+      else if (b < 4) c2::d12_pend_step(prev, b, t0[b], t1[b], ln, z, z2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { out.e[r] = e[r] + es[r]; out.d[r] = d[r] + ds[r]; }
+  out.mb = mb;
+  out.tpoff = (2 * yl) * c2::SRS + ln.toff + 4 * (16 * xh + 4 * lq);
+}
+
+// the wave's weight fragments from the staged [48][289] matrix: block b of the odd-column run of tap row ky holds k-groups
+// G = 4 (b % 3) + lq: G < 6 -> tap (ky, 2), co = 8 G ..; else tap (ky, 0), co = 8 (G - 6) ..; the even-column run (two blocks) holds
+// tap (ky, 1), co = 8 G .. for G < 6 and zeros behind
+__device__ __forceinline__ void wfrag(const float* stage, int ci, int tap, int co0, float sign_or_zero, bf16x8_t (&out)[3]) {
+  unsigned v[3][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* sp = stage + (co0 + 2 * i) * c2::W2_LD + ci * 9 + tap;
+    const float w0 = sp[0] * sign_or_zero, w1 = sp[c2::W2_LD] * sign_or_zero;
+    split3_pk(w0, w1, v[0][i], v[1][i], v[2][i]);
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) out[p] = __builtin_bit_cast(bf16x8_t, u32x4_t{v[p][0], v[p][1], v[p][2], v[p][3]});
+}
+
+template <int PY>
+__device__ __forceinline__ void run(unsigned char* lds, const ImgSrc& x, const unsigned* __restrict__ m1, const float* __restrict__ dp2,
+                                    const float* __restrict__ p2, const uint8_t* __restrict__ amax, float* __restrict__ slab1, int n_img,
+                                    int tid, int lane, int wave) {
+  constexpr int NR = 1 + PY;
+  const int nt = wave & 1, g = (wave >> 1) & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ci = 16 * nt + lr;
+  float* red = reinterpret_cast<float*>(lds + 2 * BUFB);
+
+  // v_mfma_f32_16x16x32_bf16 adds in four steps of eight products, and in every step FLOORS all nine addends - the accumulator
+  // included - to 25 bits below the step's largest product before it sums them (scripts/micro/mfma_bf16_accum.hip): a small
+  // accumulator that passes a step of huge products loses its low bits towards minus infinity even when those products cancel.
+  // One such loss is no larger than the fp32 chain's rounding in the same spot, but it always points the same way, and the conv1
+  // weight gradient sums d a1 over every position of the batch.  So half of the waves (row group g = 1) hold the NEGATED weights:
+  // their accumulators carry -d a1 with the same downward losses, the sign comes back for free in the tap operand of the conv1
+  // weight-gradient MFMAs (tmask / tconst), and over the two row groups of a band the losses cancel instead of adding up.
+  const float sg = g ? -1.f : 1.f;
+  bf16x8_t wd[3 * NR][3], we[2 * NR][3];
+  {
+    const float* stage = reinterpret_cast<const float*>(lds);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int ky = PY ? (r == 0 ? 2 : 0) : 1;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int G = 4 * b + lq;
+        wfrag(stage, ci, ky * 3 + (G < 6 ? 2 : 0), 8 * (G < 6 ? G : G - 6), sg, wd[3 * r + b]);
+        if (b < 2) wfrag(stage, ci, ky * 3 + 1, 8 * (G < 6 ? G : 0), G < 6 ? sg : 0.f, we[2 * r + b]);
+      }
+    }
+  }
+  __syncthreads();        // the staging area becomes the band buffers
+  const int toff = lr < 9 ? (lr / 3) * c2::SRS + lr % 3 : 0;
+  const c2::D12Lane ln{ci, lr, lq, toff, lr < 9 ? sg : 0.f, lr == 9 ? sg : 0.f, (unsigned)(ci & 15), (unsigned)(ci & 15) + 16u};
+  f32x4_t z = {0.f, 0.f, 0.f, 0.f}, z2 = z;
+
+  for (int bsel = 0; bsel < 2; ++bsel) {
+    unsigned char* b0 = lds + bsel * BUFB;
+    float* stripb = reinterpret_cast<float*>(b0 + DYPB);
+    for (int i = tid; i < 3 * 5 * (DPOSB / 4); i += NT2)       // halo column 32 of every row and piece
+      reinterpret_cast<unsigned*>(b0 + (i / (5 * 24)) * DPLANEB + ((i / 24) % 5) * DROWB + 32 * DPOSB)[i % 24] = 0u;
+    for (int i = tid; i < 17; i += NT2) stripb[i * c2::SRS] = 0.f;                                   // ix = -1 column
+  }
+  const int ntiles = n_img * 8;
+  // pooled cells of a band in pairs of adjacent output channels (one dword of packed pieces): 24 pairs x 3 pooled rows x 16 px
+  float cdp[3][2], cp[3][2]; unsigned cam[3][2];
+  float4 sv[2];
+  auto cells_fetch = [&](int t) {
+    const int img = t >> 3, band = t & 7;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int e = tid + j * NT2, px = e & 15, q = e >> 4, pr = q % 24, pyl = q / 24;
+      const int py = 2 * band + pyl;
+      cdp[j][0] = cdp[j][1] = 0.f; cp[j][0] = cp[j][1] = 0.f; cam[j][0] = cam[j][1] = 0u;
+      if (e < 1152 && py < 16) {
+        const size_t o = (((size_t)img * COUT + 2 * pr) * 16 + py) * 16 + px;
+        cdp[j][0] = dp2[o]; cp[j][0] = p2[o]; cam[j][0] = amax[o];
+        cdp[j][1] = dp2[o + 256]; cp[j][1] = p2[o + 256]; cam[j][1] = amax[o + 256];
+      }
+    }
+    const float* xi = x.img(img);       // image strip: 17 rows x 32 float4
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * NT2, row = e >> 5, x4 = e & 31;
+      const int iy = 16 * band - 1 + row;
+      sv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < 17 * 32 && iy >= 0) sv[j] = *reinterpret_cast<const float4*>(xi + iy * 128 + 4 * x4);
+    }
+  };
+  auto cells_store = [&](unsigned char* b0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int e = tid + j * NT2, px = e & 15, q = e >> 4, pr = q % 24, pyl = q / 24;
+      if (e < 1152) {
+        unsigned pc[3];
+        split3_pk(cp[j][0] > 0.f ? cdp[j][0] : 0.f, cp[j][1] > 0.f ? cdp[j][1] : 0.f, pc[0], pc[1], pc[2]);
+        unsigned char* d = b0 + ((2 * pyl) * DCOLS + 2 * px) * DPOSB + 4 * pr;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {          // window position (row w4 >> 1, column w4 & 1): the pair's pieces where its arg-max points
+          if (w4 >= 2 && pyl == 2) continue;      // the halo pooled row gives only its upper row
+          const unsigned m = (cam[j][0] == (unsigned)w4 ? 0xffffu : 0u) | (cam[j][1] == (unsigned)w4 ? 0xffff0000u : 0u);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + (w4 >> 1) * DROWB + (w4 & 1) * DPOSB + p * DPLANEB) = pc[p] & m;
+        }
+      }
+    }
+    float* stripb = reinterpret_cast<float*>(b0 + DYPB);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * NT2, row = e >> 5, x4 = e & 31;
+      if (e < 17 * 32) {
+        float* d = stripb + row * c2::SRS + 1 + 4 * x4;
+        d[0] = sv[j].x; d[1] = sv[j].y; d[2] = sv[j].z; d[3] = sv[j].w;
+      }
+    }
+  };
+  int tile = c2::first_tile<8>(blockIdx.x, gridDim.x);
+  __syncthreads();
+  if (tile < ntiles) { cells_fetch(tile); cells_store(lds); }
+  if (tile + (int)gridDim.x < ntiles) cells_fetch(tile + gridDim.x);
+  __syncthreads();
+  int cur = 0;
+  for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+    const unsigned char* dyp = lds + cur * BUFB;
+    const float* strip = reinterpret_cast<const float*>(dyp + DYPB);
+    const int img = tile >> 3, band = tile & 7;
+    // this wave's a1 rows of the band: PY + 4 g and PY + 4 g + 2, both column halves
+    const int y0 = PY + 4 * g;
+    const unsigned* mrow = m1 + ((size_t)img * 64 + 8 * band + y0) * 64;
+    c2::D12Pend pa, pb;
+    half<PY, false>(dyp, strip, wd, we, mrow, z, z2, y0, 0, ln, pb, pa);
+    half<PY, true>(dyp, strip, wd, we, mrow, z, z2, y0, 1, ln, pa, pb);
+    const int next = tile + (int)gridDim.x;
+    if (next < ntiles) {
+      cells_store(lds + (cur ^ 1) * BUFB);
+      if (next + (int)gridDim.x < ntiles) cells_fetch(next + gridDim.x);
+    }
+    half<PY, true>(dyp, strip, wd, we, mrow + 128, z, z2, y0 + 2, 0, ln, pb, pa);
+    half<PY, true>(dyp, strip, wd, we, mrow + 128, z, z2, y0 + 2, 1, ln, pa, pb);
+    c2::d12_flush(strip, pb, ln, z, z2);
+    __syncthreads();
+  }
+  // conv1 gradient partials: wave (nt, PY, g) holds Z[ci = 16 nt + 4 lq + r][tap column lr] of its rows
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * lq + r) * 16 + lr] = z[r] + z2[r];
+}
+}  // namespace dg
+
+__global__ __launch_bounds__(dg::NT2) void conv12_dgrad_split_kernel(const ImgSrc x, const unsigned* __restrict__ m1,
+                                                                      const float* __restrict__ dp2, const float* __restrict__ p2,
+                                                                      const uint8_t* __restrict__ amax, const float* __restrict__ w,
+                                                                      float* __restrict__ slab1, int n_img) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[dg::LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  c2::conv2w_stage<dg::NT2>(reinterpret_cast<float*>(lds), w, tid);
+  __syncthreads();
+  if (wave & 4) dg::run<1>(lds, x, m1, dp2, p2, amax, slab1, n_img, tid, lane, wave);
+  else dg::run<0>(lds, x, m1, dp2, p2, amax, slab1, n_img, tid, lane, wave);
+  __syncthreads();
+  const float* red = reinterpret_cast<const float*>(lds + 2 * dg::BUFB);
+  {
+    const int c = tid >> 4, q = tid & 15, ntc = c >> 4, cl = c & 15;     // channel c, tap column q; waves with (wave & 1) == ntc hold it
+    float sacc = 0.f;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) sacc += red[((2 * g4 + ntc) * 16 + cl) * 16 + q];
+    if (q < 10) slab1[(size_t)blockIdx.x * 320 + (q < 9 ? c * 9 + q : 288 + c)] = sacc;     // [block][32 x 9 weights | 32 biases]
+  }
 }
 
 }  // namespace c2s

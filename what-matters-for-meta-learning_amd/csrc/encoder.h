@@ -87,6 +87,48 @@ inline EncScratch enc_scratch_carve(int n, int dim_w, void* base, size_t cap) {
 }
 inline size_t enc_scratch_bytes(int n, int dim_w) { return enc_scratch_carve(n, dim_w, nullptr, 0).bytes; }
 
+#ifndef MLHOT_HOSTSIM
+// conv1 + ReLU + conv2 + ReLU + 2x2 max-pool in one kernel (a1 is recomputed band by band in LDS and never stored): p2, the pool
+// arg-max and conv1's ReLU sign bits land in `sv`.  Option conv2_split: bit 1 forward, bit 2 data gradient, bit 4 weight gradient
+// run conv2 on the bf16 pipe over split operands (conv_split.h) - same inputs, same outputs' layout.
+inline int conv12_forward(const c2::ImgSrc& xs, int n, const float* w1, const float* b1, const float* w2, const float* b2,
+                          const EncSaved& sv, hipStream_t s) {
+  if (g_opt.conv2_split & 1) {
+    const int grid2 = n * 16 < C2_GRID ? n * 16 : C2_GRID;
+    ProfScope ps("enc.conv12.split", s);
+    hipLaunchKernelGGL(c2s::conv12_fwd_split_kernel, dim3(grid2), dim3(c2s::NT), 0, s, xs, w1, b1, w2, b2, sv.p2, sv.am2, sv.m1, n);
+  } else {
+    const int grid = n * 8 < C2_GRID ? n * 8 : C2_GRID;
+    ProfScope ps("enc.conv12", s);
+    hipLaunchKernelGGL(c2::conv12_fwd_pool_kernel, dim3(grid), dim3(c2::NT), 0, s, xs, w1, b1, w2, b2, sv.p2, sv.am2, sv.m1, n, g_opt.dbg);
+  }
+  return check_launch("enc.conv12");
+}
+// the block's two backward kernels: slab_w / slab_b rows of R2 = 48 * 288 + 48 floats per workgroup ([dW2 in accumulator order | db2]),
+// slab_1 rows of 320 ([dW1 | db1]); the caller folds the `grid` rows
+constexpr int C12_L2 = 48 * 288, C12_R2 = C12_L2 + 48;
+inline int conv12_grid(int n) { return n * 8 < C2_GRID ? n * 8 : C2_GRID; }
+template <class Between>          // between(): called behind the weight-gradient launch (the caller's slab fold beside the next kernel)
+inline int conv12_backward(const c2::ImgSrc& xs, int n, const float* w1, const float* b1, const float* w2, const float* dp2,
+                           const EncSaved& sv, float* slab_w, float* slab_b, float* slab_1, hipStream_t s, Between&& between) {
+  const int grid = conv12_grid(n);
+  {
+    ProfScope ps("enc.bwd.conv12.wgrad", s);
+    hipLaunchKernelGGL(c2::conv12_wgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, xs, w1, b1, dp2, sv.p2, sv.am2, slab_w, slab_b, n, g_opt.dbg);
+  }
+  MLHOT_TRY(check_launch("enc.bwd.conv12.wgrad"));
+  MLHOT_TRY(between());
+  if (g_opt.conv2_split & 2) {
+    ProfScope ps("enc.bwd.conv12.dgrad.split", s);
+    hipLaunchKernelGGL(c2s::conv12_dgrad_split_kernel, dim3(grid), dim3(c2s::dg::NT2), 0, s, xs, sv.m1, dp2, sv.p2, sv.am2, w2, slab_1, n);
+  } else {
+    ProfScope ps("enc.bwd.conv12.dgrad", s);
+    hipLaunchKernelGGL(c2::conv12_dgrad_kernel, dim3(grid), dim3(c2::NT2), 0, s, xs, sv.m1, dp2, sv.p2, sv.am2, w2, slab_1, n);
+  }
+  return check_launch("enc.bwd.conv12.dgrad");
+}
+#endif
+
 inline int enc_forward(const float* img0, int n0, const float* img1, int n1, const mlhot_enc_params& p, int dim_w,
                        Rows2 feat, void* saved, void* scratch, size_t scratch_bytes, hipStream_t s) {
   const int n = n0 + n1;
@@ -99,19 +141,7 @@ inline int enc_forward(const float* img0, int n0, const float* img1, int n1, con
   if (g_opt.conv2_tc) {
     // conv1 + conv2 + pool in one kernel: a1 is recomputed band by band in LDS and never stored
     if (g_opt.materialize_a1) MLHOT_TRY(run_foreach(Conv1Fwd<Src2>{x, p.w1, p.b1, sv.a1}, (size_t)n * 4096, s, "enc.conv1.debug"));
-    const int grid = n * 8 < C2_GRID ? n * 8 : C2_GRID;
-    if (g_opt.conv2_split) {
-      // conv2 on the bf16 pipe with hi / mid / lo split operands (conv_split.h): same outputs' layout, opt-in
-      const int grid2 = n * 16 < C2_GRID ? n * 16 : C2_GRID;
-      ProfScope ps("enc.conv12.split", s);
-      hipLaunchKernelGGL(c2s::conv12_fwd_split_kernel, dim3(grid2), dim3(c2s::NT), 0, s, c2::ImgSrc{img0, n0, img1}, p.w1, p.b1,
-                         p.w2, p.b2, sv.p2, sv.am2, sv.m1, n);
-    } else {
-      ProfScope ps("enc.conv12", s);
-      hipLaunchKernelGGL(c2::conv12_fwd_pool_kernel, dim3(grid), dim3(c2::NT), 0, s, c2::ImgSrc{img0, n0, img1}, p.w1, p.b1,
-                         p.w2, p.b2, sv.p2, sv.am2, sv.m1, n, g_opt.dbg);
-    }
-    MLHOT_TRY(check_launch("enc.conv12"));
+    MLHOT_TRY(conv12_forward(c2::ImgSrc{img0, n0, img1}, n, p.w1, p.b1, p.w2, p.b2, sv, s));
   } else
 #endif
   {
@@ -271,26 +301,17 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
   const DyPooled<48, 32, 32> dy2{sc.dp2, sv.p2, sv.am2};
 #ifndef MLHOT_HOSTSIM
   if (g_opt.conv2_tc) {
-    const int grid = n * 8 < C2_GRID ? n * 8 : C2_GRID;
-    constexpr int L2 = 48 * 288, R2 = L2 + 48;          // slab row = [dW2 | db2], see conv3 above
+    const int grid = conv12_grid(n);
+    constexpr int L2 = C12_L2, R2 = C12_R2;             // slab row = [dW2 | db2], see conv3 above
     float* slab_w = sc.slab + (size_t)C2_GRID * (64 * 433);      // behind conv3's region
     float* slab_b = slab_w + L2;
     float* slab_1 = slab_w + (size_t)C2_GRID * R2;
-    const c2::ImgSrc xs{img0, n0, img1};
-    {
-      ProfScope ps("enc.bwd.conv12.wgrad", s);
-      hipLaunchKernelGGL(c2::conv12_wgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, xs, p.w1, p.b1, sc.dp2, sv.p2, sv.am2, slab_w, slab_b, n, g_opt.dbg);
-    }
-    MLHOT_TRY(check_launch("enc.bwd.conv12.wgrad"));
-    // the weights sit in the slab in accumulator order (coalesced stores in the kernel); the fold un-permutes them
-    pend(slab_w, g.w2, grid, L2, R2, 1);
-    pend(slab_b, g.b2, grid, 48, R2);
-    MLHOT_TRY(fold_aside());
-    {
-      ProfScope ps("enc.bwd.conv12.dgrad", s);
-      hipLaunchKernelGGL(c2::conv12_dgrad_kernel, dim3(grid), dim3(c2::NT2), 0, s, xs, sv.m1, sc.dp2, sv.p2, sv.am2, p.w2, slab_1, n);
-    }
-    MLHOT_TRY(check_launch("enc.bwd.conv12.dgrad"));
+    MLHOT_TRY(conv12_backward(c2::ImgSrc{img0, n0, img1}, n, p.w1, p.b1, p.w2, sc.dp2, sv, slab_w, slab_b, slab_1, s, [&]() -> int {
+      // the weights sit in the slab in accumulator order (coalesced stores in the kernel); the fold un-permutes them
+      pend(slab_w, g.w2, grid, L2, R2, 1);
+      pend(slab_b, g.b2, grid, 48, R2);
+      return fold_aside();
+    }));
     if (g.b1 == g.w1 + 288 && (reinterpret_cast<uintptr_t>(g.w1) & 15) == 0) {
       pend(slab_1, g.w1, grid, 320, 320);           // conv1's gradients came out of the dgrad kernel
     } else {

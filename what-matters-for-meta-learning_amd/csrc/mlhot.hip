@@ -157,6 +157,52 @@ int mlhot_enc_vanilla_bwd(const float* img0, int n0, const float* img1, int n1, 
                       scratch, scratch_bytes, (hipStream_t)stream);
 }
 
+// ---- E1's first block on its own: conv1 + ReLU + conv2 + ReLU + 2x2 max-pool (tests and micro-benchmarks of the kernels that
+// carry 80 % of the vanilla models' FLOPs; `saved` has the layout of mlhot_enc_vanilla_saved_bytes) -------------------------------
+size_t mlhot_conv12_scratch_bytes(int n_img) {
+#ifndef MLHOT_HOSTSIM
+  return ((size_t)conv12_grid(n_img < 1 ? 1 : n_img) * (C12_R2 + 320)) * sizeof(float) + 256;
+#else
+  (void)n_img; return 256;
+#endif
+}
+int mlhot_conv12_fwd(const float* img, int n_img, const float* w1, const float* b1, const float* w2, const float* b2, void* saved,
+                     void* stream) {
+  if (n_img < 0 || !w1 || !b1 || !w2 || !b2 || !saved) { set_error("conv12_fwd: bad argument"); return MLHOT_ERR_ARG; }
+  if (n_img == 0) return MLHOT_OK;
+#ifndef MLHOT_HOSTSIM
+  return conv12_forward(c2::ImgSrc{img, n_img, nullptr}, n_img, w1, b1, w2, b2, enc_saved_carve(n_img, saved, (size_t)-1 / 2),
+                        (hipStream_t)stream);
+#else
+  (void)img; (void)stream; set_error("conv12_fwd: GPU build only"); return MLHOT_ERR_ARG;
+#endif
+}
+int mlhot_conv12_bwd(const float* img, int n_img, const float* w1, const float* b1, const float* w2, const float* dp2,
+                     const void* saved, float* dw1, float* db1, float* dw2, float* db2, void* scratch, size_t scratch_bytes,
+                     void* stream) {
+  if (n_img <= 0 || !w1 || !b1 || !w2 || !dp2 || !saved || !dw1 || !db1 || !dw2 || !db2) { set_error("conv12_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  if (scratch_bytes < mlhot_conv12_scratch_bytes(n_img)) { set_error("conv12_bwd: scratch too small"); return MLHOT_ERR_WORKSPACE; }
+#ifndef MLHOT_HOSTSIM
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = conv12_grid(n_img);
+  float* slab_w = reinterpret_cast<float*>(scratch);
+  float* slab_1 = slab_w + (size_t)grid * C12_R2;
+  MLHOT_TRY(conv12_backward(c2::ImgSrc{img, n_img, nullptr}, n_img, w1, b1, w2, dp2, enc_saved_carve(n_img, (void*)saved, (size_t)-1 / 2),
+                            slab_w, slab_w + C12_L2, slab_1, s, []() -> int { return MLHOT_OK; }));
+  c2::SumPartsMulti mp{};
+  mp.seg[0] = c2::SumParts{slab_w, dw2, grid, C12_L2, C12_R2, 1};
+  mp.seg[1] = c2::SumParts{slab_w + C12_L2, db2, grid, 48, C12_R2, 0};
+  mp.first[1] = c2::sum_parts_blocks(C12_L2);
+  mp.first[2] = mp.first[1] + c2::sum_parts_blocks(48);
+  mp.n = 2;
+  hipLaunchKernelGGL(c2::sum_parts_multi_kernel, dim3(mp.first[2]), dim3(256), 0, s, mp);
+  hipLaunchKernelGGL(c2::conv1_grads_kernel, dim3(16), dim3(320), 0, s, slab_1, grid, dw1, db1);
+  return check_launch("conv12_bwd");
+#else
+  (void)img; (void)stream; set_error("conv12_bwd: GPU build only"); return MLHOT_ERR_ARG;
+#endif
+}
+
 // ---- linear -----------------------------------------------------------------------------------
 size_t mlhot_linear_bwd_scratch_bytes(int M, int K, int N) { (void)M; (void)K; (void)N; return 256; }
 

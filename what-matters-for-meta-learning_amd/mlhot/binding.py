@@ -22,7 +22,7 @@ LOSS = {"azimuth": 0, "mse": 1, "quaternion": 2, "degree": 3, "distractor": 4}
 _f = C.c_void_p  # every device pointer travels as void*
 
 
-ABI_VERSION = 2     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients)
+ABI_VERSION = 3     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients; 3: + conv12_fwd / _bwd)
 
 
 class MlhotError(RuntimeError):
@@ -178,8 +178,9 @@ class MlhotLib:
         c.mlhot_last_error.restype = C.c_char_p
         for fn in ("mlhot_enc_vanilla_saved_bytes", "mlhot_enc_vanilla_scratch_bytes", "mlhot_linear_bwd_scratch_bytes",
                    "mlhot_favor_ws_bytes", "mlhot_np_struct_bytes", "mlhot_np_saved_bytes", "mlhot_np_scratch_bytes",
-                   "mlhot_np_grads_flat_layout"):
+                   "mlhot_np_grads_flat_layout", "mlhot_conv12_scratch_bytes"):
             getattr(c, fn).restype = C.c_size_t
+        c.mlhot_conv12_scratch_bytes.argtypes = [C.c_int]
         c.mlhot_enc_vanilla_saved_bytes.argtypes = [C.c_int]
         c.mlhot_enc_vanilla_scratch_bytes.argtypes = [C.c_int, C.c_int]
         c.mlhot_favor_ws_bytes.argtypes = [C.c_int] * 6
@@ -190,6 +191,8 @@ class MlhotLib:
         i, z, P = C.c_int, C.c_size_t, C.c_void_p
         c.mlhot_enc_vanilla_fwd.argtypes = [P, i, P, i, C.POINTER(EncParams), i, P, i, P, i, P, P, z, P]
         c.mlhot_enc_vanilla_bwd.argtypes = [P, i, P, i, C.POINTER(EncParams), i, P, i, P, i, P, C.POINTER(EncParams), P, z, P]
+        c.mlhot_conv12_fwd.argtypes = [P, i, P, P, P, P, P, P]
+        c.mlhot_conv12_bwd.argtypes = [P, i, P, P, P, P, P, P, P, P, P, P, z, P]
         c.mlhot_linear_fwd.argtypes = [P, i, P, P, P, i, i, i, i, i, P]
         c.mlhot_linear_bwd.argtypes = [P, i, P, P, i, P, i, i, i, i, i, P, i, i, P, P, P, z, P]
         c.mlhot_agg_fwd.argtypes = [i, P, P, i, i, i, P, P, P, P]
@@ -279,6 +282,29 @@ class MlhotLib:
                                               _ptr(feat1), dim_w, _ptr(saved), _ptr(scratch), sb, _stream(img0)),
                  "mlhot_enc_vanilla_fwd")
         return feat0, feat1, saved
+
+    def conv12_fwd(self, img, w1, b1, w2, b2):
+        """The encoder's first block on its own (conv1 + ReLU + conv2 + ReLU + 2x2 max-pool of [n,1,128,128] images) ->
+        (p2 [n,48,16,16], arg-max uint8 [n,48,16,16], saved); `saved` as enc_vanilla_fwd's (enc_saved_views / enc_routes)."""
+        _chk(img, w1, b1, w2, b2)
+        n = img.shape[0]
+        saved = self._bytes(self.c.mlhot_enc_vanilla_saved_bytes(n), img)
+        self._rc(self.c.mlhot_conv12_fwd(_ptr(img), n, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(saved), _stream(img)),
+                 "mlhot_conv12_fwd")
+        _, p2, am2, _ = self.enc_saved_views(saved, n)
+        return p2, am2, saved
+
+    def conv12_bwd(self, img, w1, b1, w2, dp2, saved):
+        """d p2 [n,48,16,16] -> (dw1, db1, dw2, db2) of the block."""
+        _chk(img, w1, b1, w2, dp2)
+        n = img.shape[0]
+        dw1, db1, dw2 = torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2)
+        db2 = torch.empty(48, device=img.device)
+        sb = self.c.mlhot_conv12_scratch_bytes(n)
+        scratch = self._bytes(sb, img)
+        self._rc(self.c.mlhot_conv12_bwd(_ptr(img), n, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(dp2), _ptr(saved), _ptr(dw1), _ptr(db1),
+                                         _ptr(dw2), _ptr(db2), _ptr(scratch), sb, _stream(img)), "mlhot_conv12_bwd")
+        return dw1, db1, dw2, db2
 
     @staticmethod
     def enc_saved_views(saved, n):
