@@ -490,14 +490,24 @@ def measure_extras(w, device, loss_fn, batch, iters):
             model.zero_grad(set_to_none=True)
             loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
 
-        lib().set_option("conv2_split", 1)
-        try:
-            out["split_precision_conv2"] = {
-                "fwd_only_ms": _time_graph(fwd, iters), "step_ms": _time_graph(step, iters),
-                "arithmetic": "conv2 forward: v_mfma_f32_16x16x32_bf16 over 3-piece bf16 splits of fp32 operands, 6 of 9 piece "
-                              "products, fp32 accumulation; everything else fp32 as in `value`"}
-        finally:
-            lib().set_option("conv2_split", 0)
+        # bits: 1 forward, 2 data gradient, 4 weight gradient.  Its own roof next to the fp32 one: the bf16 matrix pipe's dense 2.5 PFLOP/s
+        # (MI355X_MICROARCH.md) / 6 piece products = 417 fp32-equivalent TFLOP/s (fp32 MFMA: 157.3)
+        def split_run(bits):
+            lib().set_option("conv2_split", bits)
+            try:
+                r = {"fwd_only_ms": _time_graph(fwd, iters), "step_ms": _time_graph(step, iters)}
+            finally:
+                lib().set_option("conv2_split", 0)
+            r["tasks_per_s"] = round(w["T"] / (r["step_ms"] * 1e-3), 1)
+            return r
+        out["split_precision_conv2"] = {
+            "forward": split_run(1), "forward_and_gradients": split_run(7),
+            "dtype": "bf16x3-split fp32 (conv2 of the vanilla encoder only; fp32 everywhere else)",
+            "arithmetic": "v_mfma_f32_16x16x32_bf16 over 3-piece nearest-even bf16 splits of both fp32 operands (x = hi + mid + lo exactly), "
+                          "6 of 9 piece products (dropped: below 2^-26 of a product), fp32 accumulation; csrc/conv_split.h",
+            "roof": {"peak_tflops_fp32_equivalent": round(2500.0 / 6, 1), "from": "2.5 PFLOP/s dense bf16 / 6 products", "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS},
+            "error_vs_float64": "tests/test_gpu_parity.py::test_split_precision_error_vs_fp32_mfma (forward 0.2-0.8 x the fp32 kernels' error, gradients 0.2-2.5 x)",
+            "note": "opt-in (mlhot_set_option conv2_split); never in `value`"}
         # PCIe-inclusive view (the reference hands over HOST batches, model_trainer.py:63-70): pinned host -> device copy of
         # one batch's images + labels, NOT overlapped with compute; `value` above never includes it
         host = [t.detach().cpu().pin_memory() for t in (cx, qx, cy, qy)]

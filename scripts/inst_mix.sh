@@ -1,12 +1,12 @@
 #!/bin/bash
 # Instruction mix per kernel (wave-instructions per launch, and per MFMA): rocprofv3 --pmc SQ_INSTS_* over a few eager steps.
-# usage (GPU box): bash scripts/inst_mix.sh c3|c5
+# usage (GPU box): bash scripts/inst_mix.sh c3|c5 [extra bench.py arguments, e.g. --opt conv2_split=7]
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 WL=${1:-c3}
 OUT=$REPO/gpurun_out/mix_$WL
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT -o mix -- python3 $REPO/bench.py --workload $WL --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/run.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT -o mix -- python3 $REPO/bench.py --workload $WL --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 ${@:2} > $OUT/run.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 path = sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True))[0]

@@ -6,7 +6,7 @@ WL=${1:-c3}
 OUT=$REPO/gpurun_out/lds_$WL
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT -o lds -- python3 $REPO/bench.py --workload $WL --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/run.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT -o lds -- python3 $REPO/bench.py --workload $WL --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 ${@:2} > $OUT/run.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 path = sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True))[0]

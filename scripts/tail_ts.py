@@ -28,6 +28,8 @@ loss_fn = LossFunc("mse", "shapenet_1d")
 cx, qx, cy, qy = synth.get_batch("shapenet_1d", 16, 15, 15, seed=1234, device=dev)
 ts = torch.zeros(512, dtype=torch.int64, device=dev)
 L = mlhot.lib()
+for kv in filter(None, os.environ.get("MLHOT_OPTS", "").split(",")):       # e.g. MLHOT_OPTS=conv2_split=7
+    L.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 L.c.mlhot_dbg_tsbuf.argtypes = [ctypes.c_void_p]
 assert L.c.mlhot_dbg_tsbuf(ts.data_ptr()) == 0
 acc = None
@@ -83,7 +85,8 @@ if raw[0][0]:
 raw = ts.cpu()[360:420].view(12, 5).tolist()
 if raw[0][0]:
     t0 = min(r[0] for r in raw)
-    print("conv12 wgrad per-wave band timeline [previous band's MFMAs done, barrier passed, conv1 + dY staged, barrier passed, MFMAs done] (cycles):")
+    print("conv12 wgrad per-wave band timeline (cycles) - fp32 kernel: [previous band's MFMAs done, barrier passed, conv1 + dY staged, barrier passed, MFMAs done]; "
+          "split kernel: [band start, conv1 tiles done, dY cell stored, barrier passed, MFMAs done]:")
     for w, r in enumerate(raw):
         print("  wave %2d" % w, [x - t0 for x in r])
 c3t = ts.cpu()[340:358].tolist()

@@ -112,7 +112,10 @@ template <class Between>          // between(): called behind the weight-gradien
 inline int conv12_backward(const c2::ImgSrc& xs, int n, const float* w1, const float* b1, const float* w2, const float* dp2,
                            const EncSaved& sv, float* slab_w, float* slab_b, float* slab_1, hipStream_t s, Between&& between) {
   const int grid = conv12_grid(n);
-  {
+  if (g_opt.conv2_split & 4) {
+    ProfScope ps("enc.bwd.conv12.wgrad.split", s);          // the same `grid` slab rows as the fp32 kernel (the caller folds that many)
+    hipLaunchKernelGGL(c2s::conv12_wgrad_split_kernel, dim3(grid), dim3(c2s::NT), 0, s, xs, w1, b1, dp2, sv.p2, sv.am2, slab_w, slab_b, n);
+  } else {
     ProfScope ps("enc.bwd.conv12.wgrad", s);
     hipLaunchKernelGGL(c2::conv12_wgrad_kernel, dim3(grid), dim3(c2::NT), 0, s, xs, w1, b1, dp2, sv.p2, sv.am2, slab_w, slab_b, n, g_opt.dbg);
   }
@@ -120,7 +123,7 @@ inline int conv12_backward(const c2::ImgSrc& xs, int n, const float* w1, const f
   MLHOT_TRY(between());
   if (g_opt.conv2_split & 2) {
     ProfScope ps("enc.bwd.conv12.dgrad.split", s);
-    hipLaunchKernelGGL(c2s::conv12_dgrad_split_kernel, dim3(grid), dim3(c2s::dg::NT2), 0, s, xs, sv.m1, dp2, sv.p2, sv.am2, w2, slab_1, n);
+    hipLaunchKernelGGL(c2s::conv12_dgrad_split_kernel, dim3(grid), dim3(c2s::dg::NT2), 0, s, xs, sv.m1, dp2, sv.p2, sv.am2, w2, slab_1, n, g_opt.dbg >> 8);
   } else {
     ProfScope ps("enc.bwd.conv12.dgrad", s);
     hipLaunchKernelGGL(c2::conv12_dgrad_kernel, dim3(grid), dim3(c2::NT2), 0, s, xs, sv.m1, dp2, sv.p2, sv.am2, w2, slab_1, n);
