@@ -588,6 +588,10 @@ __global__ __launch_bounds__(dg::NT2) void conv12_dgrad_split_kernel(const ImgSr
 // ci half) tiles, row ph) x all 3 co tiles: 9 accumulators, 54 MFMAs per band, every one on a different accumulator than the one
 // before it.  All six piece products go into the ONE accumulator of their tile: it sums the whole batch share of the workgroup, so
 // it is large beside any single product and the five small products have nothing to gain from an accumulator of their own.
+// (Measured and dropped: the next band's conv1 tiles and dY cell computed into registers - 30 dwords of packed pieces - between this
+// band's M-tiles and only STORED between the barriers: 102 -> 123 us.  The kernel is bound by vector issue - knock-outs put conv1 +
+// split at 38 us, the bf16 MFMAs at 26, the patch stores at 13: they add up, they do not overlap - so moving work under the MFMAs moves
+// nothing, and the fp32 MFMAs of conv1 between the bf16 ones cost both pipes.)
 // ==================================================================================================================================
 namespace wg {
 constexpr int CISB = 1952, PATCHB = CIN * CISB;                       // 62,464 B
@@ -674,8 +678,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_split_kernel(const ImgSrc x, 
     bsum += g;
     unsigned pc[3];
     split3_pk(g, g, pc[0], pc[1], pc[2]);
-    // window position w4 = 2 row + column: the plain copy's dword (ox = 2 px | 2 px + 1) of each row; the moved copy takes ox = 2 px
-    // at index 2 px - 1 (upper half of dword px - 1) and ox = 2 px + 1 at index 2 px (lower half of dword px)
+    // window position w4 = 2 row + column: the plain copy's dword px of a row is (ox = 2 px | 2 px + 1), the moved copy's (2 px + 1 | 2 px + 2)
     unsigned char* dp = dyp + cco * wg::COSB + 4 * cpx;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
@@ -685,8 +688,11 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_split_kernel(const ImgSrc x, 
         const unsigned v = pc[p] & m;
         unsigned char* a = dp + p * wg::DYPIECEB + 64 * dy;
         *reinterpret_cast<unsigned*>(a) = v;
-        *reinterpret_cast<unsigned short*>(a + wg::DYCOPYB) = (unsigned short)(v >> 16);
-        if (cpx > 0) *reinterpret_cast<unsigned short*>(a + wg::DYCOPYB - 2) = (unsigned short)v;
+        // moved dword px = (dY[2 px + 1], dY[2 px + 2]) = (this cell's upper half, the next cell's lower half): the neighbour's dword
+        // comes over DPP (row_shl:1 inside the 16 lanes of a channel, zero behind the last one) and v_alignbit joins the halves.  (As
+        // two ds_write_b16 into the neighbours' halves per dword, those twelve stores were 20 us of this kernel: 122 -> 102 us.)
+        const unsigned vn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);
+        *reinterpret_cast<unsigned*>(a + wg::DYCOPYB) = __builtin_amdgcn_alignbit(vn, v, 16);
       }
     }
   };
