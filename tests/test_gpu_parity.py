@@ -543,11 +543,13 @@ def test_split_precision_error_vs_fp32_mfma(gpulib, case):
     same-sign sums, conv1 exact by construction so that only conv2's three reductions differ).  Measured on MI355X
     (gpurun_out/split_error_<case>.txt has the table of the run; DESIGN.md section 4 the round's):
       forward (p2): the split kernel's error is 0.2 - 0.8 x the fp32 kernel's in every case, max and rms -> asserted <= 1.0 x;
-      gradients: 0.2 - 2.5 x.  v_mfma_f32_16x16x32_bf16 FLOORS its addends - the accumulator included - to 25 bits below the largest
-      product of each 8-term step (scripts/micro/mfma_bf16_accum.hip), which an fp32 chain rounds to nearest; the data-gradient kernel
-      runs half of its waves on negated weights so that the floors cancel over a band instead of adding up over the batch, which
-      leaves them at about the fp32 kernel's level but not below it in every case -> asserted <= 3 x (and <= 2e-6 of the largest
-      element wherever the fp32 kernel itself is that exact).  This is why the split kernels stay opt-in."""
+      gradients: 0.2 - 2.5 x (rms: dW2 0.9 - 1.1, dW1 / db1 0.8 - 2.1).  v_mfma_f32_16x16x32_bf16 FLOORS its addends - the
+      accumulator included - to 25 bits below the largest product of each 8-term step (scripts/micro/mfma_bf16_accum.hip), where an
+      fp32 chain rounds to nearest; the gradient kernels therefore run half of their sums on negated operands (the data gradient:
+      half of the waves hold -W2; the weight gradient: every other band goes as -dY into a second accumulator set), so that the
+      floors cancel instead of adding up over the batch.  That leaves them AT the fp32 kernels' level, not below it in every
+      case -> asserted <= 3 x (and <= 2e-6 of the largest element wherever the fp32 kernel itself is that exact).  This is why the
+      split kernels stay opt-in."""
     n = 8
     res = SC.measure(gpulib, case, n)
     lines = [f"{case} n={n}: quantity, (max, rms) fp32, (max, rms) split, ratios"]

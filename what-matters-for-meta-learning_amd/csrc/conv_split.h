@@ -673,9 +673,10 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_split_kernel(const ImgSrc x, 
     cdp = dp2[o]; cp = p2[o]; cam = amax[o];
   };
   float bsum = 0.f;
-  auto cell_store = [&]() {
-    const float g = cp > 0.f ? cdp : 0.f;
-    bsum += g;
+  auto cell_store = [&](bool negate) {
+    const float g0 = cp > 0.f ? cdp : 0.f;
+    bsum += g0;
+    const float g = negate ? -g0 : g0;
     unsigned pc[3];
     split3_pk(g, g, pc[0], pc[1], pc[2]);
     // window position w4 = 2 row + column: the plain copy's dword px of a row is (ox = 2 px | 2 px + 1), the moved copy's (2 px + 1 | 2 px + 2)
@@ -697,11 +698,16 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_split_kernel(const ImgSrc x, 
     }
   };
 
-  f32x4_t acc[3][3];
+  // TWO accumulator sets: the workgroup's bands alternate between +dY into `acc` and -dY into `accn`, and the result is acc - accn.
+  // v_mfma_f32_16x16x32_bf16 floors its addends (the accumulator included) to 25 bits below the largest product of each 8-term step
+  // (scripts/micro/mfma_bf16_accum.hip): every such loss points down, and a sum over the whole batch collects them; in the
+  // difference of two sums that lose the same way they cancel (dW2 against float64, rms over the adversarial cases of
+  // tests/split_cases.py: 1.0 - 1.7 x the fp32 kernel's error with one set, 0.9 - 1.1 x with two; same kernel time).
+  f32x4_t acc[3][3], accn[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 3; ++j) { acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accn[i][j] = acc[i][j]; }
   // fragment bases of the wave's M-tiles mt = 3 mg + i = (tap, ci half): patch row 2 ph + ky, plane E for kx = 1, O otherwise
   int aoff[3]; bool moved[3];
 #pragma unroll
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_split_kernel(const ImgSrc x, 
   float px[2][3];
   if (tile < ntiles) { c1_load(tile, row0, px[0]); c1_load(tile, row1, px[1]); cell_fetch(tile); }
   __syncthreads();                                   // the zero fill
-  for (; tile < ntiles; tile += gridDim.x) {
+  auto band = [&](f32x4_t (&ac)[3][3], bool negate) {
 #ifdef MLHOT_TS
     const bool tsb = tf::g_ts_dev && blockIdx.x == 0 && lane == 0 && (tile - c2::first_tile<16>(0, gridDim.x)) / (int)gridDim.x == 6;
 #define WGS_STAMP(i) do { if (tsb) tf::g_ts_dev[360 + wave * 5 + (i)] = clock64(); } while (0)
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_split_kernel(const ImgSrc x, 
     c1_tile(tile, row0, px[0]);
     if (wave < 8) c1_tile(tile, row0 + 3, px[1]);
     WGS_STAMP(1);
-    cell_store();
+    cell_store(negate);
     WGS_STAMP(2);
     __syncthreads();
     WGS_STAMP(3);
@@ -759,12 +765,23 @@ __global__ __launch_bounds__(NT) void conv12_wgrad_split_kernel(const ImgSrc x, 
         const int pa = pp == 0 ? 2 : (pp == 1 || pp == 2) ? 1 : 0;          // (l,h) (m,h) (m,m) (h,h) (h,m) (h,l)
         const int pb = pp == 0 ? 0 : pp == 1 ? 0 : pp == 2 ? 1 : pp - 3;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = mfma_bf16(af[pa], bf[j][pb], acc[i][j]);
+        for (int j = 0; j < 3; ++j) ac[i][j] = mfma_bf16(af[pa], bf[j][pb], ac[i][j]);
       }
     }
     WGS_STAMP(4);
     __syncthreads();
+  };
+  while (tile < ntiles) {
+    band(acc, false);
+    tile += gridDim.x;
+    if (tile >= ntiles) break;
+    band(accn, true);
+    tile += gridDim.x;
   }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] -= accn[i][j];
 
   // fold the two rows' accumulators through LDS, one slab row per workgroup in accumulator order (c2::conv12_wgrad_kernel's epilogue)
   float* fl = reinterpret_cast<float*>(lds);
