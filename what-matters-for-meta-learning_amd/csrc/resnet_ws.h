@@ -925,6 +925,9 @@ __device__ __forceinline__ void wgrad_body(const WgJob& jb, float* lds, int rel)
   float* dyt = lds + G::XS;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
+  // (Measured and dropped: the four q of a slab row 8 workgroups apart - on ONE XCD, so that the dy tile they all stage meets in one
+  // L2 instead of being fetched from HBM up to four times: block 1's launches unchanged (122 / 72 us: they are not HBM-bound), block
+  // 2's 42 -> 47 and 25 -> 32 us, the c5 step 1.445 -> 1.456 ms.)
   const int q = rel & 3, z = rel >> 2;
   constexpr int NT = TAP1 ? 1 : 9;
 
