@@ -847,6 +847,9 @@ def main():
                "roofline": roof}
         if args.opt:
             out["options"] = args.opt
+            if any(kv.partition("=")[0] == "conv2_split" and int(kv.partition("=")[2]) for kv in args.opt):
+                # an A/B line, not the headline: conv2 ran on the bf16 pipe over split operands (extras.split_precision_conv2)
+                out["dtype"] = "f32, conv2 of the vanilla encoder on bf16x3-split operands (opt-in arithmetic: NOT the headline line)"
         if eps is not None and eps.source == "host":
             d0 = time.perf_counter()
             eps.stage()

@@ -36,5 +36,16 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 cd $REPO
 python3 scripts/pmc_by_label.py $OUT/seq_c5.json $OUT/${TAG}_pmc_traffic_c5.json c5 $(find $OUT/pmc_fetch_c5 -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write_c5 -name "*counter_collection.csv" | head -1)
 python3 scripts/pmc_by_label.py $OUT/seq_c5.json $OUT/${TAG}_pmc_sq_c5.json c5 $(find $OUT/pmc_sq_c5 -name "*counter_collection.csv" | head -1)
+# the opt-in split-precision conv12 kernels (extras, never `value`): an A/B bench line, kernel stats, instruction mix, LDS conflicts,
+# SQ counters and the error table against float64
+cd $REPO
+python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --opt conv2_split=7 > $OUT/${TAG}_split_bench_c3.json 2> $OUT/bench_split.err
+python scripts/dev/split_error.py 8 > $OUT/${TAG}_split_error_vs_float64.txt 2> /dev/null
+bash scripts/inst_mix.sh c3 --opt conv2_split=7 > $OUT/${TAG}_split_inst_mix.txt 2>&1
+bash scripts/lds_conflicts.sh c3 --opt conv2_split=7 > $OUT/${TAG}_split_lds_conflicts.txt 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_split -o stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --prof-steps 0 --opt conv2_split=7 > $OUT/stats_split.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq_split -o sq -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 --opt conv2_split=7 > $OUT/pmc_sq_split.log 2>&1
+cd $REPO
 find $OUT -name "*.csv" | head -20
 ls -la $OUT

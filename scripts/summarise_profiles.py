@@ -97,3 +97,34 @@ if labels:
     with open(os.path.join(DST, f"{tag}_pmc_sq.json"), "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps({k: {kk: (round(vv, 4) if isinstance(vv, float) and vv < 10 else vv) for kk, vv in v.items()} for k, v in res.items() if k != "_note"}, indent=1))
+
+
+# ---- the opt-in split-precision conv12 kernels (extras) -----------------------------------------------------------------------
+for name in (f"{tag}_split_bench_c3.json", f"{tag}_split_error_vs_float64.txt", f"{tag}_split_inst_mix.txt", f"{tag}_split_lds_conflicts.txt"):
+    p = os.path.join(SRC, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(DST, name))
+st = find("stats_split/**/*kernel_stats.csv")
+if st:
+    shutil.copy(st, os.path.join(DST, f"{tag}_split_kernel_stats.csv"))
+SPLIT_LABEL = {"conv12_fwd_split_kernel": "enc.conv12.split", "conv12_wgrad_split_kernel": "enc.bwd.conv12.wgrad.split",
+               "conv12_dgrad_split_kernel": "enc.bwd.conv12.dgrad.split"}
+KERNEL_LABEL.clear()
+KERNEL_LABEL.update(SPLIT_LABEL)
+sq = {c: pmc("pmc_sq_split", c) for c in SQ}
+labels = sorted(set().union(*[set(v) for v in sq.values()]))
+if labels:
+    res = {"_note": "as <tag>_pmc_sq.json, `bench.py ... --opt conv2_split=7`.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024): "
+                    "the share of SIMD cycles in which either matrix pipe (bf16 conv2, fp32 conv1 / conv1's gradient) is busy."}
+    for lb in labels:
+        v = {c: sq[c].get(lb) for c in SQ}
+        d = dict(v)
+        if v["GRBM_GUI_ACTIVE"]:
+            d["mfma_busy_frac"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        if v["SQ_WAVE_CYCLES"]:
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+                d["frac_" + c[3:].lower()] = v[c] / v["SQ_WAVE_CYCLES"]
+        res[lb] = d
+    with open(os.path.join(DST, f"{tag}_split_pmc_sq.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({k: {kk: (round(vv, 4) if isinstance(vv, float) and vv < 10 else vv) for kk, vv in v.items()} for k, v in res.items() if k != "_note"}, indent=1))
