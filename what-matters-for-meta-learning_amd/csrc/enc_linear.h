@@ -138,6 +138,131 @@ __global__ __launch_bounds__(NTH) void enc_linear_bwd_kernel(const Rows2 dfeat, 
   }
 }
 
+// Forward of the same layer: feat[n][64] = a3[n][4096] wl[64][4096]^T (+ bias in the slab fold).  A [480 x 64] result has 120 output
+// tiles - too few for the chip - so K is split 16 ways: workgroup = (16 rows, 256 k), wave = 16 outputs, 480 workgroups for the
+// 480-image batch; the 16 partial results [16][n][64] are folded (+ bias) by enc_linear_fold_kernel.  (The generic 64 x 64
+// igemm needed 32 K splits to fill the chip: 3.9 MB of slabs, 9.0 + 4.8 us.)  K runs in chunks of 64, double-buffered in LDS: every
+// thread brings 5 float4 per chunk, whole 256-byte row pieces per 16 lanes.  Operands are ds_read_b128: a lane (row lr, k-group lq) takes 4
+// consecutive k at 16 j + 4 lq and MFMA (j, i) uses element i of every lane's float4 - the k order inside a block of 16 is permuted
+// the same way for both operands, which a dot product does not see.  Row stride 72 words = 8 mod 16: a 16-lane group of a
+// ds_read_b128 covers the 64 banks once.  Measured (rocprofv3): product 9.0 -> 7.3 us, fold 4.8 -> 4.7 us.  Both are latency, not
+// work: the product reads a cold a3 (7.9 MB, ~1.1 TB/s over the kernel), the fold is one round trip.  On the way: the same float4s
+// fed to the MFMAs straight from global memory (no LDS): 9.2 us, and 5.2 us with every load hitting ONE cache line - 64 loads of
+// 16 rows x 64 bytes per wave are bound by the vector memory pipe's request rate, not by bytes, MFMAs or loads in flight (32 per wave
+// made no difference, nor did walking the K slice from a different start per workgroup to spread the L2 channels).
+constexpr int F_KS = 16, F_KLEN = KIN / F_KS, F_CH = 64, F_NCH = F_KLEN / F_CH, F_LD = 72;
+constexpr int F_BUF = (16 + DW) * F_LD;                               // floats per chunk buffer: A rows 0..15, then the 64 wl rows
+__global__ __launch_bounds__(256) void enc_linear_fwd_kernel(const float* __restrict__ a3, const float* __restrict__ wl, float* __restrict__ slab, int n) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * F_BUF];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int mt = (n + 15) / 16, mtile = blockIdx.x % mt, ks = blockIdx.x / mt;
+  const int r0 = 16 * mtile;
+  // staging items: (row of the 80-row chunk image, float4 of its 16): item e = tid + 256 u, u < 5; rows 0..15 = a3, 16..79 = wl
+#define EL_ITEM(u)                                                                                                              \
+  const int e##u = tid + 256 * u, row##u = e##u >> 4, c4##u = e##u & 15;                                                         \
+  const float* src##u = (row##u < 16 ? a3 + (size_t)min(r0 + row##u, n - 1) * KIN : wl + (size_t)(row##u - 16) * KIN) + ks * F_KLEN + 4 * c4##u; \
+  const int dst##u = row##u * F_LD + 4 * c4##u;
+  EL_ITEM(0) EL_ITEM(1) EL_ITEM(2) EL_ITEM(3) EL_ITEM(4)
+#undef EL_ITEM
+  // ALL of the workgroup's 80 KB are requested up front (20 float4 per thread): a3 is cold (HBM / fabric latency ~2 us) and with
+  // one chunk of look-ahead every chunk waited that latency out again (8 K splits x 8 chunks: 8.1 us); 8 K splits with all 40
+  // float4 up front went to scratch memory (21 us)
+  // twenty NAMED float4s, loads and stores written out: as arrays indexed in `#pragma unroll` loops (or passed to a lambda) hipcc
+  // unrolled after it had already decided to keep them in scratch memory (21 us)
+  static_assert(F_NCH == 4, "four chunk register sets");
+  float4 v00, v01, v02, v03, v04, v10, v11, v12, v13, v14, v20, v21, v22, v23, v24, v30, v31, v32, v33, v34;
+  v00 = *reinterpret_cast<const float4*>(src0 + 0 * F_CH);
+  v01 = *reinterpret_cast<const float4*>(src1 + 0 * F_CH);
+  v02 = *reinterpret_cast<const float4*>(src2 + 0 * F_CH);
+  v03 = *reinterpret_cast<const float4*>(src3 + 0 * F_CH);
+  v04 = *reinterpret_cast<const float4*>(src4 + 0 * F_CH);
+  v10 = *reinterpret_cast<const float4*>(src0 + 1 * F_CH);
+  v11 = *reinterpret_cast<const float4*>(src1 + 1 * F_CH);
+  v12 = *reinterpret_cast<const float4*>(src2 + 1 * F_CH);
+  v13 = *reinterpret_cast<const float4*>(src3 + 1 * F_CH);
+  v14 = *reinterpret_cast<const float4*>(src4 + 1 * F_CH);
+  v20 = *reinterpret_cast<const float4*>(src0 + 2 * F_CH);
+  v21 = *reinterpret_cast<const float4*>(src1 + 2 * F_CH);
+  v22 = *reinterpret_cast<const float4*>(src2 + 2 * F_CH);
+  v23 = *reinterpret_cast<const float4*>(src3 + 2 * F_CH);
+  v24 = *reinterpret_cast<const float4*>(src4 + 2 * F_CH);
+  v30 = *reinterpret_cast<const float4*>(src0 + 3 * F_CH);
+  v31 = *reinterpret_cast<const float4*>(src1 + 3 * F_CH);
+  v32 = *reinterpret_cast<const float4*>(src2 + 3 * F_CH);
+  v33 = *reinterpret_cast<const float4*>(src3 + 3 * F_CH);
+  v34 = *reinterpret_cast<const float4*>(src4 + 3 * F_CH);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int aoff = lr * F_LD + 4 * lq, boff = (16 + 16 * w + lr) * F_LD + 4 * lq;
+#define EL_MFMAS(buf)                                                                                                     \
+  _Pragma("unroll") for (int j = 0; j < F_CH / 16; ++j) {                                                                 \
+    const float4 a = *reinterpret_cast<const float4*>(buf + aoff + 16 * j), b = *reinterpret_cast<const float4*>(buf + boff + 16 * j); \
+    acc0 = mfma4(a.x, b.x, acc0);                                                                                          \
+    acc1 = mfma4(a.y, b.y, acc1);                                                                                          \
+    acc0 = mfma4(a.z, b.z, acc0);                                                                                          \
+    acc1 = mfma4(a.w, b.w, acc1);                                                                                          \
+  }
+  {
+    float* buf = lds + 0 * F_BUF;
+    *reinterpret_cast<float4*>(buf + dst0) = v00;
+    *reinterpret_cast<float4*>(buf + dst1) = v01;
+    *reinterpret_cast<float4*>(buf + dst2) = v02;
+    *reinterpret_cast<float4*>(buf + dst3) = v03;
+    *reinterpret_cast<float4*>(buf + dst4) = v04;
+    __syncthreads();                          // one barrier per chunk: the buffer written now was last read two chunks ago
+    EL_MFMAS(buf)
+  }
+  {
+    float* buf = lds + 1 * F_BUF;
+    *reinterpret_cast<float4*>(buf + dst0) = v10;
+    *reinterpret_cast<float4*>(buf + dst1) = v11;
+    *reinterpret_cast<float4*>(buf + dst2) = v12;
+    *reinterpret_cast<float4*>(buf + dst3) = v13;
+    *reinterpret_cast<float4*>(buf + dst4) = v14;
+    __syncthreads();                          // one barrier per chunk: the buffer written now was last read two chunks ago
+    EL_MFMAS(buf)
+  }
+  {
+    float* buf = lds + 0 * F_BUF;
+    *reinterpret_cast<float4*>(buf + dst0) = v20;
+    *reinterpret_cast<float4*>(buf + dst1) = v21;
+    *reinterpret_cast<float4*>(buf + dst2) = v22;
+    *reinterpret_cast<float4*>(buf + dst3) = v23;
+    *reinterpret_cast<float4*>(buf + dst4) = v24;
+    __syncthreads();                          // one barrier per chunk: the buffer written now was last read two chunks ago
+    EL_MFMAS(buf)
+  }
+  {
+    float* buf = lds + 1 * F_BUF;
+    *reinterpret_cast<float4*>(buf + dst0) = v30;
+    *reinterpret_cast<float4*>(buf + dst1) = v31;
+    *reinterpret_cast<float4*>(buf + dst2) = v32;
+    *reinterpret_cast<float4*>(buf + dst3) = v33;
+    *reinterpret_cast<float4*>(buf + dst4) = v34;
+    __syncthreads();                          // one barrier per chunk: the buffer written now was last read two chunks ago
+    EL_MFMAS(buf)
+  }
+#undef EL_MFMAS
+  float* out = slab + ((size_t)ks * n + r0) * DW + 16 * w + lr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (r0 + 4 * lq + r < n) out[(size_t)(4 * lq + r) * DW] = acc0[r] + acc1[r];
+}
+
+// feat[m][j] = bias[j] + sum over the F_KS partial results, in a fixed order; one output per thread, all 16 loads in flight
+__global__ __launch_bounds__(256) void enc_linear_fold_kernel(const float* __restrict__ slab, const float* __restrict__ bias, Rows2 out, int n) {
+  const int e = blockIdx.x * 256 + threadIdx.x, total = n * DW;
+  if (e >= total) return;
+  float p[F_KS];
+#pragma unroll
+  for (int z = 0; z < F_KS; ++z) p[z] = slab[(size_t)z * total + e];
+  float t = bias[e & (DW - 1)];
+#pragma unroll
+  for (int z = 0; z < F_KS; ++z) t += p[z];
+  out.row(e / DW)[e & (DW - 1)] = t;
+}
+
 }  // namespace el
 }  // namespace mlhot
 #endif  // !MLHOT_HOSTSIM

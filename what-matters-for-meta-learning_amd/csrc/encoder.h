@@ -170,6 +170,20 @@ inline int enc_forward(const float* img0, int n0, const float* img1, int n1, con
     MLHOT_TRY((run_igemm<C3, 64, 64, 16, 2, 2>(c3, 1, nullptr, s, "enc.conv3")));
   }
   EncLinFwd lf{n, dim_w, 4096, sv.a3, p.wl, p.bl, feat};
+#ifndef MLHOT_HOSTSIM
+  if (g_opt.conv2_tc && dim_w == el::DW) {
+    {
+      ProfScope ps("enc.linear", s);
+      hipLaunchKernelGGL(el::enc_linear_fwd_kernel, dim3(((n + 15) / 16) * el::F_KS), dim3(256), 0, s, sv.a3, p.wl, sc.slab, n);
+    }
+    MLHOT_TRY(check_launch("enc.linear"));
+    {
+      ProfScope ps("slab_reduce", s);
+      hipLaunchKernelGGL(el::enc_linear_fold_kernel, dim3((n * el::DW + 255) / 256), dim3(256), 0, s, sc.slab, p.bl, feat, n);
+    }
+    return check_launch("enc.linear.fold");
+  }
+#endif
   MLHOT_TRY((run_igemm<EncLinFwd, 64, 64, 16, 2, 2>(lf, enc_lin_split(n), sc.slab, s, "enc.linear")));
   return MLHOT_OK;
 }
