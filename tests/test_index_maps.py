@@ -128,3 +128,78 @@ def test_conv3_forward_weight_staging_is_tap_major_and_conflict_free():
     assert worst <= 2
     # the gather's k-step order: quad qd = 3 tap + g -> registers 4 qd + j = 12 tap + 4 g + j, the order the MFMA loop consumes
     assert [(4 * qd + j) for qd in range(27) for j in range(4)] == [12 * (qd // 3) + 4 * (qd % 3) + j for qd in range(27) for j in range(4)]
+
+
+# ---- the split-precision conv12 kernels (csrc/conv_split.h) and the encoder Linear forward (csrc/enc_linear.h) ----------------------
+def _b128_worst(addr):
+    """largest number of distinct 16-byte reads that share a bank inside one 16-lane group of a ds_read_b128 (1 = conflict-free);
+    addr(lane) = first dword of the lane's read, banks = dword mod 64"""
+    worst = 0
+    for g in _groups_b128():
+        per_bank = {}
+        for lane in g:
+            a = addr(lane)
+            for k in range(4):
+                per_bank.setdefault((a + k) % 64, set()).add(a)
+        worst = max(worst, max(len(v) for v in per_bank.values()))
+    return worst
+
+
+def _b32_store_worst(addr):
+    """the same for a ds_write_b32: two 32-lane halves, banks = dword mod 32"""
+    worst = 0
+    for half in (range(32), range(32, 64)):
+        per_bank = {}
+        for lane in half:
+            per_bank.setdefault(addr(lane) % 32, set()).add(addr(lane))
+        worst = max(worst, max(len(v) for v in per_bank.values()))
+    return worst
+
+
+def test_split_dgrad_dy_fragments_and_cell_stores():
+    # dY piece plane [row][col 33][co 48] bf16, dense: 24 dwords per position; lane (lr = position, lq = k-group of 8 channels = 4 dwords)
+    assert _b128_worst(lambda lane: 24 * (lane & 15) + 4 * (lane >> 4)) == 1
+    # a padded position (26 / 28 dwords) would not be: 24 = 8 mod 16 is what the lane groups of the read want
+    assert _b128_worst(lambda lane: 28 * (lane & 15) + 4 * (lane >> 4)) > 1
+    # cell pairs: a 32-lane half = 8 channel pairs x 4 px; dword (2 px) * 24 + pair -> 2 lanes per bank (free for a ds_write_b32) ...
+    assert _b32_store_worst(lambda lane: 48 * ((lane >> 3) & 7) + (lane & 7)) == 2
+    # ... where px fastest over 16 lanes put 8 on a bank
+    assert _b32_store_worst(lambda lane: 48 * (lane & 15) + (lane >> 4)) == 8
+
+
+def test_split_wgrad_patch_and_dy_layouts():
+    sw = lambda ch: (ch >> 2) & 3                                                                  # noqa: E731  granule XOR of a channel
+    # A fragments: lane (lr = channel of the half, lq = position group) reads granule lq ^ sw(lr) of its channel's 64-byte row
+    assert _b128_worst(lambda lane: 488 * (lane & 15) + 4 * ((lane >> 4) ^ sw(lane & 15))) == 1
+    assert _b128_worst(lambda lane: 488 * (lane & 15) + 4 * (lane >> 4)) == 1                      # (the XOR is for the stores)
+    assert _b128_worst(lambda lane: 484 * (lane & 15) + 4 * (lane >> 4)) > 1                       # 36 mod 64: the first layout, 41 % conflicts
+    # conv1's stores: lane (lr = channel, lq = column quad) writes dword lq of granule cg ^ sw(lr)
+    for cg in range(4):
+        assert _b32_store_worst(lambda lane, cg=cg: 488 * (lane & 15) + 4 * (cg ^ sw(lane & 15)) + (lane >> 4)) == 2
+        assert _b32_store_worst(lambda lane, cg=cg: 488 * (lane & 15) + 4 * cg + (lane >> 4)) == 4  # without the XOR
+    # dY: 40 dwords per output channel; B fragments lane (lr = co, lq), stores lane (px = lane % 16, co = lane / 16)
+    assert _b128_worst(lambda lane: 40 * (lane & 15) + 4 * (lane >> 4)) == 1
+    assert _b128_worst(lambda lane: 36 * (lane & 15) + 4 * (lane >> 4)) > 1
+    assert _b32_store_worst(lambda lane: 40 * (lane >> 4) + (lane & 15)) == 2
+
+
+def test_encoder_linear_forward_operand_reads():
+    # chunk image rows of 72 dwords; lane (lr = row, lq) reads the float4 at 16 j + 4 lq
+    for j in range(4):
+        assert _b128_worst(lambda lane, j=j: 72 * (lane & 15) + 16 * j + 4 * (lane >> 4)) == 1
+    assert _b128_worst(lambda lane: 68 * (lane & 15) + 4 * (lane >> 4)) > 1
+
+
+def test_split_dgrad_cell_items_cover_the_band_once():
+    # wave w takes items w, w + 8, w + 16 (< 18): item W = (pooled row W / 6, px half (W / 3) & 1, pair group W % 3), lane = (pair, px)
+    seen = set()
+    for wave in range(8):
+        for j in range(3):
+            W = wave + 8 * j
+            if W >= 18:
+                continue
+            for lane in range(64):
+                pr, px, pyl = 8 * (W % 3) + (lane & 7), 8 * ((W // 3) & 1) + ((lane >> 3) & 7), W // 6
+                assert (pr, px, pyl) not in seen
+                seen.add((pr, px, pyl))
+    assert len(seen) == 24 * 16 * 3
