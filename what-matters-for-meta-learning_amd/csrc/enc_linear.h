@@ -9,6 +9,11 @@
 // LDS strides: dY rows 66 words (a lane pair (row, k) of the data-gradient A operand hits 32 different
 // banks), a3 rows 16 words (the two row halves of a 32-lane group sit 16 banks apart).
 // dim_w == 64 only (every shipped configuration); other widths keep the generic path.  GPU build only.
+// Where its 12.3 us go (knock-outs, rocprofv3): 5.5 us with nothing but the loads, the barriers and the stores of zeros - launch ramp
+// and the first (cold) round trip; the data gradient 4.1, the weight gradient 2.6.  Measured and dropped: the rows split over
+// workgroup pairs with 32 features each (half of dY per workgroup: 99 KB fetched instead of 153, two partial dW rows folded by the
+// deferred sum) - 12.2 us, the same; both feature tiles of a row tile sharing the A operand in four chains - the same again.  The
+// kernel is latency and 64-byte store transactions (dy3 rows are 16 KB apart), not fetch volume or MFMA chains.
 #pragma once
 #include "common.h"
 #include "problems.h"
