@@ -210,6 +210,25 @@ __global__ __launch_bounds__(NT) void conv12_fwd_split_kernel(const ImgSrc x, co
   int band_no = -1;
   const long long ts_c0 = clock64(), ts_w0 = wall_clock64();
 #endif
+  // 2 x 2 max-pool + arg-max of a finished band: thread = (channel tid / 16, pooled column tid % 16); window order as the reference's
+  // pool kernel.  It runs BETWEEN the two MFMA halves of the band after - right behind the band's barrier it was ~1 k cycles of a
+  // 9 k-cycle band in which every wave did the same dozen instructions and two stores and the matrix pipes idled (knock-outs: 40 us
+  // of the kernel's 107 were neither conv1 nor MFMAs); the scratch is double-buffered, so the band after does not touch it.
+  auto pool_store = [&](int t, int c) {
+    const float* pool = pool0 + c * POOLF;
+    const int pc = tid >> 4, px = tid & 15, img = t >> 4, b = t & 15;
+    const float* s0 = pool + pc * POOL_LD + 2 * px;
+    const float* s1 = s0 + COUT * POOL_LD;
+    const float c0 = s0[0], c1 = s0[1], c2v = s1[0], c3 = s1[1];
+    float best = c0; unsigned which = 0;
+    if (c1 > best) { best = c1; which = 1; }
+    if (c2v > best) { best = c2v; which = 2; }
+    if (c3 > best) { best = c3; which = 3; }
+    const size_t o = (((size_t)img * COUT + pc) * 16 + b) * 16 + px;
+    p2[o] = best;
+    amax[o] = (uint8_t)which;
+  };
+  int prev_tile = -1, prev_cur = 0;
   for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
 #ifdef C2S_TS
     ++band_no;
@@ -245,6 +264,8 @@ __global__ __launch_bounds__(NT) void conv12_fwd_split_kernel(const ImgSrc x, co
     C2S_STAMP(1);
     conv2_taps<0, 5>(pa, wr, acc, accs);
     __builtin_amdgcn_sched_barrier(0);
+    if (prev_tile >= 0) pool_store(prev_tile, prev_cur);       // the band before this one: its tiles met in the scratch at its barrier
+    __builtin_amdgcn_sched_barrier(0);
     C2S_STAMP(2);
     if (slot == 1) conv1_next();
     __builtin_amdgcn_sched_barrier(0);
@@ -265,22 +286,10 @@ __global__ __launch_bounds__(NT) void conv12_fwd_split_kernel(const ImgSrc x, co
     C2S_STAMP(6);
     __syncthreads();
     C2S_STAMP(7);
-    // 2 x 2 max-pool + arg-max: thread = (channel tid / 16, pooled column tid % 16); window order as the reference's pool kernel
-    {
-      const int pc = tid >> 4, px = tid & 15, img = tile >> 4, b = tile & 15;
-      const float* s0 = pool + pc * POOL_LD + 2 * px;
-      const float* s1 = s0 + COUT * POOL_LD;
-      const float c0 = s0[0], c1 = s0[1], c2v = s1[0], c3 = s1[1];
-      float best = c0; unsigned which = 0;
-      if (c1 > best) { best = c1; which = 1; }
-      if (c2v > best) { best = c2v; which = 2; }
-      if (c3 > best) { best = c3; which = 3; }
-      const size_t o = (((size_t)img * COUT + pc) * 16 + b) * 16 + px;
-      p2[o] = best;
-      amax[o] = (uint8_t)which;
-    }
+    prev_tile = tile; prev_cur = cur;          // pooled in the middle of the next band (or behind the loop)
     C2S_STAMP(8);
   }
+  if (prev_tile >= 0) pool_store(prev_tile, prev_cur);
 #ifdef C2S_TS
   if (blockIdx.x == 0 && tid == 0) { g_c2s_ts[192] = clock64() - ts_c0; g_c2s_ts[193] = wall_clock64() - ts_w0; g_c2s_ts[194] = band_no + 1; }
 #endif
