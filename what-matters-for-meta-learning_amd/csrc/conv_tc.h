@@ -501,6 +501,9 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
 #ifdef MLHOT_TS
     if (tsb && (lane == 0)) tf::g_ts_dev[400 + wave * 4 + 1] = clock64();
 #endif
+    // (Measured and dropped, round 4: this epilogue - bias, ReLU, 2 x 2 pool, two stores - kept as pending accumulators and run in
+    // k-steps 66 .. 68 of the NEXT band, where the slot schedule has no conv1 work: 141.4 -> 141.2 us.  Vector instructions cost
+    // the same issue slots under the MFMAs as behind them.)
     const int img = tile >> 3, band = tile & 7;
     float pv[2]; unsigned pa[2];
 #pragma unroll
