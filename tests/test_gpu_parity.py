@@ -306,7 +306,7 @@ def test_encoder_fwd_bwd_vs_oracle(gpulib, conv2_impl, n0, n1):
         assert U.rel_err(got, ref.grad) <= U.RTOL, k
 
 
-@pytest.mark.parametrize("split", [0, 1], ids=["fp32", "split"])
+@pytest.mark.parametrize("split", [0, 1, 7], ids=["fp32", "split", "split_all"])
 def test_encoder_full_size_gradients_with_pinned_routing(gpulib, split):
     """480 images (the c2/c3 batch).  ReLU / max-pool routing is discontinuous, so gradients are
     compared with the oracle evaluated under the KERNEL's routing decisions (see
@@ -320,13 +320,14 @@ def test_encoder_full_size_gradients_with_pinned_routing(gpulib, split):
     plist = [t.to(DEV) for t in p.values()]
     xd = x.to(DEV)
     gpulib.set_option("materialize_a1", 1)      # the fused conv1+conv2 kernels never store a1; keep it for this check
-    gpulib.set_option("conv2_split", split)
+    gpulib.set_option("conv2_split", split)     # bits: 1 forward, 2 data gradient, 4 weight gradient on the bf16 pipe (csrc/conv_split.h)
     try:
         f0, _, saved = gpulib.enc_vanilla_fwd(xd, None, plist, 64)
+        gpulib.set_option("materialize_a1", 0)
+        grads = gpulib.enc_vanilla_bwd(xd, None, plist, 64, df.to(DEV), torch.empty(0, 64, device=DEV), saved)
     finally:
         gpulib.set_option("materialize_a1", 0)
         gpulib.set_option("conv2_split", 0)
-    grads = gpulib.enc_vanilla_bwd(xd, None, plist, 64, df.to(DEV), torch.empty(0, 64, device=DEV), saved)
     a1, p2, am2, a3 = (t.cpu() for t in gpulib.enc_saved_views(saved, n))
     pr = {k: v.clone().requires_grad_() for k, v in p.items()}
     fr, pre = O.vanilla_encoder_routed(x, pr, (a1 > 0).float(), am2, (p2 > 0).float(), (a3 > 0).float())
