@@ -353,7 +353,7 @@ __device__ __forceinline__ void block6(const bf16x8_t (&a)[3], const bf16x8_t (&
 template <int PY, bool HAS_PREV>
 __device__ __forceinline__ void half(const unsigned char* dyp, const float* strip, const bf16x8_t (&wd)[3 * (1 + PY)][3],
                                      const bf16x8_t (&we)[2 * (1 + PY)][3], const unsigned* __restrict__ mrow, f32x4_t& z, f32x4_t& z2,
-                                     int yl, int xh, const c2::D12Lane& ln, const c2::D12Pend& prev, c2::D12Pend& out, int dbg = 0) {
+                                     int yl, int xh, const c2::D12Lane& ln, const c2::D12Pend& prev, c2::D12Pend& out) {
   constexpr int NR = 1 + PY, NB = 3 * NR;
   const int lq = ln.lq;
   const unsigned* mrec = mrow + (2 * xh + (lq >> 1)) * c2::M1_REC + 2 * (ln.ci >> 4) + (lq & 1);
@@ -374,11 +374,9 @@ __device__ __forceinline__ void half(const unsigned char* dyp, const float* stri
   for (int b = 0; b < NB; ++b) {
     if (b + 1 < NB) fetch(b + 1, (b + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 4)) {       // (dbg: timing experiments only)
-      if (b % 3 < 2) block6<true>(a[b & 1], wd[b], we[2 * (b / 3) + b % 3], e, es, d, ds);
-      else block6<false>(a[b & 1], wd[b], wd[b], e, es, d, ds);
-    }
-    if (HAS_PREV && !(dbg & 2)) {          // the previous half's masks + conv1 weight-gradient MFMAs, spread over this half's blocks
+    if (b % 3 < 2) block6<true>(a[b & 1], wd[b], we[2 * (b / 3) + b % 3], e, es, d, ds);
+    else block6<false>(a[b & 1], wd[b], wd[b], e, es, d, ds);
+    if (HAS_PREV) {          // the previous half's masks + conv1 weight-gradient MFMAs, spread over this half's blocks
       if (NB == 3) { c2::d12_pend_step(prev, b, t0[b], t1[b], ln, z, z2); if (b == 2) c2::d12_pend_step(prev, 3, t0[3], t1[3], ln, z, z2); }
       else if (b < 4) c2::d12_pend_step(prev, b, t0[b], t1[b], ln, z, z2);
     }
@@ -408,7 +406,7 @@ __device__ __forceinline__ void wfrag(const float* stage, int ci, int tap, int c
 template <int PY>
 __device__ __forceinline__ void run(unsigned char* lds, const ImgSrc& x, const unsigned* __restrict__ m1, const float* __restrict__ dp2,
                                     const float* __restrict__ p2, const uint8_t* __restrict__ amax, float* __restrict__ slab1, int n_img,
-                                    int tid, int lane, int wave, int dbg) {
+                                    int tid, int lane, int wave) {
   constexpr int NR = 1 + PY;
   const int nt = wave & 1, g = (wave >> 1) & 1;
   const int lr = lane & 15, lq = lane >> 4;
@@ -421,7 +419,8 @@ __device__ __forceinline__ void run(unsigned char* lds, const ImgSrc& x, const u
   // One such loss is no larger than the fp32 chain's rounding in the same spot, but it always points the same way, and the conv1
   // weight gradient sums d a1 over every position of the batch.  So half of the waves (row group g = 1) hold the NEGATED weights:
   // their accumulators carry -d a1 with the same downward losses, the sign comes back for free in the tap operand of the conv1
-  // weight-gradient MFMAs (tmask / tconst), and over the two row groups of a band the losses cancel instead of adding up.
+  // weight-gradient MFMAs (tmask / tconst), and over the two row groups of a band the losses cancel instead of adding up.  The
+  // workgroup's bands alternate in sign on top of that (band loop).
   const float sg = g ? -1.f : 1.f;
   bf16x8_t wd[3 * NR][3], we[2 * NR][3];
   {
@@ -439,7 +438,7 @@ __device__ __forceinline__ void run(unsigned char* lds, const ImgSrc& x, const u
   }
   __syncthreads();        // the staging area becomes the band buffers
   const int toff = lr < 9 ? (lr / 3) * c2::SRS + lr % 3 : 0;
-  const c2::D12Lane ln{ci, lr, lq, toff, lr < 9 ? sg : 0.f, lr == 9 ? sg : 0.f, (unsigned)(ci & 15), (unsigned)(ci & 15) + 16u};
+  c2::D12Lane ln{ci, lr, lq, toff, lr < 9 ? sg : 0.f, lr == 9 ? sg : 0.f, (unsigned)(ci & 15), (unsigned)(ci & 15) + 16u};      // tmask / tconst flip sign from band to band, see the band loop
   f32x4_t z = {0.f, 0.f, 0.f, 0.f}, z2 = z;
 
   for (int bsel = 0; bsel < 2; ++bsel) {
@@ -487,13 +486,14 @@ __device__ __forceinline__ void run(unsigned char* lds, const ImgSrc& x, const u
     if (band > 0 || srow0 > 0) sv[0] = *reinterpret_cast<const float4*>(xs + srow0 * 128 + 4 * sx4);
     if (wave == 0 && lane < 32) sv[1] = *reinterpret_cast<const float4*>(xs + 16 * 128 + 4 * sx4);
   };
-  auto cells_store = [&](unsigned char* b0) {
+  auto cells_store = [&](unsigned char* b0, bool negate) {          // negate: the band's sign (the workgroup's bands alternate, see `sg`)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int W = wave + 8 * j;
       if (W < 18) {
         unsigned pc[3];
-        split3_pk(cp[j][0] > 0.f ? cdp[j][0] : 0.f, cp[j][1] > 0.f ? cdp[j][1] : 0.f, pc[0], pc[1], pc[2]);
+        const float g0 = cp[j][0] > 0.f ? cdp[j][0] : 0.f, g1 = cp[j][1] > 0.f ? cdp[j][1] : 0.f;
+        split3_pk(negate ? -g0 : g0, negate ? -g1 : g1, pc[0], pc[1], pc[2]);
         unsigned char* d = b0 + cell_l[j];
 #pragma unroll
         for (int w4 = 0; w4 < 4; ++w4) {          // window position (row w4 >> 1, column w4 & 1): the pair's pieces where its arg-max points
@@ -516,7 +516,7 @@ __device__ __forceinline__ void run(unsigned char* lds, const ImgSrc& x, const u
   };
   int tile = c2::first_tile<8>(blockIdx.x, gridDim.x);
   __syncthreads();
-  if (tile < ntiles) { cells_fetch(tile); cells_store(lds); }
+  if (tile < ntiles) { cells_fetch(tile); cells_store(lds, false); }
   if (tile + (int)gridDim.x < ntiles) cells_fetch(tile + gridDim.x);
   __syncthreads();
   int cur = 0;
@@ -534,19 +534,25 @@ __device__ __forceinline__ void run(unsigned char* lds, const ImgSrc& x, const u
 #define DGS_STAMP(i) do { } while (0)
 #endif
     DGS_STAMP(0);
+    // The workgroup's bands alternate in sign as well: this band's dY went into the patch as +dY (cur = 0) or -dY (cur = 1), and the
+    // sign returns in the tap operand.  The row groups' weight signs cancel the floors inside a band; over the 15 bands a workgroup
+    // sums for the 480-image batch what is left of them still pointed one way (db1 against float64 at 480 images: 4.9 / 9.9 x the
+    // fp32 kernel's error on the range / cancelling cases with the row-group signs alone).
+    const c2::D12Lane& lb = ln;
     c2::D12Pend pa, pb;
-    half<PY, false>(dyp, strip, wd, we, mrow, z, z2, y0, 0, ln, pb, pa, dbg);
-    half<PY, true>(dyp, strip, wd, we, mrow, z, z2, y0, 1, ln, pa, pb, dbg);
+    half<PY, false>(dyp, strip, wd, we, mrow, z, z2, y0, 0, lb, pb, pa);
+    half<PY, true>(dyp, strip, wd, we, mrow, z, z2, y0, 1, lb, pa, pb);
     DGS_STAMP(1);
     const int next = tile + (int)gridDim.x;
-    if (next < ntiles && !(dbg & 1)) {
-      cells_store(lds + (cur ^ 1) * BUFB);
+    if (next < ntiles) {
+      cells_store(lds + (cur ^ 1) * BUFB, cur == 0);
       if (next + (int)gridDim.x < ntiles) cells_fetch(next + gridDim.x);
     }
     DGS_STAMP(2);
-    half<PY, true>(dyp, strip, wd, we, mrow + 128, z, z2, y0 + 2, 0, ln, pb, pa, dbg);
-    half<PY, true>(dyp, strip, wd, we, mrow + 128, z, z2, y0 + 2, 1, ln, pa, pb, dbg);
-    if (!(dbg & 2)) c2::d12_flush(strip, pb, ln, z, z2);
+    half<PY, true>(dyp, strip, wd, we, mrow + 128, z, z2, y0 + 2, 0, lb, pb, pa);
+    half<PY, true>(dyp, strip, wd, we, mrow + 128, z, z2, y0 + 2, 1, lb, pa, pb);
+    c2::d12_flush(strip, pb, lb, z, z2);
+    ln.tmask = -ln.tmask; ln.tconst = -ln.tconst;        // the next band's dY is in the patch with the other sign
     DGS_STAMP(3);
     __syncthreads();
     DGS_STAMP(4);
@@ -560,13 +566,13 @@ __device__ __forceinline__ void run(unsigned char* lds, const ImgSrc& x, const u
 __global__ __launch_bounds__(dg::NT2) void conv12_dgrad_split_kernel(const ImgSrc x, const unsigned* __restrict__ m1,
                                                                       const float* __restrict__ dp2, const float* __restrict__ p2,
                                                                       const uint8_t* __restrict__ amax, const float* __restrict__ w,
-                                                                      float* __restrict__ slab1, int n_img, int dbg) {
+                                                                      float* __restrict__ slab1, int n_img) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[dg::LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   c2::conv2w_stage<dg::NT2>(reinterpret_cast<float*>(lds), w, tid);
   __syncthreads();
-  if (wave & 4) dg::run<1>(lds, x, m1, dp2, p2, amax, slab1, n_img, tid, lane, wave, dbg);
-  else dg::run<0>(lds, x, m1, dp2, p2, amax, slab1, n_img, tid, lane, wave, dbg);
+  if (wave & 4) dg::run<1>(lds, x, m1, dp2, p2, amax, slab1, n_img, tid, lane, wave);
+  else dg::run<0>(lds, x, m1, dp2, p2, amax, slab1, n_img, tid, lane, wave);
   __syncthreads();
   const float* red = reinterpret_cast<const float*>(lds + 2 * dg::BUFB);
   {

@@ -123,7 +123,7 @@ inline int conv12_backward(const c2::ImgSrc& xs, int n, const float* w1, const f
   MLHOT_TRY(between());
   if (g_opt.conv2_split & 2) {
     ProfScope ps("enc.bwd.conv12.dgrad.split", s);
-    hipLaunchKernelGGL(c2s::conv12_dgrad_split_kernel, dim3(grid), dim3(c2s::dg::NT2), 0, s, xs, sv.m1, dp2, sv.p2, sv.am2, w2, slab_1, n, g_opt.dbg >> 8);
+    hipLaunchKernelGGL(c2s::conv12_dgrad_split_kernel, dim3(grid), dim3(c2s::dg::NT2), 0, s, xs, sv.m1, dp2, sv.p2, sv.am2, w2, slab_1, n);
   } else {
     ProfScope ps("enc.bwd.conv12.dgrad", s);
     hipLaunchKernelGGL(c2::conv12_dgrad_kernel, dim3(grid), dim3(c2::NT2), 0, s, xs, sv.m1, dp2, sv.p2, sv.am2, w2, slab_1, n);
