@@ -12,6 +12,11 @@ stream; `roofline.forward`: the training forward against the MFMA and the HBM ro
 
     --workload c3 (default, BASELINE configs[2] = the headline metric) | c2 (configs[1]) | c5 (the per-GPU share of configs[4]:
     ANPMRShapeNet3D, Bayes-by-backprop ResNet encoder; eps drawn on the CPU generator by a host thread, one step ahead)
+
+The step is replayed as a hipGraph; with one rank and a vanilla workload --steps-per-graph (default 5) consecutive steps share a
+graph (the 8.8 us between two graph launches is paid once per five steps; K and W must be multiples, the timed region stays EXACTLY
+K steps).  `value` is exact fp32 arithmetic; `extras.split_precision_conv2` reports the same step with conv2 of the vanilla encoder
+on the bf16 matrix pipe over 3-piece splits of the fp32 operands (opt-in, csrc/conv_split.h) next to its own roof - never `value`.
 """
 import argparse
 import json
