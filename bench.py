@@ -810,7 +810,11 @@ def main():
                 except (OSError, ValueError):
                     pass
             lps = kernels[dom]["launches_per_step"]
-            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            roof = {"bound": "mfma", "kernel": dom,
+                    "measured_in": "eager steps, two HIP events around every launch (events cannot be read out of a replayed graph in this "
+                                   "process: scripts/micro/graph_events.hip); under back-to-back graph replay rocprofv3 sees the same kernels "
+                                   "~6 % shorter (profiles/*_kernel_stats_steady.csv)",
+                    "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_us": kernels[dom]["avg_us"],
                     "launches_per_step": lps, "alg_flops_per_launch": per_step[dom] / lps,
                     "all_labels_tflops": {k: round(per_step[k] / (agg[k][1] / args.prof_steps * 1e-3) / 1e12, 1) for k in per_step}}
