@@ -12,10 +12,10 @@ python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench_c3.json 2> $OUT/bench
 python bench.py --steps 50 --warmup 10 --workload c2 --no-cpu-baseline > $OUT/${TAG}_bench_c2.json 2> $OUT/bench_c2.err
 MLHOT_BENCH_KERNELS=$OUT/${TAG}_kernels_c3.json python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-# the roofline leg's command class: the captured step replayed a few dozen times + a few eager steps (what bench.py's per-launch events see)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-prewarm > $OUT/stats.log 2>&1
-# the same kernels under ~250 back-to-back replays (pre-warm + timed region, no eager steps): the durations the timed region runs at
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_steady -o stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/stats_steady.log 2>&1
+# the bench command itself (pre-warm replays, timed region, and the roofline leg's eager steps, each behind a few replays)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
+# the same without pre-warm and with the GPU idle in front of the eager steps (what the numbers of rounds 1-3 were taken in)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cold -o stats -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-prewarm > $OUT/stats_cold.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_write.log 2>&1
 # SQ / GRBM pass: MFMA-pipe busy cycles and the wave-cycle split (active / issue-stalled / parked) of the hot kernels

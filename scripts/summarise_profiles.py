@@ -35,9 +35,9 @@ if os.path.exists(os.path.join(SRC, f"{tag}_pmc_traffic_c5.json")):
 stats = find("stats/**/*kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(DST, f"{tag}_kernel_stats.csv"))
-steady = find("stats_steady/**/*kernel_stats.csv")
-if steady:
-    shutil.copy(steady, os.path.join(DST, f"{tag}_kernel_stats_steady.csv"))
+cold = find("stats_cold/**/*kernel_stats.csv")
+if cold:
+    shutil.copy(cold, os.path.join(DST, f"{tag}_kernel_stats_cold.csv"))
 stats_c5 = find("stats_c5/**/*kernel_stats.csv")
 if stats_c5:
     shutil.copy(stats_c5, os.path.join(DST, f"{tag}_kernel_stats_c5.csv"))
