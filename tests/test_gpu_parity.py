@@ -1517,10 +1517,15 @@ def _trajectory_check(model, p0, oracle_step, batches, make_opt, cfg, tmp_path, 
     return losses
 
 
-@pytest.mark.parametrize("optimizer", ["torch_adam", "flat_adam"])
-def test_trainer_trajectory_vs_oracle(gpulib, tmp_path, monkeypatch, optimizer):
+@pytest.mark.parametrize("optimizer", ["torch_adam", "flat_adam", "flat_adam_split"])
+def test_trainer_trajectory_vs_oracle(gpulib, tmp_path, monkeypatch, optimizer, request):
     """ANPShapeNet1D, T = 2, fixed 5 + 5 shots, 4 training iterations of trainer.ModelTrainer with torch.optim.Adam and with
-    mlhot.optim.FlatAdam against the oracle's forward + autograd + torch.optim.Adam (see _trajectory_check)."""
+    mlhot.optim.FlatAdam against the oracle's forward + autograd + torch.optim.Adam (see _trajectory_check); `_split`: the same with
+    all three conv12 kernels on the bf16 pipe over split operands (csrc/conv_split.h), same tolerances."""
+    if optimizer.endswith("_split"):
+        gpulib.set_option("conv2_split", 7)
+        request.addfinalizer(lambda: gpulib.set_option("conv2_split", 0))
+        optimizer = optimizer[:-len("_split")]
     import contextlib
     import types
     from mlhot import ops
