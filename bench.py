@@ -2,7 +2,10 @@
 """Headline benchmark: meta-tasks/s, forward+backward, ANPShapeNet1D 15+15-shot, 16 tasks per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N>1 works both ways: under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or as the plain command above - with no WORLD_SIZE in the
+    environment this process touches no GPU, starts N rank processes of itself (one per GPU, rendezvous on 127.0.0.1), relays rank
+    0's JSON line and exits with the worst rank's code (`spawn_ranks`).
 
 A step = zero_grad + forward + loss + backward (+ one flat gradient all-reduce when N>1) of the
 hand-written HIP path on a synthetic meta-batch that is already resident in HBM.  Rank 0 prints ONE
@@ -598,6 +601,65 @@ def timed_region(run, steps, warmup, world, device, sync=None, record=None):
     return elapsed, t_enqueue, out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, child_cmd, env=None, port=None, poll_s=0.05, grace_s=20.0, out=None, err=None):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of `child_cmd` (a list; each gets RANK = LOCAL_RANK = r,
+    WORLD_SIZE = n, MASTER_ADDR = 127.0.0.1 and one free MASTER_PORT), wait for all of them, relay rank 0's stdout - the ONE JSON
+    line(s) starting with '{' - to `out` and everything else (library chatter, the other ranks' stdout; prefixed) to `err`; return the WORST exit code.  When a rank dies
+    the others would sit in a collective until its timeout, so they are given `grace_s` and then terminated - by PID, these are
+    this process's own children.  The caller must not have touched the GPU: the children are fresh processes (no fork of a HIP
+    context, no exec of a process that initialised one)."""
+    import subprocess
+    import tempfile
+    out, err = out or sys.stdout, err or sys.stderr
+    env = dict(os.environ if env is None else env)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port or _free_port()))
+    env.setdefault("NCCL_DEBUG", "VERSION")              # RCCL prints its version line on stderr: evidence of the backend that ran
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC (the only kind this host driver supports) for RCCL's P2P setup
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs, files = [], []
+    try:
+        for r in range(n):
+            f = tempfile.TemporaryFile(mode="w+")
+            files.append(f)
+            procs.append(subprocess.Popen(list(child_cmd), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=f, stderr=None))
+        codes, first_fail = [None] * n, None
+        while any(c is None for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = p.poll()
+                    if codes[r] not in (None, 0) and first_fail is None:
+                        first_fail = time.monotonic()
+                        print(f"[bench] rank {r} exited with code {codes[r]}; the other ranks get {grace_s:.0f} s", file=err)
+            if first_fail is not None and time.monotonic() - first_fail > grace_s:
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.terminate()
+                first_fail = float("inf")
+            time.sleep(poll_s)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, f in enumerate(files):
+        f.seek(0)
+        for ln in f.read().splitlines():                     # rank 0's JSON line(s) are the product; library chatter on stdout ("[Gloo] Rank 0 is
+            if r == 0 and ln.startswith("{"):                # connected to ...") and the other ranks' stdout go to stderr
+                print(ln, file=out)
+            else:
+                print(f"[rank {r}] {ln}", file=err)
+        f.close()
+    out.flush()
+    worst = max(codes, key=lambda c: (c != 0, abs(c)))
+    return worst if worst >= 0 else 128 - worst          # a rank killed by signal s: 128 + s, as a shell reports it
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -626,6 +688,14 @@ def main():
                          "default) or the same MT19937 stream continued on the GPU (mlhot_mt19937_normal)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="mlhot_set_option switches for A/B runs, e.g. c12_split=0")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one.  Nothing above touched the GPU (torch.cuda.device_count() does not initialise it on this image)
+        have = torch.cuda.device_count()
+        if have < args.gpus and not os.environ.get("MLHOT_ONE_DEVICE"):
+            print(f"[bench] --gpus {args.gpus} but this node shows {have} GPU(s)", file=sys.stderr)
+            sys.exit(2)
+        print(f"[bench] no WORLD_SIZE in the environment: starting {args.gpus} rank processes (one per GPU, rendezvous on 127.0.0.1)", file=sys.stderr)
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(os.environ, MLHOT_BENCH_LAUNCHER="self")))
     w = dict(WORKLOADS[args.workload], key=args.workload)
     T = w["T"]
     c5 = w["kind"] == "resnet3d"
@@ -639,7 +709,9 @@ def main():
     # MLHOT_DIST_BACKEND / MLHOT_ONE_DEVICE: test hooks (e.g. two gloo ranks sharing the only GPU of a 1-GPU box, to
     # exercise the N>1 control flow); the driver's launch uses neither (nccl = RCCL, one rank per GPU)
     rank, local, world = mdist.init_from_env(os.environ.get("MLHOT_DIST_BACKEND"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}: start me with --gpus {world}, or without a launcher", file=sys.stderr)
+        sys.exit(2)
     if os.environ.get("MLHOT_ONE_DEVICE"):
         local = 0
     device = torch.device("cuda", local)
@@ -661,8 +733,8 @@ def main():
     if (world > 1 or mdist.force_collectives()) and rank == 0:
         print(f"[bench] key stabiliser: {stabiliser}", file=sys.stderr)
     if world > 1 and rank == 0:
-        print(f"[bench] {world} ranks over {dist.get_backend()} (RCCL when 'nccl'); rank 0 on {torch.cuda.get_device_name(device)}; "
-              f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG', '-')}", file=sys.stderr)
+        print(f"[bench] backend {dist.get_backend()} (RCCL when 'nccl') reports {dist.get_world_size()} ranks; rank 0 on "
+              f"{torch.cuda.get_device_name(device)}; NCCL_DEBUG={os.environ.get('NCCL_DEBUG', '-')}", file=sys.stderr)
 
     model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(make_cfg(w, device)).to(device)
     loss_fn = LossFunc("mse", w["task"])
@@ -864,6 +936,9 @@ def main():
                "config": {"workload": w["name"], "tasks_per_gpu": T, "global_tasks": world * T,
                           "context_shots": NC, "target_shots": NQ, "image": w["image"],
                           "parallelism": f"task-sharded x{world}, one flat grad all-reduce" if world > 1 else "single GPU"},
+               "dist": ({"backend": dist.get_backend(), "ranks_reported_by_backend": dist.get_world_size(),
+                         "launcher": "bench.py itself (spawn_ranks)" if os.environ.get("MLHOT_BENCH_LAUNCHER") == "self" else "external (WORLD_SIZE in the environment)"}
+                        if dist.is_initialized() else None),
                "final_loss": final_loss, "hipgraph": graphed, "steps_per_graph": spg, "key_stabiliser": stabiliser, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
                "ms_per_step_event_median": step_ms[len(step_ms) // 2], "ms_per_step_event_min": step_ms[0], "ms_per_step_event_max": step_ms[-1],
                "timing": f"value = wall clock over {args.steps} steps ({n_run} graph launches of {spg} step(s)) between two barrier + synchronize fences (max over ranks), "

@@ -2,6 +2,7 @@
 all-reduce (mlhot.dist.GradBucket) - the averaged shard gradients must equal the gradient of the
 un-sharded batch.  The per-rank compute here is the CPU oracle (checker), since the
 product's kernels only run on a GPU; what is under test is the sharding + bucket + collective."""
+import json
 import os
 import socket
 
@@ -210,6 +211,63 @@ def test_bench_timing_protocol_on_eight_ranks():
             assert p.exitcode == 0
         vals = [out[r] for r in range(8)]
         assert max(vals) - min(vals) < 1e-9 and vals[0] >= 5 * 0.004
+
+
+# ---- bench.py --gpus N without a launcher: spawn_ranks (no GPU needed: the children are tiny python programs) ---------------------
+_SPAWN_CHILD = r"""
+import json, os, sys
+import torch, torch.distributed as dist
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert int(os.environ["LOCAL_RANK"]) == r and os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["NCCL_DEBUG"] == "VERSION"
+dist.init_process_group("gloo", rank=r, world_size=w)          # MASTER_PORT: one free port, the same for every rank
+t = torch.tensor([float(r + 1)])
+dist.all_reduce(t)
+print("rank %d says hello" % r)                                 # the other ranks' stdout must NOT reach the parent's stdout
+if r == 0:
+    print(json.dumps({"n_gpus": dist.get_world_size(), "sum": t.item(), "backend": dist.get_backend()}))
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(int(os.environ.get("FAIL_RANK", "-1")) == r and 7 or 0)
+"""
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no WORLD_SIZE: bench.spawn_ranks starts N processes with the launcher's environment, relays
+    rank 0's stdout only, returns the worst exit code, and does not hang on a rank that dies."""
+    import io
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root]
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text(_SPAWN_CHILD)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "NCCL_DEBUG")}
+    out, err = io.StringIO(), io.StringIO()
+    rc = bench.spawn_ranks(3, [sys.executable, str(child)], env=env, out=out, err=err)
+    assert rc == 0, err.getvalue()
+    lines = out.getvalue().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 3, "sum": 6.0, "backend": "gloo"}, lines
+    assert all(f"[rank {r}] rank {r} says hello" in err.getvalue() for r in range(3))
+    # the worst exit code wins
+    out, err = io.StringIO(), io.StringIO()
+    assert bench.spawn_ranks(2, [sys.executable, str(child)], env=dict(env, FAIL_RANK="1"), out=out, err=err) == 7
+    # a rank that dies before the rendezvous: the survivor is terminated after the grace period instead of waiting out gloo's timeout
+    dies = tmp_path / "dies.py"
+    dies.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(3)\ntime.sleep(600)\n")
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(2, [sys.executable, str(dies)], env=env, grace_s=1.0, out=io.StringIO(), err=io.StringIO())
+    assert rc == 128 + 15 and time.monotonic() - t0 < 30          # SIGTERM of the sleeping rank outranks the exit code 3
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """Under a launcher whose WORLD_SIZE differs from --gpus bench.py exits with a message and code 2 (it used to be an assert)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE is 1" in r.stderr and "Traceback" not in r.stderr
 
 
 # ---- the early bucket: its all-reduce leaves from inside backward(), before the late gradients exist -----------------------------

@@ -1941,6 +1941,25 @@ def test_bench_two_rank_control_flow_on_one_gpu(gpulib, workload, tasks):
     assert abs(out["value"] - 2 * tasks * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
 
 
+def test_bench_launches_its_own_ranks_on_one_gpu(gpulib):
+    """Plain `python bench.py --gpus 2 --workload c3` - no torchrun, no WORLD_SIZE - starts its two ranks itself (bench.spawn_ranks;
+    here both share this box's only GPU through the MLHOT_ONE_DEVICE / gloo hooks, on an 8-GPU node the same command runs one rank
+    per GPU over RCCL), relays ONE JSON line and says who launched and what the backend reports."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MLHOT_DIST_BACKEND="gloo", MLHOT_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c3", "--steps", "4", "--warmup", "2"],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == [ln for ln in r.stdout.splitlines() if ln.startswith("{")] and r.stdout.count("\n") == 1, r.stdout[-2000:]
+    out = json.loads(r.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["global_tasks"] == 32 and out["hipgraph"] is True and out["scaling"] == "weak"
+    assert out["dist"]["ranks_reported_by_backend"] == 2 and out["dist"]["launcher"].startswith("bench.py itself")
+    assert "starting 2 rank processes" in r.stderr and "reports 2 ranks" in r.stderr
+
+
 def _bucket_cuda_worker(rank, world, port, out):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
