@@ -37,11 +37,11 @@ import torch  # noqa: E402
 
 WORKLOADS = {   # BASELINE.json configs[1] / configs[2] (the headline metric) and the per-GPU share of configs[4]
     "c3": dict(kind="vanilla", method="ANPShapeNet1D", agg_mode="attention", dim_r=64, T=16, image="128x128x1", task="shapenet_1d",
-               fwd_gflop_per_task=1.062, name="ANPShapeNet1D 128x128x1 15-shot context + 15 target, 16 tasks/GPU (BASELINE configs[2])"),
+               cfg="bench_c3_ANP_ShapeNet1D.yaml", fwd_gflop_per_task=1.062, name="ANPShapeNet1D 128x128x1 15-shot context + 15 target, 16 tasks/GPU (BASELINE configs[2])"),
     "c2": dict(kind="vanilla", method="CNPShapeNet1D", agg_mode="mean", dim_r=100, T=16, image="128x128x1", task="shapenet_1d",
-               fwd_gflop_per_task=1.044, name="CNPShapeNet1D mean-agg 128x128x1 15+15-shot, 16 tasks/GPU (BASELINE configs[1])"),
+               cfg="bench_c2_CNP_ShapeNet1D.yaml", fwd_gflop_per_task=1.044, name="CNPShapeNet1D mean-agg 128x128x1 15+15-shot, 16 tasks/GPU (BASELINE configs[1])"),
     "c5": dict(kind="resnet3d", method="ANPMRShapeNet3D", agg_mode="attention", T=8, image="64x64x3", task="shapenet_3d", beta=1e-7,
-               fwd_gflop_per_task=3.92,
+               cfg="bench_c5_ANPMR_ShapeNet3D.yaml", fwd_gflop_per_task=3.92,
                name="ANPMRShapeNet3D (Bayes-by-backprop ResNet encoder) 64x64x3 15+15-shot + task augmentation of the labels, 8 tasks/GPU "
                     "(the per-GPU share of BASELINE configs[4]: 64 tasks over 8 GPUs)"),
     # SURVEY §8f rank 4 (not a BASELINE config; kernel-time evidence for the 128 x 128 x 1 trunk geometries): cfg/train/ANP_Distractor.yaml
@@ -121,15 +121,21 @@ def trunk_flops_per_step(T, kind="resnet3d"):
 
 
 def make_cfg(w, device):
-    if w["kind"] == "resnet3d":
-        return types.SimpleNamespace(device=device, seed=2578, img_size=[64, 64, 4], tasks_per_batch=w["T"], input_dim=4, output_dim=4,
-                                     agg_mode="attention", img_agg="reshape", task="shapenet_3d", temperature=0.07, method=w["method"])
-    if w["kind"] == "resnet_dis":
-        return types.SimpleNamespace(device=device, seed=2578, img_size=[128, 128, 1], tasks_per_batch=w["T"], input_dim=2, output_dim=2,
-                                     agg_mode="attention", img_agg="max", dim_w=16, task="distractor", temperature=0.07, method=w["method"])
-    return types.SimpleNamespace(device=device, seed=2578, img_size=[128, 128, 1], tasks_per_batch=w["T"], input_dim=3,
-                                 output_dim=2, agg_mode=w["agg_mode"], img_agg="", dim_w=64, n_hidden_units_r=[100, 100],
-                                 dim_r=w["dim_r"], dim_z=64, task="shapenet_1d", method=w["method"])
+    """The model's config.  The BASELINE workloads come from the cfg/ YAMLs the package ships (cfg/train/bench_c*.yaml: the reference's
+    key surface, parsed by configs.config.Config as train.py would) with tasks_per_batch replaced by this rank's share."""
+    if w.get("cfg"):
+        import yaml
+        from configs.config import Config
+        with open(os.path.join(ROOT, "what-matters-for-meta-learning_amd", "cfg", "train", w["cfg"]), "rb") as f:
+            raw = yaml.safe_load(f)
+        raw["device"] = str(device)
+        cfg = Config()
+        cfg.set_init_values(raw, side_effects=False)          # no results/ directory, no log file
+        assert cfg.method == w["method"] and cfg.task == w["task"] and (w["kind"] != "vanilla" or cfg.agg_mode == w["agg_mode"])
+        cfg.tasks_per_batch = w["T"]
+        return cfg
+    return types.SimpleNamespace(device=device, seed=2578, img_size=[128, 128, 1], tasks_per_batch=w["T"], input_dim=2, output_dim=2,
+                                 agg_mode="attention", img_agg="max", dim_w=16, task="distractor", temperature=0.07, method=w["method"])
 
 
 def make_batch(w, seed, device="cpu"):
