@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLHOT_ABI_VERSION 3
+#define MLHOT_ABI_VERSION 4
 
 enum { MLHOT_ACT_NONE = 0, MLHOT_ACT_RELU = 1, MLHOT_ACT_TANH = 2 };
 enum { MLHOT_AGG_MEAN = 0, MLHOT_AGG_MAX = 1, MLHOT_AGG_BACO = 2, MLHOT_AGG_ATTENTION = 3 };
@@ -387,6 +387,17 @@ int mlhot_np_vanilla_bwd(const mlhot_np_dims* d, const mlhot_np_params* p,
                          const float* ctx_x, const float* ctx_y, const float* qry_x,
                          const float* mu, const float* dmu, const mlhot_np_grads* g,
                          const void* saved, void* scratch, size_t scratch_bytes, void* stream);
+/* The same backward taking the loss's gradient itself: trainer/model_trainer.py:77-79 computes `loss = calc_loss(mu, ., y)` and
+ * calls loss.backward(); d loss / d mu of trainer/losses.py:32-80 needs no reduction, so the model's first backward kernel derives
+ * it from (mu, gt) instead of reading a dmu that a separate launch wrote (the fused attention tail's specialised kernel does it in
+ * its prologue; every other configuration materialises it first - same result either way):
+ *   dmu_total = (dmu ? dmu : 0) + d loss(kind; mu, gt) / d mu * dloss[0]
+ * kind: MLHOT_LOSS_* with a gradient (0 azimuth, 1 mse, 2 quaternion, 4 distractor); gt[T*Nq, gt_dim]; dloss: device scalar. */
+typedef struct { int kind; const float* gt; int gt_dim; const float* dloss; } mlhot_loss_desc;
+int mlhot_np_vanilla_bwd_loss(const mlhot_np_dims* d, const mlhot_np_params* p,
+                              const float* ctx_x, const float* ctx_y, const float* qry_x,
+                              const float* mu, const float* dmu, const mlhot_loss_desc* loss, const mlhot_np_grads* g,
+                              const void* saved, void* scratch, size_t scratch_bytes, void* stream);
 /* Staged variants (see "strict sharded parity" above).  Built on the fused attention tail's launch boundaries: attention
  * aggregation with Nc, Nq <= 16 (every shipped ANP configuration); MLHOT_ERR_UNSUPPORTED otherwise. */
 int mlhot_np_vanilla_fwd_staged(const mlhot_np_dims* d, const mlhot_np_params* p,

@@ -441,7 +441,7 @@ def _run_case(gpulib, name):
     return flips
 
 
-@pytest.fixture(params=[(1, 63), (1, 0), (0, 0)], ids=["tail_spec", "tail_fused", "tail_generic"])
+@pytest.fixture(params=[(1, 127), (1, 63), (1, 0), (0, 0)], ids=["tail_spec", "tail_spec_separate_fold", "tail_fused", "tail_generic"])
 def tail_impl(gpulib, request):
     """The three flavours of everything between the encoder and the loss: the fused per-task / per-head tail kernels specialised
     for the shipped dimensions (csrc/tail_spec.h: dim_w = dim_z = 64, hidden 100; the default where it applies), the same
@@ -450,7 +450,7 @@ def tail_impl(gpulib, request):
     gpulib.set_option("tail_spec", request.param[1])
     yield request.param
     gpulib.set_option("tail_fused", 1)
-    gpulib.set_option("tail_spec", 63)
+    gpulib.set_option("tail_spec", 127)
 
 
 @pytest.mark.parametrize("name", U.model_case_names("s_"))
@@ -517,6 +517,62 @@ def test_tail_with_sharp_attention_vs_oracle(gpulib, tail_impl, T, Nc, Nq):
             assert e <= U.RTOL, f"{k}: {e:.2e}"
     print(f"sharp attention T={T} {Nc}+{Nq}: query / key gradients at {min(qk):.1e} .. {max(qk):.1e} of the largest, worst error "
           f"{worst_qk[0]:.2e} of their own scale ({worst_qk[1]}); others {worst[0]:.2e} ({worst[1]})")
+
+
+@pytest.mark.parametrize("method,agg,task,shape", [("ANPShapeNet1D", "attention", "shapenet_1d", (3, 7, 9)), ("ANPShapeNet1D", "attention", "shapenet_1d", (2, 15, 15)),
+                                                   ("ANPShapeNet1D", "attention", "shapenet_1d", (2, 17, 20)), ("CNPShapeNet1D", "mean", "shapenet_1d", (3, 7, 9)),
+                                                   ("ANPVanillaPascal1D", "attention", "pascal_1d", (2, 5, 5))])
+def test_loss_gradient_taken_inside_the_models_backward(gpulib, method, agg, task, shape):
+    """mlhot_np_vanilla_bwd_loss (mlhot.ops.defer_loss_grad): calc_loss(mu, ., y).backward() with the loss's gradient derived by the
+    model's first backward kernel (phase C' of the specialised attention tail; materialised inside the C call for every other
+    configuration: CNP, > 16 shots) gives BIT-IDENTICAL parameter gradients to the two-node form - also when mu has a second
+    consumer (autograd adds its gradient to the zero placeholder, the kernel adds the loss's on top), and with the loss VALUE
+    reduced on a forked stream (loss_value_aside)."""
+    import importlib
+    import types
+    from mlhot import ops
+    from trainer.losses import LossFunc
+    T, Nc, Nq = shape
+    pascal = task == "pascal_1d"
+    cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[128, 128, 1], tasks_per_batch=T, input_dim=1 if pascal else 3,
+                                output_dim=1 if pascal else 2, agg_mode=agg, img_agg="", dim_w=64, n_hidden_units_r=[100, 100],
+                                dim_r=64 if agg == "attention" else 100, dim_z=64, task=task)
+    model = getattr(importlib.import_module("networks." + method), method)(cfg).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    L = cfg.input_dim
+    cx, qx = torch.rand(T, Nc, 1, 128, 128, generator=g).to(DEV), torch.rand(T, Nq, 1, 128, 128, generator=g).to(DEV)
+    cy, qy = torch.rand(T, Nc, L, generator=g).to(DEV), torch.rand(T, Nq, L, generator=g).to(DEV)
+    loss_fn = LossFunc("mse", task)
+    seed = torch.full((), 0.75, device=DEV)
+
+    def run(defer, second_consumer, aside):
+        ops.defer_loss_grad = defer
+        try:
+            model.zero_grad(set_to_none=True)
+            mu = model(cx, cy, qx)[0]
+            with ops.loss_value_aside(enabled=aside):
+                loss = loss_fn.calc_loss(mu, None, qy)
+                total = loss + 0.3 * (mu * mu).sum() if second_consumer else loss
+                total.backward(gradient=seed)
+            torch.cuda.synchronize()
+            return loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        finally:
+            ops.defer_loss_grad = True
+
+    for second in (False, True):
+        ref_loss, ref = run(False, second, False)
+        for aside in ((False, True) if not second else (False,)):      # with a second consumer the sum reads the loss inside the block: no lane
+            got_loss, got = run(True, second, aside)
+            assert got_loss == ref_loss and got.keys() == ref.keys()
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), (k, second, aside)
+    # the placeholder autograd carried is still all zeros (nothing accumulated into it in place)
+    assert all(float(z.abs().max()) == 0.0 for z in ops._zero_grads.values())
+    # asking for d loss / d mu itself (retain_grad) keeps the two-node form: the real gradient reaches mu.grad
+    mu = model(cx, cy, qx)[0]
+    mu.retain_grad()
+    loss_fn.calc_loss(mu, None, qy).backward()
+    assert float(mu.grad.abs().max()) > 0
 
 
 @pytest.mark.parametrize("name", U.model_case_names("c"))

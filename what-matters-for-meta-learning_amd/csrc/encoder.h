@@ -132,8 +132,13 @@ inline int conv12_backward(const c2::ImgSrc& xs, int n, const float* w1, const f
 }
 #endif
 
+// `xfold`: the caller's first kernel folds the Linear's split-K partial results itself (the fused attention tail's phase A reads the
+// feature tiles anyway: one launch and its ~4.7 us off the forward's critical path).  On return xfold->slab / bias / k / n describe
+// the partial results [k][n][dim_w] - or slab == nullptr when this path wrote `feat` itself (generic Linear, other widths).
+struct EncXFold { const float* slab; const float* bias; int k, n; };
 inline int enc_forward(const float* img0, int n0, const float* img1, int n1, const mlhot_enc_params& p, int dim_w,
-                       Rows2 feat, void* saved, void* scratch, size_t scratch_bytes, hipStream_t s) {
+                       Rows2 feat, void* saved, void* scratch, size_t scratch_bytes, hipStream_t s, EncXFold* xfold = nullptr) {
+  if (xfold != nullptr) *xfold = EncXFold{nullptr, nullptr, 0, 0};
   const int n = n0 + n1;
   if (n <= 0) return MLHOT_OK;
   EncSaved sv = enc_saved_carve(n, saved, (size_t)-1 / 2);
@@ -177,6 +182,7 @@ inline int enc_forward(const float* img0, int n0, const float* img1, int n1, con
       hipLaunchKernelGGL(el::enc_linear_fwd_kernel, dim3(((n + 15) / 16) * el::F_KS), dim3(256), 0, s, sv.a3, p.wl, sc.slab, n);
     }
     MLHOT_TRY(check_launch("enc.linear"));
+    if (xfold != nullptr) { *xfold = EncXFold{sc.slab, p.bl, el::F_KS, n}; return MLHOT_OK; }
     {
       ProfScope ps("slab_reduce", s);
       hipLaunchKernelGGL(el::enc_linear_fold_kernel, dim3((n * el::DW + 255) / 256), dim3(256), 0, s, sc.slab, p.bl, feat, n);

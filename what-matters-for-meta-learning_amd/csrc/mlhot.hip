@@ -30,7 +30,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-Options g_opt = {1, 1, 0, 0, 63, 0};
+Options g_opt = {1, 1, 0, 0, 255, 0};
 int g_favor2 = 1;
 #ifndef MLHOT_HOSTSIM
 namespace rt { int g_trunk_fuse34 = 1, g_trunk_dual_dgrad = 1; }
@@ -88,7 +88,7 @@ int mlhot_set_option(const char* name, int value) {
   if (!strcmp(name, "conv2_tc")) { g_opt.conv2_tc = value; return MLHOT_OK; }
   if (!strcmp(name, "conv2_split")) { g_opt.conv2_split = value; return MLHOT_OK; }
   if (!strcmp(name, "tail_fused")) { g_opt.tail_fused = value; return MLHOT_OK; }
-  if (!strcmp(name, "tail_spec")) { g_opt.tail_spec = value; return MLHOT_OK; }     // fused tail: bit mask of the phases that run the kernels specialised for the shipped dimensions (csrc/tail_spec.h; default 63 = all six) instead of the run-time-shaped ones
+  if (!strcmp(name, "tail_spec")) { g_opt.tail_spec = value; return MLHOT_OK; }     // fused tail: bit mask of the phases that run the kernels specialised for the shipped dimensions (csrc/tail_spec.h; bits 1..32 = the six phases, 64 = phase A also folds the encoder Linear's split-K partial results, 128 = phase C' takes the loss's gradient itself when handed a loss descriptor; default 255 = all) instead of the run-time-shaped ones
   if (!strcmp(name, "materialize_a1")) { g_opt.materialize_a1 = value; return MLHOT_OK; }
   if (!strcmp(name, "dbg")) { g_opt.dbg = value; return MLHOT_OK; }   // timing experiments only (results become wrong)
   if (!strcmp(name, "favor2")) { g_favor2 = value; return MLHOT_OK; }
@@ -320,7 +320,7 @@ int mlhot_loss_fwd(int kind, const float* mu, const float* gt, int rows, int y_d
 int mlhot_loss_bwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim, const float* dloss,
                    float* dmu, void* stream) {
   if (kind < 0 || kind > 4 || rows <= 0 || y_dim <= 0 || y_dim > 8 || gt_dim < 1) { set_error("loss_bwd: bad argument"); return MLHOT_ERR_ARG; }
-  return run_foreach(LossBwd{kind, y_dim, gt_dim, rows, mu, gt, dloss, dmu}, (size_t)rows, (hipStream_t)stream, "loss_bwd");
+  return run_foreach(LossBwd{kind, y_dim, gt_dim, rows, mu, gt, dloss, dmu, nullptr}, (size_t)rows, (hipStream_t)stream, "loss_bwd");
 }
 
 // ---- E2 / D2 building blocks: run-time-shaped conv, residual join, 2x2 max-pool; B1: BBB sample -------
@@ -604,6 +604,16 @@ int mlhot_np_vanilla_bwd(const mlhot_np_dims* d, const mlhot_np_params* p, const
                          void* scratch, size_t scratch_bytes, void* stream) {
   if (!d || !p || !g) { set_error("np_vanilla_bwd: null dims/params/grads"); return MLHOT_ERR_ARG; }
   return np_backward(*d, *p, ctx_x, ctx_y, qry_x, mu, dmu, *g, saved, scratch, scratch_bytes, (hipStream_t)stream);
+}
+int mlhot_np_vanilla_bwd_loss(const mlhot_np_dims* d, const mlhot_np_params* p, const float* ctx_x, const float* ctx_y,
+                              const float* qry_x, const float* mu, const float* dmu, const mlhot_loss_desc* loss, const mlhot_np_grads* g,
+                              const void* saved, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!d || !p || !g || !loss) { set_error("np_vanilla_bwd_loss: null dims/params/grads/loss"); return MLHOT_ERR_ARG; }
+  if (loss->kind < 0 || loss->kind > 4 || loss->kind == 3 || !loss->gt || !loss->dloss || loss->gt_dim < 1) {
+    set_error("np_vanilla_bwd_loss: bad loss descriptor (kinds 0, 1, 2, 4 have a gradient)"); return MLHOT_ERR_ARG;
+  }
+  const LossDesc ld{loss->kind, loss->gt, loss->gt_dim, loss->dloss};
+  return np_backward(*d, *p, ctx_x, ctx_y, qry_x, mu, dmu, *g, saved, scratch, scratch_bytes, (hipStream_t)stream, Stage{}, &ld);
 }
 int mlhot_np_vanilla_fwd_staged(const mlhot_np_dims* d, const mlhot_np_params* p, const float* ctx_x, const float* ctx_y,
                                 const float* qry_x, float* mu, void* saved, void* scratch, size_t scratch_bytes, int stage, float* xchg,

@@ -62,6 +62,7 @@ struct NpScratch {
   float *d_dec_in, *dd1, *dd2, *d_cat_in, *dh[MLHOT_MAX_HIDDEN], *d_rs;
   float *d_rr, *d_merged, *dqh, *dkh, *dvh, *dzt, *dr, *d_mu_l, *d_lv;
   float* tail_slab;   // fused tail: per-task weight-gradient partials
+  float* dmu_tmp;     // [Rq][y_dim]: upstream gradient + the loss's own, where the first backward kernel cannot take the loss itself
   bool ok; size_t bytes;
 };
 
@@ -74,6 +75,7 @@ inline NpScratch np_scratch_carve(const mlhot_np_dims& d, void* base, size_t cap
   s.enc = a.take<char>(s.enc_bytes);
   s.d_dec_in = a.take<float>(Rq * (dw + d.dim_z));
   s.dd1 = a.take<float>(Rq * d.dec_hidden); s.dd2 = a.take<float>(Rq * d.dec_hidden);
+  s.dmu_tmp = a.take<float>(Rq * d.y_dim);
   if (d.Nc > 0) {
     s.d_cat_in = a.take<float>(Rc * (dw + dw / 4));
     for (int i = 0; i < d.n_hidden; ++i) s.dh[i] = a.take<float>(Rc * d.hidden[i]);
@@ -189,8 +191,13 @@ inline int tail_launch(K kernel, int grid, int block, size_t lds, const A& args,
   return check_launch(what);
 }
 
+// does phase A of this forward run the specialised kernel (which can fold the encoder Linear's partial results itself)?
+inline bool tail_phaseA_folds(const mlhot_np_dims& d) {
+  static_assert(ts::XK == el::F_KS, "phase A folds the encoder Linear's split-K factor");
+  return tail_fused_applies(d) && ts::applies(tail_dims(d)) && (g_opt.tail_spec & 1) && (g_opt.tail_spec & 64) && g_opt.conv2_tc && d.dim_w == el::DW;
+}
 inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, float* mu,
-                              const NpBuf& b, const NpScratch& sc, hipStream_t s, const Stage& st = Stage{}) {
+                              const NpBuf& b, const NpScratch& sc, hipStream_t s, const Stage& st = Stage{}, const EncXFold& xf = EncXFold{nullptr, nullptr, 0, 0}) {
   const tf::TailDims td = tail_dims(d);
   const tf::TailParams tp = tail_params(p);
   FavorDims f{d.T, MLHOT_HEADS, d.Nq, d.Nc, d.dim_w, d.m_feat};
@@ -199,9 +206,10 @@ inline int tail_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
   // the kernels specialised for the shipped dimensions (csrc/tail_spec.h) where they apply; the option is a bit mask over the
   // phases (1 / 2 / 4: forward A / B / C, 8 / 16 / 32: backward C / B / A; default 63 = all; per-phase A/B experiments)
   const int spec = ts::applies(td) ? g_opt.tail_spec : 0;
-  tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, w.pc, w.max_k, w.arg_k, b.wot};
+  tf::PhaseAArgs a{g_opt.dbg, td, tp, ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.dec_in, b.kh, w.pc, w.max_k, w.arg_k, b.wot, xf.slab, xf.bias, xf.k, xf.n};
+  if (xf.slab != nullptr && !(spec & 1)) { set_error("tail_fused: the encoder left its fold to a phase A that cannot do it"); return MLHOT_ERR_ARG; }
   if (st.first()) {
-    if (spec & 1) MLHOT_TRY(tail_launch(ts::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, ts::phaseA_lds_bytes(), a, s, "tail.A"));
+    if (spec & 1) MLHOT_TRY(tail_launch(ts::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS + (xf.slab != nullptr ? d.T : 0), 512, ts::phaseA_lds_bytes(), a, s, "tail.A"));
     else MLHOT_TRY(tail_launch(tf::phaseA_fwd_kernel, d.T + d.T * MLHOT_HEADS, 512, tf::phaseA_lds_bytes(td), a, s, "tail.A"));
   }
   // strict sharded parity (stab_xchg.h): phase B folds the (task, head) shares (max_k, arg_k) into the batch-global key stabiliser
@@ -283,7 +291,7 @@ inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
 
 inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu,
                                const float* dmu, const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s,
-                               PendingSum* later, const Stage& st = Stage{}) {
+                               PendingSum* later, const Stage& st = Stage{}, const LossDesc& loss = LossDesc{-1, nullptr, 0, nullptr}) {
   const tf::TailDims td = tail_dims(d);
   const tf::TailParams tp = tail_params(p);
   const tf::TailSlab sl = tf::tail_slab_layout(td);
@@ -291,8 +299,9 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   FavorWs w = favor_carve(f, b.favor, b.favor_bytes);
   if (!w.ok || !sc.tail_slab) { set_error("tail_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
   float* part_k = w.rsum_k;   // [T*H]
-  tf::PhaseCBwdArgs c{td, tp, sl, dmu, mu, b.d2, b.d1, b.dec_in, b.rr, sc.d_dec_in, sc.d_rr, sc.tail_slab};
+  tf::PhaseCBwdArgs c{td, tp, sl, dmu, mu, b.d2, b.d1, b.dec_in, b.rr, sc.d_dec_in, sc.d_rr, sc.tail_slab, loss};
   const int spec = ts::applies(td) ? g_opt.tail_spec : 0;
+  if (loss.kind >= 0 && !(spec & 8)) { set_error("tail_fused: a loss descriptor reached a phase C' that cannot take it"); return MLHOT_ERR_ARG; }
   if (st.first()) {
     if (spec & 8) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel, d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
     else MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
@@ -414,9 +423,15 @@ inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const fl
     set_error("np_vanilla_fwd: staged passes need the fused attention tail (attention aggregation, Nc, Nq <= 16, option tail_fused)");
     return MLHOT_ERR_UNSUPPORTED;
   }
-  if (st.first()) MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s));
 #ifndef MLHOT_HOSTSIM
-  if (fused) return tail_forward_fused(d, p, ctx_y, mu, b, sc, s, st);
+  EncXFold xf{nullptr, nullptr, 0, 0};
+  if (st.first()) MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s,
+                                        fused && tail_phaseA_folds(d) ? &xf : nullptr));
+  if (fused) return tail_forward_fused(d, p, ctx_y, mu, b, sc, s, st, xf);
+#else
+  if (st.first()) MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s));
+#endif
+#ifndef MLHOT_HOSTSIM
   if (cnp_fused_applies(d)) return cnp_forward_fused(d, p, ctx_y, mu, b, s);
 #endif
 
@@ -460,7 +475,8 @@ inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const fl
 
 inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_x, const float* ctx_y,
                        const float* qry_x, const float* mu, const float* dmu, const mlhot_np_grads& g,
-                       const void* saved, void* scratch, size_t scratch_bytes, hipStream_t s, const Stage& st = Stage{}) {
+                       const void* saved, void* scratch, size_t scratch_bytes, hipStream_t s, const Stage& st = Stage{},
+                       const LossDesc* loss = nullptr) {
   MLHOT_TRY(np_check_dims(d));
   MLHOT_TRY(stage_check(st, "np_vanilla_bwd"));
   NpBuf b = np_saved_carve(d, (void*)saved, (size_t)-1 / 2);
@@ -470,6 +486,19 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
   const int ldc = dw + dw / 4, ldd = dw + d.dim_z;
   const int out_act = d.out_tanh ? ACT_TANH : ACT_NONE;
 
+  // The loss's gradient, when the caller left it to this call (mlhot_np_vanilla_bwd_loss): the specialised phase C' derives it in
+  // its prologue; every other first kernel gets it materialised (dmu_tmp = dmu + d loss / d mu, one launch as mlhot_loss_bwd's).
+  LossDesc in_kernel{-1, nullptr, 0, nullptr};
+  if (loss != nullptr) {
+    if (st.staged()) { set_error("np_vanilla_bwd: the staged pass takes dmu, not a loss descriptor"); return MLHOT_ERR_UNSUPPORTED; }
+#ifndef MLHOT_HOSTSIM
+    if (tail_fused_applies(d) && ts::applies(tail_dims(d)) && (g_opt.tail_spec & 8) && (g_opt.tail_spec & 128)) in_kernel = *loss;
+#endif
+    if (in_kernel.kind < 0) {
+      MLHOT_TRY(run_foreach(LossBwd{loss->kind, d.y_dim, loss->gt_dim, Rq, mu, loss->gt, loss->dloss, sc.dmu_tmp, dmu}, (size_t)Rq, s, "loss_bwd"));
+      dmu = sc.dmu_tmp;
+    }
+  } else if (dmu == nullptr) { set_error("np_vanilla_bwd: null dmu"); return MLHOT_ERR_ARG; }
 #ifndef MLHOT_HOSTSIM
   if (st.staged() && !tail_fused_applies(d)) {
     set_error("np_vanilla_bwd: staged passes need the fused attention tail (attention aggregation, Nc, Nq <= 16, option tail_fused)");
@@ -477,7 +506,7 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
   }
   if (tail_fused_applies(d) || cnp_fused_applies(d)) {
     PendingSum tail_sum{};       // the tail's per-task slabs: summed by the encoder backward's final reduce launch when contiguous
-    if (tail_fused_applies(d)) MLHOT_TRY(tail_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum, st));
+    if (tail_fused_applies(d)) MLHOT_TRY(tail_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum, st, in_kernel));
     else MLHOT_TRY(cnp_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum));
     if (st.stage == 0) return MLHOT_OK;
     return enc_backward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{sc.d_cat_in, ldc, Rc, sc.d_dec_in, ldd}, b.enc, g.enc, sc.enc, sc.enc_bytes, s,

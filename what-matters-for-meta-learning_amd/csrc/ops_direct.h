@@ -354,39 +354,48 @@ struct LossRed {
   MLHOT_HD void finish(float s) const { out[0] = s / (float)(kind == 1 ? rows * y_dim : rows); }
 };
 
+// d loss / d mu of ONE row (all y_dim <= 8 entries into d[]), scaled by the upstream scalar `up`
+MLHOT_HD inline void loss_row_grad(int kind, int y_dim, int rows, const float* m, const float* g, float up, float* d) {
+  if (kind == 0 || kind == 1) {
+    const float s = up * 2.f / (float)(kind == 1 ? rows * y_dim : rows);
+    for (int j = 0; j < y_dim; ++j) d[j] = s * (m[j] - g[j]);
+  } else if (kind == 2) {
+    float nn = 0.f;
+    for (int j = 0; j < y_dim; ++j) nn += m[j] * m[j];
+    nn = sqrtf(nn);
+    float p = 0.f, q = 0.f;
+    for (int j = 0; j < y_dim; ++j) { const float u = m[j] / nn; p += fabsf(g[j] - u); q += fabsf(-g[j] - u); }
+    const float sgn = (p <= q) ? 1.f : -1.f;          // torch.minimum routes ties to ... measure zero
+    // dL/du_j = -sign(sgn*g_j - u_j) / rows ;  u = m/|m|  =>  dm = (du - u (u.du)) / |m|
+    float du[8]; float dot = 0.f;
+    for (int j = 0; j < y_dim; ++j) {
+      const float u = m[j] / nn, e = sgn * g[j] - u;
+      du[j] = -(e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * up / (float)rows;
+      dot += du[j] * u;
+    }
+    for (int j = 0; j < y_dim; ++j) d[j] = (du[j] - (m[j] / nn) * dot) / nn;
+  } else if (kind == 4) {
+    float s = 0.f;
+    for (int j = 0; j < y_dim; ++j) { const float e = g[j] - m[j]; s += e * e; }
+    s = sqrtf(s);
+    for (int j = 0; j < y_dim; ++j) d[j] = up * (m[j] - g[j]) / (s * (float)rows);
+  } else {
+    for (int j = 0; j < y_dim; ++j) d[j] = 0.f;       // degree error is evaluation-only
+  }
+}
+
 struct LossBwd {
   int kind, y_dim, gt_dim, rows;
   const float* mu; const float* gt; const float* dloss; float* dmu;
+  const float* add;          // optional: a gradient mu received from somewhere else, added to the loss's (same shape as dmu)
   MLHOT_HD void operator()(size_t r) const {
-    const float* m = mu + r * y_dim; const float* g = gt + r * gt_dim; float* d = dmu + r * y_dim;
-    const float up = dloss[0];
-    if (kind == 0 || kind == 1) {
-      const float s = up * 2.f / (float)(kind == 1 ? rows * y_dim : rows);
-      for (int j = 0; j < y_dim; ++j) d[j] = s * (m[j] - g[j]);
-    } else if (kind == 2) {
-      float nn = 0.f;
-      for (int j = 0; j < y_dim; ++j) nn += m[j] * m[j];
-      nn = sqrtf(nn);
-      float p = 0.f, q = 0.f;
-      for (int j = 0; j < y_dim; ++j) { const float u = m[j] / nn; p += fabsf(g[j] - u); q += fabsf(-g[j] - u); }
-      const float sgn = (p <= q) ? 1.f : -1.f;          // torch.minimum routes ties to ... measure zero
-      // dL/du_j = -sign(sgn*g_j - u_j) / rows ;  u = m/|m|  =>  dm = (du - u (u.du)) / |m|
-      float du[8]; float dot = 0.f;
-      for (int j = 0; j < y_dim; ++j) {
-        const float u = m[j] / nn, e = sgn * g[j] - u;
-        du[j] = -(e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * up / (float)rows;
-        dot += du[j] * u;
-      }
-      for (int j = 0; j < y_dim; ++j) d[j] = (du[j] - (m[j] / nn) * dot) / nn;
-    } else if (kind == 4) {
-      float s = 0.f;
-      for (int j = 0; j < y_dim; ++j) { const float e = g[j] - m[j]; s += e * e; }
-      s = sqrtf(s);
-      for (int j = 0; j < y_dim; ++j) d[j] = up * (m[j] - g[j]) / (s * (float)rows);
-    } else {
-      for (int j = 0; j < y_dim; ++j) d[j] = 0.f;       // degree error is evaluation-only
-    }
+    float d[8];
+    loss_row_grad(kind, y_dim, rows, mu + r * y_dim, gt + r * gt_dim, dloss[0], d);
+    for (int j = 0; j < y_dim; ++j) dmu[r * y_dim + j] = add != nullptr ? add[r * y_dim + j] + d[j] : d[j];
   }
 };
+
+// The loss whose gradient a model's backward takes itself (mlhot_np_vanilla_bwd_loss): kind < 0 = none
+struct LossDesc { int kind; const float* gt; int gt_dim; const float* dloss; };
 
 }  // namespace mlhot

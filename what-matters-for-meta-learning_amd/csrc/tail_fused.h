@@ -363,6 +363,10 @@ struct PhaseAArgs {
   float* pc;                                              // [m][dw]  c * projection
   float* tmax; int* targ;                                 // per (task, head): max of ddk, packed (row * 4096 + col)
   float* wot;                                             // [H][dw][dw] head-major copy of _W's weight: wot[h][j][e] = Wo[j][e*H + h]
+  // The encoder Linear's split-K partial results [xk][xn][dw] + its bias, when the encoder left its fold to this phase (tail_spec.h:
+  // the image features arrive as partial sums, phase A's blocks fold the tiles they read anyway and T extra blocks fold the query
+  // rows); nullptr: cat_in[:, :dw] / dec_in[:, :dw] already hold the features.
+  const float* xslab; const float* xbias; int xk, xn;
 };
 
 // (value, packed position): larger value first, then the smaller position (row-major first occurrence)
@@ -1037,6 +1041,8 @@ struct PhaseCBwdArgs {
   TailDims d; TailParams p; TailSlab sl;
   const float *dmu, *mu, *d2, *d1, *dec_in, *rr;
   float *d_dec_in, *d_rr, *slab;
+  // tail_spec.h only: the loss whose gradient this launch takes itself (dmu: nullptr = nothing else, or an addend); kind < 0: none
+  LossDesc loss;
 };
 
 __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) {

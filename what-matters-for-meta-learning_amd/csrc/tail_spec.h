@@ -157,6 +157,32 @@ struct Tile64 {
   }
 };
 
+// The same tile when the encoder Linear left its split-K fold to the consumer (PhaseAArgs::xslab): feat[row][:] = bias + the XK
+// partial results, summed in the order el::enc_linear_fold_kernel uses (bit-identical features whoever folds).  issue() requests
+// all XK + 1 float4 of a thread; finish() - called where the tile is needed, behind the kernel's other up-front requests - adds
+// them up (written as one function, hipcc put the sums, and their wait, in front of the weight fragments' loads: a second round trip).
+// `r0`: the tile's first row in the encoder's [context | target] row order.
+template <int NK>
+struct FoldTile {
+  f32x4_t part[NK], bias;
+  bool on;
+  __device__ __forceinline__ void issue(const float* __restrict__ slab, const float* __restrict__ b, int xn, int r0, int nrows, int tid) {
+    const int row = (tid >> 4) & 15, c4 = tid & 15;
+    on = tid < 256 && row < nrows;
+    const float* src = slab + (size_t)(r0 + (on ? row : 0)) * DW + 4 * c4;
+#pragma unroll
+    for (int z = 0; z < NK; ++z) part[z] = *reinterpret_cast<const f32x4_t*>(src + (size_t)z * xn * DW);
+    bias = *reinterpret_cast<const f32x4_t*>(b + 4 * c4);
+  }
+  __device__ __forceinline__ f32x4_t finish() const {
+    f32x4_t t = bias;
+#pragma unroll
+    for (int z = 0; z < NK; ++z) t += part[z];
+    return on ? t : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+};
+constexpr int XK = 16;                                    // el::F_KS (np_vanilla.h checks it)
+
 __device__ __forceinline__ void lds_zero4(lptr p, int nfloats, int tid) {      // nfloats % 4 == 0, p 16-byte aligned
   const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
   for (int i = tid; i < nfloats / 4; i += NWV * 64) reinterpret_cast<MLHOT_LDS f32x4_t*>(p)[i] = z;
@@ -181,7 +207,10 @@ __device__ __forceinline__ void keyhead_block(const PhaseAArgs& a, lptr L0, int 
   MLHOT_TSTAMP_AT(16, d.T);
   // ---- every global read of the block, up front
   Tile64 xt;
-  xt.fetch(a.cat_in + (size_t)t * d.Nc * LDC, LDC, d.Nc, tid);
+  FoldTile<XK> xf;
+  const bool folding = a.xslab != nullptr;              // kernel-uniform
+  if (folding) xf.issue(a.xslab, a.xbias, a.xn, t * d.Nc, d.Nc, tid);
+  else xt.fetch(a.cat_in + (size_t)t * d.Nc * LDC, LDC, d.Nc, tid);
   const float* wk = a.p.wk_w[0]; const float* bk = a.p.wk_b[0];
 #pragma unroll
   for (int i = 1; i < H; ++i)
@@ -212,6 +241,8 @@ __device__ __forceinline__ void keyhead_block(const PhaseAArgs& a, lptr L0, int 
       a.wot[(size_t)h * DW * DW + i] = a.p.wo_w[(size_t)j * HD + e * H + h];
     }
   }
+  __builtin_amdgcn_sched_barrier(0);               // every request above is out before the first wait
+  if (folding) xt.v = xf.finish();
   xt.stash(s_x, A_LX, tid);                        // all 16 rows (zeros beyond Nc): nothing else of the tiles is ever read
   __syncthreads();
   MLHOT_TSTAMP_AT(17, d.T);
@@ -284,6 +315,16 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  if ((int)blockIdx.x >= d.T + d.T * H) {
+    // blocks behind the key heads (only launched with a.xslab): fold the query rows of task tq into dec_in[:, :dw] - phase B's
+    // query projection, phase C and the backward read them there
+    const int tq = blockIdx.x - d.T - d.T * H;
+    FoldTile<XK> xq;
+    xq.issue(a.xslab, a.xbias, a.xn, d.T * d.Nc + tq * d.Nq, d.Nq, tid);
+    const int row = (tid >> 4) & 15, c4 = tid & 15;
+    if (xq.on) *reinterpret_cast<f32x4_t*>(a.dec_in + ((size_t)tq * d.Nq + row) * LDD + 4 * c4) = xq.finish();
+    return;
+  }
   if ((int)blockIdx.x >= d.T) { keyhead_block(a, L0, blockIdx.x - d.T, tid); return; }
   const int t = blockIdx.x;
   lptr s_cat = L0;                     // [16][A_LCAT]  [x_ctx | transform_y(ctx_y)]
@@ -294,7 +335,10 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   lptr s_red = s_y + 16 * A_LY;        // [8 waves][256] K-split partials
   // ---- every global read of the block, up front
   Tile64 xt;
-  xt.fetch(a.cat_in + (size_t)t * d.Nc * LDC, LDC, d.Nc, tid);
+  FoldTile<XK> xf;
+  const bool folding = a.xslab != nullptr;              // kernel-uniform
+  if (folding) xf.issue(a.xslab, a.xbias, a.xn, t * d.Nc, d.Nc, tid);
+  else xt.fetch(a.cat_in + (size_t)t * d.Nc * LDC, LDC, d.Nc, tid);
   float yv = 0.f;
   if (tid < 256 && (tid >> 4) < d.Nc && (tid & 15) < d.label_dim) yv = a.ctx_y[((size_t)t * d.Nc + (tid >> 4)) * d.label_dim + (tid & 15)];
   Lin<4, DW / 4> l_ty;  Lin<LDC, H0> l_e0;  Lin<H0, H1> l_e1;  Lin<H1, DW> l_e2;
@@ -324,11 +368,15 @@ __global__ __launch_bounds__(512) void phaseA_fwd_kernel(const PhaseAArgs a) {
   MLHOT_TSTAMP(1);
   // no LDS zeroing: every tile is written in full (x rows via Tile64, labels as a 16 x 16 block, layer outputs incl. their
   // zero padding columns by Lin::finish) before it is read
+  __builtin_amdgcn_sched_barrier(0);               // every request above is out before the first wait
+  if (folding) xt.v = xf.finish();
   xt.stash(s_cat, A_LCAT, tid);
   if (tid < 256) s_y[(tid >> 4) * A_LY + (tid & 15)] = yv;
+  float* g_cat = a.cat_in + (size_t)t * d.Nc * LDC;
+  if (folding && tid < 256 && ((tid >> 4) & 15) < d.Nc)       // the folded context rows: phase B' / A' and the encoder backward read them in cat_in
+    *reinterpret_cast<f32x4_t*>(g_cat + (size_t)((tid >> 4) & 15) * LDC + 4 * (tid & 15)) = xt.v;
   __syncthreads();
   MLHOT_TSTAMP(2);
-  float* g_cat = a.cat_in + (size_t)t * d.Nc * LDC;
   // transform_y -> cat[:, dw:]   (padding columns of s_y are zero, so the clamped weight columns contribute nothing)
   if (wave == 0) {
     const int lr = lane & 15, lq = lane >> 4;
@@ -829,7 +877,21 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   MLHOT_TSTAMP(96);
   if (tid < 256) {
     const int r = tid >> 4, c = tid & 15;
-    if (r < d.Nq && c < d.y_dim) gv = a.dmu[(rq + r) * d.y_dim + c] * act_grad_from_out(d.out_act, a.mu[(rq + r) * d.y_dim + c]);
+    if (r < d.Nq && c < d.y_dim) {
+      float up = a.dmu != nullptr ? a.dmu[(rq + r) * d.y_dim + c] : 0.f;
+      if (a.loss.kind >= 0) {
+        // the loss's own gradient (trainer/losses.py:59-61 and its siblings) needs no reduction: every thread of a row derives the
+        // row's y_dim <= 4 entries from mu and the labels and keeps its column - LossBwd's launch (4.6 us between the loss and this
+        // kernel) is gone from the step's dependency chain
+        float dl[8];
+        loss_row_grad(a.loss.kind, d.y_dim, d.T * d.Nq, a.mu + (rq + r) * d.y_dim, a.loss.gt + (rq + r) * a.loss.gt_dim, a.loss.dloss[0], dl);
+        float mine = dl[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) mine = c == j ? dl[j] : mine;
+        up += mine;
+      }
+      gv = up * act_grad_from_out(d.out_act, a.mu[(rq + r) * d.y_dim + c]);
+    }
   }
   TileW<DH> td2, td1; TileW<LDD> tdec; TileW<DW> trr;
   td2.fetch(a.d2 + rq * DH, DH, d.Nq, tid);

@@ -22,7 +22,7 @@ LOSS = {"azimuth": 0, "mse": 1, "quaternion": 2, "degree": 3, "distractor": 4}
 _f = C.c_void_p  # every device pointer travels as void*
 
 
-ABI_VERSION = 3     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients; 3: + conv12_fwd / _bwd)
+ABI_VERSION = 4     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients; 3: + conv12_fwd / _bwd; 4: + np_vanilla_bwd_loss)
 
 
 class MlhotError(RuntimeError):
@@ -52,6 +52,11 @@ class NpParams(C.Structure):
 
 class NpGrads(C.Structure):
     _fields_ = NpParams._fields_[:-1]
+
+
+class LossDesc(C.Structure):
+    """mlhot_loss_desc: the loss whose gradient mlhot_np_vanilla_bwd_loss takes itself."""
+    _fields_ = [("kind", C.c_int), ("gt", C.c_void_p), ("gt_dim", C.c_int), ("dloss", C.c_void_p)]
 
 
 # (struct path, state_dict key) for the vanilla CNP/ANP family
@@ -221,6 +226,7 @@ class MlhotLib:
         c.mlhot_np_vanilla_fwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, P, z, P]
         c.mlhot_np_vanilla_bwd.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, C.POINTER(NpGrads), P, P, z, P]
         c.mlhot_np_vanilla_fwd_staged.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, P, z, i, P, P]
+        c.mlhot_np_vanilla_bwd_loss.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, C.POINTER(LossDesc), C.POINTER(NpGrads), P, P, z, P]
         c.mlhot_np_vanilla_bwd_staged.argtypes = [C.POINTER(NpDims), C.POINTER(NpParams), P, P, P, P, P, C.POINTER(NpGrads), P, P, z, i, P, P]
         c.mlhot_mlp_chain_fwd.argtypes = [P, i, i, C.POINTER(ChainLayer), i, P]
         c.mlhot_mlp_chain_bwd.argtypes = [P, i, i, C.POINTER(ChainLayer), C.POINTER(ChainGrads), i, P, i, P, i, i, P]
@@ -933,8 +939,12 @@ class MlhotLib:
                                              _ptr(saved), _ptr(scratch), sb, _stream(qry_x)), "mlhot_np_vanilla_fwd")
         return mu, saved, scratch
 
-    def np_vanilla_bwd(self, dims, params, ctx_x, ctx_y, qry_x, mu, dmu, saved, scratch=None, proj=None, exchange=None):
+    def np_vanilla_bwd(self, dims, params, ctx_x, ctx_y, qry_x, mu, dmu, saved, scratch=None, proj=None, exchange=None, loss=None):
+        """loss: None, or (kind, gt, dloss) - the loss whose gradient the call takes itself (mlhot_np_vanilla_bwd_loss): the gradient
+        of mu is then dmu (may be None) + d loss / d mu * dloss."""
         _chk(dmu, mu)
+        if loss is not None and exchange is not None:
+            raise MlhotError("np_vanilla_bwd: the staged pass takes dmu, not a loss descriptor")
         # one flat gradient buffer in the library's preferred order; the per-parameter gradients are views of it
         offs = NpGrads()
         total = self.c.mlhot_np_grads_flat_layout(C.byref(dims), C.byref(offs))
@@ -953,6 +963,15 @@ class MlhotLib:
             self._staged(lambda st, xp: self._rc(self.c.mlhot_np_vanilla_bwd_staged(
                 C.byref(dims), C.byref(ps), _ptr(ctx_x), _ptr(ctx_y), _ptr(qry_x), _ptr(mu), _ptr(dmu), C.byref(gs), _ptr(saved),
                 _ptr(scratch), sb, st, xp, _stream(qry_x)), "mlhot_np_vanilla_bwd_staged"), exchange, "bwd")
+            return grads
+        if loss is not None:
+            kind, gt, dloss = loss
+            _chk(gt, dloss)
+            if gt.numel() % (dims.T * dims.Nq) or LOSS[kind] == LOSS["degree"]:
+                raise MlhotError(f"np_vanilla_bwd: loss {kind!r} with labels {tuple(gt.shape)} does not fit mu {tuple(mu.shape)}")
+            ld = LossDesc(LOSS[kind], _ptr(gt), gt.numel() // (dims.T * dims.Nq), _ptr(dloss))
+            self._rc(self.c.mlhot_np_vanilla_bwd_loss(C.byref(dims), C.byref(ps), _ptr(ctx_x), _ptr(ctx_y), _ptr(qry_x), _ptr(mu), _ptr(dmu),
+                                                      C.byref(ld), C.byref(gs), _ptr(saved), _ptr(scratch), sb, _stream(qry_x)), "mlhot_np_vanilla_bwd_loss")
             return grads
         self._rc(self.c.mlhot_np_vanilla_bwd(C.byref(dims), C.byref(ps), _ptr(ctx_x), _ptr(ctx_y), _ptr(qry_x), _ptr(mu), _ptr(dmu),
                                              C.byref(gs), _ptr(saved), _ptr(scratch), sb, _stream(qry_x)), "mlhot_np_vanilla_bwd")

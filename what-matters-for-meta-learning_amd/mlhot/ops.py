@@ -26,6 +26,71 @@ def set_stabiliser_exchange(exchange):
     _stab_exchange = exchange
 
 
+# The loss's gradient inside the model's backward.  LossFunc.calc_loss(mu, ., y).backward() is two dependent launches in front of
+# the model's first backward kernel (the loss reduction, then d loss / d mu); the gradient needs no reduction, so when mu comes
+# straight out of VanillaNPFunction the loss hands the model's backward a DESCRIPTOR (kind, labels, upstream scalar) instead of a
+# gradient tensor, and the first backward kernel derives d loss / d mu itself (mlhot_np_vanilla_bwd_loss).  What autograd carries
+# between the two nodes is a cached all-zero tensor of mu's shape: whatever else may flow into mu's gradient is ADDED to it by
+# autograd as usual and the kernel adds the loss's share on top, so the result equals the unfused graph's for any consumer set.
+defer_loss_grad = True
+_zero_grads = {}
+
+
+def _zero_like(mu):
+    key = (tuple(mu.shape), mu.device)
+    z = _zero_grads.get(key)
+    if z is None:
+        z = _zero_grads[key] = torch.zeros_like(mu)
+    return z
+
+
+# The loss VALUE off the critical path (opt-in; measured and NOT adopted): inside `with loss_value_aside():` the reduction that
+# produces the loss scalar runs on a forked stream (a parallel branch of a captured graph) and is joined when the block ends -
+# nothing in the backward needs the value; the caller promises not to read the loss before the block ends.  Round 5, c3: the
+# replayed step went 0.585 -> 0.608 ms with it (a two-branch graph costs the step's other kernels more than the 4.7 us
+# reduction it takes out of the chain; the same was seen with the eps draw as a graph branch in round 4).  trainer.ModelTrainer
+# (config.loss_aside) and bench.py (--loss-aside) keep it for the A/B.
+_loss_lane = None
+
+
+class loss_value_aside:
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _loss_lane
+        self.prev = _loss_lane
+        _loss_lane = {"stream": None, "forked": []} if self.enabled else None
+        return self
+
+    def __exit__(self, *exc):
+        global _loss_lane
+        lane, _loss_lane = _loss_lane, self.prev
+        if lane:
+            for cur, side in lane["forked"]:
+                cur.wait_stream(side)                 # the join: from here on the loss value is ordered like any other tensor
+        return False
+
+
+_lane_streams = {}
+
+
+def _loss_fwd(kind, mu, gt):
+    lane = _loss_lane
+    if lane is None or not mu.is_cuda:
+        return lib().loss_fwd(kind, mu, gt)
+    cur = torch.cuda.current_stream(mu.device)
+    side = _lane_streams.get(mu.device)
+    if side is None:
+        side = _lane_streams[mu.device] = torch.cuda.Stream(mu.device)
+    side.wait_stream(cur)                             # the fork: behind the kernel that wrote mu
+    with torch.cuda.stream(side):
+        loss = lib().loss_fwd(kind, mu, gt)
+    loss.record_stream(cur)
+    lane["forked"].append((cur, side))
+    return loss
+
+
 def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -52,6 +117,8 @@ class VanillaNPFunction(torch.autograd.Function):
         if saved_taps is not None:
             saved_taps.append(("np", dims, saved))
         ctx.dims, ctx.keys, ctx.proj = dims, keys, proj
+        ctx.takes_loss = ctx.xchg is None       # LossFunction may leave its gradient to this node's backward (a descriptor in ctx.loss)
+        ctx.loss = None
         ctx.scratch = scratch
         ctx.save_for_backward(ctx_x, ctx_y, qry_x, mu, saved, *[pd[k] for k in keys])
         return mu
@@ -60,7 +127,11 @@ class VanillaNPFunction(torch.autograd.Function):
     def backward(ctx, dmu):
         ctx_x, ctx_y, qry_x, mu, saved, *params = ctx.saved_tensors
         pd = dict(zip(ctx.keys, params))
-        grads = lib().np_vanilla_bwd(ctx.dims, pd, ctx_x, ctx_y, qry_x, mu, _c(dmu), saved, ctx.scratch, ctx.proj, exchange=ctx.xchg)
+        loss, ctx.loss = ctx.loss, None
+        if loss is not None and dmu.data_ptr() == _zero_like(mu).data_ptr():
+            dmu = None                          # nothing but the loss flowed into mu: the kernel does not even read an addend
+        grads = lib().np_vanilla_bwd(ctx.dims, pd, ctx_x, ctx_y, qry_x, mu, _c(dmu) if dmu is not None else None, saved, ctx.scratch, ctx.proj,
+                                     exchange=ctx.xchg, loss=loss)
         ctx.scratch = None
         used = used_param_keys(ctx.keys, ctx.dims.Nc)
         return (None, None, None, None, None, None) + tuple(grads[k] if k in used else None for k in ctx.keys)
@@ -375,15 +446,24 @@ class LossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kind, mu, gt):
         _need_gpu(mu, gt)
-        mu, gt = _c(mu.float()), _c(gt.float())
+        node = mu.grad_fn
+        mu_c, gt = _c(mu.float()), _c(gt.float())
         ctx.kind = kind
-        ctx.save_for_backward(mu, gt)
-        return lib().loss_fwd(kind, mu, gt)
+        # the producer of mu takes the loss's gradient itself when it says so and mu reaches the loss as it left the producer
+        # (not when the caller wants d loss / d mu itself - retain_grad() or a tensor hook on mu - which the placeholder would hide)
+        ctx.node = node if (defer_loss_grad and kind != "degree" and mu_c is mu and getattr(node, "takes_loss", False)
+                            and not mu.retains_grad and not mu._backward_hooks) else None
+        ctx.save_for_backward(mu_c, gt)
+        return _loss_fwd(kind, mu_c, gt)
 
     @staticmethod
     def backward(ctx, dloss):
         mu, gt = ctx.saved_tensors
-        return None, lib().loss_bwd(ctx.kind, mu, gt, _c(dloss.float())), None
+        dloss = _c(dloss.float())
+        if ctx.node is not None and ctx.node.loss is None:
+            ctx.node.loss = (ctx.kind, gt, dloss)        # VanillaNPFunction.backward runs next (it is this gradient's only consumer node)
+            return None, _zero_like(mu), None
+        return None, lib().loss_bwd(ctx.kind, mu, gt, dloss), None
 
 
 class Conv2dFunction(torch.autograd.Function):
