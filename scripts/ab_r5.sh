@@ -1,10 +1,12 @@
 #!/bin/bash
 # scripts/ab_r5.sh: A/B lines of one gpurun call (box-to-box spread is +-3 %, so only numbers of ONE call compare).
-# usage: scripts/ab_r5.sh "<label>:<bench args>" ...   -> gpurun_out/ab_r5.txt
+# usage: scripts/ab_r5.sh "<label>:[LIB=<other build of the library> ]<bench args>" ...   -> gpurun_out/ab_r5.txt
 out=gpurun_out/ab_r5.txt; : > $out
 for rep in 1 2 3; do
   for spec in "$@"; do
     label=${spec%%:*}; args=${spec#*:}
+    unset MLHOT_LIB
+    if [[ "$args" == LIB=* ]]; then export MLHOT_LIB=$PWD/${args%% *}; MLHOT_LIB=${MLHOT_LIB/LIB=/}; args=${args#* }; [[ "$args" == LIB=* ]] && args=""; fi
     python bench.py --no-cpu-baseline --no-extras --steps 100 --warmup 10 $args > gpurun_out/ab_tmp.json 2>/dev/null
     python - "$label" >> $out <<'PY'
 import json, sys

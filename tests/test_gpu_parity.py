@@ -1488,7 +1488,7 @@ class _FixedBatches:
         return b
 
 
-def _trajectory_check(model, p0, oracle_step, batches, make_opt, cfg, tmp_path, what, grab_routes, lr=1e-3, seed_eps=None):
+def _trajectory_check(model, p0, oracle_step, batches, make_opt, cfg, tmp_path, what, grab_routes, lr=1e-3, seed_eps=None, trainer_out=None):
     """T1 (trainer/model_trainer.py:59-93: zero_grad -> forward -> calc_loss + kl * beta -> backward -> optimizer.step): k
     iterations of ModelTrainer on the HIP path against k iterations of the CPU oracle + autograd + torch.optim.Adam on the same
     draws.  Per-iteration loss at 1e-4; final weights at 1e-4 of each tensor's scale.
@@ -1513,6 +1513,8 @@ def _trajectory_check(model, p0, oracle_step, batches, make_opt, cfg, tmp_path, 
     cfg.iterations, cfg.val_freq, cfg.val_iters, cfg.bg_gen_freq, cfg.gen_bg = k, 10 ** 6, 1, 10 ** 6, False
     cfg.save_path, cfg.logger, cfg.contrastive = str(tmp_path / what), None, False
     tr = ModelTrainer(model=model, loss=LossFunc("mse", cfg.task), optimizer=make_opt(model), config=cfg, data=_FixedBatches(list(batches)))
+    if trainer_out is not None:
+        trainer_out["trainer"] = tr
     losses, routes, entering = [], [], []
     orig = tr._train_iter
 
@@ -1573,11 +1575,18 @@ def _trajectory_check(model, p0, oracle_step, batches, make_opt, cfg, tmp_path, 
     return losses
 
 
-@pytest.mark.parametrize("optimizer", ["torch_adam", "flat_adam", "flat_adam_split"])
+@pytest.mark.parametrize("optimizer", ["torch_adam", "torch_adam_unpromoted", "flat_adam", "flat_adam_split"])
 def test_trainer_trajectory_vs_oracle(gpulib, tmp_path, monkeypatch, optimizer, request):
-    """ANPShapeNet1D, T = 2, fixed 5 + 5 shots, 4 training iterations of trainer.ModelTrainer with torch.optim.Adam and with
-    mlhot.optim.FlatAdam against the oracle's forward + autograd + torch.optim.Adam (see _trajectory_check); `_split`: the same with
-    all three conv12 kernels on the bf16 pipe over split operands (csrc/conv_split.h), same tolerances."""
+    """ANPShapeNet1D, T = 2, fixed 5 + 5 shots, 4 training iterations of trainer.ModelTrainer against the oracle's forward + autograd +
+    torch.optim.Adam (see _trajectory_check).  `torch_adam`: the reference's calling sequence as train.py writes it -
+    ModelTrainer(model, loss, torch.optim.Adam(model.parameters(), lr), config, data) - which the trainer runs through its promoted
+    defaults (round 5): FlatAdam.from_torch_adam, one eager iteration, then capture and hipGraph replays, host batches copied on the
+    copy stream; asserted below.  `_unpromoted`: config.promote_optimizer = graph_steps = host_prefetch = False, the plain eager loop with torch's
+    optimizer.  `flat_adam`: FlatAdam handed in, eager.  `_split`: the same with all three conv12 kernels on the bf16 pipe over split
+    operands (csrc/conv_split.h), same tolerances."""
+    unpromoted = optimizer.endswith("_unpromoted")
+    if unpromoted:
+        optimizer = optimizer[:-len("_unpromoted")]
     if optimizer.endswith("_split"):
         gpulib.set_option("conv2_split", 7)
         request.addfinalizer(lambda: gpulib.set_option("conv2_split", 0))
@@ -1611,7 +1620,23 @@ def test_trainer_trajectory_vs_oracle(gpulib, tmp_path, monkeypatch, optimizer, 
         return O.calc_loss("shapenet_1d", mu, qy), _vanilla_flips(routes, pres, tie)
     make = (lambda m: torch.optim.Adam(m.parameters(), lr=1e-3)) if optimizer == "torch_adam" else \
         (lambda m: FlatAdam(m, lr=1e-3, ctx_num=5, test_num=5))
-    _trajectory_check(model, p0, oracle_step, batches, make, cfg, tmp_path, "anp_shapenet1d_" + optimizer, grab_routes)
+    if unpromoted:
+        cfg.promote_optimizer, cfg.graph_steps, cfg.host_prefetch = False, False, False
+    elif optimizer == "flat_adam":
+        cfg.graph_steps = False                          # a non-capturable FlatAdam: the eager loop
+    seen = {}
+    _trajectory_check(model, p0, oracle_step, batches, make, cfg, tmp_path, "anp_shapenet1d_" + optimizer + ("_unpromoted" if unpromoted else ""),
+                      grab_routes, trainer_out=seen)
+    tr = seen["trainer"]
+    if optimizer == "torch_adam" and not unpromoted:      # the reference's sequence took the fast path by itself
+        assert type(tr.optimizer).__name__ == "FlatAdam" and tr.optimizer.capturable and tr._graph_default and tr._host_prefetch is not None
+        assert [type(v).__name__ for v in tr._graphs.values()] == ["tuple"] and int(tr.optimizer.step_dev.item()) == 4
+        sd = tr.optimizer.state_dict()                    # ... and its optimizer state reads back in torch.optim.Adam's layout
+        ref = torch.optim.Adam(model.parameters(), lr=1e-3)
+        ref.load_state_dict(sd)
+        assert len(sd["state"]) == len(list(model.parameters())) and all(int(v["step"]) == 4 for v in ref.state_dict()["state"].values())
+    elif unpromoted:
+        assert type(tr.optimizer) is torch.optim.Adam and not tr._graph_default and tr._host_prefetch is None and not tr._graphs
 
 
 def test_trainer_trajectory_vs_oracle_anpmr_shapenet3d(gpulib, tmp_path, monkeypatch):

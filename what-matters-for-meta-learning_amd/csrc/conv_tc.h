@@ -125,17 +125,8 @@ __global__ __launch_bounds__(256) void sum_parts_multi_kernel(const SumPartsMult
   const int e = (((int)blockIdx.x - mp.first[si]) * 16 + cx) * 4;
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
   auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-#ifndef SP_NO16
-  if (e < sp.len && sp.nparts == 256) {
-    // the full grid's 256 slab rows: all 16 float4 of a lane requested before the first add (as four trips of four the fold moved its
-    // 42 MB at 3.7 TB/s - a trip is a round trip to the rows the weight-gradient kernels left in L2 / MALL); same association as below
-    float4 v[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const float4*>(sp.slab + (size_t)(zl + 16 * k) * sp.stride + e);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { add(s0, v[4 * i]); add(s1, v[4 * i + 1]); add(s2, v[4 * i + 2]); add(s3, v[4 * i + 3]); }
-  } else
-#endif
+  // (round 5: all 16 float4 of a lane requested before the first add instead of four trips of four - the same 0.5805 / 0.5814 /
+  // 0.5815 ms per step as this form in a one-box A/B: the fold is bound by the rows' first touch, not by loads in flight)
   if (e < sp.len) {
     int z = zl;
     for (; z + 48 < sp.nparts; z += 64) {

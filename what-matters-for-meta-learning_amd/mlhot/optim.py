@@ -15,7 +15,12 @@ class FlatAdam:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ctx_num=15, test_num=15, capturable=False):
         """capturable: keep the step count on the device (mlhot_adam_step_counter) so that step() may sit inside a captured
         hipGraph and still advance the bias correction on every replay (torch.optim.Adam's `capturable` for the same reason)."""
-        self.model, self.lr, self.betas, self.eps, self.weight_decay = model, lr, betas, eps, weight_decay
+        self.model = model
+        # torch.optim's surface: one parameter group whose hyper-parameters step() reads (an LR scheduler writes param_groups[0]["lr"];
+        # inside a replayed hipGraph the values are the ones of the capture)
+        self.param_groups = [{"params": [p for _, p in model.named_parameters()], "lr": float(lr), "betas": tuple(betas), "eps": float(eps),
+                              "weight_decay": float(weight_decay), "amsgrad": False, "maximize": False, "foreach": None,
+                              "capturable": bool(capturable), "differentiable": False, "fused": None}]
         self.t = 0
         self.capturable = capturable
         total, offs = model.flat_layout(ctx_num, test_num)
@@ -35,8 +40,75 @@ class FlatAdam:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if capturable else None
         self._gather = None
 
+    lr = property(lambda self: self.param_groups[0]["lr"])
+    betas = property(lambda self: self.param_groups[0]["betas"])
+    eps = property(lambda self: self.param_groups[0]["eps"])
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"])
+
     def zero_grad(self, set_to_none=True):
         self.model.zero_grad(set_to_none=set_to_none)
+
+    # ---- torch.optim.Adam's checkpoint layout --------------------------------------------------------------------------------
+    def _steps_taken(self):
+        return int(self.step_dev.item()) if self.capturable else self.t
+
+    def state_dict(self):
+        """The dictionary torch.optim.Adam(model.parameters()).state_dict() would hold after the same steps: per parameter index
+        `step`, `exp_avg`, `exp_avg_sq` (copies of the flat buffers' slices), one param group."""
+        names = [k for k, _ in self.model.named_parameters()]
+        t = self._steps_taken()
+        state = {}
+        if t > 0:
+            for i, (k, p) in enumerate(self.model.named_parameters()):
+                sl = slice(self.offsets[k], self.offsets[k] + p.numel())
+                state[i] = {"step": torch.tensor(float(t)), "exp_avg": self.exp_avg[sl].view_as(p).clone(), "exp_avg_sq": self.exp_avg_sq[sl].view_as(p).clone()}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(names)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        group = sd["param_groups"][0]
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            self.param_groups[0][k] = tuple(group[k]) if k == "betas" else float(group[k])
+        steps = set()
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        for i, (k, p) in enumerate(self.model.named_parameters()):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            sl = slice(self.offsets[k], self.offsets[k] + p.numel())
+            self.exp_avg[sl].view_as(p).copy_(st["exp_avg"]); self.exp_avg_sq[sl].view_as(p).copy_(st["exp_avg_sq"])
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("FlatAdam.load_state_dict: the parameters' step counts differ (one flat update has one count)")
+        t = steps.pop() if steps else 0
+        if self.capturable:
+            self.step_dev.fill_(t)
+        else:
+            self.t = t
+
+    @classmethod
+    def from_torch_adam(cls, opt, model, ctx_num=15, test_num=15, capturable=True):
+        """The FlatAdam that continues a plain torch.optim.Adam over exactly `model`'s parameters (train.py:52-56 builds that one:
+        `torch.optim.Adam(model.parameters(), lr=config.lr[, weight_decay=config.beta])`) - same hyper-parameters, same moments and step
+        count if it has already stepped - or None when the optimizer is anything else (a subclass, several groups, amsgrad / maximize,
+        a tensor learning rate, parameters that are not the model's, a model without a flat gradient layout)."""
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1 or not hasattr(model, "flat_layout"):
+            return None
+        g = opt.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or torch.is_tensor(g["lr"]):
+            return None
+        mine = [p for _, p in model.named_parameters()]
+        if len(mine) != len(g["params"]) or any(a is not b for a, b in zip(mine, g["params"])):
+            return None
+        if any(not p.is_cuda or p.dtype != torch.float32 for p in mine):
+            return None
+        old = opt.state_dict() if len(opt.state) else None
+        new = cls(model, lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"], ctx_num=ctx_num, test_num=test_num,
+                  capturable=capturable)
+        if old is not None:
+            new.load_state_dict(old)
+        return new
 
     def _flat_grad(self):
         """The gradients as one tensor aligned with self.flat: the library's own buffer when backward produced the same

@@ -8,7 +8,14 @@ all-reduce (mlhot.dist.GradBucket) before the optimizer step, and a data source 
 batches before the host-side conversion (`get_batch_u8`: uint8 channel-last images) is read through
 mlhot.ingest.BatchIngest: the next training batch crosses PCIe as uint8 while the current step computes.
 
-`config.graph_steps = True` (off by default; needs an optimizer whose step is capture-safe, e.g.
+The reference's own calling sequence is the fast one (round 5): `ModelTrainer(model, loss, torch.optim.Adam(model.parameters(),
+lr=...), config, data).train()` as train.py:52-90 writes it, with a loader that hands out fp32 host batches, runs as
+  * mlhot.optim.FlatAdam.from_torch_adam(...): a plain torch.optim.Adam over the model's parameters is continued by the
+    one-launch flat update (same hyper-parameters, moments and step count; `config.promote_optimizer = False` keeps torch's),
+  * `config.graph_steps` defaulting to True whenever the optimizer is capture-safe and the model is a vanilla CNP / ANP plugin,
+  * the next host batch copied to the device on a copy stream while the current step computes (`_HostPrefetch`; the reference's
+    pageable `.to(device)` - the fastest route for fp32 host tensors on this box, 50 GB/s - just not in front of the step).
+`config.graph_steps` (needs an optimizer whose step is capture-safe, e.g.
 mlhot.optim.FlatAdam(capturable=True)) replays every training iteration from a hipGraph: the eager host path of one
 iteration (autograd bookkeeping, ~20 launches, the optimizer) costs about twice the GPU time of the step, the replay a few
 tens of microseconds.  One graph per batch shape (the context size is drawn per iteration, dataset/shapenet_1d.py:120); the
@@ -36,6 +43,31 @@ from trainer.base_trainer import BaseTrainer
 # thread polls its work events continuously, so with a process group alive a capture would abort at random (seen with bench.py).
 CAPTURE_MODE = "thread_local"
 
+class _HostPrefetch:
+    """fp32 host batches (the reference's loaders: dataset/shapenet_1d.py:189-196 -> utils/utils.py:26-30) to the device on a copy
+    stream.  stage() copies - `.to(device)` from pageable memory blocks the HOST for the transfer (0.62 ms for c3's 31.5 MB), which
+    is why the trainer calls it behind the step's launch - and take() orders the batch on the current stream."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+
+    def stage(self, host_batch):
+        with torch.cuda.stream(self.stream):
+            dev = tuple(t.to(self.device, non_blocking=True) for t in host_batch)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return dev, ev
+
+    def take(self, ticket):
+        dev, ev = ticket
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for t in dev:
+            t.record_stream(cur)
+        return dev
+
+
 class ModelTrainer(BaseTrainer):
     def __init__(self, model, loss, optimizer, config, data):
         super().__init__(model=model, loss=loss, optimizer=optimizer, config=config)
@@ -52,13 +84,31 @@ class ModelTrainer(BaseTrainer):
             from mlhot import ops
             from mlhot.dist import StabiliserExchange
             ops.set_stabiliser_exchange(StabiliserExchange(dedicated_group=True))
+        cuda = torch.device(config.device).type == "cuda"
+        # train.py:52-56's optimizer continued by the flat one-launch update
+        if cuda and getattr(config, "promote_optimizer", True):
+            from mlhot.optim import FlatAdam
+            shot = int(getattr(config, "max_ctx_num", 15) or 15)
+            flat = FlatAdam.from_torch_adam(self.optimizer, model, ctx_num=min(shot, 15), test_num=min(shot, 15))
+            if flat is not None:
+                self.optimizer = flat
+        if not hasattr(config, "graph_steps"):
+            # default: replay whenever it is possible - a capture-safe optimizer, a model whose step is one static launch sequence
+            # (the vanilla plugins), no collective between two C calls of the forward
+            self._graph_default = (cuda and getattr(self.optimizer, "capturable", False) and hasattr(model, "flat_layout")
+                                   and not getattr(config, "strict_sharded_parity", False) and not getattr(config, "contrastive", False))
+        else:
+            self._graph_default = bool(config.graph_steps)
         self.ingest, self._staged = None, None
+        self._host_prefetch = None
         self._prefetch = False          # set per iteration by train(): may the NEXT training batch be drawn right away?
         self.rank0 = dist_rank() == 0   # files / logs / TensorBoard are rank 0's business (every rank holds the same weights)
         self._graphs, self._static_in, self._side = {}, {}, None       # graph_steps: per batch shape
-        if hasattr(data, "get_batch_u8") and torch.device(config.device).type == "cuda" and getattr(config, "ingest_u8", True):
+        if hasattr(data, "get_batch_u8") and cuda and getattr(config, "ingest_u8", True):
             from mlhot.ingest import BatchIngest
             self.ingest = BatchIngest(config.device)
+        elif cuda and getattr(config, "host_prefetch", True):
+            self._host_prefetch = _HostPrefetch(config.device)
 
     def _log(self, msg):
         logger = getattr(self.config, "logger", None)
@@ -96,10 +146,17 @@ class ModelTrainer(BaseTrainer):
         soon as the current one is handed out (when train() allows it: see `_prefetch`), so it overlaps with the step the
         caller is about to run; validation / test batches are staged and taken on the spot."""
         if self.ingest is None:
-            ctx_x, qry_x, ctx_y, qry_y = self.data.get_batch(source=source, tasks_per_batch=self.config.tasks_per_batch,
-                                                             shot=self.config.max_ctx_num)
-            dev = self.config.device
-            return ctx_x.to(dev), qry_x.to(dev), ctx_y.to(dev), qry_y.to(dev)
+            def draw(src):
+                return self.data.get_batch(source=src, tasks_per_batch=self.config.tasks_per_batch, shot=self.config.max_ctx_num)
+            hp = self._host_prefetch
+            if hp is None:
+                dev = self.config.device
+                return tuple(t.to(dev) for t in draw(source))
+            if source != "train":
+                return hp.take(hp.stage(draw(source)))
+            ticket, self._staged = (self._staged or hp.stage(draw("train"))), None
+            self._stage_later = self._prefetch          # the next batch's (host-blocking) copy goes out BEHIND this step's launch: _stage_next()
+            return hp.take(ticket)
 
         def stage(src):
             return self.ingest.stage(*self.data.get_batch_u8(source=src, tasks_per_batch=self.config.tasks_per_batch,
@@ -111,6 +168,14 @@ class ModelTrainer(BaseTrainer):
         if self._prefetch:
             self._staged = stage("train")
         return batch
+
+    def _stage_next(self):
+        """Host-batch route: draw the next training batch and start its copy to the device - called right after the current
+        step has been enqueued, so the (pageable, host-blocking) copy runs beside the step instead of in front of it."""
+        if self._host_prefetch is not None and getattr(self, "_stage_later", False):
+            self._stage_later = False
+            self._staged = self._host_prefetch.stage(self.data.get_batch(source="train", tasks_per_batch=self.config.tasks_per_batch,
+                                                                         shot=self.config.max_ctx_num))
 
     def _seed(self, loss):
         """d loss / d loss = 1, allocated once: autograd's implicit seed is a fill kernel per iteration."""
@@ -167,20 +232,28 @@ class ModelTrainer(BaseTrainer):
             cur.wait_stream(self._side)
             self._graphs[key] = "warm"
         else:
+            from mlhot import ops
             if entry == "warm":                                      # second time: capture (nothing executes), then replay below
                 graph = torch.cuda.CUDAGraph()
                 self._side.wait_stream(cur)
-                with torch.cuda.graph(graph, stream=self._side, capture_error_mode=CAPTURE_MODE):
-                    static_loss = self._step_body(*static, with_optimizer=single)
+                taps, ops.saved_taps = ops.saved_taps, []            # the captured forward's saved buffers (test / diagnostic hook, see below)
+                try:
+                    with torch.cuda.graph(graph, stream=self._side, capture_error_mode=CAPTURE_MODE):
+                        static_loss = self._step_body(*static, with_optimizer=single)
+                finally:
+                    captured_taps, ops.saved_taps = ops.saved_taps, taps
                 # the gradient tensors THIS graph writes (its private pool): a replay does not rebind p.grad, and another
                 # shape's graph or eager warm-up may have re-pointed it since
-                entry = self._graphs[key] = (graph, static_loss, [p.grad for p in self.bucket.params])
+                entry = self._graphs[key] = (graph, static_loss, [p.grad for p in self.bucket.params], captured_taps)
             entry[0].replay()
             loss = entry[1]
             for p, g in zip(self.bucket.params, entry[2]):
                 p.grad = g
+            if ops.saved_taps is not None:                          # a replay runs no Python forward: hand a listener the graph's own saved
+                ops.saved_taps.extend(entry[3])                      # buffers, which now hold THIS iteration's routing
         if not single:
             self._sync_and_step()
+        self._stage_next()
         return loss
 
     def _sync_and_step(self):
@@ -197,7 +270,7 @@ class ModelTrainer(BaseTrainer):
             self.optimizer.step()
 
     def _train_iter(self, it):
-        if getattr(self.config, "graph_steps", False):
+        if self._graph_default:
             loss = self._graph_train_iter(it)
             every = max(1, int(getattr(self.config, "log_every", 1)))
             if it % every and it != self.iterations:
@@ -225,6 +298,7 @@ class ModelTrainer(BaseTrainer):
             self.bucket.arm()                                         # world > 1: the early bucket's all-reduce goes out from inside backward()
             losses.backward(gradient=self._seed(losses))
         self._sync_and_step()
+        self._stage_next()
         value = losses.item()                                     # the iteration's only host sync
         if self.writer is not None and self.rank0:
             self.writer.add_scalar("Loss/train", value, it)
