@@ -716,6 +716,9 @@ def main():
                          "1.5 %% of a 0.6 ms step that no kernel owns.  1 = one step per graph.  Ignored (1) with more than one rank (the "
                          "all-reduce sits between steps) and for the Bayes-by-backprop workload (fresh eps per step)")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--one-graph", action="store_true",
+                    help="N > 1, ResNet family: ONE graph per step and one gradient all-reduce behind it (A/B; default: two graphs with the "
+                         "early bucket's all-reduce between them)")
     ap.add_argument("--strict", action="store_true",
                     help="N > 1: FAVOR+'s key stabiliser is the maximum over the WHOLE meta-batch, as in the reference's single-process batch "
                          "(fast_attention.py:96-97), through mlhot.dist.StabiliserExchange - two scalar collectives per attention pass between "
@@ -790,7 +793,20 @@ def main():
     beta = w.get("beta", 0.0)
     seed = torch.ones((), device=device)     # d loss / d loss: torch.ones_like(loss) allocated once instead of per step
 
-    def fwd_bwd(arm=False, batch=None):
+    # More than one rank, ResNet family: the step runs as TWO graphs - everything down to the image trunks' inputs, then the trunks'
+    # backward - with the early bucket's all-reduce (11.6 of c5's 15.1 MB) issued between the two replays, under the second
+    # (mlhot.dist.backward_in_two; the model cuts its autograd graph in front of the trunks).  --one-graph: the single graph + one
+    # collective behind it, for the A/B.
+    split = ((world > 1 or mdist.force_collectives()) and hasattr(model, "enable_split_backward") and not args.one_graph
+             and not args.no_graph and not args.strict)
+    if split:
+        model.enable_split_backward(True)
+
+    def fwd_bwd(arm=False, batch=None, part=None):
+        """part: None = the whole step; 1 = forward + the backward above the cut; 2 = the trunks' backward (split only)."""
+        if part == 2:
+            mdist.run_second_part(model)
+            return None
         bx, by, tx, ty = batch if batch is not None else (cx, cy, qx, qy)
         model.zero_grad(set_to_none=True)
         mu, var, kl = model(bx, by, tx)
@@ -804,6 +820,8 @@ def main():
             if arm:
                 bucket.arm()                     # eager steps only: the early bucket's all-reduce is issued from inside backward()
             loss.backward(gradient=seed)         # the constant 1.0 autograd would otherwise make with a fill kernel every step
+            if split and part is None:
+                mdist.run_second_part(model)     # (the armed early bucket went out when part 1's last gradient landed)
         return loss.detach()
 
     # Bayes-by-backprop eps: the reference draws them on the torch CPU generator inside the forward (bbb/BBBConv.py:88).  Every rank
@@ -839,12 +857,12 @@ def main():
             if spg < 1 or args.steps % spg or args.warmup % spg:
                 spg = 1                      # K and W must be whole graphs: the timed region is EXACTLY --steps steps
 
-            def body():
-                if eps is not None:
+            def body(part=None):
+                if eps is not None and part != 2:
                     eps.rewind()
                 out = None
                 for _ in range(spg):
-                    out = fwd_bwd()
+                    out = fwd_bwd(part=part)
                 return out
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -857,8 +875,13 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             model.zero_grad(set_to_none=True)
+            graph2 = None
             with (eps.active() if eps is not None else contextlib_null()), torch.cuda.graph(graph, stream=side, capture_error_mode=CAPTURE_MODE):   # the warm-up's stream: the parameters' grad-accumulation nodes live there
-                static_loss = body()
+                static_loss = body(part=1 if split else None)
+            if split:                        # the trunks' backward: a second graph in the first one's memory pool (always replayed in this order)
+                graph2 = torch.cuda.CUDAGraph()
+                with (eps.active() if eps is not None else contextlib_null()), torch.cuda.graph(graph2, stream=side, pool=graph.pool(), capture_error_mode=CAPTURE_MODE):
+                    body(part=2)
 
             def run():
                 if eps is not None:
@@ -866,6 +889,9 @@ def main():
                     if eps.source == "host":
                         eps.prefetch()       # next step's draws, on a host thread, while this step runs (the device source looks ahead by itself)
                 graph.replay()
+                if graph2 is not None:
+                    bucket.issue_early()     # on the communication stream, behind graph 1 and beside graph 2
+                    graph2.replay()
                 bucket.sync(defer_scale=True)
                 return static_loss
             graphed = True
@@ -886,6 +912,7 @@ def main():
     elapsed, t_enqueue, loss = timed_region(run, n_run, args.warmup // spg, world, device, sync=torch.cuda.synchronize,
                                             record=lambda i, k: ev[i][k].record())
     final_loss = loss.item()
+    replay_collectives = [list(e) for e in bucket.issue_log]       # of the timed region's last step (the roofline leg below runs eager steps)
     step_ms = sorted(a.elapsed_time(b) / spg for a, b in ev)       # device time per step (events on the replaying stream, per graph launch / steps per graph)
     if eps is not None and eps._worker is not None:
         eps.stage()                                          # collect the last prefetch: the CPU generator is free again
@@ -983,6 +1010,8 @@ def main():
                           "context_shots": NC, "target_shots": NQ, "image": w["image"],
                           "parallelism": f"task-sharded x{world}, one flat grad all-reduce" if world > 1 else "single GPU"},
                "dist": ({"backend": dist.get_backend(), "ranks_reported_by_backend": dist.get_world_size(),
+                         "collectives_per_step": replay_collectives,
+                         "step_graphs": (2 if split and graphed else 1) if graphed else 0,
                          "launcher": "bench.py itself (spawn_ranks)" if os.environ.get("MLHOT_BENCH_LAUNCHER") == "self" else "external (WORLD_SIZE in the environment)"}
                         if dist.is_initialized() else None),
                "final_loss": final_loss, "hipgraph": graphed, "steps_per_graph": spg, "key_stabiliser": stabiliser, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,

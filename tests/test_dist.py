@@ -385,6 +385,73 @@ def _stab_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _two_part_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "what-matters-for-meta-learning_amd"), root]
+    from mlhot import dist as mdist
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    mdist.init_from_env("gloo")
+    torch.manual_seed(0)
+
+    class Cut(torch.nn.Module):                         # the ResNet family's shape: a "trunk" whose output the forward detaches
+        def __init__(self):
+            super().__init__()
+            self.trunk = torch.nn.Linear(8, 8)
+            self.head = torch.nn.Sequential(torch.nn.Linear(8, 6), torch.nn.Tanh(), torch.nn.Linear(6, 3))
+
+        def forward(self, x, cut):
+            f = torch.relu(self.trunk(x))
+            if cut:
+                leaf = f.detach().requires_grad_(True)
+                self.__dict__["_cut_pairs"] = [(f, leaf)]
+                f = leaf
+            return self.head(f).pow(2).mean()
+
+    m = Cut()
+    params = list(m.parameters())
+    x = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + rank))
+    grads = {}
+    for cut in (False, True):
+        for p in params:
+            p.grad = None
+        bucket = mdist.GradBucket(params, early=list(m.head.parameters()))
+        loss = m(x, cut)
+        if cut:
+            seen = {}
+
+            def between():
+                seen["trunk_has_no_gradient_yet"] = m.trunk.weight.grad is None
+                bucket.issue_early()                     # what bench.py does between its two graph replays
+            mdist.backward_in_two(loss, m, between=between)
+        else:
+            loss.backward()
+        bucket.sync()
+        grads[cut] = ([p.grad.clone() for p in params], [k for k, _ in bucket.issue_log])
+    assert grads[False][1] == ["all"] and grads[True][1] == ["early", "rest"] and seen["trunk_has_no_gradient_yet"]
+    out[rank] = all(torch.equal(a, b) for a, b in zip(grads[False][0], grads[True][0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_backward_in_two_with_the_early_bucket_issued_in_between():
+    """mlhot.dist.backward_in_two + GradBucket.issue_early() on two gloo ranks: the early bucket leaves between the two parts of
+    the backward (no autograd hook involved - the form a step replayed as two hipGraphs uses), the rest behind the second part,
+    and the averaged gradients are bit-identical to one backward + one collective."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_two_part_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        assert out[0] and out[1]
+
+
 def test_stabiliser_exchange_on_two_ranks():
     """mlhot.dist.StabiliserExchange (the collective between the staged halves of the attention passes, include/mlhot.h "strict
     sharded parity"): the batch maximum reaches every rank, exactly one rank owns the arg-max (the lowest on ties), the

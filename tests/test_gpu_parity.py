@@ -2276,11 +2276,13 @@ def test_rccl_world_of_one_grad_bucket_and_stabiliser_exchange(gpulib):
         assert same and calls == ["fwd", "bwd"]
 
 
-@pytest.mark.parametrize("workload,extra", [("c3", []), ("c5", []), ("c5", ["--strict"])], ids=["c3", "c5", "c5_strict"])
+@pytest.mark.parametrize("workload,extra", [("c3", []), ("c5", []), ("c5", ["--one-graph"]), ("c5", ["--strict"])], ids=["c3", "c5", "c5_one_graph", "c5_strict"])
 def test_rccl_world_of_one_bench(gpulib, workload, extra):
     """bench.py --gpus 1 with the collectives forced over backend "nccl": the timing protocol's barrier / MAX all-reduce, the
     gradient bucket behind the hipGraph replay and - with --strict - the eager step with the batch-global key stabiliser, all
-    through RCCL; the JSON line says which stabiliser form ran."""
+    through RCCL; the JSON line says which stabiliser form ran.  c5 (ResNet family): the replayed step is TWO graphs with the
+    early bucket's all-reduce issued between them (`collectives_per_step` == early, rest); --one-graph keeps the single graph and
+    its one collective - same loss either way."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -2297,11 +2299,73 @@ def test_rccl_world_of_one_bench(gpulib, workload, extra):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 4
-    if extra:
+    if extra == ["--strict"]:
         assert out["hipgraph"] is False and out["key_stabiliser"].startswith("batch-global")
     else:
         assert out["hipgraph"] is True and out["key_stabiliser"].startswith("rank-local")
+        kinds = [k for k, _ in out["dist"]["collectives_per_step"]]
+        if workload == "c5" and not extra:
+            assert out["dist"]["step_graphs"] == 2 and kinds == ["early", "rest"], out["dist"]
+            sizes = [n for _, n in out["dist"]["collectives_per_step"]]
+            assert sizes[0] > 2 * sizes[1]               # the early bucket is the larger part (11.6 of 15.1 MB)
+        else:
+            assert out["dist"]["step_graphs"] == 1 and kinds == ["all"], out["dist"]
+        if workload == "c5":
+            _C5_LOSSES[tuple(extra)] = out["final_loss"]
+            if len(_C5_LOSSES) == 2:
+                a, b = _C5_LOSSES.values()
+                assert abs(a - b) <= 1e-6 * abs(a), _C5_LOSSES
     assert "key stabiliser" in r.stderr
+
+
+_C5_LOSSES = {}
+
+
+@pytest.mark.parametrize("method", ["ANPMRShapeNet3D", "ANP", "CondNeuralProcess"])
+def test_backward_in_two_equals_one_backward(gpulib, method):
+    """mlhot.dist.backward_in_two on a forward cut in front of the image trunks (ResNetNP.enable_split_backward): part 1 leaves every
+    early-bucket parameter with its FINAL gradient and no trunk parameter with any (that is the moment the caller issues the early
+    all-reduce), part 2 adds the trunks' - and the result is bit-identical to the one-piece loss.backward()."""
+    import importlib
+    import types
+    from mlhot import dist as mdist
+    from mlhot.ops import add_scaled
+    from mlhot.synth import get_batch_3d
+    from trainer.losses import LossFunc
+    cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[64, 64, 4], tasks_per_batch=2, input_dim=4, output_dim=4,
+                                agg_mode="attention" if method != "CondNeuralProcess" else "max", img_agg="reshape" if method == "ANPMRShapeNet3D" else "max",
+                                task="shapenet_3d", temperature=0.07)
+    model = getattr(importlib.import_module("networks." + method), method)(cfg).to(DEV)
+    cx, qx, cy, qy = (t.to(DEV) for t in get_batch_3d(2, 4, 5, seed=3))
+    loss_fn = LossFunc("mse", "shapenet_3d")
+    early = {id(p) for p in model.early_grad_parameters()}
+
+    def run(split):
+        model.enable_split_backward(split)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(7)                              # the Bayes-by-backprop eps
+        mu, var, kl = model(cx, cy, qx)
+        loss = add_scaled(loss_fn.calc_loss(mu, var, qy), kl, 1e-3)
+        seen = {}
+        if split:
+            def between():
+                seen["early"] = {k: p.grad.clone() for k, p in model.named_parameters() if id(p) in early and p.grad is not None}
+                seen["late_none"] = all(p.grad is None for p in model.parameters() if id(p) not in early)
+            mdist.backward_in_two(loss, model, between=between)
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, seen
+
+    l0, g0, _ = run(False)
+    l1, g1, seen = run(True)
+    model.enable_split_backward(False)
+    assert l0 == l1 and g0.keys() == g1.keys() and len(g0) > 20
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    assert seen["late_none"] and len(seen["early"]) > 10
+    for k, g in seen["early"].items():
+        assert torch.equal(g, g1[k]), k                   # complete before the trunks' backward ran
 
 
 def _strict_worker(rank, world, port, name, opts, out):

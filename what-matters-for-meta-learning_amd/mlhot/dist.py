@@ -205,19 +205,33 @@ class GradBucket:
         self._left -= 1
         if self._left == 0:
             self._armed = False
-            live = [q for q in self.early if q.grad is not None]
-            if live:
-                flat, views = self._shared_flat(live), None      # a gradient arena (mlhot/arena.py): reduce the range in place
-                if flat is not None and flat.numel() > sum(q.grad.numel() for q in live) + 4 * len(live) + sum(
-                        q.numel() for q in self.early if q.grad is None):
-                    flat = None                                  # the range holds more than the early gradients (+ padding, unused ones): not theirs alone
-                if flat is None:
-                    flat = torch.empty(sum(q.grad.numel() for q in live), dtype=torch.float32, device=live[0].grad.device)
-                    views = list(flat.split([q.grad.numel() for q in live]))
-                    torch._foreach_copy_(views, [q.grad.reshape(-1) for q in live])
-                self.issue_log.append(("early", flat.numel()))
-                self._issue(flat, asynchronous=True)
-                self._early_state = (live, flat, views)
+            self._issue_early_now()
+
+    def _issue_early_now(self):
+        live = [q for q in self.early if q.grad is not None]
+        if live:
+            flat, views = self._shared_flat(live), None      # a gradient arena (mlhot/arena.py): reduce the range in place
+            if flat is not None and flat.numel() > sum(q.grad.numel() for q in live) + 4 * len(live) + sum(
+                    q.numel() for q in self.early if q.grad is None):
+                flat = None                                  # the range holds more than the early gradients (+ padding, unused ones): not theirs alone
+            if flat is None:
+                flat = torch.empty(sum(q.grad.numel() for q in live), dtype=torch.float32, device=live[0].grad.device)
+                views = list(flat.split([q.grad.numel() for q in live]))
+                torch._foreach_copy_(views, [q.grad.reshape(-1) for q in live])
+            self.issue_log.append(("early", flat.numel()))
+            self._issue(flat, asynchronous=True)
+            self._early_state = (live, flat, views)
+
+    def issue_early(self):
+        """The early bucket's all-reduce, issued by the CALLER at the point where those gradients are complete - for steps that run
+        no autograd hooks: a step replayed as two hipGraphs (everything down to the image trunks' inputs | the trunks' backward,
+        backward_in_two below) calls this between the two replays, so the collective runs under the second graph; sync() then
+        reduces the rest and joins both, exactly as after an armed eager backward."""
+        self.issue_log = []
+        self._armed = False
+        if not self.early or self._single():
+            return
+        self._issue_early_now()
 
     # ---- per step -------------------------------------------------------------------------------------------------------
     def sync(self, defer_scale=False, wait=True):
@@ -302,6 +316,29 @@ class GradBucket:
         self.wait()
         if getattr(self, "_unpack", None) is not None:
             self._finish(1.0, True)
+
+
+def backward_in_two(loss, model, gradient=None, between=None):
+    """loss.backward() of a model whose forward cut its autograd graph in front of the image trunks (ResNetNP.enable_split_backward):
+    part 1 runs every node above the cut - all of GradBucket's early parameters have their gradients then -, `between()` is called
+    (e.g. bucket.issue_early()), part 2 runs the trunks' backward (and what hangs below it: the Bayes-by-backprop sampling) from
+    the gradients part 1 left at the cut.  Same gradients as the one-piece backward (tests/test_gpu_parity.py).  The two parts can
+    be captured as two hipGraphs (bench.py): the all-reduce issued in between overlaps the second."""
+    pairs = model.__dict__.get("_cut_pairs")
+    if not pairs:
+        raise ValueError("backward_in_two: the model's last forward recorded no cut (enable_split_backward(True) before the forward)")
+    loss.backward(gradient=gradient)
+    if between is not None:
+        between()
+    run_second_part(model)
+
+
+def run_second_part(model):
+    pairs = model.__dict__.get("_cut_pairs") or []
+    live = [(o, leaf.grad) for o, leaf in pairs if leaf.grad is not None]
+    model.__dict__["_cut_pairs"] = []
+    if live:
+        torch.autograd.backward([o for o, _ in live], [g for _, g in live])
 
 
 def rank():

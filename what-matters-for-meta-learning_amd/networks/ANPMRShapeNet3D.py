@@ -127,6 +127,9 @@ class ANPMRShapeNet3D(ResNetNP):
                 w_ctx, w_tgt, kl = sample_twice(self.img_encoder._bbb_layers())
                 log = self.img_encoder.tap_log
                 maps = run_trunks([(ctx_imgs, w_ctx, 3, log), (tgt_imgs, w_tgt, 3, log), self.decoder.trunk_job(tgt_imgs)])
+                if maps is not None and self.__dict__.get("_split_backward"):
+                    self.__dict__["_cut_pairs"] = []
+                    *maps, kl = self._cut(list(maps) + [kl])          # the KL hangs off the same sampling node as the trunks' weights
             if maps is not None:
                 x_ctx, x_tgt, fmap_dec = maps[0].reshape(-1, 256), maps[1].reshape(-1, 256), maps[2]
             else:

@@ -110,6 +110,29 @@ class ResNetNP(nn.Module):
         binding.set_grad_arena(arena)
         return arena
 
+    def enable_split_backward(self, on=True):
+        """Cut the autograd graph in front of the image trunks: the forward hands everything downstream DETACHED copies of the
+        trunks' output maps (and of the Bayes-by-backprop KL) and remembers the (output, leaf) pairs, so that the backward can run
+        in two parts - mlhot.dist.backward_in_two: all early-bucket gradients, then the trunks - with the first bucket's
+        all-reduce in between.  Values and gradients are unchanged; a plain loss.backward() on a cut forward would stop at the
+        cut, so only callers that run the second part switch this on."""
+        self.__dict__["_split_backward"] = bool(on)
+        self.__dict__["_cut_pairs"] = []
+
+    def _cut(self, tensors):
+        """Identity unless enable_split_backward(True): then each tensor that carries a graph is replaced by a detached leaf."""
+        if not self.__dict__.get("_split_backward") or not torch.is_grad_enabled():
+            return tensors
+        out = []
+        for t in tensors:
+            if torch.is_tensor(t) and t.requires_grad:
+                leaf = t.detach().requires_grad_(True)
+                self.__dict__["_cut_pairs"].append((t, leaf))
+                out.append(leaf)
+            else:
+                out.append(t)
+        return out
+
     def _refresh_arena(self):
         arena = self.__dict__.get("_arena")
         if arena is not None:
@@ -188,7 +211,11 @@ class ResNetNP(nn.Module):
             if self.ATTENTION or contra_cnp:
                 jobs.append(self.img_encoder.trunk_job(tgt_imgs)); roles.append("tgt")
         jobs.append(self.decoder.trunk_job(tgt_imgs)); roles.append("dec")
+        if self.__dict__.get("_split_backward"):
+            self.__dict__["_cut_pairs"] = []
         maps = run_trunks(jobs)
+        if maps is not None:
+            maps = self._cut(maps)
         fm = dict(zip(roles, maps)) if maps is not None else {}
 
         def encode(imgs, role):
