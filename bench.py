@@ -1014,6 +1014,7 @@ def main():
                          "step_graphs": (2 if split and graphed else 1) if graphed else 0,
                          "launcher": "bench.py itself (spawn_ranks)" if os.environ.get("MLHOT_BENCH_LAUNCHER") == "self" else "external (WORLD_SIZE in the environment)"}
                         if dist.is_initialized() else None),
+               "library": _library_id(),
                "final_loss": final_loss, "hipgraph": graphed, "steps_per_graph": spg, "key_stabiliser": stabiliser, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
                "ms_per_step_event_median": step_ms[len(step_ms) // 2], "ms_per_step_event_min": step_ms[0], "ms_per_step_event_max": step_ms[-1],
                "timing": f"value = wall clock over {args.steps} steps ({n_run} graph launches of {spg} step(s)) between two barrier + synchronize fences (max over ranks), "
@@ -1025,6 +1026,11 @@ def main():
             if any(kv.partition("=")[0] == "conv2_split" and int(kv.partition("=")[2]) for kv in args.opt):
                 # an A/B line, not the headline: conv2 ran on the bf16 pipe over split operands (extras.split_precision_conv2)
                 out["dtype"] = "f32, conv2 of the vanilla encoder on bf16x3-split operands (opt-in arithmetic: NOT the headline line)"
+        if eps is not None:
+            # which random stream this line's Bayes-by-backprop weights were sampled from (VERDICT r4 item 4 iv): "host" = the torch CPU
+            # generator in the reference's draw order, bit-identical samples, the step then costs max(GPU, host draw); "device" = the same
+            # MT19937 stream continued on the GPU (uniforms bit-identical, normals within 4 ulp)
+            out["config"]["eps_source"] = eps.source
         if eps is not None and eps.source == "host":
             d0 = time.perf_counter()
             eps.stage()
@@ -1060,6 +1066,18 @@ def main():
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def _library_id():
+    """Which build of the HIP library produced this line (profiles/<tag>_MANIFEST.json carries the same sha for the rocprof summaries)."""
+    import hashlib
+    import mlhot
+    path = os.environ.get("MLHOT_LIB") or mlhot.PRODUCT_SO
+    try:
+        with open(path, "rb") as f:
+            return {"path": os.path.relpath(path, ROOT), "sha256": hashlib.sha256(f.read()).hexdigest()}
+    except OSError:
+        return {"path": path, "sha256": None}
 
 
 def contextlib_null():

@@ -2,12 +2,21 @@
 # Run on the GPU box (gpurun): bench lines, rocprofv3 kernel stats and HBM-traffic counters of the headline
 # workload.  Everything lands under gpurun_out/prof/; scripts/summarise_profiles.py turns it into profiles/*.
 # PMC passes are separate runs with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+# EVERY <tag>_* summary comes out of THIS run: the raw directory is emptied first, the library's sha256 and the start time go into
+# $OUT/MANIFEST.json, and scripts/summarise_profiles.py refuses raw files older than that or a library other than that
+# (round 4 committed a "final" set that mixed two library states).
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof
-TAG=${1:-r04_final}
+TAG=${1:-r05_final}
+rm -rf $OUT
 mkdir -p $OUT
 cd $REPO
+LIB=$REPO/what-matters-for-meta-learning_amd/csrc/libmlhot.so
+python3 - "$LIB" "$OUT/MANIFEST.json" "$TAG" <<'PY'
+import hashlib, json, sys, time
+json.dump({"tag": sys.argv[3], "lib_sha256": hashlib.sha256(open(sys.argv[1], "rb").read()).hexdigest(), "started_at": time.time()}, open(sys.argv[2], "w"))
+PY
 python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench_c3.json 2> $OUT/bench_c3.err
 python bench.py --steps 50 --warmup 10 --workload c2 --no-cpu-baseline > $OUT/${TAG}_bench_c2.json 2> $OUT/bench_c2.err
 MLHOT_BENCH_KERNELS=$OUT/${TAG}_kernels_c3.json python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
@@ -20,6 +29,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_write.log 2>&1
 # SQ / GRBM pass: MFMA-pipe busy cycles and the wave-cycle split (active / issue-stalled / parked) of the hot kernels
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o sq -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras --prof-steps 0 > $OUT/pmc_sq.log 2>&1
+# instruction mix and LDS bank conflicts of the same library (round 4's copies of these two were collected hours before its final build)
+cd $REPO
+bash scripts/inst_mix.sh c3 > $OUT/${TAG}_inst_mix_c3.txt 2>&1
+bash scripts/lds_conflicts.sh c3 > $OUT/${TAG}_lds_conflicts_c3.txt 2>&1
 # BASELINE config c5's per-GPU step (ANPMRShapeNet3D, bench.py --workload c5): bench line, per-label kernel times, kernel stats
 cd $REPO
 python bench.py --workload c5 --steps 30 --warmup 5 > $OUT/${TAG}_bench_c5.json 2> $OUT/bench_c5.err

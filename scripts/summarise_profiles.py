@@ -12,7 +12,50 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05_final"
+force = "--force" in sys.argv
+
+# ---- one library build behind every summary ----------------------------------------------------------------------------------
+import hashlib
+import time
+try:
+    MAN = json.load(open(os.path.join(SRC, "MANIFEST.json")))
+except OSError:
+    sys.exit("summarise_profiles: gpurun_out/prof/MANIFEST.json is missing - collect with scripts/collect_profiles.sh (it records the library's sha256)")
+lib = os.path.join(ROOT, "what-matters-for-meta-learning_amd", "csrc", "libmlhot.so")
+local_sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+if MAN.get("tag") != tag:
+    sys.exit(f"summarise_profiles: the raw directory was collected as {MAN.get('tag')!r}, not {tag!r}")
+if local_sha != MAN["lib_sha256"] and not force:
+    sys.exit(f"summarise_profiles: the profiles were collected with library {MAN['lib_sha256'][:12]}, the tree now builds {str(local_sha)[:12]}: "
+             "re-collect (or --force to summarise the older library's numbers, which the manifest will say)")
+stale = [p for p in glob.glob(os.path.join(SRC, "**", "*"), recursive=True)
+         if os.path.isfile(p) and os.path.getmtime(p) < MAN["started_at"] - 5 and not p.endswith("MANIFEST.json")]
+if stale:
+    sys.exit("summarise_profiles: raw files older than this collection's start: " + ", ".join(os.path.relpath(p, SRC) for p in stale[:8]))
+WRITTEN = []
+_copy = shutil.copy
+
+
+def _tracked_copy(src, dst):
+    WRITTEN.append(os.path.basename(dst))
+    return _copy(src, dst)
+
+
+shutil.copy = _tracked_copy
+import atexit
+
+
+def _manifest():
+    json.dump({"tag": tag, "lib_sha256": MAN["lib_sha256"], "lib_matches_tree": local_sha == MAN["lib_sha256"],
+               "collected_at": time.strftime("%Y-%m-%d %H:%M:%S", time.gmtime(MAN["started_at"])) + " UTC",
+               "files": sorted(set(WRITTEN + [n for n in os.listdir(DST) if n.startswith(tag + "_") and n.endswith((".json", ".txt", ".csv"))
+                                               and os.path.getmtime(os.path.join(DST, n)) >= MAN["started_at"]])),
+               "note": "every file listed was produced by ONE run of scripts/collect_profiles.sh with the library above"},
+              open(os.path.join(DST, f"{tag}_MANIFEST.json"), "w"), indent=1)
+
+
+atexit.register(_manifest)
 
 KERNEL_LABEL = {            # kernel-name fragment -> bench.py label
     "conv12_fwd_pool_kernel": "enc.conv12", "conv12_wgrad_kernel": "enc.bwd.conv12.wgrad", "conv12_dgrad_kernel": "enc.bwd.conv12.dgrad",
@@ -26,7 +69,7 @@ def find(pattern):
 
 
 for name in (f"{tag}_bench_c3.json", f"{tag}_bench_c2.json", f"{tag}_kernels_c3.json", f"{tag}_bench_c5.json", f"{tag}_bench_c5_device_eps.json", f"{tag}_kernels_c5.json",
-             f"{tag}_pmc_traffic_c5.json", f"{tag}_pmc_sq_c5.json"):
+             f"{tag}_pmc_traffic_c5.json", f"{tag}_pmc_sq_c5.json", f"{tag}_inst_mix_c3.txt", f"{tag}_lds_conflicts_c3.txt"):
     p = os.path.join(SRC, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(DST, name))
@@ -62,7 +105,7 @@ def pmc(dirname, counter):
 
 
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
-out = {"_workload": "c3", "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-graph`, c3 workload, "
+out = {"_workload": "c3", "_lib_sha256": MAN["lib_sha256"], "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-graph`, c3 workload, "
                 "480 images. Counter unit KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); "
                 "WRITE_SIZE as read. Bytes per launch (mean over the launches of the run)."}
 for label in sorted(set(fetch) | set(write)):
@@ -73,7 +116,7 @@ if len(out) > 1:
     for name in (f"{tag}_pmc_traffic.json", "pmc_traffic.json"):
         with open(os.path.join(DST, name), "w") as f:
             json.dump(out, f, indent=1)
-print(json.dumps({k: v for k, v in out.items() if k != "_note"}, indent=1))
+print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
 
 
 # ---- SQ / GRBM counters of the hot kernels: MFMA-pipe utilisation and where the wave cycles go -----------------------------
@@ -83,7 +126,7 @@ sq = {c: pmc("pmc_sq", c) for c in SQ}
 labels = sorted(set().union(*[set(v) for v in sq.values()]))
 if labels:
     N_SIMD, N_XCD = 256 * 4, 8
-    res = {"_note": "rocprofv3 --pmc (one pass, 7 SQ + 1 GRBM counter) of `bench.py --steps 3 --warmup 1 --no-graph`, c3 workload; per-launch means. "
+    res = {"_lib_sha256": MAN["lib_sha256"], "_note": "rocprofv3 --pmc (one pass, 7 SQ + 1 GRBM counter) of `bench.py --steps 3 --warmup 1 --no-graph`, c3 workload; per-launch means. "
                     "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): SQ_VALU_MFMA_BUSY_CYCLES is summed over "
                     "all SIMDs in shader cycles (it equals 32 x the kernel's v_mfma_f32_16x16x4_f32 count: 238.9 M for enc.conv12 = 7.47 M MFMAs), "
                     "GRBM_GUI_ACTIVE is summed over the 8 XCDs (1/8 of it x 1/2.4 GHz is the kernel's duration). wave-cycle split: WAIT_ANY (parked: s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + "
@@ -99,7 +142,7 @@ if labels:
         res[lb] = d
     with open(os.path.join(DST, f"{tag}_pmc_sq.json"), "w") as f:
         json.dump(res, f, indent=1)
-    print(json.dumps({k: {kk: (round(vv, 4) if isinstance(vv, float) and vv < 10 else vv) for kk, vv in v.items()} for k, v in res.items() if k != "_note"}, indent=1))
+    print(json.dumps({k: {kk: (round(vv, 4) if isinstance(vv, float) and vv < 10 else vv) for kk, vv in v.items()} for k, v in res.items() if not k.startswith("_")}, indent=1))
 
 
 # ---- the opt-in split-precision conv12 kernels (extras) -----------------------------------------------------------------------
@@ -130,4 +173,4 @@ if labels:
         res[lb] = d
     with open(os.path.join(DST, f"{tag}_split_pmc_sq.json"), "w") as f:
         json.dump(res, f, indent=1)
-    print(json.dumps({k: {kk: (round(vv, 4) if isinstance(vv, float) and vv < 10 else vv) for kk, vv in v.items()} for k, v in res.items() if k != "_note"}, indent=1))
+    print(json.dumps({k: {kk: (round(vv, 4) if isinstance(vv, float) and vv < 10 else vv) for kk, vv in v.items()} for k, v in res.items() if not k.startswith("_")}, indent=1))
