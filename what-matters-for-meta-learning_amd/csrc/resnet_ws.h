@@ -301,6 +301,35 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
     stage_patch<G>(patch, jb.x, img0, oy0, jb.n_img, tid, jb.img_lo);
     RW_TS(3 + 4 * ts_k);
 
+    // ---- the epilogue's addresses and its `aux` loads (residual / mask epilogues), in front of the MFMA loop ----------------------
+    // Round 5, band timeline of the 16 x 16 conv2 (scripts/dev/trunk_ts.py): MFMAs done at 32.6 k cycles, aux loads issued at 34.2 k,
+    // first tile stored at 49.5 k - the band sat 15 k cycles (as long as its MFMAs take) waiting for 16 floats per lane that could
+    // have been requested before the first MFMA: every workgroup of the chip asks for its residual tile at about the same time.
+    constexpr int VW = G::PI < 16 ? 4 : (G::TC >= 4 ? 4 : 2);
+    constexpr int NV = 4 / VW;
+    typedef float vw_t __attribute__((ext_vector_type(VW)));
+    const bool need_aux = jb.epi == EPI_BIAS_RES_RELU || jb.epi == EPI_MASK;
+    unsigned offs[G::NACC][NV];      // element offsets into y / aux / y1 (maps stay far below 2^32 elements; 64-bit offsets cost a register more each - the kernel sits at the 256-register limit)
+    bool live[G::NACC][NV];
+    vw_t ax[G::NACC][NV];
+#pragma unroll
+    for (int t = 0; t < G::NACC; ++t) {
+#pragma unroll
+      for (int vi = 0; vi < NV; ++vi) {
+        const int v = vi * VW;
+        int il = 0, oy = 0, ox = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (lq == q) { il = G::tile_il(t, 4 * q + v); oy = G::tile_oy(t, 4 * q + v); ox = G::tile_ox(t, 4 * q + v); }
+        const int img = img0 + il;
+        live[t][vi] = img < jb.n_img && img >= jb.img_lo;
+        offs[t][vi] = (((unsigned)(live[t][vi] ? img : 0) * CH + co) * G::HO + oy0 + oy) * G::WO + ox;
+#pragma unroll
+        for (int q = 0; q < VW; ++q) ax[t][vi][q] = 0.f;
+        if (need_aux && live[t][vi]) ax[t][vi] = *reinterpret_cast<const vw_t*>(jb.aux + offs[t][vi]);
+      }
+    }
+
     // ---- 144 k-steps x NACC tiles ----
     f32x4_t acc[G::NACC], acc1[SKIP1 ? G::NACC : 1];
 #pragma unroll
@@ -344,33 +373,9 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
     RW_TS(4 + 4 * ts_k);
     // ---- epilogue: lane holds rows 4lq..4lq+3 of every tile for channel co ----
     // The four rows are contiguous in the NCHW plane in runs of VW (a tile row has TC >= 2 columns; 2x2 maps: a whole plane).
-    // Two passes: first every tile's output offset and - for the residual / mask epilogues - its `aux` load, ALL of them in
-    // flight together; then the arithmetic and the stores.  (One pass, tile by tile, hipcc waited for each tile's aux load
+    // Two passes: every tile's output offset and - for the residual / mask epilogues - its `aux` load are made IN FRONT of the
+    // MFMA loop (round 5, below); here the arithmetic and the stores.  (One pass, tile by tile, hipcc waited for each tile's aux load
     // before it issued the next: the band timeline of the 16x16 conv2 showed 23 k cycles of epilogue behind 19.6 k of MFMAs.)
-    constexpr int VW = G::PI < 16 ? 4 : (G::TC >= 4 ? 4 : 2);
-    constexpr int NV = 4 / VW;
-    typedef float vw_t __attribute__((ext_vector_type(VW)));
-    const bool need_aux = jb.epi == EPI_BIAS_RES_RELU || jb.epi == EPI_MASK;
-    unsigned offs[G::NACC][NV];      // element offsets into y / aux / y1 (maps stay far below 2^32 elements; 64-bit offsets cost a register more each - the kernel sits at the 256-register limit)
-    bool live[G::NACC][NV];
-    vw_t ax[G::NACC][NV];
-#pragma unroll
-    for (int t = 0; t < G::NACC; ++t) {
-#pragma unroll
-      for (int vi = 0; vi < NV; ++vi) {
-        const int v = vi * VW;
-        int il = 0, oy = 0, ox = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (lq == q) { il = G::tile_il(t, 4 * q + v); oy = G::tile_oy(t, 4 * q + v); ox = G::tile_ox(t, 4 * q + v); }
-        const int img = img0 + il;
-        live[t][vi] = img < jb.n_img && img >= jb.img_lo;
-        offs[t][vi] = (((unsigned)(live[t][vi] ? img : 0) * CH + co) * G::HO + oy0 + oy) * G::WO + ox;
-#pragma unroll
-        for (int q = 0; q < VW; ++q) ax[t][vi][q] = 0.f;
-        if (need_aux && live[t][vi]) ax[t][vi] = *reinterpret_cast<const vw_t*>(jb.aux + offs[t][vi]);
-      }
-    }
     RW_TS(16 + (ts_k > 0));
 #pragma unroll
     for (int t = 0; t < G::NACC; ++t) {
