@@ -29,10 +29,15 @@ if MAN.get("tag") != tag:
 if local_sha != MAN["lib_sha256"] and not force:
     sys.exit(f"summarise_profiles: the profiles were collected with library {MAN['lib_sha256'][:12]}, the tree now builds {str(local_sha)[:12]}: "
              "re-collect (or --force to summarise the older library's numbers, which the manifest will say)")
-stale = [p for p in glob.glob(os.path.join(SRC, "**", "*"), recursive=True)
-         if os.path.isfile(p) and os.path.getmtime(p) < MAN["started_at"] - 5 and not p.endswith("MANIFEST.json")]
+# gpurun MERGES the box's gpurun_out/ into the local one, so leftovers of earlier collections sit beside this one's files: anything
+# older than this collection's start is not part of it and is never read below (fresh() / find())
+def fresh(path):
+    return os.path.isfile(path) and os.path.getsize(path) > 0 and os.path.getmtime(path) >= MAN["started_at"] - 5
+
+
+stale = [p for p in glob.glob(os.path.join(SRC, "**", "*"), recursive=True) if os.path.isfile(p) and not fresh(p) and not p.endswith("MANIFEST.json")]
 if stale:
-    sys.exit("summarise_profiles: raw files older than this collection's start: " + ", ".join(os.path.relpath(p, SRC) for p in stale[:8]))
+    print(f"summarise_profiles: ignoring {len(stale)} raw files older than this collection's start (leftovers of earlier collections)", file=sys.stderr)
 WRITTEN = []
 _copy = shutil.copy
 
@@ -64,16 +69,16 @@ KERNEL_LABEL = {            # kernel-name fragment -> bench.py label
 
 
 def find(pattern):
-    hits = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True))
+    hits = [h for h in sorted(glob.glob(os.path.join(SRC, pattern), recursive=True)) if fresh(h)]
     return hits[0] if hits else None
 
 
 for name in (f"{tag}_bench_c3.json", f"{tag}_bench_c2.json", f"{tag}_kernels_c3.json", f"{tag}_bench_c5.json", f"{tag}_bench_c5_device_eps.json", f"{tag}_kernels_c5.json",
              f"{tag}_pmc_traffic_c5.json", f"{tag}_pmc_sq_c5.json", f"{tag}_inst_mix_c3.txt", f"{tag}_lds_conflicts_c3.txt"):
     p = os.path.join(SRC, name)
-    if os.path.exists(p) and os.path.getsize(p):
+    if fresh(p):
         shutil.copy(p, os.path.join(DST, name))
-if os.path.exists(os.path.join(SRC, f"{tag}_pmc_traffic_c5.json")):
+if fresh(os.path.join(SRC, f"{tag}_pmc_traffic_c5.json")):
     shutil.copy(os.path.join(SRC, f"{tag}_pmc_traffic_c5.json"), os.path.join(DST, "pmc_traffic_c5.json"))      # what bench.py --workload c5 reads
 stats = find("stats/**/*kernel_stats.csv")
 if stats:
@@ -148,7 +153,7 @@ if labels:
 # ---- the opt-in split-precision conv12 kernels (extras) -----------------------------------------------------------------------
 for name in (f"{tag}_split_bench_c3.json", f"{tag}_split_error_vs_float64.txt", f"{tag}_split_inst_mix.txt", f"{tag}_split_lds_conflicts.txt"):
     p = os.path.join(SRC, name)
-    if os.path.exists(p) and os.path.getsize(p):
+    if fresh(p):
         shutil.copy(p, os.path.join(DST, name))
 st = find("stats_split/**/*kernel_stats.csv")
 if st:

@@ -618,7 +618,12 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
           for (int h = 0; h < 2; ++h) {
             float4 v = make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]);
             if (jb.accumulate) { const float4 u = *reinterpret_cast<const float4*>(jb.dx + o + 4 * h); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-            if (jb.xact) {
+#ifndef KNOCK_XACT
+            if (jb.xact)
+#else
+            if (false)
+#endif
+            {
               const float4 u = *reinterpret_cast<const float4*>(jb.xact + o + 4 * h);
               v.x = u.x > 0.f ? v.x : 0.f; v.y = u.y > 0.f ? v.y : 0.f; v.z = u.z > 0.f ? v.z : 0.f; v.w = u.w > 0.f ? v.w : 0.f;
             }
