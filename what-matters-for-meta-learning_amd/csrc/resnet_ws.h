@@ -490,6 +490,13 @@ struct DgJobs { DgJob j[MAX_JOBS]; int n; };
 // gradient map: 262 MB of HBM traffic in c5's block 1, `frac_wait_any` 0.61).  Waves 0-3 run the first source, waves 4-7 the
 // second, each with its own weight registers and patch; the second half hands its accumulators over through LDS and the first
 // half writes dx once, masked.
+// mask rows in LDS: per band 2 RB dx rows x 2 HO columns = 128 floats per channel for the three geometries with whole-row bands
+// (D8 / D16 / D32); channel stride 132 words = 4 (mod 64): the 16 lanes of an epilogue read (one channel each, one float4) cover the
+// 64 banks once
+constexpr int DG_XL_LD = 132, DG_XL_F4 = CH * 32;       // float4 items per band
+template <class G> __host__ __device__ constexpr bool dg_xl() { return !G::MULTI && G::PI >= 16 && 2 * G::RB * 2 * G::HO == 128; }
+template <class G> __host__ __device__ constexpr int dg_xl_floats() { return dg_xl<G>() ? CH * DG_XL_LD : 0; }
+
 template <class G, bool SKIP1, bool DUAL = false>
 __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, int band0, int band_end, int band_step) {
   static_assert(G::KIND == 1 && (G::TC >= 4 || G::PI < 16), "epilogue needs 4 consecutive grid columns per lane (or whole 2x2 maps)");
@@ -502,6 +509,14 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
   const int ci = 16 * nt + lr;
   constexpr int NT = G::NACC, HX = 2 * G::HO;
   const float* src_dy = (DUAL && half) ? jb.g1 : jb.dy;
+  // The ReLU mask's source rows (xact, the block's input under this band's dx rows) ride through LDS: requested together with the
+  // band's dy patch, read by the epilogue.  (Round 5: as global loads IN the epilogue they cost the c5 step 35 us - knock-out,
+  // profiles/r05_ab_dgrad2_mask_knockout.txt: block 1's dual launch 116.7 -> 95.3 us without them - the dual kernel has ONE
+  // workgroup per CU and nothing else to run while 8 float4 per lane make their round trip.)
+  constexpr bool XL = dg_xl<G>();
+  constexpr int XNT = DUAL ? 512 : 256, XK = DG_XL_F4 / XNT;
+  static_assert(XK == 4 || XK == 8, "mask staging items per thread");
+  float* xl = patch_all + (DUAL ? 2 * G::PATCH + 4 * 16 * G::NACC * 64 : G::PATCH * (SKIP1 ? 2 : 1));
 
   float wr[NKS];
   {
@@ -532,8 +547,28 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
   for (int band = band0; band < nbands; band += band_step) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
     const int a0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
+    const bool xl_on = XL && jb.xact != nullptr;                  // job-uniform
+    // eight NAMED float4s (an array indexed in an unrolled loop stays in scratch memory: hipcc decides before it unrolls - 144 bytes
+    // per lane in the first version of this)
+    float4 xr0, xr1, xr2, xr3, xr4, xr5, xr6, xr7;
+    xr0 = xr1 = xr2 = xr3 = xr4 = xr5 = xr6 = xr7 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define DG_XE(k) ((int)threadIdx.x + XNT * (k))
+#define DG_XLOAD(k) *reinterpret_cast<const float4*>(xg + (size_t)(DG_XE(k) >> 5) * (HX * HX) + 4 * (DG_XE(k) & 31))
+#define DG_XSTORE(k, v) *reinterpret_cast<float4*>(xl + (DG_XE(k) >> 5) * DG_XL_LD + 4 * (DG_XE(k) & 31)) = v
+    if (XL && xl_on) {                                            // the band's 128 mask floats per channel: contiguous rows 2 a0 .. 2 (a0 + RB) - 1
+      const float* xg = jb.xact + ((size_t)img0 * CH * HX + 2 * a0) * HX;
+      xr0 = DG_XLOAD(0); xr1 = DG_XLOAD(1); xr2 = DG_XLOAD(2); xr3 = DG_XLOAD(3);
+      if (XK == 8) { xr4 = DG_XLOAD(4); xr5 = DG_XLOAD(5); xr6 = DG_XLOAD(6); xr7 = DG_XLOAD(7); }
+    }
     stage_patch<G>(patch, src_dy, img0, a0, jb.n_img, tid, jb.img_lo);
     if (has1) stage_patch<G>(patch1, jb.g1, img0, a0, jb.n_img, tid, jb.img_lo);
+    if (XL && xl_on) {                                            // (the previous band's epilogue is behind stage_patch's first barrier)
+      DG_XSTORE(0, xr0); DG_XSTORE(1, xr1); DG_XSTORE(2, xr2); DG_XSTORE(3, xr3);
+      if (XK == 8) { DG_XSTORE(4, xr4); DG_XSTORE(5, xr5); DG_XSTORE(6, xr6); DG_XSTORE(7, xr7); }
+    }
+#undef DG_XE
+#undef DG_XLOAD
+#undef DG_XSTORE
 
     f32x4_t acc[4][NT];
 #pragma unroll
@@ -596,6 +631,7 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
             for (int r = 0; r < 4; ++r) acc[c][t][r] += xw[((c * NT + t) * 4 + r) * 64];
       }
     }
+    if (!DUAL && XL && xl_on) __syncthreads();                    // the mask rows are complete (DUAL: the exchange's barrier above)
     // ---- epilogue: rows 4lq..4lq+3 of tile t = 4 consecutive grid columns (or a whole 2x2 grid) of channel ci ----
     if (!DUAL || half == 0)
 #pragma unroll
@@ -618,13 +654,9 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
           for (int h = 0; h < 2; ++h) {
             float4 v = make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]);
             if (jb.accumulate) { const float4 u = *reinterpret_cast<const float4*>(jb.dx + o + 4 * h); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-#ifndef KNOCK_XACT
-            if (jb.xact)
-#else
-            if (false)
-#endif
-            {
-              const float4 u = *reinterpret_cast<const float4*>(jb.xact + o + 4 * h);
+            if (jb.xact) {
+              const float4 u = XL ? *reinterpret_cast<const float4*>(xl + ci * DG_XL_LD + (2 * a + py) * HX + 2 * b + 4 * h)
+                                  : *reinterpret_cast<const float4*>(jb.xact + o + 4 * h);
               v.x = u.x > 0.f ? v.x : 0.f; v.y = u.y > 0.f ? v.y : 0.f; v.z = u.z > 0.f ? v.z : 0.f; v.w = u.w > 0.f ? v.w : 0.f;
             }
             *reinterpret_cast<float4*>(jb.dx + o + 4 * h) = v;
@@ -650,7 +682,8 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
 
 template <class G, bool SKIP1>
 __global__ __launch_bounds__(256, 2) void dgrad2_kernel(const DgJobs jobs) {
-  __shared__ float patch[G::PATCH * (SKIP1 ? 2 : 1)];
+  __shared__ __attribute__((aligned(16))) float patch[G::PATCH * (SKIP1 ? 2 : 1) + dg_xl_floats<G>()];
+  static_assert((G::PATCH * (SKIP1 ? 2 : 1) + dg_xl_floats<G>()) * 4 <= 80 * 1024, "two workgroups per CU");
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
   const DgJob& jb = jobs.j[ji];
@@ -693,7 +726,7 @@ inline int dgrad2_dispatch(int HO, bool skip1, DgJobs& jobs, hipStream_t s, cons
 
 template <class G>
 __global__ __launch_bounds__(512) void dgrad2_dual_kernel(const DgJobs jobs) {
-  __shared__ float patch[2 * G::PATCH + 4 * 16 * G::NACC * 64];      // two dy patches + the accumulator exchange
+  __shared__ __attribute__((aligned(16))) float patch[2 * G::PATCH + 4 * 16 * G::NACC * 64 + dg_xl_floats<G>()];      // two dy patches + the accumulator exchange + the mask rows
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
   const DgJob& jb = jobs.j[ji];
