@@ -310,7 +310,8 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   tf::PhaseBBwdArgs bb{td, tp, sl, b.qh, b.kh, b.vh, w.pc, w.qf, w.kf, w.S, w.D, b.merged, sc.d_rr, w.arg_q,
                        b.dec_in, b.cat_in, b.rs, b.wot, sc.dqh, sc.dkh, sc.dvh, part_k, sc.tail_slab};
   if (st.first()) {
-    if (spec & 16) MLHOT_TRY(tail_launch(ts::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, ts::phaseB_bwd_lds_bytes(), bb, s, "tail.bwd.B"));
+    if ((spec & 16) && (spec & 512)) MLHOT_TRY(tail_launch(ts::phaseB_bwd_kernel<true>, 2 * d.T * MLHOT_HEADS, 512, ts::phaseB_bwd_lds_bytes(), bb, s, "tail.bwd.B"));
+    else if (spec & 16) MLHOT_TRY(tail_launch(ts::phaseB_bwd_kernel<false>, d.T * MLHOT_HEADS, 512, ts::phaseB_bwd_lds_bytes(), bb, s, "tail.bwd.B"));
     else MLHOT_TRY(tail_launch(tf::phaseB_bwd_kernel, d.T * MLHOT_HEADS, 512, tf::phaseB_bwd_lds_bytes(td), bb, s, "tail.bwd.B"));
   }
   // strict sharded parity: phase A folds part_k into the stabiliser's gradient and routes it to the arg-max key's task

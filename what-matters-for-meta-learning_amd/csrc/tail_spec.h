@@ -1106,11 +1106,18 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
 constexpr int BB_FLOATS = 16 * (12 * B_LX + 4 * B_LF) + 2 * 16 * 17 + 64 + NWV * 32 + 2 * NWV * 256;
 __host__ inline size_t phaseB_bwd_lds_bytes() { return sizeof(float) * BB_FLOATS; }
 
+// SPLIT (round 5, VERDICT r4 item 1 i): TWO workgroups per (task, head) - the query side and the key / value side of the backward
+// are independent once dS is known, so side 0 takes G_q, d x_qry's share, W_q's and _W's weight gradients, side 1 takes dV, G_k,
+// the key row-sum share, d x_ctx's / d rs's shares, W_k's and W_v's gradients; both compute the small common part (dO, dS) and
+// load both feature tiles.  256 workgroups (one per CU at T = 16) instead of 128, no exchange between the two.
+template <bool SPLIT>
 __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
-  const int t = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  const int bth = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x, side = SPLIT ? (int)blockIdx.x & 1 : 0;
+  const bool doq = !SPLIT || side == 0, dok = !SPLIT || side == 1;          // block-uniform
+  const int t = bth / H, h = bth % H, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   lptr s_q = L0;                    // [16][B_LX]
   lptr s_k = s_q + 16 * B_LX;
@@ -1137,12 +1144,13 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   // ---- every global read of the block, up front
   Tile64 tq, tk, tv, txq, txc, trs, tdrr;
   MLHOT_TSTAMP(128);
-  tq.fetch(a.qh + rq * HD + h * DW, HD, d.Nq, tid);
-  tk.fetch(a.kh + rc * HD + h * DW, HD, d.Nc, tid);
+  tq.v = tk.v = txq.v = txc.v = trs.v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (doq) tq.fetch(a.qh + rq * HD + h * DW, HD, d.Nq, tid);
+  if (dok) tk.fetch(a.kh + rc * HD + h * DW, HD, d.Nc, tid);
   tv.fetch(a.vh + rc * HD + h * DW, HD, d.Nc, tid);
-  txq.fetch(a.dec_in + rq * LDD, LDD, d.Nq, tid);
-  txc.fetch(a.cat_in + rc * LDC, LDC, d.Nc, tid);
-  trs.fetch(a.rs + rc * DW, DW, d.Nc, tid);
+  if (doq) txq.fetch(a.dec_in + rq * LDD, LDD, d.Nq, tid);
+  if (dok) txc.fetch(a.cat_in + rc * LDC, LDC, d.Nc, tid);
+  if (dok) trs.fetch(a.rs + rc * DW, DW, d.Nc, tid);
   tdrr.fetch(a.d_rr + rq * DW, DW, d.Nq, tid);
   float ov[2];
 #pragma unroll
@@ -1166,7 +1174,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     if (n < d.Nq) dval = a.D[((size_t)t * H + h) * d.Nq + n];
     if (n < d.Nq && np < d.Nc) sdv = a.S[(((size_t)t * H + h) * d.Nq + n) * d.Nc + np];
   }
-  if (tid < d.Nq) argq = a.arg_q[(t * d.Nq + tid) * H + h];
+  if (doq && tid < d.Nq) argq = a.arg_q[(t * d.Nq + tid) * H + h];
   const float *wq = a.p.wq_w[0], *wk = a.p.wk_w[0], *wv = a.p.wv_w[0];
 #pragma unroll
   for (int i = 1; i < H; ++i)
@@ -1179,7 +1187,8 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   float wsh[2][4][4];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int item = wave + 8 * u;
+    // SPLIT: the query side's four items on its waves 0-3, the key / value side's eight on its waves 0-7, one each
+    const int item = SPLIT ? (u == 0 ? (side == 0 ? (wave < 4 ? wave : 99) : 4 + wave) : 99) : wave + 8 * u;
     if (item < 12) {
       const int pj = item >> 2, i0 = (item & 3) * 16;
       const float* wsel = (pj == 0 ? wq : pj == 1 ? wk : wv) + i0 + lr;
@@ -1220,7 +1229,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     if (part == 0) s_st[n] = sum;
   }
   // dV[n'][e] = sum_n (S/D)[n][n'] dO[n][e]  (waves 4-7, one e tile each)
-  if (wave >= 4) {
+  if (wave >= 4 && dok) {
     const int et = wave - 4;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1261,11 +1270,11 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
   {
     float rsq[4] = {0.f, 0.f, 0.f, 0.f}, rsk[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tr = 0; tr < 5; ++tr) {
+    for (int tr = 0; tr < (SPLIT ? 3 : 5); ++tr) {
       const int it = wave + 8 * tr;
-      if (it < 2 * NTILE) {
-        const bool isk = it >= NTILE;
-        const int jt = isk ? it - NTILE : it;
+      if (it < (SPLIT ? NTILE : 2 * NTILE)) {
+        const bool isk = SPLIT ? side == 1 : it >= NTILE;
+        const int jt = (!SPLIT && isk) ? it - NTILE : it;
         const int j = jt * 16 + lr;
         const bool vj = j < M;
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -1302,18 +1311,19 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
 #pragma unroll
     for (int w = 0; w < NWV; ++w) sum += s_part[w * 32 + tid];
     s_st[32 + tid] = sum;
-    if (tid < d.Nq) s_gq[tid * B_LF + argq] -= sum;
+    if (doq && tid < d.Nq) s_gq[tid * B_LF + argq] -= sum;
     float ks = (tid >= 16 && tid - 16 < d.Nc) ? sum : 0.f;
 #pragma unroll
     for (int off = 1; off < 32; off <<= 1) ks += __shfl_xor(ks, off, 64);
-    if (tid == 0) a.part_k[t * H + h] = ks;
+    if (tid == 0 && dok) a.part_k[t * H + h] = ks;
   }
   __syncthreads();
   MLHOT_TSTAMP(134);
   // dx[row][e] = sum_j d(dd)[row][j] pc[j][e] - rsum[row] c^2 x[row][e], query and key rows on the same pc fragments;
   // the two halves of the j range are folded through LDS
   {
-    f32x4_t aq = g_p.mma(s_gq, B_LF, wave, lane), ak = g_p.mma(s_gk, B_LF, wave, lane);
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t aq = doq ? g_p.mma(s_gq, B_LF, wave, lane) : zero4, ak = dok ? g_p.mma(s_gk, B_LF, wave, lane) : zero4;
     constexpr int NI = Dg<M, DW>::NI;                   // 4 tiles x 2 chunks
     const int tile = wave % NI, chunk = wave / NI;
     if (chunk > 0) {
@@ -1328,8 +1338,8 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * lq + r;
         const float vq = aq[r] + s_red[((wave + NI) * 4 + r) * 64 + lane], vk = ak[r] + s_red[NWV * 256 + ((wave + NI) * 4 + r) * 64 + lane];
-        s_dq[row * B_LX + e] = row < d.Nq ? vq - s_st[32 + row] * c2 * s_q[row * B_LX + e] : 0.f;
-        s_dk[row * B_LX + e] = row < d.Nc ? vk - s_st[48 + row] * c2 * s_k[row * B_LX + e] : 0.f;
+        if (doq) s_dq[row * B_LX + e] = row < d.Nq ? vq - s_st[32 + row] * c2 * s_q[row * B_LX + e] : 0.f;
+        if (dok) s_dk[row * B_LX + e] = row < d.Nc ? vk - s_st[48 + row] * c2 * s_k[row * B_LX + e] : 0.f;
       }
     }
   }
@@ -1342,7 +1352,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     // input-gradient shares first (their weights have been in registers since the prologue)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int item = wave + 8 * u;
+      const int item = SPLIT ? (u == 0 ? (side == 0 ? (wave < 4 ? wave : 99) : 4 + wave) : 99) : wave + 8 * u;
       if (item < 12) {
         const int pj = item >> 2, i0 = (item & 3) * 16;
         lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
@@ -1364,8 +1374,10 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     }
     // weight gradients dW[n][i] = sum_row dY[row][n] X[row][i]: 3 nt^2 tiles of 4 MFMAs over the waves
 #pragma unroll
-    for (int tr = 0; tr < 3 * nt * nt / NWV; ++tr) {
-      const int it = wave + NWV * tr;
+    for (int tr = 0; tr < (SPLIT ? 4 : 3 * nt * nt / NWV); ++tr) {
+      // SPLIT: the query side's 16 tiles (W_q) in two trips, the key / value side's 32 (W_k, W_v) in four
+      if (SPLIT && side == 0 && tr >= 2) break;
+      const int it = (SPLIT && side == 1 ? nt * nt : 0) + wave + NWV * tr;
       const int pj = it / (nt * nt), rem = it - pj * nt * nt, j0 = (rem / nt) * 16, i0 = (rem % nt) * 16;
       lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
       lcptr x = pj == 0 ? s_xq : pj == 1 ? s_xc : s_rs;
@@ -1379,6 +1391,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
     // _W's weight gradient for this head's columns: dWo[j][e*H + h] = sum_n d rr[n][j] O[n][e]
 #pragma unroll
     for (int tr = 0; tr < nt * nt / NWV; ++tr) {
+      if (!doq) break;                                  // SPLIT: _W's weight gradient rides with the (lighter) query side
       const int it = wave + NWV * tr;
       const int j0 = (it / nt) * 16, e0 = (it % nt) * 16;
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -1389,7 +1402,7 @@ __global__ __launch_bounds__(512) void phaseB_bwd_kernel(const PhaseBBwdArgs a) 
       for (int r = 0; r < 4; ++r) dst[(size_t)(j0 + 4 * lq + r) * HD + (e0 + lr) * H + h] = acc[r];
     }
     // bias gradients: column sums
-    if (tid < 3 * DW) {
+    if (tid < 3 * DW && (tid < DW ? doq : dok)) {
       const int pj = tid / DW, n = tid - pj * DW;
       lcptr dy = pj == 0 ? s_dq : pj == 1 ? s_dk : s_dv;
       float sum = 0.f;
