@@ -797,14 +797,16 @@ struct Dg {
 
 // dW[NOUT x KIN] = dY^T X over the 16 rows (padded rows of dY are zero), db = column sums of dY; both to the task's slab.
 // Output tiles (16 j x 16 i) round-robin over the waves, 4 MFMAs each, operands straight from LDS.
-template <int NOUT, int KIN>
+// GROUPS > 1: the tiles are dealt over GROUPS workgroups (this one is `grp`; `wave` = grp * NWV + the wave's index), the bias
+// sums belong to group 0.
+template <int NOUT, int KIN, int GROUPS = 1>
 __device__ __forceinline__ void wgrad16(lcptr dys, int ldy, lcptr xs, int ldx, float* __restrict__ dw, float* __restrict__ db,
                                         int wave, int lane, int tid, int nout = NOUT, int kin = KIN) {
-  constexpr int NJ = (NOUT + 15) / 16, NI = (KIN + 15) / 16, TRIPS = (NJ * NI + NWV - 1) / NWV;
+  constexpr int NJ = (NOUT + 15) / 16, NI = (KIN + 15) / 16, TRIPS = (NJ * NI + GROUPS * NWV - 1) / (GROUPS * NWV);
   const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
   for (int tr = 0; tr < TRIPS; ++tr) {
-    const int it = wave + NWV * tr;
+    const int it = wave + GROUPS * NWV * tr;
     if (it < NJ * NI) {
       const int jt = it / NI, j0 = jt * 16, i0 = (it - jt * NI) * 16;
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -856,11 +858,18 @@ constexpr int CB_LY = 20;
 constexpr int CB_FLOATS = 16 * (CB_LY + 4 * C_LH + 2 * C_LD + 2 * C_LR) + NWV * 256;
 __host__ inline size_t phaseC_bwd_lds_bytes() { return sizeof(float) * CB_FLOATS; }
 
+// SPLIT (round 5): TWO workgroups per task.  The data-gradient chain is short and serial - both walk it - but the weight gradients
+// riding in its barrier intervals (7 + 49 + 56 + 16 tiles of 4 MFMAs and their scattered stores) are dealt over the 16 waves of the
+// pair; workgroup 0 of a pair alone writes d_dec_in, d_rr and the bias sums.
+template <bool SPLIT>
 __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
-  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  const int t = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x, grp = SPLIT ? (int)blockIdx.x & 1 : 0;
+  constexpr int GR = SPLIT ? 2 : 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), gwave = grp * NWV + wave;
+  const bool first = grp == 0;
   lptr s_g = L0;                   // [16][CB_LY]   dmu * act'(mu)
   lptr s_d2 = s_g + 16 * CB_LY;     // saved activations
   lptr s_d1 = s_d2 + 16 * C_LH;
@@ -914,22 +923,22 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   MLHOT_TSTAMP(98);
   // decoder0.2: d d1  |  decoder0.4 weight gradient
   g1.finish(g1.mma(s_dd2, C_LH, wave, lane), s_red, s_d1, C_LH, s_dd1, C_LH, nullptr, 0, 0, wave, lane);
-  wgrad16<4, DH>(s_g, CB_LY, s_d2, C_LH, sl + a.sl.dec_w[2], sl + a.sl.dec_b[2], wave, lane, tid, d.y_dim, DH);
+  wgrad16<4, DH, GR>(s_g, CB_LY, s_d2, C_LH, sl + a.sl.dec_w[2], first ? sl + a.sl.dec_b[2] : nullptr, gwave, lane, tid, d.y_dim, DH);
   __syncthreads();
   MLHOT_TSTAMP(99);
   // decoder0.0: input gradient = [d x_qry | dz]  |  decoder0.2 weight gradient
-  g0.finish(g0.mma(s_dd1, C_LH, wave, lane), s_red, nullptr, 0, s_ddec, C_LD, a.d_dec_in + rq * LDD, LDD, d.Nq, wave, lane);
-  wgrad16<DH, DH>(s_dd2, C_LH, s_d1, C_LH, sl + a.sl.dec_w[1], sl + a.sl.dec_b[1], wave, lane, tid);
+  g0.finish(g0.mma(s_dd1, C_LH, wave, lane), s_red, nullptr, 0, s_ddec, C_LD, first ? a.d_dec_in + rq * LDD : nullptr, LDD, d.Nq, wave, lane);
+  wgrad16<DH, DH, GR>(s_dd2, C_LH, s_d1, C_LH, sl + a.sl.dec_w[1], first ? sl + a.sl.dec_b[1] : nullptr, gwave, lane, tid);
   __syncthreads();
   MLHOT_TSTAMP(100);
   // r_to_z (dz = s_ddec[:, dw:]): d rr  |  decoder0.0 weight gradient
-  gz.finish(gz.mma(s_ddec + DW, C_LD, wave, lane), s_red, nullptr, 0, s_drr, C_LR, a.d_rr + rq * DW, DW, d.Nq, wave, lane);
-  wgrad16<DH, LDD>(s_dd1, C_LH, s_dec, C_LD, sl + a.sl.dec_w[0], sl + a.sl.dec_b[0], wave, lane, tid);
+  gz.finish(gz.mma(s_ddec + DW, C_LD, wave, lane), s_red, nullptr, 0, s_drr, C_LR, first ? a.d_rr + rq * DW : nullptr, DW, d.Nq, wave, lane);
+  wgrad16<DH, LDD, GR>(s_dd1, C_LH, s_dec, C_LD, sl + a.sl.dec_w[0], first ? sl + a.sl.dec_b[0] : nullptr, gwave, lane, tid);
   __syncthreads();
   MLHOT_TSTAMP(101);
-  wgrad16<DZ, DW>(s_ddec + DW, C_LD, s_rr, C_LR, sl + a.sl.r2z_w, sl + a.sl.r2z_b, wave, lane, tid);
+  wgrad16<DZ, DW, GR>(s_ddec + DW, C_LD, s_rr, C_LR, sl + a.sl.r2z_w, first ? sl + a.sl.r2z_b : nullptr, gwave, lane, tid);
   // _W: only its bias gradient here (column sums of d rr); weight and input gradient run per head in phase B
-  if (tid >= 256 && tid < 256 + DW) {
+  if (first && tid >= 256 && tid < 256 + DW) {
     float sum = 0.f;
 #pragma unroll
     for (int row = 0; row < 16; ++row) sum += s_drr[row * C_LR + tid - 256];
@@ -945,11 +954,18 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
 constexpr int AB_FLOATS = 16 * (2 * A_LCAT + 4 * A_LH + 2 * A_LX + A_LY) + NWV * 256 + 64 + 16;
 __host__ inline size_t phaseA_bwd_lds_bytes() { return sizeof(float) * AB_FLOATS; }
 
+// SPLIT (round 5): two workgroups per task, as phase C': both sum the heads' shares and walk EncoderFC's data gradients, the weight
+// gradients' 28 + 49 + 35 tiles are dealt over the pair; workgroup 0 alone applies the arg-max fix-up (a read-modify-write of slab
+// entries), adds into d_dec_in and writes d_cat_in.
+template <bool SPLIT>
 __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
-  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  const int t = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x, grp = SPLIT ? (int)blockIdx.x & 1 : 0;
+  constexpr int GR = SPLIT ? 2 : 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), gwave = grp * NWV + wave;
+  const bool first = grp == 0;
   lptr s_cat = L0;                  // saved activations
   lptr s_h0 = s_cat + 16 * A_LCAT;
   lptr s_h1 = s_h0 + 16 * A_LH;
@@ -1002,7 +1018,7 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   // The batch-global key arg-max (see tf::phaseA_bwd_kernel): a rank-1 fix-up in the ONE task that holds it.  Its operands
   // (the [dw][dw] slab block it updates, W_k of that head, the projection row) are requested here with everything else.
   float* sl = a.slab + (size_t)t * a.sl.total;
-  const bool fix = grow / (d.Nc * H) == t;           // block-uniform
+  const bool fix = first && grow / (d.Nc * H) == t;           // block-uniform
   const int fn = (grow / H) % d.Nc, fh = grow % H;
   float gwv[8], wkv[8], pcv = 0.f, bkv = 0.f;
   if (fix) {
@@ -1029,7 +1045,7 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
     }
     s_drs[srow * A_LX + scol] = s1.x; s_drs[srow * A_LX + scol + 1] = s1.y;
     s_dxc[srow * A_LX + scol] = s2.x; s_dxc[srow * A_LX + scol + 1] = s2.y;
-    if (srow < d.Nq) {
+    if (first && srow < d.Nq) {
       float2 s3 = make_float2(0.f, 0.f);
 #pragma unroll
       for (int h = 0; h < H; ++h) { s3.x += v3[h].x; s3.y += v3[h].y; }
@@ -1076,21 +1092,21 @@ __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) 
   __syncthreads();
   MLHOT_TSTAMP(163);
   g1.finish(g1.mma(s_dh1, A_LH, wave, lane), s_red, s_h0, A_LH, s_dh0, A_LH, nullptr, 0, 0, wave, lane);
-  wgrad16<DW, H1>(s_drs, A_LX, s_h1, A_LH, sl + a.sl.er_w[2], sl + a.sl.er_b[2], wave, lane, tid);
+  wgrad16<DW, H1, GR>(s_drs, A_LX, s_h1, A_LH, sl + a.sl.er_w[2], first ? sl + a.sl.er_b[2] : nullptr, gwave, lane, tid);
   __syncthreads();
   MLHOT_TSTAMP(164);
   g0.finish(g0.mma(s_dh0, A_LH, wave, lane), s_red, nullptr, 0, s_dcat, A_LCAT, nullptr, 0, 0, wave, lane);
-  wgrad16<H1, H0>(s_dh1, A_LH, s_h0, A_LH, sl + a.sl.er_w[1], sl + a.sl.er_b[1], wave, lane, tid);
+  wgrad16<H1, H0, GR>(s_dh1, A_LH, s_h0, A_LH, sl + a.sl.er_w[1], first ? sl + a.sl.er_b[1] : nullptr, gwave, lane, tid);
   __syncthreads();
   MLHOT_TSTAMP(165);
   // d_cat_in = EncoderFC input gradient (+ K-projection share on the x_ctx columns)
-  for (int i = tid; i < d.Nc * LDC; i += NWV * 64) {
+  for (int i = first ? tid : d.Nc * LDC; i < d.Nc * LDC; i += NWV * 64) {
     const int r = i / LDC, c = i - r * LDC;
     a.d_cat_in[(rc + r) * LDC + c] = s_dcat[r * A_LCAT + c] + (c < DW ? s_dxc[r * A_LX + c] : 0.f);
   }
-  wgrad16<H0, LDC>(s_dh0, A_LH, s_cat, A_LCAT, sl + a.sl.er_w[0], sl + a.sl.er_b[0], wave, lane, tid);
+  wgrad16<H0, LDC, GR>(s_dh0, A_LH, s_cat, A_LCAT, sl + a.sl.er_w[0], first ? sl + a.sl.er_b[0] : nullptr, gwave, lane, tid);
   // transform_y: dW = d_cat[:, dw:]^T ctx_y, db
-  wgrad16<DW / 4, 4>(s_dcat + DW, A_LCAT, s_y, A_LY, sl + a.sl.ty_w, sl + a.sl.ty_b, wave, lane, tid, DW / 4, d.label_dim);
+  if (first) wgrad16<DW / 4, 4>(s_dcat + DW, A_LCAT, s_y, A_LY, sl + a.sl.ty_w, sl + a.sl.ty_b, wave, lane, tid, DW / 4, d.label_dim);
   MLHOT_TSTAMP(166);
 #ifdef MLHOT_TS
   if (g_ts_dev && threadIdx.x == 0 && blockIdx.x < 16) g_ts_dev[220 + blockIdx.x] = wall_clock64();
