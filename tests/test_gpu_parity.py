@@ -441,18 +441,18 @@ def _run_case(gpulib, name):
     return flips
 
 
-@pytest.fixture(params=[(1, 3839), (1, 63), (1, 0), (0, 0)], ids=["tail_spec", "tail_spec_round4_form", "tail_fused", "tail_generic"])
+@pytest.fixture(params=[(1, 7935), (1, 63), (1, 0), (0, 0)], ids=["tail_spec", "tail_spec_round4_form", "tail_fused", "tail_generic"])
 def tail_impl(gpulib, request):
     """The three flavours of everything between the encoder and the loss: the fused per-task / per-head tail kernels specialised
     for the shipped dimensions (csrc/tail_spec.h: dim_w = dim_z = 64, hidden 100; the default where it applies), the same
     phases with run-time shapes (csrc/tail_fused.h; ANP with <= 16 shots) and the generic operator chain.  `round4_form`: the six
-    specialised kernels without round 5's additions (bits 64 / 128 / 512 / 1024 / 2048 of the option: the encoder Linear's fold inside phase A,
-    the loss's gradient inside phase C', phases B' / C' / A' as two workgroups per (task, head) / task)."""
+    specialised kernels without round 5's additions (bits 64 .. 4096 of the option: the encoder Linear's fold inside phase A,
+    the loss's gradient inside phase C', phases B' / C' / A' as two / four / four workgroups per (task, head) / task)."""
     gpulib.set_option("tail_fused", request.param[0])
     gpulib.set_option("tail_spec", request.param[1])
     yield request.param
     gpulib.set_option("tail_fused", 1)
-    gpulib.set_option("tail_spec", 3839)
+    gpulib.set_option("tail_spec", 7935)
 
 
 @pytest.mark.parametrize("name", U.model_case_names("s_"))

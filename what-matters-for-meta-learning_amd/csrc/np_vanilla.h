@@ -303,8 +303,9 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   const int spec = ts::applies(td) ? g_opt.tail_spec : 0;
   if (loss.kind >= 0 && !(spec & 8)) { set_error("tail_fused: a loss descriptor reached a phase C' that cannot take it"); return MLHOT_ERR_ARG; }
   if (st.first()) {
-    if ((spec & 8) && (spec & 1024)) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<true>, 2 * d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
-    else if (spec & 8) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<false>, d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
+    if ((spec & 8) && (spec & 1024) && (spec & 4096)) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<4>, 4 * d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
+    else if ((spec & 8) && (spec & 1024)) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<2>, 2 * d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
+    else if (spec & 8) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<1>, d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
     else MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
   }
   // sc.dqh / dkh / dvh double as the heads' input-gradient shares [T*H][N][dw] (same sizes)
@@ -320,8 +321,9 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   if (st.stage == 1) MLHOT_TRY(sx::sum_apply(part_k, d.T * MLHOT_HEADS, st.x, part_k, 1, s));
   tf::PhaseABwdArgs a{td, tp, sl, ctx_y, b.cat_in, b.h[0], b.h[1], sc.dqh, sc.dkh, sc.dvh, w.pc, part_k, w.gpos,
                       sc.d_dec_in, sc.d_cat_in, sc.tail_slab};
-  if ((spec & 32) && (spec & 2048)) MLHOT_TRY(tail_launch(ts::phaseA_bwd_kernel<true>, 2 * d.T, 512, ts::phaseA_bwd_lds_bytes(), a, s, "tail.bwd.A"));
-  else if (spec & 32) MLHOT_TRY(tail_launch(ts::phaseA_bwd_kernel<false>, d.T, 512, ts::phaseA_bwd_lds_bytes(), a, s, "tail.bwd.A"));
+  if ((spec & 32) && (spec & 2048) && (spec & 4096)) MLHOT_TRY(tail_launch(ts::phaseA_bwd_kernel<4>, 4 * d.T, 512, ts::phaseA_bwd_lds_bytes(), a, s, "tail.bwd.A"));
+  else if ((spec & 32) && (spec & 2048)) MLHOT_TRY(tail_launch(ts::phaseA_bwd_kernel<2>, 2 * d.T, 512, ts::phaseA_bwd_lds_bytes(), a, s, "tail.bwd.A"));
+  else if (spec & 32) MLHOT_TRY(tail_launch(ts::phaseA_bwd_kernel<1>, d.T, 512, ts::phaseA_bwd_lds_bytes(), a, s, "tail.bwd.A"));
   else MLHOT_TRY(tail_launch(tf::phaseA_bwd_kernel, d.T, 512, tf::phaseA_bwd_lds_bytes(td), a, s, "tail.bwd.A"));
   // per-task slabs -> parameter gradients
   tf::SlabReduce r{};

@@ -858,16 +858,16 @@ constexpr int CB_LY = 20;
 constexpr int CB_FLOATS = 16 * (CB_LY + 4 * C_LH + 2 * C_LD + 2 * C_LR) + NWV * 256;
 __host__ inline size_t phaseC_bwd_lds_bytes() { return sizeof(float) * CB_FLOATS; }
 
-// SPLIT (round 5): TWO workgroups per task.  The data-gradient chain is short and serial - both walk it - but the weight gradients
-// riding in its barrier intervals (7 + 49 + 56 + 16 tiles of 4 MFMAs and their scattered stores) are dealt over the 16 waves of the
-// pair; workgroup 0 of a pair alone writes d_dec_in, d_rr and the bias sums.
-template <bool SPLIT>
+// GR > 1 (round 5): GR workgroups per task.  The data-gradient chain is short and serial - all of them walk it - but the weight
+// gradients riding in its barrier intervals (7 + 49 + 56 + 16 tiles of 4 MFMAs and their scattered stores) are dealt over the group's
+// 8 GR waves; workgroup 0 of a group alone writes d_dec_in, d_rr and the bias sums.  Measured (one box): 1 -> 2 -> 4 workgroups:
+// 14.9 -> 13.1 -> 12.6 us.
+template <int GR>
 __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
-  const int t = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x, grp = SPLIT ? (int)blockIdx.x & 1 : 0;
-  constexpr int GR = SPLIT ? 2 : 1;
+  const int t = (int)blockIdx.x / GR, grp = (int)blockIdx.x % GR;          // GR workgroups per task
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), gwave = grp * NWV + wave;
   const bool first = grp == 0;
   lptr s_g = L0;                   // [16][CB_LY]   dmu * act'(mu)
@@ -954,16 +954,15 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
 constexpr int AB_FLOATS = 16 * (2 * A_LCAT + 4 * A_LH + 2 * A_LX + A_LY) + NWV * 256 + 64 + 16;
 __host__ inline size_t phaseA_bwd_lds_bytes() { return sizeof(float) * AB_FLOATS; }
 
-// SPLIT (round 5): two workgroups per task, as phase C': both sum the heads' shares and walk EncoderFC's data gradients, the weight
-// gradients' 28 + 49 + 35 tiles are dealt over the pair; workgroup 0 alone applies the arg-max fix-up (a read-modify-write of slab
-// entries), adds into d_dec_in and writes d_cat_in.
-template <bool SPLIT>
+// GR > 1 (round 5): GR workgroups per task, as phase C': all sum the heads' shares and walk EncoderFC's data gradients, the weight
+// gradients' 28 + 49 + 35 tiles are dealt over the group; workgroup 0 alone applies the arg-max fix-up (a read-modify-write of slab
+// entries), adds into d_dec_in and writes d_cat_in.  1 -> 2 -> 4 workgroups: 18.2 -> 15.9 -> 15.2 us.
+template <int GR>
 __global__ __launch_bounds__(512) void phaseA_bwd_kernel(const PhaseABwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
-  const int t = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x, grp = SPLIT ? (int)blockIdx.x & 1 : 0;
-  constexpr int GR = SPLIT ? 2 : 1;
+  const int t = (int)blockIdx.x / GR, grp = (int)blockIdx.x % GR;          // GR workgroups per task
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), gwave = grp * NWV + wave;
   const bool first = grp == 0;
   lptr s_cat = L0;                  // saved activations
