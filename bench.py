@@ -81,6 +81,7 @@ def alg_flops(label, n_img):
         "enc.conv3": 2.0 * n_img * 64 * 64 * 432,
         "enc.bwd.conv3.wgrad": 2.0 * n_img * 64 * 64 * 432,
         "enc.bwd.conv3.dgrad": 2.0 * n_img * 64 * 48 * 64 * 9,          # all 4 parity classes in one launch
+        "enc.bwd.conv3": 2.0 * n_img * 64 * 64 * 432 + 2.0 * n_img * 64 * 48 * 64 * 9,      # weight + data gradient in one launch (csrc/conv3_tc.h conv3_bwd_kernel)
         "enc.conv1": 2.0 * n_img * 4096 * 32 * 9,
         "enc.bwd.conv1.wgrad": 2.0 * n_img * 4096 * 32 * 9,
         "enc.linear": 2.0 * n_img * 4096 * 64,

@@ -65,6 +65,7 @@ atexit.register(_manifest)
 KERNEL_LABEL = {            # kernel-name fragment -> bench.py label
     "conv12_fwd_pool_kernel": "enc.conv12", "conv12_wgrad_kernel": "enc.bwd.conv12.wgrad", "conv12_dgrad_kernel": "enc.bwd.conv12.dgrad",
     "conv3_fwd_kernel": "enc.conv3", "conv3_wgrad_kernel": "enc.bwd.conv3.wgrad", "conv3_dgrad_kernel": "enc.bwd.conv3.dgrad",
+    "conv3_bwd_kernel": "enc.bwd.conv3",
 }
 
 

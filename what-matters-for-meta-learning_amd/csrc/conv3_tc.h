@@ -244,9 +244,10 @@ constexpr int W_RS = 24, W_PS = 17 * W_RS + 1, W_PATCH = CIN * W_PS, W_DS = 66, 
 constexpr int W_NT = 768;
 constexpr int W_LDS = (W_PATCH + W_DYT) > 6 * 18 * 256 ? (W_PATCH + W_DYT) : 6 * 18 * 256;
 
-__global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restrict__ p2, const float* __restrict__ dy3,
-                                                           float* __restrict__ slab_w, float* __restrict__ slab_b, int n_img) {
-  __shared__ float lds[W_LDS];
+// wg / nwg: this workgroup's index among the nwg that share the images (the kernel below: blockIdx / gridDim; the merged backward
+// launch: its weight-gradient half)
+__device__ __forceinline__ void conv3_wgrad_body(const float* __restrict__ p2, const float* __restrict__ dy3,
+                                                 float* __restrict__ slab_w, float* __restrict__ slab_b, int n_img, float* lds, int wg, int nwg) {
   float* patch = lds;
   float* dyt = lds + W_PATCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -274,11 +275,11 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
       if (e < 1024) sd[j] = *reinterpret_cast<const float4*>(dy3 + (size_t)img * 4096 + 4 * e);
     }
   };
-  int img = blockIdx.x;
+  int img = wg;
   if (img < n_img) fetch(img);
   const int aoff = lr * W_PS + (2 * (4 * ph + lq) + tg) * W_RS;
   const int boff = (8 * (4 * ph + lq)) * W_DS + 32 * np + lr;
-  for (; img < n_img; img += gridDim.x) {
+  for (; img < n_img; img += nwg) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                 // image: float4 e -> ci = e / 64, iy = (e / 4) % 16, ix = 4 (e % 4)
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
       }
     }
     __syncthreads();
-    if (img + (int)gridDim.x < n_img) fetch(img + gridDim.x);
+    if (img + nwg < n_img) fetch(img + nwg);
     // (double-buffering the 11 operands of a k-step across k-steps measured equal here: 35.7 vs 35.4 us)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
   }
   __syncthreads();
   if (ph == 0) {
-    float* sw = slab_w + (size_t)blockIdx.x * (COUT * KW + COUT);      // slab row = [weights | bias]
+    float* sw = slab_w + (size_t)wg * (COUT * KW + COUT);      // slab row = [weights | bias]
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -354,8 +355,14 @@ __global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     const int e = tid + j * W_NT;
-    if ((lane & 15) == 0 && e < 1024) slab_b[(size_t)blockIdx.x * (COUT * KW + COUT) + (e >> 4)] = v;
+    if ((lane & 15) == 0 && e < 1024) slab_b[(size_t)wg * (COUT * KW + COUT) + (e >> 4)] = v;
   }
+}
+
+__global__ __launch_bounds__(W_NT) void conv3_wgrad_kernel(const float* __restrict__ p2, const float* __restrict__ dy3,
+                                                           float* __restrict__ slab_w, float* __restrict__ slab_b, int n_img) {
+  __shared__ float lds[W_LDS];
+  conv3_wgrad_body(p2, dy3, slab_w, slab_b, n_img, lds, blockIdx.x, gridDim.x);
 }
 
 // ---- data gradient ----------------------------------------------------------------------------------
@@ -372,7 +379,7 @@ constexpr int D_WLD = KW + 1;                       // weight staging rows [co][
 
 template <int PY, int PX>
 __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const float* __restrict__ dy3, float* __restrict__ dp2,
-                                            float* patch2, int n_img, int nt, int tid, int lane, float4 (&sd)[2]) {
+                                            float* patch2, int n_img, int nt, int tid, int lane, float4 (&sd)[2], int wg, int nwg) {
   constexpr int NTY = PY ? 2 : 1, NTX = PX ? 2 : 1, T = NTY * NTX;
   float* outt = patch2 + 2 * D_PATCH;
   const int lr = lane & 15, lq = lane >> 4;
@@ -404,18 +411,18 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
       if (e < 1024) *reinterpret_cast<float4*>(buf + (e >> 4) * D_PS + ((e >> 1) & 7) * D_RS + 4 * (e & 1)) = sd[j];
     }
   };
-  int img = blockIdx.x;
+  int img = wg;
   if (img < n_img) stash(patch2);                    // fetched by the kernel, under the weight staging
-  if (img + (int)gridDim.x < n_img) fetch(img + gridDim.x);
+  if (img + nwg < n_img) fetch(img + nwg);
   __syncthreads();
   const int aoff = lq * D_PS + (lr >> 3) * D_RS + (lr & 7);
   int cur = 0;
-  for (; img < n_img; img += gridDim.x, cur ^= 1) {
+  for (; img < n_img; img += nwg, cur ^= 1) {
     const float* ab = patch2 + cur * D_PATCH + aoff;
-    const int next = img + (int)gridDim.x;
+    const int next = img + nwg;
     if (next < n_img) {
       stash(patch2 + (cur ^ 1) * D_PATCH);
-      if (next + (int)gridDim.x < n_img) fetch(next + gridDim.x);
+      if (next + nwg < n_img) fetch(next + nwg);
     }
     // operand i of the image: M-tile mt = i / (16 T), tap t = (i / 16) % T, k-step ks = i % 16; a 4-deep register ring keeps the
     // reads ahead of their MFMAs (see conv3_fwd_kernel)
@@ -457,10 +464,10 @@ __device__ __forceinline__ void dgrad_class(const float* __restrict__ w, const f
   }
 }
 
-__global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dy3,
-                                                           float* __restrict__ dp2, int n_img) {
-  __shared__ float patch2[2 * D_PATCH + CIN * D_OS];
-  static_assert(2 * D_PATCH + CIN * D_OS >= COUT * D_WLD, "weight staging area");
+constexpr int D_LDS = 2 * D_PATCH + CIN * D_OS;
+static_assert(D_LDS >= COUT * D_WLD, "weight staging area");
+__device__ __forceinline__ void conv3_dgrad_body(const float* __restrict__ w, const float* __restrict__ dy3, float* __restrict__ dp2, int n_img,
+                                                 float* patch2, int wg, int nwg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // the [64][432] weight matrix through LDS with coalesced float4 loads (rows of 433 words); the waves' register slices are
   // stride-9 / stride-432 gathers of it - straight from global ~20 cache lines per load instruction, 16-64 of them per lane
@@ -469,7 +476,7 @@ __global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restri
   for (int j = 0; j < 2; ++j) {
     const int e = tid + j * D_NT;
     sd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < 1024 && (int)blockIdx.x < n_img) sd[j] = *reinterpret_cast<const float4*>(dy3 + (size_t)blockIdx.x * 4096 + 4 * e);
+    if (e < 1024 && wg < n_img) sd[j] = *reinterpret_cast<const float4*>(dy3 + (size_t)wg * 4096 + 4 * e);
   }
   // ((co, ci) items as in the forward - conflict-free stores instead of 4-way - made this kernel 1.2 us SLOWER: 36 dword loads per
   // thread whose lanes are 36 bytes apart cost the vector memory pipe more than the stores saved; it has no 108-read gather to win back)
@@ -478,10 +485,31 @@ __global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restri
   // per image a class costs 64 MFMAs per tap and tile: 256 / 128 / 128 / 64.  Waves w, w + 4, w + 8 share a SIMD:
   // SIMDs 0..2 get {256, 128, 64} (classes 11, 01, 00 of tile w), SIMD 3 gets the three 128s of class 10.
   const int s = wave & 3, g = wave >> 2;
-  if (s == 3) dgrad_class<1, 0>(w, dy3, dp2, patch2, n_img, g, tid, lane, sd);
-  else if (g == 0) dgrad_class<1, 1>(w, dy3, dp2, patch2, n_img, s, tid, lane, sd);
-  else if (g == 1) dgrad_class<0, 1>(w, dy3, dp2, patch2, n_img, s, tid, lane, sd);
-  else dgrad_class<0, 0>(w, dy3, dp2, patch2, n_img, s, tid, lane, sd);
+  if (s == 3) dgrad_class<1, 0>(w, dy3, dp2, patch2, n_img, g, tid, lane, sd, wg, nwg);
+  else if (g == 0) dgrad_class<1, 1>(w, dy3, dp2, patch2, n_img, s, tid, lane, sd, wg, nwg);
+  else if (g == 1) dgrad_class<0, 1>(w, dy3, dp2, patch2, n_img, s, tid, lane, sd, wg, nwg);
+  else dgrad_class<0, 0>(w, dy3, dp2, patch2, n_img, s, tid, lane, sd, wg, nwg);
+}
+
+__global__ __launch_bounds__(D_NT) void conv3_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dy3,
+                                                           float* __restrict__ dp2, int n_img) {
+  __shared__ float patch2[D_LDS];
+  conv3_dgrad_body(w, dy3, dp2, n_img, patch2, blockIdx.x, gridDim.x);
+}
+
+// ---- weight AND data gradient in ONE launch (round 5) ----------------------------------------------------------------------------
+// Both read the same dy3 and neither reads what the other writes.  As two launches of one persistent workgroup per CU each ran ~1.9
+// images per workgroup behind its own launch ramp and weight / LDS prologue: 23.7 + 22.6 us for 2 x 10.8 us of matrix pipe.  Here the
+// first `nw` workgroups run the weight gradient over ALL images and the others the data gradient: one ramp and one prologue per CU
+// for ~3.75 images, and the weight gradient leaves `nw` slab rows instead of 256 (half the bytes for the final fold).
+static_assert(W_NT == D_NT, "one block size");
+constexpr int B_LDS = W_LDS > D_LDS ? W_LDS : D_LDS;
+__global__ __launch_bounds__(W_NT) void conv3_bwd_kernel(const float* __restrict__ p2, const float* __restrict__ w, const float* __restrict__ dy3,
+                                                         float* __restrict__ slab_w, float* __restrict__ slab_b, float* __restrict__ dp2,
+                                                         int n_img, int nw) {
+  __shared__ float lds[B_LDS];
+  if ((int)blockIdx.x < nw) conv3_wgrad_body(p2, dy3, slab_w, slab_b, n_img, lds, blockIdx.x, nw);
+  else conv3_dgrad_body(w, dy3, dp2, n_img, lds, (int)blockIdx.x - nw, (int)gridDim.x - nw);
 }
 
 }  // namespace c3

@@ -23,7 +23,7 @@ namespace mlhot {
 
 // Run-time switches (mlhot_set_option): which implementation of a hot-path row runs.  The
 // generic igemm problems are always available as the A/B reference of the specialised kernels.
-struct Options { int conv2_tc; int tail_fused; int materialize_a1; int dbg; int tail_spec; int conv2_split; };
+struct Options { int conv2_tc; int tail_fused; int materialize_a1; int dbg; int tail_spec; int conv2_split; int conv3_bwd_merged; };
 extern Options g_opt;
 constexpr int C2_GRID = 256;   // one persistent workgroup per CU
 
@@ -294,6 +294,18 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
     constexpr int L3 = 64 * 432, R3 = L3 + 64;
     float* slab_w = sc.slab;                       // conv3's slab region: alive until the deferred reduce
     float* slab_b = sc.slab + L3;
+    if (g_opt.conv3_bwd_merged && grid == C2_GRID) {
+      // weight and data gradient in ONE launch: the first nw workgroups the weight gradient, the rest the data gradient (conv3_tc.h)
+      const int nw = g_opt.conv3_bwd_merged > 1 && g_opt.conv3_bwd_merged < C2_GRID ? g_opt.conv3_bwd_merged : C2_GRID / 2;
+      {
+        ProfScope ps("enc.bwd.conv3", s);
+        hipLaunchKernelGGL(c3::conv3_bwd_kernel, dim3(C2_GRID), dim3(c3::W_NT), 0, s, sv.p2, p.w3, sc.dy3, slab_w, slab_b, sc.dp2, n, nw);
+      }
+      MLHOT_TRY(check_launch("enc.bwd.conv3"));
+      pend(slab_w, g.w3, nw, L3, R3, 2);
+      pend(slab_b, g.b3, nw, 64, R3);
+      MLHOT_TRY(fold_aside());
+    } else {
     {
       ProfScope ps("enc.bwd.conv3.wgrad", s);
       hipLaunchKernelGGL(c3::conv3_wgrad_kernel, dim3(grid), dim3(c3::W_NT), 0, s, sv.p2, sc.dy3, slab_w, slab_b, n);
@@ -308,6 +320,7 @@ inline int enc_backward(const float* img0, int n0, const float* img1, int n1, co
       hipLaunchKernelGGL(c3::conv3_dgrad_kernel, dim3(grid), dim3(c3::D_NT), 0, s, p.w3, sc.dy3, sc.dp2, n);
     }
     MLHOT_TRY(check_launch("enc.bwd.conv3.dgrad"));
+    }
   } else
 #endif
   {

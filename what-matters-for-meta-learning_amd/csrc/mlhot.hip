@@ -30,7 +30,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-Options g_opt = {1, 1, 0, 0, 7935, 0};
+Options g_opt = {1, 1, 0, 0, 7935, 0, 1};
 int g_favor2 = 1;
 #ifndef MLHOT_HOSTSIM
 namespace rt { int g_trunk_fuse34 = 1, g_trunk_dual_dgrad = 1; }
@@ -89,6 +89,7 @@ int mlhot_set_option(const char* name, int value) {
   if (!strcmp(name, "conv2_split")) { g_opt.conv2_split = value; return MLHOT_OK; }
   if (!strcmp(name, "tail_fused")) { g_opt.tail_fused = value; return MLHOT_OK; }
   if (!strcmp(name, "tail_spec")) { g_opt.tail_spec = value; return MLHOT_OK; }     // fused tail: bit mask of the phases that run the kernels specialised for the shipped dimensions (csrc/tail_spec.h; bits 1..32 = the six phases, 64 = phase A also folds the encoder Linear's split-K partial results, 128 = phase C' takes the loss's gradient itself when handed a loss descriptor, 512 = phase B' as two workgroups per (task, head): query side | key / value side, 1024 / 2048 = phases C' / A' as several workgroups per task sharing the weight-gradient tiles (two; four with 4096); default 7935 = all) instead of the run-time-shaped ones
+  if (!strcmp(name, "conv3_bwd_merged")) { g_opt.conv3_bwd_merged = value; return MLHOT_OK; }     // 0: two launches; 1: one launch, 128 + 128 workgroups; n > 1: n weight-gradient workgroups of 256
   if (!strcmp(name, "materialize_a1")) { g_opt.materialize_a1 = value; return MLHOT_OK; }
   if (!strcmp(name, "dbg")) { g_opt.dbg = value; return MLHOT_OK; }   // timing experiments only (results become wrong)
   if (!strcmp(name, "favor2")) { g_favor2 = value; return MLHOT_OK; }
