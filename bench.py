@@ -1076,7 +1076,8 @@ def _library_id():
     path = os.environ.get("MLHOT_LIB") or mlhot.PRODUCT_SO
     try:
         with open(path, "rb") as f:
-            return {"path": os.path.relpath(path, ROOT), "sha256": hashlib.sha256(f.read()).hexdigest()}
+            from mlhot.build import source_sha256
+            return {"path": os.path.relpath(path, ROOT), "sha256": hashlib.sha256(f.read()).hexdigest(), "src_sha256": source_sha256()}
     except OSError:
         return {"path": path, "sha256": None}
 

@@ -2,8 +2,9 @@
 # Run on the GPU box (gpurun): bench lines, rocprofv3 kernel stats and HBM-traffic counters of the headline
 # workload.  Everything lands under gpurun_out/prof/; scripts/summarise_profiles.py turns it into profiles/*.
 # PMC passes are separate runs with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one pass).
-# EVERY <tag>_* summary comes out of THIS run: the raw directory is emptied first, the library's sha256 and the start time go into
-# $OUT/MANIFEST.json, and scripts/summarise_profiles.py refuses raw files older than that or a library other than that
+# EVERY <tag>_* summary comes out of THIS run: the raw directory is emptied first, the hash of the library's SOURCES (the box may
+# rebuild the .so: file times do not survive the copy, and hipcc's output differs from box to box), the .so's own sha256 and the start
+# time go into $OUT/MANIFEST.json, and scripts/summarise_profiles.py refuses raw files older than that or sources other than the tree's
 # (round 4 committed a "final" set that mixed two library states).
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
@@ -13,9 +14,13 @@ rm -rf $OUT
 mkdir -p $OUT
 cd $REPO
 LIB=$REPO/what-matters-for-meta-learning_amd/csrc/libmlhot.so
-python3 - "$LIB" "$OUT/MANIFEST.json" "$TAG" <<'PY'
+python3 -c "import sys; sys.path.insert(0, '$REPO/what-matters-for-meta-learning_amd'); import mlhot; mlhot.build_product()"   # the box rebuilds when the copy's file times say so: do it BEFORE hashing
+python3 - "$LIB" "$OUT/MANIFEST.json" "$TAG" "$REPO" <<'PY'
 import hashlib, json, sys, time
-json.dump({"tag": sys.argv[3], "lib_sha256": hashlib.sha256(open(sys.argv[1], "rb").read()).hexdigest(), "started_at": time.time()}, open(sys.argv[2], "w"))
+sys.path.insert(0, sys.argv[4] + "/what-matters-for-meta-learning_amd")
+from mlhot.build import source_sha256
+json.dump({"tag": sys.argv[3], "src_sha256": source_sha256(), "lib_sha256": hashlib.sha256(open(sys.argv[1], "rb").read()).hexdigest(),
+           "started_at": time.time()}, open(sys.argv[2], "w"))
 PY
 python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench_c3.json 2> $OUT/bench_c3.err
 python bench.py --steps 50 --warmup 10 --workload c2 --no-cpu-baseline > $OUT/${TAG}_bench_c2.json 2> $OUT/bench_c2.err

@@ -22,13 +22,14 @@ try:
     MAN = json.load(open(os.path.join(SRC, "MANIFEST.json")))
 except OSError:
     sys.exit("summarise_profiles: gpurun_out/prof/MANIFEST.json is missing - collect with scripts/collect_profiles.sh (it records the library's sha256)")
-lib = os.path.join(ROOT, "what-matters-for-meta-learning_amd", "csrc", "libmlhot.so")
-local_sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+sys.path.insert(0, os.path.join(ROOT, "what-matters-for-meta-learning_amd"))
+from mlhot.build import source_sha256
+local_sha = source_sha256()
 if MAN.get("tag") != tag:
     sys.exit(f"summarise_profiles: the raw directory was collected as {MAN.get('tag')!r}, not {tag!r}")
-if local_sha != MAN["lib_sha256"] and not force:
-    sys.exit(f"summarise_profiles: the profiles were collected with library {MAN['lib_sha256'][:12]}, the tree now builds {str(local_sha)[:12]}: "
-             "re-collect (or --force to summarise the older library's numbers, which the manifest will say)")
+if local_sha != MAN.get("src_sha256") and not force:
+    sys.exit(f"summarise_profiles: the profiles were collected from library sources {str(MAN.get('src_sha256'))[:12]}, the tree now holds {local_sha[:12]}: "
+             "re-collect (or --force to summarise the older sources' numbers, which the manifest will say)")
 # gpurun MERGES the box's gpurun_out/ into the local one, so leftovers of earlier collections sit beside this one's files: anything
 # older than this collection's start is not part of it and is never read below (fresh() / find())
 def fresh(path):
@@ -52,11 +53,12 @@ import atexit
 
 
 def _manifest():
-    json.dump({"tag": tag, "lib_sha256": MAN["lib_sha256"], "lib_matches_tree": local_sha == MAN["lib_sha256"],
+    json.dump({"tag": tag, "src_sha256": MAN.get("src_sha256"), "lib_sha256": MAN["lib_sha256"], "sources_match_tree": local_sha == MAN.get("src_sha256"),
                "collected_at": time.strftime("%Y-%m-%d %H:%M:%S", time.gmtime(MAN["started_at"])) + " UTC",
                "files": sorted(set(WRITTEN + [n for n in os.listdir(DST) if n.startswith(tag + "_") and n.endswith((".json", ".txt", ".csv"))
                                                and os.path.getmtime(os.path.join(DST, n)) >= MAN["started_at"]])),
-               "note": "every file listed was produced by ONE run of scripts/collect_profiles.sh with the library above"},
+               "note": "every file listed was produced by ONE run of scripts/collect_profiles.sh with the library built from the sources above "
+                       "(src_sha256: csrc/*.hip, csrc/*.h, include/mlhot.h; lib_sha256: the .so that ran - the GPU box may rebuild it from the same sources)"},
               open(os.path.join(DST, f"{tag}_MANIFEST.json"), "w"), indent=1)
 
 
@@ -111,7 +113,7 @@ def pmc(dirname, counter):
 
 
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
-out = {"_workload": "c3", "_lib_sha256": MAN["lib_sha256"], "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-graph`, c3 workload, "
+out = {"_workload": "c3", "_src_sha256": MAN.get("src_sha256"), "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-graph`, c3 workload, "
                 "480 images. Counter unit KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); "
                 "WRITE_SIZE as read. Bytes per launch (mean over the launches of the run)."}
 for label in sorted(set(fetch) | set(write)):
@@ -132,7 +134,7 @@ sq = {c: pmc("pmc_sq", c) for c in SQ}
 labels = sorted(set().union(*[set(v) for v in sq.values()]))
 if labels:
     N_SIMD, N_XCD = 256 * 4, 8
-    res = {"_lib_sha256": MAN["lib_sha256"], "_note": "rocprofv3 --pmc (one pass, 7 SQ + 1 GRBM counter) of `bench.py --steps 3 --warmup 1 --no-graph`, c3 workload; per-launch means. "
+    res = {"_src_sha256": MAN.get("src_sha256"), "_note": "rocprofv3 --pmc (one pass, 7 SQ + 1 GRBM counter) of `bench.py --steps 3 --warmup 1 --no-graph`, c3 workload; per-launch means. "
                     "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): SQ_VALU_MFMA_BUSY_CYCLES is summed over "
                     "all SIMDs in shader cycles (it equals 32 x the kernel's v_mfma_f32_16x16x4_f32 count: 238.9 M for enc.conv12 = 7.47 M MFMAs), "
                     "GRBM_GUI_ACTIVE is summed over the 8 XCDs (1/8 of it x 1/2.4 GHz is the kernel's duration). wave-cycle split: WAIT_ANY (parked: s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + "

@@ -15,6 +15,19 @@ def _headers():
     return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "mlhot.h")]
 
 
+def source_sha256():
+    """One hash over the library's sources (csrc/*.hip, csrc/*.h, include/mlhot.h; names + contents): what identifies a build across
+    machines - the GPU box may rebuild the .so from the same sources (file times do not survive the copy), and hipcc's output is not
+    bit-identical from box to box."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(_deps()):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True
