@@ -33,7 +33,7 @@ void set_error(const char* fmt, ...) {
 Options g_opt = {1, 1, 0, 0, 7935, 0, 1};
 int g_favor2 = 1;
 #ifndef MLHOT_HOSTSIM
-namespace rt { int g_trunk_fuse34 = 1, g_trunk_dual_dgrad = 1; }
+namespace rt { int g_trunk_fuse34 = 1, g_trunk_dual_dgrad = 1, g_trunk_wg_rows = 128; }
 #endif
 
 
@@ -95,6 +95,7 @@ int mlhot_set_option(const char* name, int value) {
   if (!strcmp(name, "favor2")) { g_favor2 = value; return MLHOT_OK; }
 #ifndef MLHOT_HOSTSIM
   if (!strcmp(name, "trunk_dual_dgrad")) { rt::g_trunk_dual_dgrad = value; return MLHOT_OK; }   // 1 (default): a 3x3-skip block's two stride-2 data gradients in one 512-thread launch (resnet_ws.h dgrad2_dual_kernel)
+  if (!strcmp(name, "trunk_wg_rows")) { if (value < 16 || value > 128) { set_error("trunk_wg_rows: 16 .. 128"); return MLHOT_ERR_ARG; } rt::g_trunk_wg_rows = value; return MLHOT_OK; }   // slab rows (x 4 channel tiles = workgroups) a trunk weight-gradient launch is planned against
   if (!strcmp(name, "trunk_fuse34")) { rt::g_trunk_fuse34 = value; return MLHOT_OK; }   // 1 (default): blocks 3-4 of a 64 x 64 trunk as one launch per direction (resnet_ws.h tail34_*)
   if (!strcmp(name, "side_fold")) { g_side_fold = value; return MLHOT_OK; }   // 1 (default 0): slab folds of the encoder backward on the library's helper stream (common.h SideLane)
 #endif  // FAVOR+: the two-launch kernels (csrc/favor2.h, default) or favor.h's chain

@@ -67,7 +67,8 @@ inline int conv_stride(int conv) { return (conv - 1) % 3 == 1 ? 1 : 2; }
 // slab-row target of a 3x3 / 1x1 weight-gradient job: every row is 147 KB written by the kernel and read again by the fold.  The
 // 4 x 4 / 2 x 2 output maps get 64 rows (256 workgroups): measured 128 / 64 / 32 rows at c5's shape - weight gradient of block 3's
 // conv1 19.2 / 17.9 / 22.9 us, conv2 13.0 / 13.0 / 15.4, fold 34.3 / 33.9 / 32.9
-inline int wg_target(const Levels& lv, int conv) { return conv_hin(lv, conv) / conv_stride(conv) <= 4 ? 64 : 128; }
+extern int g_trunk_wg_rows;      // slab rows per weight-gradient launch of the larger maps (option "trunk_wg_rows", default 128)
+inline int wg_target(const Levels& lv, int conv) { return conv_hin(lv, conv) / conv_stride(conv) <= 4 ? 64 : g_trunk_wg_rows; }
 
 // the band total a job's slab rows are planned against: the 1x1 skips of a step share a launch of their own (skip1_wgrad_kernel),
 // so they split ITS workgroups among themselves, not those of a launch that also serves the other passes
