@@ -14,6 +14,7 @@
 #include "tail_fused.h"
 #include "tail_spec.h"
 #include "tail_cnp.h"
+#include "cnp_spec.h"
 #include "linear_skinny.h"
 #include "favor2.h"
 
@@ -239,9 +240,32 @@ inline tf::CnpParams cnp_params(const mlhot_np_params& p) {
   for (int i = 0; i < 3; ++i) { q.er_w[i] = p.er_w[i]; q.er_b[i] = p.er_b[i]; q.dec_w[i] = p.dec_w[i]; q.dec_b[i] = p.dec_b[i]; }
   return q;
 }
-inline int cnp_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, float* mu, const NpBuf& b, hipStream_t s) {
+// the kernels specialised for the shipped CNP dimensions (csrc/cnp_spec.h) where they apply; option tail_spec bits as for the
+// attention tail: 1 forward, 8 backward, 64 the forward folds the encoder Linear's partial results, 128 the backward takes the loss's
+// gradient from a descriptor, 1024 / 4096 two / four workgroups per task in the backward
+inline bool cnp_spec_applies(const mlhot_np_dims& d) { return cnp_fused_applies(d) && ts::cnp_applies(cnp_dims(d)); }
+inline bool cnp_spec_folds(const mlhot_np_dims& d) {
+  return cnp_spec_applies(d) && (g_opt.tail_spec & 1) && (g_opt.tail_spec & 64) && g_opt.conv2_tc && d.dim_w == el::DW;
+}
+template <class K, class... A>
+inline int cnp_spec_launch(K kernel, int grid, size_t lds, hipStream_t s, const char* what, const A&... args) {
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    set_error("%s: %zu bytes of LDS refused", what, lds);
+    return MLHOT_ERR_LAUNCH;
+  }
+  {
+    ProfScope ps(what, s);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, s, args...);
+  }
+  return check_launch(what);
+}
+inline int cnp_forward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, float* mu, const NpBuf& b, hipStream_t s,
+                             const EncXFold& xf = EncXFold{nullptr, nullptr, 0, 0}) {
   const tf::CnpDims cd = cnp_dims(d);
   tf::CnpFwdArgs a{cd, cnp_params(p), ctx_y, b.cat_in, b.h[0], b.h[1], b.rs, b.r, b.zt, b.dec_in, b.d1, b.d2, mu, b.amax};
+  if (ts::cnp_applies(cd) && (g_opt.tail_spec & 1))
+    return cnp_spec_launch(ts::cnp_fwd_kernel, d.T, ts::cnp_fwd_lds_bytes(), s, "tail.cnp", a, ts::CnpXFold{xf.slab, xf.bias, xf.k, xf.n});
+  if (xf.slab != nullptr) { set_error("cnp_fused: the encoder left its fold to a tail kernel that cannot do it"); return MLHOT_ERR_ARG; }
   return tail_launch(tf::cnp_fwd_kernel, d.T, 512, tf::cnp_fwd_lds_bytes(cd), a, s, "tail.cnp");
 }
 // Per-task slabs -> parameter gradients.  When the caller laid the gradient tensors out as ONE flat buffer in slab
@@ -265,13 +289,22 @@ inline int tail_slab_reduce(tf::SlabReduce& r, hipStream_t s, PendingSum* later 
 }
 
 inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu, const float* dmu,
-                              const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s, PendingSum* later) {
+                              const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s, PendingSum* later,
+                              const LossDesc& loss = LossDesc{-1, nullptr, 0, nullptr}) {
   const tf::CnpDims cd = cnp_dims(d);
   const tf::CnpSlab sl = tf::cnp_slab_layout(cd);
   if (!sc.tail_slab) { set_error("cnp_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
   tf::CnpBwdArgs a{cd, cnp_params(p), sl, ctx_y, dmu, mu, b.d2, b.d1, b.dec_in, b.r, b.rs, b.h[1], b.h[0], b.cat_in, b.amax,
                    sc.d_dec_in, sc.d_cat_in, sc.tail_slab};
-  MLHOT_TRY(tail_launch(tf::cnp_bwd_kernel, d.T, 512, tf::cnp_bwd_lds_bytes(cd), a, s, "tail.bwd.cnp"));
+  if (ts::cnp_applies(cd) && (g_opt.tail_spec & 8)) {
+    const int gr = (g_opt.tail_spec & 1024) ? ((g_opt.tail_spec & 4096) ? 4 : 2) : 1;
+    if (gr == 4) MLHOT_TRY(cnp_spec_launch(ts::cnp_bwd_kernel<4>, 4 * d.T, ts::cnp_bwd_lds_bytes(), s, "tail.bwd.cnp", a, loss));
+    else if (gr == 2) MLHOT_TRY(cnp_spec_launch(ts::cnp_bwd_kernel<2>, 2 * d.T, ts::cnp_bwd_lds_bytes(), s, "tail.bwd.cnp", a, loss));
+    else MLHOT_TRY(cnp_spec_launch(ts::cnp_bwd_kernel<1>, d.T, ts::cnp_bwd_lds_bytes(), s, "tail.bwd.cnp", a, loss));
+  } else {
+    if (loss.kind >= 0) { set_error("cnp_fused: a loss descriptor reached a backward kernel that cannot take it"); return MLHOT_ERR_ARG; }
+    MLHOT_TRY(tail_launch(tf::cnp_bwd_kernel, d.T, 512, tf::cnp_bwd_lds_bytes(cd), a, s, "tail.bwd.cnp"));
+  }
   tf::SlabReduce r{};
   int ns = 0, maxlen = 0;
   auto seg = [&](float* dst, int off, int len) { r.dst[ns] = dst; r.off[ns] = off; r.len[ns] = len; if (len > maxlen) maxlen = len; ++ns; };
@@ -430,14 +463,13 @@ inline int np_forward(const mlhot_np_dims& d, const mlhot_np_params& p, const fl
   }
 #ifndef MLHOT_HOSTSIM
   EncXFold xf{nullptr, nullptr, 0, 0};
+  const bool cnp_folds = !fused && cnp_spec_folds(d);
   if (st.first()) MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s,
-                                        fused && tail_phaseA_folds(d) ? &xf : nullptr));
+                                        (fused && tail_phaseA_folds(d)) || cnp_folds ? &xf : nullptr));
   if (fused) return tail_forward_fused(d, p, ctx_y, mu, b, sc, s, st, xf);
+  if (cnp_fused_applies(d)) return cnp_forward_fused(d, p, ctx_y, mu, b, s, xf);
 #else
   if (st.first()) MLHOT_TRY(enc_forward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{b.cat_in, ldc, Rc, b.dec_in, ldd}, b.enc, sc.enc, sc.enc_bytes, s));
-#endif
-#ifndef MLHOT_HOSTSIM
-  if (cnp_fused_applies(d)) return cnp_forward_fused(d, p, ctx_y, mu, b, s);
 #endif
 
   if (d.Nc > 0) {
@@ -498,6 +530,7 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
     if (st.staged()) { set_error("np_vanilla_bwd: the staged pass takes dmu, not a loss descriptor"); return MLHOT_ERR_UNSUPPORTED; }
 #ifndef MLHOT_HOSTSIM
     if (tail_fused_applies(d) && ts::applies(tail_dims(d)) && (g_opt.tail_spec & 8) && (g_opt.tail_spec & 128)) in_kernel = *loss;
+    if (!tail_fused_applies(d) && cnp_spec_applies(d) && (g_opt.tail_spec & 8) && (g_opt.tail_spec & 128)) in_kernel = *loss;
 #endif
     if (in_kernel.kind < 0) {
       MLHOT_TRY(run_foreach(LossBwd{loss->kind, d.y_dim, loss->gt_dim, Rq, mu, loss->gt, loss->dloss, sc.dmu_tmp, dmu}, (size_t)Rq, s, "loss_bwd"));
@@ -512,7 +545,7 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
   if (tail_fused_applies(d) || cnp_fused_applies(d)) {
     PendingSum tail_sum{};       // the tail's per-task slabs: summed by the encoder backward's final reduce launch when contiguous
     if (tail_fused_applies(d)) MLHOT_TRY(tail_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum, st, in_kernel));
-    else MLHOT_TRY(cnp_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum));
+    else MLHOT_TRY(cnp_backward_fused(d, p, ctx_y, mu, dmu, g, b, sc, s, &tail_sum, in_kernel));
     if (st.stage == 0) return MLHOT_OK;
     return enc_backward(ctx_x, Rc, qry_x, Rq, p.enc, dw, Rows2{sc.d_cat_in, ldc, Rc, sc.d_dec_in, ldd}, b.enc, g.enc, sc.enc, sc.enc_bytes, s,
                         &tail_sum);
