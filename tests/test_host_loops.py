@@ -202,3 +202,29 @@ def test_mt19937_jump_ahead_polynomials_against_brute_force():
     a = blocks[S * 2].copy()
     a[0] ^= np.uint32(0x7fffffff)
     assert np.array_equal(MT.next_state(a), blocks[S * 2 + 1])
+
+
+def test_flat_adam_promotion_refuses_what_it_cannot_continue():
+    """mlhot.optim.FlatAdam.from_torch_adam only continues a plain torch.optim.Adam over exactly the model's parameters (train.py:52-56's
+    optimizer); anything else - and CPU parameters, where the flat update kernel cannot run - is left alone (None), without touching
+    the library."""
+    import torch
+    from mlhot.optim import FlatAdam
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(3, 3), torch.nn.Linear(3, 2)
+
+        def flat_layout(self, *a):
+            raise AssertionError("must not be reached for a refused optimizer")
+
+    m = M()
+    assert FlatAdam.from_torch_adam(torch.optim.AdamW(m.parameters(), lr=1e-3), m) is None
+    assert FlatAdam.from_torch_adam(torch.optim.SGD(m.parameters(), lr=1e-3), m) is None
+    assert FlatAdam.from_torch_adam(torch.optim.Adam([{"params": m.a.parameters()}, {"params": m.b.parameters()}], lr=1e-3), m) is None
+    assert FlatAdam.from_torch_adam(torch.optim.Adam(m.parameters(), lr=1e-3, amsgrad=True), m) is None
+    assert FlatAdam.from_torch_adam(torch.optim.Adam(m.a.parameters(), lr=1e-3), m) is None          # not all of the model's parameters
+    assert FlatAdam.from_torch_adam(torch.optim.Adam(m.parameters(), lr=torch.tensor(1e-3)), m) is None
+    assert FlatAdam.from_torch_adam(torch.optim.Adam(m.parameters(), lr=1e-3), m) is None             # CPU parameters
+    assert FlatAdam.from_torch_adam(torch.optim.Adam(m.parameters(), lr=1e-3), torch.nn.Linear(2, 2)) is None   # no flat gradient layout
