@@ -14,7 +14,7 @@ d = json.load(open("gpurun_out/ab_tmp.json"))
 k = d.get("kernel_us_per_step") or {}
 fwd = (d.get("roofline") or {}).get("forward") or {}
 print(f"{sys.argv[1]:28s} ms/step {d['ms_per_step']:.4f}  event median {d['ms_per_step_event_median']:.4f}  fwd {fwd.get('fwd_ms', float('nan')):.4f}  launches {d.get('launches_per_step')}  "
-      + " ".join(f"{n}={v}" for n, v in k.items() if n.startswith('tail') or 'dgrad2' in n or 'conv3' in n or 'wgrad' in n or 'wsum' in n or n in ('slab_reduce', 'loss_fwd', 'loss_bwd', 'enc.linear')))
+      + " ".join(f"{n}={v}" for n, v in k.items() if n.startswith('tail') or 'dgrad2' in n or 'conv3' in n or 'wgrad' in n or 'wsum' in n or 'trunk.conv' in n or 'conv2.dgrad' in n or n in ('slab_reduce', 'loss_fwd', 'loss_bwd', 'enc.linear')))
 PY
   done
 done
