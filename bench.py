@@ -14,7 +14,7 @@ stream; `roofline.forward`: the training forward against the MFMA and the HBM ro
 (the CPU oracle - a port of the reference arithmetic - on the host's physical cores, plus a 1-thread figure).
 
     --workload c3 (default, BASELINE configs[2] = the headline metric) | c2 (configs[1]) | c5 (the per-GPU share of configs[4]:
-    ANPMRShapeNet3D, Bayes-by-backprop ResNet encoder; eps drawn on the CPU generator by a host thread, one step ahead)
+    ANPMRShapeNet3D, Bayes-by-backprop ResNet encoder; eps drawn on the CPU generator by host threads, one step ahead)
 
 The step is replayed as a hipGraph; with one rank and a vanilla workload --steps-per-graph (default 5) consecutive steps share a
 graph (the 8.8 us between two graph launches is paid once per five steps; K and W must be multiples, the timed region stays EXACTLY
@@ -1036,8 +1036,10 @@ def main():
             d0 = time.perf_counter()
             eps.stage()
             out["eps"] = {"source": "host", "floats_per_step": eps._total, "host_draw_ms_per_step": 1e3 * (time.perf_counter() - d0),
-                          "note": "drawn on the torch CPU generator in the reference's order (bit-identical samples), on a host thread while "
-                                  "the previous step runs; a step costs max(GPU time, draw time)"}
+                          "host_threads": len(eps._pieces) if eps._pieces else 1,
+                          "note": "drawn on the torch CPU generator in the reference's order (bit-identical samples and final generator state) "
+                                  "while the previous step runs; the draw is cut into host_threads pieces, each drawn by normal_() on a "
+                                  "generator positioned with mlhot_mt19937_advance (MLHOT_EPS_THREADS); a step costs max(GPU time, draw time)"}
         elif eps is not None:
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -86,6 +86,12 @@ size_t mlhot_mt19937_jump_ws_words(int n_sub);
 int mlhot_mt19937_normal_par(uint32_t* engine, float* uniform_ws, float* out, const int64_t* segs, int nseg, int64_t total_outputs,
                              int64_t total_groups, const uint32_t* polys, int n_sub, int stride_blocks, uint32_t* jump_ws, void* stream);
 
+/* Host only (no device, no stream): the engine (uint32[626] as above) moved forward by n_outputs calls without producing them - the
+ * state `n_outputs` draws of torch's CPU generator would leave behind.  Lets K host threads draw K contiguous pieces of one
+ * `normal_()` stream at once, each on a torch.Generator set to its piece's starting state (networks/bbb/eps.py, bit-identical to
+ * the sequential draw of bbb/BBBConv.py:86-95).                                                                              */
+int mlhot_mt19937_advance(uint32_t* engine, uint64_t n_outputs);
+
 /* ---- E1: vanilla image encoder `encoder_w0` -------------------------------------------
  * replaces nn.Sequential(conv3x3s2+ReLU, conv3x3s2+ReLU, MaxPool2d(2), conv3x3s2+ReLU,
  * Flatten, Linear(4096,dim_w))   (networks/ANPShapeNet1D.py:46-56, CNPShapeNet1D.py:46-56,

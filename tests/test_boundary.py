@@ -131,6 +131,68 @@ def test_staged_eps_reproduces_the_lazy_draws():
     assert eps._active is None and eps._recorder is None
 
 
+def test_mt19937_advance_leaves_the_state_the_draws_would():
+    """mlhot_mt19937_advance (host only, include/mlhot.h): the engine after n calls without the outputs == torch's CPU generator after
+    drawing n 32-bit outputs, from a fresh seed and from mid-block positions, across block boundaries."""
+    import numpy as np
+    import torch
+    import mlhot
+    from mlhot import rng
+    L = mlhot.lib()
+    g = torch.Generator()
+    g.manual_seed(20260)
+    for n in (0, 1, 5, 622, 623, 624, 625, 1000, 3 * 624, 3 * 624 + 1, 100003, 896016):
+        before = g.get_state()
+        engine = rng._unpack(before).copy()
+        L.mt19937_advance(engine, n)
+        if n:
+            torch.empty(n).uniform_(generator=g)          # a float uniform is ONE engine call
+        assert torch.equal(rng._pack(before, engine), g.get_state()), n
+    with pytest.raises(mlhot.MlhotError):
+        L.mt19937_advance(np.zeros(10, dtype=np.uint32), 1)
+
+
+@pytest.mark.parametrize("threads", [2, 3, 8])
+def test_staged_eps_on_several_host_threads_draws_the_same_stream(threads):
+    """networks/bbb/eps.py with `threads` > 1: the recorded sequence cut into pieces, every piece drawn by normal_() on its own generator
+    positioned by mlhot_mt19937_advance - numbers AND final CPU generator state equal the lazy per-layer draws of the reference
+    (bbb/BBBConv.py:88-95), for c5's sequence (2 x 26 tensors, 896 k normals) and for a ragged one (sizes that are not multiples of
+    16 or 4: each consumes 16 extra outputs)."""
+    import torch
+    from networks.bbb import eps
+    c5 = []
+    for _ in range(2):
+        c5 += [(64, 3, 5, 5), (64,)]
+        for _ in range(12):
+            c5 += [(64, 64, 3, 3), (64,)]
+    ragged = [(100003,), (64,), (17,), (333, 7, 11), (64, 64, 3, 3), (50,), (16,), (99999,)] * 2
+    for shapes in (c5, ragged):
+        st = eps.StagedEps("cpu", threads=threads)
+        torch.manual_seed(5)
+        with st.recording():
+            lazy = [eps.draw(s, "cpu") for s in shapes]
+        lazy_state = torch.get_rng_state()
+        for _ in range(2):
+            torch.manual_seed(5)
+            st.stage()
+            assert st._pieces is not None and len(st._pieces) == threads
+            assert torch.equal(torch.get_rng_state(), lazy_state)
+            with st.active():
+                for a, s_ in zip(lazy, shapes):
+                    assert torch.equal(a, eps.draw(s_, "cpu"))
+        torch.manual_seed(5)                               # and through the prefetch thread
+        st.prefetch()
+        st.stage()
+        assert torch.equal(torch.get_rng_state(), lazy_state)
+        with st.active():
+            assert all(torch.equal(a, eps.draw(s_, "cpu")) for a, s_ in zip(lazy, shapes))
+    one = eps.StagedEps("cpu", threads=1)
+    one.shapes = list(c5)
+    one._plan()
+    one.draw_host(torch.zeros(one._total))
+    assert one._pieces is None
+
+
 def test_committed_bench_line_honours_the_contract():
     """The newest profiles/r*_final_bench_c3.json is a bench.py line from the MI355X box: the driver's contract fields, the
     roofline and cpu_baseline objects, metric / unit as BASELINE.json names them."""

@@ -430,6 +430,11 @@ int mlhot_nt_xent_bwd(const float* z, int N, int d, int div, int mod, float t, c
 }
 
 // ---- torch's CPU normal_() stream on the device (csrc/mt_normal.h) ----------------------------------------------------
+int mlhot_mt19937_advance(uint32_t* engine, uint64_t n_outputs) {       // host only: no stream, no device
+  if (!engine || (int)engine[mt::N] < 0 || (int)engine[mt::N] > mt::N || engine[mt::N + 1] > (uint32_t)mt::N) { set_error("mt19937_advance: bad engine"); return MLHOT_ERR_ARG; }
+  mt::host_advance(engine, n_outputs);
+  return MLHOT_OK;
+}
 size_t mlhot_mt19937_jump_ws_words(int n_sub) {
   return n_sub < 1 ? 0 : (size_t)33 * 624 + 8 + (size_t)(n_sub - 1) * 8 * 624;
 }

@@ -204,5 +204,34 @@ __global__ __launch_bounds__(256) void mt_box_muller_kernel(const float* __restr
 }
 #endif
 
+// ---- host side: the engine moved forward by n calls, no output --------------------------------------------------------
+// Lets K host threads draw K contiguous pieces of ONE torch CPU stream at the same time (networks/bbb/eps.py: a torch.Generator per
+// piece, set to the state the sequential draw would have reached there).  The block regeneration is ATen's next_state() written as
+// three dependence-free runs (words 0-226 read old words only, 227-453 read the first run's results, 454-622 the second's) so that
+// the compiler vectorises them: ~0.2 ms per million outputs on one core.
+inline unsigned host_twist(unsigned u, unsigned v) {
+  return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((0u - (v & 1u)) & 0x9908b0dfu);
+}
+inline void host_next_state(unsigned* p) {
+  for (int i = 0; i < N - M; ++i) p[i] = p[i + M] ^ host_twist(p[i], p[i + 1]);                                  // 0 .. 226
+  for (int i = N - M; i < 2 * (N - M); ++i) p[i] = p[i + M - N] ^ host_twist(p[i], p[i + 1]);                    // 227 .. 453
+  for (int i = 2 * (N - M); i < N - 1; ++i) p[i] = p[i + M - N] ^ host_twist(p[i], p[i + 1]);                    // 454 .. 622
+  p[N - 1] = p[M - 1] ^ host_twist(p[N - 1], p[0]);
+}
+// engine = state[624], left, next as ATen's MT19937RNGEngine holds them; one call there is `if (--left == 0) next_state(); y = state[next++]`
+inline void host_advance(unsigned* engine, unsigned long long n) {
+  long long left = (int)engine[N], next = (int)engine[N + 1];
+  while (n > 0) {
+    if (left > 1) {                                   // calls that stay inside the current block
+      const unsigned long long k = n < (unsigned long long)(left - 1) ? n : (unsigned long long)(left - 1);
+      left -= (long long)k; next += (long long)k; n -= k;
+      continue;
+    }
+    host_next_state(engine);                          // this call regenerates, then reads word 0
+    left = N; next = 1; --n;
+  }
+  engine[N] = (unsigned)left; engine[N + 1] = (unsigned)next;
+}
+
 }  // namespace mt
 }  // namespace mlhot

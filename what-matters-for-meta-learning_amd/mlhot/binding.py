@@ -549,6 +549,15 @@ class MlhotLib:
         self.c.mlhot_mt19937_jump_ws_words.argtypes = [C.c_int]
         return int(self.c.mlhot_mt19937_jump_ws_words(n_sub))
 
+    def mt19937_advance(self, engine, n_outputs):
+        """engine: numpy uint32[626] (state, left, next), advanced IN PLACE by n_outputs calls.  Host only: works without a GPU."""
+        import numpy as np
+        if not (isinstance(engine, np.ndarray) and engine.dtype == np.uint32 and engine.size == 626 and engine.flags.c_contiguous and engine.flags.writeable):
+            raise MlhotError("mt19937_advance: engine must be a writeable contiguous numpy uint32[626]")
+        self.c.mlhot_mt19937_advance.argtypes = [C.c_void_p, C.c_uint64]
+        self._rc(self.c.mlhot_mt19937_advance(C.c_void_p(engine.ctypes.data), int(n_outputs)), "mlhot_mt19937_advance")
+        return engine
+
     # ---- whole ResNet trunks -------------------------------------------------------------------
     @staticmethod
     def trunk_supported(C_, H):

@@ -17,6 +17,13 @@ order, so the numbers are exactly those of the lazy route) into the alternate pi
 next `stage()` only waits for that thread and starts the copy.  A step then costs max(GPU time, draw time), not their sum.
 Nothing else may use the torch CPU generator between prefetch() and the stage() that collects it.
 
+The host draw itself runs on `threads` host threads (default MLHOT_EPS_THREADS or 4): the recorded sequence is cut - at multiples
+of 16 outputs, where ATen's normal_fill has no state beyond the engine - into that many pieces of equal length, the engine state
+at the start of every piece comes from mlhot_mt19937_advance (the MT19937 recurrence without the outputs, ~0.3 ms per million on
+one core), every piece is drawn by `normal_()` itself on a torch.Generator of its own, and the CPU generator is left where the
+sequential draw would leave it.  Same numbers, bit for bit (checked once per plan against the one-thread draw); c5's 896 k normals
+per step: 1.83 ms on one thread of the GPU box - longer than the 1.43 ms GPU step, i.e. the step's floor - against ~0.3 + 1.83 / K.
+
 `StagedEps(device, source="device")` lifts the host out of the loop altogether: the CPU generator's MT19937 engine is handed to
 the device (mlhot.rng.DeviceNormal -> mlhot_mt19937_normal) and every stage() receives the SAME random stream from there -
 identical uniforms, normals equal to torch's up to <= 4 ulp of logf / sincosf (so a model output moves by ~1e-7, far inside the
@@ -25,7 +32,9 @@ stream while step k runs (one CU for ~0.3 ms); stage() is then an event wait and
 engine back: the CPU generator continues exactly where a host-only run would be.
 """
 import contextlib
+import os
 import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
@@ -44,11 +53,13 @@ def draw(size, device):
 
 
 class StagedEps:
-    def __init__(self, device, source="host"):
+    def __init__(self, device, source="host", threads=None):
         if source not in ("host", "device"):
             raise ValueError("StagedEps: source is 'host' (torch CPU generator, bit-exact) or 'device' (the same stream on the GPU)")
         self.device = torch.device(device)
         self.source = source
+        self.threads = max(1, int(os.environ.get("MLHOT_EPS_THREADS", "4")) if threads is None else int(threads))
+        self._pieces, self._pool, self._gens = None, None, None
         self._dn, self._dn_buf, self._dn_stream, self._dn_ready, self._dn_free = None, None, None, None, None
         self.shapes = []
         self._offsets, self._total, self._cursor = None, 0, 0
@@ -60,7 +71,7 @@ class StagedEps:
     @contextlib.contextmanager
     def recording(self):
         global _recorder
-        self.shapes, self._offsets, self._runs = [], None, None
+        self.shapes, self._offsets, self._runs, self._pieces = [], None, None, None
         _recorder = self
         try:
             yield self
@@ -95,8 +106,84 @@ class StagedEps:
         per step become 2, ~10 % of the draw time."""
         if self._runs is None:
             self._plan_runs()
+        if self._pieces:
+            return self._draw_pieces(out, generator)
         for lo, hi in self._runs:
             out[lo:hi].normal_(0, 1, generator=generator)
+        return out
+
+    # ---- the same draw on several host threads ------------------------------------------------------------------------------
+    def _plan_pieces(self):
+        """Cut the runs into `threads` pieces of (nearly) equal engine consumption.  A run of n elements consumes n outputs (+ 16 when
+        n % 16 != 0: ATen redoes the last 16 elements with fresh uniforms); a run may be cut at any multiple of 16 as long as what
+        follows the cut keeps >= 16 elements (below that normal_() takes the scalar double-precision path)."""
+        self._pieces = None
+        if self.threads < 2 or any(hi - lo < 16 for lo, hi in self._runs):
+            return
+        cons = [(hi - lo) + (16 if (hi - lo) % 16 else 0) for lo, hi in self._runs]
+        total = sum(cons)
+        if total < 64 * 1024:                       # a small draw is faster on one thread than through the pool
+            return
+        target = -(-total // self.threads)
+        pieces, cur, room = [], [], target          # piece = [(lo, hi, consumption)]
+        for lo, hi in self._runs:
+            while lo < hi:
+                n = hi - lo
+                whole = n + (16 if n % 16 else 0)
+                if whole <= room or len(pieces) == self.threads - 1:      # fits, or this is the last piece: it takes what is left
+                    cur.append((lo, hi, whole)); room -= whole; lo = hi
+                    continue
+                cut = min(room // 16 * 16, (n - 16) // 16 * 16)           # the head that still fits; >= 16 elements stay behind
+                if cut >= 16:
+                    cur.append((lo, lo + cut, cut)); lo += cut
+                elif not cur:
+                    cur.append((lo, hi, whole)); lo = hi                  # cannot be cut: goes whole
+                pieces.append(cur); cur, room = [], target
+        if cur:
+            pieces.append(cur)
+        pieces = [p for p in pieces if p]
+        if len(pieces) < 2:
+            return
+        self._pieces = [([(lo, hi) for lo, hi, _ in p], sum(c for _, _, c in p)) for p in pieces]
+        self._pool = ThreadPoolExecutor(max_workers=len(self._pieces) - 1, thread_name_prefix="mlhot-eps-piece")
+        self._gens = [torch.Generator() for _ in self._pieces]
+        # once per plan: the pieces give the numbers AND the final generator state of the one-thread draw, or they are not used
+        g = torch.Generator()
+        g.manual_seed(0x5eed + 1)
+        state = g.get_state()
+        keep, self._pieces = self._pieces, None
+        ref = self.draw_host(torch.zeros(self._total), g)
+        after = g.get_state()
+        g.set_state(state)
+        self._pieces = keep
+        try:
+            ok = torch.equal(ref, self.draw_host(torch.zeros(self._total), g)) and torch.equal(after, g.get_state())
+        except Exception:                            # noqa: BLE001 - e.g. the library is missing: the one-thread draw needs nothing
+            ok = False
+        if not ok:
+            self._pieces = None
+
+    def _draw_pieces(self, out, generator=None):
+        from mlhot import lib
+        from mlhot.rng import _pack, _unpack
+        g = generator if generator is not None else torch.default_generator
+        s0 = g.get_state()
+        engine = _unpack(s0).copy()
+        L = lib()
+        for (_, cons), gk in zip(self._pieces, self._gens):
+            gk.set_state(_pack(s0, engine))
+            L.mt19937_advance(engine, cons)
+
+        def one(k):
+            runs, _ = self._pieces[k]
+            for lo, hi in runs:
+                out[lo:hi].normal_(0, 1, generator=self._gens[k])
+
+        jobs = [self._pool.submit(one, k) for k in range(1, len(self._pieces))]
+        one(0)
+        for j in jobs:
+            j.result()
+        g.set_state(_pack(s0, engine))
         return out
 
     def _plan_runs(self):
@@ -118,6 +205,7 @@ class StagedEps:
             self._runs = merged
             if not torch.equal(ref, self.draw_host(torch.zeros(self._total), g)):
                 self._runs = single                 # this torch build fills differently: keep one call per tensor
+        self._plan_pieces()
 
     def prefetch(self):
         """Start drawing the NEXT stage()'s eps on a worker thread (into the pinned buffer that stage() will ship)."""
