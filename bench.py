@@ -511,6 +511,62 @@ def measure_train_loop(w, device, loss_fn, iters):
     return out
 
 
+def measure_train_loop_3d(w, device, loss_fn, iters):
+    """c5's model through the reference's own training sequence (train.py:52-90: torch.optim.Adam(model.parameters(), lr), a loader
+    handing out fp32 host batches, ModelTrainer(...).train() with loss.item() every iteration), twice: as trainer.ModelTrainer runs it
+    by default (round 5: FlatAdam over ResNetNP.flat_layout, gradients in the mirror arena, hipGraph replay, the Bayes-by-backprop eps
+    staged per step and drawn on host threads under the previous step, host batches on a copy stream) and with every promotion off
+    (eager autograd, torch's optimizer over 144 tensors, 52 lazy `normal_()` + `.to(device)` draws per forward)."""
+    import importlib
+    import tempfile
+    from mlhot import binding, synth
+    from trainer.model_trainer import ModelTrainer
+    cls = getattr(importlib.import_module("networks." + w["method"]), w["method"])
+    host = tuple(synth.get_batch_3d(w["T"], NC, NQ, seed=1234))
+
+    class HostLoader:
+        def get_batch(self, source, tasks_per_batch, shot):
+            return host
+
+        def gen_bg(self, *a, **k):
+            pass
+
+    out = {}
+    for name, promoted in (("reference_style_ms_per_iter", True), ("reference_style_unpromoted_ms_per_iter", False)):
+        with tempfile.TemporaryDirectory() as tmp:
+            cfg = make_cfg(w, device)
+            cfg.iterations, cfg.val_freq, cfg.val_iters, cfg.bg_gen_freq, cfg.gen_bg = 4, 10 ** 9, 1, 10 ** 9, False
+            cfg.save_path, cfg.logger, cfg.contrastive, cfg.max_ctx_num = tmp, None, False, NC
+            if not promoted:
+                cfg.promote_optimizer, cfg.graph_steps, cfg.host_prefetch = False, False, False
+            model = cls(cfg).to(device)
+            try:
+                tr = ModelTrainer(model=model, loss=loss_fn, optimizer=torch.optim.Adam(model.parameters(), lr=1e-4), config=cfg, data=HostLoader())
+                tr.train()                                  # eager warm-up of the batch shape, capture, two replays (+ the final checkpoint)
+                tr.iterations = 10 ** 9
+                n = max(20, 2 * iters) if promoted else max(5, iters // 2)
+                for timed in (False, True):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for it in range(5, 5 + n):
+                        tr._prefetch = True
+                        tr._train_iter(it)
+                    torch.cuda.synchronize()
+                    if timed:
+                        out[name] = 1e3 * (time.perf_counter() - t0) / n
+                if promoted:
+                    out["reference_style_promoted"] = {"optimizer": type(tr.optimizer).__name__, "graph_replay": bool(tr._graph_default),
+                                                       "host_batch_prefetch": tr._host_prefetch is not None,
+                                                       "eps_host_threads": len(tr._eps._pieces) if tr._eps and tr._eps._pieces else 1}
+                    if tr._eps and tr._eps._worker is not None:
+                        tr._eps.stage()                     # collect the last prefetch: the CPU generator is free again
+            finally:
+                binding.set_grad_arena(None)
+    out["tasks_per_s"] = {"reference_style": 1e3 * w["T"] / out["reference_style_ms_per_iter"],
+                          "reference_style_unpromoted": 1e3 * w["T"] / out["reference_style_unpromoted_ms_per_iter"]}
+    return out
+
+
 def measure_extras(w, device, loss_fn, batch, iters):
     """Not the headline metric: (a) the training forward alone (activations saved, no backward), (b) the full step
     followed by the fused flat Adam update (mlhot.optim.FlatAdam: one launch over the flat parameter buffer).  The Adam
@@ -997,8 +1053,11 @@ def main():
             extras = {"variable_context": measure_variable_nc_3d(w, device, loss_fn, model, eps,
                                                                  lambda a, b_, c_, d_: fwd_bwd(batch=(a, c_, b_, d_)), max(10, args.steps // 2)),
                       "note": "informational, not the headline metric"}
+            if eps is not None and eps._worker is not None:
+                eps.stage()                                      # the trainer below draws from the same CPU generator
+            extras["train_loop"] = measure_train_loop_3d(w, device, loss_fn, max(10, args.steps // 2))
         except Exception as e:  # noqa: BLE001 - extras must never break the bench line
-            extras = {"error": f"{type(e).__name__}: {e}"}
+            extras = dict(extras or {}, error=f"{type(e).__name__}: {e}")
     if dist.is_initialized():
         dist.barrier()
 

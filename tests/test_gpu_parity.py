@@ -1641,20 +1641,32 @@ def test_trainer_trajectory_vs_oracle(gpulib, tmp_path, monkeypatch, optimizer, 
         assert type(tr.optimizer) is torch.optim.Adam and not tr._graph_default and tr._host_prefetch is None and not tr._graphs
 
 
-def test_trainer_trajectory_vs_oracle_anpmr_shapenet3d(gpulib, tmp_path, monkeypatch):
-    """The same for BASELINE config c5's model (ANPMRShapeNet3D, Bayes-by-backprop encoder, loss + 1e-7 * kl): T = 2, 4 + 4 shots,
-    3 iterations; both loops draw their eps from the torch CPU generator seeded once before the first iteration, in the
-    reference's order (bbb/BBBConv.py:88), so iteration i of either run samples the same eps."""
+@pytest.mark.parametrize("method,promoted", [("ANPMRShapeNet3D", True), ("ANPMRShapeNet3D", False), ("ANP", True), ("CondNeuralProcess", True)])
+def test_trainer_trajectory_vs_oracle_resnet_family(gpulib, tmp_path, monkeypatch, method, promoted):
+    """The same for BASELINE config c5's model (ANPMRShapeNet3D, Bayes-by-backprop encoder, loss + 1e-7 * kl) and its deterministic
+    relatives (ANP / CondNeuralProcess over the ResNet trunks): T = 2, 4 + 4 shots, 4 iterations of the reference's calling sequence
+    - ModelTrainer(model, loss, torch.optim.Adam(model.parameters(), lr), config, data).  Both loops draw their eps from the torch
+    CPU generator seeded once before the first iteration, in the reference's order (bbb/BBBConv.py:88), so iteration i of either
+    run samples the same eps.  `promoted` (the default since round 5): FlatAdam.from_torch_adam over ResNetNP.flat_layout, the
+    gradients in the mirror arena, one eager iteration, then capture and hipGraph replays with the eps staged per step (the
+    third and fourth iteration's draws made on host threads under the previous step); unpromoted: the plain eager loop with
+    torch's optimizer and lazy per-layer draws."""
     import contextlib
+    import importlib
     import types
+    from mlhot import binding
     from mlhot.synth import get_batch_3d
-    from networks.ANPMRShapeNet3D import ANPMRShapeNet3D
     monkeypatch.chdir(tmp_path)
+    mr = method == "ANPMRShapeNet3D"
+    agg = "attention" if method != "CondNeuralProcess" else "max"
     cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[64, 64, 4], tasks_per_batch=2, input_dim=4, output_dim=4,
-                                agg_mode="attention", img_agg="reshape", task="shapenet_3d", temperature=0.07, max_ctx_num=4, beta=1e-7)
-    model = ANPMRShapeNet3D(cfg).to(cfg.device)
+                                agg_mode=agg, img_agg="reshape" if mr else "max", task="shapenet_3d", temperature=0.07, max_ctx_num=4,
+                                beta=1e-7 if mr else 0)
+    if not promoted:
+        cfg.promote_optimizer, cfg.graph_steps, cfg.host_prefetch = False, False, False
+    model = getattr(importlib.import_module("networks." + method), method)(cfg).to(cfg.device)
     p0 = {n: v.detach().cpu().clone() for n, v in model.state_dict().items()}
-    batches = [get_batch_3d(2, 4, 4, seed=200 + i) for i in range(3)]
+    batches = [get_batch_3d(2, 4, 4, seed=200 + i) for i in range(4)]
 
     @contextlib.contextmanager
     def grab_routes(out):
@@ -1667,11 +1679,34 @@ def test_trainer_trajectory_vs_oracle_anpmr_shapenet3d(gpulib, tmp_path, monkeyp
 
     def oracle_step(p, cx, cy, qx, qy, routes, tie):
         pres = []
-        mu, kl = O.anpmr3d_forward(p, cx, cy, qx, routes=routes, pres=pres)
+        if mr:
+            mu, kl = O.anpmr3d_forward(p, cx, cy, qx, routes=routes, pres=pres)
+        else:
+            mu, kl = O.resnet_np_forward(p, cx, cy, qx, agg, cfg.img_agg, routes=routes, pres=pres), 0.0
         flips = sum(U.relu_flips(m, v, "resnet", tie) for masks, pre in zip(routes, pres) for m, v in zip(masks, pre))
         return O.calc_loss("shapenet_3d", mu, qy) + 1e-7 * kl, flips
-    _trajectory_check(model, p0, oracle_step, batches, lambda m: torch.optim.Adam(m.parameters(), lr=1e-3), cfg, tmp_path,
-                      "anpmr_shapenet3d", grab_routes, seed_eps=99)
+    seen = {}
+    try:
+        _trajectory_check(model, p0, oracle_step, batches, lambda m: torch.optim.Adam(m.parameters(), lr=1e-3), cfg, tmp_path,
+                          f"{method}_{'promoted' if promoted else 'unpromoted'}", grab_routes, seed_eps=99, trainer_out=seen)
+        tr = seen["trainer"]
+        if promoted:        # the reference's sequence took the fast path by itself
+            assert type(tr.optimizer).__name__ == "FlatAdam" and tr.optimizer.capturable and tr._graph_default
+            assert [type(v).__name__ for v in tr._graphs.values()] == ["tuple"] and int(tr.optimizer.step_dev.item()) == 4
+            assert tr.optimizer.active < tr.optimizer.flat.numel()                      # resnet.fc.* parked behind the update
+            assert all(p.untyped_storage().data_ptr() == tr.optimizer.flat.untyped_storage().data_ptr() for p in model.parameters())
+            assert (tr._eps is not None and bool(tr._eps)) == mr
+            if mr:
+                assert tr._eps._pieces is not None and len(tr._eps._pieces) > 1     # ... and its eps were drawn on several host threads
+            sd = tr.optimizer.state_dict()
+            ref = torch.optim.Adam(model.parameters(), lr=1e-3)
+            ref.load_state_dict(sd)
+            stepped = [i for i, (n, _) in enumerate(model.named_parameters()) if ".resnet.fc." not in n]
+            assert sorted(sd["state"]) == stepped
+        else:
+            assert type(tr.optimizer) is torch.optim.Adam and not tr._graph_default and not tr._graphs and tr._eps is None
+    finally:
+        binding.set_grad_arena(None)
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 12, 12, 8, 5, 2, 2), (2, 4, 9, 9, 6, 3, 2, 1), (1, 5, 8, 8, 7, 3, 1, 1), (2, 4, 8, 8, 5, 1, 2, 0),

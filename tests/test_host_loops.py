@@ -228,3 +228,47 @@ def test_flat_adam_promotion_refuses_what_it_cannot_continue():
     assert FlatAdam.from_torch_adam(torch.optim.Adam(m.parameters(), lr=torch.tensor(1e-3)), m) is None
     assert FlatAdam.from_torch_adam(torch.optim.Adam(m.parameters(), lr=1e-3), m) is None             # CPU parameters
     assert FlatAdam.from_torch_adam(torch.optim.Adam(m.parameters(), lr=1e-3), torch.nn.Linear(2, 2)) is None   # no flat gradient layout
+
+
+@pytest.mark.parametrize("method", ["ANPMRShapeNet3D", "ANP", "CondNeuralProcess"])
+def test_resnet_family_flat_layout_keeps_buckets_and_head_stacks_contiguous(method):
+    """ResNetNP.flat_layout (what FlatAdam lays the ResNet / Bayes-by-backprop models' parameters out by, train.py:52-56's one optimizer
+    over all parameters): early-bucket parameters first, each per-head stack one block that HeadStack adopts without a copy, the
+    trunks behind, `resnet.fc.*` (never given a gradient) parked behind the stepped range; GradArena mirrors it offset for offset."""
+    import importlib
+    from mlhot.arena import GradArena
+    cfg = types.SimpleNamespace(device=torch.device("cpu"), seed=2578, img_size=[64, 64, 4], tasks_per_batch=2, input_dim=4, output_dim=4,
+                                agg_mode="attention" if method != "CondNeuralProcess" else "max", img_agg="reshape" if method == "ANPMRShapeNet3D" else "max",
+                                task="shapenet_3d", temperature=0.07)
+    model = getattr(importlib.import_module("networks." + method), method)(cfg)
+    named = dict(model.named_parameters())
+    total, offs, active = model.flat_layout()
+    assert set(offs) == set(named) and all(o % 4 == 0 for o in offs.values()) and total % 4 == 0
+    spans = sorted((o, o + named[n].numel(), n) for n, o in offs.items())
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= total              # no overlap
+    early = {n for n, p in named.items() if any(p is q for q in model.early_grad_parameters())}
+    dead = {n for n in named if ".resnet.fc." in n}
+    assert dead and "decoder.conv1.weight" not in early and "decoder.fc_mu.0.weight" in early
+    assert max(offs[n] + named[n].numel() for n in early) <= min(offs[n] for n in named if n not in early)
+    assert min(offs[n] for n in dead) == active and max(offs[n] + named[n].numel() for n in named if n not in dead) <= active
+    # what FlatAdam.__init__ does, on the CPU: every parameter a view of one flat tensor
+    before = {n: p.detach().clone() for n, p in named.items()}
+    flat = torch.zeros(total)
+    with torch.no_grad():
+        for n, p in named.items():
+            v = flat[offs[n]:offs[n] + p.numel()].view_as(p)
+            v.copy_(p)
+            p.data = v
+    if model.ATTENTION:
+        for prefix, mods in (("_W_q", model._W_q), ("_W_k", model._W_k), ("_W_v", model._W_v)):
+            w, b = model._stack(mods).tensors()
+            assert w.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() and w.shape == (8 * 256, 256) and b.shape == (8 * 256,)
+            assert all(m.linear.weight.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for m in mods)   # nothing was pulled out again
+            assert torch.equal(w, torch.cat([before[f"{prefix}.{i}.linear.weight"] for i in range(8)]))
+            assert torch.equal(b, torch.cat([before[f"{prefix}.{i}.linear.bias"] for i in range(8)]))
+    assert all(torch.equal(p, before[n]) for n, p in named.items())
+    arena = GradArena(model.parameters(), first=model.early_grad_parameters()).refresh()
+    assert arena.flat.numel() == total
+    for n, p in named.items():
+        g = arena.slot(p)
+        assert g is not None and g.shape == p.shape and g.storage_offset() == offs[n]

@@ -23,7 +23,10 @@ class FlatAdam:
                               "capturable": bool(capturable), "differentiable": False, "fused": None}]
         self.t = 0
         self.capturable = capturable
-        total, offs = model.flat_layout(ctx_num, test_num)
+        total, offs, *rest = model.flat_layout(ctx_num, test_num)
+        # floats the update covers: a layout may park parameters that never receive a gradient behind it (the ResNet family's
+        # `resnet.fc.*`): torch.optim.Adam skips a parameter whose .grad is None - no moments, no weight decay - and so does this
+        self.active = int(rest[0]) if rest else total
         params = dict(model.named_parameters())
         if set(offs) != set(params):
             raise ValueError("FlatAdam: the model's parameters and the library's gradient layout differ")
@@ -60,6 +63,8 @@ class FlatAdam:
         state = {}
         if t > 0:
             for i, (k, p) in enumerate(self.model.named_parameters()):
+                if self.offsets[k] >= self.active:
+                    continue                       # never stepped: torch's Adam holds no state for a parameter without gradients
                 sl = slice(self.offsets[k], self.offsets[k] + p.numel())
                 state[i] = {"step": torch.tensor(float(t)), "exp_avg": self.exp_avg[sl].view_as(p).clone(), "exp_avg_sq": self.exp_avg_sq[sl].view_as(p).clone()}
         group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
@@ -118,8 +123,16 @@ class FlatAdam:
         if g0 is None:
             return None
         st, base, ok = g0.untyped_storage(), None, True
+        arena = getattr(self.model, "__dict__", {}).get("_arena")
+        mirrored = arena is not None and arena.flat is not None and arena.flat.untyped_storage().data_ptr() == st.data_ptr()
         for k, p in params.items():
             g = p.grad
+            if g is None and mirrored:
+                # a zero-initialised mirror of the parameter buffer (mlhot/arena.py) that no kernel wrote for this parameter: a zero
+                # gradient (moments stay 0, update 0).  With weight decay that would still move what torch leaves alone
+                if self.weight_decay and self.offsets[k] < self.active:
+                    raise RuntimeError(f"FlatAdam: weight decay, and parameter {k} received no gradient (torch.optim.Adam would skip it)")
+                continue
             if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != st.data_ptr():
                 ok = False
                 break
@@ -143,10 +156,11 @@ class FlatAdam:
         g = self._flat_grad()
         if g is None:
             return
+        n = self.active
+        flat, g, m1, m2 = (self.flat, g, self.exp_avg, self.exp_avg_sq) if n == self.flat.numel() else \
+            (self.flat[:n], g[:n], self.exp_avg[:n], self.exp_avg_sq[:n])
         if self.capturable:
-            lib().adam_step_counter(self.flat, g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
-                                    self.weight_decay, grad_scale, self.step_dev)
+            lib().adam_step_counter(flat, g, m1, m2, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale, self.step_dev)
             return
         self.t += 1
-        lib().adam_step(self.flat, g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
-                        self.weight_decay, grad_scale, self.t)
+        lib().adam_step(flat, g, m1, m2, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale, self.t)

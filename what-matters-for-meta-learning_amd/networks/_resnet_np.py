@@ -33,8 +33,25 @@ class HeadStack:
                 return False
         return True
 
+    def _adopt(self):
+        """The heads' Parameters already lie behind one another in ONE storage (mlhot.optim.FlatAdam re-points every parameter at
+        a view of its flat buffer, laid out by ResNetNP.flat_layout with the stacks contiguous): the stack IS that range - take
+        views of it instead of concatenating (a cat would pull the parameters out of the optimizer's buffer again)."""
+        ws, bs = [m.linear.weight for m in self.mods], [m.linear.bias for m in self.mods]
+        for ts in (ws, bs):
+            t0, n = ts[0], ts[0].numel()
+            for i, t in enumerate(ts):
+                if (not t.is_contiguous() or t.device != t0.device or t.dtype != t0.dtype or t.shape != t0.shape
+                        or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr() or t.storage_offset() != t0.storage_offset() + i * n):
+                    return False
+        N, (h, k) = len(ws), ws[0].shape
+        with torch.no_grad():
+            self.w = torch.empty(0, dtype=ws[0].dtype, device=ws[0].device).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (N * h, k))
+            self.b = torch.empty(0, dtype=bs[0].dtype, device=bs[0].device).set_(bs[0].untyped_storage(), bs[0].storage_offset(), (N * h,))
+        return True
+
     def tensors(self):
-        if not self._aliased():
+        if not self._aliased() and not self._adopt():
             ws, bs = [m.linear.weight for m in self.mods], [m.linear.bias for m in self.mods]
             h = ws[0].shape[0]
             with torch.no_grad():
@@ -95,9 +112,51 @@ class ResNetNP(nn.Module):
     def early_grad_parameters(self):
         """Parameters whose gradients are complete before the image trunks' backward starts (that backward - ONE C call over
         the context / target / decoder passes - is the last node of the autograd graph): the MLPs, the attention and the decoder
-        head, i.e. everything outside `img_encoder` and `decoder.resnet`.  mlhot.dist.GradBucket(early=...) all-reduces them
+        head, i.e. everything outside `img_encoder`, `decoder.resnet` and `decoder.conv1`.  mlhot.dist.GradBucket(early=...) all-reduces them
         from inside the backward, under the trunks' ~1 ms."""
-        return [p for k, p in self.named_parameters() if not (k.startswith("img_encoder.") or k.startswith("decoder.resnet."))]
+        return [p for k, p in self.named_parameters() if not self._trunk_parameter(k)]
+
+    @staticmethod
+    def _trunk_parameter(name):
+        """Gradient produced by the image trunks' backward: the encoder, the decoder's ResNet and the decoder's stem convolution
+        (`decoder.conv1` is the first layer of the decoder's trunk pass, models.py:120-192 - until round 5 it was counted among the
+        early parameters, so an armed eager backward issued the early bucket only after the trunks: correct, but nothing overlapped)."""
+        return name.startswith("img_encoder.") or name.startswith("decoder.resnet.") or name.startswith("decoder.conv1.")
+
+    def flat_layout(self, ctx_num=None, test_num=None):
+        """(total floats, {parameter name: offset}, floats that are ever stepped) for mlhot.optim.FlatAdam: ONE flat parameter buffer
+        (and, through enable_flat_grads(), its mirror for the gradients) - the early-bucket parameters first (the range
+        mlhot.dist.GradBucket all-reduces from inside the backward stays contiguous), each per-head AttnLinear stack as one block
+        (its 8 weights, then its 8 biases: HeadStack adopts the range), the image trunks, and at the very end the parameters no
+        forward ever uses (`resnet.fc.*`: part of the reference's state_dict and of its optimizer, never given a gradient - torch's
+        Adam skips them, the flat update stops in front of them).  Every slice 16-byte aligned.  The batch shape does not matter."""
+        named = dict(self.named_parameters())
+        order, seen = [], set()
+
+        def take(names):
+            for n in names:
+                if n in named and n not in seen:
+                    seen.add(n)
+                    order.append(n)
+        if self.ATTENTION:
+            for stack in ("_W_q", "_W_k", "_W_v"):
+                take([f"{stack}.{i}.linear.weight" for i in range(self.N_HEADS)])
+                take([f"{stack}.{i}.linear.bias" for i in range(self.N_HEADS)])
+        dead = [n for n in named if ".resnet.fc." in n]
+        late = [n for n in named if self._trunk_parameter(n) and n not in dead]
+        take([n for n in named if n not in late and n not in dead])
+        take(late)
+        active_names = len(order)
+        take(dead)
+        offs, total, active = {}, 0, 0
+        for i, n in enumerate(order):
+            if i == active_names:
+                active = total
+            offs[n] = total
+            total += (named[n].numel() + 3) // 4 * 4
+        if active_names == len(order):
+            active = total
+        return total, offs, active
 
     def enable_flat_grads(self, on=True):
         """Every gradient of this model in ONE flat buffer (mlhot/arena.py): the kernels write weight / bias gradients straight

@@ -14,7 +14,9 @@ buffer - which is what makes a Bayes-by-backprop training step capturable in a h
 
 `prefetch()` takes the draws off the critical path: step k+1's eps are drawn on a worker thread (the torch CPU generator, same
 order, so the numbers are exactly those of the lazy route) into the alternate pinned buffer while step k runs on the GPU; the
-next `stage()` only waits for that thread and starts the copy.  A step then costs max(GPU time, draw time), not their sum.
+next `stage()` only waits for that thread and starts the copy.  A step then costs max(GPU time, draw time), not their sum.  The
+drawer thread also sends its numbers across PCIe itself, on a copy stream, into one of two device-side staging buffers (3.5 MB per
+c5 step: ~65 us the replaying stream would otherwise wait for); `stage()` is then an event wait and a device -> device copy.
 Nothing else may use the torch CPU generator between prefetch() and the stage() that collects it.
 
 The host draw itself runs on `threads` host threads (default MLHOT_EPS_THREADS or 4): the recorded sequence is cut - at multiples
@@ -95,6 +97,11 @@ class StagedEps:
         self._offsets, self._total = offs, n
         pin = self.device.type == "cuda"
         self._host = [torch.empty(n).pin_memory() if pin else torch.empty(n) for _ in range(2)]
+        # prefetched draws cross PCIe on a stream of their own, under the step that is running (3.5 MB per c5 step = ~65 us that the
+        # replaying stream would otherwise wait for); stage() then only copies device -> device
+        self._near = [torch.empty(n, device=self.device) for _ in range(2)] if pin else None
+        self._copy_stream = torch.cuda.Stream(self.device) if pin else None
+        self._arrived = [None, None]
         self._dev = torch.empty(n, device=self.device)
         self._done = [torch.cuda.Event() if pin else None for _ in range(2)]
 
@@ -233,8 +240,14 @@ class StagedEps:
             try:
                 if self._done[k] is not None:
                     with torch.cuda.device(self.device):
-                        self._done[k].synchronize()    # the copy out of this pinned buffer two steps ago
+                        self._done[k].synchronize()    # the copies out of this pair of buffers two steps ago
+                        if self._arrived[k] is not None:
+                            self._arrived[k].synchronize()
                 self.draw_host(self._host[k])
+                if self._near is not None:
+                    with torch.cuda.device(self.device), torch.cuda.stream(self._copy_stream):
+                        self._near[k].copy_(self._host[k], non_blocking=True)
+                        self._arrived[k] = self._copy_stream.record_event()
                 self._state_after = torch.get_rng_state()      # stage() checks that nobody else drew in the meantime
             except BaseException as e:             # noqa: BLE001 - surfaced by the collecting stage()
                 self._worker_err = e
@@ -291,6 +304,7 @@ class StagedEps:
         if self.source == "device":
             return self._device_stage()
         k = self._turn = self._turn ^ 1
+        prefetched = self._worker is not None
         if self._worker is not None:
             self._ready.wait()
             self._worker = None
@@ -305,7 +319,11 @@ class StagedEps:
             if self._done[k] is not None:
                 self._done[k].synchronize()        # the copy out of this pinned buffer two steps ago
             self.draw_host(self._host[k])
-        self._dev.copy_(self._host[k], non_blocking=True)
+        if prefetched and self._near is not None and self._arrived[k] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._arrived[k])
+            self._dev.copy_(self._near[k])             # the drawer thread already sent the numbers across
+        else:
+            self._dev.copy_(self._host[k], non_blocking=True)
         if self._done[k] is not None:
             self._done[k].record()
         self._cursor = 0

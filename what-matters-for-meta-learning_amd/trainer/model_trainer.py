@@ -12,7 +12,9 @@ The reference's own calling sequence is the fast one (round 5): `ModelTrainer(mo
 lr=...), config, data).train()` as train.py:52-90 writes it, with a loader that hands out fp32 host batches, runs as
   * mlhot.optim.FlatAdam.from_torch_adam(...): a plain torch.optim.Adam over the model's parameters is continued by the
     one-launch flat update (same hyper-parameters, moments and step count; `config.promote_optimizer = False` keeps torch's),
-  * `config.graph_steps` defaulting to True whenever the optimizer is capture-safe and the model is a vanilla CNP / ANP plugin,
+  * `config.graph_steps` defaulting to True whenever the optimizer is capture-safe and the model has a flat parameter layout (the
+    vanilla CNP / ANP plugins: the library's; the ResNet / Bayes-by-backprop family: ResNetNP.flat_layout, gradients through the
+    mirror arena, the Bayes-by-backprop eps staged per step by networks/bbb/eps.py - drawn on host threads under the previous step),
   * the next host batch copied to the device on a copy stream while the current step computes (`_HostPrefetch`; the reference's
     pageable `.to(device)` - the fastest route for fp32 host tensors on this box, 50 GB/s - just not in front of the step).
 `config.graph_steps` (needs an optimizer whose step is capture-safe, e.g.
@@ -28,6 +30,7 @@ rank's shard - one scalar all-gather in the forward and one scalar all-reduce in
 (mlhot.dist.StabiliserExchange, include/mlhot.h "strict sharded parity").  Eager iterations only: the exchange runs between
 two C calls, so it cannot sit inside a replayed hipGraph.
 """
+import contextlib
 import math
 import os
 import sys
@@ -92,6 +95,8 @@ class ModelTrainer(BaseTrainer):
             flat = FlatAdam.from_torch_adam(self.optimizer, model, ctx_num=min(shot, 15), test_num=min(shot, 15))
             if flat is not None:
                 self.optimizer = flat
+                if hasattr(model, "enable_flat_grads") and model.__dict__.get("_arena") is None:
+                    model.enable_flat_grads()      # ResNet / BBB family: the gradients as the mirror of the flat parameter buffer
         if not hasattr(config, "graph_steps"):
             # default: replay whenever it is possible - a capture-safe optimizer, a model whose step is one static launch sequence
             # (the vanilla plugins), no collective between two C calls of the forward
@@ -104,6 +109,7 @@ class ModelTrainer(BaseTrainer):
         self._prefetch = False          # set per iteration by train(): may the NEXT training batch be drawn right away?
         self.rank0 = dist_rank() == 0   # files / logs / TensorBoard are rank 0's business (every rank holds the same weights)
         self._graphs, self._static_in, self._side = {}, {}, None       # graph_steps: per batch shape
+        self._eps = None                # graph_steps of a Bayes-by-backprop model: its eps draws staged per step (networks/bbb/eps.py)
         if hasattr(data, "get_batch_u8") and cuda and getattr(config, "ingest_u8", True):
             from mlhot.ingest import BatchIngest
             self.ingest = BatchIngest(config.device)
@@ -225,9 +231,13 @@ class ModelTrainer(BaseTrainer):
                 d.copy_(t)
         entry = self._graphs.get(key)
         cur = torch.cuda.current_stream(self.config.device)
+        eps = self._eps_stager()
+        if eps is not None and eps.shapes:
+            eps.stage()                                              # this iteration's draws (collected from the prefetch, or drawn now): the
+        staged = eps.active() if eps is not None and eps.shapes else contextlib.nullcontext()     # reference's order - batch, then eps
         if entry is None:                                            # first time: a real, eager iteration on the capture stream
             self._side.wait_stream(cur)
-            with torch.cuda.stream(self._side):
+            with torch.cuda.stream(self._side), (eps.recording() if eps is not None and not eps.shapes else staged):
                 loss = self._step_body(*static, with_optimizer=single)
             cur.wait_stream(self._side)
             self._graphs[key] = "warm"
@@ -237,24 +247,50 @@ class ModelTrainer(BaseTrainer):
                 graph = torch.cuda.CUDAGraph()
                 self._side.wait_stream(cur)
                 taps, ops.saved_taps = ops.saved_taps, []            # the captured forward's saved buffers (test / diagnostic hook, see below)
+                loggers = [m for m in self.model.modules() if hasattr(m, "tap_log")]      # the ResNet family's form of the same hook
+                listening = [m.tap_log for m in loggers]
+                for m in loggers:
+                    m.tap_log = []
                 try:
-                    with torch.cuda.graph(graph, stream=self._side, capture_error_mode=CAPTURE_MODE):
+                    with staged, torch.cuda.graph(graph, stream=self._side, capture_error_mode=CAPTURE_MODE):
                         static_loss = self._step_body(*static, with_optimizer=single)
                 finally:
                     captured_taps, ops.saved_taps = ops.saved_taps, taps
+                    captured_logs = [m.tap_log for m in loggers]
+                    for m, log in zip(loggers, listening):
+                        m.tap_log = log
                 # the gradient tensors THIS graph writes (its private pool): a replay does not rebind p.grad, and another
                 # shape's graph or eager warm-up may have re-pointed it since
-                entry = self._graphs[key] = (graph, static_loss, [p.grad for p in self.bucket.params], captured_taps)
+                entry = self._graphs[key] = (graph, static_loss, [p.grad for p in self.bucket.params], captured_taps, (loggers, captured_logs))
             entry[0].replay()
             loss = entry[1]
             for p, g in zip(self.bucket.params, entry[2]):
                 p.grad = g
             if ops.saved_taps is not None:                          # a replay runs no Python forward: hand a listener the graph's own saved
                 ops.saved_taps.extend(entry[3])                      # buffers, which now hold THIS iteration's routing
+            for m, log in zip(*entry[4]):
+                if m.tap_log is not None:
+                    m.tap_log.extend(log)
         if not single:
             self._sync_and_step()
         self._stage_next()
-        return loss
+        if eps is not None and eps.shapes and self._prefetch:
+            eps.prefetch()      # the next iteration's draws on host threads under this step - behind the next batch's draw, and only
+        return loss             # when nothing else (a validation forward) touches the CPU generator in between
+
+    def _eps_stager(self):
+        """A StagedEps for models with Bayes-by-backprop layers (their forward draws eps on the torch CPU generator, bbb/BBBConv.py:86-95:
+        not capturable as it stands), None otherwise.  Always the host source: the same numbers as the lazy draws, bit for bit, and the
+        validation forwards in between keep drawing from the same generator."""
+        if self._eps is None:
+            from networks.bbb.BBBConv import BBBConv2d
+            from networks.bbb.BBBLinear import BBBLinear
+            if any(isinstance(m, (BBBConv2d, BBBLinear)) for m in self.model.modules()):
+                from networks.bbb.eps import StagedEps
+                self._eps = StagedEps(self.config.device)
+            else:
+                self._eps = False
+        return self._eps or None
 
     def _sync_and_step(self):
         """Gradient all-reduce + optimizer step of a multi-rank iteration; the 1/world average rides in the optimizer's
