@@ -1980,6 +1980,73 @@ def test_graph_replayed_multi_rank_training_uses_each_graphs_own_gradients(gpuli
         assert torch.equal(finals[0][k], finals[2][k]), ("graph two-rank", k)
 
 
+def test_promoted_bbb_trainer_keeps_the_generator_order(gpulib, tmp_path, monkeypatch):
+    """ANPMRShapeNet3D through trainer.ModelTrainer's promoted defaults: the Bayes-by-backprop eps come from the torch CPU generator in the
+    reference's order (bbb/BBBConv.py:86-95) whichever way an iteration runs - lazily inside an eager forward, staged in front of a
+    replay, prefetched on host threads under the previous step - and the validation forwards in between draw from the same generator.
+    12 iterations with two context sizes (two graphs) and two validation rounds: the eager loop, the replayed loop and the replayed
+    loop of two simulated ranks (sum = 2x, 1/world in FlatAdam's gradient scale: exact) land on bit-identical losses and weights."""
+    import types
+    from mlhot import binding, dist as mdist
+    from mlhot.synth import get_batch_3d
+    from networks.ANPMRShapeNet3D import ANPMRShapeNet3D
+    from trainer.losses import LossFunc
+    from trainer.model_trainer import ModelTrainer
+    monkeypatch.chdir(tmp_path)
+
+    class Data3D:
+        def __init__(self):
+            self.rng, self.val_rng = np.random.RandomState(3), np.random.RandomState(4)
+
+        def gen_bg(self, *a, **k):
+            pass
+
+        def get_batch(self, source, tasks_per_batch, shot):
+            rng = self.rng if source == "train" else self.val_rng
+            n_ctx = int(rng.randint(3, shot + 1)) if source == "train" else shot
+            return get_batch_3d(tasks_per_batch, n_ctx, shot, seed=int(rng.randint(0, 2 ** 31 - 1)))
+
+    class TwoRanks(mdist.GradBucket):
+        def world_size(self):
+            return 2
+
+        def _all_reduce(self, flat):
+            flat.mul_(2.0)
+
+    runs = []
+    try:
+        for tag, graph, two in (("eager", False, False), ("replayed", None, False), ("replayed_two_ranks", None, True)):
+            cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[64, 64, 4], tasks_per_batch=2, input_dim=4, output_dim=4,
+                                        agg_mode="attention", img_agg="reshape", task="shapenet_3d", temperature=0.07, max_ctx_num=4, beta=1e-7,
+                                        iterations=12, val_freq=6, val_iters=1, bg_gen_freq=1000, gen_bg=False, contrastive=False, log_every=1,
+                                        save_path=str(tmp_path / tag), logger=None)
+            if graph is not None:
+                cfg.graph_steps = graph
+            model = ANPMRShapeNet3D(cfg).to(cfg.device)
+            tr = ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_3d"), optimizer=torch.optim.Adam(model.parameters(), lr=1e-3), config=cfg,
+                              data=Data3D())
+            assert type(tr.optimizer).__name__ == "FlatAdam" and tr._graph_default == (graph is None)
+            if two:
+                tr.bucket = TwoRanks(model.parameters(), early=model.early_grad_parameters())
+            seen = []
+            orig = tr._train_iter
+            tr._train_iter = lambda it, _o=orig, _s=seen: _s.append(_o(it))
+            torch.manual_seed(31)
+            tr.train()
+            if graph is None:
+                assert 1 <= len([v for v in tr._graphs.values() if isinstance(v, tuple)]) <= 2 and tr._eps._pieces is not None
+            assert int(tr.optimizer.step_dev.item()) == 12
+            runs.append((seen, {k: v.clone() for k, v in model.state_dict().items()}, torch.get_rng_state()))
+            binding.set_grad_arena(None)
+    finally:
+        binding.set_grad_arena(None)
+    for tag, (seen, final, state) in zip(("replayed", "replayed_two_ranks"), runs[1:]):
+        assert seen == runs[0][0], tag
+        assert torch.equal(state, runs[0][2]), tag                  # the CPU generator ends where the eager loop leaves it
+        for k in final:
+            assert torch.equal(final[k], runs[0][1][k]), (tag, k)
+
+
 def test_trainer_ingest_prefetch_keeps_the_reference_draw_order(gpulib, tmp_path, monkeypatch):
     """The reference draws train_k, then the validation / test batches of iteration k, then train_k+1, possibly all from ONE
     shared generator (np.random in its loaders).  The ingest route prefetches train_k+1 while step k computes - but only when
