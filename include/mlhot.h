@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLHOT_ABI_VERSION 4
+#define MLHOT_ABI_VERSION 5
 
 enum { MLHOT_ACT_NONE = 0, MLHOT_ACT_RELU = 1, MLHOT_ACT_TANH = 2 };
 enum { MLHOT_AGG_MEAN = 0, MLHOT_AGG_MAX = 1, MLHOT_AGG_BACO = 2, MLHOT_AGG_ATTENTION = 3 };

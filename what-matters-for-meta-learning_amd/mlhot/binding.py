@@ -22,7 +22,7 @@ LOSS = {"azimuth": 0, "mse": 1, "quaternion": 2, "degree": 3, "distractor": 4}
 _f = C.c_void_p  # every device pointer travels as void*
 
 
-ABI_VERSION = 4     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients; 3: + conv12_fwd / _bwd; 4: + np_vanilla_bwd_loss)
+ABI_VERSION = 5     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients; 3: + conv12_fwd / _bwd; 4: + np_vanilla_bwd_loss; 5: + mt19937_advance)
 
 
 class MlhotError(RuntimeError):
