@@ -783,7 +783,9 @@ def main():
                          "(negligible for ANPShapeNet1D, up to 15 %% of a gradient's scale for the d = 256 models, DESIGN.md section 6d)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fwd-only / +Adam timing legs")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the ~0.1 s of untimed steps in front of the W warm-up steps")
-    ap.add_argument("--loss-aside", action="store_true", help="A/B: the loss reduction on a forked stream (a parallel graph branch) instead of the step's own")
+    ap.add_argument("--no-loss-aside", action="store_true",
+                    help="A/B: the loss VALUE as a launch of its own between forward and backward (mlhot_loss_fwd) instead of one extra workgroup of "
+                         "the model's first backward kernel (mlhot.ops.loss_value_aside; vanilla workloads)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing experiments (results become WRONG; never a bench line)")
     ap.add_argument("--eps", choices=("host", "device"), default="host",
                     help="c5: where the Bayes-by-backprop eps stream is produced - the torch CPU generator (the reference's route, bit-exact; "
@@ -867,10 +869,9 @@ def main():
         bx, by, tx, ty = batch if batch is not None else (cx, cy, qx, qy)
         model.zero_grad(set_to_none=True)
         mu, var, kl = model(bx, by, tx)
-        # --loss-aside (A/B only): the loss's reduction on a forked stream beside the backward (mlhot.ops.loss_value_aside).  Measured,
-        # round 5: as a parallel branch of the captured graph it costs the step 22 us (0.585 -> 0.608 ms) instead of saving the
-        # reduction's 4.7 - off by default here and in trainer.ModelTrainer
-        with loss_value_aside(enabled=args.loss_aside and not c5):
+        # the loss VALUE comes out of the model's first backward kernel (one extra workgroup; mlhot.ops.loss_value_aside) - the step reads
+        # it only after the backward, as trainer.ModelTrainer does.  Not for c5: its objective adds kl * beta to the value right here.
+        with loss_value_aside(enabled=not args.no_loss_aside and not c5):
             loss = loss_fn.calc_loss(mu, var, ty)
             if c5:
                 loss = add_scaled(loss, kl, beta)     # loss + kl * beta as the trainer writes it; identical on every rank (same weights, kl does not depend on the batch): averaged, never summed

@@ -399,7 +399,10 @@ int mlhot_np_vanilla_bwd(const mlhot_np_dims* d, const mlhot_np_params* p,
  * its prologue; every other configuration materialises it first - same result either way):
  *   dmu_total = (dmu ? dmu : 0) + d loss(kind; mu, gt) / d mu * dloss[0]
  * kind: MLHOT_LOSS_* with a gradient (0 azimuth, 1 mse, 2 quaternion, 4 distractor); gt[T*Nq, gt_dim]; dloss: device scalar. */
-typedef struct { int kind; const float* gt; int gt_dim; const float* dloss; } mlhot_loss_desc;
+typedef struct { int kind; const float* gt; int gt_dim; const float* dloss;
+                 float* value;   /* ABI 5: NULL, or where this call also leaves the loss VALUE (what mlhot_loss_fwd(kind, mu, gt) writes, same
+                                  * bits): one more workgroup of the first backward kernel instead of a launch between forward and backward */
+} mlhot_loss_desc;
 int mlhot_np_vanilla_bwd_loss(const mlhot_np_dims* d, const mlhot_np_params* p,
                               const float* ctx_x, const float* ctx_y, const float* qry_x,
                               const float* mu, const float* dmu, const mlhot_loss_desc* loss, const mlhot_np_grads* g,

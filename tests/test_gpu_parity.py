@@ -528,8 +528,9 @@ def test_loss_gradient_taken_inside_the_models_backward(gpulib, method, agg, tas
     """mlhot_np_vanilla_bwd_loss (mlhot.ops.defer_loss_grad): calc_loss(mu, ., y).backward() with the loss's gradient derived by the
     model's first backward kernel (phase C' of the specialised attention tail; materialised inside the C call for every other
     configuration: CNP, > 16 shots) gives BIT-IDENTICAL parameter gradients to the two-node form - also when mu has a second
-    consumer (autograd adds its gradient to the zero placeholder, the kernel adds the loss's on top), and with the loss VALUE
-    reduced on a forked stream (loss_value_aside)."""
+    consumer (autograd adds its gradient to the zero placeholder, the kernel adds the loss's on top), and with the loss VALUE left to
+    the same kernel (loss_value_aside: one extra workgroup of phase C' / the CNP tail's backward; a launch inside the C call for the
+    other configurations) - the same bits as mlhot_loss_fwd's."""
     import importlib
     import types
     from mlhot import ops

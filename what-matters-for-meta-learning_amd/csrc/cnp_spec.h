@@ -157,6 +157,10 @@ __global__ __launch_bounds__(512) void cnp_bwd_kernel(const CnpBwdArgs a, const 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lptr L0 = (lptr)lds;
   const CnpDims& d = a.d;
+  if (loss.value != nullptr && (int)blockIdx.x == GR * d.T) {              // one workgroup more than the tasks need: the loss VALUE (ops_direct.h)
+    loss_value_block(LossRed{loss.kind, d.y_dim, loss.gt_dim, d.T * d.Nq, a.mu, loss.gt, loss.value}, d.T * d.Nq, lds);
+    return;
+  }
   const int t = (int)blockIdx.x / GR, grp = (int)blockIdx.x % GR;          // GR workgroups per task
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), gwave = grp * NWV + wave;
   const bool first = grp == 0;

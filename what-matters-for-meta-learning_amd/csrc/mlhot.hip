@@ -619,7 +619,7 @@ int mlhot_np_vanilla_bwd_loss(const mlhot_np_dims* d, const mlhot_np_params* p, 
   if (loss->kind < 0 || loss->kind > 4 || loss->kind == 3 || !loss->gt || !loss->dloss || loss->gt_dim < 1) {
     set_error("np_vanilla_bwd_loss: bad loss descriptor (kinds 0, 1, 2, 4 have a gradient)"); return MLHOT_ERR_ARG;
   }
-  const LossDesc ld{loss->kind, loss->gt, loss->gt_dim, loss->dloss};
+  const LossDesc ld{loss->kind, loss->gt, loss->gt_dim, loss->dloss, loss->value};
   return np_backward(*d, *p, ctx_x, ctx_y, qry_x, mu, dmu, *g, saved, scratch, scratch_bytes, (hipStream_t)stream, Stage{}, &ld);
 }
 int mlhot_np_vanilla_fwd_staged(const mlhot_np_dims* d, const mlhot_np_params* p, const float* ctx_x, const float* ctx_y,

@@ -290,7 +290,7 @@ inline int tail_slab_reduce(tf::SlabReduce& r, hipStream_t s, PendingSum* later 
 
 inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu, const float* dmu,
                               const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s, PendingSum* later,
-                              const LossDesc& loss = LossDesc{-1, nullptr, 0, nullptr}) {
+                              const LossDesc& loss = LossDesc{-1, nullptr, 0, nullptr, nullptr}) {
   const tf::CnpDims cd = cnp_dims(d);
   const tf::CnpSlab sl = tf::cnp_slab_layout(cd);
   if (!sc.tail_slab) { set_error("cnp_fused: workspace"); return MLHOT_ERR_WORKSPACE; }
@@ -298,9 +298,10 @@ inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
                    sc.d_dec_in, sc.d_cat_in, sc.tail_slab};
   if (ts::cnp_applies(cd) && (g_opt.tail_spec & 8)) {
     const int gr = (g_opt.tail_spec & 1024) ? ((g_opt.tail_spec & 4096) ? 4 : 2) : 1;
-    if (gr == 4) MLHOT_TRY(cnp_spec_launch(ts::cnp_bwd_kernel<4>, 4 * d.T, ts::cnp_bwd_lds_bytes(), s, "tail.bwd.cnp", a, loss));
-    else if (gr == 2) MLHOT_TRY(cnp_spec_launch(ts::cnp_bwd_kernel<2>, 2 * d.T, ts::cnp_bwd_lds_bytes(), s, "tail.bwd.cnp", a, loss));
-    else MLHOT_TRY(cnp_spec_launch(ts::cnp_bwd_kernel<1>, d.T, ts::cnp_bwd_lds_bytes(), s, "tail.bwd.cnp", a, loss));
+    const int lv = loss.value != nullptr ? 1 : 0;           // one workgroup more: the loss value
+    if (gr == 4) MLHOT_TRY(cnp_spec_launch(ts::cnp_bwd_kernel<4>, 4 * d.T + lv, ts::cnp_bwd_lds_bytes(), s, "tail.bwd.cnp", a, loss));
+    else if (gr == 2) MLHOT_TRY(cnp_spec_launch(ts::cnp_bwd_kernel<2>, 2 * d.T + lv, ts::cnp_bwd_lds_bytes(), s, "tail.bwd.cnp", a, loss));
+    else MLHOT_TRY(cnp_spec_launch(ts::cnp_bwd_kernel<1>, d.T + lv, ts::cnp_bwd_lds_bytes(), s, "tail.bwd.cnp", a, loss));
   } else {
     if (loss.kind >= 0) { set_error("cnp_fused: a loss descriptor reached a backward kernel that cannot take it"); return MLHOT_ERR_ARG; }
     MLHOT_TRY(tail_launch(tf::cnp_bwd_kernel, d.T, 512, tf::cnp_bwd_lds_bytes(cd), a, s, "tail.bwd.cnp"));
@@ -324,7 +325,7 @@ inline int cnp_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, 
 
 inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p, const float* ctx_y, const float* mu,
                                const float* dmu, const mlhot_np_grads& g, const NpBuf& b, const NpScratch& sc, hipStream_t s,
-                               PendingSum* later, const Stage& st = Stage{}, const LossDesc& loss = LossDesc{-1, nullptr, 0, nullptr}) {
+                               PendingSum* later, const Stage& st = Stage{}, const LossDesc& loss = LossDesc{-1, nullptr, 0, nullptr, nullptr}) {
   const tf::TailDims td = tail_dims(d);
   const tf::TailParams tp = tail_params(p);
   const tf::TailSlab sl = tf::tail_slab_layout(td);
@@ -336,9 +337,10 @@ inline int tail_backward_fused(const mlhot_np_dims& d, const mlhot_np_params& p,
   const int spec = ts::applies(td) ? g_opt.tail_spec : 0;
   if (loss.kind >= 0 && !(spec & 8)) { set_error("tail_fused: a loss descriptor reached a phase C' that cannot take it"); return MLHOT_ERR_ARG; }
   if (st.first()) {
-    if ((spec & 8) && (spec & 1024) && (spec & 4096)) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<4>, 4 * d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
-    else if ((spec & 8) && (spec & 1024)) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<2>, 2 * d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
-    else if (spec & 8) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<1>, d.T, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
+    const int lv = loss.value != nullptr ? 1 : 0;           // one workgroup more: the loss value
+    if ((spec & 8) && (spec & 1024) && (spec & 4096)) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<4>, 4 * d.T + lv, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
+    else if ((spec & 8) && (spec & 1024)) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<2>, 2 * d.T + lv, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
+    else if (spec & 8) MLHOT_TRY(tail_launch(ts::phaseC_bwd_kernel<1>, d.T + lv, 512, ts::phaseC_bwd_lds_bytes(), c, s, "tail.bwd.C"));
     else MLHOT_TRY(tail_launch(tf::phaseC_bwd_kernel, d.T, 512, tf::phaseC_bwd_lds_bytes(td), c, s, "tail.bwd.C"));
   }
   // sc.dqh / dkh / dvh double as the heads' input-gradient shares [T*H][N][dw] (same sizes)
@@ -525,7 +527,7 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
 
   // The loss's gradient, when the caller left it to this call (mlhot_np_vanilla_bwd_loss): the specialised phase C' derives it in
   // its prologue; every other first kernel gets it materialised (dmu_tmp = dmu + d loss / d mu, one launch as mlhot_loss_bwd's).
-  LossDesc in_kernel{-1, nullptr, 0, nullptr};
+  LossDesc in_kernel{-1, nullptr, 0, nullptr, nullptr};
   if (loss != nullptr) {
     if (st.staged()) { set_error("np_vanilla_bwd: the staged pass takes dmu, not a loss descriptor"); return MLHOT_ERR_UNSUPPORTED; }
 #ifndef MLHOT_HOSTSIM
@@ -533,6 +535,8 @@ inline int np_backward(const mlhot_np_dims& d, const mlhot_np_params& p, const f
     if (!tail_fused_applies(d) && cnp_spec_applies(d) && (g_opt.tail_spec & 8) && (g_opt.tail_spec & 128)) in_kernel = *loss;
 #endif
     if (in_kernel.kind < 0) {
+      // (the loss VALUE, when the caller left that to this call as well: the launch mlhot_loss_fwd would have made)
+      if (loss->value != nullptr) MLHOT_TRY(run_reduce1(LossRed{loss->kind, d.y_dim, loss->gt_dim, Rq, mu, loss->gt, loss->value}, Rq, s, "loss_fwd"));
       MLHOT_TRY(run_foreach(LossBwd{loss->kind, d.y_dim, loss->gt_dim, Rq, mu, loss->gt, loss->dloss, sc.dmu_tmp, dmu}, (size_t)Rq, s, "loss_bwd"));
       dmu = sc.dmu_tmp;
     }

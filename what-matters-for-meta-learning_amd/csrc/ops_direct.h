@@ -396,6 +396,33 @@ struct LossBwd {
 };
 
 // The loss whose gradient a model's backward takes itself (mlhot_np_vanilla_bwd_loss): kind < 0 = none
-struct LossDesc { int kind; const float* gt; int gt_dim; const float* dloss; };
+struct LossDesc { int kind; const float* gt; int gt_dim; const float* dloss; float* value; };
+
+#ifndef MLHOT_HOSTSIM
+// The loss VALUE by one extra workgroup of the model's first backward kernel (LossDesc.value != nullptr): nothing in the backward
+// reads the value, but as a launch of its own the reduction sits between the forward's last kernel and the backward's first (4.9 us
+// of c3's step + a kernel boundary; as a forked graph branch it cost the step +22 us).  reduce1_kernel<LossRed>'s arithmetic thread for
+// thread - virtual thread v of 1024 sums rows v, v + 1024, ... into the same four accumulators, then the same LDS tree - so the
+// value has the bits of mlhot_loss_fwd's.  sm: 1024 floats of LDS; any block size.
+__device__ __forceinline__ void loss_value_block(const LossRed& r, int n, float* sm) {
+  const int nt = (int)blockDim.x, tid = (int)threadIdx.x;
+  for (int v = tid; v < 1024; v += nt) {
+    float a0 = r.identity(), a1 = r.identity(), a2 = r.identity(), a3 = r.identity();
+    int i = v;
+    for (; i + 3072 < n; i += 4096) {
+      a0 = r.combine(a0, r.load(i)); a1 = r.combine(a1, r.load(i + 1024));
+      a2 = r.combine(a2, r.load(i + 2048)); a3 = r.combine(a3, r.load(i + 3072));
+    }
+    for (; i < n; i += 1024) a0 = r.combine(a0, r.load(i));
+    sm[v] = r.combine(r.combine(a0, a1), r.combine(a2, a3));
+  }
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    for (int v = tid; v < s; v += nt) sm[v] = r.combine(sm[v], sm[v + s]);
+    __syncthreads();
+  }
+  if (tid == 0) r.finish(sm[0]);
+}
+#endif
 
 }  // namespace mlhot

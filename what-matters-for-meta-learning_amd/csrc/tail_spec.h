@@ -867,6 +867,10 @@ __global__ __launch_bounds__(512) void phaseC_bwd_kernel(const PhaseCBwdArgs a) 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   lptr L0 = (lptr)lds;
   const TailDims& d = a.d;
+  if (a.loss.value != nullptr && (int)blockIdx.x == GR * d.T) {            // one workgroup more than the tasks need: the loss VALUE (ops_direct.h)
+    loss_value_block(LossRed{a.loss.kind, d.y_dim, a.loss.gt_dim, d.T * d.Nq, a.mu, a.loss.gt, a.loss.value}, d.T * d.Nq, lds);
+    return;
+  }
   const int t = (int)blockIdx.x / GR, grp = (int)blockIdx.x % GR;          // GR workgroups per task
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), gwave = grp * NWV + wave;
   const bool first = grp == 0;

@@ -56,7 +56,7 @@ class NpGrads(C.Structure):
 
 class LossDesc(C.Structure):
     """mlhot_loss_desc: the loss whose gradient mlhot_np_vanilla_bwd_loss takes itself."""
-    _fields_ = [("kind", C.c_int), ("gt", C.c_void_p), ("gt_dim", C.c_int), ("dloss", C.c_void_p)]
+    _fields_ = [("kind", C.c_int), ("gt", C.c_void_p), ("gt_dim", C.c_int), ("dloss", C.c_void_p), ("value", C.c_void_p)]
 
 
 # (struct path, state_dict key) for the vanilla CNP/ANP family
@@ -949,8 +949,9 @@ class MlhotLib:
         return mu, saved, scratch
 
     def np_vanilla_bwd(self, dims, params, ctx_x, ctx_y, qry_x, mu, dmu, saved, scratch=None, proj=None, exchange=None, loss=None):
-        """loss: None, or (kind, gt, dloss) - the loss whose gradient the call takes itself (mlhot_np_vanilla_bwd_loss): the gradient
-        of mu is then dmu (may be None) + d loss / d mu * dloss."""
+        """loss: None, or (kind, gt, dloss[, value]) - the loss whose gradient the call takes itself (mlhot_np_vanilla_bwd_loss): the
+        gradient of mu is then dmu (may be None) + d loss / d mu * dloss; `value`: None, or the scalar tensor that receives the loss
+        VALUE from the same call (what loss_fwd would have written)."""
         _chk(dmu, mu)
         if loss is not None and exchange is not None:
             raise MlhotError("np_vanilla_bwd: the staged pass takes dmu, not a loss descriptor")
@@ -974,11 +975,14 @@ class MlhotLib:
                 _ptr(scratch), sb, st, xp, _stream(qry_x)), "mlhot_np_vanilla_bwd_staged"), exchange, "bwd")
             return grads
         if loss is not None:
-            kind, gt, dloss = loss
+            kind, gt, dloss, *rest = loss
+            value = rest[0] if rest else None
             _chk(gt, dloss)
+            if value is not None:
+                _chk(value)
             if gt.numel() % (dims.T * dims.Nq) or LOSS[kind] == LOSS["degree"]:
                 raise MlhotError(f"np_vanilla_bwd: loss {kind!r} with labels {tuple(gt.shape)} does not fit mu {tuple(mu.shape)}")
-            ld = LossDesc(LOSS[kind], _ptr(gt), gt.numel() // (dims.T * dims.Nq), _ptr(dloss))
+            ld = LossDesc(LOSS[kind], _ptr(gt), gt.numel() // (dims.T * dims.Nq), _ptr(dloss), _ptr(value))
             self._rc(self.c.mlhot_np_vanilla_bwd_loss(C.byref(dims), C.byref(ps), _ptr(ctx_x), _ptr(ctx_y), _ptr(qry_x), _ptr(mu), _ptr(dmu),
                                                       C.byref(ld), C.byref(gs), _ptr(saved), _ptr(scratch), sb, _stream(qry_x)), "mlhot_np_vanilla_bwd_loss")
             return grads

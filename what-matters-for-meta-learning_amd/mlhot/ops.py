@@ -44,13 +44,15 @@ def _zero_like(mu):
     return z
 
 
-# The loss VALUE off the critical path (opt-in; measured and NOT adopted): inside `with loss_value_aside():` the reduction that
-# produces the loss scalar runs on a forked stream (a parallel branch of a captured graph) and is joined when the block ends -
-# nothing in the backward needs the value; the caller promises not to read the loss before the block ends.  Round 5, c3: the
-# replayed step went 0.585 -> 0.608 ms with it (a two-branch graph costs the step's other kernels more than the 4.7 us
-# reduction it takes out of the chain; the same was seen with the eps draw as a graph branch in round 4).  trainer.ModelTrainer
-# (config.loss_aside) and bench.py (--loss-aside) keep it for the A/B.
-_loss_lane = None
+# The loss VALUE off the critical path.  Nothing in the backward reads the value, but as a launch of its own the reduction sits
+# between the forward's last kernel and the backward's first.  Inside `with loss_value_aside():` a loss whose gradient is deferred to
+# the model's backward (above) defers its value too: LossFunction.forward returns an UNWRITTEN scalar and the model's first backward
+# kernel fills it from one extra workgroup (mlhot_loss_desc.value; the bits of mlhot_loss_fwd's result).  The caller promises to run
+# the backward before it reads the loss and not to compute with the value in between (loss + kl * beta does: trainer.ModelTrainer
+# switches this on only for a bare loss) - bench.py's step and the trainer's step are such callers.  Round 5: the first form of this
+# switch ran the reduction on a forked stream (a parallel branch of the captured graph): 0.585 -> 0.608 ms per c3 step - a two-branch
+# graph costs the step's other kernels more than the 4.7 us it takes out of the chain; this form has no branch.
+_loss_aside = False
 
 
 class loss_value_aside:
@@ -58,37 +60,14 @@ class loss_value_aside:
         self.enabled = enabled
 
     def __enter__(self):
-        global _loss_lane
-        self.prev = _loss_lane
-        _loss_lane = {"stream": None, "forked": []} if self.enabled else None
+        global _loss_aside
+        self.prev, _loss_aside = _loss_aside, bool(self.enabled)
         return self
 
     def __exit__(self, *exc):
-        global _loss_lane
-        lane, _loss_lane = _loss_lane, self.prev
-        if lane:
-            for cur, side in lane["forked"]:
-                cur.wait_stream(side)                 # the join: from here on the loss value is ordered like any other tensor
+        global _loss_aside
+        _loss_aside = self.prev
         return False
-
-
-_lane_streams = {}
-
-
-def _loss_fwd(kind, mu, gt):
-    lane = _loss_lane
-    if lane is None or not mu.is_cuda:
-        return lib().loss_fwd(kind, mu, gt)
-    cur = torch.cuda.current_stream(mu.device)
-    side = _lane_streams.get(mu.device)
-    if side is None:
-        side = _lane_streams[mu.device] = torch.cuda.Stream(mu.device)
-    side.wait_stream(cur)                             # the fork: behind the kernel that wrote mu
-    with torch.cuda.stream(side):
-        loss = lib().loss_fwd(kind, mu, gt)
-    loss.record_stream(cur)
-    lane["forked"].append((cur, side))
-    return loss
 
 
 def _need_gpu(*ts):
@@ -454,15 +433,23 @@ class LossFunction(torch.autograd.Function):
         ctx.node = node if (defer_loss_grad and kind != "degree" and mu_c is mu and getattr(node, "takes_loss", False)
                             and not mu.retains_grad and not mu._backward_hooks) else None
         ctx.save_for_backward(mu_c, gt)
-        return _loss_fwd(kind, mu_c, gt)
+        ctx.value = None
+        if ctx.node is not None and _loss_aside:          # (node: mu carries a graph, i.e. a backward can follow)
+            out = torch.empty((), device=mu_c.device)             # written by the model's backward (loss_value_aside above)
+            ctx.value = out.detach()                               # (the same storage without the output's grad_fn: no reference cycle)
+            return out
+        return lib().loss_fwd(kind, mu_c, gt)
 
     @staticmethod
     def backward(ctx, dloss):
         mu, gt = ctx.saved_tensors
         dloss = _c(dloss.float())
         if ctx.node is not None and ctx.node.loss is None:
-            ctx.node.loss = (ctx.kind, gt, dloss)        # VanillaNPFunction.backward runs next (it is this gradient's only consumer node)
+            # VanillaNPFunction.backward runs next (it is this gradient's only consumer node)
+            ctx.node.loss = (ctx.kind, gt, dloss) if ctx.value is None else (ctx.kind, gt, dloss, ctx.value)
             return None, _zero_like(mu), None
+        if ctx.value is not None:                         # the producer's slot was taken (a second loss on the same mu): the value now
+            ctx.value.copy_(lib().loss_fwd(ctx.kind, mu, gt))
         return None, lib().loss_bwd(ctx.kind, mu, gt, dloss), None
 
 

@@ -198,8 +198,8 @@ class ModelTrainer(BaseTrainer):
         else:
             pr_mu, pr_var, kl = self.model(ctx_x, ctx_y, qry_x)
             contra_loss = None
-        # config.loss_aside (default off): with the bare loss as the objective (no KL / contrastive term reads its value) its reduction
-        # may run on a forked stream beside the backward - measured SLOWER as a branch of the captured graph (+22 us per c3 step)
+        # config.loss_aside (default on): with the bare loss as the objective (no KL / contrastive term computes with its value) the value
+        # is left to the model's first backward kernel (mlhot.ops.loss_value_aside) - it is read after the backward, below
         with loss_value_aside(enabled=self._bare_loss(kl, contra_loss)):
             losses = add_scaled(self.loss.calc_loss(pr_mu, pr_var, qry_y), kl, self.config.beta)
             if contra_loss is not None:
@@ -210,7 +210,7 @@ class ModelTrainer(BaseTrainer):
         return losses.detach()
 
     def _bare_loss(self, kl, contra_loss):
-        return (bool(getattr(self.config, "loss_aside", False)) and contra_loss is None and not isinstance(kl, torch.Tensor)
+        return (bool(getattr(self.config, "loss_aside", True)) and contra_loss is None and not isinstance(kl, torch.Tensor)
                 and (not kl or not self.config.beta))
 
     def _graph_train_iter(self, it):
