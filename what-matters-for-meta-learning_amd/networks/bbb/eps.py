@@ -40,6 +40,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
+from mlhot.binding import MlhotError
+
 _active = None        # the StagedEps the layers read from (None: the reference's lazy route); callers are single-threaded
 _recorder = None
 
@@ -74,6 +76,9 @@ class StagedEps:
     def recording(self):
         global _recorder
         self.shapes, self._offsets, self._runs, self._pieces = [], None, None, None
+        if self._pool is not None:
+            self._pool.shutdown(wait=False)          # a new recording re-plans the pieces: the old plan's threads are not needed
+            self._pool = None
         _recorder = self
         try:
             yield self
@@ -165,7 +170,7 @@ class StagedEps:
         self._pieces = keep
         try:
             ok = torch.equal(ref, self.draw_host(torch.zeros(self._total), g)) and torch.equal(after, g.get_state())
-        except Exception:                            # noqa: BLE001 - e.g. the library is missing: the one-thread draw needs nothing
+        except (ImportError, OSError, MlhotError):   # no library to position the generators with: the one-thread draw needs nothing
             ok = False
         if not ok:
             self._pieces = None
