@@ -272,6 +272,7 @@ def measure_host_fed(w, device, loss_fn, model, iters):
                        computes -> mlhot_ingest_u8_nhwc -> the step (mlhot.ingest.BatchIngest)."""
     from mlhot import synth
     from mlhot.ingest import BatchIngest
+    from mlhot.ops import loss_grad_in_backward
     hb = synth.get_batch_u8("shapenet_1d", T_LOCAL, NC, NQ, seed=1234)
     ing = BatchIngest(device)
     ing.stage(*hb)
@@ -279,7 +280,8 @@ def measure_host_fed(w, device, loss_fn, model, iters):
 
     def step():
         model.zero_grad(set_to_none=True)
-        loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+        with loss_grad_in_backward():
+            loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
 
     graph = _capture(step)
     out = {}
@@ -336,6 +338,7 @@ def measure_variable_nc(w, device, loss_fn, model, batch, iters):
     """The reference's TRAINING batches draw the context size per iteration (dataset/shapenet_1d.py:120: 3..shot); the
     target count stays `shot`.  One captured hipGraph per context size, replayed in a seeded random order."""
     import numpy as np
+    from mlhot.ops import loss_grad_in_backward
     cx, qx, cy, qy = batch
     graphs, ins = {}, {}
     for nc in range(3, NC + 1):
@@ -343,7 +346,8 @@ def measure_variable_nc(w, device, loss_fn, model, batch, iters):
 
         def step(nc=nc):
             model.zero_grad(set_to_none=True)
-            loss_fn.calc_loss(model(ins[nc][0], ins[nc][1], qx)[0], None, qy).backward()
+            with loss_grad_in_backward():
+                loss_fn.calc_loss(model(ins[nc][0], ins[nc][1], qx)[0], None, qy).backward()
 
         graphs[nc] = _capture(step)
     order = np.random.RandomState(0).randint(3, NC + 1, size=4 * iters)
@@ -410,6 +414,7 @@ def measure_train_loop(w, device, loss_fn, iters):
     from mlhot import synth
     from mlhot.ingest import BatchIngest
     from mlhot.optim import FlatAdam
+    from mlhot.ops import loss_grad_in_backward
     cls = getattr(importlib.import_module("networks." + w["method"]), w["method"])
     hb = synth.get_batch_u8("shapenet_1d", T_LOCAL, NC, NQ, seed=1234)
     host = [synth.host_convert(hb[0]), synth.host_convert(hb[1]), hb[2], hb[3]]
@@ -433,6 +438,7 @@ def measure_train_loop(w, device, loss_fn, iters):
         cfg = make_cfg(w, device)
         cfg.iterations, cfg.val_freq, cfg.val_iters, cfg.bg_gen_freq, cfg.gen_bg = 4, 10 ** 9, 1, 10 ** 9, False
         cfg.save_path, cfg.logger, cfg.contrastive, cfg.max_ctx_num, cfg.beta = tmp, None, False, NC, 0
+        cfg.close_after_train = False
         model = cls(cfg).to(device)
         tr = ModelTrainer(model=model, loss=loss_fn, optimizer=torch.optim.Adam(model.parameters(), lr=1e-4), config=cfg, data=HostLoader())
         tr.train()                                      # 4 iterations: eager warm-up of the batch shape, capture, two replays (+ the final checkpoint)
@@ -446,8 +452,30 @@ def measure_train_loop(w, device, loss_fn, iters):
             torch.cuda.synchronize()
             if timed:
                 out["reference_style_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_ref
+        feed = tr._host_prefetch.u8 if tr._host_prefetch is not None else None
         out["reference_style_promoted"] = {"optimizer": type(tr.optimizer).__name__, "graph_replay": bool(tr._graph_default),
-                                           "host_batch_prefetch": tr._host_prefetch is not None}
+                                           "host_batch_prefetch": tr._host_prefetch is not None,
+                                           "host_batches_as_bytes": ({"shipped": feed.shipped, "refused": feed.refused, "host_threads": feed.threads,
+                                                                      "bytes_per_batch": int(host[0].numel() + host[1].numel() + 4 * (host[2].numel() + host[3].numel()))}
+                                                                     if feed is not None else None)}
+        # the same loop with the byte route off (config.host_u8 = False): the round-5 form, fp32 over PCIe behind the step
+        cfg2 = make_cfg(w, device)
+        cfg2.iterations, cfg2.val_freq, cfg2.val_iters, cfg2.bg_gen_freq, cfg2.gen_bg = 4, 10 ** 9, 1, 10 ** 9, False
+        cfg2.save_path, cfg2.logger, cfg2.contrastive, cfg2.max_ctx_num, cfg2.beta = tmp, None, False, NC, 0
+        cfg2.close_after_train, cfg2.host_u8 = False, False
+        model2 = cls(cfg2).to(device)
+        tr2 = ModelTrainer(model=model2, loss=loss_fn, optimizer=torch.optim.Adam(model2.parameters(), lr=1e-4), config=cfg2, data=HostLoader())
+        tr2.train()
+        tr2.iterations = 10 ** 9
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for it in range(5, 5 + n_ref):
+                tr2._prefetch = True
+                tr2._train_iter(it)
+            torch.cuda.synchronize()
+            if timed:
+                out["reference_style_fp32_over_pcie_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_ref
     # the same sequence with nothing promoted: eager autograd, torch.optim.Adam over ~70 tensors, the copy in front of the step
     model = cls(make_cfg(w, device)).to(device)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
@@ -474,8 +502,9 @@ def measure_train_loop(w, device, loss_fn, iters):
 
     def it():
         opt.zero_grad()
-        loss = loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy)
-        loss.backward()
+        with loss_grad_in_backward():
+            loss = loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy)
+            loss.backward()
         opt.step()
         return loss.detach()
 
@@ -537,6 +566,7 @@ def measure_train_loop_3d(w, device, loss_fn, iters):
             cfg = make_cfg(w, device)
             cfg.iterations, cfg.val_freq, cfg.val_iters, cfg.bg_gen_freq, cfg.gen_bg = 4, 10 ** 9, 1, 10 ** 9, False
             cfg.save_path, cfg.logger, cfg.contrastive, cfg.max_ctx_num = tmp, None, False, NC
+            cfg.close_after_train = False                  # the timed loop below keeps calling _train_iter: tr.close() in the finally
             if not promoted:
                 cfg.promote_optimizer, cfg.graph_steps, cfg.host_prefetch = False, False, False
             model = cls(cfg).to(device)
@@ -561,6 +591,8 @@ def measure_train_loop_3d(w, device, loss_fn, iters):
                     if tr._eps and tr._eps._worker is not None:
                         tr._eps.stage()                     # collect the last prefetch: the CPU generator is free again
             finally:
+                if "tr" in locals():
+                    tr.close()
                 binding.set_grad_arena(None)
     out["tasks_per_s"] = {"reference_style": 1e3 * w["T"] / out["reference_style_ms_per_iter"],
                           "reference_style_unpromoted": 1e3 * w["T"] / out["reference_style_unpromoted_ms_per_iter"]}
@@ -573,6 +605,7 @@ def measure_extras(w, device, loss_fn, batch, iters):
     leg is timing only: inside a replayed graph the bias-correction step count is frozen at capture time."""
     import importlib
     from mlhot.optim import FlatAdam
+    from mlhot.ops import loss_grad_in_backward
     cx, qx, cy, qy = batch
     try:
         model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(make_cfg(w, device)).to(device)
@@ -583,7 +616,8 @@ def measure_extras(w, device, loss_fn, batch, iters):
 
         def step_adam():
             model.zero_grad(set_to_none=True)
-            loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+            with loss_grad_in_backward():
+                loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
             opt.step()
 
         out = {"fwd_only_ms": _time_graph(fwd, iters), "step_with_flat_adam_ms": _time_graph(step_adam, iters),
@@ -594,7 +628,8 @@ def measure_extras(w, device, loss_fn, batch, iters):
 
         def step():
             model.zero_grad(set_to_none=True)
-            loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
+            with loss_grad_in_backward():
+                loss_fn.calc_loss(model(cx, cy, qx)[0], None, qy).backward()
 
         # bits: 1 forward, 2 data gradient, 4 weight gradient.  Its own roof next to the fp32 one: the bf16 matrix pipe's dense 2.5 PFLOP/s
         # (MI355X_MICROARCH.md) / 6 piece products = 417 fp32-equivalent TFLOP/s (fp32 MFMA: 157.3)
@@ -634,6 +669,41 @@ def measure_extras(w, device, loss_fn, batch, iters):
         return out
     except Exception as e:  # noqa: BLE001 - extras must never break the bench line
         return {"error": f"{type(e).__name__}: {e}"}
+
+
+def measure_other_configs(keys, steps, warmup, timeout_s=600):
+    """extras.configs: the other BASELINE configs that fit one GPU - c2 (configs[1]) and c5 (the per-GPU share of configs[4]) - each
+    timed by a CHILD process running this file with `--workload <key>` under the same protocol (pre-warm, W warm-up steps, EXACTLY K
+    timed steps between fences, hipGraph replay, the per-launch HIP-event roofline leg), after this process's own timed region is
+    over and its GPU work drained.  A child is a fresh process (started, never exec'ed over this one); `value` stays c3's."""
+    import subprocess
+    out = {}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "MLHOT_BENCH_SEQ", "MLHOT_BENCH_KERNELS", "MLHOT_BENCH_LAUNCHER", "MLHOT_FORCE_COLLECTIVES")}
+    for key in keys:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", key, "--steps", str(steps), "--warmup", str(warmup),
+               "--no-extras", "--no-cpu-baseline", "--no-configs"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[key] = {"error": f"rc {r.returncode}: {(r.stderr or '').strip()[-300:]}"}
+                continue
+            j = json.loads(lines[-1])
+            roof = j.get("roofline") or {}
+            out[key] = {"workload": j["config"]["workload"], "ms_per_step": j["ms_per_step"], "ms_per_step_event_median": j.get("ms_per_step_event_median"),
+                        "tasks_per_s": j["value"], "steps": j["steps"], "warmup": j["warmup"], "hipgraph": j.get("hipgraph"),
+                        "steps_per_graph": j.get("steps_per_graph"), "final_loss": j.get("final_loss"),
+                        "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+                                                              "launches_per_step", "alg_flops_per_launch")},
+                        "fwd_only_ms": (roof.get("forward") or {}).get("fwd_ms"),
+                        "launches_per_step": j.get("launches_per_step"), "gpu_busy_us_per_step": j.get("gpu_busy_us_per_step"),
+                        "eps_source": j["config"].get("eps_source"), "eps": j.get("eps"), "library_sha256": (j.get("library") or {}).get("sha256"),
+                        "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:  # noqa: BLE001 - extras must never break the bench line
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def forward_roofline(w, fwd_ms):
@@ -782,6 +852,8 @@ def main():
                          "the staged C calls, so the step runs eagerly (implies --no-graph).  Default: each rank's own maximum "
                          "(negligible for ANPShapeNet1D, up to 15 %% of a gradient's scale for the d = 256 models, DESIGN.md section 6d)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fwd-only / +Adam timing legs")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="default workload, one GPU: skip extras.configs (c2 and c5 timed by child processes of this file after the headline's timed region)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the ~0.1 s of untimed steps in front of the W warm-up steps")
     ap.add_argument("--no-loss-aside", action="store_true",
                     help="A/B: the loss VALUE as a launch of its own between forward and backward (mlhot_loss_fwd) instead of one extra workgroup of "
@@ -1059,7 +1131,23 @@ def main():
             extras["train_loop"] = measure_train_loop_3d(w, device, loss_fn, max(10, args.steps // 2))
         except Exception as e:  # noqa: BLE001 - extras must never break the bench line
             extras = dict(extras or {}, error=f"{type(e).__name__}: {e}")
+    if world == 1 and not mdist.force_collectives() and args.workload == "c3" and not args.no_extras and not args.no_configs and not args.no_graph:
+        torch.cuda.synchronize()
+        extras = dict(extras or {})
+        extras["configs"] = measure_other_configs(("c2", "c5"), steps=20, warmup=5)
+    per_rank = None
     if dist.is_initialized():
+        # every rank's loss of the last timed step (rank-local: the ranks hold different tasks) and a checksum of its gradients after
+        # the last all-reduce (the SUM over ranks, still unscaled: the same bits on every rank, or the collective is broken)
+        torch.cuda.synchronize()
+        live = [p.grad for p in bucket.params if p.grad is not None]
+        mine = torch.stack([torch.as_tensor(final_loss, dtype=torch.float64, device=device),
+                            torch.stack([g.double().sum() for g in live]).sum() if live else torch.zeros((), dtype=torch.float64, device=device),
+                            torch.stack([g.double().abs().sum() for g in live]).sum() if live else torch.zeros((), dtype=torch.float64, device=device)])
+        table = torch.zeros(world, 3, dtype=torch.float64, device=device)
+        table[rank] = mine
+        dist.all_reduce(table, op=dist.ReduceOp.SUM)            # an all-gather spelled as a sum of one-hot rows (every backend takes it)
+        per_rank = {"final_loss": table[:, 0].tolist(), "grad_sum": table[:, 1].tolist(), "grad_abs_sum": table[:, 2].tolist()}
         dist.barrier()
 
     if rank == 0:
@@ -1071,12 +1159,14 @@ def main():
                           "context_shots": NC, "target_shots": NQ, "image": w["image"],
                           "parallelism": f"task-sharded x{world}, one flat grad all-reduce" if world > 1 else "single GPU"},
                "dist": ({"backend": dist.get_backend(), "ranks_reported_by_backend": dist.get_world_size(),
-                         "collectives_per_step": replay_collectives,
+                         "collectives_per_step": replay_collectives, "per_rank": per_rank,
                          "step_graphs": (2 if split and graphed else 1) if graphed else 0,
                          "launcher": "bench.py itself (spawn_ranks)" if os.environ.get("MLHOT_BENCH_LAUNCHER") == "self" else "external (WORLD_SIZE in the environment)"}
                         if dist.is_initialized() else None),
                "library": _library_id(),
-               "final_loss": final_loss, "hipgraph": graphed, "steps_per_graph": spg, "key_stabiliser": stabiliser, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
+               "final_loss": final_loss, "hipgraph": graphed, "steps_per_graph": spg,
+               "steps_per_graph_note": (f"`value` replays {spg} consecutive steps per hipGraph launch (a bench arrangement: ~9 us of launch gap paid once per {spg} "
+                                        "steps); a training loop replays ONE iteration per graph - extras.train_loop.replayed_ms_per_iter") if spg > 1 else None, "key_stabiliser": stabiliser, "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
                "ms_per_step_event_median": step_ms[len(step_ms) // 2], "ms_per_step_event_min": step_ms[0], "ms_per_step_event_max": step_ms[-1],
                "timing": f"value = wall clock over {args.steps} steps ({n_run} graph launches of {spg} step(s)) between two barrier + synchronize fences (max over ranks), "
                          f"after {prewarm * spg} untimed pre-warm steps and the {args.warmup} warm-up steps; "
@@ -1095,8 +1185,11 @@ def main():
         if eps is not None and eps.source == "host":
             d0 = time.perf_counter()
             eps.stage()
+            from networks.bbb.eps import usable_cores
             out["eps"] = {"source": "host", "floats_per_step": eps._total, "host_draw_ms_per_step": 1e3 * (time.perf_counter() - d0),
                           "host_threads": len(eps._pieces) if eps._pieces else 1,
+                          "host_threads_per_rank": {"eps_draw_pieces": len(eps._pieces) if eps._pieces else 1, "eps_drawer": 1, "main": 1},
+                          "usable_cores": usable_cores(), "ranks_on_node": int(os.environ.get("LOCAL_WORLD_SIZE") or world),
                           "note": "drawn on the torch CPU generator in the reference's order (bit-identical samples and final generator state) "
                                   "while the previous step runs; the draw is cut into host_threads pieces, each drawn by normal_() on a "
                                   "generator positioned with mlhot_mt19937_advance (MLHOT_EPS_THREADS); a step costs max(GPU time, draw time)"}

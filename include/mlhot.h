@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLHOT_ABI_VERSION 5
+#define MLHOT_ABI_VERSION 6
 
 enum { MLHOT_ACT_NONE = 0, MLHOT_ACT_RELU = 1, MLHOT_ACT_TANH = 2 };
 enum { MLHOT_AGG_MEAN = 0, MLHOT_AGG_MAX = 1, MLHOT_AGG_BACO = 2, MLHOT_AGG_ATTENTION = 3 };
@@ -91,6 +91,14 @@ int mlhot_mt19937_normal_par(uint32_t* engine, float* uniform_ws, float* out, co
  * `normal_()` stream at once, each on a torch.Generator set to its piece's starting state (networks/bbb/eps.py, bit-identical to
  * the sequential draw of bbb/BBBConv.py:86-95).                                                                              */
 int mlhot_mt19937_advance(uint32_t* engine, uint64_t n_outputs);
+
+/* Host only (no device, no stream; ABI 6): the inverse of the loaders' host conversion `img.astype(float32) / 255.0`
+ * (dataset/shapenet_1d.py:189-190, dataset/shapenet_3d.py, utils/utils.py:26-30), checked element by element: dst[i] = the byte k
+ * nearest to src[i] * div, *n_inexact = the number of elements whose (float)k / div differs from src[i] in any bit.  When it is 0
+ * the batch may cross PCIe as the n bytes of dst and mlhot_ingest_u8_nhwc (same div) reproduces src bit for bit on the device;
+ * otherwise the caller ships the fp32 data as before.  Element order is kept (a channel-first fp32 batch gives channel-first bytes:
+ * ingest it as [n_img * C, H, W, 1]).  Thread-safe; callers split large batches over host threads (mlhot/ingest.py).        */
+int mlhot_host_f32_to_u8_exact(const float* src, uint8_t* dst, int64_t n, float div, int64_t* n_inexact);
 
 /* ---- E1: vanilla image encoder `encoder_w0` -------------------------------------------
  * replaces nn.Sequential(conv3x3s2+ReLU, conv3x3s2+ReLU, MaxPool2d(2), conv3x3s2+ReLU,

@@ -220,6 +220,60 @@ def run_resnet_case(name, method, cfgd, Nc, Nq, C, LossFunc):
     print(f"{name}: loss={loss.item():.8f} sum(mu)={mu.sum().item():.8f} params={meta['n_params']}")
 
 
+# BASELINE configs[4]'s per-GPU share at its REAL size: ANPMRShapeNet3D, 8 tasks x (15 + 15) resp. the training
+# draw's (7 + 23) 3x64x64 views, torch.manual_seed(99) right before the forward, backward on loss + 1e-7 * kl.  Inputs follow
+# tests/test_gpu_parity.py::test_c5_full_size_forward_backward_vs_oracle (one generator seeded 1234: images U[0, 1), labels =
+# normalised N(0, 1)^4 quaternions).  Weights by sha, gradients as norms + heads + strided samples: ~2 MB per case.
+# `labels`: "quat" as described; "rand" = SURVEY.md section 8c's recipe (cx, qx, cy, qy all torch.rand from the one generator), whose
+# answers the survey recorded: loss 2.26335859, kl 1383162.5, |grad| 2.12012622.  The FAVOR+ projection buffer (1.45 MB, the same
+# for every fixture of this model and seed) is NOT repeated: tests load it from r_anpmr_shapenet3d.npz (sha-checked).
+C5_FULL_CASES = {"c5_anpmr_shapenet3d_t8": (15, 15, "quat"), "c5_anpmr_shapenet3d_t8_7_23": (7, 23, "quat"),
+                 "c5_anpmr_shapenet3d_t8_survey": (15, 15, "rand")}
+
+
+def run_c5_full_case(name, Nc, Nq, labels, LossFunc):
+    cfgd = dict(task="shapenet_3d", img_size=[64, 64, 4], tasks_per_batch=8, input_dim=4, output_dim=4, agg_mode="attention",
+                img_agg="reshape", seed=2578, temperature=0.07)
+    cfg = types.SimpleNamespace(device=torch.device("cpu"), **cfgd)
+    model = importlib.import_module("networks.ANPMRShapeNet3D").ANPMRShapeNet3D(cfg)
+    T = 8
+    g = torch.Generator().manual_seed(1234)
+    cx, qx = torch.rand(T, Nc, 3, 64, 64, generator=g), torch.rand(T, Nq, 3, 64, 64, generator=g)
+    if labels == "quat":
+        cy = torch.nn.functional.normalize(torch.randn(T, Nc, 4, generator=g), dim=-1)
+        qy = torch.nn.functional.normalize(torch.randn(T, Nq, 4, generator=g), dim=-1)
+    else:
+        cy, qy = torch.rand(T, Nc, 4, generator=g), torch.rand(T, Nq, 4, generator=g)
+    model.train()
+    torch.manual_seed(99)
+    mu, var, kl = model(cx, cy, qx)
+    assert var is None
+    loss = LossFunc("mse", cfg.task).calc_loss(mu, var, qy)
+    (loss + 1e-7 * kl).backward()
+    out = {"mu": np32(mu), "loss": np.float64(loss.item()), "kl": np.float64(float(kl))}
+    state_sha, grad_norm, total = {k: sha(v) for k, v in model.state_dict().items()}, {}, 0.0
+    for k, prm in model.named_parameters():
+        if prm.grad is None:
+            grad_norm[k] = None
+            continue
+        gnp = np32(prm.grad)
+        grad_norm[k] = float(np.linalg.norm(gnp.astype(np.float64)))
+        total += grad_norm[k] ** 2
+        if gnp.nbytes <= 16 * 1024:
+            out["grad/" + k] = gnp
+        else:
+            flat = gnp.reshape(-1)
+            out["gradhead/" + k] = flat[:1024].copy()
+            out["gradstride/" + k] = flat[1::61][:4096].copy()
+    meta = dict(name=name, method="ANPMRShapeNet3D", cfg=cfgd, Nc=Nc, Nq=Nq, C=3, input_seed=1234, eps_seed=99, labels=labels,
+                projection_from="r_anpmr_shapenet3d", state_sha=state_sha,
+                grad_norm=grad_norm, grad_norm_total=total ** 0.5,
+                input_sha=dict(cx=sha(cx), qx=sha(qx), cy=sha(cy), qy=sha(qy)), n_params=sum(p.numel() for p in model.parameters()))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.8f} kl={float(kl):.1f} |grad|={total ** 0.5:.8f} mu[0,0]={mu[0, 0].tolist()} params={meta['n_params']}")
+
+
 def run_fcl_case(name, method, cfgd, Nc, Nq, C, LossFunc):
     cfg = types.SimpleNamespace(device=torch.device("cpu"), **cfgd)
     model = getattr(importlib.import_module(f"networks.{method}"), method)(cfg)
@@ -502,6 +556,10 @@ def main():
         if only and name not in only:
             continue
         run_fcl_case(name, method, cfgd, Nc, Nq, C, LossFunc)
+    for name, (Nc, Nq, labels) in C5_FULL_CASES.items():
+        if only and name not in only:
+            continue
+        run_c5_full_case(name, Nc, Nq, labels, LossFunc)
     if not only or "favor" in only:
         run_favor_cases()
     if not only or "favor_c5" in only:

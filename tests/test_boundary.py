@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in sorted(names):
         assert hasattr(lib, n), f"libmlhot.so does not export {n}"
-    assert mlhot.lib().c.mlhot_version() == mlhot.binding.ABI_VERSION == 5
+    assert mlhot.lib().c.mlhot_version() == mlhot.binding.ABI_VERSION == 6
 
 
 def test_cpu_tensors_fail_loudly():
@@ -152,6 +152,74 @@ def test_mt19937_advance_leaves_the_state_the_draws_would():
         L.mt19937_advance(np.zeros(10, dtype=np.uint32), 1)
 
 
+def test_host_f32_to_u8_exact_checks_every_element():
+    """mlhot_host_f32_to_u8_exact (host only, ABI 6): the loaders' `u8.astype(float32) / 255.0` (dataset/shapenet_1d.py:189-190) inverted
+    with every element checked - all 256 byte values round-trip, and a value one ulp off, a NaN, an infinity, a negative or > 1
+    value each count as inexact (the caller then ships the fp32 batch unchanged)."""
+    import numpy as np
+    import mlhot
+    L = mlhot.lib()
+    u8 = np.concatenate([np.arange(256, dtype=np.uint8), np.random.RandomState(3).randint(0, 256, size=100003).astype(np.uint8)])
+    x = u8.astype(np.float32) / 255.0
+    for n in (0, 1, 7, 256, 32768, 32769, x.size):              # block and vector remainders
+        dst = np.full(x.size, 77, dtype=np.uint8)
+        assert L.host_f32_to_u8_exact(x.ctypes.data, dst.ctypes.data, n) == 0
+        assert np.array_equal(dst[:n], u8[:n]) and (dst[n:] == 77).all()
+    for bad_value in (np.nextafter(x[300], np.float32(2)), np.nextafter(x[300], np.float32(-2)), np.float32("nan"), np.float32("inf"),
+                      np.float32(-0.25), np.float32(1.5), np.float32(0.5)):
+        y = x.copy()
+        y[300] = bad_value
+        y[70000] = bad_value
+        assert L.host_f32_to_u8_exact(y.ctypes.data, dst.ctypes.data, y.size) == 2, bad_value
+    # another divisor (a loader that scales by 1 / 256 is exact too; by 1 / 100 is not for most bytes)
+    x256 = u8.astype(np.float32) / np.float32(256.0)
+    assert L.host_f32_to_u8_exact(x256.ctypes.data, dst.ctypes.data, x256.size, div=256.0) == 0 and np.array_equal(dst, u8)
+    assert L.host_f32_to_u8_exact(x.ctypes.data, dst.ctypes.data, x.size, div=100.0) > 1000
+    with pytest.raises(mlhot.MlhotError):
+        L.host_f32_to_u8_exact(0, dst.ctypes.data, 4)
+
+
+def test_mt19937_advance_from_random_offsets_and_lengths():
+    """The same statement from 200 random (offset, length) pairs: the engine is first moved to a random position inside / across
+    blocks by real draws, then advanced by a random count - lengths from 1 to a few blocks and a few long ones."""
+    import numpy as np
+    import torch
+    import mlhot
+    from mlhot import rng
+    L = mlhot.lib()
+    r = np.random.RandomState(7)
+    g = torch.Generator()
+    for i in range(200):
+        g.manual_seed(int(r.randint(0, 2 ** 31)))
+        off = int(r.randint(0, 3 * 624))
+        n = int(r.randint(1, 4 * 624)) if i % 10 else int(r.randint(10 ** 5, 10 ** 6))
+        if off:
+            torch.empty(off).uniform_(generator=g)
+        before = g.get_state()
+        engine = rng._unpack(before).copy()
+        L.mt19937_advance(engine, n)
+        torch.empty(n).uniform_(generator=g)
+        assert torch.equal(rng._pack(before, engine), g.get_state()), (off, n)
+
+
+def test_eps_thread_default_adapts_to_the_ranks_of_the_node(monkeypatch):
+    """min(4, usable cores // (2 x ranks)), at least 1; an explicit MLHOT_EPS_THREADS is capped by cores // ranks."""
+    from networks.bbb import eps
+    monkeypatch.setattr(eps, "usable_cores", lambda: 128)
+    monkeypatch.delenv("MLHOT_EPS_THREADS", raising=False)
+    for ranks, want in ((1, 4), (8, 4), (16, 4), (32, 2), (64, 1), (128, 1)):
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(ranks))
+        assert eps.default_threads() == want
+    monkeypatch.setattr(eps, "usable_cores", lambda: 8)
+    for ranks, want in ((1, 4), (2, 2), (4, 1), (8, 1)):
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(ranks))
+        assert eps.default_threads() == want
+    monkeypatch.setenv("MLHOT_EPS_THREADS", "16")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    assert eps.default_threads() == 4
+    assert eps.StagedEps("cpu").threads == 4 and eps.StagedEps("cpu", threads=3).threads == 3
+
+
 @pytest.mark.parametrize("threads", [2, 3, 8])
 def test_staged_eps_on_several_host_threads_draws_the_same_stream(threads):
     """networks/bbb/eps.py with `threads` > 1: the recorded sequence cut into pieces, every piece drawn by normal_() on its own generator
@@ -186,6 +254,21 @@ def test_staged_eps_on_several_host_threads_draws_the_same_stream(threads):
         assert torch.equal(torch.get_rng_state(), lazy_state)
         with st.active():
             assert all(torch.equal(a, eps.draw(s_, "cpu")) for a, s_ in zip(lazy, shapes))
+    # from a generator in the MIDDLE of a block, three steps in a row (training's normal case: every step starts where the last ended)
+    st = eps.StagedEps("cpu", threads=threads)
+    torch.manual_seed(11)
+    torch.empty(1001).normal_()
+    start = torch.get_rng_state()
+    with st.recording():
+        lazy = [[eps.draw(s, "cpu") for s in c5] for _ in range(1)]
+    lazy += [[torch.empty(s).normal_(0, 1) for s in c5] for _ in range(2)]
+    lazy_state = torch.get_rng_state()
+    torch.set_rng_state(start)
+    for step in range(3):
+        st.stage()
+        with st.active():
+            assert all(torch.equal(a, eps.draw(s_, "cpu")) for a, s_ in zip(lazy[step], c5)), step
+    assert torch.equal(torch.get_rng_state(), lazy_state)
     one = eps.StagedEps("cpu", threads=1)
     one.shapes = list(c5)
     one._plan()

@@ -422,22 +422,34 @@ def _run_case(gpulib, name):
     assert U.rel_err(mu, mu_r) <= U.RTOL
     flips = _vanilla_flips(routes, pres)
     decisions = _count_decisions(routes)
-    print(f"{name}: {flips} of {decisions} routing decisions differ from the oracle's own (each proven a <= {U.TIE:g} tie); "
-          f"reference-gradient branch {'RUNS' if flips == 0 else 'skipped'}")
     assert flips <= max(1, FLIP_RATE * decisions), f"{name}: {flips} flips in {decisions} decisions"
     gmax = max(p[k].grad.abs().max().item() for k, _ in model.named_parameters() if p[k].grad is not None)
+    worst_routed = (0.0, None)
     for k, _ in model.named_parameters():
         if p[k].grad is None:
             assert grads[k] is None, k           # an empty context leaves the latent path without gradients
             continue
-        assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= U.RTOL, k
-    if flips == 0:
-        U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL)
+        e = U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax)
+        if e >= worst_routed[0]:
+            worst_routed = (e, k)
+        assert e <= U.RTOL, k
+    # the REFERENCE's own gradients (the fixture), always: at 1e-4 when every routing decision equals the reference's, otherwise at
+    # 1e-4 + flips x U.FLIP_SHARE (every differing decision was proven a <= 1e-5 tie above) - never skipped
+    w_fix, k_fix, bound = U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name)
+    line = (f"{name} [{os.environ.get('PYTEST_CURRENT_TEST', '').split('::')[-1].split(' ')[0]}]: {flips} of {decisions} routing decisions differ from the "
+            f"oracle's own (each proven a <= {U.TIE:g} tie); gradients vs the oracle under the kernels' routing: worst {worst_routed[0]:.2e} "
+            f"({worst_routed[1]}) <= {U.RTOL:g}; vs the REFERENCE's own gradients (fixture): worst {w_fix:.2e} ({k_fix}) <= {bound:.2e}")
+    print(line)
+    U.parity_log(line)
     with torch.no_grad():
         model.eval()
         mu_t, _, _ = model(cx.to(DEV), cy.to(DEV), qx.to(DEV), test=True)
         lt = LossFunc("mse", task).calc_loss(mu_t, None, qy.to(DEV), test=True)
-    assert abs(lt.item() - float(fx["loss_test"])) <= 1e-3 * max(1.0, abs(float(fx["loss_test"])))
+    # derived from the 1e-4 bar on mu (tests/util.py::test_loss_allowance: the degree loss's acos is the one amplifying step), not a flat 1e-3
+    allow = U.test_loss_allowance(task, mu_t, qy) + 1e-5 * max(1.0, abs(float(fx["loss_test"])))
+    err_t = abs(lt.item() - float(fx["loss_test"]))
+    U.parity_log(f"{name}: test-mode loss {lt.item():.6f} vs the reference's {float(fx['loss_test']):.6f}: off by {err_t:.2e}, allowed {allow:.2e}")
+    assert err_t <= allow, (name, err_t, allow)
     return flips
 
 
@@ -549,19 +561,16 @@ def test_loss_gradient_taken_inside_the_models_backward(gpulib, method, agg, tas
     seed = torch.full((), 0.75, device=DEV)
 
     def run(defer, second_consumer, aside):
-        ops.defer_loss_grad = defer
-        try:
-            model.zero_grad(set_to_none=True)
-            mu = model(cx, cy, qx)[0]
-            with ops.loss_value_aside(enabled=aside):
-                loss = loss_fn.calc_loss(mu, None, qy)
-                total = loss + 0.3 * (mu * mu).sum() if second_consumer else loss
-                total.backward(gradient=seed)
-            torch.cuda.synchronize()
-            return loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-        finally:
-            ops.defer_loss_grad = True
+        model.zero_grad(set_to_none=True)
+        mu = model(cx, cy, qx)[0]
+        with (ops.loss_value_aside(enabled=True) if aside else ops.loss_grad_in_backward(enabled=defer)):
+            loss = loss_fn.calc_loss(mu, None, qy)
+            total = loss + 0.3 * (mu * mu).sum() if second_consumer else loss
+            total.backward(gradient=seed)
+        torch.cuda.synchronize()
+        return loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
 
+    assert ops.defer_loss_grad is False          # opt-in: outside a scope the two-node form runs
     for second in (False, True):
         ref_loss, ref = run(False, second, False)
         for aside in ((False, True) if not second else (False,)):      # with a second consumer the sum reads the loss inside the block: no lane
@@ -572,10 +581,31 @@ def test_loss_gradient_taken_inside_the_models_backward(gpulib, method, agg, tas
     # the placeholder autograd carried is still all zeros (nothing accumulated into it in place)
     assert all(float(z.abs().max()) == 0.0 for z in ops._zero_grads.values())
     # asking for d loss / d mu itself (retain_grad) keeps the two-node form: the real gradient reaches mu.grad
+    with ops.loss_grad_in_backward():
+        mu = model(cx, cy, qx)[0]
+        mu.retain_grad()
+        loss_fn.calc_loss(mu, None, qy).backward()
+        assert float(mu.grad.abs().max()) > 0
+    # outside a scope a pass that stops at mu gets the real gradient ...
     mu = model(cx, cy, qx)[0]
-    mu.retain_grad()
-    loss_fn.calc_loss(mu, None, qy).backward()
-    assert float(mu.grad.abs().max()) > 0
+    loss = loss_fn.calc_loss(mu, None, qy)
+    real = torch.autograd.grad(loss, mu, retain_graph=True)[0]
+    assert float(real.abs().max()) > 0
+    # ... and inside one it is an ERROR, not a placeholder of zeros; the parked descriptor is gone afterwards, so a later full
+    # backward of the same graph is the plain two-node one
+    mu = model(cx, cy, qx)[0]
+    with ops.loss_grad_in_backward():
+        loss = loss_fn.calc_loss(mu, None, qy)
+        with pytest.raises(RuntimeError, match="placeholder"):
+            torch.autograd.grad(loss, mu, retain_graph=True)
+    assert mu.grad_fn.loss is None
+    model.zero_grad(set_to_none=True)
+    with ops.loss_grad_in_backward():
+        loss.backward(gradient=seed)
+    torch.cuda.synchronize()
+    ref_loss, ref = run(False, False, False)
+    for k in ref:
+        assert torch.equal(model.get_parameter(k).grad, ref[k]), k
 
 
 @pytest.mark.parametrize("name", U.model_case_names("c"))
@@ -682,8 +712,7 @@ def test_resnet_models_vs_reference(gpulib, name):
             flips += int(bad.sum())
             assert not bool((bad & (v.abs() > 1e-5 * v.abs().max())).any()), "routing differs away from a tie"
     decisions = _count_decisions(routes)
-    print(f"{name}: {flips} of {decisions} ReLU decisions differ from the oracle's own; reference-gradient branch "
-          f"{'RUNS' if flips == 0 else 'skipped'}")
+    print(f"{name}: {flips} of {decisions} ReLU decisions differ from the oracle's own")
     assert flips <= max(1, FLIP_RATE * decisions)       # these cases hold 2-5 images: one tie at most
     gmax = max(p[k].grad.abs().max().item() for k, _ in model.named_parameters() if p[k].grad is not None)
     for k, prm in model.named_parameters():
@@ -691,11 +720,11 @@ def test_resnet_models_vs_reference(gpulib, name):
             assert grads[k] is None, k
             continue
         assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= U.RTOL, k
-    if flips == 0:
-        U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
+    # the reference's own gradients, always (1e-4, + U.FLIP_SHARE per decision that sits on a tie and fell the other way)
+    U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name, head=1024, stride_cap=4096)
 
 
-def _anpmr3d_routed_check(model, cx, cy, qx, qy, fx=None, meta=None, dtype=torch.float32):
+def _anpmr3d_routed_check(model, cx, cy, qx, qy, fx=None, meta=None, dtype=torch.float32, fx_kw=None):
     """One seeded forward + backward of an ANPMRShapeNet3D on the device against the oracle under the same eps draws and the
     KERNELS' ReLU routing (2 Bayes-by-backprop encoder passes + the decoder ResNet, 9 masks each); returns (mu, kl, loss, flips).
     `dtype`: the oracle's arithmetic.  fp32 is the reference's own; at the full c5 size the stem's weight gradient is a sum over
@@ -723,8 +752,7 @@ def _anpmr3d_routed_check(model, cx, cy, qx, qy, fx=None, meta=None, dtype=torch
     assert abs(loss.item() - loss_o.item()) <= U.RTOL * max(1.0, abs(loss_o.item()))
     flips = sum(U.relu_flips(m, v, "resnet") for masks, pre in zip(routes, pres) for m, v in zip(masks, pre))
     decisions = _count_decisions(routes)
-    print(f"anpmr3d {tuple(cx.shape)}: {flips} of {decisions} ReLU decisions differ from the oracle's own; reference-gradient "
-          f"branch {'RUNS' if fx is not None and flips == 0 else 'skipped'}")
+    print(f"anpmr3d {tuple(cx.shape)}: {flips} of {decisions} ReLU decisions differ from the oracle's own")
     assert flips <= max(1, FLIP_RATE * decisions)
     gmax = max(p[k].grad.abs().max().item() for k, _ in model.named_parameters() if p[k].grad is not None)
     for k, _ in model.named_parameters():
@@ -732,8 +760,8 @@ def _anpmr3d_routed_check(model, cx, cy, qx, qy, fx=None, meta=None, dtype=torch
             assert grads[k] is None, k       # decoder.resnet.fc.* never receive a gradient
             continue
         assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= U.RTOL, k
-    if fx is not None and flips == 0:
-        U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
+    if fx is not None:
+        U.check_grads_against_fixture_flipped(grads, fx, meta, flips, f"anpmr3d {tuple(cx.shape)} {meta.get('name', '')}", head=1024, stride_cap=4096, **(fx_kw or {}))
     return mu, kl, loss, kl_o, flips
 
 
@@ -751,27 +779,40 @@ def test_anpmr_shapenet3d_vs_reference(gpulib):
     assert abs(loss.item() - float(fx["loss"])) <= U.RTOL * max(1.0, abs(float(fx["loss"])))
 
 
-@pytest.mark.parametrize("Nc,Nq", [(15, 15), (7, 23)])
-def test_c5_full_size_forward_backward_vs_oracle(gpulib, Nc, Nq):
+@pytest.mark.parametrize("name", U.c5_full_case_names())
+def test_c5_full_size_forward_backward_vs_oracle(gpulib, name):
     """BASELINE config c5 at its per-GPU size (ANPMRShapeNet3D, 8 tasks x (15 + 15) 3x64x64 images: 240 + 120 encoder images,
-    FAVOR+ at d = 256 / m = 1419 over 15 x 15 shots): mu, kl, the quaternion loss AND every gradient of loss + 1e-7*kl at 1e-4
-    against the CPU oracle (evaluated in fp64, see _anpmr3d_routed_check) under the same seeded eps draws and the kernels' ReLU
-    routing (360 images x ~1e5 decisions each).  (7, 23): one batch of the reference's TRAINING draw - context size ~ U{1..15},
-    the other 30 - Nc views of the object are the targets (dataset/shapenet_3d.py:110, 200-204)."""
-    import types
-    from networks.ANPMRShapeNet3D import ANPMRShapeNet3D
-    T = 8
-    cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[64, 64, 4], tasks_per_batch=T, input_dim=4, output_dim=4,
-                                agg_mode="attention", img_agg="reshape", task="shapenet_3d", temperature=0.07)
-    model = ANPMRShapeNet3D(cfg).to(DEV)
-    g = torch.Generator().manual_seed(1234)
-    cx, qx = torch.rand(T, Nc, 3, 64, 64, generator=g), torch.rand(T, Nq, 3, 64, 64, generator=g)
-    cy = F.normalize(torch.randn(T, Nc, 4, generator=g), dim=-1)
-    qy = F.normalize(torch.randn(T, Nq, 4, generator=g), dim=-1)
+    FAVOR+ at d = 256 / m = 1419 over 15 x 15 shots) against (1) the REFERENCE's own vectors at that size
+    (tests/golden/c5_anpmr_shapenet3d_t8*.npz, generated by importing /root/reference: mu, kl, the quaternion loss at 1e-4, every
+    gradient of loss + 1e-7*kl at 1e-4 + U.FLIP_SHARE per routing decision that sits on a tie and fell the other way - never
+    skipped), and (2) the CPU oracle evaluated in fp64 (see _anpmr3d_routed_check) under the same seeded eps draws and the kernels'
+    ReLU routing (360 images x ~1e5 decisions each) at 1e-4 flat.  `_7_23`: one batch of the reference's TRAINING draw - context
+    size ~ U{1..15}, the other 30 - Nc views of the object are the targets (dataset/shapenet_3d.py:110, 200-204); `_survey`:
+    SURVEY section 8c's input recipe, whose recorded answers (loss 2.26335859, kl 1383162.5) are asserted as well.
+    The stem's weight gradient sums 245 760 positions; the reference's fp32 CPU sum itself carries ~2e-4 of rounding noise there
+    (fp32 oracle vs fp64 oracle), so against the fixture the conv1 (stem) tensors get 3e-4, everything else 1e-4."""
+    fx, meta = U.load_case(name)
+    model = U.build_model(meta, DEV, fx=fx).to(DEV)
+    cx, qx, cy, qy = U.c5_full_case_inputs(meta)
+    T, Nq = cx.shape[0], qx.shape[1]
     mu, kl, loss, kl_o, flips = _anpmr3d_routed_check(model, cx, cy, qx, qy, dtype=torch.float64)
     assert mu.shape == (T, Nq, 4)
     assert abs(kl_o.item() - 1383162.5) < 4.0      # SURVEY §8c known answer
-    print(f"c5 per-GPU size: {flips} routing decisions on a tie")
+    # the reference's own answers at this size
+    assert U.rel_err(mu, fx["mu"]) <= U.RTOL
+    assert abs(kl.item() - float(fx["kl"])) <= U.RTOL * float(fx["kl"])
+    assert abs(loss.item() - float(fx["loss"])) <= U.RTOL * max(1.0, abs(float(fx["loss"])))
+    if meta["labels"] == "rand":
+        assert abs(loss.item() - 2.26335859) <= U.RTOL * 2.26335859
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    stem = {k: g for k, g in grads.items() if k.startswith("img_encoder.net.layer1.conv.") or k.startswith("decoder.conv1.")}
+    rest = {k: g for k, g in grads.items() if k not in stem}
+    w1 = U.check_grads_against_fixture_flipped(rest, fx, meta, flips, name, head=1024, stride_cap=4096)
+    w2 = U.check_grads_against_fixture_flipped(stem, fx, meta, flips, name + " (stem tensors)", tol=3e-4, head=1024, stride_cap=4096)
+    total = sum(float(g.double().norm()) ** 2 for g in grads.values() if g is not None) ** 0.5
+    assert abs(total - meta["grad_norm_total"]) <= U.RTOL * meta["grad_norm_total"]
+    print(f"{name}: {flips} routing decisions on a tie; vs the reference's vectors: gradients worst {w1[0]:.2e} ({w1[1]}), stem {w2[0]:.2e} ({w2[1]}); "
+          f"|grad| {total:.8f} (reference {meta['grad_norm_total']:.8f})")
 
 
 def _sharpen_resnet_attention(model, forward):
@@ -932,8 +973,7 @@ def test_fcl_models_vs_reference(gpulib, name):
             # 3e-4: the NT-Xent term divides cosine similarities by the temperature (0.07), which scales the fp32 rounding
             # differences of the embeddings ~14x on their way back (measured worst case 1.4e-4, on the attention queries)
             assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= 3e-4, k
-        if flips == 0:
-            U.check_grads_against_fixture(grads, fx, meta, tol=3e-4, head=1024, stride_cap=4096)
+        U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name, tol=3e-4, head=1024, stride_cap=4096)
     with torch.no_grad():
         model.eval()
         if resnet:
@@ -1038,8 +1078,7 @@ def test_mr_vanilla_models_vs_reference(gpulib, name):
             assert grads[k] is None, k       # task_encoder / mu / decoder.* never receive a gradient
             continue
         assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= U.RTOL, k
-    if flips == 0:
-        U.check_grads_against_fixture(grads, fx, meta, tol=U.RTOL, head=1024, stride_cap=4096)
+    U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name, head=1024, stride_cap=4096)
 
 
 
@@ -1782,6 +1821,56 @@ def test_batch_ingest_pipeline_matches_host_conversion(gpulib):
         BatchIngest("cpu")
 
 
+@pytest.mark.parametrize("C,H,W", [(1, 128, 128), (3, 64, 64)])
+def test_exact_u8_feed_round_trip_is_bit_exact(gpulib, C, H, W):
+    """mlhot.ingest.ExactU8Feed: a reference-style loader's fp32 channel-first host batch (dataset/shapenet_1d.py:
+    189-196, utils/utils.py:26-30: bytes / 255) crosses PCIe as bytes and comes out of the ingest kernel with the SAME fp32 bits as
+    `.to(device)` of the host tensors - for one-channel and three-channel images, on several host threads, batch after batch in the
+    same device tensors; a batch holding ONE element that is not k / 255 is refused (stage() -> None), and trainer._HostPrefetch then
+    ships it as fp32, again bit-identical."""
+    from mlhot import synth
+    from mlhot.ingest import ExactU8Feed
+    from trainer.model_trainer import _HostPrefetch
+    T, Nc, Nq = 3, 5, 7
+    rs = np.random.RandomState(11)
+
+    def host_batch():
+        xs = synth.host_convert(rs.randint(0, 256, size=(T, Nc, H, W, C)).astype(np.uint8))
+        xq = synth.host_convert(rs.randint(0, 256, size=(T, Nq, H, W, C)).astype(np.uint8))
+        return xs, xq, torch.from_numpy(rs.rand(T, Nc, 3).astype(np.float32)), torch.from_numpy(rs.rand(T, Nq, 3).astype(np.float32))
+
+    feed = ExactU8Feed(DEV, threads=3, chunk=50000)
+    ptrs = None
+    for _ in range(3):
+        hb = host_batch()
+        ticket = feed.stage(hb)
+        assert ticket is not None
+        got = feed.take(ticket)
+        torch.cuda.synchronize()
+        for g, h in zip(got, hb):
+            assert g.shape == h.shape and torch.equal(g.cpu(), h)
+        assert ptrs is None or ptrs == [g.data_ptr() for g in got]       # fixed addresses per batch shape (graph replay reads them)
+        ptrs = [g.data_ptr() for g in got]
+    assert feed.shipped == 3 and feed.refused == 0
+    hb = host_batch()
+    hb[1].view(-1)[12345] = torch.nextafter(hb[1].view(-1)[12345], torch.tensor(2.0))
+    assert feed.stage(hb) is None and feed.refused == 1 and feed.ok
+    hp = _HostPrefetch(DEV)
+    for batch, route in ((hb, "fp32"), (host_batch(), "u8")):
+        ticket = hp.stage(batch)
+        assert (ticket[0] == "u8") == (route == "u8")
+        got = hp.take(ticket)
+        torch.cuda.synchronize()
+        for g, h in zip(got, batch):
+            assert torch.equal(g.cpu(), h)
+    # a loader that never hands out byte images: after three refusals in a row the check is not attempted any more
+    feed = ExactU8Feed(DEV, threads=2)
+    noise = (torch.rand(T, Nc, C, H, W), torch.rand(T, Nq, C, H, W), torch.rand(T, Nc, 3), torch.rand(T, Nq, 3))
+    for _ in range(3):
+        assert feed.stage(noise) is None
+    assert not feed.ok and feed.stage(host_batch()) is None
+
+
 def test_trainer_ingest_path_equals_host_path(gpulib, tmp_path, monkeypatch):
     """The trainer fed through BatchIngest (uint8 over PCIe, prefetched) walks exactly the trajectory of the reference's
     route (host conversion, `.to(device)`): same draws, bit-identical inputs, identical final weights."""
@@ -2161,6 +2250,43 @@ def test_bench_launches_its_own_ranks_on_one_gpu(gpulib):
     assert out["n_gpus"] == 2 and out["config"]["global_tasks"] == 32 and out["hipgraph"] is True and out["scaling"] == "weak"
     assert out["dist"]["ranks_reported_by_backend"] == 2 and out["dist"]["launcher"].startswith("bench.py itself")
     assert "starting 2 rank processes" in r.stderr and "reports 2 ranks" in r.stderr
+
+
+@pytest.mark.parametrize("workload", ["c3", "c5"])
+def test_bench_eight_ranks_on_one_gpu(gpulib, workload):
+    """BASELINE configs[3..4]'s control flow before a real node ever sees it: plain `python bench.py --gpus 8` starts EIGHT fresh rank
+    processes (bench.spawn_ranks; here all share this box's one GPU through the MLHOT_ONE_DEVICE / gloo hooks, on an 8-GPU node the
+    same command is one rank per GPU over RCCL): clean exit codes, ONE JSON line, n_gpus == 8, the gradients every rank holds after
+    the last all-reduce identical, the step's collectives as designed (c5: the early bucket between the two graphs, then the rest;
+    c3: one flat all-reduce), and the eps draw threads adapted to eight ranks sharing the node's cores."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LOCAL_WORLD_SIZE", "MLHOT_EPS_THREADS")}
+    env.update(MLHOT_DIST_BACKEND="gloo", MLHOT_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", workload, "--steps", "2", "--warmup", "1",
+                        "--prof-steps", "1"], capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    out = json.loads(lines[0])
+    tasks = 16 if workload == "c3" else 8
+    assert out["n_gpus"] == 8 and out["config"]["global_tasks"] == 8 * tasks and out["hipgraph"] is True and out["scaling"] == "weak"
+    assert out["dist"]["ranks_reported_by_backend"] == 8 and out["dist"]["launcher"].startswith("bench.py itself")
+    assert "starting 8 rank processes" in r.stderr and "reports 8 ranks" in r.stderr
+    per = out["dist"]["per_rank"]
+    assert len(per["final_loss"]) == 8 and all(np.isfinite(v) and v > 0 for v in per["final_loss"])
+    assert len(set(per["grad_sum"])) == 1 and len(set(per["grad_abs_sum"])) == 1 and per["grad_abs_sum"][0] > 0, per
+    kinds = [k for k, _ in out["dist"]["collectives_per_step"]]
+    if workload == "c5":
+        assert kinds == ["early", "rest"] and out["dist"]["step_graphs"] == 2
+        assert len(set(per["final_loss"])) == 8            # eight different task shards (the kl term is common, the losses are not)
+        from networks.bbb import eps
+        want = max(1, min(4, eps.usable_cores() // 16))
+        assert out["eps"]["host_threads"] <= want and out["eps"]["ranks_on_node"] == 8, out["eps"]
+    else:
+        assert kinds == ["all"] and out["dist"]["step_graphs"] == 1
+    assert abs(out["value"] - 8 * tasks * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
 
 
 def _bucket_cuda_worker(rank, world, port, out):

@@ -88,10 +88,33 @@ def test_oracle_mr_vanilla_models_match_reference(name):
 
 
 def test_oracle_known_answers_of_the_survey():
-    """SURVEY.md §8c known answers (loss values of configs c1-c3)."""
-    for name, want in (("c1_cnp_pascal1d", 0.37023053), ("c2_cnp_shapenet1d_mean", 0.66624528), ("c3_anp_shapenet1d", 0.51365805)):
-        fx, _ = U.load_case(name)
+    """SURVEY.md §8c known answers (loss values of configs c1-c3; c5 at T = 8: loss, kl and the gradient's norm of loss + 1e-7 kl)."""
+    for name, want in (("c1_cnp_pascal1d", 0.37023053), ("c2_cnp_shapenet1d_mean", 0.66624528), ("c3_anp_shapenet1d", 0.51365805),
+                       ("c5_anpmr_shapenet3d_t8_survey", 2.26335859)):
+        fx, meta = U.load_case(name)
         assert abs(float(fx["loss"]) - want) < 2e-7
+    assert abs(float(fx["kl"]) - 1383162.5) < 1.0 and abs(meta["grad_norm_total"] - 2.12012622) < 2e-6
+    assert np.allclose(fx["mu"][0, 0], [0.0957505, -0.0838672, -0.6735486, 0.4293967], atol=2e-7)
+
+
+@pytest.mark.parametrize("name", U.c5_full_case_names())
+def test_oracle_c5_at_its_per_gpu_size_matches_reference(name):
+    """BASELINE configs[4]'s per-GPU share at its real size (ANPMRShapeNet3D, 8 tasks, 15 + 15 / 7 + 23 views of 3x64x64): the
+    oracle's mu / kl / loss / every gradient of loss + 1e-7 kl against the REFERENCE's own vectors under the same eps draws
+    (tests/golden/make_fixtures.py::run_c5_full_case; ANPMRShapeNet3D.py:185-218, bbb/BBBConv.py:86-108)."""
+    fx, meta = U.load_case(name)
+    model = U.build_model(meta, fx=fx)
+    cx, qx, cy, qy = U.c5_full_case_inputs(meta)
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+    torch.manual_seed(meta["eps_seed"])
+    mu, kl = O.anpmr3d_forward(p, cx, cy, qx, meta["cfg"]["img_agg"])
+    assert abs(kl.item() - float(fx["kl"])) <= 1e-5 * float(fx["kl"])
+    assert U.rel_err(mu, fx["mu"]) <= 1e-5
+    loss = O.calc_loss("shapenet_3d", mu, qy)
+    assert abs(loss.item() - float(fx["loss"])) <= 1e-5
+    (loss + 1e-7 * kl).backward()
+    grads = {k: p[k].grad for k, _ in model.named_parameters()}
+    U.check_grads_against_fixture(grads, fx, meta, tol=1e-4, head=1024, stride_cap=4096)
 
 
 def test_oracle_favor_matches_reference():

@@ -87,5 +87,44 @@ inline int run(const uint8_t* src, float* dst, long n_img, int H, int W, int C, 
   return run_foreach(IngestAny{src, dst, C, HW, div}, (size_t)total, s, "ingest.u8.any");
 }
 
+// ---- host side: the inverse of the loaders' `astype(float32) / div` (dataset/shapenet_1d.py:189-190), checked element by element -----
+// A reference-style loader hands out fp32 host images that ARE k / 255 for byte values k; such a batch can cross PCIe as bytes (a
+// quarter of the traffic) and be expanded again by the ingest kernel - bit for bit the same fp32 values - but only if EVERY element
+// round-trips.  One pass: k = round(x * div) clamped to a byte, dst = k, and the count of elements with (float)k / div != x.  Plain
+// loops the host compiler vectorises; on x86 a second copy of the loop is compiled for AVX2 and picked at run time (the fp32 divide
+// is the cost: 8 lanes instead of 4).  Callers cut a batch into pieces and run them on several host threads (mlhot/ingest.py).
+template <int UNUSED = 0>
+static inline long host_f32_to_u8_exact_body(const float* src, uint8_t* dst, long n, float div) {
+  long bad = 0;
+  for (long b0 = 0; b0 < n; b0 += 32768) {                  // 32-bit counters inside a block: the loop vectorises at the floats' width
+    const int m = (int)(n - b0 < 32768 ? n - b0 : 32768);
+    const float* __restrict__ sp = src + b0;
+    uint8_t* __restrict__ dp = dst + b0;
+    int bad32 = 0;
+    for (int i = 0; i < m; ++i) {
+      const float x = sp[i];
+      float r = x * div + 0.5f;
+      r = r > 0.f ? r : 0.f;                                 // a NaN lands on 0 here (the comparison is false) and fails the check below
+      r = r < 255.f ? r : 255.f;
+      const int k = (int)r;
+      dp[i] = (uint8_t)k;
+      bad32 += ((float)k / div != x) ? 1 : 0;
+    }
+    bad += bad32;
+  }
+  return bad;
+}
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2"))) static long host_f32_to_u8_exact_avx2(const float* src, uint8_t* dst, long n, float div) {
+  return host_f32_to_u8_exact_body<1>(src, dst, n, div);
+}
+#endif
+inline long host_f32_to_u8_exact(const float* src, uint8_t* dst, long n, float div) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  if (__builtin_cpu_supports("avx2")) return host_f32_to_u8_exact_avx2(src, dst, n, div);
+#endif
+  return host_f32_to_u8_exact_body<0>(src, dst, n, div);
+}
+
 }  // namespace ingest
 }  // namespace mlhot

@@ -429,6 +429,13 @@ int mlhot_nt_xent_bwd(const float* z, int N, int d, int div, int mod, float t, c
 #endif
 }
 
+// ---- host only: fp32 images that are k / div back to bytes, every element checked (csrc/ingest.h) -------------------------
+int mlhot_host_f32_to_u8_exact(const float* src, uint8_t* dst, int64_t n, float div, int64_t* n_inexact) {
+  if (!src || !dst || n < 0 || !(div > 0.f) || !n_inexact) { set_error("host_f32_to_u8_exact: bad argument"); return MLHOT_ERR_ARG; }
+  *n_inexact = (int64_t)ingest::host_f32_to_u8_exact(src, dst, (long)n, div);
+  return MLHOT_OK;
+}
+
 // ---- torch's CPU normal_() stream on the device (csrc/mt_normal.h) ----------------------------------------------------
 int mlhot_mt19937_advance(uint32_t* engine, uint64_t n_outputs) {       // host only: no stream, no device
   if (!engine || (int)engine[mt::N] < 0 || (int)engine[mt::N] > mt::N || engine[mt::N + 1] > (uint32_t)mt::N) { set_error("mt19937_advance: bad engine"); return MLHOT_ERR_ARG; }

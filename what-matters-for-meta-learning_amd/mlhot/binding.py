@@ -22,7 +22,7 @@ LOSS = {"azimuth": 0, "mse": 1, "quaternion": 2, "degree": 3, "distractor": 4}
 _f = C.c_void_p  # every device pointer travels as void*
 
 
-ABI_VERSION = 5     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients; 3: + conv12_fwd / _bwd; 4: + np_vanilla_bwd_loss; 5: + mt19937_advance)
+ABI_VERSION = 6     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients; 3: + conv12_fwd / _bwd; 4: + np_vanilla_bwd_loss; 5: + mt19937_advance; 6: + host_f32_to_u8_exact)
 
 
 class MlhotError(RuntimeError):
@@ -137,6 +137,10 @@ def set_grad_arena(arena):
     into (mlhot/arena.py).  Process-global, like the parameters it mirrors: one model trains at a time."""
     global _GRAD_ARENA
     _GRAD_ARENA = arena
+
+
+def get_grad_arena():
+    return _GRAD_ARENA
 
 
 def _grad_like(t):
@@ -548,6 +552,14 @@ class MlhotLib:
         self.c.mlhot_mt19937_jump_ws_words.restype = C.c_size_t
         self.c.mlhot_mt19937_jump_ws_words.argtypes = [C.c_int]
         return int(self.c.mlhot_mt19937_jump_ws_words(n_sub))
+
+    def host_f32_to_u8_exact(self, src_ptr, dst_ptr, n, div=255.0):
+        """Raw host pointers (ints), n elements: bytes into dst, returns the number of elements that do NOT round-trip through
+        (float)byte / div bit for bit.  Host only; releases the GIL (ctypes), so pieces of one batch run on several threads."""
+        self.c.mlhot_host_f32_to_u8_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.POINTER(C.c_int64)]
+        bad = C.c_int64(0)
+        self._rc(self.c.mlhot_host_f32_to_u8_exact(C.c_void_p(src_ptr), C.c_void_p(dst_ptr), int(n), float(div), C.byref(bad)), "mlhot_host_f32_to_u8_exact")
+        return int(bad.value)
 
     def mt19937_advance(self, engine, n_outputs):
         """engine: numpy uint32[626] (state, left, next), advanced IN PLACE by n_outputs calls.  Host only: works without a GPU."""

@@ -83,12 +83,7 @@ class BatchIngest:
         self._out = {}                          # shapes -> _Out (fixed fp32 outputs)
         self._queue = collections.deque()
 
-    def stage(self, xs_u8, xq_u8, ys, yq):
-        """Queue one host batch: images uint8 [T,N,H,W,C] (channel-last), labels fp32 [T,N,L].  Returns a ticket."""
-        src = [_host(xs_u8, torch.uint8), _host(xq_u8, torch.uint8), _host(ys, torch.float32), _host(yq, torch.float32)]
-        if src[0].dim() != 5 or src[1].dim() != 5:
-            raise MlhotError("BatchIngest: images must be [T, N, H, W, C]")
-        key = tuple(tuple(t.shape) for t in src)
+    def _free_slot(self, key):
         ring = self._slots.setdefault(key, [])
         slot = next((sl for sl in ring if not sl.busy), None)
         if slot is None:
@@ -97,9 +92,30 @@ class BatchIngest:
             slot = _Slot(key, self.device)
             ring.append(slot)
         slot.copied.synchronize()               # the previous H2D out of this pinned buffer is done (no-op when fresh)
+        return slot
+
+    def stage(self, xs_u8, xq_u8, ys, yq):
+        """Queue one host batch: images uint8 [T,N,H,W,C] (channel-last), labels fp32 [T,N,L].  Returns a ticket."""
+        src = [_host(xs_u8, torch.uint8), _host(xq_u8, torch.uint8), _host(ys, torch.float32), _host(yq, torch.float32)]
+        if src[0].dim() != 5 or src[1].dim() != 5:
+            raise MlhotError("BatchIngest: images must be [T, N, H, W, C]")
+        key = tuple(tuple(t.shape) for t in src)
+        slot = self._free_slot(key)
         for h, t in zip(slot.host_np, src):
             np.copyto(h, t.numpy())             # one thread on purpose: torch's copy_ wakes the whole OpenMP pool, whose
                                                 # spinning workers then starve the HIP runtime's helper threads
+        return self._ship(key, slot)
+
+    def stage_filled(self, key, fill):
+        """Queue a batch whose bytes the CALLER writes into the pinned staging buffers: `fill(host_np)` gets the slot's four numpy views
+        ([ctx images u8 | qry images u8 | ctx labels f32 | qry labels f32], shaped like `key`) and returns True to ship the batch or
+        False to give the slot back (nothing is queued; returns None)."""
+        slot = self._free_slot(key)
+        if not fill(slot.host_np):
+            return None
+        return self._ship(key, slot)
+
+    def _ship(self, key, slot):
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(slot.consumed)      # do not overwrite bytes an ingest kernel still reads
             slot.dev.copy_(slot.host, non_blocking=True)
@@ -149,3 +165,92 @@ class BatchIngest:
         slot.consumed.record(cur)
         slot.busy = False
         return out.tensors
+
+
+class ExactU8Feed:
+    """fp32 host batches of a reference-style loader (dataset/shapenet_1d.py:189-196 -> utils/utils.py:26-30: `img.astype(float32) /
+    255.0`, channel-first) across PCIe as BYTES when - and only when - every image element is exactly k / 255 for a byte k
+    (mlhot_host_f32_to_u8_exact checks all of them while it converts; K host threads, one pass): a quarter of the traffic, and the ingest
+    kernel's `(float)k / 255` on the device gives the loader's fp32 values back bit for bit.  A batch with ANY other value (an
+    augmentation that blends pixels, a loader that normalises differently) is refused - stage() returns None and the caller ships the
+    fp32 tensors as before; after `give_up` refusals in a row the check is not attempted any more.
+
+        feed = ExactU8Feed(device)
+        ticket = feed.stage((ctx_x, qry_x, ctx_y, qry_y))     # fp32 host tensors [T, N, C, H, W] / [T, N, L]; None = not byte images
+        ctx_x, qry_x, ctx_y, qry_y = feed.take(ticket)        # fp32 device tensors (fixed addresses per batch shape)
+    """
+
+    def __init__(self, device, threads=None, div=255.0, give_up=3, chunk=1 << 20):
+        from concurrent.futures import ThreadPoolExecutor
+        self.ing = BatchIngest(device, div=div)
+        self.div, self.chunk, self.give_up = float(div), int(chunk), int(give_up)
+        self.threads = default_feed_threads() if threads is None else max(1, int(threads))
+        self._pool = ThreadPoolExecutor(max_workers=self.threads - 1, thread_name_prefix="mlhot-u8-feed") if self.threads > 1 else None
+        self.ok, self.refused_in_a_row = True, 0
+        self.shipped, self.refused = 0, 0
+
+    def stage(self, host_batch):
+        if not self.ok:
+            return None
+        xs, xq, ys, yq = host_batch
+        for t in (xs, xq, ys, yq):
+            if not (torch.is_tensor(t) and t.device.type == "cpu" and t.dtype == torch.float32 and t.is_contiguous()):
+                return self._refuse()
+        if xs.dim() != 5 or xq.dim() != 5:
+            return self._refuse()
+        # channel-first bytes are ingested as one-channel images: [T, N * C, H, W, 1] -> [T, N * C, 1, H, W] = the fp32 layout itself
+        (T, Nc, C, H, W), (_, Nq, C2, H2, W2) = xs.shape, xq.shape
+        key = ((T, Nc * C, H, W, 1), (T, Nq * C2, H2, W2, 1), tuple(ys.shape), tuple(yq.shape))
+        L = lib()
+
+        def fill(host_np):
+            jobs = []
+            for src, dst in ((xs, host_np[0]), (xq, host_np[1])):
+                n, sp, dp = src.numel(), src.data_ptr(), dst.ctypes.data
+                jobs += [(sp + 4 * o, dp + o, min(self.chunk, n - o)) for o in range(0, n, self.chunk)]
+
+            def one(j):
+                return L.host_f32_to_u8_exact(j[0], j[1], j[2], self.div)
+            if self._pool is not None and len(jobs) > 1:
+                rest = [self._pool.submit(one, j) for j in jobs[1:]]
+                bad = one(jobs[0]) + sum(r.result() for r in rest)
+            else:
+                bad = sum(one(j) for j in jobs)
+            if bad:
+                return False
+            np.copyto(host_np[2], ys.numpy())
+            np.copyto(host_np[3], yq.numpy())
+            return True
+
+        slot = self.ing.stage_filled(key, fill)
+        if slot is None:
+            return self._refuse()
+        self.refused_in_a_row = 0
+        self.shipped += 1
+        return (slot, tuple(xs.shape), tuple(xq.shape))
+
+    def _refuse(self):
+        self.refused += 1
+        self.refused_in_a_row += 1
+        if self.refused_in_a_row >= self.give_up:
+            self.ok = False                    # this loader does not hand out byte images: stop paying for the check
+        return None
+
+    def take(self, ticket):
+        slot, sc, sq = ticket
+        cx, qx, cy, qy = self.ing.take(slot)
+        return cx.view(sc), qx.view(sq), cy, qy
+
+
+def default_feed_threads():
+    """Host threads of the byte conversion: MLHOT_FEED_THREADS, else min(8, usable cores // (2 x ranks on this node)), at least 1."""
+    import os
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    env = os.environ.get("MLHOT_FEED_THREADS")
+    if env is not None:
+        return max(1, min(int(env), max(1, cores // ranks)))
+    return max(1, min(8, cores // (2 * ranks)))

@@ -32,8 +32,33 @@ def set_stabiliser_exchange(exchange):
 # gradient tensor, and the first backward kernel derives d loss / d mu itself (mlhot_np_vanilla_bwd_loss).  What autograd carries
 # between the two nodes is a cached all-zero tensor of mu's shape: whatever else may flow into mu's gradient is ADDED to it by
 # autograd as usual and the kernel adds the loss's share on top, so the result equals the unfused graph's for any consumer set.
-defer_loss_grad = True
+#
+# OPT-IN (round 6; it was a global default): the hand-over assumes that the backward pass which runs LossFunction.backward also runs
+# the producer's node.  `loss.backward()` of a training step does; `torch.autograd.grad(loss, mu)` or `loss.backward(inputs=[mu])`
+# stop at mu and would be handed the placeholder.  So only a caller that owns the whole step switches it on - `with
+# loss_grad_in_backward():` around calc_loss + backward (trainer.ModelTrainer, bench.py's step) - and even there every hand-over is
+# checked: LossFunction.backward queues an end-of-pass callback on the autograd engine, and a descriptor that is still parked on
+# the producer when the pass ends (the pass stopped at mu, or raised in between) is removed and reported as an error instead of
+# leaving zeros in somebody's gradient and a stale descriptor for the next pass.
+defer_loss_grad = False
 _zero_grads = {}
+
+
+class loss_grad_in_backward:
+    """Scope in which calc_loss(...).backward() leaves d loss / d mu to the model's first backward kernel (see above)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global defer_loss_grad
+        self.prev, defer_loss_grad = defer_loss_grad, bool(self.enabled)
+        return self
+
+    def __exit__(self, *exc):
+        global defer_loss_grad
+        defer_loss_grad = self.prev
+        return False
 
 
 def _zero_like(mu):
@@ -42,6 +67,17 @@ def _zero_like(mu):
     if z is None:
         z = _zero_grads[key] = torch.zeros_like(mu)
     return z
+
+
+def _check_handed_over(node, desc):
+    """End of the backward pass that parked `desc` on `node`: the producer's backward must have taken it."""
+    def check():
+        if node.loss is desc:
+            node.loss = None
+            raise RuntimeError("mlhot: the loss's gradient was left to the model's backward (loss_grad_in_backward), but this "
+                               "backward pass ended without running it (autograd.grad(loss, mu) / backward(inputs=[mu])?): the "
+                               "gradient handed out for mu is a placeholder of zeros.  Run such passes outside the scope.")
+    return check
 
 
 # The loss VALUE off the critical path.  Nothing in the backward reads the value, but as a launch of its own the reduction sits
@@ -56,17 +92,21 @@ _loss_aside = False
 
 
 class loss_value_aside:
+    """`enabled`: leave the loss VALUE to the backward as well; the scope always implies loss_grad_in_backward (the value rides on
+    the gradient's descriptor)."""
+
     def __init__(self, enabled=True):
         self.enabled = enabled
 
     def __enter__(self):
-        global _loss_aside
-        self.prev, _loss_aside = _loss_aside, bool(self.enabled)
+        global _loss_aside, defer_loss_grad
+        self.prev, _loss_aside = (_loss_aside, defer_loss_grad), bool(self.enabled)
+        defer_loss_grad = True
         return self
 
     def __exit__(self, *exc):
-        global _loss_aside
-        _loss_aside = self.prev
+        global _loss_aside, defer_loss_grad
+        _loss_aside, defer_loss_grad = self.prev
         return False
 
 
@@ -446,7 +486,8 @@ class LossFunction(torch.autograd.Function):
         dloss = _c(dloss.float())
         if ctx.node is not None and ctx.node.loss is None:
             # VanillaNPFunction.backward runs next (it is this gradient's only consumer node)
-            ctx.node.loss = (ctx.kind, gt, dloss) if ctx.value is None else (ctx.kind, gt, dloss, ctx.value)
+            desc = ctx.node.loss = (ctx.kind, gt, dloss) if ctx.value is None else (ctx.kind, gt, dloss, ctx.value)
+            torch.autograd.Variable._execution_engine.queue_callback(_check_handed_over(ctx.node, desc))
             return None, _zero_like(mu), None
         if ctx.value is not None:                         # the producer's slot was taken (a second loss on the same mu): the value now
             ctx.value.copy_(lib().loss_fwd(ctx.kind, mu, gt))

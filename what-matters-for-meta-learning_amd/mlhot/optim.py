@@ -117,8 +117,16 @@ class FlatAdam:
 
     def _flat_grad(self):
         """The gradients as one tensor aligned with self.flat: the library's own buffer when backward produced the same
-        layout (the normal case), otherwise a gathered copy (e.g. a step with an empty context uses another layout)."""
+        layout (the normal case), otherwise a gathered copy (e.g. a step with an empty context uses another layout).
+
+        Sets self._skip: the (offset, numel) ranges of stepped parameters WITHOUT a gradient this step.  torch.optim.Adam skips
+        such a parameter - no moment decay, no weight decay, no move - and step() restores those ranges after the flat update, so
+        that whatever their gradient slots hold (a mirrored arena is zeroed once, at refresh(): a parameter that had a gradient
+        last step and has none now still shows last step's values there) never reaches the parameter.  The one thing a single
+        flat update cannot mirror is torch's PER-PARAMETER step count: a skipped parameter's bias correction runs one step ahead
+        of torch's from then on."""
         params = dict(self.model.named_parameters())
+        self._skip = [(self.offsets[k], p.numel()) for k, p in params.items() if p.grad is None and self.offsets[k] < self.active]
         g0 = next((p.grad for p in params.values() if p.grad is not None), None)
         if g0 is None:
             return None
@@ -128,11 +136,7 @@ class FlatAdam:
         for k, p in params.items():
             g = p.grad
             if g is None and mirrored:
-                # a zero-initialised mirror of the parameter buffer (mlhot/arena.py) that no kernel wrote for this parameter: a zero
-                # gradient (moments stay 0, update 0).  With weight decay that would still move what torch leaves alone
-                if self.weight_decay and self.offsets[k] < self.active:
-                    raise RuntimeError(f"FlatAdam: weight decay, and parameter {k} received no gradient (torch.optim.Adam would skip it)")
-                continue
+                continue                # its slot of the mirror holds zeros or a stale gradient: in self._skip, restored by step()
             if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != st.data_ptr():
                 ok = False
                 break
@@ -152,15 +156,30 @@ class FlatAdam:
                              [p.grad for _, p in live])
         return self._gather
 
+    def _assert_owned(self):
+        """Every parameter must still be a view of self.flat: something that re-points `.data` (a HeadStack falling back to
+        torch.cat, load_state_dict(assign=True), `.to()`) would leave the flat update training a buffer nobody reads."""
+        lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
+        for k, p in self.model.named_parameters():
+            if not lo <= p.data_ptr() < hi:
+                raise RuntimeError(f"FlatAdam: parameter {k} no longer lives in the optimizer's flat buffer (its .data was re-pointed)")
+
     def step(self, grad_scale=1.0):
         g = self._flat_grad()
         if g is None:
             return
+        self._assert_owned()
         n = self.active
         flat, g, m1, m2 = (self.flat, g, self.exp_avg, self.exp_avg_sq) if n == self.flat.numel() else \
             (self.flat[:n], g[:n], self.exp_avg[:n], self.exp_avg_sq[:n])
+        kept = None
+        if self._skip:
+            kept = [buf[a:a + k] for buf in (flat, m1, m2) for a, k in self._skip]
+            kept = (kept, [v.clone() for v in kept])
         if self.capturable:
             lib().adam_step_counter(flat, g, m1, m2, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale, self.step_dev)
-            return
-        self.t += 1
-        lib().adam_step(flat, g, m1, m2, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale, self.t)
+        else:
+            self.t += 1
+            lib().adam_step(flat, g, m1, m2, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale, self.t)
+        if kept is not None:
+            torch._foreach_copy_(*kept)

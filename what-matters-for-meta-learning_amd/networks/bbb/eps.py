@@ -56,13 +56,32 @@ def draw(size, device):
     return torch.empty(size).normal_(0, 1).to(device)
 
 
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def default_threads():
+    """Host threads of one rank's eps draw: MLHOT_EPS_THREADS, else min(4, usable cores // (2 x ranks on this node)), at least 1 - a
+    real loader's workers (imgaug on the host) need the other half, and 8 ranks x (4 draw threads + the drawer + the batch prefetch)
+    must not oversubscribe the node.  An explicit MLHOT_EPS_THREADS is capped by usable cores // ranks as well."""
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    cores = usable_cores()
+    env = os.environ.get("MLHOT_EPS_THREADS")
+    if env is not None:
+        return max(1, min(int(env), max(1, cores // ranks)))
+    return max(1, min(4, cores // (2 * ranks)))
+
+
 class StagedEps:
     def __init__(self, device, source="host", threads=None):
         if source not in ("host", "device"):
             raise ValueError("StagedEps: source is 'host' (torch CPU generator, bit-exact) or 'device' (the same stream on the GPU)")
         self.device = torch.device(device)
         self.source = source
-        self.threads = max(1, int(os.environ.get("MLHOT_EPS_THREADS", "4")) if threads is None else int(threads))
+        self.threads = default_threads() if threads is None else max(1, int(threads))
         self._pieces, self._pool, self._gens = None, None, None
         self._dn, self._dn_buf, self._dn_stream, self._dn_ready, self._dn_free = None, None, None, None, None
         self.shapes = []
@@ -159,21 +178,25 @@ class StagedEps:
         self._pieces = [([(lo, hi) for lo, hi, _ in p], sum(c for _, _, c in p)) for p in pieces]
         self._pool = ThreadPoolExecutor(max_workers=len(self._pieces) - 1, thread_name_prefix="mlhot-eps-piece")
         self._gens = [torch.Generator() for _ in self._pieces]
-        # once per plan: the pieces give the numbers AND the final generator state of the one-thread draw, or they are not used
+        # once per plan: the pieces give the numbers AND the final generator state of the one-thread draw, or they are not used.
+        # Checked where training runs them: from an engine in the MIDDLE of a 624-word block (1000 normals = 1016 outputs drawn
+        # first), over two consecutive steps (the second starts wherever the first ended; several block regenerations per piece)
         g = torch.Generator()
         g.manual_seed(0x5eed + 1)
-        state = g.get_state()
-        keep, self._pieces = self._pieces, None
-        ref = self.draw_host(torch.zeros(self._total), g)
-        after = g.get_state()
-        g.set_state(state)
-        self._pieces = keep
+        torch.empty(1000).normal_(generator=g)
+        keep, ok = self._pieces, True
         try:
-            ok = torch.equal(ref, self.draw_host(torch.zeros(self._total), g)) and torch.equal(after, g.get_state())
+            for _ in range(2):
+                state = g.get_state()
+                self._pieces = None
+                ref = self.draw_host(torch.zeros(self._total), g)
+                after = g.get_state()
+                g.set_state(state)
+                self._pieces = keep
+                ok = ok and torch.equal(ref, self.draw_host(torch.zeros(self._total), g)) and torch.equal(after, g.get_state())
         except (ImportError, OSError, MlhotError):   # no library to position the generators with: the one-thread draw needs nothing
             ok = False
-        if not ok:
-            self._pieces = None
+        self._pieces = keep if ok else None
 
     def _draw_pieces(self, out, generator=None):
         from mlhot import lib

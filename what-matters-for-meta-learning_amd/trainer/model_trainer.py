@@ -49,13 +49,26 @@ CAPTURE_MODE = "thread_local"
 class _HostPrefetch:
     """fp32 host batches (the reference's loaders: dataset/shapenet_1d.py:189-196 -> utils/utils.py:26-30) to the device on a copy
     stream.  stage() copies - `.to(device)` from pageable memory blocks the HOST for the transfer (0.62 ms for c3's 31.5 MB), which
-    is why the trainer calls it behind the step's launch - and take() orders the batch on the current stream."""
+    is why the trainer calls it behind the step's launch - and take() orders the batch on the current stream.
 
-    def __init__(self, device):
+    Round 6 (`config.host_u8`, default on): those loaders' images ARE bytes divided by 255, so a batch first goes through
+    mlhot.ingest.ExactU8Feed - every element is checked to be exactly k / 255 while it is converted back to its byte (host threads, one
+    pass) and the batch then crosses PCIe as 7.9 instead of 31.5 MB, expanded by the ingest kernel to the same fp32 bits.  A batch that
+    holds anything else takes the fp32 route below, unchanged; the loader's contract is untouched either way."""
+
+    def __init__(self, device, u8=True):
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(self.device)
+        self.u8 = None
+        if u8:
+            from mlhot.ingest import ExactU8Feed
+            self.u8 = ExactU8Feed(self.device)
 
     def stage(self, host_batch):
+        if self.u8 is not None:
+            ticket = self.u8.stage(host_batch)
+            if ticket is not None:
+                return ("u8", ticket)
         with torch.cuda.stream(self.stream):
             dev = tuple(t.to(self.device, non_blocking=True) for t in host_batch)
             ev = torch.cuda.Event()
@@ -63,6 +76,8 @@ class _HostPrefetch:
         return dev, ev
 
     def take(self, ticket):
+        if ticket[0] == "u8":
+            return self.u8.take(ticket[1])      # fixed device tensors per batch shape, ordered on the current stream
         dev, ev = ticket
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
@@ -94,9 +109,12 @@ class ModelTrainer(BaseTrainer):
             shot = int(getattr(config, "max_ctx_num", 15) or 15)
             flat = FlatAdam.from_torch_adam(self.optimizer, model, ctx_num=min(shot, 15), test_num=min(shot, 15))
             if flat is not None:
-                self.optimizer = flat
+                # From here on `trainer.optimizer` IS the optimizer: checkpoint its state_dict() (torch.optim.Adam's layout), point an LR
+                # scheduler at its param_groups[0]["lr"].  The caller's torch object is left as it was - it no longer steps anything.
+                self.replaced_optimizer, self.optimizer = self.optimizer, flat
                 if hasattr(model, "enable_flat_grads") and model.__dict__.get("_arena") is None:
                     model.enable_flat_grads()      # ResNet / BBB family: the gradients as the mirror of the flat parameter buffer
+                    self._installed_arena = True
         if not hasattr(config, "graph_steps"):
             # default: replay whenever it is possible - a capture-safe optimizer, a model whose step is one static launch sequence
             # (the vanilla plugins), no collective between two C calls of the forward
@@ -105,7 +123,7 @@ class ModelTrainer(BaseTrainer):
         else:
             self._graph_default = bool(config.graph_steps)
         self.ingest, self._staged = None, None
-        self._host_prefetch = None
+        self._host_prefetch, self._fixed_batch = None, False
         self._prefetch = False          # set per iteration by train(): may the NEXT training batch be drawn right away?
         self.rank0 = dist_rank() == 0   # files / logs / TensorBoard are rank 0's business (every rank holds the same weights)
         self._graphs, self._static_in, self._side = {}, {}, None       # graph_steps: per batch shape
@@ -114,7 +132,36 @@ class ModelTrainer(BaseTrainer):
             from mlhot.ingest import BatchIngest
             self.ingest = BatchIngest(config.device)
         elif cuda and getattr(config, "host_prefetch", True):
-            self._host_prefetch = _HostPrefetch(config.device)
+            self._host_prefetch = _HostPrefetch(config.device, u8=bool(getattr(config, "host_u8", True)))
+
+    def _announce(self):
+        """Once, at the start of train(): what the constructor promoted (nothing here is silent)."""
+        from mlhot.optim import FlatAdam
+        if isinstance(self.optimizer, FlatAdam) and getattr(self, "replaced_optimizer", None) is not None:
+            self._log("mlhot: torch.optim.Adam continued by mlhot.optim.FlatAdam (one launch over the flat parameter buffer; same hyper-parameters, "
+                      "moments and step count).  Checkpoint / schedule `trainer.optimizer`; the optimizer object passed in no longer steps.")
+        if self._graph_default:
+            self._log("mlhot: training iterations are replayed from hipGraphs (one per batch shape); a change of trainer.optimizer.param_groups[0] "
+                      "(lr, betas, eps, weight_decay) is picked up by re-capturing.")
+        if self._host_prefetch is not None:
+            self._log("mlhot: host batches are copied on a copy stream behind the step" +
+                      (" - as bytes when every image element is exactly k / 255 (checked per batch), as fp32 otherwise" if self._host_prefetch.u8 is not None else ""))
+
+    def close(self):
+        """Undo the process-wide installs of the constructor (the gradient arena in mlhot.binding, the stabiliser exchange in mlhot.ops);
+        train() calls it when it is done, a caller that only uses _train_iter calls it itself."""
+        if getattr(self, "_installed_arena", False):
+            from mlhot import binding
+            if binding.get_grad_arena() is self.model.__dict__.get("_arena"):
+                binding.set_grad_arena(None)
+            self._installed_arena = False
+        if getattr(self.config, "strict_sharded_parity", False):
+            from mlhot import ops
+            ops.set_stabiliser_exchange(None)
+
+    def _hyper(self):
+        g = self.optimizer.param_groups[0]
+        return (float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g.get("weight_decay", 0.0)))
 
     def _log(self, msg):
         logger = getattr(self.config, "logger", None)
@@ -127,6 +174,7 @@ class ModelTrainer(BaseTrainer):
 
     def train(self):
         self._log("\n================== Start training ===================")
+        self._announce()
         it = self.start_iter
         for it in range(self.start_iter, self.iterations + 1):
             if it % self.config.bg_gen_freq == 0 and self.config.gen_bg:
@@ -144,6 +192,8 @@ class ModelTrainer(BaseTrainer):
             if it % 1000 == 0:
                 self.save_intermediate_model(it)
         self._save(f"model_end_{it}.pt")
+        if getattr(self.config, "close_after_train", True):
+            self.close()
         self._log(f"models have been saved to {self.config.save_path}")
         self._log("================= Training finished =================\n")
 
@@ -162,6 +212,7 @@ class ModelTrainer(BaseTrainer):
                 return hp.take(hp.stage(draw(source)))
             ticket, self._staged = (self._staged or hp.stage(draw("train"))), None
             self._stage_later = self._prefetch          # the next batch's (host-blocking) copy goes out BEHIND this step's launch: _stage_next()
+            self._fixed_batch = ticket[0] == "u8"       # the byte route delivers every batch of a shape in the same device tensors
             return hp.take(ticket)
 
         def stage(src):
@@ -225,10 +276,18 @@ class ModelTrainer(BaseTrainer):
             self._side = torch.cuda.Stream(self.config.device)
         static = self._static_in.get(key)
         if static is None:                                           # fixed input addresses for this shape
-            static = self._static_in[key] = batch if self.ingest is not None else tuple(t.clone() for t in batch)
+            static = self._static_in[key] = batch if (self.ingest is not None or self._fixed_batch) else tuple(t.clone() for t in batch)
         if static[0].data_ptr() != batch[0].data_ptr():
             for d, t in zip(static, batch):
                 d.copy_(t)
+        # lr / betas / eps / weight decay are scalar kernel arguments, frozen inside a captured graph: when a scheduler (or the caller)
+        # changed them since the capture, every shape's graph is dropped - this iteration runs eagerly with the new values, the next
+        # one captures again
+        hyper = self._hyper()
+        if getattr(self, "_captured_hyper", hyper) != hyper:
+            self._graphs.clear()
+            self.recaptures = getattr(self, "recaptures", 0) + 1
+        self._captured_hyper = hyper
         entry = self._graphs.get(key)
         cur = torch.cuda.current_stream(self.config.device)
         eps = self._eps_stager()
