@@ -599,6 +599,92 @@ def measure_train_loop_3d(w, device, loss_fn, iters):
     return out
 
 
+SHIPPED = {"c3": ("shipped_ANP_ShapeNet1D.yaml", "cfg/train/ANP_ShapeNet1D.yaml:10-11; dataset/shapenet_1d.py:120,139-141"),
+           "c5": ("shipped_ANPMR_ShapeNet3D.yaml", "cfg/train/ANPMR_ShapeNet3D.yaml:9-10; dataset/shapenet_3d.py:110,200-204")}
+
+
+def measure_shipped_cfg(w, device, loss_fn, iters):
+    """extras.shipped_cfg: tasks/s of trainer.ModelTrainer's promoted loop (the reference's calling sequence, train.py:52-90: a
+    torch.optim.Adam over the model's parameters, a loader of fp32 host batches, loss.item() every iteration) at the reference's
+    SHIPPED training shape - not the 16- / 8-task BASELINE configs: ANPShapeNet1D 10 tasks, context ~ U{3..15}, 15 targets; ANPMRShapeNet3D
+    20 tasks, context ~ U{1..15}, targets = the other 30 - Nc views.  Image counts per step are then not 480 / 360: the persistent band
+    decompositions see 180 .. 300 (1D) resp. 2 x 600 (3D) images.  One hipGraph per context size (13 / 15), a pool of one host batch
+    per size handed out in a seeded random order (synthesising a batch on the host costs 100 x the step)."""
+    import importlib
+    import tempfile
+    import numpy as np
+    import yaml
+    from configs.config import Config
+    from mlhot import binding, synth
+    from trainer.model_trainer import ModelTrainer
+    name, cite = SHIPPED[w["key"]]
+    with open(os.path.join(ROOT, "what-matters-for-meta-learning_amd", "cfg", "train", name), "rb") as f:
+        raw = yaml.safe_load(f)
+    raw["device"] = str(device)
+    cfg = Config()
+    cfg.set_init_values(raw, side_effects=False)
+    assert cfg.method == w["method"]
+    T, shot = int(cfg.tasks_per_batch), int(cfg.max_ctx_num)
+    three_d = w["kind"] == "resnet3d"
+    sizes = list(range(1 if three_d else 3, shot + 1))
+    pool = {}
+    for nc in sizes:
+        if three_d:
+            cx, qx, cy, qy = synth.get_batch_3d(T, 15, 15, seed=100 + nc, task_aug=False)
+            px, py = torch.cat([cx, qx], dim=1), torch.cat([cy, qy], dim=1)                  # the object's 30 views
+            pool[nc] = (px[:, :nc].contiguous(), px[:, nc:].contiguous(), py[:, :nc].contiguous(), py[:, nc:].contiguous())
+        else:
+            hb = synth.get_batch_u8("shapenet_1d", T, nc, shot, seed=100 + nc)
+            pool[nc] = (synth.host_convert(hb[0]), synth.host_convert(hb[1]), hb[2], hb[3])     # bytes / 255, channel-first: what the loader hands out
+
+    class Loader:
+        def __init__(self):
+            self.rng, self.drawn = np.random.RandomState(0), []
+
+        def get_batch(self, source, tasks_per_batch, shot):
+            nc = int(self.rng.randint(sizes[0], shot + 1))
+            self.drawn.append(nc)
+            return pool[nc]
+
+        def gen_bg(self, *a, **k):
+            pass
+
+    out = {"yaml": "cfg/train/" + name, "reference": cite, "tasks_per_batch": T, "context": f"U{{{sizes[0]}..{shot}}} per batch",
+           "targets": "30 - Nc" if three_d else str(shot)}
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg.iterations, cfg.val_freq, cfg.val_iters, cfg.bg_gen_freq, cfg.gen_bg = 3 * len(sizes) + 8, 10 ** 9, 1, 10 ** 9, False
+        cfg.save_path, cfg.logger, cfg.contrastive, cfg.close_after_train = tmp, None, False, False
+        model = getattr(importlib.import_module("networks." + w["method"]), w["method"])(cfg).to(device)
+        data = Loader()
+        tr = None
+        try:
+            tr = ModelTrainer(model=model, loss=loss_fn, optimizer=torch.optim.Adam(model.parameters(), lr=cfg.lr), config=cfg, data=data)
+            tr.train()                                   # every size's eager warm-up + capture happens in here or in the untimed round below
+            tr.iterations = 10 ** 9
+            n = max(60, 4 * iters)
+            for timed in (False, True):
+                torch.cuda.synchronize()
+                d0 = len(data.drawn)
+                t0 = time.perf_counter()
+                for it in range(1000, 1000 + n):
+                    tr._prefetch = True
+                    tr._train_iter(it)
+                torch.cuda.synchronize()
+                if timed:
+                    ms = 1e3 * (time.perf_counter() - t0) / n
+                    out.update(ms_per_iter=ms, tasks_per_s=1e3 * T / ms, iterations=n, mean_context=float(np.mean(data.drawn[d0:])))
+            out["graphs"] = len([v for v in tr._graphs.values() if isinstance(v, tuple)])
+            out["promoted"] = {"optimizer": type(tr.optimizer).__name__, "graph_replay": bool(tr._graph_default),
+                               "host_batches_as_bytes": bool(tr._host_prefetch is not None and tr._host_prefetch.u8 is not None and tr._host_prefetch.u8.shipped)}
+            if tr._eps and tr._eps._worker is not None:
+                tr._eps.stage()
+        finally:
+            if tr is not None:
+                tr.close()
+            binding.set_grad_arena(None)
+    return out
+
+
 def measure_extras(w, device, loss_fn, batch, iters):
     """Not the headline metric: (a) the training forward alone (activations saved, no backward), (b) the full step
     followed by the fused flat Adam update (mlhot.optim.FlatAdam: one launch over the flat parameter buffer).  The Adam
@@ -666,6 +752,8 @@ def measure_extras(w, device, loss_fn, batch, iters):
         out["host_fed"] = measure_host_fed(w, device, loss_fn, model, iters)
         out["variable_context"] = measure_variable_nc(w, device, loss_fn, model, batch, iters)
         out["train_loop"] = measure_train_loop(w, device, loss_fn, iters)
+        if w["key"] in SHIPPED:
+            out["shipped_cfg"] = {w["method"]: measure_shipped_cfg(w, device, loss_fn, iters)}
         return out
     except Exception as e:  # noqa: BLE001 - extras must never break the bench line
         return {"error": f"{type(e).__name__}: {e}"}
@@ -682,7 +770,7 @@ def measure_other_configs(keys, steps, warmup, timeout_s=600):
                                                             "MLHOT_BENCH_SEQ", "MLHOT_BENCH_KERNELS", "MLHOT_BENCH_LAUNCHER", "MLHOT_FORCE_COLLECTIVES")}
     for key in keys:
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", key, "--steps", str(steps), "--warmup", str(warmup),
-               "--no-extras", "--no-cpu-baseline", "--no-configs"]
+               "--no-extras", "--no-cpu-baseline", "--no-configs"] + (["--shipped-cfg"] if key == "c5" else [])
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
@@ -700,6 +788,7 @@ def measure_other_configs(keys, steps, warmup, timeout_s=600):
                         "fwd_only_ms": (roof.get("forward") or {}).get("fwd_ms"),
                         "launches_per_step": j.get("launches_per_step"), "gpu_busy_us_per_step": j.get("gpu_busy_us_per_step"),
                         "eps_source": j["config"].get("eps_source"), "eps": j.get("eps"), "library_sha256": (j.get("library") or {}).get("sha256"),
+                        "shipped_cfg": (j.get("extras") or {}).get("shipped_cfg"),
                         "wall_s": round(time.perf_counter() - t0, 1)}
         except Exception as e:  # noqa: BLE001 - extras must never break the bench line
             out[key] = {"error": f"{type(e).__name__}: {e}"}
@@ -852,6 +941,7 @@ def main():
                          "the staged C calls, so the step runs eagerly (implies --no-graph).  Default: each rank's own maximum "
                          "(negligible for ANPShapeNet1D, up to 15 %% of a gradient's scale for the d = 256 models, DESIGN.md section 6d)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fwd-only / +Adam timing legs")
+    ap.add_argument("--shipped-cfg", action="store_true", help="with --no-extras: still run the extras.shipped_cfg leg (the reference's shipped training shape)")
     ap.add_argument("--no-configs", action="store_true",
                     help="default workload, one GPU: skip extras.configs (c2 and c5 timed by child processes of this file after the headline's timed region)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the ~0.1 s of untimed steps in front of the W warm-up steps")
@@ -1131,10 +1221,21 @@ def main():
             extras["train_loop"] = measure_train_loop_3d(w, device, loss_fn, max(10, args.steps // 2))
         except Exception as e:  # noqa: BLE001 - extras must never break the bench line
             extras = dict(extras or {}, error=f"{type(e).__name__}: {e}")
+    if world == 1 and args.shipped_cfg and (args.no_extras or c5) and args.workload in SHIPPED and not args.no_graph:
+        try:
+            if eps is not None and eps._worker is not None:
+                eps.stage()
+            extras = dict(extras or {})
+            extras["shipped_cfg"] = {w["method"]: measure_shipped_cfg(w, device, loss_fn, max(10, args.steps // 2))}
+        except Exception as e:  # noqa: BLE001 - extras must never break the bench line
+            extras = dict(extras or {}, shipped_cfg={"error": f"{type(e).__name__}: {e}"})
     if world == 1 and not mdist.force_collectives() and args.workload == "c3" and not args.no_extras and not args.no_configs and not args.no_graph:
         torch.cuda.synchronize()
         extras = dict(extras or {})
         extras["configs"] = measure_other_configs(("c2", "c5"), steps=20, warmup=5)
+        moved = (extras["configs"].get("c5") or {}).pop("shipped_cfg", None)            # one place for both shipped shapes
+        if moved:
+            extras.setdefault("shipped_cfg", {}).update(moved)
     per_rank = None
     if dist.is_initialized():
         # every rank's loss of the last timed step (rank-local: the ranks hold different tasks) and a checksum of its gradients after
