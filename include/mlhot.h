@@ -97,8 +97,9 @@ int mlhot_mt19937_advance(uint32_t* engine, uint64_t n_outputs);
  * nearest to src[i] * div, *n_inexact = the number of elements whose (float)k / div differs from src[i] in any bit.  When it is 0
  * the batch may cross PCIe as the n bytes of dst and mlhot_ingest_u8_nhwc (same div) reproduces src bit for bit on the device;
  * otherwise the caller ships the fp32 data as before.  Element order is kept (a channel-first fp32 batch gives channel-first bytes:
- * ingest it as [n_img * C, H, W, 1]).  Thread-safe; callers split large batches over host threads (mlhot/ingest.py).        */
-int mlhot_host_f32_to_u8_exact(const float* src, uint8_t* dst, int64_t n, float div, int64_t* n_inexact);
+ * ingest it as [n_img * C, H, W, 1]).  `threads` (1 .. 64): the conversion runs on that many native host threads started by
+ * the call (pieces of >= 64 K elements); thread-safe.                                                                         */
+int mlhot_host_f32_to_u8_exact(const float* src, uint8_t* dst, int64_t n, float div, int threads, int64_t* n_inexact);
 
 /* ---- E1: vanilla image encoder `encoder_w0` -------------------------------------------
  * replaces nn.Sequential(conv3x3s2+ReLU, conv3x3s2+ReLU, MaxPool2d(2), conv3x3s2+ReLU,

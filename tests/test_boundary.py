@@ -171,6 +171,17 @@ def test_host_f32_to_u8_exact_checks_every_element():
         y[300] = bad_value
         y[70000] = bad_value
         assert L.host_f32_to_u8_exact(y.ctypes.data, dst.ctypes.data, y.size) == 2, bad_value
+    # several native threads: the same bytes and counts (pieces of >= 64 K elements; a short input stays on one thread)
+    big = np.tile(u8, 12)
+    xb = big.astype(np.float32) / 255.0
+    xb[5], xb[xb.size - 3], xb[xb.size // 2] = 0.3, -1.0, np.float32("nan")
+    for thr in (1, 2, 3, 8, 64):
+        db = np.zeros_like(big)
+        assert L.host_f32_to_u8_exact(xb.ctypes.data, db.ctypes.data, xb.size, threads=thr) == 3
+        ok = np.ones(big.size, dtype=bool)
+        ok[[5, big.size - 3, big.size // 2]] = False
+        assert np.array_equal(db[ok], big[ok])
+    assert L.host_f32_to_u8_exact(x.ctypes.data, dst.ctypes.data, 1000, threads=8) == 0
     # another divisor (a loader that scales by 1 / 256 is exact too; by 1 / 100 is not for most bytes)
     x256 = u8.astype(np.float32) / np.float32(256.0)
     assert L.host_f32_to_u8_exact(x256.ctypes.data, dst.ctypes.data, x256.size, div=256.0) == 0 and np.array_equal(dst, u8)

@@ -434,8 +434,13 @@ def _run_case(gpulib, name):
             worst_routed = (e, k)
         assert e <= U.RTOL, k
     # the REFERENCE's own gradients (the fixture), always: at 1e-4 when every routing decision equals the reference's, otherwise at
-    # 1e-4 + flips x U.FLIP_SHARE (every differing decision was proven a <= 1e-5 tie above) - never skipped
-    w_fix, k_fix, bound = U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name)
+    # 2e-4 + 1.25 x the differing decisions' effect on that tensor, measured in the oracle (tests/util.py::flip_effect; every differing
+    # decision was proven a <= 1e-5 tie above) - never skipped
+    def effect():          # the differing decisions' exact effect, measured in the oracle: its gradients under its OWN routing vs under the kernels'
+        p2 = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+        O.calc_loss(task, O.vanilla_np_forward(p2, cx, cy, qx, agg, tanh=model.OUT_TANH), qy).backward()
+        return U.flip_effect({k: p[k].grad for k, _ in model.named_parameters()}, {k: p2[k].grad for k, _ in model.named_parameters()}, U.GRAD_FLOOR * gmax)
+    w_fix, k_fix, bound = U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name, effect=effect)
     line = (f"{name} [{os.environ.get('PYTEST_CURRENT_TEST', '').split('::')[-1].split(' ')[0]}]: {flips} of {decisions} routing decisions differ from the "
             f"oracle's own (each proven a <= {U.TIE:g} tie); gradients vs the oracle under the kernels' routing: worst {worst_routed[0]:.2e} "
             f"({worst_routed[1]}) <= {U.RTOL:g}; vs the REFERENCE's own gradients (fixture): worst {w_fix:.2e} ({k_fix}) <= {bound:.2e}")
@@ -720,8 +725,12 @@ def test_resnet_models_vs_reference(gpulib, name):
             assert grads[k] is None, k
             continue
         assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= U.RTOL, k
-    # the reference's own gradients, always (1e-4, + U.FLIP_SHARE per decision that sits on a tie and fell the other way)
-    U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name, head=1024, stride_cap=4096)
+    # the reference's own gradients, always (1e-4; with decisions that sit on a tie and fell the other way: + their measured effect)
+    def effect():
+        p2 = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+        O.calc_loss(meta["cfg"]["task"], O.resnet_np_forward(p2, cx, cy, qx, meta["cfg"]["agg_mode"], meta["cfg"]["img_agg"]), qy).backward()
+        return U.flip_effect({k: p[k].grad for k, _ in model.named_parameters()}, {k: p2[k].grad for k, _ in model.named_parameters()}, U.GRAD_FLOOR * gmax)
+    U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name, effect=effect, head=1024, stride_cap=4096)
 
 
 def _anpmr3d_routed_check(model, cx, cy, qx, qy, fx=None, meta=None, dtype=torch.float32, fx_kw=None):
@@ -760,8 +769,15 @@ def _anpmr3d_routed_check(model, cx, cy, qx, qy, fx=None, meta=None, dtype=torch
             assert grads[k] is None, k       # decoder.resnet.fc.* never receive a gradient
             continue
         assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= U.RTOL, k
+    def effect():
+        p2 = {k: v.detach().cpu().to(dtype).requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+        torch.manual_seed(99)
+        mu2, kl2 = O.anpmr3d_forward(p2, cx.to(dtype), cy.to(dtype), qx.to(dtype))
+        (O.calc_loss("shapenet_3d", mu2, qy.to(dtype)) + 1e-7 * kl2).backward()
+        return U.flip_effect({k: p[k].grad for k, _ in model.named_parameters()}, {k: p2[k].grad for k, _ in model.named_parameters()}, U.GRAD_FLOOR * gmax)
+    _anpmr3d_routed_check.effect = effect          # for callers that compare against a fixture themselves (the c5 full-size test)
     if fx is not None:
-        U.check_grads_against_fixture_flipped(grads, fx, meta, flips, f"anpmr3d {tuple(cx.shape)} {meta.get('name', '')}", head=1024, stride_cap=4096, **(fx_kw or {}))
+        U.check_grads_against_fixture_flipped(grads, fx, meta, flips, f"anpmr3d {tuple(cx.shape)} {meta.get('name', '')}", effect=effect, head=1024, stride_cap=4096, **(fx_kw or {}))
     return mu, kl, loss, kl_o, flips
 
 
@@ -784,8 +800,8 @@ def test_c5_full_size_forward_backward_vs_oracle(gpulib, name):
     """BASELINE config c5 at its per-GPU size (ANPMRShapeNet3D, 8 tasks x (15 + 15) 3x64x64 images: 240 + 120 encoder images,
     FAVOR+ at d = 256 / m = 1419 over 15 x 15 shots) against (1) the REFERENCE's own vectors at that size
     (tests/golden/c5_anpmr_shapenet3d_t8*.npz, generated by importing /root/reference: mu, kl, the quaternion loss at 1e-4, every
-    gradient of loss + 1e-7*kl at 1e-4 + U.FLIP_SHARE per routing decision that sits on a tie and fell the other way - never
-    skipped), and (2) the CPU oracle evaluated in fp64 (see _anpmr3d_routed_check) under the same seeded eps draws and the kernels'
+    gradient of loss + 1e-7*kl at 1e-4 - plus, when routing decisions sit on a tie and fell the other way, their effect measured in
+    the oracle (tests/util.py::flip_effect) - never skipped), and (2) the CPU oracle evaluated in fp64 (see _anpmr3d_routed_check) under the same seeded eps draws and the kernels'
     ReLU routing (360 images x ~1e5 decisions each) at 1e-4 flat.  `_7_23`: one batch of the reference's TRAINING draw - context
     size ~ U{1..15}, the other 30 - Nc views of the object are the targets (dataset/shapenet_3d.py:110, 200-204); `_survey`:
     SURVEY section 8c's input recipe, whose recorded answers (loss 2.26335859, kl 1383162.5) are asserted as well.
@@ -807,8 +823,10 @@ def test_c5_full_size_forward_backward_vs_oracle(gpulib, name):
     grads = {k: p.grad for k, p in model.named_parameters()}
     stem = {k: g for k, g in grads.items() if k.startswith("img_encoder.net.layer1.conv.") or k.startswith("decoder.conv1.")}
     rest = {k: g for k, g in grads.items() if k not in stem}
-    w1 = U.check_grads_against_fixture_flipped(rest, fx, meta, flips, name, head=1024, stride_cap=4096)
-    w2 = U.check_grads_against_fixture_flipped(stem, fx, meta, flips, name + " (stem tensors)", tol=3e-4, head=1024, stride_cap=4096)
+    eff = _anpmr3d_routed_check.effect() if flips else None
+    gm = U.fixture_gmax(grads, fx)
+    w1 = U.check_grads_against_fixture_flipped(rest, fx, meta, flips, name, effect=eff, gmax=gm, head=1024, stride_cap=4096)
+    w2 = U.check_grads_against_fixture_flipped(stem, fx, meta, flips, name + " (stem tensors)", tol=3e-4, effect=eff, gmax=gm, head=1024, stride_cap=4096)
     total = sum(float(g.double().norm()) ** 2 for g in grads.values() if g is not None) ** 0.5
     assert abs(total - meta["grad_norm_total"]) <= U.RTOL * meta["grad_norm_total"]
     print(f"{name}: {flips} routing decisions on a tie; vs the reference's vectors: gradients worst {w1[0]:.2e} ({w1[1]}), stem {w2[0]:.2e} ({w2[1]}); "
@@ -973,7 +991,12 @@ def test_fcl_models_vs_reference(gpulib, name):
             # 3e-4: the NT-Xent term divides cosine similarities by the temperature (0.07), which scales the fp32 rounding
             # differences of the embeddings ~14x on their way back (measured worst case 1.4e-4, on the attention queries)
             assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= 3e-4, k
-        U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name, tol=3e-4, head=1024, stride_cap=4096)
+        def effect():
+            p2 = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+            mu2, contra2 = O.fcl_resnet_forward(p2, cx, cy, qx, qy, c["agg_mode"], c["img_agg"], c.get("temperature", 0.07))
+            (O.calc_loss(c["task"], mu2, qy) + contra2).backward()
+            return U.flip_effect({k: p[k].grad for k, _ in model.named_parameters()}, {k: p2[k].grad for k, _ in model.named_parameters()}, U.GRAD_FLOOR * gmax)
+        U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name, tol=3e-4, effect=effect, head=1024, stride_cap=4096)
     with torch.no_grad():
         model.eval()
         if resnet:
@@ -1078,7 +1101,13 @@ def test_mr_vanilla_models_vs_reference(gpulib, name):
             assert grads[k] is None, k       # task_encoder / mu / decoder.* never receive a gradient
             continue
         assert U.rel_err(grads[k], p[k].grad, floor=U.GRAD_FLOOR * gmax) <= U.RTOL, k
-    U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name, head=1024, stride_cap=4096)
+    def effect():
+        p2 = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "projection" not in k) for k, v in model.state_dict().items()}
+        torch.manual_seed(99)
+        mu2, kl2 = O.vanilla_mr_forward(p2, cx, cy, qx, meta["cfg"]["agg_mode"], attention=meta["method"].startswith("ANP"), tanh=meta["method"].endswith("ShapeNet1D"))
+        (O.calc_loss(meta["cfg"]["task"], mu2, qy) + 1e-7 * kl2).backward()
+        return U.flip_effect({k: p[k].grad for k, _ in model.named_parameters()}, {k: p2[k].grad for k, _ in model.named_parameters()}, U.GRAD_FLOOR * gmax)
+    U.check_grads_against_fixture_flipped(grads, fx, meta, flips, name, effect=effect, head=1024, stride_cap=4096)
 
 
 
@@ -1839,7 +1868,7 @@ def test_exact_u8_feed_round_trip_is_bit_exact(gpulib, C, H, W):
         xq = synth.host_convert(rs.randint(0, 256, size=(T, Nq, H, W, C)).astype(np.uint8))
         return xs, xq, torch.from_numpy(rs.rand(T, Nc, 3).astype(np.float32)), torch.from_numpy(rs.rand(T, Nq, 3).astype(np.float32))
 
-    feed = ExactU8Feed(DEV, threads=3, chunk=50000)
+    feed = ExactU8Feed(DEV, threads=3)
     ptrs = None
     for _ in range(3):
         hb = host_batch()

@@ -553,12 +553,13 @@ class MlhotLib:
         self.c.mlhot_mt19937_jump_ws_words.argtypes = [C.c_int]
         return int(self.c.mlhot_mt19937_jump_ws_words(n_sub))
 
-    def host_f32_to_u8_exact(self, src_ptr, dst_ptr, n, div=255.0):
+    def host_f32_to_u8_exact(self, src_ptr, dst_ptr, n, div=255.0, threads=1):
         """Raw host pointers (ints), n elements: bytes into dst, returns the number of elements that do NOT round-trip through
-        (float)byte / div bit for bit.  Host only; releases the GIL (ctypes), so pieces of one batch run on several threads."""
-        self.c.mlhot_host_f32_to_u8_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.POINTER(C.c_int64)]
+        (float)byte / div bit for bit.  Host only; `threads` native threads inside the call (the GIL is released for its duration)."""
+        self.c.mlhot_host_f32_to_u8_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.POINTER(C.c_int64)]
         bad = C.c_int64(0)
-        self._rc(self.c.mlhot_host_f32_to_u8_exact(C.c_void_p(src_ptr), C.c_void_p(dst_ptr), int(n), float(div), C.byref(bad)), "mlhot_host_f32_to_u8_exact")
+        self._rc(self.c.mlhot_host_f32_to_u8_exact(C.c_void_p(src_ptr), C.c_void_p(dst_ptr), int(n), float(div), int(threads), C.byref(bad)),
+                 "mlhot_host_f32_to_u8_exact")
         return int(bad.value)
 
     def mt19937_advance(self, engine, n_outputs):

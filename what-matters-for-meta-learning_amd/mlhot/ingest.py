@@ -170,7 +170,7 @@ class BatchIngest:
 class ExactU8Feed:
     """fp32 host batches of a reference-style loader (dataset/shapenet_1d.py:189-196 -> utils/utils.py:26-30: `img.astype(float32) /
     255.0`, channel-first) across PCIe as BYTES when - and only when - every image element is exactly k / 255 for a byte k
-    (mlhot_host_f32_to_u8_exact checks all of them while it converts; K host threads, one pass): a quarter of the traffic, and the ingest
+    (mlhot_host_f32_to_u8_exact checks all of them while it converts; K native host threads, one pass): a quarter of the traffic, and the ingest
     kernel's `(float)k / 255` on the device gives the loader's fp32 values back bit for bit.  A batch with ANY other value (an
     augmentation that blends pixels, a loader that normalises differently) is refused - stage() returns None and the caller ships the
     fp32 tensors as before; after `give_up` refusals in a row the check is not attempted any more.
@@ -180,12 +180,10 @@ class ExactU8Feed:
         ctx_x, qry_x, ctx_y, qry_y = feed.take(ticket)        # fp32 device tensors (fixed addresses per batch shape)
     """
 
-    def __init__(self, device, threads=None, div=255.0, give_up=3, chunk=1 << 20):
-        from concurrent.futures import ThreadPoolExecutor
+    def __init__(self, device, threads=None, div=255.0, give_up=3):
         self.ing = BatchIngest(device, div=div)
-        self.div, self.chunk, self.give_up = float(div), int(chunk), int(give_up)
-        self.threads = default_feed_threads() if threads is None else max(1, int(threads))
-        self._pool = ThreadPoolExecutor(max_workers=self.threads - 1, thread_name_prefix="mlhot-u8-feed") if self.threads > 1 else None
+        self.div, self.give_up = float(div), int(give_up)
+        self.threads = default_feed_threads() if threads is None else max(1, min(64, int(threads)))
         self.ok, self.refused_in_a_row = True, 0
         self.shipped, self.refused = 0, 0
 
@@ -204,20 +202,9 @@ class ExactU8Feed:
         L = lib()
 
         def fill(host_np):
-            jobs = []
             for src, dst in ((xs, host_np[0]), (xq, host_np[1])):
-                n, sp, dp = src.numel(), src.data_ptr(), dst.ctypes.data
-                jobs += [(sp + 4 * o, dp + o, min(self.chunk, n - o)) for o in range(0, n, self.chunk)]
-
-            def one(j):
-                return L.host_f32_to_u8_exact(j[0], j[1], j[2], self.div)
-            if self._pool is not None and len(jobs) > 1:
-                rest = [self._pool.submit(one, j) for j in jobs[1:]]
-                bad = one(jobs[0]) + sum(r.result() for r in rest)
-            else:
-                bad = sum(one(j) for j in jobs)
-            if bad:
-                return False
+                if L.host_f32_to_u8_exact(src.data_ptr(), dst.ctypes.data, src.numel(), self.div, threads=self.threads):
+                    return False
             np.copyto(host_np[2], ys.numpy())
             np.copyto(host_np[3], yq.numpy())
             return True
