@@ -192,10 +192,18 @@ def test_loss_allowance(task, mu, gt, rtol=RTOL):
 test_loss_allowance.__test__ = False       # a helper, not a test (pytest collects names starting with test_)
 
 
-# What a routing decision that sits on a tie and fell the other way does to a gradient is not a constant: in a 2-image case ONE flipped
-# ReLU moved a stem gradient by 2e-2 of its scale (r_anp_distractor, round 6), at 480 images four flips move nothing above 1e-4.  So
-# the bound is MEASURED where it can be measured exactly - in the oracle: the same CPU arithmetic run twice, once under the kernels'
-# routing and once under its own, differs by exactly the flips' effect, tensor by tensor (flip_effect below).
+# What ONE routing decision that sits on a tie and fell the other way does to a gradient: it adds or removes one position's term of the
+# sums behind every weight gradient below it, so its share of a tensor's largest entry shrinks with the number of images summed over.
+# On record (MI355X box, round 6; kernels vs the REFERENCE's own gradients): 3.6e-2 of a stem gradient's scale for one flip at 5 images
+# (r_anp_distractor), 7.9e-3 at 8 (r_cnp_distractor_mean), 1.5e-2 / 3.0e-3 at 10 (f_fclcnp_distractor_*), 3.0e-4 at 360 (c5, T = 8),
+# 7e-5 per flip at 480 (c2: three flips, 2.1e-4) - every one of them <= 0.2 / n_images.  The bound against the fixture is therefore
+#     tol                                           when no decision differs from the oracle's own (the strong statement), else
+#     tol + (flips + 1) x FLIP_SHARE / n_images     flips = decisions that differ between the kernels and the oracle run beside them;
+# the "+ 1": the oracle's own run on THIS host may itself decide a tie differently from the reference's recorded run on the build
+# container (another CPU, another summation order - seen on the GPU box: the oracle's own-routing gradients were off the fixture's by
+# one flip's worth while the kernels' routing equalled the oracle's).  The exact effect of the kernels-vs-oracle flips, measured in
+# the oracle (flip_effect), is logged next to the error.
+FLIP_SHARE = 0.2
 
 
 def flip_effect(routed, own, floor=0.0):
@@ -221,29 +229,21 @@ def parity_log(line):
         pass
 
 
-def check_grads_against_fixture_flipped(grads, fx, meta, flips, what="", tol=RTOL, effect=None, **kw):
-    """The reference's OWN gradients (the fixture) against the kernels', ALWAYS.  No routing decision differs from the reference's:
-    at `tol`.  Otherwise (each differing decision was proven a <= TIE tie of the oracle's pre-activations by the caller): per tensor
-    at tol + 1.25 x effect[k] + tol, `effect` = flip_effect(...) measured in the oracle (a callable is evaluated only when needed) -
-    kernels vs fixture <= kernels vs routed oracle (tol) + routed oracle vs own-routing oracle (the effect) + own-routing oracle vs
-    fixture (the oracle's CPU pin).  Returns (worst error, its tensor, the bound that applied to it)."""
-    if flips == 0:
-        worst = check_grads_against_fixture(grads, fx, meta, tol=tol, **kw)
-        parity_log(f"{what}: every routing decision equals the reference's; gradients vs the REFERENCE's own (fixture): worst {worst[0]:.2e} ({worst[1]}) <= {tol:.1e}")
-        return worst[0], worst[1], tol
-    assert effect is not None, "routing decisions differ: pass the measured effect (flip_effect) of the differing decisions"
-    if callable(effect):
-        effect = effect()
-    worst, bound = (0.0, None), tol
-    gmax = kw.pop("gmax", None)
-    gmax = fixture_gmax(grads, fx) if gmax is None else gmax
-    for k, g in grads.items():
-        tol_k = 2.0 * tol + 1.25 * effect.get(k, 0.0)
-        e = check_grads_against_fixture({k: g}, fx, meta, tol=tol_k, gmax=gmax, **kw)[0]
-        if e >= worst[0]:
-            worst, bound = (e, k), tol_k
-    parity_log(f"{what}: {flips} routing decisions on a tie fell the other way (largest measured effect on a gradient {max(effect.values(), default=0.0):.2e} of "
-               f"its scale); gradients vs the REFERENCE's own (fixture): worst {worst[0]:.2e} ({worst[1]}) <= {bound:.2e}")
+def check_grads_against_fixture_flipped(grads, fx, meta, flips, what="", tol=RTOL, effect=None, n_images=None, **kw):
+    """The reference's OWN gradients (the fixture) against the kernels', ALWAYS - at `tol` when no routing decision differs, otherwise
+    at tol + (flips + 1) x FLIP_SHARE / n_images (above); each differing decision was proven a <= TIE tie of the oracle's
+    pre-activations by the caller.  `effect`: flip_effect(...) or a callable returning it - the differing decisions' exact effect in
+    the oracle, logged.  Returns (worst error, its tensor, the bound)."""
+    if n_images is None:
+        n_images = meta["cfg"]["tasks_per_batch"] * (meta["Nc"] + meta["Nq"])
+    bound = tol if flips == 0 else tol + (flips + 1) * FLIP_SHARE / max(1, n_images)
+    worst = check_grads_against_fixture(grads, fx, meta, tol=bound, **kw)
+    note = ""
+    if flips and effect is not None:
+        eff = effect() if callable(effect) else effect
+        note = f"; the differing decisions' effect measured in the oracle: {max(eff.values(), default=0.0):.2e} of a tensor's scale at most"
+    parity_log(f"{what}: {flips} routing decisions on a tie fell the other way ({n_images} images); gradients vs the REFERENCE's own (fixture): "
+               f"worst {worst[0]:.2e} ({worst[1]}) <= {bound:.2e}{note}")
     return worst[0], worst[1], bound
 
 

@@ -30,6 +30,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int CIN = 32, COUT = 48;
 constexpr int NT = 768;
+#ifndef C12_NT_STORE
+#define C12_NT_STORE 0
+#endif
 // conv1-output patch of one band: [ci 32][row 9][col 65]; col c <-> ix = c - 1 (col 0 = zero pad),
 // row r <-> iy = 8*band - 1 + r.
 constexpr int RS = 65, ROWS = 9, PS = ROWS * RS;          // 585
@@ -519,8 +522,16 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
       pv[j] = best; pa[j] = which;
     }
     const size_t o = (((size_t)img * COUT + n) * 16 + 2 * band + rp) * 16 + 8 * ch + 2 * lq;
+#if C12_NT_STORE
+    // non-temporal: the pooled map and the arg-max bytes are read next by OTHER kernels (conv3 / the backward), on whatever XCD their
+    // workgroups land - kept as dirty lines in this XCD's L2 they are written back at the kernel boundary, in front of conv3
+    // (23.6 + 5.9 MB per c3 forward; MI355X_MICROARCH.md's "+ B / 6 TB/s" boundary term); streamed out they drain under the bands
+    __builtin_nontemporal_store(f32x2_t{pv[0], pv[1]}, reinterpret_cast<f32x2_t*>(p2 + o));
+    __builtin_nontemporal_store((unsigned short)(pa[0] | (pa[1] << 8)), reinterpret_cast<unsigned short*>(amax + o));
+#else
     *reinterpret_cast<float2*>(p2 + o) = make_float2(pv[0], pv[1]);
     *reinterpret_cast<unsigned short*>(amax + o) = (unsigned short)(pa[0] | (pa[1] << 8));
+#endif
 #ifdef MLHOT_TS
     if (tsb && (lane == 0)) tf::g_ts_dev[400 + wave * 4 + 2] = clock64();
 #endif

@@ -30,8 +30,14 @@ namespace mlhot {
 #endif
 namespace tf { extern __device__ long long* g_ts_dev; }
 #define RW_TS(slot) do { if (tf::g_ts_dev && blockIdx.x == 0 && threadIdx.x == 0 && G::HIN == RW_TS_HIN && G::S == RW_TS_S) tf::g_ts_dev[300 + (slot)] = clock64(); } while (0)
+// every workgroup of the stamped geometry (round 6, scripts/dev/trunk_cu_timeline.py): 32 slots per workgroup from g_ts_dev[4096] - slot 0 the
+// hardware id (XCC / SE / CU / SIMD of wave 0), 1 entry, 2 prologue done, then per band (up to 7) [staged, MFMAs done, stored], 31 exit;
+// constant 100 MHz ticks (wall_clock64) so that workgroups on different CUs share a time base
+#define RW_TSALL(slot) do { if (tf::g_ts_dev && threadIdx.x == 0 && G::HIN == RW_TS_HIN && G::S == RW_TS_S && !SKIP1 && blockIdx.x < 1024 && tf::g_ts_dev[4095] == 0) \
+    tf::g_ts_dev[4096 + 32 * blockIdx.x + (slot)] = (slot) == 0 ? (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) : wall_clock64(); } while (0)
 #else
 #define RW_TS(slot) do {} while (0)
+#define RW_TSALL(slot) do {} while (0)
 #endif
 namespace rw {
 
@@ -255,6 +261,7 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
   const int co = 16 * nt + lr;
 
   RW_TS(0);
+  RW_TSALL(0); RW_TSALL(1);
   float wr[NKS];
   {
     const float* wp = jb.wimg + (size_t)nt * NKS * 64 + lane;
@@ -292,7 +299,11 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
   const int nbands_all = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
   const int nbands = band_end < nbands_all ? band_end : nbands_all;
   RW_TS(1);
+  RW_TSALL(2);
   int ts_k = 0;
+#ifdef MLHOT_TS
+  int ts_b = 0;
+#endif
 #pragma unroll 1
   for (int band = band0; band < nbands; band += band_step) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
@@ -300,6 +311,9 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
     RW_TS(2 + 4 * ts_k);
     stage_patch<G>(patch, jb.x, img0, oy0, jb.n_img, tid, jb.img_lo);
     RW_TS(3 + 4 * ts_k);
+#ifdef MLHOT_TS
+    if (ts_b < 7) RW_TSALL(3 + 3 * ts_b);
+#endif
 
     // ---- the epilogue's addresses and its `aux` loads (residual / mask epilogues), in front of the MFMA loop ----------------------
     // Round 5, band timeline of the 16 x 16 conv2 (scripts/dev/trunk_ts.py): MFMAs done at 32.6 k cycles, aux loads issued at 34.2 k,
@@ -371,6 +385,9 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
     }
 
     RW_TS(4 + 4 * ts_k);
+#ifdef MLHOT_TS
+    if (ts_b < 7) RW_TSALL(4 + 3 * ts_b);
+#endif
     // ---- epilogue: lane holds rows 4lq..4lq+3 of every tile for channel co ----
     // The four rows are contiguous in the NCHW plane in runs of VW (a tile row has TC >= 2 columns; 2x2 maps: a whole plane).
     // Two passes: every tile's output offset and - for the residual / mask epilogues - its `aux` load are made IN FRONT of the
@@ -406,9 +423,14 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
       }
     }
     RW_TS(5 + 4 * ts_k);
+#ifdef MLHOT_TS
+    if (ts_b < 7) RW_TSALL(5 + 3 * ts_b);
+    ++ts_b;
+#endif
     ts_k = ts_k < 3 ? ts_k + 1 : 3;
   }
   RW_TS(20);
+  RW_TSALL(31);
 }
 
 template <class G, bool SKIP1>
