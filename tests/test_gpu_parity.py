@@ -823,7 +823,7 @@ def test_c5_full_size_forward_backward_vs_oracle(gpulib, name):
     grads = {k: p.grad for k, p in model.named_parameters()}
     stem = {k: g for k, g in grads.items() if k.startswith("img_encoder.net.layer1.conv.") or k.startswith("decoder.conv1.")}
     rest = {k: g for k, g in grads.items() if k not in stem}
-    eff = _anpmr3d_routed_check.effect if flips else None
+    eff = None            # (the measured effect would be a second fp64 oracle run at 360 images: ~30 s per case; the bound does not use it)
     gm = U.fixture_gmax(grads, fx)
     w1 = U.check_grads_against_fixture_flipped(rest, fx, meta, flips, name, effect=eff, gmax=gm, head=1024, stride_cap=4096)
     w2 = U.check_grads_against_fixture_flipped(stem, fx, meta, flips, name + " (stem tensors)", tol=3e-4, gmax=gm, head=1024, stride_cap=4096)

@@ -33,6 +33,9 @@ constexpr int NT = 768;
 #ifndef C12_NT_STORE
 #define C12_NT_STORE 0
 #endif
+#ifndef C12_M1_LANE0
+#define C12_M1_LANE0 0
+#endif
 // conv1-output patch of one band: [ci 32][row 9][col 65]; col c <-> ix = c - 1 (col 0 = zero pad),
 // row r <-> iy = 8*band - 1 + r.
 constexpr int RS = 65, ROWS = 9, PS = ROWS * RS;          // 585
@@ -355,12 +358,15 @@ __device__ __forceinline__ float* c1t_dst_cl(float* patch, int t, int lr, int lq
   return patch + ((t >> 2) * RS + 1 + 16 * (t & 3) + 4 * lq) * CS + lr;
 }
 template <bool MASK>
-__device__ __forceinline__ void c1t_post_cl(Conv1Tile& t, int r, float* d, unsigned* __restrict__ mrec) {
+__device__ __forceinline__ void c1t_post_cl(Conv1Tile& t, int r, float* d, unsigned* __restrict__ mrec, bool lane0 = true) {
   const bool p0 = t.c0[r] > 0.f, p1 = t.c1[r] > 0.f;
   d[r * CS] = p0 ? t.c0[r] : 0.f;
   d[r * CS + 16] = p1 ? t.c1[r] : 0.f;
   if (MASK) {
     const unsigned long long b0 = __builtin_amdgcn_ballot_w64(p0), b1 = __builtin_amdgcn_ballot_w64(p1);
+#if C12_M1_LANE0
+    if (lane0)
+#endif
     *reinterpret_cast<uint4*>(mrec + 4 * r) = make_uint4((unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32));
   }
 }
@@ -495,7 +501,11 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
         if (s < 3) ct.a[s] = conv1a_pixel_load(cl, x, next, j, s);                           // raw pixel: in flight for 5 k-steps
         else if (s >= 5 && s < 8) ct.a[s - 5] = conv1a_pixel_blend(ct.a[s - 5], cl, next, j, s - 5, wave >> 2);
         else if (s >= 8 && s < 14) c1t_mfma(ct, cw, s - 8);
-        else if (s >= 15 && s < 19) c1t_post_cl<true>(ct, s - 15, c1t_dst_cl(nb, tt, lr, lq), c1t_rec(m1, next, tt, n_img));
+#ifdef C12_KNOCK_M1      // timing experiment only (results WRONG for the backward): no sign-bit record stores
+        else if (s >= 15 && s < 19) c1t_post_cl<false>(ct, s - 15, c1t_dst_cl(nb, tt, lr, lq), nullptr);
+#else
+        else if (s >= 15 && s < 19) c1t_post_cl<true>(ct, s - 15, c1t_dst_cl(nb, tt, lr, lq), c1t_rec(m1, next, tt, n_img), lane == 0);
+#endif
       }
       // the warmed line has to be consumed somewhere or the load is dead code: it rides into the epilogue's bias as + 0 * pixel,
       // at the k-step where the wait for it costs nothing (inline asm would do, but see m1_record's note on AGPRs)

@@ -44,6 +44,28 @@ namespace rw {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// A barrier that orders LDS traffic only: `s_waitcnt lgkmcnt(0)` + `s_barrier`.  __syncthreads() is also a workgroup-scope fence for
+// GLOBAL memory, and with a band's output stores still in flight hipcc puts `s_waitcnt vmcnt(0)` in front of the barrier: every band
+// then waited out its predecessor's store acknowledgements (and the first band the whole weight image) before it even ASKED for its
+// patch (round 6, per-workgroup stamps of block 1's conv1: scripts/dev/trunk_cu_timeline.py).  The barriers of the band loop guard the
+// LDS patch and nothing else - waves of a workgroup never exchange data through global memory inside a body (the fused small-map
+// kernels do between bodies: they keep __syncthreads()).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// A wave's 144 (or 16) registers of a lane-native weight image through ONE buffer descriptor: `buffer_load_dword v, v_lane, s[rsrc],
+// s_group offen offset:256 j` - the lane part of the address is one VGPR, the k-step part an immediate (16 steps of 256 B) plus an SGPR
+// (4 KB groups).  As `wp[ks * 64]` on a flat pointer every load carried its own 64-bit VGPR address (the 36 KB span does not fit
+// global_load's 12-bit immediate): the address registers did not fit beside the 144 destinations, hipcc spilled, and the reload's
+// `s_waitcnt vmcnt(0)` cut the sequence into several full L2 round trips - 5.2 us of prologue per workgroup (stamps, as above).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wimg_rsrc(const float* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float wimg_load(__amdgpu_buffer_rsrc_t rs, int lane_bytes, int idx) {      // element [idx][lane] of a [..][64] image
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_bytes + (idx % 16) * 256, (idx / 16) * 4096, 0));
+}
+
 constexpr int CH = 64;                 // channels of every block convolution
 constexpr int NKS = 144;               // k-steps of a 3x3 convolution over 64 channels (9 taps x 16 groups of 4 channels)
 constexpr int WIMG = 4 * NKS * 64;     // floats of one lane-native 3x3 weight image
@@ -177,7 +199,7 @@ template <class G>
 __device__ __forceinline__ void stage_patch(float* patch, const float* __restrict__ x, int img0, int oy0, int n_img, int tid, int img_lo = 0) {
   typedef float stage_t __attribute__((ext_vector_type(G::SEGW)));
   constexpr int CH_ITEMS = 10;
-  __syncthreads();
+  lds_barrier();
   if constexpr (G::SEG >= 4) {
     // Maps of 16 x 16 and up: thread = (row segment seg, channel cil of a group of 256 / SEG); its items run over (channel group,
     // image, patch row) - compile-time steps, so the requests and stores of a thread differ by wave-uniform / immediate offsets
@@ -198,24 +220,34 @@ __device__ __forceinline__ void stage_patch(float* patch, const float* __restric
         if (j >= CNT2) break;
         const int ch = j / NROW, il = (j % NROW) / G::PR, pr = j % G::PR;
         const int iy = G::S * oy0 + G::ROW0 + pr;                                     // wave-uniform
-        stage_t v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = 0.f;
-        if (iy >= 0 && iy < G::HIN && img0 + il < n_img && img0 + il >= img_lo)
-          v = *reinterpret_cast<const stage_t*>(gl + ((size_t)(img0 + il) * CH + ch * TCI) * (G::HIN * G::HIN) + iy * G::HIN);
-        st[jj] = v;
+        // UNCONDITIONAL loads from a clamped (row, image): a row outside the map / an absent image is decided when its words are
+        // stored (zeros).  As `v = 0; if (row exists) v = load` every item was a phi of a constant and a load: hipcc copied the
+        // loaded registers right behind the request (`global_load_dwordx4 v[4:7]; s_waitcnt vmcnt(0); v_mov v45, v4`) - the second
+        // of a band's 18 requests waited for the first two AND for everything older (the weight image), the rest went out a round
+        // trip later (round 6, the kernel's ISA next to scripts/dev/trunk_cu_timeline.py's stamps).
+        const int iyc = iy < 0 ? 0 : (iy >= G::HIN ? G::HIN - 1 : iy);
+        int ic = img0 + il;
+        ic = ic >= n_img ? n_img - 1 : ic;
+        ic = ic < img_lo ? img_lo : ic;
+        st[jj] = *reinterpret_cast<const stage_t*>(gl + ((size_t)ic * CH + ch * TCI) * (G::HIN * G::HIN) + iyc * G::HIN);
       }
 #pragma unroll
       for (int jj = 0; jj < CH_ITEMS; ++jj) {
         const int j = j0 + jj;
         if (j >= CNT2) break;
         const int ch = j / NROW, il = (j % NROW) / G::PR, pr = j % G::PR;
+        const int iy = G::S * oy0 + G::ROW0 + pr;
         float* d = dl + ch * TCI * G::PS + il * G::ISZ + pr * G::RS;
+        if (iy >= 0 && iy < G::HIN && img0 + il < n_img && img0 + il >= img_lo) {     // wave-uniform: a scalar branch around four LDS stores
 #pragma unroll
-        for (int q = 0; q < 4; ++q) d[q] = st[jj][q];
+          for (int q = 0; q < 4; ++q) d[q] = st[jj][q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) d[q] = 0.f;
+        }
       }
     }
-    __syncthreads();
+    lds_barrier();
     return;
   }
 #pragma unroll
@@ -248,7 +280,7 @@ __device__ __forceinline__ void stage_patch(float* patch, const float* __restric
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // The body of a forward-type launch: bands band0, band0 + band_step, ... < band_end of job `jb`, the patch in `patch` (G::PATCH floats
@@ -262,29 +294,30 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
 
   RW_TS(0);
   RW_TSALL(0); RW_TSALL(1);
+  const float bn = jb.b ? jb.b[co] : 0.f;            // in front of the weight image: vmcnt retires in order, and a use of the bias must not wait for 144 younger loads
   float wr[NKS];
   {
-    const float* wp = jb.wimg + (size_t)nt * NKS * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rs = wimg_rsrc(jb.wimg + (size_t)nt * NKS * 64, NKS * 64 * 4);
     if (jb.flip) {
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) wr[ks] = wp[((8 - ks / 16) * 16 + ks % 16) * 64];
+      for (int ks = 0; ks < NKS; ++ks) wr[ks] = wimg_load(rs, 4 * lane, (8 - ks / 16) * 16 + ks % 16);
     } else {
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) wr[ks] = wp[ks * 64];
+      for (int ks = 0; ks < NKS; ++ks) wr[ks] = wimg_load(rs, 4 * lane, ks);
     }
   }
   float w1[SKIP1 ? 16 : 1];
   float bn1 = 0.f;
   const bool has1 = SKIP1 && jb.w1img != nullptr;      // per job: a launch may mix blocks with and without the fused 1x1 skip
   if (has1) {
-    const float* wp = jb.w1img + (size_t)nt * 16 * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rs1 = wimg_rsrc(jb.w1img + (size_t)nt * 16 * 64, 16 * 64 * 4);
 #pragma unroll
-    for (int cg = 0; cg < 16; ++cg) w1[cg] = wp[cg * 64];
+    for (int cg = 0; cg < 16; ++cg) w1[cg] = wimg_load(rs1, 4 * lane, cg);
     bn1 = jb.b1 ? jb.b1[co] : 0.f;
   }
-  const float bn = jb.b ? jb.b[co] : 0.f;
 
-  for (int i = tid; i < G::PATCH; i += 256) patch[i] = 0.f;        // halo columns (and pad words) stay zero for good
+  static_assert(G::PATCH % 4 == 0, "patch zeroing");
+  for (int i = tid; i < G::PATCH / 4; i += 256) reinterpret_cast<float4*>(patch)[i] = make_float4(0.f, 0.f, 0.f, 0.f);      // halo columns (and pad words) stay zero for good
 
   // A-operand base of every M-tile: channel lq of the lane's position (row lr of the tile)
   int aoff[G::NACC];
@@ -304,16 +337,24 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
 #ifdef MLHOT_TS
   int ts_b = 0;
 #endif
+  // The first band's patch is staged HERE, in front of the loop, and every later band's at the end of its predecessor's iteration.
+  // With the staging at the top of the loop body the loop header carried the back edge's `s_waitcnt vmcnt(0)` (the epilogue's stores
+  // have to have read their data registers before the staging reuses them) - and on the way IN that same instruction waited for the
+  // whole weight image before the first patch request went out: two dependent round trips in every workgroup's prologue (round 6,
+  // scripts/dev/trunk_cu_timeline.py: 5.2 us of prologue + 3.3 us of first staging with no wave of the CU on the matrix pipe).
+  auto stage = [&](int band) {
+    const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
+    const int oy0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
+    stage_patch<G>(patch, jb.x, img0, oy0, jb.n_img, tid, jb.img_lo);
+  };
+  RW_TS(2);
+  if (band0 < nbands) stage(band0);
+  RW_TS(3);
+  RW_TSALL(3);
 #pragma unroll 1
   for (int band = band0; band < nbands; band += band_step) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
     const int oy0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
-    RW_TS(2 + 4 * ts_k);
-    stage_patch<G>(patch, jb.x, img0, oy0, jb.n_img, tid, jb.img_lo);
-    RW_TS(3 + 4 * ts_k);
-#ifdef MLHOT_TS
-    if (ts_b < 7) RW_TSALL(3 + 3 * ts_b);
-#endif
 
     // ---- the epilogue's addresses and its `aux` loads (residual / mask epilogues), in front of the MFMA loop ----------------------
     // Round 5, band timeline of the 16 x 16 conv2 (scripts/dev/trunk_ts.py): MFMAs done at 32.6 k cycles, aux loads issued at 34.2 k,
@@ -338,10 +379,16 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
         const int img = img0 + il;
         live[t][vi] = img < jb.n_img && img >= jb.img_lo;
         offs[t][vi] = (((unsigned)(live[t][vi] ? img : 0) * CH + co) * G::HO + oy0 + oy) * G::WO + ox;
-#pragma unroll
-        for (int q = 0; q < VW; ++q) ax[t][vi][q] = 0.f;
-        if (need_aux && live[t][vi]) ax[t][vi] = *reinterpret_cast<const vw_t*>(jb.aux + offs[t][vi]);
       }
+    }
+    // all of them in ONE job-uniform branch, unconditional on `live` (a dead tile reads image 0's words and never uses them), no
+    // zero-initialisation: as `ax = 0; if (need_aux && live) ax = load` each was a phi of a constant and a load, and hipcc waited
+    // `vmcnt(0)` behind the first request to copy it - a full round trip in front of every band's MFMAs (round 6, ISA)
+    if (need_aux) {
+#pragma unroll
+      for (int t = 0; t < G::NACC; ++t)
+#pragma unroll
+        for (int vi = 0; vi < NV; ++vi) ax[t][vi] = *reinterpret_cast<const vw_t*>(jb.aux + offs[t][vi]);
     }
 
     // ---- 144 k-steps x NACC tiles ----
@@ -428,6 +475,14 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
     ++ts_b;
 #endif
     ts_k = ts_k < 3 ? ts_k + 1 : 3;
+    if (band + band_step < nbands) {
+      RW_TS(2 + 4 * ts_k);
+      stage(band + band_step);
+      RW_TS(3 + 4 * ts_k);
+#ifdef MLHOT_TS
+      if (ts_b < 7) RW_TSALL(3 + 3 * ts_b);
+#endif
+    }
   }
   RW_TS(20);
   RW_TSALL(31);
@@ -435,7 +490,7 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
 
 template <class G, bool SKIP1>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const FwdJobs jobs) {
-  __shared__ float patch[G::PATCH];
+  __shared__ __attribute__((aligned(16))) float patch[G::PATCH];
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ++ji;
   const FwdJob& jb = jobs.j[ji];
@@ -542,16 +597,16 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
 
   float wr[NKS];
   {
-    const float* wp = ((DUAL && half) ? jb.w1img : jb.wimg) + (size_t)nt * NKS * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rs = wimg_rsrc(((DUAL && half) ? jb.w1img : jb.wimg) + (size_t)nt * NKS * 64, NKS * 64 * 4);
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) wr[ks] = wp[ks * 64];
+    for (int ks = 0; ks < NKS; ++ks) wr[ks] = wimg_load(rs, 4 * lane, ks);
   }
   float w1[SKIP1 ? 16 : 1];
   const bool has1 = SKIP1 && jb.w1img != nullptr;      // per job
   if (has1) {
-    const float* wp = jb.w1img + (size_t)nt * 16 * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rs1 = wimg_rsrc(jb.w1img + (size_t)nt * 16 * 64, 16 * 64 * 4);
 #pragma unroll
-    for (int cg = 0; cg < 16; ++cg) w1[cg] = wp[cg * 64];
+    for (int cg = 0; cg < 16; ++cg) w1[cg] = wimg_load(rs1, 4 * lane, cg);
   }
   for (int i = tid; i < G::PATCH * (SKIP1 ? 2 : 1); i += 256) patch[i] = 0.f;      // halo column / pad words stay zero
 
@@ -818,7 +873,7 @@ constexpr int GI = T34_GI;        // images per workgroup: 1, 2 or 4.  The 2 x 2
 static_assert(GI == 1 || GI == 2 || GI == 4, "image group");
 
 __global__ __launch_bounds__(256, 2) void tail34_fwd_kernel(const T34Jobs jobs) {
-  __shared__ float patch[cmax(cmax(G8s2::PATCH, G4s1::PATCH), cmax(G4s2::PATCH, G2s1::PATCH))];
+  __shared__ __attribute__((aligned(16))) float patch[cmax(cmax(G8s2::PATCH, G4s1::PATCH), cmax(G4s2::PATCH, G2s1::PATCH))];
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.p[ji + 1].wg0) ++ji;
   const T34Pass& P = jobs.p[ji];
@@ -860,7 +915,7 @@ __global__ __launch_bounds__(256, 2) void tail34_fwd_kernel(const T34Jobs jobs) 
 }
 
 __global__ __launch_bounds__(256, 2) void tail34_bwd_kernel(const T34Jobs jobs) {
-  __shared__ float patch[cmax(cmax(G2s1::PATCH, G4s1::PATCH), 2 * cmax(D2::PATCH, D4::PATCH))];
+  __shared__ __attribute__((aligned(16))) float patch[cmax(cmax(G2s1::PATCH, G4s1::PATCH), 2 * cmax(D2::PATCH, D4::PATCH))];
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.p[ji + 1].wg0) ++ji;
   const T34Pass& P = jobs.p[ji];
@@ -1393,7 +1448,7 @@ struct StemGeo {
 template <int C, int HIN>
 __global__ __launch_bounds__(256, 2) void stem_kernel(const StemJobs jobs) {
   typedef StemGeo<C, HIN> G;
-  __shared__ float patch[G::PATCH];
+  __shared__ __attribute__((aligned(16))) float patch[G::PATCH];
   const int tid = threadIdx.x, lane = tid & 63, nt = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   int ji = 0;

@@ -54,6 +54,11 @@ class HeadStack:
         if not self._aliased() and not self._adopt():
             ws, bs = [m.linear.weight for m in self.mods], [m.linear.bias for m in self.mods]
             h = ws[0].shape[0]
+            if any(t.untyped_storage().nbytes() > 4 * t.numel() + 64 for t in ws + bs):
+                # views of a larger buffer (mlhot.optim.FlatAdam's) that do not lie behind one another: concatenating would pull them out
+                # of the optimizer's buffer and training of these heads would stop without a word
+                raise RuntimeError("HeadStack: the heads' parameters are views of a flat buffer but not one contiguous block "
+                                   "(ResNetNP.flat_layout lays a stack's weights, then its biases, back to back)")
             with torch.no_grad():
                 self.w, self.b = torch.cat([t.detach() for t in ws], dim=0), torch.cat([t.detach() for t in bs], dim=0)
                 for i, (wt, bt) in enumerate(zip(ws, bs)):
@@ -149,11 +154,16 @@ class ResNetNP(nn.Module):
         active_names = len(order)
         take(dead)
         offs, total, active = {}, 0, 0
+        stacked = set()        # members of a head stack's block except the last: laid back to back, the 16-byte padding behind the block
+        if self.ATTENTION:
+            for stack in ("_W_q", "_W_k", "_W_v"):
+                for kind in ("weight", "bias"):
+                    stacked.update(f"{stack}.{i}.linear.{kind}" for i in range(self.N_HEADS - 1))
         for i, n in enumerate(order):
             if i == active_names:
                 active = total
             offs[n] = total
-            total += (named[n].numel() + 3) // 4 * 4
+            total += named[n].numel() if n in stacked else (named[n].numel() + 3) // 4 * 4
         if active_names == len(order):
             active = total
         return total, offs, active
