@@ -9,7 +9,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof
-TAG=${1:-r05_final}
+TAG=${1:-r06_final}
 rm -rf $OUT
 mkdir -p $OUT
 cd $REPO
@@ -38,6 +38,9 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 cd $REPO
 bash scripts/inst_mix.sh c3 > $OUT/${TAG}_inst_mix_c3.txt 2>&1
 bash scripts/lds_conflicts.sh c3 > $OUT/${TAG}_lds_conflicts_c3.txt 2>&1
+# the parity log the GPU tests keep (flip counts, decisions, worst errors against the oracle and against the reference's fixtures)
+rm -f $REPO/gpurun_out/parity_flips.txt
+MLHOT_PARITY_LOG=$OUT/${TAG}_parity_flips.txt python -m pytest tests -m gpu -q -p no:cacheprovider -k "baseline_configs_vs_reference or resnet_models_vs_reference or anpmr_shapenet3d_vs_reference or c5_full_size or mr_vanilla_models or fcl_models or mid_size_case or edge_cases" > $OUT/parity_tests.log 2>&1
 # BASELINE config c5's per-GPU step (ANPMRShapeNet3D, bench.py --workload c5): bench line, per-label kernel times, kernel stats
 cd $REPO
 python bench.py --workload c5 --steps 30 --warmup 5 > $OUT/${TAG}_bench_c5.json 2> $OUT/bench_c5.err
@@ -58,8 +61,9 @@ cd $REPO
 python3 scripts/pmc_by_label.py $OUT/seq_c5.json $OUT/${TAG}_pmc_traffic_c5.json c5 $(find $OUT/pmc_fetch_c5 -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write_c5 -name "*counter_collection.csv" | head -1)
 python3 scripts/pmc_by_label.py $OUT/seq_c5.json $OUT/${TAG}_pmc_sq_c5.json c5 $(find $OUT/pmc_sq_c5 -name "*counter_collection.csv" | head -1)
 # the opt-in split-precision conv12 kernels (extras, never `value`): an A/B bench line, kernel stats, instruction mix, LDS conflicts,
-# SQ counters and the error table against float64
+# SQ counters and the error table against float64.  Frozen since round 5: SKIP_SPLIT=1 leaves the section out.
 cd $REPO
+if [ "${SKIP_SPLIT:-0}" = "1" ]; then ls -la $OUT; exit 0; fi
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras --opt conv2_split=7 > $OUT/${TAG}_split_bench_c3.json 2> $OUT/bench_split.err
 python scripts/dev/split_error.py 8 > $OUT/${TAG}_split_error_vs_float64.txt 2> /dev/null
 bash scripts/inst_mix.sh c3 --opt conv2_split=7 > $OUT/${TAG}_split_inst_mix.txt 2>&1

@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06_final"
 force = "--force" in sys.argv
 
 # ---- one library build behind every summary ----------------------------------------------------------------------------------
@@ -77,7 +77,7 @@ def find(pattern):
 
 
 for name in (f"{tag}_bench_c3.json", f"{tag}_bench_c2.json", f"{tag}_kernels_c3.json", f"{tag}_bench_c5.json", f"{tag}_bench_c5_device_eps.json", f"{tag}_kernels_c5.json",
-             f"{tag}_pmc_traffic_c5.json", f"{tag}_pmc_sq_c5.json", f"{tag}_inst_mix_c3.txt", f"{tag}_lds_conflicts_c3.txt"):
+             f"{tag}_pmc_traffic_c5.json", f"{tag}_pmc_sq_c5.json", f"{tag}_inst_mix_c3.txt", f"{tag}_lds_conflicts_c3.txt", f"{tag}_parity_flips.txt"):
     p = os.path.join(SRC, name)
     if fresh(p):
         shutil.copy(p, os.path.join(DST, name))
