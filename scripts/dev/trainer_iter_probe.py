@@ -12,11 +12,21 @@ from trainer.model_trainer import ModelTrainer
 from networks.ANPShapeNet1D import ANPShapeNet1D
 
 DEV = torch.device("cuda:0")
-fixed = len(sys.argv) > 1 and sys.argv[1] == "fixed"
+fixed = "fixed" in sys.argv[1:]
+
+
+bytes_mode = "bytes" in sys.argv[1:]          # images that ARE bytes / 255 (what the reference's loaders hand out): the ExactU8Feed route
 
 
 class Data(Data1D):
     def get_batch(self, source, tasks_per_batch, shot):
+        if bytes_mode and source == "train":
+            from mlhot import synth
+            pool = self.__dict__.setdefault("_bytes", [])
+            if not pool:
+                hb = synth.get_batch_u8("shapenet_1d", tasks_per_batch, shot, shot, seed=5)
+                pool.append((synth.host_convert(hb[0]), synth.host_convert(hb[1]), hb[2], hb[3]))
+            return pool[0]
         if fixed and source == "train":
             pool = self.__dict__.setdefault("_fixed", [])
             if not pool:

@@ -1884,14 +1884,16 @@ def test_exact_u8_feed_round_trip_is_bit_exact(gpulib, C, H, W):
     hb = host_batch()
     hb[1].view(-1)[12345] = torch.nextafter(hb[1].view(-1)[12345], torch.tensor(2.0))
     assert feed.stage(hb) is None and feed.refused == 1 and feed.ok
-    hp = _HostPrefetch(DEV)
-    for batch, route in ((hb, "fp32"), (host_batch(), "u8")):
-        ticket = hp.stage(batch)
-        assert (ticket[0] == "u8") == (route == "u8")
-        got = hp.take(ticket)
-        torch.cuda.synchronize()
-        for g, h in zip(got, batch):
-            assert torch.equal(g.cpu(), h)
+    for background in (True, False):          # the copy on the worker thread (default) and on the caller's
+        hp = _HostPrefetch(DEV, background=background)
+        for batch, route in ((hb, "fp32"), (host_batch(), "u8"), (host_batch(), "u8")):
+            ticket = hp.stage(batch)
+            assert (ticket[0] == "later") == background
+            got = hp.take(ticket)
+            assert hp.last_fixed == (route == "u8")
+            torch.cuda.synchronize()
+            for g, h in zip(got, batch):
+                assert torch.equal(g.cpu(), h)
     # a loader that never hands out byte images: after three refusals in a row the check is not attempted any more
     feed = ExactU8Feed(DEV, threads=2)
     noise = (torch.rand(T, Nc, C, H, W), torch.rand(T, Nq, C, H, W), torch.rand(T, Nc, 3), torch.rand(T, Nq, 3))

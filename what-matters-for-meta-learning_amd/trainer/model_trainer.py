@@ -56,29 +56,48 @@ class _HostPrefetch:
     pass) and the batch then crosses PCIe as 7.9 instead of 31.5 MB, expanded by the ingest kernel to the same fp32 bits.  A batch that
     holds anything else takes the fp32 route below, unchanged; the loader's contract is untouched either way."""
 
-    def __init__(self, device, u8=True):
+    def __init__(self, device, u8=True, background=True):
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(self.device)
         self.u8 = None
+        self.last_fixed = False         # did the last take() hand out the byte route's fixed per-shape device tensors?
         if u8:
             from mlhot.ingest import ExactU8Feed
             self.u8 = ExactU8Feed(self.device)
+        # Round 6: the copy itself runs on ONE worker thread.  Whichever route a batch takes, putting it on its way blocks the calling
+        # thread for ~0.5 ms (the pageable fp32 copy: 0.60 ms; the byte conversion + its issue: 0.58 ms - measured inside this loop,
+        # scripts/dev/trainer_iter_probe.py), and with the reference's `loss.item()` every iteration that time is SERIAL with the
+        # iteration's other host work (~0.25 ms of Python around the replay): 0.87 ms per iteration for a 0.6 ms GPU step.  The worker
+        # makes the hand-over a queue push; the loader itself (get_batch, possibly on a shared generator) stays on the caller's thread.
+        self._pool = None
+        if background:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mlhot-host-batch")
+
+    def _stage_now(self, host_batch):
+        with torch.cuda.device(self.device):
+            if self.u8 is not None:
+                ticket = self.u8.stage(host_batch)
+                if ticket is not None:
+                    return ("u8", ticket)
+            with torch.cuda.stream(self.stream):
+                dev = tuple(t.to(self.device, non_blocking=True) for t in host_batch)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            return ("f32", dev, ev)
 
     def stage(self, host_batch):
-        if self.u8 is not None:
-            ticket = self.u8.stage(host_batch)
-            if ticket is not None:
-                return ("u8", ticket)
-        with torch.cuda.stream(self.stream):
-            dev = tuple(t.to(self.device, non_blocking=True) for t in host_batch)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        return dev, ev
+        if self._pool is not None:
+            return ("later", self._pool.submit(self._stage_now, host_batch))
+        return self._stage_now(host_batch)
 
     def take(self, ticket):
+        if ticket[0] == "later":
+            ticket = ticket[1].result()         # normally long done: the worker had a whole GPU step for it
+        self.last_fixed = ticket[0] == "u8"
         if ticket[0] == "u8":
             return self.u8.take(ticket[1])      # fixed device tensors per batch shape, ordered on the current stream
-        dev, ev = ticket
+        _, dev, ev = ticket
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
         for t in dev:
@@ -132,7 +151,8 @@ class ModelTrainer(BaseTrainer):
             from mlhot.ingest import BatchIngest
             self.ingest = BatchIngest(config.device)
         elif cuda and getattr(config, "host_prefetch", True):
-            self._host_prefetch = _HostPrefetch(config.device, u8=bool(getattr(config, "host_u8", True)))
+            self._host_prefetch = _HostPrefetch(config.device, u8=bool(getattr(config, "host_u8", True)),
+                                                background=bool(getattr(config, "host_copy_thread", True)))
 
     def _announce(self):
         """Once, at the start of train(): what the constructor promoted (nothing here is silent)."""
@@ -212,8 +232,9 @@ class ModelTrainer(BaseTrainer):
                 return hp.take(hp.stage(draw(source)))
             ticket, self._staged = (self._staged or hp.stage(draw("train"))), None
             self._stage_later = self._prefetch          # the next batch's (host-blocking) copy goes out BEHIND this step's launch: _stage_next()
-            self._fixed_batch = ticket[0] == "u8"       # the byte route delivers every batch of a shape in the same device tensors
-            return hp.take(ticket)
+            batch = hp.take(ticket)
+            self._fixed_batch = hp.last_fixed           # the byte route delivers every batch of a shape in the same device tensors
+            return batch
 
         def stage(src):
             return self.ingest.stage(*self.data.get_batch_u8(source=src, tasks_per_batch=self.config.tasks_per_batch,
