@@ -476,6 +476,25 @@ def measure_train_loop(w, device, loss_fn, iters):
             torch.cuda.synchronize()
             if timed:
                 out["reference_style_fp32_over_pcie_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_ref
+        # the promoted loop with every iteration's loss logged and checked ONE ITERATION LATE (config.lagged_loss_log, opt-in): the
+        # reference's `losses.item()` behind every step is a host sync that keeps iteration k + 1 from being launched before k is done
+        cfg3 = make_cfg(w, device)
+        cfg3.iterations, cfg3.val_freq, cfg3.val_iters, cfg3.bg_gen_freq, cfg3.gen_bg = 4, 10 ** 9, 1, 10 ** 9, False
+        cfg3.save_path, cfg3.logger, cfg3.contrastive, cfg3.max_ctx_num, cfg3.beta = tmp, None, False, NC, 0
+        cfg3.close_after_train, cfg3.lagged_loss_log = False, True
+        model3 = cls(cfg3).to(device)
+        tr3 = ModelTrainer(model=model3, loss=loss_fn, optimizer=torch.optim.Adam(model3.parameters(), lr=1e-4), config=cfg3, data=HostLoader())
+        tr3.train()
+        tr3.iterations = 10 ** 9
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for it in range(5, 5 + n_ref):
+                tr3._prefetch = True
+                tr3._train_iter(it)
+            torch.cuda.synchronize()
+            if timed:
+                out["reference_style_lagged_log_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_ref
     # the same sequence with nothing promoted: eager autograd, torch.optim.Adam over ~70 tensors, the copy in front of the step
     model = cls(make_cfg(w, device)).to(device)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
@@ -534,6 +553,7 @@ def measure_train_loop(w, device, loss_fn, iters):
             out["replayed_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_rep
     ing.take()
     out["tasks_per_s"] = {"reference_style": 1e3 * T_LOCAL / out["reference_style_ms_per_iter"],
+                          "reference_style_lagged_log": 1e3 * T_LOCAL / out["reference_style_lagged_log_ms_per_iter"],
                           "reference_style_unpromoted": 1e3 * T_LOCAL / out["reference_style_unpromoted_ms_per_iter"],
                           "replayed": 1e3 * T_LOCAL / out["replayed_ms_per_iter"]}
     out["adam_steps_taken"] = int(opt.step_dev.item())

@@ -2050,6 +2050,43 @@ def test_graph_replayed_training_equals_eager_training(gpulib, tmp_path, monkeyp
         assert torch.equal(finals[0][k], finals[1][k]), k
 
 
+def test_lagged_loss_log_reports_every_iteration_one_late(gpulib, tmp_path, monkeypatch):
+    """config.lagged_loss_log (opt-in): the replayed loop logs and checks EVERY iteration's loss, one iteration late - the same
+    (iteration, value) pairs in the same order as the loop that reads `losses.item()` behind every step (model_trainer.py:87-91),
+    nothing left behind a validation round or the end of train(), identical final weights."""
+    import types
+    from mlhot.optim import FlatAdam
+    from mlhot.synth import SyntheticData
+    from networks.ANPShapeNet1D import ANPShapeNet1D
+    from trainer.losses import LossFunc
+    from trainer.model_trainer import ModelTrainer
+    monkeypatch.chdir(tmp_path)
+    reports, finals, returned = [], [], []
+    for lag in (False, True):
+        cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[128, 128, 1], tasks_per_batch=2, input_dim=3,
+                                    output_dim=2, agg_mode="attention", img_agg="", dim_w=64, n_hidden_units_r=[100, 100], dim_r=64,
+                                    dim_z=64, task="shapenet_1d", iterations=13, val_freq=5, val_iters=1, bg_gen_freq=1000, gen_bg=False,
+                                    max_ctx_num=5, beta=0, contrastive=False, graph_steps=True, log_every=1, lagged_loss_log=lag,
+                                    save_path=str(tmp_path / f"l{int(lag)}"), logger=None)
+        model = ANPShapeNet1D(cfg).to(cfg.device)
+        tr = ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=FlatAdam(model, lr=1e-3, ctx_num=5, test_num=5, capturable=True),
+                          config=cfg, data=SyntheticData())
+        seen, rets = [], []
+        orig_report, orig_iter = tr._report, tr._train_iter
+        tr._report = lambda it, value, _o=orig_report, _s=seen: (_s.append((it, value)), _o(it, value))[1]
+        tr._train_iter = lambda it, _o=orig_iter, _r=rets: _r.append(_o(it))
+        tr.train()
+        reports.append(seen); returned.append(rets)
+        finals.append({k: v.clone() for k, v in model.state_dict().items()})
+    assert [it for it, _ in reports[0]] == list(range(1, 14)) and reports[0] == reports[1]
+    # what _train_iter hands back: the iteration's own loss / the previous iteration's (None right behind a flush: iterations 1, 6, 11)
+    assert returned[0] == [v for _, v in reports[0]]
+    want = [None if it in (1, 6, 11) else reports[0][it - 2][1] for it in range(1, 14)]
+    assert returned[1] == want
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+
+
 def test_graph_replayed_multi_rank_training_uses_each_graphs_own_gradients(gpulib, tmp_path, monkeypatch):
     """graph_steps with world > 1: the all-reduce and the optimizer step run OUTSIDE the graphs and read p.grad, which a replay
     does not rebind - with several batch shapes (the context size is drawn per iteration) each captured graph owns different

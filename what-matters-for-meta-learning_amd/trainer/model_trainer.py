@@ -205,6 +205,9 @@ class ModelTrainer(BaseTrainer):
             self._prefetch = (it < self.iterations and it % self.config.val_freq != 0
                               and not ((it + 1) % self.config.bg_gen_freq == 0 and self.config.gen_bg))
             self._train_iter(it)
+            if getattr(self, "_loss_pending", None) is not None and (it % self.config.val_freq == 0 or it == self.iterations):
+                pending, self._loss_pending = self._loss_pending, None
+                self._flush_loss(pending)                               # lagged log: nothing stays behind a validation round or the end
             if it % self.config.val_freq == 0:
                 self._validate_iter(it, source="validation")
                 if self.config.task != "pascal_1d":
@@ -389,16 +392,12 @@ class ModelTrainer(BaseTrainer):
         if self._graph_default:
             loss = self._graph_train_iter(it)
             every = max(1, int(getattr(self.config, "log_every", 1)))
+            if getattr(self.config, "lagged_loss_log", False) and every == 1:
+                return self._lagged_log(it, loss)
             if it % every and it != self.iterations:
                 return None                                          # no host sync on this iteration
             value = loss.item()
-            if self.writer is not None and self.rank0:
-                self.writer.add_scalar("Loss/train", value, it)
-            self._log(f"Train Iteration {it} loss: {value:.4f}\n")
-            if not math.isfinite(value):
-                self._log(f"Loss is {value}, stopping training")
-                sys.exit(1)
-            return value
+            return self._report(it, value)
         self.model.train()
         self.optimizer.zero_grad()
         ctx_x, qry_x, ctx_y, qry_y = self._batch("train")
@@ -416,6 +415,9 @@ class ModelTrainer(BaseTrainer):
         self._sync_and_step()
         self._stage_next()
         value = losses.item()                                     # the iteration's only host sync
+        return self._report(it, value)
+
+    def _report(self, it, value):
         if self.writer is not None and self.rank0:
             self.writer.add_scalar("Loss/train", value, it)
         self._log(f"Train Iteration {it} loss: {value:.4f}\n")
@@ -423,6 +425,32 @@ class ModelTrainer(BaseTrainer):
             self._log(f"Loss is {value}, stopping training")
             sys.exit(1)
         return value
+
+    def _lagged_log(self, it, loss):
+        """`config.lagged_loss_log` (opt-in): every iteration's loss is still fetched, logged and checked - one iteration LATE.  The
+        reference reads `losses.item()` right behind the step (model_trainer.py:87-91); behind a replayed step that read is a host
+        sync, so iteration k + 1 cannot be launched before k has finished and the GPU idles through the host's turn-around (~0.2 ms of
+        a 0.8 ms iteration at c3's shape: scripts/dev/trainer_iter_probe.py).  Here iteration k's loss leaves the device by an
+        asynchronous copy into pinned memory queued behind its graph; it is read, logged and checked when iteration k + 1 has been
+        launched (a non-finite loss stops training one optimizer step later than the reference would), the last one when train()
+        ends.  Returns the PREVIOUS iteration's loss (None for the first)."""
+        dev = torch.device(self.config.device)
+        ring = getattr(self, "_loss_ring", None)
+        if ring is None:
+            ring = self._loss_ring = [(torch.zeros((), dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            self._loss_pending = None
+        buf, ev = ring[it & 1]
+        buf.copy_(loss, non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        prev, self._loss_pending = self._loss_pending, (it, buf, ev)
+        if prev is None:
+            return None
+        return self._flush_loss(prev)
+
+    def _flush_loss(self, pending):
+        it, buf, ev = pending
+        ev.synchronize()
+        return self._report(it, float(buf))
 
     def _validate_iter(self, it, source):
         self.model.eval()
