@@ -295,26 +295,8 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
   RW_TS(0);
   RW_TSALL(0); RW_TSALL(1);
   const float bn = jb.b ? jb.b[co] : 0.f;            // in front of the weight image: vmcnt retires in order, and a use of the bias must not wait for 144 younger loads
-  float wr[NKS];
-  {
-    const __amdgpu_buffer_rsrc_t rs = wimg_rsrc(jb.wimg + (size_t)nt * NKS * 64, NKS * 64 * 4);
-    if (jb.flip) {
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) wr[ks] = wimg_load(rs, 4 * lane, (8 - ks / 16) * 16 + ks % 16);
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) wr[ks] = wimg_load(rs, 4 * lane, ks);
-    }
-  }
-  float w1[SKIP1 ? 16 : 1];
-  float bn1 = 0.f;
   const bool has1 = SKIP1 && jb.w1img != nullptr;      // per job: a launch may mix blocks with and without the fused 1x1 skip
-  if (has1) {
-    const __amdgpu_buffer_rsrc_t rs1 = wimg_rsrc(jb.w1img + (size_t)nt * 16 * 64, 16 * 64 * 4);
-#pragma unroll
-    for (int cg = 0; cg < 16; ++cg) w1[cg] = wimg_load(rs1, 4 * lane, cg);
-    bn1 = jb.b1 ? jb.b1[co] : 0.f;
-  }
+  const float bn1 = (has1 && jb.b1) ? jb.b1[co] : 0.f;
 
   static_assert(G::PATCH % 4 == 0, "patch zeroing");
   for (int i = tid; i < G::PATCH / 4; i += 256) reinterpret_cast<float4*>(patch)[i] = make_float4(0.f, 0.f, 0.f, 0.f);      // halo columns (and pad words) stay zero for good
@@ -351,6 +333,29 @@ __device__ __forceinline__ void conv3x3_body(const FwdJob& jb, float* patch, int
   if (band0 < nbands) stage(band0);
   RW_TS(3);
   RW_TSALL(3);
+  // The weight image is asked for BEHIND the first patch: vmcnt retires in order, so the patch (39 MB over the chip, the burst every
+  // workgroup of the launch makes in the same microsecond) is waited for alone, and the 144 weight loads (L2-resident after the first
+  // workgroups) then stream in under the first band's MFMAs - k-step ks needs wr[ks] only, hipcc counts the waits down
+  // (`s_waitcnt vmcnt(143 - ks ...)`).  Asked for first, the whole image stood between every workgroup and its first MFMA: 8.5 us
+  // from kernel entry in block 1's conv1 (scripts/dev/trunk_cu_timeline.py).  One load sequence for both tap orders: the transposed
+  // convolution's 8 - tap is nine scalar selects on the descriptor offset, not a second copy of the loads behind a branch (two
+  // definitions of every weight register would be 144 phis).
+  float wr[NKS];
+  {
+    const __amdgpu_buffer_rsrc_t rs = wimg_rsrc(jb.wimg + (size_t)nt * NKS * 64, NKS * 64 * 4);
+    int goff[9];
+#pragma unroll
+    for (int g = 0; g < 9; ++g) goff[g] = (jb.flip ? 8 - g : g) * 4096;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+      wr[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * lane + (ks % 16) * 256, goff[ks / 16], 0));
+  }
+  float w1[SKIP1 ? 16 : 1];
+  if (has1) {
+    const __amdgpu_buffer_rsrc_t rs1 = wimg_rsrc(jb.w1img + (size_t)nt * 16 * 64, 16 * 64 * 4);
+#pragma unroll
+    for (int cg = 0; cg < 16; ++cg) w1[cg] = wimg_load(rs1, 4 * lane, cg);
+  }
 #pragma unroll 1
   for (int band = band0; band < nbands; band += band_step) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
@@ -595,19 +600,7 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
   static_assert(XK == 4 || XK == 8, "mask staging items per thread");
   float* xl = patch_all + (DUAL ? 2 * G::PATCH + 4 * 16 * G::NACC * 64 : G::PATCH * (SKIP1 ? 2 : 1));
 
-  float wr[NKS];
-  {
-    const __amdgpu_buffer_rsrc_t rs = wimg_rsrc(((DUAL && half) ? jb.w1img : jb.wimg) + (size_t)nt * NKS * 64, NKS * 64 * 4);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) wr[ks] = wimg_load(rs, 4 * lane, ks);
-  }
-  float w1[SKIP1 ? 16 : 1];
   const bool has1 = SKIP1 && jb.w1img != nullptr;      // per job
-  if (has1) {
-    const __amdgpu_buffer_rsrc_t rs1 = wimg_rsrc(jb.w1img + (size_t)nt * 16 * 64, 16 * 64 * 4);
-#pragma unroll
-    for (int cg = 0; cg < 16; ++cg) w1[cg] = wimg_load(rs1, 4 * lane, cg);
-  }
   for (int i = tid; i < G::PATCH * (SKIP1 ? 2 : 1); i += 256) patch[i] = 0.f;      // halo column / pad words stay zero
 
   int aoff[NT];
@@ -620,11 +613,12 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
   }
   const int nbands_all = G::MULTI ? (jb.n_img + G::NI - 1) / G::NI : jb.n_img * G::BANDS_PER_IMG;
   const int nbands = band_end < nbands_all ? band_end : nbands_all;
-#pragma unroll 1
-  for (int band = band0; band < nbands; band += band_step) {
+  const bool xl_on = XL && jb.xact != nullptr;                  // job-uniform
+  // one band's staging: the mask rows' requests, the dy patch(es), the mask rows' LDS stores.  As in conv3x3_body (round 6) the FIRST
+  // band is staged in front of the loop and in front of the weight image, every later band at the end of its predecessor's iteration.
+  auto stage_all = [&](int band) __attribute__((always_inline)) {
     const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
     const int a0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
-    const bool xl_on = XL && jb.xact != nullptr;                  // job-uniform
     // eight NAMED float4s (an array indexed in an unrolled loop stays in scratch memory: hipcc decides before it unrolls - 144 bytes
     // per lane in the first version of this)
     float4 xr0, xr1, xr2, xr3, xr4, xr5, xr6, xr7;
@@ -646,6 +640,24 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
 #undef DG_XE
 #undef DG_XLOAD
 #undef DG_XSTORE
+  };
+  if (band0 < nbands) stage_all(band0);
+  float wr[NKS];
+  {
+    const __amdgpu_buffer_rsrc_t rs = wimg_rsrc(((DUAL && half) ? jb.w1img : jb.wimg) + (size_t)nt * NKS * 64, NKS * 64 * 4);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) wr[ks] = wimg_load(rs, 4 * lane, ks);
+  }
+  float w1[SKIP1 ? 16 : 1];
+  if (has1) {
+    const __amdgpu_buffer_rsrc_t rs1 = wimg_rsrc(jb.w1img + (size_t)nt * 16 * 64, 16 * 64 * 4);
+#pragma unroll
+    for (int cg = 0; cg < 16; ++cg) w1[cg] = wimg_load(rs1, 4 * lane, cg);
+  }
+#pragma unroll 1
+  for (int band = band0; band < nbands; band += band_step) {
+    const int img0 = G::MULTI ? band * G::NI : band / G::BANDS_PER_IMG;
+    const int a0 = G::MULTI ? 0 : (band % G::BANDS_PER_IMG) * G::RB;
 
     f32x4_t acc[4][NT];
 #pragma unroll
@@ -754,6 +766,7 @@ __device__ __forceinline__ void dgrad2_body(const DgJob& jb, float* patch_all, i
         }
       }
     }
+    if (band + band_step < nbands) stage_all(band + band_step);
   }
 }
 
