@@ -36,6 +36,9 @@ constexpr int NT = 768;
 #ifndef C12_M1_LANE0
 #define C12_M1_LANE0 0
 #endif
+#ifndef C12_EARLY_PIXELS
+#define C12_EARLY_PIXELS 0
+#endif
 // conv1-output patch of one band: [ci 32][row 9][col 65]; col c <-> ix = c - 1 (col 0 = zero pad),
 // row r <-> iy = 8*band - 1 + r.
 constexpr int RS = 65, ROWS = 9, PS = ROWS * RS;          // 585
@@ -498,8 +501,17 @@ __global__ __launch_bounds__(NT) void conv12_fwd_pool_kernel(const ImgSrc x, con
       const int j = ks / 22, s = ks - 22 * j;          // j = 3 for ks >= 66: no slot
       if (j < 3) {
         const int tt = wave + 12 * j;
+#if C12_EARLY_PIXELS
+        // vmcnt retires in order: asked for at k-steps 22 j .. 22 j + 2, a tile's pixels queue BEHIND the previous tile's four sign-bit
+        // record stores (k-steps 22 (j - 1) + 15 .. + 18), and the blend's wait for them is a wait for those stores' acknowledgements.
+        // Tiles 1 and 2 therefore ask at 22 (j - 1) + 12 .. + 14 - in front of the stores, into operand registers the previous tile's
+        // MFMAs have just released (a[0] after k-step 9, a[1] after 11, a[2] after 13) - and are 15 instead of 5 k-steps in flight.
+        if (j == 0 && s < 3) ct.a[s] = conv1a_pixel_load(cl, x, next, 0, s);
+        else if (j < 2 && s >= 12 && s < 15) ct.a[s - 12] = conv1a_pixel_load(cl, x, next, j + 1, s - 12);
+#else
         if (s < 3) ct.a[s] = conv1a_pixel_load(cl, x, next, j, s);                           // raw pixel: in flight for 5 k-steps
-        else if (s >= 5 && s < 8) ct.a[s - 5] = conv1a_pixel_blend(ct.a[s - 5], cl, next, j, s - 5, wave >> 2);
+#endif
+        if (s >= 5 && s < 8) ct.a[s - 5] = conv1a_pixel_blend(ct.a[s - 5], cl, next, j, s - 5, wave >> 2);
         else if (s >= 8 && s < 14) c1t_mfma(ct, cw, s - 8);
 #ifdef C12_KNOCK_M1      // timing experiment only (results WRONG for the backward): no sign-bit record stores
         else if (s >= 15 && s < 19) c1t_post_cl<false>(ct, s - 15, c1t_dst_cl(nb, tt, lr, lq), nullptr);
