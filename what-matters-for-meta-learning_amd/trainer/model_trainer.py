@@ -178,6 +178,13 @@ class ModelTrainer(BaseTrainer):
         if getattr(self.config, "strict_sharded_parity", False):
             from mlhot import ops
             ops.set_stabiliser_exchange(None)
+        hp = self._host_prefetch
+        if hp is not None and hp._pool is not None and getattr(self.config, "close_after_train", True):
+            staged, self._staged = self._staged, None
+            if staged is not None and staged[0] == "later":
+                staged[1].result()                      # nothing left in flight when the worker goes
+            hp._pool.shutdown(wait=True)
+            hp._pool = None                             # a later stage() copies on the caller's thread
 
     def _hyper(self):
         g = self.optimizer.param_groups[0]
