@@ -179,7 +179,7 @@ class ModelTrainer(BaseTrainer):
             from mlhot import ops
             ops.set_stabiliser_exchange(None)
         hp = self._host_prefetch
-        if hp is not None and hp._pool is not None and getattr(self.config, "close_after_train", True):
+        if hp is not None and hp._pool is not None:
             staged, self._staged = self._staged, None
             if staged is not None and staged[0] == "later":
                 staged[1].result()                      # nothing left in flight when the worker goes
