@@ -876,38 +876,42 @@ struct T34Pass {
 struct T34Jobs { T34Pass p[MAX_JOBS]; int n; };
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-#ifndef T34_GI
-#define T34_GI 1
+#ifndef T34_GI_F
+#define T34_GI_F 2
 #endif
-constexpr int GI = T34_GI;        // images per workgroup: 1, 2 or 4.  The 2 x 2 maps of FOUR images fill an M-tile, so with fewer the block-4
-                                  // stages (and with one image block 3's stride-1 stages, two images per band) run their band with the other
-                                  // images masked out (img_lo / n_img of the job): wasted matrix rows, but a dependent chain of 1008 / 1296 MFMAs per
-                                  // wave instead of 2160 - these launches are latency-bound (measured, c5: forward 63 us with 4 images per workgroup)
-static_assert(GI == 1 || GI == 2 || GI == 4, "image group");
+#ifndef T34_GI_B
+#define T34_GI_B 1
+#endif
+// images per workgroup (1, 2 or 4), forward and backward kernel separately (round 6; one constant before).  The 2 x 2 maps of FOUR images
+// fill an M-tile, so with fewer the block-4 stages (and with one image block 3's stride-1 stages, two images per band) run their band
+// with the other images masked out (img_lo / n_img of the job): wasted matrix rows, but a shorter dependent chain per workgroup - these
+// launches are latency-bound.  Measured (c5, round 4): forward 64 / 49 / 53 us with 4 / 2 / 1 images per workgroup, backward 78 / 54 / 53.
+constexpr int GIF = T34_GI_F, GIB = T34_GI_B;
+static_assert((GIF == 1 || GIF == 2 || GIF == 4) && (GIB == 1 || GIB == 2 || GIB == 4), "image group");
 
 __global__ __launch_bounds__(256, 2) void tail34_fwd_kernel(const T34Jobs jobs) {
   __shared__ __attribute__((aligned(16))) float patch[cmax(cmax(G8s2::PATCH, G4s1::PATCH), cmax(G4s2::PATCH, G2s1::PATCH))];
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.p[ji + 1].wg0) ++ji;
   const T34Pass& P = jobs.p[ji];
-  const int g = (int)blockIdx.x - P.wg0, i0 = GI * g;       // image group: images i0 .. i0 + GI - 1
-  const int hi = i0 + GI < P.n_img ? i0 + GI : P.n_img;
+  const int g = (int)blockIdx.x - P.wg0, i0 = GIF * g;       // image group: images i0 .. i0 + GIF - 1
+  const int hi = i0 + GIF < P.n_img ? i0 + GIF : P.n_img;
   const bool s1 = P.skip1 != 0;
   // block 3, stage A: 8 x 8 -> 4 x 4, one image per band
   {
     const FwdJob a{P.x, P.wimg[0], P.b[0], P.mid3, nullptr, s1 ? P.wimg[2] : nullptr, s1 ? P.b[2] : nullptr, s1 ? P.idn3 : nullptr, hi, EPI_BIAS_RELU, 0, 0, 0, i0};
-    if (s1) conv3x3_body<G8s2, true>(a, patch, i0, i0 + GI, 1);
+    if (s1) conv3x3_body<G8s2, true>(a, patch, i0, i0 + GIF, 1);
     else {
-      conv3x3_body<G8s2, false>(a, patch, i0, i0 + GI, 1);
+      conv3x3_body<G8s2, false>(a, patch, i0, i0 + GIF, 1);
       __syncthreads();
       const FwdJob k{P.x, P.wimg[2], P.b[2], P.idn3, nullptr, nullptr, nullptr, nullptr, hi, EPI_BIAS, 0, 0, 0, i0};
-      conv3x3_body<G8s2, false>(k, patch, i0, i0 + GI, 1);
+      conv3x3_body<G8s2, false>(k, patch, i0, i0 + GIF, 1);
     }
   }
   __syncthreads();
   {   // block 3, stage B: 4 x 4 stride 1, two images per band
     const FwdJob c{P.mid3, P.wimg[1], P.b[1], P.y3, P.idn3, nullptr, nullptr, nullptr, hi, EPI_BIAS_RES_RELU, 0, 0, 0, i0};
-    conv3x3_body<G4s1, false>(c, patch, i0 / 2, (i0 + GI + 1) / 2, 1);
+    conv3x3_body<G4s1, false>(c, patch, i0 / 2, (i0 + GIF + 1) / 2, 1);
   }
   __syncthreads();
   {   // block 4, stage A: 4 x 4 -> 2 x 2, four images per band
@@ -932,8 +936,8 @@ __global__ __launch_bounds__(256, 2) void tail34_bwd_kernel(const T34Jobs jobs) 
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.p[ji + 1].wg0) ++ji;
   const T34Pass& P = jobs.p[ji];
-  const int g = (int)blockIdx.x - P.wg0, i0 = GI * g;
-  const int hi = i0 + GI < P.n_img ? i0 + GI : P.n_img;
+  const int g = (int)blockIdx.x - P.wg0, i0 = GIB * g;
+  const int hi = i0 + GIB < P.n_img ? i0 + GIB : P.n_img;
   const bool s1 = P.skip1 != 0;
   {   // block 4: d mid4 = conv2^T(g4) . (mid4 > 0)
     const FwdJob c{P.g4, P.wimg[4], nullptr, P.dm4, P.mid4, nullptr, nullptr, nullptr, hi, EPI_MASK, 1, 0, 0, i0};
@@ -954,25 +958,25 @@ __global__ __launch_bounds__(256, 2) void tail34_bwd_kernel(const T34Jobs jobs) 
   __syncthreads();
   {   // block 3: d mid3 = conv2^T(g3) . (mid3 > 0); 4 x 4 maps, two images per band
     const FwdJob c{P.g3, P.wimg[1], nullptr, P.dm3, P.mid3, nullptr, nullptr, nullptr, hi, EPI_MASK, 1, 0, 0, i0};
-    conv3x3_body<G4s1, false>(c, patch, i0 / 2, (i0 + GI + 1) / 2, 1);
+    conv3x3_body<G4s1, false>(c, patch, i0 / 2, (i0 + GIB + 1) / 2, 1);
   }
   __syncthreads();
   // block 3: gradient wrt y2; dy maps 4 x 4, one image per band
   if (s1) {
     const DgJob a{P.dm3, P.wimg[0], P.g2, P.x, P.g3, P.wimg[2], hi, 0, 0, 0, i0};
-    dgrad2_body<D4, true>(a, patch, i0, i0 + GI, 1);
+    dgrad2_body<D4, true>(a, patch, i0, i0 + GIB, 1);
   } else {
     const DgJob a{P.g3, P.wimg[2], P.g2, nullptr, nullptr, nullptr, hi, 0, 0, 0, i0};
-    dgrad2_body<D4, false>(a, patch, i0, i0 + GI, 1);
+    dgrad2_body<D4, false>(a, patch, i0, i0 + GIB, 1);
     __syncthreads();
     const DgJob b2{P.dm3, P.wimg[0], P.g2, P.x, nullptr, nullptr, hi, 1, 0, 0, i0};
-    dgrad2_body<D4, false>(b2, patch, i0, i0 + GI, 1);
+    dgrad2_body<D4, false>(b2, patch, i0, i0 + GIB, 1);
   }
 }
 
 inline int tail34_launch(T34Jobs& jobs, bool backward, hipStream_t s, const char* what) {
   int wg = 0;
-  for (int i = 0; i < jobs.n; ++i) { jobs.p[i].wg0 = wg; jobs.p[i].nwg = (jobs.p[i].n_img + GI - 1) / GI; wg += jobs.p[i].nwg; }
+  for (int i = 0; i < jobs.n; ++i) { jobs.p[i].wg0 = wg; { const int gi = backward ? GIB : GIF; jobs.p[i].nwg = (jobs.p[i].n_img + gi - 1) / gi; } wg += jobs.p[i].nwg; }
   if (wg == 0) return MLHOT_OK;
   {
     ProfScope ps(what, s);
