@@ -58,8 +58,15 @@ METRIC = {   # BASELINE.json's headline metric string is c3's; every other workl
 # hipGraph capture mode: "global" (torch's default) makes ANY thread's event query / allocation during a capture an error - and
 # with a process group alive ProcessGroupNCCL's watchdog thread polls its work events all the time (seen on the GPU box: the
 # bench aborting inside the capture, rc -6, once in two runs at a forced world of one).  "thread_local" confines the check to the
-# capturing thread, which is the one that matters here.
+# capturing thread, which is the one that matters here.  mlhot.graphs.capture also pauses Python's cyclic collector for the capture.
 CAPTURE_MODE = "thread_local"
+
+
+def capture_graph(graph, stream, pool=None):
+    from mlhot.graphs import capture
+    return capture(graph, stream, pool=pool)
+
+
 NC, NQ = 15, 15
 T_LOCAL = 16                    # vanilla workloads; WORKLOADS[...]["T"] is authoritative
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = fp32 vector rate
@@ -238,7 +245,7 @@ def _time_graph(fn, iters):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side, capture_error_mode=CAPTURE_MODE):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
+    with capture_graph(graph, side):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
         fn()
     for _ in range(5):
         graph.replay()
@@ -259,7 +266,7 @@ def _capture(fn):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side, capture_error_mode=CAPTURE_MODE):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
+    with capture_graph(graph, side):      # the warm-up's stream: the parameters' grad-accumulation nodes live there
         fn()
     return graph
 
@@ -447,14 +454,15 @@ def measure_train_loop(w, device, loss_fn, iters):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for it in range(5, 5 + n_ref):
-                tr._prefetch = True
+                tr._prefetch = 2      # what train() sets far from a validation round: two batches may be drawn ahead
                 tr._train_iter(it)
             torch.cuda.synchronize()
             if timed:
                 out["reference_style_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_ref
         feed = tr._host_prefetch.u8 if tr._host_prefetch is not None else None
         out["reference_style_promoted"] = {"optimizer": type(tr.optimizer).__name__, "graph_replay": bool(tr._graph_default),
-                                           "host_batch_prefetch": tr._host_prefetch is not None,
+                                           "host_batch_prefetch": tr._host_prefetch is not None, "batches_drawn_ahead": 2,
+                                           "loss_logged_one_iteration_late": bool(tr._lagged()),
                                            "host_batches_as_bytes": ({"shipped": feed.shipped, "refused": feed.refused, "host_threads": feed.threads,
                                                                       "bytes_per_batch": int(host[0].numel() + host[1].numel() + 4 * (host[2].numel() + host[3].numel()))}
                                                                      if feed is not None else None)}
@@ -471,17 +479,18 @@ def measure_train_loop(w, device, loss_fn, iters):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for it in range(5, 5 + n_ref):
-                tr2._prefetch = True
+                tr2._prefetch = 2      # what train() sets far from a validation round: two batches may be drawn ahead
                 tr2._train_iter(it)
             torch.cuda.synchronize()
             if timed:
                 out["reference_style_fp32_over_pcie_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_ref
-        # the promoted loop with every iteration's loss logged and checked ONE ITERATION LATE (config.lagged_loss_log, opt-in): the
-        # reference's `losses.item()` behind every step is a host sync that keeps iteration k + 1 from being launched before k is done
+        # the promoted loop with `losses.item()` read right BEHIND every step, as the reference does (config.lagged_loss_log = False): a
+        # host sync that keeps iteration k + 1 from being launched before k is done.  The trainer's default reads, logs and checks every
+        # iteration's loss one iteration late instead (same log, same exit on a non-finite loss, same files: model_trainer._lagged_log).
         cfg3 = make_cfg(w, device)
         cfg3.iterations, cfg3.val_freq, cfg3.val_iters, cfg3.bg_gen_freq, cfg3.gen_bg = 4, 10 ** 9, 1, 10 ** 9, False
         cfg3.save_path, cfg3.logger, cfg3.contrastive, cfg3.max_ctx_num, cfg3.beta = tmp, None, False, NC, 0
-        cfg3.close_after_train, cfg3.lagged_loss_log = False, True
+        cfg3.close_after_train, cfg3.lagged_loss_log = False, False
         model3 = cls(cfg3).to(device)
         tr3 = ModelTrainer(model=model3, loss=loss_fn, optimizer=torch.optim.Adam(model3.parameters(), lr=1e-4), config=cfg3, data=HostLoader())
         tr3.train()
@@ -490,11 +499,11 @@ def measure_train_loop(w, device, loss_fn, iters):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for it in range(5, 5 + n_ref):
-                tr3._prefetch = True
+                tr3._prefetch = 2      # what train() sets far from a validation round: two batches may be drawn ahead
                 tr3._train_iter(it)
             torch.cuda.synchronize()
             if timed:
-                out["reference_style_lagged_log_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_ref
+                out["reference_style_sync_every_iter_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_ref
     # the same sequence with nothing promoted: eager autograd, torch.optim.Adam over ~70 tensors, the copy in front of the step
     model = cls(make_cfg(w, device)).to(device)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
@@ -535,7 +544,7 @@ def measure_train_loop(w, device, loss_fn, iters):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side, capture_error_mode=CAPTURE_MODE):
+    with capture_graph(graph, side):
         static_loss = it()
     ing.stage(*hb)
     n_rep = 4 * iters
@@ -553,7 +562,7 @@ def measure_train_loop(w, device, loss_fn, iters):
             out["replayed_ms_per_iter"] = 1e3 * (time.perf_counter() - t0) / n_rep
     ing.take()
     out["tasks_per_s"] = {"reference_style": 1e3 * T_LOCAL / out["reference_style_ms_per_iter"],
-                          "reference_style_lagged_log": 1e3 * T_LOCAL / out["reference_style_lagged_log_ms_per_iter"],
+                          "reference_style_sync_every_iter": 1e3 * T_LOCAL / out["reference_style_sync_every_iter_ms_per_iter"],
                           "reference_style_unpromoted": 1e3 * T_LOCAL / out["reference_style_unpromoted_ms_per_iter"],
                           "replayed": 1e3 * T_LOCAL / out["replayed_ms_per_iter"]}
     out["adam_steps_taken"] = int(opt.step_dev.item())
@@ -599,7 +608,7 @@ def measure_train_loop_3d(w, device, loss_fn, iters):
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     for it in range(5, 5 + n):
-                        tr._prefetch = True
+                        tr._prefetch = 2      # what train() sets far from a validation round: two batches may be drawn ahead
                         tr._train_iter(it)
                     torch.cuda.synchronize()
                     if timed:
@@ -687,7 +696,7 @@ def measure_shipped_cfg(w, device, loss_fn, iters):
                 d0 = len(data.drawn)
                 t0 = time.perf_counter()
                 for it in range(1000, 1000 + n):
-                    tr._prefetch = True
+                    tr._prefetch = 2      # what train() sets far from a validation round: two batches may be drawn ahead
                     tr._train_iter(it)
                 torch.cuda.synchronize()
                 if timed:
@@ -1116,11 +1125,11 @@ def main():
             graph = torch.cuda.CUDAGraph()
             model.zero_grad(set_to_none=True)
             graph2 = None
-            with (eps.active() if eps is not None else contextlib_null()), torch.cuda.graph(graph, stream=side, capture_error_mode=CAPTURE_MODE):   # the warm-up's stream: the parameters' grad-accumulation nodes live there
+            with (eps.active() if eps is not None else contextlib_null()), capture_graph(graph, side):   # the warm-up's stream: the parameters' grad-accumulation nodes live there
                 static_loss = body(part=1 if split else None)
             if split:                        # the trunks' backward: a second graph in the first one's memory pool (always replayed in this order)
                 graph2 = torch.cuda.CUDAGraph()
-                with (eps.active() if eps is not None else contextlib_null()), torch.cuda.graph(graph2, stream=side, pool=graph.pool(), capture_error_mode=CAPTURE_MODE):
+                with (eps.active() if eps is not None else contextlib_null()), capture_graph(graph2, side, pool=graph.pool()):
                     body(part=2)
 
             def run():

@@ -15,6 +15,7 @@ DEV = torch.device("cuda:0")
 fixed = "fixed" in sys.argv[1:]
 
 
+lagged = "lagged" in sys.argv[1:]            # config.lagged_loss_log: the loss of iteration k is read behind the launch of k + 1
 bytes_mode = "bytes" in sys.argv[1:]          # images that ARE bytes / 255 (what the reference's loaders hand out): the ExactU8Feed route
 
 
@@ -41,7 +42,8 @@ with tempfile.TemporaryDirectory() as tmp:
     os.chdir(tmp)
     cfg = types.SimpleNamespace(device=DEV, seed=2578, img_size=[128, 128, 1], tasks_per_batch=16, input_dim=3, output_dim=2, agg_mode="attention",
                                 img_agg="", dim_w=64, n_hidden_units_r=[100, 100], dim_r=64, dim_z=64, task="shapenet_1d", iterations=400, val_freq=10 ** 9,
-                                val_iters=1, bg_gen_freq=10 ** 9, gen_bg=False, max_ctx_num=15, beta=0, contrastive=False, log_every=1, save_path=tmp, logger=None)
+                                val_iters=1, bg_gen_freq=10 ** 9, gen_bg=False, max_ctx_num=15, beta=0, contrastive=False, log_every=1, save_path=tmp, logger=None,
+                                lagged_loss_log=lagged, close_after_train=False)
     model = ANPShapeNet1D(cfg).to(DEV)
     tr = ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=torch.optim.Adam(model.parameters(), lr=1e-3), config=cfg, data=Data())
     tr.train()                                   # captures
@@ -57,6 +59,9 @@ with tempfile.TemporaryDirectory() as tmp:
         return w
     tr._batch = timed("_batch", tr._batch)
     tr._stage_next = timed("_stage_next", tr._stage_next)
+    tr._flush_loss = timed("_flush_loss (event wait + log)", tr._flush_loss)
+    if tr._host_prefetch is not None:
+        tr._host_prefetch.take = timed("prefetch.take (worker's future + stream wait)", tr._host_prefetch.take)
     graphs = [v for v in tr._graphs.values() if isinstance(v, tuple)]
     for g in graphs:
         g[0].replay = timed("graph.replay", g[0].replay)
@@ -64,10 +69,33 @@ with tempfile.TemporaryDirectory() as tmp:
     n = 1000
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    evs = []
+    inner = tr._graph_train_iter
+
+    def stamped(it):                              # device time of one iteration's own work: an event in front of its first launch, one behind its last
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = inner(it)
+        b.record()
+        evs.append((a, b))
+        return r
+    if "stamps" in sys.argv[1:]:
+        tr._graph_train_iter = stamped
+    marks = [time.perf_counter()]
     for it in range(401, 401 + n):
-        tr._prefetch = True
+        tr._prefetch = 2      # what train() sets far from a validation round: two batches may be drawn ahead
         tr._train_iter(it)
+        marks.append(time.perf_counter())
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    print(f"{'fixed 15+15' if fixed else 'context sizes 3..15'}: {len(graphs)} graphs, {1e3 * wall / n:.3f} ms per iteration; host time inside: "
+    per = 1e3 * np.diff(np.array(marks))
+    print(f"host: per iteration median {np.median(per):.3f} ms, mean {per.mean():.3f}, p90 {np.percentile(per, 90):.3f}, p99 {np.percentile(per, 99):.3f}, "
+          f"max {per.max():.3f} (at iteration {int(per.argmax())} of {n}); the {int((per > 3 * np.median(per)).sum())} iterations above 3 x median hold {per[per > 3 * np.median(per)].sum():.1f} ms")
+    if evs:
+        busy = np.array([a.elapsed_time(b) for a, b in evs[50:]])
+        gap = np.array([evs[i][1].elapsed_time(evs[i + 1][0]) for i in range(50, len(evs) - 1)])
+        print(f"device: an iteration's own work (first launch -> last) median {np.median(busy):.3f} ms (mean {busy.mean():.3f}, p10 {np.percentile(busy, 10):.3f}, p90 {np.percentile(busy, 90):.3f}, "
+              f"p99 {np.percentile(busy, 99):.3f}, max {busy.max():.3f}); between iterations median {np.median(gap):.3f} ms (mean {gap.mean():.3f}, p90 {np.percentile(gap, 90):.3f}, p99 {np.percentile(gap, 99):.3f}, max {gap.max():.3f})")
+    tr.close()
+    print(f"{'fixed 15+15' if fixed else 'context sizes 3..15'}{', bytes' if bytes_mode else ''}{', lagged log' if lagged else ''}: {len(graphs)} graphs, {1e3 * wall / n:.3f} ms per iteration; host time inside: "
           + ", ".join(f"{k} {1e3 * v / n:.3f} ms" for k, v in acc.items()))

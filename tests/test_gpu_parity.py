@@ -1048,7 +1048,8 @@ def test_staged_eps_step_equals_lazy_step_and_captures(gpulib):
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     st.stage()
-    with st.active(), torch.cuda.graph(graph):
+    from mlhot.graphs import capture
+    with st.active(), capture(graph, None):
         mu2, kl2 = step()
     torch.manual_seed(99)
     st.stage()
@@ -1592,8 +1593,10 @@ def _trajectory_check(model, p0, oracle_step, batches, make_opt, cfg, tmp_path, 
     def one_iteration(it):
         entering.append({n: prm.detach().cpu().clone() for n, prm in model.named_parameters()})
         with grab_routes(routes):
-            losses.append(orig(it))
+            orig(it)
     tr._train_iter = one_iteration
+    orig_report = tr._report
+    tr._report = lambda it, v: (losses.append(v), orig_report(it, v))[1]      # every iteration's loss, whichever call hands it out (the lagged log: one late)
     if seed_eps is not None:
         torch.manual_seed(seed_eps)
     tr.train()
@@ -2035,8 +2038,8 @@ def test_graph_replayed_training_equals_eager_training(gpulib, tmp_path, monkeyp
         opt = FlatAdam(model, lr=1e-3, ctx_num=5, test_num=5, capturable=True)
         tr = ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=opt, config=cfg, data=SyntheticData())
         seen = []
-        orig = tr._train_iter
-        tr._train_iter = lambda it, _o=orig, _s=seen: _s.append(_o(it))
+        orig = tr._report
+        tr._report = lambda it, v, _o=orig, _s=seen: (_s.append(v), _o(it, v))[1]      # every iteration's loss in iteration order (lagged log: handed out one call late)
         tr.train()
         losses.append(seen)
         finals.append({k: v.clone() for k, v in model.state_dict().items()})
@@ -2051,7 +2054,8 @@ def test_graph_replayed_training_equals_eager_training(gpulib, tmp_path, monkeyp
 
 
 def test_lagged_loss_log_reports_every_iteration_one_late(gpulib, tmp_path, monkeypatch):
-    """config.lagged_loss_log (opt-in): the replayed loop logs and checks EVERY iteration's loss, one iteration late - the same
+    """config.lagged_loss_log (the default of replayed iterations; False = read behind every step): the replayed loop logs and checks
+    EVERY iteration's loss, one iteration late - the same
     (iteration, value) pairs in the same order as the loop that reads `losses.item()` behind every step (model_trainer.py:87-91),
     nothing left behind a validation round or the end of train(), identical final weights."""
     import types
@@ -2083,6 +2087,7 @@ def test_lagged_loss_log_reports_every_iteration_one_late(gpulib, tmp_path, monk
     assert returned[0] == [v for _, v in reports[0]]
     want = [None if it in (1, 6, 11) else reports[0][it - 2][1] for it in range(1, 14)]
     assert returned[1] == want
+    assert ModelTrainer._lagged(types.SimpleNamespace(config=types.SimpleNamespace())) is True       # a config that does not say: late
     for k in finals[0]:
         assert torch.equal(finals[0][k], finals[1][k]), k
 
@@ -2187,8 +2192,8 @@ def test_promoted_bbb_trainer_keeps_the_generator_order(gpulib, tmp_path, monkey
             if two:
                 tr.bucket = TwoRanks(model.parameters(), early=model.early_grad_parameters())
             seen = []
-            orig = tr._train_iter
-            tr._train_iter = lambda it, _o=orig, _s=seen: _s.append(_o(it))
+            orig = tr._report
+            tr._report = lambda it, v, _o=orig, _s=seen: (_s.append(v), _o(it, v))[1]
             torch.manual_seed(31)
             tr.train()
             if graph is None:

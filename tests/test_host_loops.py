@@ -272,3 +272,26 @@ def test_resnet_family_flat_layout_keeps_buckets_and_head_stacks_contiguous(meth
     for n, p in named.items():
         g = arena.slot(p)
         assert g is not None and g.shape == p.shape and g.storage_offset() == offs[n]
+
+
+def test_batches_drawn_ahead_never_cross_a_validation_round_or_a_background_regeneration():
+    """trainer.ModelTrainer._clear_ahead: how many training batches may be drawn under step `it` (host_prefetch_depth, default 2).
+    The reference draws train_k, [validation / test of k], [gen_bg(k + 1)], train_k+1 (model_trainer.py:59-70, train loop): batch
+    it + j may be drawn early only if no iteration it .. it + j - 1 ends in a validation round, is the last one, or is followed by a
+    background regeneration.  Replayed here against a literal walk of the reference's order of events."""
+    from trainer.model_trainer import ModelTrainer
+    for depth, val_freq, bg, gen_bg, iters in ((2, 3, 1000, False, 10), (2, 4, 5, True, 23), (1, 2, 3, True, 9), (3, 5, 7, True, 40), (2, 1, 1, True, 6)):
+        stub = types.SimpleNamespace(config=types.SimpleNamespace(host_prefetch_depth=depth, val_freq=val_freq, bg_gen_freq=bg, gen_bg=gen_bg),
+                                     iterations=iters)
+        for it in range(1, iters + 1):
+            n = ModelTrainer._clear_ahead(stub, it)
+            assert 0 <= n <= depth
+            # literal walk: the events between "train_it has been drawn" and "train_it+j is drawn"
+            ok = 0
+            for j in range(1, depth + 1):
+                last = it + j - 1                               # the iteration whose tail lies in front of draw it + j
+                blocked = last >= iters or last % val_freq == 0 or (gen_bg and (last + 1) % bg == 0)
+                if blocked:
+                    break
+                ok = j
+            assert n == ok, (depth, val_freq, bg, gen_bg, it, n, ok)

@@ -180,8 +180,8 @@ class ExactU8Feed:
         ctx_x, qry_x, ctx_y, qry_y = feed.take(ticket)        # fp32 device tensors (fixed addresses per batch shape)
     """
 
-    def __init__(self, device, threads=None, div=255.0, give_up=3):
-        self.ing = BatchIngest(device, div=div)
+    def __init__(self, device, threads=None, div=255.0, give_up=3, slots=3):
+        self.ing = BatchIngest(device, slots=slots, div=div)      # three: two batches drawn ahead (trainer, host_prefetch_depth 2) + one on the spot
         self.div, self.give_up = float(div), int(give_up)
         self.threads = default_feed_threads() if threads is None else max(1, min(64, int(threads)))
         self.ok, self.refused_in_a_row = True, 0

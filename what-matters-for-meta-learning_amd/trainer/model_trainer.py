@@ -30,6 +30,7 @@ rank's shard - one scalar all-gather in the forward and one scalar all-reduce in
 (mlhot.dist.StabiliserExchange, include/mlhot.h "strict sharded parity").  Eager iterations only: the exchange runs between
 two C calls, so it cannot sit inside a replayed hipGraph.
 """
+import collections
 import contextlib
 import math
 import os
@@ -42,9 +43,7 @@ from mlhot.ops import add_scaled, loss_value_aside
 from trainer.base_trainer import BaseTrainer
 
 
-# torch's default capture mode ("global") turns any OTHER thread's event query into a capture error; ProcessGroupNCCL's watchdog
-# thread polls its work events continuously, so with a process group alive a capture would abort at random (seen with bench.py).
-CAPTURE_MODE = "thread_local"
+from mlhot.graphs import CAPTURE_MODE, capture as capture_graph      # thread_local error mode, collector paused: see mlhot/graphs.py
 
 class _HostPrefetch:
     """fp32 host batches (the reference's loaders: dataset/shapenet_1d.py:189-196 -> utils/utils.py:26-30) to the device on a copy
@@ -142,8 +141,9 @@ class ModelTrainer(BaseTrainer):
         else:
             self._graph_default = bool(config.graph_steps)
         self.ingest, self._staged = None, None
+        self._staged_q = collections.deque()      # host-batch route: tickets of the training batches drawn ahead, oldest first
         self._host_prefetch, self._fixed_batch = None, False
-        self._prefetch = False          # set per iteration by train(): may the NEXT training batch be drawn right away?
+        self._prefetch = False          # set per iteration by train(): may the NEXT training batch be drawn right away?  (an int: how many)
         self.rank0 = dist_rank() == 0   # files / logs / TensorBoard are rank 0's business (every rank holds the same weights)
         self._graphs, self._static_in, self._side = {}, {}, None       # graph_steps: per batch shape
         self._eps = None                # graph_steps of a Bayes-by-backprop model: its eps draws staged per step (networks/bbb/eps.py)
@@ -165,7 +165,11 @@ class ModelTrainer(BaseTrainer):
                       "(lr, betas, eps, weight_decay) is picked up by re-capturing.")
         if self._host_prefetch is not None:
             self._log("mlhot: host batches are copied on a copy stream behind the step" +
-                      (" - as bytes when every image element is exactly k / 255 (checked per batch), as fp32 otherwise" if self._host_prefetch.u8 is not None else ""))
+                      (" - as bytes when every image element is exactly k / 255 (checked per batch), as fp32 otherwise" if self._host_prefetch.u8 is not None else "")
+                      + f"; up to {max(1, int(getattr(self.config, 'host_prefetch_depth', 2)))} batches are drawn ahead where no validation round / background regeneration lies between")
+        if self._graph_default and self._lagged():
+            self._log("mlhot: every iteration's loss is logged and checked one iteration late (read behind the NEXT iteration's launch; flushed before "
+                      "validation rounds, checkpoints and the end of training).  config.lagged_loss_log = False reads it right behind the step.")
 
     def close(self):
         """Undo the process-wide installs of the constructor (the gradient arena in mlhot.binding, the stabiliser exchange in mlhot.ops);
@@ -180,9 +184,10 @@ class ModelTrainer(BaseTrainer):
             ops.set_stabiliser_exchange(None)
         hp = self._host_prefetch
         if hp is not None and hp._pool is not None:
-            staged, self._staged = self._staged, None
-            if staged is not None and staged[0] == "later":
-                staged[1].result()                      # nothing left in flight when the worker goes
+            while self._staged_q:
+                staged = self._staged_q.popleft()
+                if staged[0] == "later":
+                    staged[1].result()                  # nothing left in flight when the worker goes
             hp._pool.shutdown(wait=True)
             hp._pool = None                             # a later stage() copies on the caller's thread
 
@@ -209,12 +214,14 @@ class ModelTrainer(BaseTrainer):
             # The reference draws train_k, [validation / test batches of k], [gen_bg(k+1)], train_k+1 - and its loaders may share
             # one global generator.  Batch k+1 is therefore prefetched (drawn while step k computes) only when nothing else
             # draws or regenerates between the two; otherwise it is drawn at the top of iteration k+1, in the reference's place.
-            self._prefetch = (it < self.iterations and it % self.config.val_freq != 0
-                              and not ((it + 1) % self.config.bg_gen_freq == 0 and self.config.gen_bg))
+            # `config.host_prefetch_depth` (default 2, host-batch route): the conversion + copy of a batch takes about as long as a
+            # step, so drawn ONE ahead the iteration waited for the worker (scripts/dev/trainer_iter_probe.py lagged); the same rule,
+            # applied to every iteration in between, lets batch k+2 be drawn under step k.
+            self._prefetch = self._clear_ahead(it)
             self._train_iter(it)
-            if getattr(self, "_loss_pending", None) is not None and (it % self.config.val_freq == 0 or it == self.iterations):
+            if getattr(self, "_loss_pending", None) is not None and (it % self.config.val_freq == 0 or it == self.iterations or it % 1000 == 0):
                 pending, self._loss_pending = self._loss_pending, None
-                self._flush_loss(pending)                               # lagged log: nothing stays behind a validation round or the end
+                self._flush_loss(pending)                               # lagged log: nothing stays behind a validation round, a checkpoint or the end
             if it % self.config.val_freq == 0:
                 self._validate_iter(it, source="validation")
                 if self.config.task != "pascal_1d":
@@ -226,6 +233,19 @@ class ModelTrainer(BaseTrainer):
             self.close()
         self._log(f"models have been saved to {self.config.save_path}")
         self._log("================= Training finished =================\n")
+
+    def _clear_ahead(self, it):
+        """How many of the training batches behind iteration `it`'s may be drawn now: batch it+j only if no validation round, end of
+        training or background regeneration lies between iteration it and it+j (the reference's order of draws, train.py /
+        model_trainer.py:59-70)."""
+        depth = max(1, int(getattr(self.config, "host_prefetch_depth", 2)))
+        n = 0
+        for i in range(it, it + depth):
+            if i < self.iterations and i % self.config.val_freq != 0 and not ((i + 1) % self.config.bg_gen_freq == 0 and self.config.gen_bg):
+                n += 1
+            else:
+                break
+        return n
 
     def _batch(self, source):
         """One device batch of `source`.  With the ingest path the NEXT training batch starts its host -> device copy as
@@ -240,8 +260,8 @@ class ModelTrainer(BaseTrainer):
                 return tuple(t.to(dev) for t in draw(source))
             if source != "train":
                 return hp.take(hp.stage(draw(source)))
-            ticket, self._staged = (self._staged or hp.stage(draw("train"))), None
-            self._stage_later = self._prefetch          # the next batch's (host-blocking) copy goes out BEHIND this step's launch: _stage_next()
+            ticket = self._staged_q.popleft() if self._staged_q else hp.stage(draw("train"))
+            self._stage_later = int(self._prefetch)     # the next batches' (host-blocking) copies go out BEHIND this step's launch: _stage_next()
             batch = hp.take(ticket)
             self._fixed_batch = hp.last_fixed           # the byte route delivers every batch of a shape in the same device tensors
             return batch
@@ -260,10 +280,13 @@ class ModelTrainer(BaseTrainer):
     def _stage_next(self):
         """Host-batch route: draw the next training batch and start its copy to the device - called right after the current
         step has been enqueued, so the (pageable, host-blocking) copy runs beside the step instead of in front of it."""
-        if self._host_prefetch is not None and getattr(self, "_stage_later", False):
-            self._stage_later = False
-            self._staged = self._host_prefetch.stage(self.data.get_batch(source="train", tasks_per_batch=self.config.tasks_per_batch,
-                                                                         shot=self.config.max_ctx_num))
+        if self._host_prefetch is not None and getattr(self, "_stage_later", 0):
+            ahead, self._stage_later = self._stage_later, 0
+            if self._eps is not None and self._eps is not False:
+                ahead = 1       # Bayes-by-backprop models: batch k+2 would be drawn in front of step k+1's eps - one ahead keeps the reference's order on a shared generator
+            while len(self._staged_q) < ahead:
+                self._staged_q.append(self._host_prefetch.stage(self.data.get_batch(source="train", tasks_per_batch=self.config.tasks_per_batch,
+                                                                                    shot=self.config.max_ctx_num)))
 
     def _seed(self, loss):
         """d loss / d loss = 1, allocated once: autograd's implicit seed is a fill kernel per iteration."""
@@ -342,7 +365,7 @@ class ModelTrainer(BaseTrainer):
                 for m in loggers:
                     m.tap_log = []
                 try:
-                    with staged, torch.cuda.graph(graph, stream=self._side, capture_error_mode=CAPTURE_MODE):
+                    with staged, capture_graph(graph, self._side):
                         static_loss = self._step_body(*static, with_optimizer=single)
                 finally:
                     captured_taps, ops.saved_taps = ops.saved_taps, taps
@@ -399,7 +422,7 @@ class ModelTrainer(BaseTrainer):
         if self._graph_default:
             loss = self._graph_train_iter(it)
             every = max(1, int(getattr(self.config, "log_every", 1)))
-            if getattr(self.config, "lagged_loss_log", False) and every == 1:
+            if self._lagged() and every == 1:
                 return self._lagged_log(it, loss)
             if it % every and it != self.iterations:
                 return None                                          # no host sync on this iteration
@@ -433,8 +456,15 @@ class ModelTrainer(BaseTrainer):
             sys.exit(1)
         return value
 
+    def _lagged(self):
+        return bool(getattr(self.config, "lagged_loss_log", True))
+
     def _lagged_log(self, it, loss):
-        """`config.lagged_loss_log` (opt-in): every iteration's loss is still fetched, logged and checked - one iteration LATE.  The
+        """`config.lagged_loss_log` (default on for replayed iterations; False = the read right behind the step): every iteration's loss
+        is still fetched, logged and checked - one iteration LATE.  What an observer of the reference's loop sees is unchanged: the same
+        log lines and TensorBoard points in the same order, the same exit code on a non-finite loss with the same files on disk (the
+        pending loss is flushed before everything that writes - validation rounds, the it % 1000 checkpoints, the final save); only the
+        process's in-memory weights have taken one more step when it exits.  The
         reference reads `losses.item()` right behind the step (model_trainer.py:87-91); behind a replayed step that read is a host
         sync, so iteration k + 1 cannot be launched before k has finished and the GPU idles through the host's turn-around (~0.2 ms of
         a 0.8 ms iteration at c3's shape: scripts/dev/trainer_iter_probe.py).  Here iteration k's loss leaves the device by an
