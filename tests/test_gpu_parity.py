@@ -1853,6 +1853,48 @@ def test_batch_ingest_pipeline_matches_host_conversion(gpulib):
         BatchIngest("cpu")
 
 
+def test_host_batches_two_ahead_on_the_worker_thread_arrive_in_order_and_intact(gpulib):
+    """trainer._HostPrefetch as the trainer drives it since round 6: TWO batches staged ahead on the worker thread while the owner takes
+    the oldest (BatchIngest's slot choice and queue under a lock, three slots per shape).  300 batches of two alternating shapes, byte
+    images (the byte route) with every 7th batch off the byte grid (the fp32 route), each checked bit for bit against the host tensors
+    after the NEXT two have been put on their way."""
+    import collections
+    from mlhot import synth
+    from trainer.model_trainer import _HostPrefetch
+    rs = np.random.RandomState(5)
+
+    def host_batch(i):
+        nc = 3 + (i % 2)
+        xs = synth.host_convert(rs.randint(0, 256, size=(2, nc, 32, 32, 1)).astype(np.uint8))
+        xq = synth.host_convert(rs.randint(0, 256, size=(2, 5, 32, 32, 1)).astype(np.uint8))
+        if i % 7 == 3:
+            xs.view(-1)[i] = 0.5001
+        return xs, xq, torch.full((2, nc, 3), float(i)), torch.full((2, 5, 3), float(-i))
+
+    hp = _HostPrefetch(DEV)
+    try:
+        q = collections.deque()
+        n, routes = 300, collections.Counter()
+        for i in range(n + 2):
+            if i < n:
+                hb = host_batch(i)
+                q.append((hb, hp.stage(hb)))
+            if len(q) > 2 or i >= n:
+                if not q:
+                    break
+                hb, ticket = q.popleft()
+                got = hp.take(ticket)
+                routes["u8" if hp.last_fixed else "fp32"] += 1
+                got = [g.clone() for g in got]          # the byte route hands every batch of a shape out in the same device tensors
+                torch.cuda.synchronize()
+                for g, h in zip(got, hb):
+                    assert g.shape == h.shape and torch.equal(g.cpu(), h)
+        assert not q and routes["u8"] + routes["fp32"] == n and routes["fp32"] == len([i for i in range(n) if i % 7 == 3])
+        assert all(len(ring) <= 3 for ring in hp.u8.ing._slots.values())
+    finally:
+        hp._pool.shutdown(wait=True)
+
+
 @pytest.mark.parametrize("C,H,W", [(1, 128, 128), (3, 64, 64)])
 def test_exact_u8_feed_round_trip_is_bit_exact(gpulib, C, H, W):
     """mlhot.ingest.ExactU8Feed: a reference-style loader's fp32 channel-first host batch (dataset/shapenet_1d.py:

@@ -15,6 +15,7 @@ and `mlhot_ingest_u8_nhwc` does the divide + permute on the device (bit-identica
 reading valid addresses.  There is no CPU fallback: the device must be a ROCm GPU.
 """
 import collections
+import threading
 
 import numpy as np
 import torch
@@ -82,15 +83,20 @@ class BatchIngest:
         self._slots = {}                        # shapes -> [slot, ...]
         self._out = {}                          # shapes -> _Out (fixed fp32 outputs)
         self._queue = collections.deque()
+        # stage*() may run on a worker thread while the owner take()s an earlier batch (trainer._HostPrefetch, two batches drawn ahead):
+        # slot choice and the queue are guarded; the fill and the copy of a reserved slot are not (they touch only that slot).
+        self._lock = threading.Lock()
 
     def _free_slot(self, key):
-        ring = self._slots.setdefault(key, [])
-        slot = next((sl for sl in ring if not sl.busy), None)
-        if slot is None:
-            if len(ring) >= self.n_slots:
-                raise MlhotError("BatchIngest: more batches staged than slots; call take() first")
-            slot = _Slot(key, self.device)
-            ring.append(slot)
+        with self._lock:
+            ring = self._slots.setdefault(key, [])
+            slot = next((sl for sl in ring if not sl.busy), None)
+            if slot is None:
+                if len(ring) >= self.n_slots:
+                    raise MlhotError("BatchIngest: more batches staged than slots; call take() first")
+                slot = _Slot(key, self.device)
+                ring.append(slot)
+            slot.busy = True                    # reserved from here on (given back by take(), or by a fill that refuses the batch)
         slot.copied.synchronize()               # the previous H2D out of this pinned buffer is done (no-op when fresh)
         return slot
 
@@ -111,7 +117,13 @@ class BatchIngest:
         ([ctx images u8 | qry images u8 | ctx labels f32 | qry labels f32], shaped like `key`) and returns True to ship the batch or
         False to give the slot back (nothing is queued; returns None)."""
         slot = self._free_slot(key)
-        if not fill(slot.host_np):
+        try:
+            ok = fill(slot.host_np)
+        except BaseException:
+            slot.busy = False
+            raise
+        if not ok:
+            slot.busy = False
             return None
         return self._ship(key, slot)
 
@@ -120,8 +132,8 @@ class BatchIngest:
             self.copy_stream.wait_event(slot.consumed)      # do not overwrite bytes an ingest kernel still reads
             slot.dev.copy_(slot.host, non_blocking=True)
             slot.copied.record(self.copy_stream)
-        slot.busy = True
-        self._queue.append((key, slot))
+        with self._lock:
+            self._queue.append((key, slot))
         return slot
 
     def device_views(self, ticket=None):
@@ -137,16 +149,17 @@ class BatchIngest:
     def take(self, ticket=None):
         """A staged batch (the oldest, or the one `ticket` names) as (ctx_x, qry_x, ctx_y, qry_y): fp32, channel-first,
         valid on the current stream.  Batches of one shape share their output tensors: use a batch before taking the next."""
-        if not self._queue:
-            raise MlhotError("BatchIngest.take() without a staged batch")
-        if ticket is None:
-            key, slot = self._queue.popleft()
-        else:
-            hit = [e for e in self._queue if e[1] is ticket]
-            if not hit:
-                raise MlhotError("BatchIngest.take(): unknown or already taken ticket")
-            key, slot = hit[0]
-            self._queue.remove(hit[0])
+        with self._lock:
+            if not self._queue:
+                raise MlhotError("BatchIngest.take() without a staged batch")
+            if ticket is None:
+                key, slot = self._queue.popleft()
+            else:
+                hit = [e for e in self._queue if e[1] is ticket]
+                if not hit:
+                    raise MlhotError("BatchIngest.take(): unknown or already taken ticket")
+                key, slot = hit[0]
+                self._queue.remove(hit[0])
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(slot.copied)
         out = self._out.get(key)
