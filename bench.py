@@ -977,6 +977,8 @@ def main():
     ap.add_argument("--no-loss-aside", action="store_true",
                     help="A/B: the loss VALUE as a launch of its own between forward and backward (mlhot_loss_fwd) instead of one extra workgroup of "
                          "the model's first backward kernel (mlhot.ops.loss_value_aside; vanilla workloads)")
+    ap.add_argument("--no-loss-plus", action="store_true",
+                    help="A/B (c5): `loss + kl * beta` as two launches per direction (mlhot_loss_fwd + mlhot_axpy) instead of inside the loss's own (mlhot_loss_plus_*)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing experiments (results become WRONG; never a bench line)")
     ap.add_argument("--eps", choices=("host", "device"), default="host",
                     help="c5: where the Bayes-by-backprop eps stream is produced - the torch CPU generator (the reference's route, bit-exact; "
@@ -1063,9 +1065,11 @@ def main():
         # the loss VALUE comes out of the model's first backward kernel (one extra workgroup; mlhot.ops.loss_value_aside) - the step reads
         # it only after the backward, as trainer.ModelTrainer does.  Not for c5: its objective adds kl * beta to the value right here.
         with loss_value_aside(enabled=not args.no_loss_aside and not c5):
-            loss = loss_fn.calc_loss(mu, var, ty)
-            if c5:
-                loss = add_scaled(loss, kl, beta)     # loss + kl * beta as the trainer writes it; identical on every rank (same weights, kl does not depend on the batch): averaged, never summed
+            if c5:      # loss + kl * beta as trainer.ModelTrainer writes it (LossFunc.calc_objective: the sum inside the loss's launches, the bits of
+                loss = loss_fn.calc_objective(mu, var, ty, kl, beta) if not args.no_loss_plus else add_scaled(loss_fn.calc_loss(mu, var, ty), kl, beta)
+                # loss + kl * beta); identical on every rank (same weights, kl does not depend on the batch): averaged, never summed
+            else:
+                loss = loss_fn.calc_loss(mu, var, ty)
             if arm:
                 bucket.arm()                     # eager steps only: the early bucket's all-reduce is issued from inside backward()
             loss.backward(gradient=seed)         # the constant 1.0 autograd would otherwise make with a fill kernel every step

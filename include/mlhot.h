@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLHOT_ABI_VERSION 6
+#define MLHOT_ABI_VERSION 7
 
 enum { MLHOT_ACT_NONE = 0, MLHOT_ACT_RELU = 1, MLHOT_ACT_TANH = 2 };
 enum { MLHOT_AGG_MEAN = 0, MLHOT_AGG_MAX = 1, MLHOT_AGG_BACO = 2, MLHOT_AGG_ATTENTION = 3 };
@@ -240,6 +240,15 @@ int mlhot_favor_bwd_staged(const float* q, const float* k, const float* v, const
 int mlhot_loss_fwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim, float* loss, void* stream);
 int mlhot_loss_bwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim,
                    const float* dloss, float* dmu, void* stream);
+/* ABI 7: the trainer's objective `losses = loss + kl * beta` (trainer/model_trainer.py:77-78) inside the loss's own launches - in a
+ * replayed step every dependent launch costs ~4.7 us whatever it computes, and this pair of scalars was four of them.
+ *   fwd: loss[0] (may be NULL) as mlhot_loss_fwd; total[0] = loss + alpha * x[0], product and sum rounded separately (mlhot_axpy's bits)
+ *   bwd: dmu as mlhot_loss_bwd(dloss = dtotal); dx[0] (may be NULL) = alpha * dtotal[0]
+ * x, total, dtotal, dx: device scalars.                                                                                               */
+int mlhot_loss_plus_fwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim, const float* x, float alpha,
+                        float* loss, float* total, void* stream);
+int mlhot_loss_plus_bwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim, const float* dtotal, float alpha,
+                        float* dmu, float* dx, void* stream);
 
 /* ---- E2 / D2: ResNet encoder building blocks --------------------------------------------------
  * nn.Conv2d (cross-correlation, zero padding, NCHW, weight [Cout,Cin,k,k], optional fused ReLU) for

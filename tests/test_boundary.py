@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in sorted(names):
         assert hasattr(lib, n), f"libmlhot.so does not export {n}"
-    assert mlhot.lib().c.mlhot_version() == mlhot.binding.ABI_VERSION == 6
+    assert mlhot.lib().c.mlhot_version() == mlhot.binding.ABI_VERSION == 7
 
 
 def test_cpu_tensors_fail_loudly():

@@ -266,6 +266,41 @@ def test_losses_against_reference_vectors(gpulib):
             assert U.rel_err(dmu, pro.grad) <= U.RTOL, kind
 
 
+def test_objective_inside_the_loss_launches_has_the_bits_of_loss_plus_kl_beta(gpulib):
+    """mlhot_loss_plus_fwd / _bwd (ABI 7): the trainer's `losses = loss + kl * beta` (trainer/model_trainer.py:77-78) inside the loss's own
+    launches.  For every training loss kind on the reference's vectors: the total, d mu and d kl have the BITS of mlhot_loss_fwd +
+    mlhot_axpy (and so of the reference's two torch operators: product and sum rounded separately), for several (kl, beta, upstream)
+    triples; through autograd (LossFunc.calc_objective) the gradients equal those of `add_scaled(calc_loss(...), kl, beta)`."""
+    from mlhot.ops import add_scaled
+    from trainer.losses import LossFunc
+    fx = np.load(os.path.join(U.GOLDEN, "losses.npz"))
+    rs = np.random.RandomState(3)
+    for kind, tag, task in (("azimuth", "az", "shapenet_1d"), ("mse", "pas", "pascal_1d"), ("quaternion", "quat", "shapenet_3d"),
+                            ("distractor", "dis", "distractor")):
+        pr, gt = torch.from_numpy(fx[f"{tag}/pr"]).to(DEV), torch.from_numpy(fx[f"{tag}/gt"]).to(DEV)
+        for kl_v, beta, up_v in ((1383162.5, 1e-7, 1.0), (float(rs.rand() * 1e4), float(rs.rand()), float(rs.randn())), (3.0, 0.5, -2.25)):
+            kl, up = torch.tensor(kl_v, device=DEV), torch.tensor(up_v, device=DEV)
+            total = gpulib.loss_plus_fwd(kind, pr, gt, kl, beta)
+            want = gpulib.axpy(gpulib.loss_fwd(kind, pr, gt), kl, beta)
+            assert torch.equal(total, want), (kind, kl_v, beta)
+            assert total.item() == np.float32(np.float32(gpulib.loss_fwd(kind, pr, gt).item()) + np.float32(np.float32(beta) * np.float32(kl_v)))
+            dmu, dkl = gpulib.loss_plus_bwd(kind, pr, gt, up, beta)
+            assert torch.equal(dmu, gpulib.loss_bwd(kind, pr, gt, up)) and torch.equal(dkl, gpulib.axpy(None, up, beta)), (kind, kl_v, beta)
+            assert gpulib.loss_plus_bwd(kind, pr, gt, up, beta, need_dx=False)[1] is None
+        # through autograd, as trainer.ModelTrainer._objective calls it
+        lf = LossFunc("mse", task)
+        grads = []
+        for fused in (True, False):
+            mu, kl = pr.clone().requires_grad_(), torch.tensor(12.5, device=DEV, requires_grad=True)
+            obj = lf.calc_objective(mu, None, gt, kl * 1.0, 0.25) if fused else add_scaled(lf.calc_loss(mu, None, gt), kl * 1.0, 0.25)
+            assert (type(obj.grad_fn).__name__ == "LossPlusFunctionBackward") == fused
+            obj.backward()
+            grads.append((obj.detach().clone(), mu.grad.clone(), kl.grad.clone()))
+        for a, b in zip(*grads):
+            assert torch.equal(a, b), kind
+        assert lf.calc_objective(pr, None, gt, 0, 0.25).grad_fn is None and torch.equal(lf.calc_objective(pr, None, gt, 0, 0.25), lf.calc_loss(pr, None, gt))
+
+
 # ---- E1 encoder vs oracle -----------------------------------------------------------------------
 def _enc_params(seed=0):
     g = torch.Generator().manual_seed(seed)

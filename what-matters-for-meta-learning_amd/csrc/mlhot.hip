@@ -326,6 +326,23 @@ int mlhot_loss_bwd(int kind, const float* mu, const float* gt, int rows, int y_d
   return run_foreach(LossBwd{kind, y_dim, gt_dim, rows, mu, gt, dloss, dmu, nullptr}, (size_t)rows, (hipStream_t)stream, "loss_bwd");
 }
 
+int mlhot_loss_plus_fwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim, const float* x, float alpha,
+                        float* loss, float* total, void* stream) {
+  if (kind < 0 || kind > 4 || rows <= 0 || y_dim <= 0 || y_dim > 8 || gt_dim < 1 || !x || !total) { set_error("loss_plus_fwd: bad argument"); return MLHOT_ERR_ARG; }
+  LossPlusRed r;
+  static_cast<LossRed&>(r) = LossRed{kind, y_dim, gt_dim, rows, mu, gt, loss};
+  r.x = x; r.alpha = alpha; r.total = total;
+  return run_reduce1(r, rows, (hipStream_t)stream, "loss_fwd");
+}
+int mlhot_loss_plus_bwd(int kind, const float* mu, const float* gt, int rows, int y_dim, int gt_dim, const float* dtotal, float alpha,
+                        float* dmu, float* dx, void* stream) {
+  if (kind < 0 || kind > 4 || rows <= 0 || y_dim <= 0 || y_dim > 8 || gt_dim < 1 || !dtotal || !dmu) { set_error("loss_plus_bwd: bad argument"); return MLHOT_ERR_ARG; }
+  LossPlusBwd f;
+  static_cast<LossBwd&>(f) = LossBwd{kind, y_dim, gt_dim, rows, mu, gt, dtotal, dmu, nullptr};
+  f.alpha = alpha; f.dx = dx;
+  return run_foreach(f, (size_t)rows, (hipStream_t)stream, "loss_bwd");
+}
+
 // ---- E2 / D2 building blocks: run-time-shaped conv, residual join, 2x2 max-pool; B1: BBB sample -------
 size_t mlhot_conv2d_bwd_scratch_bytes(int N, int Cin, int H, int W, int Cout, int k, int stride, int pad) {
   return conv_bwd_scratch_bytes(conv_shape(N, Cin, H, W, Cout, k, stride, pad));

@@ -70,13 +70,13 @@ struct AddRelu { const float* a; const float* b; float* y; MLHOT_HD void operato
 struct Axpy {
   const float* a; const float* x; float alpha; float* y;
   MLHOT_HD void operator()(size_t i) const {
+#pragma clang fp contract(off)      // (the *_rn intrinsics alone do not keep hipcc from fusing the two: see LossPlusRed)
 #ifdef MLHOT_HOSTSIM
     volatile float p = alpha * x[i];
-    y[i] = a ? a[i] + p : p;
 #else
-    const float p = __fmul_rn(alpha, x[i]);
-    y[i] = a ? __fadd_rn(a[i], p) : p;
+    const float p = alpha * x[i];
 #endif
+    y[i] = a ? a[i] + p : p;
   }
 };
 struct AddReluBwd { const float* y; const float* dy; float* g; MLHOT_HD void operator()(size_t i) const { g[i] = y[i] > 0.f ? dy[i] : 0.f; } };
@@ -353,6 +353,22 @@ struct LossRed {
   }
   MLHOT_HD void finish(float s) const { out[0] = s / (float)(kind == 1 ? rows * y_dim : rows); }
 };
+// loss + alpha * x[0] in the loss's own launch (trainer/model_trainer.py:77-78: `losses = loss + kl * beta`): the loss value as LossRed
+// leaves it, then the product and the sum rounded separately - the bits of mlhot_loss_fwd followed by mlhot_axpy.
+struct LossPlusRed : LossRed {
+  const float* x; float alpha; float* total;
+  MLHOT_HD void finish(float s) const {
+#pragma clang fp contract(off)      // product and sum rounded separately: hipcc's __fadd_rn(l, __fmul_rn(..)) came out as ONE v_fma here (a last-bit difference to mlhot_axpy, caught by the parity test)
+    const float l = s / (float)(kind == 1 ? rows * y_dim : rows);
+    if (out != nullptr) out[0] = l;
+#ifdef MLHOT_HOSTSIM
+    volatile float pr = alpha * x[0];
+#else
+    const float pr = alpha * x[0];
+#endif
+    total[0] = l + pr;
+  }
+};
 
 // d loss / d mu of ONE row (all y_dim <= 8 entries into d[]), scaled by the upstream scalar `up`
 MLHOT_HD inline void loss_row_grad(int kind, int y_dim, int rows, const float* m, const float* g, float up, float* d) {
@@ -392,6 +408,21 @@ struct LossBwd {
     float d[8];
     loss_row_grad(kind, y_dim, rows, mu + r * y_dim, gt + r * gt_dim, dloss[0], d);
     for (int j = 0; j < y_dim; ++j) dmu[r * y_dim + j] = add != nullptr ? add[r * y_dim + j] + d[j] : d[j];
+  }
+};
+// ... and the backward of `loss + alpha * x`: d mu as LossBwd, d x = alpha * d total by row 0's thread (mlhot_axpy(NULL, dtotal, alpha)'s bits)
+struct LossPlusBwd : LossBwd {
+  float alpha; float* dx;
+  MLHOT_HD void operator()(size_t r) const {
+    LossBwd::operator()(r);
+    if (r == 0 && dx != nullptr) {
+#ifdef MLHOT_HOSTSIM
+      volatile float pr = alpha * dloss[0];
+      dx[0] = pr;
+#else
+      dx[0] = __fmul_rn(alpha, dloss[0]);
+#endif
+    }
   }
 };
 

@@ -22,7 +22,7 @@ LOSS = {"azimuth": 0, "mse": 1, "quaternion": 2, "degree": 3, "distractor": 4}
 _f = C.c_void_p  # every device pointer travels as void*
 
 
-ABI_VERSION = 6     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients; 3: + conv12_fwd / _bwd; 4: + np_vanilla_bwd_loss; 5: + mt19937_advance; 6: + host_f32_to_u8_exact)
+ABI_VERSION = 7     # include/mlhot.h MLHOT_ABI_VERSION (2: + nt_xent, mt19937_normal, the *_staged entries, trunk / skinny flat gradients; 3: + conv12_fwd / _bwd; 4: + np_vanilla_bwd_loss; 5: + mt19937_advance; 6: + host_f32_to_u8_exact; 7: + loss_plus_fwd / _bwd)
 
 
 class MlhotError(RuntimeError):
@@ -212,6 +212,8 @@ class MlhotLib:
         c.mlhot_favor_bwd_staged.argtypes = [P, P, P, P, i, i, i, i, i, i, P, P, P, P, P, P, z, i, P, P]
         c.mlhot_loss_fwd.argtypes = [i, P, P, i, i, i, P, P]
         c.mlhot_loss_bwd.argtypes = [i, P, P, i, i, i, P, P, P]
+        c.mlhot_loss_plus_fwd.argtypes = [i, P, P, i, i, i, P, C.c_float, P, P, P]
+        c.mlhot_loss_plus_bwd.argtypes = [i, P, P, i, i, i, P, C.c_float, P, P, P]
         c.mlhot_conv2d_bwd_scratch_bytes.restype = C.c_size_t
         c.mlhot_conv2d_bwd_scratch_bytes.argtypes = [i] * 8
         c.mlhot_conv2d_fwd.argtypes = [P, P, P, P] + [i] * 9 + [P]
@@ -873,6 +875,27 @@ class MlhotLib:
         self._rc(self.c.mlhot_loss_bwd(LOSS[kind], _ptr(mu), _ptr(gt), rows, mu.shape[-1], gt.shape[-1], _ptr(dloss), _ptr(dmu), _stream(mu)),
                  "mlhot_loss_bwd")
         return dmu
+
+    def loss_plus_fwd(self, kind, mu, gt, x, alpha):
+        """loss(kind; mu, gt) + alpha * x (x a device scalar: the KL term) in the loss's launch; the total, a device scalar."""
+        _chk(mu, gt, x)
+        if x.numel() != 1:
+            raise MlhotError(f"loss_plus_fwd: x must be a scalar, got {tuple(x.shape)}")
+        rows = mu.numel() // mu.shape[-1]
+        total = torch.empty((), device=mu.device)
+        self._rc(self.c.mlhot_loss_plus_fwd(LOSS[kind], _ptr(mu), _ptr(gt), rows, mu.shape[-1], gt.shape[-1], _ptr(x), float(alpha), None,
+                                            _ptr(total), _stream(mu)), "mlhot_loss_plus_fwd")
+        return total
+
+    def loss_plus_bwd(self, kind, mu, gt, dtotal, alpha, need_dx=True):
+        """(d mu, d x) of loss_plus_fwd for the upstream scalar dtotal; d x = alpha * dtotal (None when not needed)."""
+        _chk(dtotal)
+        rows = mu.numel() // mu.shape[-1]
+        dmu = torch.empty_like(mu)
+        dx = torch.empty((), device=mu.device) if need_dx else None
+        self._rc(self.c.mlhot_loss_plus_bwd(LOSS[kind], _ptr(mu), _ptr(gt), rows, mu.shape[-1], gt.shape[-1], _ptr(dtotal), float(alpha),
+                                            _ptr(dmu), _ptr(dx) if dx is not None else None, _stream(mu)), "mlhot_loss_plus_bwd")
+        return dmu, dx
 
     # ---- batch ingest ---------------------------------------------------------------------------
     def ingest_u8_nhwc(self, src, out=None, div=255.0):

@@ -494,6 +494,35 @@ class LossFunction(torch.autograd.Function):
         return None, lib().loss_bwd(ctx.kind, mu, gt, dloss), None
 
 
+class LossPlusFunction(torch.autograd.Function):
+    """loss(kind; mu, gt) + alpha * x for a device scalar x - the trainer's `losses = loss + kl * beta` (trainer/model_trainer.py:77-78)
+    inside the loss's own launches: mlhot_loss_plus_fwd / _bwd (ABI 7).  Bit-identical to LossFunction followed by ScaledAddFunction
+    (same reduction, product and sum rounded separately); in a replayed step it is two dependent launches instead of four, and every
+    dependent launch of a graph costs ~4.7 us on this GPU whatever it computes.  Call through loss_plus()."""
+
+    @staticmethod
+    def forward(ctx, kind, mu, gt, x, alpha):
+        _need_gpu(mu, gt, x)
+        mu_c, gt, x = _c(mu.float()), _c(gt.float()), _c(x.float())
+        ctx.kind, ctx.alpha = kind, float(alpha)
+        ctx.save_for_backward(mu_c, gt)
+        return lib().loss_plus_fwd(kind, mu_c, gt, x, ctx.alpha)
+
+    @staticmethod
+    def backward(ctx, dtotal):
+        mu, gt = ctx.saved_tensors
+        dmu, dx = lib().loss_plus_bwd(ctx.kind, mu, gt, _c(dtotal.float()), ctx.alpha, need_dx=ctx.needs_input_grad[3])
+        return None, (dmu if ctx.needs_input_grad[1] else None), None, dx, None
+
+
+def loss_plus(kind, mu, gt, x, alpha):
+    """`LossFunction.apply(kind, mu, gt) + x * alpha` the way the reference's trainer writes its objective; one launch per direction
+    when x is a one-element fp32 device tensor (a KL term), add_scaled() behind the plain loss otherwise (x = 0: the bare loss)."""
+    if torch.is_tensor(x) and x.is_cuda and x.numel() == 1 and x.dtype == torch.float32 and mu.is_cuda and kind != "degree":
+        return LossPlusFunction.apply(kind, mu, gt, x.reshape(()), alpha)
+    return add_scaled(LossFunction.apply(kind, mu, gt), x, alpha)
+
+
 class Conv2dFunction(torch.autograd.Function):
     """nn.Conv2d (+ optional fused ReLU): mlhot_conv2d_fwd / _bwd (generic run-time-shaped conv)."""
 

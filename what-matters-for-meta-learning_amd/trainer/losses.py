@@ -11,7 +11,7 @@ outside the kernels' limits (N > 2048 rows or d > 256 / d % 16 != 0) raise - the
 import torch
 
 from mlhot.binding import MlhotError
-from mlhot.ops import LossFunction, NTXentFunction
+from mlhot.ops import LossFunction, NTXentFunction, add_scaled, loss_plus
 
 
 def nt_xent(z, div, mod, t=0.07):
@@ -42,6 +42,18 @@ class LossFunc:
         if self.task == "distractor":
             return LossFunction.apply("distractor", pr_mu, gt_y)
         return None
+
+    def calc_objective(self, pr_mu, pr_var, gt_y, kl, beta):
+        """`calc_loss(pr_mu, pr_var, gt_y) + kl * beta` (the reference's trainer/model_trainer.py:77-78) - the same value and gradients, bit
+        for bit; with a KL term on the device the sum rides in the loss's own launches (mlhot.ops.loss_plus: in a replayed step two
+        dependent launches instead of four).  Not part of the reference's LossFunc; trainer.ModelTrainer uses it when the loss object
+        has it and writes `add_scaled(calc_loss(...), kl, beta)` otherwise."""
+        kind = {"shapenet_3d": "quaternion", "shapenet_1d": "azimuth", "pascal_1d": "mse", "distractor": "distractor"}.get(self.task)
+        if self.loss_type != "mse" or kind is None:
+            return None
+        if torch.is_tensor(kl) and kl.is_cuda and kl.numel() == 1 and beta:
+            return loss_plus(kind, pr_mu, gt_y, kl, beta)
+        return add_scaled(self.calc_loss(pr_mu, pr_var, gt_y), kl, beta)
 
     def quaternion_loss(self, q_gt, q_pr):
         return LossFunction.apply("quaternion", q_pr, q_gt)

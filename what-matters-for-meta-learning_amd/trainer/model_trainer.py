@@ -306,13 +306,23 @@ class ModelTrainer(BaseTrainer):
         # config.loss_aside (default on): with the bare loss as the objective (no KL / contrastive term computes with its value) the value
         # is left to the model's first backward kernel (mlhot.ops.loss_value_aside) - it is read after the backward, below
         with loss_value_aside(enabled=self._bare_loss(kl, contra_loss)):
-            losses = add_scaled(self.loss.calc_loss(pr_mu, pr_var, qry_y), kl, self.config.beta)
+            losses = self._objective(pr_mu, pr_var, qry_y, kl)
             if contra_loss is not None:
                 losses = losses + contra_loss * self.config.contrastive_rate
             losses.backward(gradient=self._seed(losses))
         if with_optimizer:
             self.optimizer.step()
         return losses.detach()
+
+    def _objective(self, pr_mu, pr_var, qry_y, kl):
+        """loss + kl * beta: inside the loss's launches when the loss object offers that (trainer.losses.LossFunc.calc_objective), as the
+        reference's two operators behind `calc_loss` for any other loss object."""
+        fused = getattr(self.loss, "calc_objective", None)
+        if fused is not None:
+            out = fused(pr_mu, pr_var, qry_y, kl, self.config.beta)
+            if out is not None:
+                return out
+        return add_scaled(self.loss.calc_loss(pr_mu, pr_var, qry_y), kl, self.config.beta)
 
     def _bare_loss(self, kl, contra_loss):
         return (bool(getattr(self.config, "loss_aside", True)) and contra_loss is None and not isinstance(kl, torch.Tensor)
@@ -437,7 +447,7 @@ class ModelTrainer(BaseTrainer):
         else:
             pr_mu, pr_var, kl = self.model(ctx_x, ctx_y, qry_x)
         with loss_value_aside(enabled=self._bare_loss(kl, contra_loss if contrastive else None)):
-            losses = add_scaled(self.loss.calc_loss(pr_mu, pr_var, qry_y), kl, self.config.beta)      # loss + kl * beta (model_trainer.py:77-78), one launch
+            losses = self._objective(pr_mu, pr_var, qry_y, kl)        # loss + kl * beta (model_trainer.py:77-78)
             if contrastive:
                 losses = losses + contra_loss * self.config.contrastive_rate
             self.bucket.arm()                                         # world > 1: the early bucket's all-reduce goes out from inside backward()
