@@ -690,7 +690,7 @@ def measure_shipped_cfg(w, device, loss_fn, iters):
             tr = ModelTrainer(model=model, loss=loss_fn, optimizer=torch.optim.Adam(model.parameters(), lr=cfg.lr), config=cfg, data=data)
             tr.train()                                   # every size's eager warm-up + capture happens in here or in the untimed round below
             tr.iterations = 10 ** 9
-            n = max(60, 4 * iters)
+            n = max(150 if three_d else 400, 4 * iters)      # ~0.2 / 0.5 s: a 60-iteration window moved by 15 % between boxes (one first-use allocation = hundreds of iterations' worth)
             for timed in (False, True):
                 torch.cuda.synchronize()
                 d0 = len(data.drawn)
