@@ -2169,6 +2169,64 @@ def test_lagged_loss_log_reports_every_iteration_one_late(gpulib, tmp_path, monk
         assert torch.equal(finals[0][k], finals[1][k]), k
 
 
+def test_late_loss_read_stops_on_a_non_finite_loss_with_the_same_log_exit_code_and_files(gpulib, tmp_path, monkeypatch):
+    """The claim behind `config.lagged_loss_log` being the default: an observer of the reference's loop (trainer/model_trainer.py:87-93:
+    log the loss, `sys.exit(1)` when it is not finite) sees the same thing.  A loader whose 7th training batch holds a NaN label, a
+    validation round at iteration 5, an (untouched) checkpoint cadence: with the read behind every step and with the read one iteration
+    late the logger receives the SAME lines in the same order, the process exits with the same code, and the same files exist."""
+    import types
+    from mlhot.optim import FlatAdam
+    from mlhot.synth import SyntheticData
+    from networks.ANPShapeNet1D import ANPShapeNet1D
+    from trainer.losses import LossFunc
+    from trainer.model_trainer import ModelTrainer
+    monkeypatch.chdir(tmp_path)
+
+    class Poisoned(SyntheticData):
+        def __init__(self):
+            super().__init__()
+            self.n_train = 0
+
+        def get_batch_u8(self, source, tasks_per_batch, shot):        # the route the trainer takes for this loader (bytes + labels)
+            xs, xq, ys, yq = super().get_batch_u8(source, tasks_per_batch, shot)
+            if source == "train":
+                self.n_train += 1
+                if self.n_train == 7:
+                    yq = yq.copy() if isinstance(yq, np.ndarray) else yq.clone()
+                    yq[0, 0, 0] = float("nan")
+            return xs, xq, ys, yq
+
+    class Lines:
+        def __init__(self):
+            self.lines = []
+
+        def info(self, msg):
+            self.lines.append(msg)
+
+    seen = []
+    for lag in (False, True):
+        log = Lines()
+        cfg = types.SimpleNamespace(device=torch.device(DEV), seed=2578, img_size=[128, 128, 1], tasks_per_batch=2, input_dim=3,
+                                    output_dim=2, agg_mode="attention", img_agg="", dim_w=64, n_hidden_units_r=[100, 100], dim_r=64,
+                                    dim_z=64, task="shapenet_1d", iterations=12, val_freq=5, val_iters=1, bg_gen_freq=1000, gen_bg=False,
+                                    max_ctx_num=5, beta=0, contrastive=False, graph_steps=True, log_every=1, lagged_loss_log=lag,
+                                    save_path=str(tmp_path / f"n{int(lag)}"), logger=log)
+        model = ANPShapeNet1D(cfg).to(cfg.device)
+        tr = ModelTrainer(model=model, loss=LossFunc("mse", "shapenet_1d"), optimizer=FlatAdam(model, lr=1e-3, ctx_num=5, test_num=5, capturable=True),
+                          config=cfg, data=Poisoned())
+        with pytest.raises(SystemExit) as stop:
+            tr.train()
+        tr.close()
+        files = sorted(os.path.relpath(os.path.join(d, f), cfg.save_path) for d, _, fs in os.walk(cfg.save_path) for f in fs if not f.startswith("events."))
+        lines = [l for l in log.lines if not l.startswith("mlhot:")]           # (the announcements say which of the two modes runs)
+        seen.append((stop.value.code, lines, files))
+    assert seen[0][0] == seen[1][0] == 1
+    assert any("Train Iteration 6 " in l for l in seen[0][1]) and any("Loss is nan" in l for l in seen[0][1])
+    assert not any("Train Iteration 8 " in l for l in seen[0][1] + seen[1][1])
+    assert seen[0][1] == seen[1][1]
+    assert seen[0][2] == seen[1][2] and not any("model_end" in f for f in seen[0][2])
+
+
 def test_graph_replayed_multi_rank_training_uses_each_graphs_own_gradients(gpulib, tmp_path, monkeypatch):
     """graph_steps with world > 1: the all-reduce and the optimizer step run OUTSIDE the graphs and read p.grad, which a replay
     does not rebind - with several batch shapes (the context size is drawn per iteration) each captured graph owns different
