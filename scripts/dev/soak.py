@@ -63,14 +63,14 @@ def run(method, cfg, data, loss, iters):
     model = getattr(importlib.import_module("networks." + method), method)(cfg).to(DEV)
     tr = ModelTrainer(model=model, loss=loss, optimizer=torch.optim.Adam(model.parameters(), lr=1e-3), config=cfg, data=data)
     seen = []
-    orig = tr._train_iter
-    tr._train_iter = lambda it: seen.append(orig(it))
+    orig = tr._report                             # every iteration's loss, whichever call hands it out (the late read: one iteration behind)
+    tr._report = lambda it, v: (seen.append(v), orig(it, v))[1]
     torch.manual_seed(7)
     t0 = time.perf_counter()
     tr.train()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    assert all(v is not None and np.isfinite(v) for v in seen), "non-finite loss"
+    assert len(seen) == iters and all(v is not None and np.isfinite(v) for v in seen), "non-finite or missing loss"
     first, last = float(np.mean(seen[:50])), float(np.mean(seen[-50:]))
     graphs = len([v for v in tr._graphs.values() if isinstance(v, tuple)])
     print(f"{method}: {iters} iterations in {dt:.1f} s ({iters / dt:.0f} it/s incl. {iters // cfg.val_freq} validation rounds and the captures), "
