@@ -308,3 +308,30 @@ def test_committed_bench_line_honours_the_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"] and c["sample"]
     if isinstance(base, dict) and "unit" in base:
         assert base["unit"].split("/")[0].strip().lower()[:4] in line["unit"].lower() or line["unit"].lower()[:4] in base["unit"].lower()
+
+
+def test_library_staleness_is_decided_by_source_content_not_file_times(tmp_path, monkeypatch):
+    """mlhot.build: csrc/libmlhot.so carries a sidecar with the sha256 of the sources it was built from; "stale" compares that with the
+    tree's sources.  File times are an accident of how the tree travelled (a `git checkout` of unchanged text once made the GPU box
+    rebuild an identical library inside the driver's bench run); they decide only for a library without a sidecar."""
+    import os
+    import time
+    from mlhot import build as B
+    so, src = tmp_path / "libmlhot.so", tmp_path / "dep.h"
+    monkeypatch.setattr(B, "PRODUCT_SO", str(so))
+    monkeypatch.setattr(B, "SIDECAR", str(so) + ".src")
+    monkeypatch.setattr(B, "_deps", lambda: [str(src)])
+    assert B._product_stale()                                   # no library at all
+    src.write_text("int a;\n")
+    so.write_bytes(b"\x7fELF")
+    B.stamp_product()
+    assert not B._product_stale()
+    os.utime(src, (time.time() + 100, time.time() + 100))       # "newer" source, same text
+    assert not B._product_stale()
+    src.write_text("int b;\n")                                  # different text, whatever its time
+    os.utime(src, (1, 1))
+    assert B._product_stale()
+    os.remove(str(so) + ".src")                                 # no sidecar: file times decide
+    assert not B._product_stale()
+    os.utime(src, (time.time() + 100, time.time() + 100))
+    assert B._product_stale()

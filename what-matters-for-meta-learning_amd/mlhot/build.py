@@ -39,17 +39,40 @@ def _deps():
     return [os.path.join(CSRC, f) for f in SOURCES] + _headers()
 
 
+SIDECAR = PRODUCT_SO + ".src"          # source_sha256() of the sources the library next to it was built from
+
+
+def _product_stale():
+    """Is csrc/libmlhot.so older than its sources?  By CONTENT when the sidecar written at build time is there (file times are an
+    accident of how the tree got where it is: a `git checkout` of unchanged text makes a header "newer" than a library built from
+    exactly that text - the GPU box then spent 40 s rebuilding an identical library inside the driver's bench run), by file time
+    otherwise."""
+    if not os.path.exists(PRODUCT_SO):
+        return True
+    try:
+        with open(SIDECAR) as f:
+            return f.read().strip() != source_sha256()
+    except OSError:
+        return _stale(PRODUCT_SO, _deps())
+
+
+def stamp_product():
+    """Record which sources csrc/libmlhot.so was built from (build_product does; scripts/build_lib.sh calls it for its own hipcc run)."""
+    with open(SIDECAR, "w") as f:
+        f.write(source_sha256() + "\n")
+
+
 def build_product(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> csrc/libmlhot.so (cross-compiles without a GPU).  Safe to call from every rank of a
     multi-process launch at once: one process builds (into a temporary file, renamed into place), the others wait on a file
     lock and then find the library fresh."""
-    if not force and not _stale(PRODUCT_SO, _deps()):
+    if not force and not _product_stale():
         return PRODUCT_SO
     import fcntl
     with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not _stale(PRODUCT_SO, _deps()):
+            if not force and not _product_stale():
                 return PRODUCT_SO              # another process built it while this one waited
             hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
             if not os.path.exists(hipcc):
@@ -65,8 +88,11 @@ def build_product(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             try:
+                sha = source_sha256()          # of what hipcc is about to read
                 subprocess.run(cmd, check=True, cwd=CSRC)
                 os.replace(tmp, PRODUCT_SO)
+                with open(SIDECAR, "w") as f:
+                    f.write(sha + "\n")
             finally:
                 if os.path.exists(tmp):
                     os.remove(tmp)
